@@ -1,0 +1,143 @@
+"""Seeded input generators shared by make_golden.py (which runs the reference on
+them, in the build container only) and by the tests (which run the oracle and
+the HIP path on the same values).  numpy RandomState streams are stable across
+numpy versions; parameters use an RNG-free closed form keyed by tensor name so
+that no 80 MB state_dict has to be committed.
+"""
+import math
+import zlib
+
+import numpy as np
+
+
+# ---------------------------------------------------------------------------
+# decode
+# ---------------------------------------------------------------------------
+DECODE_CASES = {
+    # name: (B, C, H, W, K, rotated, with_reg, seed)
+    'small':   (2, 6, 32, 32, 20, False, True, 11),
+    'cfg3':    (2, 6, 128, 128, 150, False, True, 12),
+    'coco80':  (1, 80, 128, 128, 100, False, True, 13),
+    'rotated': (2, 6, 40, 40, 30, True, True, 14),
+    'noreg':   (1, 3, 24, 20, 16, False, False, 15),
+}
+
+
+def decode_inputs(name):
+    B, C, H, W, K, rotated, with_reg, seed = DECODE_CASES[name]
+    rs = np.random.RandomState(seed)
+    logits = rs.standard_normal((B, C, H, W)).astype(np.float32) - np.float32(2.19)
+    heat = (1.0 / (1.0 + np.exp(-logits.astype(np.float64)))).astype(np.float32)
+    heat = np.clip(heat, np.float32(1e-4), np.float32(1 - 1e-4))
+    wh = (rs.uniform(2, 60, (B, 3 if rotated else 2, H, W))).astype(np.float32)
+    if rotated:
+        wh[:, 2] = rs.standard_normal((B, H, W)).astype(np.float32)
+    reg = rs.uniform(0, 1, (B, 2, H, W)).astype(np.float32) if with_reg else None
+    return dict(heat=heat, wh=wh, reg=reg, K=K, rotated=rotated)
+
+
+# ---------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------
+LOSS_CASES = {
+    # name: (B, C, H, W, M, n_obj per image, wh channels, periodic, seed)
+    'plain':    (2, 6, 16, 16, 8, (3, 5), 2, False, 21),
+    'rotated':  (2, 6, 16, 16, 8, (2, 8), 3, False, 22),
+    'periodic': (2, 6, 16, 16, 8, (4, 1), 3, True, 23),
+    'nopos':    (2, 4, 12, 12, 6, (0, 0), 2, False, 24),
+}
+
+
+def gaussian_splat(hm, cx, cy, radius):
+    """draw_umich_gaussian semantics (utils/image.py:40-57): max-merge of an
+    exp(-(x^2+y^2)/(2 sigma^2)) patch, sigma = diameter/6, exact 1.0 at centre."""
+    d = 2 * radius + 1
+    sigma = d / 6.0
+    ys, xs = np.ogrid[-radius:radius + 1, -radius:radius + 1]
+    g = np.exp(-(xs * xs + ys * ys) / (2 * sigma * sigma)).astype(np.float32)
+    g[g < np.finfo(np.float32).eps * g.max()] = 0
+    H, W = hm.shape
+    l, r = min(cx, radius), min(W - cx, radius + 1)
+    t, b = min(cy, radius), min(H - cy, radius + 1)
+    patch = hm[cy - t:cy + b, cx - l:cx + r]
+    np.maximum(patch, g[radius - t:radius + b, radius - l:radius + r], out=patch)
+
+
+def detection_batch(B, C, H, W, M, n_obj, wh_ch, seed):
+    """Synthetic batch with the schema of datasets/coco.py:168-174,242-251."""
+    rs = np.random.RandomState(seed)
+    hm = np.zeros((B, C, H, W), np.float32)
+    reg_mask = np.zeros((B, M), np.uint8)
+    ind = np.zeros((B, M), np.int64)
+    wh = np.zeros((B, M, wh_ch), np.float32)
+    reg = np.zeros((B, M, 2), np.float32)
+    for b in range(B):
+        n = n_obj[b] if isinstance(n_obj, (tuple, list)) else int(n_obj)
+        for k in range(n):
+            cx, cy, c = rs.randint(0, W), rs.randint(0, H), rs.randint(0, C)
+            gaussian_splat(hm[b, c], cx, cy, int(rs.randint(1, max(2, min(H, W) // 6))))
+            reg_mask[b, k] = 1
+            ind[b, k] = cy * W + cx
+            wh[b, k, 0:2] = rs.uniform(2, 0.6 * W, 2)
+            if wh_ch == 3:
+                wh[b, k, 2] = rs.uniform(-90, 90)
+            reg[b, k] = rs.uniform(0, 1, 2)
+        # rows past n keep garbage-looking (but masked) targets, as a dataloader
+        # could produce -- exercises the in-place masking (Q2)
+        wh[b, n:] = rs.uniform(1, 5, (M - n, wh_ch))
+        ind[b, n:] = rs.randint(0, H * W, M - n)
+    return dict(hm=hm, reg_mask=reg_mask, ind=ind, wh=wh, reg=reg)
+
+
+def loss_inputs(name):
+    B, C, H, W, M, n_obj, wh_ch, periodic, seed = LOSS_CASES[name]
+    batch = detection_batch(B, C, H, W, M, n_obj, wh_ch, seed)
+    rs = np.random.RandomState(seed + 1000)
+    out = dict(hm=(rs.standard_normal((B, C, H, W)) * 1.5 - 1.0).astype(np.float32),
+               wh=(rs.standard_normal((B, wh_ch, H, W)) * 3.0).astype(np.float32),
+               reg=rs.standard_normal((B, 2, H, W)).astype(np.float32))
+    weights = dict(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=0.7, periodic=periodic)
+    return out, batch, weights
+
+
+# ---------------------------------------------------------------------------
+# network parameters: closed-form, RNG-free fill keyed by the state_dict name
+# ---------------------------------------------------------------------------
+def _phase(name):
+    return (zlib.crc32(name.encode()) % 100003) / 100003.0 * 2 * math.pi
+
+
+def fill_value(name, shape):
+    """float32 array for state_dict entry `name` of `shape`."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    i = np.arange(n, dtype=np.float64)
+    wave = np.sin(0.37 * i + _phase(name))
+    if name.endswith('num_batches_tracked'):
+        return np.zeros(shape, np.int64)
+    if name.endswith('running_var'):
+        v = 1.0 + 0.3 * wave
+    elif name.endswith('running_mean'):
+        v = 0.1 * wave
+    elif len(shape) == 1 and name.endswith('.weight'):          # BN gamma
+        v = 1.0 + 0.2 * wave
+    elif len(shape) == 1:                                        # biases / BN beta
+        v = 0.05 * wave
+        if name == 'hm.2.bias':
+            v = v - 2.19
+    else:                                                        # conv kernels
+        fan_in = int(np.prod(shape[1:]))
+        scale = 1.8 / math.sqrt(fan_in)
+        if 'conv_offset_mask' in name:
+            scale = 1.2 / math.sqrt(fan_in)                      # offsets ~ +-1 px (Q7)
+        v = scale * wave
+    return v.reshape(shape).astype(np.float32)
+
+
+def fill_state(shapes):
+    """shapes: dict name -> shape.  Returns dict name -> np.ndarray."""
+    return {k: fill_value(k, tuple(s)) for k, s in shapes.items()}
+
+
+def image_batch(B, H, W, seed):
+    rs = np.random.RandomState(seed)
+    return rs.standard_normal((B, 3, H, W)).astype(np.float32)

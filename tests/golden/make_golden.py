@@ -1,0 +1,270 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz by IMPORTING the reference (read-only, from
+/root/reference) in the build container.  Only inputs' recipes (inputs.py) and
+the reference's OUTPUT VALUES are written; no reference source travels.
+
+    python tests/golden/make_golden.py            # needs /root/reference
+
+What runs as-is from the reference: utils.tensor, backends.decode,
+losses.{centernet,entropy,max_square,advent(.crit)}, utils.image.entropy_map
+(imported through a stub for the unrelated cv2/imgaug imports at the top of that
+file -- see _load_entropy_map), backends.dla.
+What cannot: the native `_ext` (libs/DCNv2/src needs <TH/TH.h>, absent from
+this image -> unbuildable here).  backends.dla is therefore imported with
+`sys.modules['_ext']` bound to this repo's CPU oracle (oracle/dcn.py), and
+`torchsummary` (imported but unused, backends/dla.py:15) bound to an empty
+module; `DLA.load_pretrained_model` (an HTTP download, dla.py:297-309) is
+replaced by a no-op.  The DLA fixtures thus pin the reference's *network
+wiring, BN/conv/upsample arithmetic and head layout* around the oracle's DCN;
+the DCN arithmetic itself is pinned by tests/test_oracle_dcn.py.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get('CENTERNET_UDA_REFERENCE', '/root/reference')
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+sys.path.insert(2, HERE)
+
+import torch  # noqa: E402
+
+import inputs as gin  # noqa: E402
+from oracle import dcn as oracle_dcn  # noqa: E402
+
+warnings.filterwarnings('ignore')
+torch.manual_seed(0)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print('wrote %-28s %7.1f KiB' % (name + '.npz', os.path.getsize(path) / 1024))
+
+
+# ---------------------------------------------------------------------------
+def make_decode():
+    from backends.decode import decode_detection, _nms, _topk
+    for name in gin.DECODE_CASES:
+        d = gin.decode_inputs(name)
+        heat = T(d['heat'])
+        nmsd = _nms(heat.clone())
+        scores, inds, clses, ys, xs = _topk(nmsd, K=d['K'])
+        # tie-free check (torch.topk order among equals is unspecified)
+        s = scores.numpy()
+        assert (s[:, :-1] > s[:, 1:]).all(), 'fixture %s has tied scores' % name
+        assert s.min() > 0, 'fixture %s selected suppressed (zero) entries' % name
+        dets = decode_detection(heat.clone(), T(d['wh']).clone(),
+                                reg=None if d['reg'] is None else T(d['reg']).clone(),
+                                K=d['K'], rotated=d['rotated'])
+        nz = nmsd.numpy() != 0
+        save('decode_' + name, dets=dets.numpy(), inds=inds.numpy(), clses=clses.numpy(),
+             nms_nonzero_count=np.array(nz.sum()), nms_sum=np.array(nmsd.double().sum().item()))
+
+
+# ---------------------------------------------------------------------------
+def make_losses():
+    from losses.centernet import DetectionLoss
+    from losses.entropy import EntropyLoss
+    from losses.max_square import MaxSquareLoss
+    from losses.advent import AdventLoss
+    for name in gin.LOSS_CASES:
+        out_np, batch_np, w = gin.loss_inputs(name)
+        out = {k: T(v).clone().requires_grad_(True) for k, v in out_np.items()}
+        leaves = dict(out)
+        # the loss mutates its inputs in place (Q1/Q2): hand it non-leaf views
+        out_in = {k: v * 1.0 for k, v in out.items()}
+        batch = {k: T(v).clone() for k, v in batch_np.items()}
+        crit = DetectionLoss(**w)
+        loss, stats = crit(out_in, batch)
+        loss.backward()
+        save('losses_det_' + name,
+             loss=loss.item(), **{'stat_' + k: v.item() for k, v in stats.items()},
+             hm_after=out_in['hm'].detach().numpy(),            # Q1: sigmoid-clamped in place
+             wh_target_after=batch['wh'].numpy(), reg_target_after=batch['reg'].numpy(),  # Q2
+             **{'grad_' + k: v.grad.numpy() for k, v in leaves.items()})
+    # UDA losses on raw logits
+    rs = np.random.RandomState(31)
+    hm = (rs.standard_normal((2, 6, 16, 16)) * 2.0 - 1.0).astype(np.float32)
+    res = {'hm': hm}
+    for tag, mod, key in (('entropy', EntropyLoss(), 'entropy_loss'),
+                          ('maxsq', MaxSquareLoss(), 'max_square_loss')):
+        x = T(hm).clone().requires_grad_(True)
+        l, st = mod({'hm': x}, None)
+        l.backward()
+        res[tag + '_loss'] = l.item()
+        res[tag + '_grad'] = x.grad.numpy()
+        assert abs(st[key].item() - l.item()) == 0
+    from utils_image_entropy import entropy_map
+    x = T(hm).clone().requires_grad_(True)
+    em = entropy_map(x)
+    em.sum().backward()
+    res['entropy_map'] = em.detach().numpy()
+    res['entropy_map_grad_of_sum'] = x.grad.numpy()
+    # AdventLoss.forward calls y_pred.get_device() (-1 on CPU) and fails; its
+    # arithmetic is the member `crit` (advent.py:8) against a filled label.
+    adv = AdventLoss()
+    logits = (rs.standard_normal((2, 1, 5, 5)) * 1.5).astype(np.float32)
+    res['advent_logits'] = logits
+    for label in (0, 1):
+        y = T(logits).clone().requires_grad_(True)
+        l = adv.crit(y, torch.full_like(y, float(label)))
+        l.backward()
+        res['advent_loss_%d' % label] = l.item()
+        res['advent_grad_%d' % label] = y.grad.numpy()
+    save('losses_uda', **res)
+
+
+def _load_entropy_map():
+    """utils/image.py imports cv2/imgaug at module scope (absent here); only
+    its pure-torch `entropy_map` (:121-124) is on the hot path.  Import the
+    module with empty stand-ins for those two unrelated packages."""
+    for missing in ('cv2', 'imgaug', 'imgaug.augmenters'):
+        if missing not in sys.modules:
+            try:
+                __import__(missing)
+            except Exception:
+                sys.modules[missing] = types.ModuleType(missing)
+    import importlib
+    m = importlib.import_module('utils.image')
+    shim = types.ModuleType('utils_image_entropy')
+    shim.entropy_map = m.entropy_map
+    sys.modules['utils_image_entropy'] = shim
+
+
+# ---------------------------------------------------------------------------
+def _import_reference_dla():
+    ext = types.ModuleType('_ext')
+    ext.dcn_v2_forward = oracle_dcn.dcn_v2_forward
+    ext.dcn_v2_backward = oracle_dcn.dcn_v2_backward
+    sys.modules['_ext'] = ext
+    ts = types.ModuleType('torchsummary')
+    ts.summary = lambda *a, **k: None
+    sys.modules['torchsummary'] = ts
+    from backends import dla
+    dla.DLA.load_pretrained_model = lambda self, *a, **k: None
+    return dla
+
+
+def _checksums(t):
+    t = t.detach().double().reshape(-1)
+    idx = torch.arange(t.numel(), dtype=torch.float64)
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * torch.cos(0.01 * idx)).sum().item()])
+
+
+GRAD_PROBES = [
+    'base.base_layer.0.weight', 'base.level2.tree1.conv1.weight', 'base.level3.tree2.root.conv.weight',
+    'base.level5.project.0.weight', 'base.level4.tree1.tree2.bn2.weight',
+    'dla_up.ida_0.proj_1.conv.weight', 'dla_up.ida_0.proj_1.conv.conv_offset_mask.weight',
+    'dla_up.ida_2.node_3.conv.bias', 'dla_up.ida_1.up_2.weight', 'ida_up.proj_2.conv.conv_offset_mask.bias',
+    'ida_up.node_2.actf.0.bias', 'hm.0.weight', 'hm.2.bias', 'wh.2.weight', 'reg.0.bias',
+]
+
+
+def make_dla():
+    dla = _import_reference_dla()
+    for tag, rotated, B, S, seed in (('axis', False, 2, 64, 41), ('rot', True, 1, 96, 42)):
+        model = dla.build(num_classes=6, rotated_boxes=rotated)
+        sd = model.state_dict()
+        shapes = {k: tuple(v.shape) for k, v in sd.items()}
+        model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes).items()})
+        x = T(gin.image_batch(B, S, S, seed))
+        res = {'state_names': np.array(sorted(shapes)), 'n_params': sum(p.numel() for p in model.parameters())}
+        res['shapes_json'] = np.array(repr(sorted((k, v) for k, v in shapes.items())))
+        # eval forward
+        model.eval()
+        with torch.no_grad():
+            out = model(x)
+        for k in out:
+            res['eval_' + k] = out[k].numpy()
+        # train forward + backward of a fixed scalar
+        model.train()
+        out = model(x)
+        res['head_order'] = np.array(list(out.keys()))
+        for k in out:
+            res['train_' + k] = out[k].detach().numpy()
+        scalar = sum((out[k] * torch.cos(torch.arange(out[k].numel(), dtype=torch.float32)
+                                         .reshape(out[k].shape) * 0.1)).sum() for k in out)
+        scalar.backward()
+        res['scalar'] = scalar.item()
+        params = dict(model.named_parameters())
+        for n in GRAD_PROBES:
+            g = params[n].grad
+            res['gradsum__' + n] = _checksums(g)
+        res['grad_none'] = np.array(sorted(n for n, p in params.items() if p.grad is None))
+        sd2 = model.state_dict()
+        for n in ('base.base_layer.1', 'base.level3.project.1', 'base.level4.project.1',
+                  'dla_up.ida_0.node_1.actf.0', 'ida_up.node_2.actf.0'):
+            res['rm__' + n] = sd2[n + '.running_mean'].numpy()
+            res['rv__' + n] = sd2[n + '.running_var'].numpy()
+            res['nbt__' + n] = sd2[n + '.num_batches_tracked'].numpy()
+        save('dla_' + tag, **res)
+    return dla
+
+
+def make_step(dla):
+    """One `EntropyMinimization.step` (uda/entropy_minimization.py:11-43) and one
+    `MaxSquaresMinimization.step` re-enacted with the imported reference pieces
+    (uda.* itself needs hydra, absent here; its step bodies are pure sequencing)."""
+    from losses.centernet import DetectionLoss
+    from losses.entropy import EntropyLoss
+    from losses.max_square import MaxSquareLoss
+    B, S, M = 2, 64, 8
+    for tag, uda_loss, key, weight in (('entropy', EntropyLoss(), 'entropy_loss', 1e-4),
+                                       ('maxsq', MaxSquareLoss(), 'max_square_loss', 0.3)):
+        model = dla.build(num_classes=6)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes).items()})
+        model.train()
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5, weight_decay=1e-4)
+        crit = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0, periodic=False)
+        batch = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, (3, 2), 2, 51).items()}
+        batch['input'] = T(gin.image_batch(B, S, S, 52))
+        batch['target_domain_input'] = T(gin.image_batch(B, S, S, 53))
+        opt.zero_grad()
+        out_s = model(batch['input'])
+        out_t = model(batch['target_domain_input'])
+        c_loss, c_stats = crit(out_s, batch)
+        e_loss, e_stats = uda_loss(out_t, batch)
+        e_loss *= weight
+        c_loss.backward()
+        e_loss.backward()
+        opt.step()
+        stats = {**c_stats, **e_stats}
+        stats['total_loss'] = c_loss + e_loss
+        res = {'stat_' + k: v.item() for k, v in stats.items()}
+        params = dict(model.named_parameters())
+        for n in GRAD_PROBES:
+            if n in params and params[n].grad is not None:
+                res['gradsum__' + n] = _checksums(params[n].grad)
+                res['param__' + n] = _checksums(params[n])
+        sd = model.state_dict()
+        res['rm__base.base_layer.1'] = sd['base.base_layer.1.running_mean'].numpy()
+        res['rv__base.base_layer.1'] = sd['base.base_layer.1.running_var'].numpy()
+        res['nbt__base.base_layer.1'] = sd['base.base_layer.1.num_batches_tracked'].numpy()
+        res['src_hm_after'] = out_s['hm'].detach().numpy()
+        save('step_' + tag, **res)
+
+
+if __name__ == '__main__':
+    oracle_dcn.build()
+    which = set(sys.argv[1:]) or {'decode', 'losses', 'dla', 'step'}
+    if 'decode' in which:
+        make_decode()
+    if 'losses' in which:
+        _load_entropy_map()
+        make_losses()
+    if 'dla' in which or 'step' in which:
+        d = make_dla() if 'dla' in which else _import_reference_dla()
+        if 'step' in which:
+            make_step(d)

@@ -1,0 +1,105 @@
+"""Pins oracle/dla.py (functional DLA-34 restatement) against outputs of the
+reference module (tests/golden/dla_*.npz, step_*.npz)."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+import inputs as gin
+from oracle import dla as odla
+from oracle import losses as ol
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _checksums(t):
+    t = t.detach().double().reshape(-1)
+    idx = torch.arange(t.numel(), dtype=torch.float64)
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * torch.cos(0.01 * idx)).sum().item()])
+
+
+def _state(g, requires_grad=True):
+    shapes = dict(ast.literal_eval(str(g['shapes_json'])))
+    st = {}
+    for k, v in gin.fill_state(shapes).items():
+        t = T(v).clone()
+        if requires_grad and t.is_floating_point() and 'running_' not in k:
+            t.requires_grad_(True)
+        st[k] = t
+    return st
+
+
+def _close(a, b, tol=2e-4):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = max(1.0, np.abs(b).max())
+    assert np.abs(a - b).max() <= tol * scale, (np.abs(a - b).max(), scale)
+
+
+@pytest.mark.parametrize('tag,rotated,B,S,seed', [('axis', False, 2, 64, 41), ('rot', True, 1, 96, 42)])
+def test_dla_forward_backward(golden, tag, rotated, B, S, seed):
+    g = golden('dla_' + tag)
+    heads = [str(h) for h in g['head_order']]
+    assert heads == ['hm', 'wh', 'reg']
+    x = T(gin.image_batch(B, S, S, seed))
+    st = _state(g, requires_grad=False)
+    with torch.no_grad():
+        out = odla.forward(st, x, heads, training=False)
+    for k in heads:
+        _close(out[k].numpy(), g['eval_' + k])
+    st = _state(g)
+    out = odla.forward(st, x, heads, training=True)
+    for k in heads:
+        _close(out[k].detach().numpy(), g['train_' + k])
+    scalar = sum((out[k] * torch.cos(torch.arange(out[k].numel(), dtype=torch.float32)
+                                     .reshape(out[k].shape) * 0.1)).sum() for k in heads)
+    scalar.backward()
+    assert abs(scalar.item() - float(g['scalar'])) <= 2e-4 * max(1, abs(float(g['scalar'])))
+    for key in g.files:
+        if key.startswith('gradsum__'):
+            n = key[len('gradsum__'):]
+            got, want = _checksums(st[n].grad), g[key]
+            assert np.abs(got - want).max() <= 5e-4 * max(1.0, want[1]), (n, got, want)
+    none = sorted(k for k, v in st.items() if v.requires_grad and v.grad is None)
+    assert none == sorted(str(s) for s in g['grad_none'])
+    for key in g.files:
+        if key.startswith('rm__'):
+            n = key[4:]
+            _close(st[n + '.running_mean'].numpy(), g[key], 1e-5)
+            _close(st[n + '.running_var'].numpy(), g['rv__' + n], 1e-5)
+            assert int(st[n + '.num_batches_tracked']) == int(g['nbt__' + n])
+
+
+@pytest.mark.parametrize('tag,weight', [('entropy', 1e-4), ('maxsq', 0.3)])
+def test_uda_step(golden, tag, weight):
+    g = golden('step_' + tag)
+    gd = golden('dla_axis')
+    st = _state(gd)
+    B, S, M = 2, 64, 8
+    batch = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, (3, 2), 2, 51).items()}
+    params = [v for k, v in st.items() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-5, weight_decay=1e-4)
+    opt.zero_grad()
+    out_s = odla.forward(st, T(gin.image_batch(B, S, S, 52)), training=True)
+    out_t = odla.forward(st, T(gin.image_batch(B, S, S, 53)), training=True)
+    c_loss, stats, prob = ol.detection_loss(out_s, batch, 1.0, 0.1, 1.0, 1.0, False)
+    u = (ol.entropy_loss if tag == 'entropy' else ol.max_square_loss)(out_t['hm']) * weight
+    c_loss.backward()
+    u.backward()
+    opt.step()
+    key = 'entropy_loss' if tag == 'entropy' else 'max_square_loss'
+    assert abs(u.item() - float(g['stat_' + key])) <= 1e-5 * max(1e-6, abs(float(g['stat_' + key])))  # Q4: weighted value is logged
+    for k, v in stats.items():
+        assert abs(v.item() - float(g['stat_' + k])) <= 2e-4 * max(1, abs(float(g['stat_' + k]))), k
+    assert abs((c_loss + u).item() - float(g['stat_total_loss'])) <= 2e-4 * max(1, abs(float(g['stat_total_loss'])))
+    _close(prob.detach().numpy(), g['src_hm_after'], 1e-4)
+    for fk in g.files:
+        if fk.startswith('gradsum__'):
+            n = fk[len('gradsum__'):]
+            got, want = _checksums(st[n].grad), g[fk]
+            assert np.abs(got - want).max() <= 1e-3 * max(1.0, want[1]), (n, got, want)
+            gotp, wantp = _checksums(st[n]), g['param__' + n]
+            assert np.abs(gotp - wantp).max() <= 1e-5 * max(1.0, wantp[1]), (n, gotp, wantp)
+    _close(st['base.base_layer.1.running_mean'].numpy(), g['rm__base.base_layer.1'], 1e-5)
+    _close(st['base.base_layer.1.running_var'].numpy(), g['rv__base.base_layer.1'], 1e-5)
+    assert int(st['base.base_layer.1.num_batches_tracked']) == 2      # Q6: two BN updates per step
