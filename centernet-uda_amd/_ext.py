@@ -1,0 +1,68 @@
+"""Drop-in for the reference's native pybind module `_ext`
+(libs/DCNv2/src/vision.cpp:4-8; imported as `import _ext as _backend` by
+libs/DCNv2/dcn_v2.py:13).  Same two function names, same positional argument
+order (input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg),
+same return values; the work is done by libcenternet_uda_hip.so on the current
+HIP stream.  Deformable PSROI pooling is not provided (no backend calls it).
+"""
+import torch
+
+import hip_runtime as hr
+
+
+def _shapes(input, weight, offset, mask, kh, kw, dg):
+    if input.dim() != 4 or weight.dim() != 4:
+        raise RuntimeError("dcn_v2: input and weight must be 4-D")
+    B, C, H, W = input.shape
+    Co, Ck, wkh, wkw = weight.shape
+    if (wkh, wkw) != (kh, kw):
+        raise RuntimeError("Input shape and kernel shape wont match: (%d x %d vs %d x %d)." % (kh, kw, wkh, wkw))
+    if Ck != C:
+        raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (C, Ck))
+    return B, C, H, W, Co
+
+
+def _out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw):
+    return ((H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1, (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1)
+
+
+def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w,
+                   pad_h, pad_w, dilation_h, dilation_w, deformable_group):
+    hr.require_gpu(input, weight, bias, offset, mask)
+    input, weight, bias, offset, mask = [hr.f32c(t) for t in (input, weight, bias, offset, mask)]
+    B, C, H, W, Co = _shapes(input, weight, offset, mask, kernel_h, kernel_w, deformable_group)
+    Ho, Wo = _out_hw(H, W, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w)
+    T = kernel_h * kernel_w
+    if tuple(offset.shape) != (B, 2 * T * deformable_group, Ho, Wo) or \
+            tuple(mask.shape) != (B, T * deformable_group, Ho, Wo):
+        raise RuntimeError("dcn_v2_forward: offset %s / mask %s do not match output %dx%d"
+                           % (tuple(offset.shape), tuple(mask.shape), Ho, Wo))
+    geom = (B, C, H, W, Co, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
+            dilation_h, dilation_w, deformable_group)
+    out = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=input.device)
+    L = hr.lib()
+    nbytes = L.cnuda_dcn_v2_workspace_bytes(*geom)
+    ws = hr.workspace(nbytes, input.device)
+    hr.check(L.cnuda_dcn_v2_forward(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
+                                    hr.ptr(out), *geom, hr.ptr(ws), ws.numel(), hr.stream()),
+             'dcn_v2_forward')
+    return out
+
+
+def dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h, stride_w,
+                    pad_h, pad_w, dilation_h, dilation_w, deformable_group):
+    hr.require_gpu(input, weight, bias, offset, mask, grad_output)
+    input, weight, bias, offset, mask, grad_output = [
+        hr.f32c(t) for t in (input, weight, bias, offset, mask, grad_output)]
+    B, C, H, W, Co = _shapes(input, weight, offset, mask, kernel_h, kernel_w, deformable_group)
+    geom = (B, C, H, W, Co, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
+            dilation_h, dilation_w, deformable_group)
+    grads = [torch.empty_like(t) for t in (input, offset, mask, weight, bias)]
+    L = hr.lib()
+    nbytes = L.cnuda_dcn_v2_workspace_bytes(*geom)
+    ws = hr.workspace(nbytes, input.device)
+    hr.check(L.cnuda_dcn_v2_backward(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
+                                     hr.ptr(grad_output), *[hr.ptr(g) for g in grads], *geom,
+                                     hr.ptr(ws), ws.numel(), hr.stream()),
+             'dcn_v2_backward')
+    return grads        # [grad_input, grad_offset, grad_mask, grad_weight, grad_bias]

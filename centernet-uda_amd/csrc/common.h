@@ -1,0 +1,76 @@
+// Shared device/host helpers for the gfx950 (CDNA4) kernels of this library.
+// Wavefront = 64 lanes everywhere; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/centernet_uda_hip.h"
+
+namespace cnuda {
+
+constexpr int kWave = 64;
+
+void set_error(const char* fmt, ...);
+
+// Every entry point funnels its launch through this check: a failed launch is
+// an error code for the caller, never a printf (the reference only printf'd,
+// libs/DCNv2/src/cuda/dcn_v2_im2col_cuda.cu:346-350).
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+#define CNUDA_REQUIRE(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::cnuda::set_error(__VA_ARGS__);     \
+            return CNUDA_ERR_INVALID_ARGUMENT;   \
+        }                                        \
+    } while (0)
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// grid cap for grid-stride memory-bound kernels: 256 CUs x 8 resident blocks
+constexpr int kMaxStreamBlocks = 2048;
+inline int stream_grid(long long work_items, int block) {
+    long long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g > kMaxStreamBlocks ? kMaxStreamBlocks : g);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum for blockDim.x a multiple of 64 and <= 1024; result valid in
+// every thread.  `red` must hold >= 16 elements of T.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    T r = (lane < nw) ? red[lane] : T(0);
+    r = wave_sum(r);
+    return r;
+}
+
+}  // namespace cnuda

@@ -1,0 +1,331 @@
+// Dense 2-D convolution (NCHW fp32, groups = 1, dilation = 1) as implicit GEMM on
+// the fp32 MFMA: forward, input gradient (transposed-conv gather) and weight
+// gradient (split-K with fixed-order slab reduction).  These replace the
+// torch.nn.Conv2d -> cuDNN calls on the reference's hot path
+// (backends/dla.py:37-44,153-155,234-235,281-283,478-483; the DCN
+// offset/mask convolution libs/DCNv2/dcn_v2.py:104-110; the ADVENT
+// discriminator uda/adversarial_entropy_minimization.py:51-68).
+//
+// K axis order is (tap, channel): within one 16-deep K chunk the tap is constant
+// whenever C % 16 == 0 (every layer but the 3-channel stem), so the bounds test
+// and address of a gathered element are computed once per chunk.
+#include "igemm.cuh"
+#include "igemm_host.h"
+
+namespace cnuda {
+namespace {
+
+struct ConvGeom {
+    int B, C, H, W, Co, kh, kw, sh, sw, ph, pw, Ho, Wo;
+};
+
+struct ConvFwdParams {
+    ConvGeom g;
+    const float *x, *bias;
+    float* y;
+    int relu;
+};
+
+// B[k = tap*C + c][n] = x[b][c][oy*sh - ph + r][ox*sw - pw + s]   (0 outside)
+template <bool FAST>
+struct ConvFwdLoader {
+    using Params = ConvFwdParams;
+    const ConvGeom& g;
+    const float* x_b;
+    int iy0, ix0;
+    bool valid;
+    __device__ ConvFwdLoader(const Params& p, long long n, bool n_valid) : g(p.g), valid(n_valid) {
+        const int HoWo = g.Ho * g.Wo;
+        const long long nn = n_valid ? n : 0;
+        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
+        const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
+        iy0 = oy * g.sh - g.ph;
+        ix0 = ox * g.sw - g.pw;
+        x_b = p.x + (size_t)b * g.C * g.H * g.W;
+    }
+    __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
+        const int HW = g.H * g.W, K = g.kh * g.kw * g.C;
+        if (FAST) {
+            const int tap = k0 / g.C, c0 = k0 - tap * g.C + ksub;
+            const int r = tap / g.kw, s = tap - r * g.kw;
+            const int iy = iy0 + r, ix = ix0 + s;
+            const bool ok = valid && k0 < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            const float* ptr = x_b + (size_t)c0 * HW + (ok ? iy * g.W + ix : 0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ok ? ptr[(size_t)(2 * j) * HW] : 0.0f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + ksub + 2 * j;
+                float val = 0.0f;
+                if (valid && k < K) {
+                    const int tap = k / g.C, c = k - tap * g.C;
+                    const int r = tap / g.kw, s = tap - r * g.kw;
+                    const int iy = iy0 + r, ix = ix0 + s;
+                    if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) val = x_b[(size_t)c * HW + iy * g.W + ix];
+                }
+                v[j] = val;
+            }
+        }
+    }
+    struct Out {
+        float* base;
+        int HoWo;
+        __device__ Out(const Params& p, long long n) {
+            HoWo = p.g.Ho * p.g.Wo;
+            const int b = (int)(n / HoWo), pp = (int)(n - (long long)b * HoWo);
+            base = p.y + (size_t)b * p.g.Co * HoWo + pp;
+        }
+        __device__ __forceinline__ void store(const Params& p, int m, float v) {
+            if (p.bias) v += p.bias[m];
+            if (p.relu) v = fmaxf(v, 0.0f);
+            base[(size_t)m * HoWo] = v;
+        }
+    };
+};
+
+// Input gradient: gx[b][c][iy][ix] = sum_{tap,o} W[o][c][tap] * gy[b][o][(iy+ph-r)/sh][(ix+pw-s)/sw]
+// (terms exist only where the divisions are exact and land inside the output).
+struct ConvDgradParams {
+    ConvGeom g;
+    const float* gy;
+    float* gx;
+};
+template <bool FAST>
+struct ConvDgradLoader {
+    using Params = ConvDgradParams;
+    const ConvGeom& g;
+    const float* gy_b;
+    int iy, ix;
+    bool valid;
+    __device__ ConvDgradLoader(const Params& p, long long n, bool n_valid) : g(p.g), valid(n_valid) {
+        const int HW = g.H * g.W;
+        const long long nn = n_valid ? n : 0;
+        const int b = (int)(nn / HW), pp = (int)(nn - (long long)b * HW);
+        iy = pp / g.W;
+        ix = pp - iy * g.W;
+        gy_b = p.gy + (size_t)b * g.Co * g.Ho * g.Wo;
+    }
+    __device__ __forceinline__ bool locate(int tap, int& off) const {
+        const int r = tap / g.kw, s = tap - r * g.kw;
+        const int ty = iy + g.ph - r, tx = ix + g.pw - s;
+        if (ty < 0 || tx < 0) return false;
+        const int oy = ty / g.sh, ox = tx / g.sw;
+        if (oy * g.sh != ty || ox * g.sw != tx || oy >= g.Ho || ox >= g.Wo) return false;
+        off = oy * g.Wo + ox;
+        return true;
+    }
+    __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
+        const int HoWo = g.Ho * g.Wo, K = g.kh * g.kw * g.Co;
+        if (FAST) {
+            const int tap = k0 / g.Co, o0 = k0 - tap * g.Co + ksub;
+            int off = 0;
+            const bool ok = valid && k0 < K && locate(tap, off);
+            const float* ptr = gy_b + (size_t)o0 * HoWo + off;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ok ? ptr[(size_t)(2 * j) * HoWo] : 0.0f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + ksub + 2 * j;
+                float val = 0.0f;
+                if (valid && k < K) {
+                    const int tap = k / g.Co, o = k - tap * g.Co;
+                    int off;
+                    if (locate(tap, off)) val = gy_b[(size_t)o * HoWo + off];
+                }
+                v[j] = val;
+            }
+        }
+    }
+    struct Out {
+        float* base;
+        int HW;
+        __device__ Out(const Params& p, long long n) {
+            HW = p.g.H * p.g.W;
+            const int b = (int)(n / HW), pp = (int)(n - (long long)b * HW);
+            base = p.gx + (size_t)b * p.g.C * HW + pp;
+        }
+        __device__ __forceinline__ void store(const Params&, int m, float v) { base[(size_t)m * HW] = v; }
+    };
+};
+
+// Weight gradient: gw[o][(tap,c)] = sum_{b,p} gy[b][o][p] * x[b][c][window(p, tap)]
+struct ConvWParams {
+    ConvGeom g;
+    const float *x, *gy;
+};
+struct ConvWLoader {
+    using Params = ConvWParams;
+    const Params& p;
+    __device__ ConvWLoader(const Params& pp) : p(pp) {}
+    __device__ __forceinline__ void load_g(long long n, bool valid, int m0, int msub, float (&v)[16]) {
+        const ConvGeom& g = p.g;
+        const int HoWo = g.Ho * g.Wo;
+        const long long nn = valid ? n : 0;
+        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
+        const float* base = p.gy + (size_t)b * g.Co * HoWo + pp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + msub + 4 * i;
+            v[i] = (valid && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void load_b(long long n, bool valid, int j0, int jsub, float (&v)[16]) {
+        const ConvGeom& g = p.g;
+        const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, K = g.kh * g.kw * g.C;
+        const long long nn = valid ? n : 0;
+        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
+        const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
+        const int iy0 = oy * g.sh - g.ph, ix0 = ox * g.sw - g.pw;
+        const float* x_b = p.x + (size_t)b * g.C * HW;
+        int cur = -1, off = 0;
+        bool ok = false;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = j0 + jsub + 4 * i;
+            float val = 0.0f;
+            if (valid && k < K) {
+                const int tap = k / g.C, c = k - tap * g.C;
+                if (tap != cur) {
+                    const int r = tap / g.kw, s = tap - r * g.kw;
+                    const int iy = iy0 + r, ix = ix0 + s;
+                    ok = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                    off = iy * g.W + ix;
+                    cur = tap;
+                }
+                if (ok) val = x_b[(size_t)c * HW + off];
+            }
+            v[i] = val;
+        }
+    }
+};
+
+int fill_geom(ConvGeom& g, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
+              const char* who) {
+    CNUDA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Co > 0, "%s: empty tensor", who);
+    CNUDA_REQUIRE(kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0, "%s: bad kernel geometry", who);
+    g = ConvGeom{B, C, H, W, Co, kh, kw, sh, sw, ph, pw, (H + 2 * ph - kh) / sh + 1, (W + 2 * pw - kw) / sw + 1};
+    CNUDA_REQUIRE(H + 2 * ph >= kh && W + 2 * pw >= kw && g.Ho > 0 && g.Wo > 0, "%s: kernel larger than padded input",
+                  who);
+    return 0;
+}
+
+int pick_bm(int M) { return M > 64 ? 128 : (M > 32 ? 64 : 32); }
+
+struct ConvPlan {
+    int T;
+    int Kf, Kpf, bmf, Mpf;   // forward:  K = T*C,  M = Co
+    int Kd, Kpd, bmd, Mpd;   // dgrad:    K = T*Co, M = C
+    int Mpw, Jp, Z;          // wgrad slabs
+    long long Nf, Nd, pix_per_split;
+    size_t fwd_bytes, dgrad_bytes, wgrad_bytes;
+};
+ConvPlan make_plan(const ConvGeom& g) {
+    ConvPlan q;
+    q.T = g.kh * g.kw;
+    q.Kf = q.T * g.C;   q.Kpf = round_up(q.Kf, IG_BK);  q.bmf = pick_bm(g.Co);  q.Mpf = round_up(g.Co, q.bmf);
+    q.Kd = q.T * g.Co;  q.Kpd = round_up(q.Kd, IG_BK);  q.bmd = pick_bm(g.C);   q.Mpd = round_up(g.C, q.bmd);
+    q.Nf = (long long)g.B * g.Ho * g.Wo;
+    q.Nd = (long long)g.B * g.H * g.W;
+    q.Mpw = round_up(g.Co, WG_BM);
+    q.Jp = round_up(q.Kf, WG_BJ);
+    const long long tiles = (long long)(q.Mpw / WG_BM) * (q.Jp / WG_BJ);
+    long long z = (1024 + tiles - 1) / tiles;
+    const long long max_z = (q.Nf + WG_BP - 1) / WG_BP;
+    if (z > max_z) z = max_z;
+    if (z < 1) z = 1;
+    q.pix_per_split = ((q.Nf + z - 1) / z + WG_BP - 1) / WG_BP * WG_BP;
+    q.Z = (int)((q.Nf + q.pix_per_split - 1) / q.pix_per_split);
+    q.fwd_bytes = carve_bytes((size_t)q.Kpf * q.Mpf, 4) + 256;
+    q.dgrad_bytes = carve_bytes((size_t)q.Kpd * q.Mpd, 4) + 256;
+    q.wgrad_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) + 256;
+    return q;
+}
+
+template <class Loader>
+int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp, int Kp, int M, long long N,
+               hipStream_t st, const char* who) {
+    const int n_tiles = ceil_div(N, IG_BN), m_tiles = Mp / bm;
+    const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
+    if (bm == 128)
+        hipLaunchKernelGGL((igemm_fwd_kernel<128, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+    else if (bm == 64)
+        hipLaunchKernelGGL((igemm_fwd_kernel<64, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+    else
+        hipLaunchKernelGGL((igemm_fwd_kernel<32, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+    return check_launch(who);
+}
+
+}  // namespace
+}  // namespace cnuda
+
+using namespace cnuda;
+
+extern "C" size_t cnuda_conv2d_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw,
+                                               int ph, int pw) {
+    ConvGeom g;
+    if (fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_workspace_bytes")) return 0;
+    const ConvPlan q = make_plan(g);
+    size_t m = q.fwd_bytes;
+    if (q.dgrad_bytes > m) m = q.dgrad_bytes;
+    if (q.wgrad_bytes > m) m = q.wgrad_bytes;
+    return m;
+}
+
+extern "C" int cnuda_conv2d_forward(const float* x, const float* weight, const float* bias, float* y, int B, int C,
+                                    int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int relu,
+                                    void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && weight && y, "cnuda_conv2d_forward: null pointer");
+    ConvGeom g;
+    if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_forward")) return rc;
+    const ConvPlan q = make_plan(g);
+    CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_conv2d_forward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    float* A = cv.take<float>((size_t)q.Kpf * q.Mpf);
+    launch_pack(weight, A, Cout, C, q.T, PACK_FWD, q.Kpf, q.Mpf, 0, st);
+    ConvFwdParams p{g, x, bias, y, relu};
+    if (C % IG_BK == 0)
+        return launch_fwd<ConvFwdLoader<true>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
+    return launch_fwd<ConvFwdLoader<false>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
+}
+
+extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weight, float* grad_x, int B, int C, int H,
+                                          int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                                          void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(grad_y && weight && grad_x, "cnuda_conv2d_backward_data: null pointer");
+    ConvGeom g;
+    if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_backward_data")) return rc;
+    const ConvPlan q = make_plan(g);
+    CNUDA_REQUIRE(workspace && workspace_bytes >= q.dgrad_bytes, "cnuda_conv2d_backward_data: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    float* A = cv.take<float>((size_t)q.Kpd * q.Mpd);
+    launch_pack(weight, A, Cout, C, q.T, PACK_DGRAD, q.Kpd, q.Mpd, 0, st);
+    ConvDgradParams p{g, grad_y, grad_x};
+    if (Cout % IG_BK == 0)
+        return launch_fwd<ConvDgradLoader<true>>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
+    return launch_fwd<ConvDgradLoader<false>>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
+}
+
+extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y, float* grad_weight, float* grad_bias,
+                                            int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw,
+                                            int ph, int pw, void* workspace, size_t workspace_bytes,
+                                            cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && grad_y && grad_weight, "cnuda_conv2d_backward_weight: null pointer");
+    ConvGeom g;
+    if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_backward_weight")) return rc;
+    const ConvPlan q = make_plan(g);
+    CNUDA_REQUIRE(workspace && workspace_bytes >= q.wgrad_bytes, "cnuda_conv2d_backward_weight: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    float* slabs = cv.take<float>((size_t)q.Z * q.Mpw * q.Jp);
+    ConvWParams p{g, x, grad_y};
+    hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z), dim3(IG_THREADS), 0,
+                       st, p, slabs, q.Mpw, q.Jp, q.Nf, q.pix_per_split);
+    if (int rc = check_launch("cnuda_conv2d_backward_weight")) return rc;
+    launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, st);
+    if (grad_bias) launch_channel_sum(grad_y, grad_bias, B, Cout, (long long)g.Ho * g.Wo, st);
+    return check_launch("cnuda_conv2d_backward_weight(reduce)");
+}

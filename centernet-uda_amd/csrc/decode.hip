@@ -1,0 +1,301 @@
+// Detection decode for gfx950: 3x3 (or kxk) max-pool NMS + two-stage top-K +
+// box assembly.  Replaces backends/decode.py:6-76 of the reference.
+//
+// Stage 1 (one 1024-thread workgroup per (b, c) plane): the plane is read once
+// from HBM (neighbours come from L1), the NMS'd scores are cached in LDS, and
+// the K best are found by an 8-bit MSB radix select over 64-bit order keys
+// (wave-ballot free: LDS histograms + one-wave suffix scan), then sorted with
+// an in-LDS bitonic network.  Stage 2 (one workgroup per image) runs the same
+// select over the C*K candidates and assembles the boxes.
+//
+// Order key: high 32 bits = order-preserving image of the fp32 score, low 32
+// bits = ~index, so "larger key" == "higher score, or equal score and lower
+// index" -- a strict total order (the reference's torch.topk leaves ties
+// unspecified; see include/centernet_uda_hip.h).
+#include "common.h"
+
+namespace cnuda {
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kMaxK = 1024;
+
+__device__ __forceinline__ uint32_t float_order_bits(float v) {
+    v += 0.0f;  // -0.0 -> +0.0 so that both zeros tie like they do for torch.topk
+    uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float order_bits_float(uint32_t u) {
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ uint64_t make_key(float score, uint32_t index) {
+    return ((uint64_t)float_order_bits(score) << 32) | (uint64_t)(0xffffffffu - index);
+}
+
+struct SelectScratch {
+    int hist[256];
+    uint64_t prefix;     // decided high bits of the K-th key
+    int remaining;       // how many keys are still to be taken from the current bucket
+    int done;
+    int out_count;
+    uint64_t sel[kMaxK];
+};
+
+// Block-wide exact top-K of n unique 64-bit keys, result sorted descending in
+// s.sel[0..K).  key_at(i) must be cheap and deterministic (called once per pass).
+template <typename KeyAt>
+__device__ void block_topk(KeyAt key_at, int n, int K, int KP, SelectScratch& s) {
+    const int tid = threadIdx.x;
+    if (tid == 0) { s.prefix = 0; s.remaining = K; s.done = 0; s.out_count = 0; }
+    // threshold search: after the loop every key >= s.prefix (compared on the
+    // decided bits) belongs to the top K.
+    int shift = 56;
+    uint64_t decided_mask = 0;
+    for (int pass = 0; pass < 8; ++pass, shift -= 8) {
+        if (tid < 256) s.hist[tid] = 0;
+        __syncthreads();
+        if (s.done) break;
+        const uint64_t prefix = s.prefix;
+        for (int i = tid; i < n; i += kThreads) {
+            const uint64_t k = key_at(i);
+            if ((k & decided_mask) == prefix) atomicAdd(&s.hist[(int)((k >> shift) & 0xff)], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // suffix counts over 256 bins, 4 bins per lane (lane 63 owns the top bins)
+            const int base = (63 - tid) * 4;  // lane 0 -> bins 252..255
+            int c3 = s.hist[base + 3], c2 = s.hist[base + 2], c1 = s.hist[base + 1], c0 = s.hist[base];
+            int local = c0 + c1 + c2 + c3;
+            int incl = local;  // inclusive scan over lanes 0..tid (higher bins first)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                int t = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += t;
+            }
+            const int above = incl - local;  // keys in strictly higher bins than this lane's four
+            const int rem = s.remaining;
+            // walk this lane's bins from high to low
+            int acc = above;
+            int cs[4] = {c3, c2, c1, c0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cnt = cs[j];
+                if (acc < rem && rem <= acc + cnt) {
+                    const int digit = base + 3 - j;
+                    s.prefix = prefix | ((uint64_t)digit << shift);
+                    s.remaining = rem - acc;
+                    if (cnt == rem - acc) s.done = 1;  // whole bucket is selected
+                }
+                acc += cnt;
+            }
+        }
+        decided_mask |= (uint64_t)0xff << shift;
+        __syncthreads();
+    }
+    __syncthreads();
+    // collect: keys whose decided bits are >= the threshold prefix
+    {
+        // decided_mask covers exactly the digits fixed when the loop ended
+        const uint64_t prefix = s.prefix;
+        const uint64_t m = decided_mask;
+        for (int i = tid; i < KP; i += kThreads) s.sel[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += kThreads) {
+            const uint64_t k = key_at(i);
+            if ((k & m) >= prefix) {
+                const int pos = atomicAdd(&s.out_count, 1);
+                if (pos < KP) s.sel[pos] = k;
+            }
+        }
+        __syncthreads();
+    }
+    // bitonic sort, descending, KP a power of two <= 1024
+    for (int size = 2; size <= KP; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (tid < (KP >> 1)) {
+                const int lo = (tid / stride) * (stride << 1) + (tid % stride);
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const uint64_t a = s.sel[lo], b = s.sel[hi];
+                if ((a < b) == desc) { s.sel[lo] = b; s.sel[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ float nms_value(const float* __restrict__ plane, int H, int W, int y, int x, int pad) {
+    const float v = plane[y * W + x];
+    float m = v;
+    for (int dy = -pad; dy <= pad; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -pad; dx <= pad; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W) continue;
+            m = fmaxf(m, plane[yy * W + xx]);
+        }
+    }
+    // keep = 1 - ceil(hmax - heat)  (decode.py:12), NOT (hmax == heat): identical
+    // for scores in [0,1], reproduced literally for anything else (Q9)
+    const float keep = 1.0f - ceilf(m - v);
+    return v * keep;
+}
+
+__global__ void nms_kernel(const float* __restrict__ heat, float* __restrict__ out,
+                           long long planes, int H, int W, int pad) {
+    const long long total = planes * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const long long p = i / ((long long)W * H);
+        out[i] = nms_value(heat + p * H * W, H, W, y, x, pad);
+    }
+}
+
+// Stage 1.  Dynamic LDS: HW floats (NMS'd plane cache) when CACHE, nothing otherwise.
+template <bool CACHE>
+__global__ __launch_bounds__(kThreads) void plane_topk_kernel(
+    const float* __restrict__ heat, uint64_t* __restrict__ cand, float* __restrict__ nms_scratch,
+    int H, int W, int K, int KP, int pad) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    SelectScratch& s = *reinterpret_cast<SelectScratch*>(smem);
+    float* cache = reinterpret_cast<float*>(smem + sizeof(SelectScratch));
+    const int HW = H * W;
+    const float* plane = heat + (size_t)blockIdx.x * HW;
+    float* vals = CACHE ? cache : nms_scratch + (size_t)blockIdx.x * HW;
+    for (int i = threadIdx.x; i < HW; i += kThreads)
+        vals[i] = nms_value(plane, H, W, i / W, i % W, pad);
+    __syncthreads();
+    block_topk([&](int i) { return make_key(vals[i], (uint32_t)i); }, HW, K, KP, s);
+    uint64_t* dst = cand + (size_t)blockIdx.x * K;
+    for (int i = threadIdx.x; i < K; i += kThreads) dst[i] = s.sel[i];
+}
+
+// Stage 2: per image, top-K over C*K candidates + box assembly.
+__global__ __launch_bounds__(kThreads) void merge_decode_kernel(
+    const uint64_t* __restrict__ cand, const float* __restrict__ wh, const float* __restrict__ reg,
+    float* __restrict__ dets, int64_t* __restrict__ inds,
+    int C, int H, int W, int K, int KP, int wh_ch, int rotated) {
+    __shared__ SelectScratch s;
+    const int b = blockIdx.x;
+    const int HW = H * W;
+    const int n = C * K;
+    const uint64_t* cb = cand + (size_t)b * n;
+    // second-stage key: same score bits, position c*K+rank as the index
+    block_topk([&](int i) { return (cb[i] & 0xffffffff00000000ull) | (uint64_t)(0xffffffffu - (uint32_t)i); },
+               n, K, KP, s);
+    const int ncol = rotated ? 7 : 6;
+    for (int k = threadIdx.x; k < K; k += kThreads) {
+        const uint64_t key = s.sel[k];
+        const uint32_t pos = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
+        const int cls = (int)(pos / (uint32_t)K);
+        const float score = order_bits_float((uint32_t)(key >> 32));
+        const uint32_t idx = 0xffffffffu - (uint32_t)(cb[pos] & 0xffffffffu);
+        float xs = (float)(int)(idx % (uint32_t)W);
+        float ys = (float)(int)(idx / (uint32_t)W);
+        if (reg) {
+            xs += reg[((size_t)b * 2 + 0) * HW + idx];
+            ys += reg[((size_t)b * 2 + 1) * HW + idx];
+        } else {
+            xs += 0.5f;
+            ys += 0.5f;
+        }
+        const float w = wh[((size_t)b * wh_ch + 0) * HW + idx];
+        const float h = wh[((size_t)b * wh_ch + 1) * HW + idx];
+        float* d = dets + ((size_t)b * K + k) * ncol;
+        if (!rotated) {
+            d[0] = xs - w / 2.0f;
+            d[1] = ys - h / 2.0f;
+            d[2] = xs + w / 2.0f;
+            d[3] = ys + h / 2.0f;
+            d[4] = score;
+            d[5] = (float)cls;
+        } else {
+            const float a = wh[((size_t)b * wh_ch + 2) * HW + idx];
+            float sg = 1.0f / (1.0f + expf(-a));
+            sg = fminf(fmaxf(sg, 1e-4f), 1.0f - 1e-4f);
+            d[0] = xs;
+            d[1] = ys;
+            d[2] = w;
+            d[3] = h;
+            d[4] = sg * 360.0f - 180.0f;
+            d[5] = score;
+            d[6] = (float)cls;
+        }
+        if (inds) inds[(size_t)b * K + k] = (int64_t)idx;
+    }
+}
+
+int next_pow2(int v) {
+    int p = 2;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+constexpr size_t kCacheLimitBytes = 128 * 1024;  // of the 160 KiB LDS per CU
+
+}  // namespace
+}  // namespace cnuda
+
+using namespace cnuda;
+
+extern "C" size_t cnuda_decode_workspace_bytes(int B, int C, int H, int W, int K) {
+    size_t cand = (size_t)B * C * K * sizeof(uint64_t);
+    size_t scratch = ((size_t)H * W * sizeof(float) > kCacheLimitBytes) ? (size_t)B * C * H * W * sizeof(float) : 0;
+    return cand + scratch + 256;
+}
+
+extern "C" int cnuda_nms(const float* heat, float* out, int B, int C, int H, int W, int nms_size,
+                         cnuda_stream_t stream) {
+    CNUDA_REQUIRE(heat && out, "cnuda_nms: null pointer");
+    CNUDA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "cnuda_nms: empty tensor");
+    CNUDA_REQUIRE(nms_size >= 1 && (nms_size & 1), "cnuda_nms: nms_size must be odd, got %d", nms_size);
+    const long long total = (long long)B * C * H * W;
+    hipLaunchKernelGGL(nms_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       heat, out, (long long)B * C, H, W, (nms_size - 1) / 2);
+    return check_launch("cnuda_nms");
+}
+
+extern "C" int cnuda_decode_detection(const float* heat, const float* wh, const float* reg,
+                                      float* dets, int64_t* inds,
+                                      int B, int C, int H, int W, int K, int wh_ch, int rotated, int nms_size,
+                                      void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(heat && wh && dets, "cnuda_decode_detection: null pointer");
+    CNUDA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "cnuda_decode_detection: empty tensor");
+    CNUDA_REQUIRE(nms_size >= 1 && (nms_size & 1), "cnuda_decode_detection: nms_size must be odd, got %d", nms_size);
+    // torch.topk raises when k exceeds the row length (decode.py:18)
+    CNUDA_REQUIRE(K >= 1 && (long long)K <= (long long)H * W, "selected index k out of range (K=%d, H*W=%d)", K, H * W);
+    CNUDA_REQUIRE(K <= kMaxK, "cnuda_decode_detection: K=%d exceeds the supported maximum %d", K, kMaxK);
+    CNUDA_REQUIRE(wh_ch >= (rotated ? 3 : 2), "cnuda_decode_detection: wh has %d channels", wh_ch);
+    CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_decode_workspace_bytes(B, C, H, W, K),
+                  "cnuda_decode_detection: workspace too small");
+    const int KP = next_pow2(K);
+    const int pad = (nms_size - 1) / 2;
+    uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    uint64_t* cand = reinterpret_cast<uint64_t*>(base);
+    float* scratch = reinterpret_cast<float*>(base + (size_t)B * C * K * sizeof(uint64_t));
+    const size_t plane_bytes = (size_t)H * W * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (plane_bytes <= kCacheLimitBytes) {
+        const size_t lds = sizeof(SelectScratch) + plane_bytes;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(plane_topk_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(SelectScratch) + kCacheLimitBytes));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(plane_topk_kernel<true>, dim3(B * C), dim3(kThreads), lds, st,
+                           heat, cand, (float*)nullptr, H, W, K, KP, pad);
+    } else {
+        hipLaunchKernelGGL(plane_topk_kernel<false>, dim3(B * C), dim3(kThreads), sizeof(SelectScratch), st,
+                           heat, cand, scratch, H, W, K, KP, pad);
+    }
+    int rc = check_launch("cnuda_decode_detection(stage 1)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(merge_decode_kernel, dim3(B), dim3(kThreads), 0, st,
+                       cand, wh, reg, dets, inds, C, H, W, K, KP, wh_ch, rotated ? 1 : 0);
+    return check_launch("cnuda_decode_detection(stage 2)");
+}

@@ -1,0 +1,217 @@
+// Implicit-GEMM building blocks on the fp32 MFMA (v_mfma_f32_32x32x2_f32) for
+// gfx950.  fp32 in / fp32 accumulate is exact f32 (a k-ordered fma chain), so
+// the 1e-4 parity budget of the hot path is spent on summation order only.
+//
+// GEMM view shared by every user of this header:
+//     D[m][n] = sum_k A[k][m] * B[k][n]
+//   A: a small "packed" matrix in global memory, [Kp][Mp] row-major (m
+//      contiguous), zero padded to multiples of (BK, BM) by a pack kernel.
+//   B: produced on the fly by a Loader (im2col gather, transposed-conv gather,
+//      bilinear deformable sampling, or a plain row read), n = flattened
+//      (batch, y, x) "pixel" so that consecutive lanes touch consecutive
+//      addresses of an NCHW plane.
+// Workgroup = 256 threads = 4 waves; block tile BM x 128 x 16; every wave owns
+// TM x TN tiles of 32x32.  LDS holds As[BK][BM] and Bs[BK][BN]: both operand
+// reads are lane-consecutive ds_read_b32 (conflict-free, MI355X_MICROARCH LDS
+// table), fragment maps per cdna_hip_programming.md section 3:
+//   A operand: lane l holds A[k = l>>5][i = l&31]; B: B[k = l>>5][j = l&31]
+//   D: col j = l&31, row i = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+#pragma once
+#include "common.h"
+
+namespace cnuda {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int IG_BN = 128;
+constexpr int IG_BK = 16;
+constexpr int IG_THREADS = 256;
+
+template <int BM> struct IgTile;
+template <> struct IgTile<128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; };
+template <> struct IgTile<64>  { static constexpr int WM = 2, WN = 2, TM = 1, TN = 2; };
+template <> struct IgTile<32>  { static constexpr int WM = 1, WN = 4, TM = 1, TN = 1; };
+
+// XCD-aware, bijective remap of a linear workgroup id: workgroups are dealt
+// round-robin over the 8 XCDs (b and b+8 share an L2), so give every XCD a
+// contiguous run of tiles -- neighbouring pixel tiles share halo rows and the
+// M tiles of one pixel tile share the whole gathered B panel.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    constexpr int NX = 8;
+    const int per = nwg / NX, rem = nwg % NX;
+    const int x = bid % NX, q = bid / NX;
+    // XCD x owns `per` tiles (+1 for the first `rem` XCDs)
+    const int start = x * per + (x < rem ? x : rem);
+    return start + q;
+}
+
+// row m of D tile element `reg` for this lane
+__device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <int BM>
+__device__ __forceinline__ void ig_mma_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
+                                             f32x16 (&acc)[IgTile<BM>::TM][IgTile<BM>::TN],
+                                             int wm_off, int wn_off, int lane) {
+    using T = IgTile<BM>;
+    const int kl = lane >> 5, il = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < IG_BK; kk += 2) {
+        float a[T::TM], b[T::TN];
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i) a[i] = As[(kk + kl) * BM + wm_off + i * 32 + il];
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) b[j] = Bs[(kk + kl) * IG_BN + wn_off + j * 32 + il];
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// Stage the A tile rows [k0, k0+BK) x cols [m0, m0+BM) of the packed matrix.
+template <int BM>
+__device__ __forceinline__ void ig_load_a(const float* __restrict__ A, int Mp, int k0, int m0, int tid,
+                                          float (&r)[BM / 16]) {
+    // BK*BM floats over 256 threads; consecutive threads -> consecutive m
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) {
+        const int e = tid + i * IG_THREADS;
+        const int kk = e / BM, m = e % BM;
+        r[i] = A[(size_t)(k0 + kk) * Mp + m0 + m];
+    }
+}
+template <int BM>
+__device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, const float (&r)[BM / 16]) {
+#pragma unroll
+    for (int i = 0; i < BM / 16; ++i) As[tid + i * IG_THREADS] = r[i];
+}
+
+// Generic forward-type kernel.  Loader contract:
+//   Loader(const Params&, long long n, bool n_valid)   per-thread pixel setup
+//   void load(int k0, int ksub, float (&v)[8])         v[j] = B[k0 + ksub + 2j][n]
+// Epilogue contract:
+//   void store(const Params&, int m, long long n, float value)
+template <int BM, class Loader>
+__global__ __launch_bounds__(IG_THREADS) void igemm_fwd_kernel(
+    typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
+    int n_tiles, int m_tiles) {
+    using T = IgTile<BM>;
+    __shared__ float As[IG_BK * BM];
+    __shared__ float Bs[IG_BK * IG_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wg = xcd_remap(blockIdx.x, n_tiles * m_tiles);
+    const int m0 = (wg % m_tiles) * BM;
+    const long long n0 = (long long)(wg / m_tiles) * IG_BN;
+    const int wm_off = (wid / T::WN) * (T::TM * 32), wn_off = (wid % T::WN) * (T::TN * 32);
+
+    const int nl = tid & (IG_BN - 1), ksub = tid >> 7;  // pixel within tile, k parity
+    Loader ld(p, n0 + nl, n0 + nl < N);
+
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float ra[BM / 16], rb[8];
+    ig_load_a<BM>(A, Mp, 0, m0, tid, ra);
+    ld.load(0, ksub, rb);
+    for (int k0 = 0; k0 < Kp; k0 += IG_BK) {
+        __syncthreads();  // previous chunk's fragment reads are done
+        ig_store_a<BM>(As, tid, ra);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Bs[(ksub + 2 * j) * IG_BN + nl] = rb[j];
+        __syncthreads();
+        if (k0 + IG_BK < Kp) {  // prefetch the next chunk under this chunk's MFMAs
+            ig_load_a<BM>(A, Mp, k0 + IG_BK, m0, tid, ra);
+            ld.load(k0 + IG_BK, ksub, rb);
+        }
+        ig_mma_chunk<BM>(As, Bs, acc, wm_off, wn_off, lane);
+    }
+    // epilogue: lane owns pixel column (lane&31) of each tile
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const long long n = n0 + wn_off + j * 32 + (lane & 31);
+        if (n >= N) continue;
+        typename Loader::Out out(p, n);
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm_off + i * 32 + mfma_row(r, lane);
+                if (m < M) out.store(p, m, acc[i][j][r]);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Weight-gradient-type kernel:  D[m][j] = sum_n  G[m][n] * B[j][n]
+// (m = output channel, j = column of the packed K axis, n = pixel).  The pixel
+// range is split over blockIdx.z; every workgroup writes one fp32 partial slab
+// [Mp x Jp] and a second kernel sums the slabs in a fixed order (bitwise
+// reproducible, no float atomics).
+// Tile 64(m) x 64(j), 64 pixels per chunk; LDS images are [pixel][m|j] with an
+// odd row stride so that the pixel-major stores are conflict-free.
+// Loader contract (WLoader):
+//   WLoader(const Params&)                                  per-thread state
+//   void load_b(long long n, bool valid, int j0, int jsub, float (&v)[16])   v[i] = B[j0 + jsub + 4i][n]
+//   void load_g(long long n, bool valid, int m0, int msub, float (&v)[16])   v[i] = G[m0 + msub + 4i][n]
+// ---------------------------------------------------------------------------
+constexpr int WG_BM = 64, WG_BJ = 64, WG_BP = 64, WG_LD = 65;
+
+template <class WLoader>
+__global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
+    typename WLoader::Params p, float* __restrict__ slabs, int Mp, int Jp, long long N, long long pix_per_split) {
+    __shared__ float Gs[WG_BP * WG_LD];
+    __shared__ float Bs[WG_BP * WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j0 = blockIdx.x * WG_BJ, m0 = blockIdx.y * WG_BM;
+    const long long n_begin = (long long)blockIdx.z * pix_per_split;
+    long long n_end = n_begin + pix_per_split;
+    if (n_end > N) n_end = N;
+    const int pl = tid & 63, sub = tid >> 6;  // pixel within chunk, row phase (0..3)
+    const int wm_off = (wid >> 1) * 32, wj_off = (wid & 1) * 32;
+    WLoader ld(p);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float rg[16], rb[16];
+    {
+        const long long n = n_begin + pl;
+        ld.load_g(n, n < n_end, m0, sub, rg);
+        ld.load_b(n, n < n_end, j0, sub, rb);
+    }
+    for (long long nb = n_begin; nb < n_end; nb += WG_BP) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            Gs[pl * WG_LD + sub + 4 * i] = rg[i];
+            Bs[pl * WG_LD + sub + 4 * i] = rb[i];
+        }
+        __syncthreads();
+        if (nb + WG_BP < n_end) {
+            const long long n = nb + WG_BP + pl;
+            ld.load_g(n, n < n_end, m0, sub, rg);
+            ld.load_b(n, n < n_end, j0, sub, rb);
+        }
+        const int kl = lane >> 5, il = lane & 31;
+#pragma unroll
+        for (int kk = 0; kk < WG_BP; kk += 2) {
+            const float a = Gs[(kk + kl) * WG_LD + wm_off + il];
+            const float b = Bs[(kk + kl) * WG_LD + wj_off + il];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    float* slab = slabs + (size_t)blockIdx.z * Mp * Jp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm_off + mfma_row(r, lane);
+        const int j = j0 + wj_off + (lane & 31);
+        slab[(size_t)m * Jp + j] = acc[r];
+    }
+}
+
+}  // namespace cnuda

@@ -1,0 +1,39 @@
+// Host-side helpers shared by conv.hip and dcn.hip (packing of the small weight
+// operand, split-K slab reduction, workspace carving).
+#pragma once
+#include "common.h"
+
+namespace cnuda {
+
+enum PackMode {
+    PACK_FWD = 0,    // dst[k = tap*C + c][m = o]        (forward / wgrad column order)
+    PACK_DGRAD = 1,  // dst[k = tap*Co + o][m = c]       (transposed conv)
+    PACK_DCOL = 2,   // dst[k = o][m = tap*Cpad + c]     (DCN column gradient)
+};
+
+inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
+
+// W is the reference layout [Co][C][T] (T = kh*kw).  dst is [Kp][Mp], zero padded.
+void launch_pack(const float* W, float* dst, int Co, int C, int T, PackMode mode,
+                 int Kp, int Mp, int Cpad, hipStream_t st);
+
+// gw[o][c][tap] = sum_z slabs[z][o][tap*C + c]
+void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp,
+                        int Co, int C, int T, hipStream_t st);
+
+// out[c] = sum over (b, hw) of x[b][c][hw]   (bias gradients)
+void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st);
+
+struct Carver {
+    uintptr_t cur, end;
+    Carver(void* ws, size_t bytes) : cur(((uintptr_t)ws + 255) & ~(uintptr_t)255), end((uintptr_t)ws + bytes) {}
+    template <typename T> T* take(size_t count) {
+        T* p = reinterpret_cast<T*>(cur);
+        cur = (cur + count * sizeof(T) + 255) & ~(uintptr_t)255;
+        return p;
+    }
+    bool ok() const { return cur <= end; }
+};
+inline size_t carve_bytes(size_t count, size_t elem) { return (count * elem + 255) / 256 * 256; }
+
+}  // namespace cnuda

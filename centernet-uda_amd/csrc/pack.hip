@@ -1,0 +1,72 @@
+// Small helper kernels around the implicit-GEMM cores: weight packing, split-K
+// slab reduction, per-channel sums.
+#include "igemm_host.h"
+
+namespace cnuda {
+namespace {
+
+__global__ void pack_kernel(const float* __restrict__ W, float* __restrict__ dst, int Co, int C, int T,
+                            int mode, int Kp, int Mp, int Cpad) {
+    const long long total = (long long)Kp * Mp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / Mp), m = (int)(i % Mp);
+        int o = -1, c = -1, tap = -1;
+        if (mode == PACK_FWD) {
+            if (k < T * C && m < Co) { tap = k / C; c = k % C; o = m; }
+        } else if (mode == PACK_DGRAD) {
+            if (k < T * Co && m < C) { tap = k / Co; o = k % Co; c = m; }
+        } else {
+            if (k < Co && m < T * Cpad) { o = k; tap = m / Cpad; c = m % Cpad; if (c >= C) o = -1; }
+        }
+        dst[i] = (o >= 0) ? W[((size_t)o * C + c) * T + tap] : 0.0f;
+    }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw, int Z, int Mp, int Jp,
+                                   int Co, int C, int T) {
+    const long long total = (long long)Co * C * T;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % T), c = (int)((i / T) % C), o = (int)(i / ((long long)T * C));
+        const size_t off = (size_t)o * Jp + (size_t)tap * C + c;
+        float s = 0.0f;
+        for (int z = 0; z < Z; ++z) s += slabs[(size_t)z * Mp * Jp + off];
+        gw[i] = s;
+    }
+}
+
+// one workgroup per channel; fixed-order tree -> reproducible
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          int B, int C, long long HW) {
+    __shared__ float red[16];
+    const int c = blockIdx.x;
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float* p = x + ((size_t)b * C + c) * HW;
+        for (long long i = threadIdx.x; i < HW; i += 256) s += p[i];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[c] = s;
+}
+
+}  // namespace
+
+void launch_pack(const float* W, float* dst, int Co, int C, int T, PackMode mode, int Kp, int Mp, int Cpad,
+                 hipStream_t st) {
+    const long long total = (long long)Kp * Mp;
+    hipLaunchKernelGGL(pack_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, W, dst, Co, C, T, (int)mode, Kp,
+                       Mp, Cpad);
+}
+
+void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp, int Co, int C, int T, hipStream_t st) {
+    const long long total = (long long)Co * C * T;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, slabs, gw, Z, Mp, Jp, Co,
+                       C, T);
+}
+
+void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st) {
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, st, x, out, B, C, HW);
+}
+
+}  // namespace cnuda

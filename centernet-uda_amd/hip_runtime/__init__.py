@@ -1,0 +1,104 @@
+"""ctypes binding of libcenternet_uda_hip.so (the C ABI in include/centernet_uda_hip.h).
+
+This is the only place the product path touches native code.  There is no
+fallback: if the shared library is missing or a call fails, a RuntimeError is
+raised (the reference raises RuntimeError out of its pybind module too,
+libs/DCNv2/src/dcn_v2.h:35).  torch is used for device memory and the current
+HIP stream only.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, 'libcenternet_uda_hip.so')
+ABI_VERSION = 1
+
+_lib = None
+_lock = threading.Lock()
+_workspaces = {}
+
+c_int, c_size_t, c_void_p, c_float = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_float
+
+
+def lib():
+    """Load the HIP library (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        "%s not found: build it with `make -C centernet-uda_amd/csrc` "
+                        "(or __graft_entry__.build()); there is no CPU/eager fallback" % LIB_PATH)
+                l = ctypes.CDLL(LIB_PATH)
+                l.cnuda_last_error.restype = ctypes.c_char_p
+                l.cnuda_abi_version.restype = c_int
+                if l.cnuda_abi_version() != ABI_VERSION:
+                    raise RuntimeError("libcenternet_uda_hip.so ABI %d != expected %d"
+                                       % (l.cnuda_abi_version(), ABI_VERSION))
+                for name in dir(_Sig):
+                    if name.startswith('cnuda_'):
+                        restype, argtypes = getattr(_Sig, name)
+                        fn = getattr(l, name)
+                        fn.restype, fn.argtypes = restype, argtypes
+                _lib = l
+    return _lib
+
+
+_I = c_int
+_P = c_void_p
+
+
+class _Sig:
+    """restype, argtypes for every exported symbol (mirrors include/centernet_uda_hip.h)."""
+    cnuda_decode_workspace_bytes = (c_size_t, [_I] * 5)
+    cnuda_decode_detection = (_I, [_P] * 5 + [_I] * 8 + [_P, c_size_t, _P])
+    cnuda_nms = (_I, [_P, _P] + [_I] * 5 + [_P])
+    cnuda_dcn_v2_workspace_bytes = (c_size_t, [_I] * 14)
+    cnuda_dcn_v2_forward = (_I, [_P] * 6 + [_I] * 14 + [_P, c_size_t, _P])
+    cnuda_dcn_v2_backward = (_I, [_P] * 11 + [_I] * 14 + [_P, c_size_t, _P])
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().cnuda_last_error().decode('utf-8', 'replace')
+        raise RuntimeError(msg or ('%s failed with code %d' % (what, rc)))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("centernet-uda_amd ops run on MI355X only: got a %s tensor "
+                               "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests)"
+                               % t.device)
+
+
+def f32c(t):
+    """contiguous fp32 view/copy -- the native side reads raw NCHW fp32 (dcn_v2_cuda.cu:58,219-220)."""
+    if t.dtype != torch.float32:
+        raise RuntimeError("expected float32, got %s" % t.dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device.  All kernels of one step run on one
+    stream, so stream order makes reuse between consecutive calls safe."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

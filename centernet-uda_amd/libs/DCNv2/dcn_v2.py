@@ -1,0 +1,88 @@
+"""Python face of the deformable convolution: `dcn_v2_conv`, `DCNv2`, `DCN`
+with the constructor/forward signatures, parameter names (`weight`, `bias`,
+`conv_offset_mask.{weight,bias}` -- checkpoint keys) and initialisation of the
+reference (libs/DCNv2/dcn_v2.py:18-128), running on the MI355X kernels behind
+`_ext`.  The offset/mask generating 3x3 convolution of `DCN` is this repo's own
+implicit-GEMM convolution (hip_runtime.nn.Conv2d), not a vendor library.
+"""
+import math
+
+import torch
+from torch import nn
+
+import _ext as _backend
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+class _DeformConvFn(torch.autograd.Function):
+    # autograd-visible argument order (dcn_v2.py:18-19): input, offset, mask, weight, bias, ...
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
+        kh, kw = weight.shape[2], weight.shape[3]
+        ctx.geom = (kh, kw) + _pair(stride) + _pair(padding) + _pair(dilation) + (deformable_groups,)
+        ctx.save_for_backward(input, offset, mask, weight, bias)
+        return _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geom)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        input, offset, mask, weight, bias = ctx.saved_tensors
+        g_in, g_off, g_mask, g_w, g_b = _backend.dcn_v2_backward(
+            input, weight, bias, offset, mask, grad_output, *ctx.geom)
+        return g_in, g_off, g_mask, g_w, g_b, None, None, None, None
+
+
+dcn_v2_conv = _DeformConvFn.apply
+
+
+class DCNv2(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1,
+                 deformable_groups=1):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        self.deformable_groups = deformable_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # U(-1/sqrt(fan_in), +1/sqrt(fan_in)) weights, zero bias (dcn_v2.py:75-81)
+        bound = 1.0 / math.sqrt(self.in_channels * self.kernel_size[0] * self.kernel_size[1])
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            self.bias.zero_()
+
+    def forward(self, input, offset, mask):
+        taps = self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]
+        assert offset.shape[1] == 2 * taps and mask.shape[1] == taps
+        return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                           self.dilation, self.deformable_groups)
+
+
+class DCN(DCNv2):
+    """DCNv2 that predicts its own offsets and modulation mask from the input."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1,
+                 deformable_groups=1):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, deformable_groups)
+        from hip_runtime import nn as hnn
+        taps = self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]
+        self.conv_offset_mask = hnn.Conv2d(in_channels, 3 * taps, self.kernel_size, self.stride,
+                                           self.padding, bias=True)
+        with torch.no_grad():        # zero init: offsets 0, mask sigmoid(0)=0.5 (dcn_v2.py:114-116, Q7)
+            self.conv_offset_mask.weight.zero_()
+            self.conv_offset_mask.bias.zero_()
+
+    def forward(self, input):
+        from hip_runtime import ops
+        om = self.conv_offset_mask(input)
+        # channels [0, 2*taps) are offsets (chunks o1|o2 re-concatenated, dcn_v2.py:120-121),
+        # [2*taps, 3*taps) the mask logits
+        offset, mask = ops.split_offset_mask(om)
+        return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                           self.dilation, self.deformable_groups)

@@ -1,0 +1,111 @@
+"""MI355X parity of backends.decode (HIP) against the golden vectors captured
+from the reference and against the numpy oracle.  Indices are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import inputs as gin
+from oracle import decode as od
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def T(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _hip_decode(d, K=None):
+    from backends import decode as hd
+    dets, inds = hd._run(T(d['heat']), T(d['wh']), T(d['reg']), K or d['K'], d['rotated'], 3)
+    torch.cuda.synchronize()
+    return dets.cpu().numpy(), inds.cpu().numpy()
+
+
+@pytest.mark.parametrize('name', sorted(gin.DECODE_CASES))
+def test_decode_golden(golden, name):
+    d = gin.decode_inputs(name)
+    g = golden('decode_' + name)
+    dets, inds = _hip_decode(d)
+    assert np.array_equal(inds, g['inds'])
+    cls_col = 6 if d['rotated'] else 5
+    assert np.array_equal(dets[..., cls_col].astype(np.int32), g['clses'])
+    assert np.array_equal(dets[..., cls_col - 1], g['dets'][..., cls_col - 1])       # scores exact
+    np.testing.assert_allclose(dets, g['dets'], rtol=1e-5, atol=5e-5)               # fp32 tolerance 1e-4 budget
+
+
+def test_public_api_matches_oracle_and_has_reference_signature():
+    from backends.decode import decode_detection, _nms, _topk
+    d = gin.decode_inputs('small')
+    out = decode_detection(T(d['heat']), T(d['wh']), reg=T(d['reg']), K=d['K'])
+    want = od.decode_detection(d['heat'], d['wh'], d['reg'], K=d['K'])
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-6, atol=1e-5)
+    nm = _nms(T(d['heat'])).cpu().numpy()
+    assert np.array_equal(nm, od.nms(d['heat']))
+    s, i, c, ys, xs = _topk(T(od.nms(d['heat'])), K=d['K'])
+    os_, oi, oc, oy, ox = od.topk(od.nms(d['heat']), d['K'])
+    assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(c.cpu().numpy(), oc)
+    assert np.array_equal(s.cpu().numpy(), os_)
+    assert np.array_equal(ys.cpu().numpy(), oy) and np.array_equal(xs.cpu().numpy(), ox)
+
+
+@pytest.mark.parametrize('case', ['ties', 'constant', 'few_peaks', 'negative', 'nms5', 'big_plane'])
+def test_decode_edge_cases_vs_oracle(case):
+    rs = np.random.RandomState(7)
+    B, C, H, W, K, nms = 2, 3, 20, 24, 50, 3
+    heat = np.clip(1 / (1 + np.exp(-(rs.standard_normal((B, C, H, W)) - 2))), 1e-4, 1 - 1e-4).astype(np.float32)
+    if case == 'ties':
+        heat = np.round(heat * 8) / 8                      # heavy quantisation -> many equal scores
+        heat = heat.astype(np.float32)
+    elif case == 'constant':
+        heat[:] = 0.25                                     # every cell is a "peak" with the same score
+    elif case == 'few_peaks':
+        heat[:] = 1e-4
+        heat[0, 1, 3, 4] = 0.9
+        heat[1, 2, 10, 10] = 0.7                           # fewer peaks than K -> suppressed zeros fill up
+    elif case == 'negative':
+        heat = rs.standard_normal((B, C, H, W)).astype(np.float32) * 3   # raw logits: Q9 literal formula
+    elif case == 'nms5':
+        nms = 5
+    elif case == 'big_plane':
+        B, C, H, W, K = 1, 2, 200, 190, 100                # 152 KB plane: the no-LDS-cache path
+        heat = np.clip(1 / (1 + np.exp(-(rs.standard_normal((B, C, H, W)) - 2))), 1e-4, 1 - 1e-4).astype(np.float32)
+    wh = rs.uniform(1, 9, (B, 2, H, W)).astype(np.float32)
+    reg = rs.uniform(0, 1, (B, 2, H, W)).astype(np.float32)
+    from backends import decode as hd
+    dets, inds = hd._run(T(heat), T(wh), T(reg), K, False, nms)
+    want, winds, wcls = od.decode_detection(heat, wh, reg, K=K, nms_size=nms, return_inds=True)
+    assert np.array_equal(inds.cpu().numpy(), winds)
+    assert np.array_equal(dets[..., 5].cpu().numpy().astype(np.int32), wcls)
+    np.testing.assert_allclose(dets.cpu().numpy(), want, rtol=1e-6, atol=1e-5)
+
+
+def test_full_size_property_cfg3_scores_sorted_and_are_local_maxima():
+    # BASELINE cfg sizes: B=16, C=6, 128x128, K=150 -- size-independent properties
+    rs = np.random.RandomState(3)
+    B, C, H, W, K = 16, 6, 128, 128, 150
+    heat = np.clip(1 / (1 + np.exp(-(rs.standard_normal((B, C, H, W)) - 2.19))), 1e-4, 1 - 1e-4).astype(np.float32)
+    wh = rs.uniform(1, 50, (B, 2, H, W)).astype(np.float32)
+    reg = rs.uniform(0, 1, (B, 2, H, W)).astype(np.float32)
+    from backends import decode as hd
+    dets, inds = hd._run(T(heat), T(wh), T(reg), K, False, 3)
+    dets, inds = dets.cpu().numpy(), inds.cpu().numpy()
+    assert (dets[:, :-1, 4] >= dets[:, 1:, 4]).all()                       # sorted
+    cls = dets[..., 5].astype(np.int64)
+    picked = np.take_along_axis(heat.reshape(B, C * H * W), cls * H * W + inds, axis=1)
+    assert np.array_equal(picked, dets[..., 4])                            # scores are the map values
+    nm = od.nms(heat).reshape(B, -1)
+    kth = np.sort(nm, axis=1)[:, -K]
+    assert np.array_equal(dets[:, -1, 4], kth)                             # the K-th score is the K-th largest
+    # idempotence: decoding the already-suppressed map gives the same detections
+    dets2, inds2 = hd._run(T(od.nms(heat)), T(wh), T(reg), K, False, 3)
+    assert np.array_equal(inds2.cpu().numpy(), inds)
+
+
+def test_errors():
+    from backends.decode import decode_detection
+    heat = torch.zeros(1, 1, 2, 2, device=DEV)
+    with pytest.raises(RuntimeError):
+        decode_detection(heat, torch.zeros(1, 2, 2, 2, device=DEV), K=5)          # K > H*W like torch.topk
+    with pytest.raises(RuntimeError):
+        decode_detection(torch.zeros(1, 1, 4, 4), torch.zeros(1, 2, 4, 4), K=2)   # CPU tensors: no fallback
