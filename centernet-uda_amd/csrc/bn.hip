@@ -1,0 +1,284 @@
+// BatchNorm2d (NCHW fp32) for gfx950, fused with the residual add and ReLU that
+// follow it everywhere in DLA-34 (backends/dla.py:48-62 BasicBlock, :150-168
+// Root, :351-372 DeformConv, :277-287 conv levels).  Replaces
+// nn.BatchNorm2d(momentum=0.1) + `out += residual` + nn.ReLU(inplace=True).
+//
+// Training forward : (1) per-channel sum / sum-of-squares partials over a
+//                    (channel, split) grid, fp64 accumulation; (2) a finalize
+//                    kernel -> mean, invstd, running-stat update (unbiased var,
+//                    momentum) ; (3) one streaming pass y = act(xhat*g + b [+ res]).
+// Backward         : same three-step shape for (sum dy, sum dy*xhat).
+// All three passes are HBM-bound streaming kernels with 16-byte accesses when
+// the plane size allows.
+#include "common.h"
+
+namespace cnuda {
+namespace {
+
+constexpr int kBnThreads = 256;
+
+struct Split {
+    int per_plane;     // splits of one (b, c) plane
+    int S;             // partials per channel = B * per_plane
+    long long chunk;   // elements of a plane per split (multiple of 4)
+};
+Split pick_split(int B, int C, long long HW) {
+    // aim for ~2048 workgroups in total, at least 4096 elements each
+    long long s = 2048 / ((long long)B * C > 0 ? (long long)B * C : 1);
+    const long long max_s = (HW + 4095) / 4096;
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    Split r;
+    r.chunk = ((HW + s - 1) / s + 3) / 4 * 4;
+    r.per_plane = (int)((HW + r.chunk - 1) / r.chunk);
+    r.S = B * r.per_plane;
+    return r;
+}
+
+// partial[(c*S + s)*2 + {0,1}] = sum(v), sum(v*w) over one chunk of one (b, c) plane
+// MODE 0: v = x, w = x                       (forward statistics)
+// MODE 1: v = dy', w = xhat                   (backward), dy' = dy * (y > 0) when relu
+template <int MODE>
+__global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ partial,
+    int C, long long HW, long long chunk, int per_plane, int S, int relu) {
+    __shared__ double red[16];
+    const int c = blockIdx.x, s = blockIdx.y;
+    const int b = s / per_plane, part = s - b * per_plane;
+    const size_t base = ((size_t)b * C + c) * HW;
+    const long long e0 = (long long)part * chunk;
+    long long e1 = e0 + chunk;
+    if (e1 > HW) e1 = HW;
+    double a0 = 0.0, a1 = 0.0;
+    float mu = 0.f, is = 0.f;
+    if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+    auto acc = [&](float xv, float gv, float yv) {
+        if (MODE == 0) {
+            const double v = (double)xv;
+            a0 += v;
+            a1 += v * v;
+        } else {
+            float g = gv;
+            if (relu && !(yv > 0.0f)) g = 0.0f;
+            const float xh = (xv - mu) * is;
+            a0 += (double)g;
+            a1 += (double)g * (double)xh;
+        }
+    };
+    if ((HW & 3) == 0) {
+        for (long long e = e0 + threadIdx.x * 4; e < e1; e += kBnThreads * 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + base + e);
+            float4 gv = make_float4(0, 0, 0, 0), yv = make_float4(1, 1, 1, 1);
+            if (MODE == 1) {
+                gv = *reinterpret_cast<const float4*>(dy + base + e);
+                if (relu) yv = *reinterpret_cast<const float4*>(y + base + e);
+            }
+            acc(xv.x, gv.x, yv.x); acc(xv.y, gv.y, yv.y); acc(xv.z, gv.z, yv.z); acc(xv.w, gv.w, yv.w);
+        }
+    } else {
+        for (long long e = e0 + threadIdx.x; e < e1; e += kBnThreads)
+            acc(x[base + e], MODE == 1 ? dy[base + e] : 0.f, (MODE == 1 && relu) ? y[base + e] : 1.f);
+    }
+    a0 = block_sum(a0, red);
+    a1 = block_sum(a1, red);
+    if (threadIdx.x == 0) {
+        partial[((size_t)c * S + s) * 2 + 0] = a0;
+        partial[((size_t)c * S + s) * 2 + 1] = a1;
+    }
+}
+
+__global__ void bn_finalize_fwd_kernel(const double* __restrict__ partial, float* __restrict__ save_mean,
+                                       float* __restrict__ save_invstd, float* __restrict__ running_mean,
+                                       float* __restrict__ running_var, int C, int S, long long count, float momentum,
+                                       float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int s = 0; s < S; ++s) {
+        s0 += partial[((size_t)c * S + s) * 2 + 0];
+        s1 += partial[((size_t)c * S + s) * 2 + 1];
+    }
+    const double n = (double)count;
+    const double mu = s0 / n;
+    double var = s1 / n - mu * mu;   // biased; fp64 sums make the subtraction safe
+    if (var < 0.0) var = 0.0;
+    save_mean[c] = (float)mu;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+
+__global__ void bn_finalize_bwd_kernel(const double* __restrict__ partial, float* __restrict__ ggamma,
+                                       float* __restrict__ gbeta, float* __restrict__ sums, int C, int S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int s = 0; s < S; ++s) {
+        s0 += partial[((size_t)c * S + s) * 2 + 0];
+        s1 += partial[((size_t)c * S + s) * 2 + 1];
+    }
+    gbeta[c] = (float)s0;
+    ggamma[c] = (float)s1;
+    sums[2 * c] = (float)s0;
+    sums[2 * c + 1] = (float)s1;
+}
+
+// y = act((x - mean) * invstd * gamma + beta [+ residual]); grid (plane, splits)
+__global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ residual,
+    float* __restrict__ y, int C, long long HW, int relu) {
+    const long long plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const float sc = invstd[c] * gamma[c];
+    const float sh = beta[c] - mean[c] * sc;
+    const size_t base = (size_t)plane * HW;
+    const long long start = (long long)blockIdx.y * kBnThreads * 4 + threadIdx.x * 4;
+    const long long stride = (long long)gridDim.y * kBnThreads * 4;
+    if ((HW & 3) == 0) {
+        for (long long i = start; i < HW; i += stride) {
+            float4 v = *reinterpret_cast<const float4*>(x + base + i);
+            v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+            if (residual) {
+                const float4 r = *reinterpret_cast<const float4*>(residual + base + i);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(y + base + i) = v;
+        }
+    } else {
+        for (long long i0 = start; i0 < HW; i0 += stride)
+            for (long long i = i0; i < i0 + 4 && i < HW; ++i) {
+                float v = x[base + i] * sc + sh;
+                if (residual) v += residual[base + i];
+                if (relu) v = fmaxf(v, 0.f);
+                y[base + i] = v;
+            }
+    }
+}
+
+// gx = gamma*invstd*(dy' - sum_dy/n - xhat*sum_dy_xhat/n);  gres = dy'
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ sums, float* __restrict__ gx, float* __restrict__ gres, int C, long long HW,
+    long long count, int relu) {
+    const long long plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const float mu = mean[c], is = invstd[c];
+    const float k = gamma[c] * is;
+    const float inv_n = 1.0f / (float)count;
+    const float m0 = sums[2 * c] * inv_n, m1 = sums[2 * c + 1] * inv_n;
+    const size_t base = (size_t)plane * HW;
+    for (long long i = (long long)blockIdx.y * kBnThreads + threadIdx.x; i < HW; i += (long long)gridDim.y * kBnThreads) {
+        float g = dy[base + i];
+        if (relu && !(y[base + i] > 0.0f)) g = 0.0f;
+        const float xh = (x[base + i] - mu) * is;
+        gx[base + i] = k * (g - m0 - xh * m1);
+        if (gres) gres[base + i] = g;
+    }
+}
+
+__global__ __launch_bounds__(kBnThreads) void bn_eval_kernel(
+    const float* __restrict__ x, const float* __restrict__ rmean, const float* __restrict__ rvar,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ residual,
+    float* __restrict__ y, int C, long long HW, float eps, int relu) {
+    const long long plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+    const float sh = beta[c] - rmean[c] * sc;
+    const size_t base = (size_t)plane * HW;
+    for (long long i = (long long)blockIdx.y * kBnThreads + threadIdx.x; i < HW; i += (long long)gridDim.y * kBnThreads) {
+        float v = x[base + i] * sc + sh;
+        if (residual) v += residual[base + i];
+        if (relu) v = fmaxf(v, 0.f);
+        y[base + i] = v;
+    }
+}
+
+int plane_splits(long long planes, long long HW, int per_block) {
+    long long want = 2048 / (planes > 0 ? planes : 1);
+    if (want < 1) want = 1;
+    const long long max_s = (HW + per_block - 1) / per_block;
+    if (want > max_s) want = max_s;
+    return (int)(want < 1 ? 1 : want);
+}
+
+}  // namespace
+}  // namespace cnuda
+
+using namespace cnuda;
+
+extern "C" size_t cnuda_bn_workspace_bytes(int B, int C, long long HW) {
+    const Split sp = pick_split(B, C, HW);
+    return (size_t)C * sp.S * 2 * sizeof(double) + (size_t)C * 2 * sizeof(float) + 512;
+}
+
+extern "C" int cnuda_bn_train_forward(const float* x, const float* gamma, const float* beta, const float* residual,
+                                      float* y, float* save_mean, float* save_invstd, float* running_mean,
+                                      float* running_var, float momentum, float eps, int relu, int B, int C,
+                                      long long HW, void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && gamma && beta && y && save_mean && save_invstd, "cnuda_bn_train_forward: null pointer");
+    CNUDA_REQUIRE(B > 0 && C > 0 && HW > 0, "cnuda_bn_train_forward: empty tensor");
+    CNUDA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "cnuda_bn_train_forward: running stats");
+    const long long count = (long long)B * HW;
+    // nn.BatchNorm2d raises for a single value per channel in training mode
+    CNUDA_REQUIRE(count > 1, "Expected more than 1 value per channel when training, got input size [%d, %d, %lld]", B, C,
+                  HW);
+    CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_bn_workspace_bytes(B, C, HW),
+                  "cnuda_bn_train_forward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const Split sp = pick_split(B, C, HW);
+    double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, C, HW,
+                       sp.chunk, sp.per_plane, sp.S, 0);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, partial, save_mean, save_invstd,
+                       running_mean, running_var, C, sp.S, count, momentum, eps);
+    const long long planes = (long long)B * C;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
+                       dim3(kBnThreads), 0, st, x, save_mean, save_invstd, gamma, beta, residual, y, C, HW, relu);
+    return check_launch("cnuda_bn_train_forward");
+}
+
+extern "C" int cnuda_bn_eval_forward(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                                     const float* running_var, const float* residual, float* y, float eps, int relu,
+                                     int B, int C, long long HW, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && gamma && beta && running_mean && running_var && y, "cnuda_bn_eval_forward: null pointer");
+    CNUDA_REQUIRE(B > 0 && C > 0 && HW > 0, "cnuda_bn_eval_forward: empty tensor");
+    const long long planes = (long long)B * C;
+    hipLaunchKernelGGL(bn_eval_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads)), dim3(kBnThreads), 0,
+                       (hipStream_t)stream, x, running_mean, running_var, gamma, beta, residual, y, C, HW, eps, relu);
+    return check_launch("cnuda_bn_eval_forward");
+}
+
+extern "C" int cnuda_bn_backward(const float* grad_y, const float* x, const float* y, const float* gamma,
+                                 const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual,
+                                 float* grad_gamma, float* grad_beta, int relu, int B, int C, long long HW,
+                                 void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(grad_y && x && gamma && save_mean && save_invstd && grad_x && grad_gamma && grad_beta,
+                  "cnuda_bn_backward: null pointer");
+    CNUDA_REQUIRE(!relu || y, "cnuda_bn_backward: relu backward needs the forward output");
+    CNUDA_REQUIRE(B > 0 && C > 0 && HW > 0, "cnuda_bn_backward: empty tensor");
+    CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_bn_workspace_bytes(B, C, HW),
+                  "cnuda_bn_backward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const long long count = (long long)B * HW;
+    const Split sp = pick_split(B, C, HW);
+    uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    double* partial = reinterpret_cast<double*>(base);
+    float* sums = reinterpret_cast<float*>(base + (size_t)C * sp.S * 2 * sizeof(double));
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, grad_y, y, save_mean,
+                       save_invstd, partial, C, HW, sp.chunk, sp.per_plane, sp.S, relu);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, partial, grad_gamma, grad_beta,
+                       sums, C, sp.S);
+    const long long planes = (long long)B * C;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads)),
+                       dim3(kBnThreads), 0, st, grad_y, x, y, save_mean, save_invstd, gamma, sums, grad_x,
+                       grad_residual, C, HW, count, relu);
+    return check_launch("cnuda_bn_backward");
+}

@@ -23,7 +23,7 @@ struct ConvFwdParams {
     ConvGeom g;
     const float *x, *bias;
     float* y;
-    int relu;
+    float act_slope;   // < 0: none, 0: ReLU, 0.2: LeakyReLU(0.2)
 };
 
 // B[k = tap*C + c][n] = x[b][c][oy*sh - ph + r][ox*sw - pw + s]   (0 outside)
@@ -78,7 +78,7 @@ struct ConvFwdLoader {
         }
         __device__ __forceinline__ void store(const Params& p, int m, float v) {
             if (p.bias) v += p.bias[m];
-            if (p.relu) v = fmaxf(v, 0.0f);
+            if (p.act_slope >= 0.0f && v < 0.0f) v *= p.act_slope;
             base[(size_t)m * HoWo] = v;
         }
     };
@@ -274,7 +274,7 @@ extern "C" size_t cnuda_conv2d_workspace_bytes(int B, int C, int H, int W, int C
 }
 
 extern "C" int cnuda_conv2d_forward(const float* x, const float* weight, const float* bias, float* y, int B, int C,
-                                    int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int relu,
+                                    int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, float act_slope,
                                     void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
     CNUDA_REQUIRE(x && weight && y, "cnuda_conv2d_forward: null pointer");
     ConvGeom g;
@@ -285,7 +285,7 @@ extern "C" int cnuda_conv2d_forward(const float* x, const float* weight, const f
     Carver cv(workspace, workspace_bytes);
     float* A = cv.take<float>((size_t)q.Kpf * q.Mpf);
     launch_pack(weight, A, Cout, C, q.T, PACK_FWD, q.Kpf, q.Mpf, 0, st);
-    ConvFwdParams p{g, x, bias, y, relu};
+    ConvFwdParams p{g, x, bias, y, act_slope};
     if (C % IG_BK == 0)
         return launch_fwd<ConvFwdLoader<true>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
     return launch_fwd<ConvFwdLoader<false>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");

@@ -1,0 +1,449 @@
+// Detection and UDA losses for gfx950 (fp32 values, fp64 block reductions).
+// Replaces, on device and without host synchronisation:
+//   utils/tensor.py:5-7         _sigmoid (clamp(sigmoid, 1e-4, 1-1e-4))
+//   losses/centernet.py:69-95   FocalLoss._neg_loss (incl. the num_pos == 0 branch, Q11)
+//   losses/centernet.py:98-133  RegL1Loss (+ rotated), :192-223 PeriodicRegL1Loss
+//   losses/entropy.py:10-28     EntropyLoss      losses/max_square.py:6-14 MaxSquareLoss
+//   utils/image.py:121-124      entropy_map      losses/advent.py:10-18    BCE-with-logits vs constant
+// Every loss is a pair (forward -> scalar(s) in device memory, backward ->
+// gradient w.r.t. the logits given a device-resident upstream scalar).
+#include "common.h"
+
+namespace cnuda {
+namespace {
+
+constexpr int kT = 256;
+constexpr float kLo = 1e-4f, kHi = 1.0f - 1e-4f;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------- focal ----------------
+// partial[blk*3 + {0,1,2}] = sum pos_loss, sum neg_loss, num_pos
+__global__ __launch_bounds__(kT) void focal_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ gt,
+                                                       float* __restrict__ prob, double* __restrict__ partial,
+                                                       long long n) {
+    __shared__ double red[16];
+    double ps = 0.0, ns = 0.0, np = 0.0;
+    for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n; i += (long long)gridDim.x * kT) {
+        const float p = fminf(fmaxf(sigmoidf_(logits[i]), kLo), kHi);
+        prob[i] = p;
+        const float g = gt[i];
+        if (g == 1.0f) {
+            const float q = 1.0f - p;
+            ps += (double)(logf(p) * (q * q));
+            np += 1.0;
+        } else if (g < 1.0f) {
+            const float w = 1.0f - g;
+            const float w2 = w * w;
+            ns += (double)(logf(1.0f - p) * (p * p) * (w2 * w2));
+        }
+    }
+    ps = block_sum(ps, red);
+    ns = block_sum(ns, red);
+    np = block_sum(np, red);
+    if (threadIdx.x == 0) {
+        partial[(size_t)blockIdx.x * 3 + 0] = ps;
+        partial[(size_t)blockIdx.x * 3 + 1] = ns;
+        partial[(size_t)blockIdx.x * 3 + 2] = np;
+    }
+}
+// out[0] = loss, out[1] = num_pos (kept for backward)
+__global__ void focal_finalize_kernel(const double* __restrict__ partial, int blocks, float weight,
+                                      float* __restrict__ out) {
+    __shared__ double red[16];
+    double ps = 0.0, ns = 0.0, np = 0.0;
+    for (int i = threadIdx.x; i < blocks; i += blockDim.x) {
+        ps += partial[(size_t)i * 3];
+        ns += partial[(size_t)i * 3 + 1];
+        np += partial[(size_t)i * 3 + 2];
+    }
+    ps = block_sum(ps, red);
+    ns = block_sum(ns, red);
+    np = block_sum(np, red);
+    if (threadIdx.x == 0) {
+        const float pos = (float)ps, neg = (float)ns, n = (float)np;
+        const float loss = (n == 0.0f) ? (0.0f - neg) : (0.0f - (pos + neg) / n);
+        out[0] = loss * weight;
+        out[1] = n;
+    }
+}
+// dlogits = upstream * weight * dL/dp * dp/dx
+__global__ void focal_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ gt,
+                                 const float* __restrict__ fwd_out, const float* __restrict__ upstream, float weight,
+                                 float* __restrict__ grad, long long n) {
+    const float np = fwd_out[1];
+    const float scale = upstream[0] * weight * (np == 0.0f ? -1.0f : -1.0f / np);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float s = sigmoidf_(logits[i]);
+        float gval = 0.0f;
+        if (s >= kLo && s <= kHi) {   // clamp passes gradient inside [min, max] only
+            const float p = s, q = 1.0f - s, g = gt[i];
+            float dldp = 0.0f;
+            if (g == 1.0f) {
+                if (np != 0.0f) dldp = (q * q) / p - 2.0f * q * logf(p);
+            } else if (g < 1.0f) {
+                const float w = 1.0f - g, w2 = w * w;
+                dldp = (2.0f * p * logf(q) - (p * p) / q) * (w2 * w2);
+            }
+            gval = scale * dldp * (s * q);
+        }
+        grad[i] = gval;
+    }
+}
+
+// ---------------- gather + masked L1 (wh / reg / angle) ----------------
+// mode 0: plain (ch 2 or 3: with 3 channels = rotated non-periodic: angle through clamped sigmoid)
+// mode 1: periodic angle
+// out[0] = loss, out[1] = denominator (expanded-mask sum + 1e-4)
+// Single workgroup: B*M is a few thousand at most (M = max_detections).
+__global__ __launch_bounds__(kT) void regl1_fwd_kernel(const float* __restrict__ feat, const unsigned char* __restrict__ mask,
+                                                       const long long* __restrict__ ind, float* __restrict__ target,
+                                                       int B, int M, int ch, int HW, int mode, float weight,
+                                                       float angle_weight, float* __restrict__ out) {
+    __shared__ double red[16];
+    double s_wh = 0.0, s_a = 0.0, s_m = 0.0;
+    for (int i = threadIdx.x; i < B * M; i += kT) {
+        const int b = i / M;
+        const float m = mask[i] ? 1.0f : 0.0f;
+        const long long id = ind[i];
+        for (int c = 0; c < ch; ++c) {
+            const float pred = feat[((size_t)b * ch + c) * HW + id] * m;
+            const float tg = target[(size_t)i * ch + c] * m;
+            target[(size_t)i * ch + c] = tg;   // in-place masking of the batch tensor (Q2)
+            s_m += (double)m;
+            if (ch == 3 && c == 2) {
+                if (mode == 0) {
+                    const float ps = fminf(fmaxf(sigmoidf_(pred), kLo), kHi);
+                    const float tsig = sigmoidf_(tg);
+                    target[(size_t)i * ch + c] = tsig;   // target[...,2:3].sigmoid_() is in place too (Q2)
+                    const float ts = fminf(fmaxf(tsig, kLo), kHi);
+                    s_a += (double)fabsf(ps - ts);
+                } else {
+                    const float pi = 3.14159265358979323846f;
+                    const float pa = fminf(fmaxf(sigmoidf_(pred), kLo), kHi) * 2.0f * pi - pi;
+                    const float ta = tg * (pi / 180.0f);
+                    const float d = (pa - ta) - pi / 2.0f;
+                    float r = fmodf(d, pi);
+                    if (r != 0.0f && r < 0.0f) r += pi;   // torch.remainder: sign of the divisor
+                    s_a += (double)fabsf(r - pi / 2.0f);
+                }
+            } else {
+                s_wh += (double)fabsf(pred - tg);
+            }
+        }
+    }
+    s_wh = block_sum(s_wh, red);
+    s_a = block_sum(s_a, red);
+    s_m = block_sum(s_m, red);
+    if (threadIdx.x == 0) {
+        const float denom = (float)s_m + 1e-4f;
+        float loss = (float)s_wh / denom * weight;
+        if (ch == 3) loss += (float)s_a / denom * angle_weight;
+        out[0] = loss;
+        out[1] = denom;
+    }
+}
+// scatter-add into a zero-initialised grad [B, ch, HW]; `target` is the (already masked / sigmoided) tensor
+__global__ void regl1_bwd_kernel(const float* __restrict__ feat, const unsigned char* __restrict__ mask,
+                                 const long long* __restrict__ ind, const float* __restrict__ target,
+                                 const float* __restrict__ fwd_out, const float* __restrict__ upstream, int B, int M,
+                                 int ch, int HW, int mode, float weight, float angle_weight, float* __restrict__ grad) {
+    const float up = upstream[0] / fwd_out[1];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * M * ch; i += gridDim.x * blockDim.x) {
+        const int c = i % ch, bm = i / ch, b = bm / M;
+        if (!mask[bm]) continue;
+        const long long id = ind[bm];
+        const float pred = feat[((size_t)b * ch + c) * HW + id];
+        const float tg = target[i];
+        float g;
+        if (ch == 3 && c == 2) {
+            const float s = sigmoidf_(pred);
+            const float ds = (s >= kLo && s <= kHi) ? s * (1.0f - s) : 0.0f;
+            const float ps = fminf(fmaxf(s, kLo), kHi);
+            if (mode == 0) {
+                const float ts = fminf(fmaxf(tg, kLo), kHi);   // target already holds sigmoid(target)
+                const float d = ps - ts;
+                g = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * ds * angle_weight;
+            } else {
+                const float pi = 3.14159265358979323846f;
+                const float pa = ps * 2.0f * pi - pi, ta = tg * (pi / 180.0f);
+                float r = fmodf((pa - ta) - pi / 2.0f, pi);
+                if (r != 0.0f && r < 0.0f) r += pi;
+                const float e = r - pi / 2.0f;
+                g = (e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f)) * (2.0f * pi) * ds * angle_weight;
+            }
+        } else {
+            const float d = pred - tg;
+            g = (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * weight;
+        }
+        atomicAdd(grad + ((size_t)b * ch + c) * HW + id, g * up);
+    }
+}
+
+// ---------------- softmax-over-channels losses ----------------
+// f(v) = v*log2(v + 1e-30);   f'(v) = log2(v + eps) + v / ((v + eps) ln 2)
+constexpr int kMaxC = 128;
+__device__ __forceinline__ float fent(float v) { return v * log2f(v + 1e-30f); }
+__device__ __forceinline__ float dfent(float v) { return log2f(v + 1e-30f) + v / ((v + 1e-30f) * 0.6931471805599453f); }
+
+// kind 0: entropy  sum_c f(v_c)         kind 1: max-squares  sum_c v_c^2
+__global__ __launch_bounds__(kT) void softmax_loss_fwd_kernel(const float* __restrict__ x, double* __restrict__ partial,
+                                                              int B, int C, long long HW, int kind) {
+    __shared__ double red[16];
+    double acc = 0.0;
+    const long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < total; i += (long long)gridDim.x * kT) {
+        const long long b = i / HW, hw = i - b * HW;
+        const float* px = x + (size_t)b * C * HW + hw;
+        float mx = px[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, px[(size_t)c * HW]);
+        float den = 0.0f;
+        for (int c = 0; c < C; ++c) den += expf(px[(size_t)c * HW] - mx);
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float v = expf(px[(size_t)c * HW] - mx) / den;
+            s += kind == 0 ? fent(v) : v * v;
+        }
+        acc += (double)s;
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+__global__ void scalar_finalize_kernel(const double* __restrict__ partial, int blocks, double scale,
+                                       float* __restrict__ out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < blocks; i += blockDim.x) s += partial[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = (float)(s * scale);
+}
+// dx_j = up*scale * v_j * (h_j - sum_i v_i h_i),  h = f'(v) (entropy) or 2v (max-squares)
+__global__ void softmax_loss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ upstream, float scale,
+                                        float* __restrict__ grad, int B, int C, long long HW, int kind) {
+    const float up = upstream[0] * scale;
+    const long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / HW, hw = i - b * HW;
+        const float* px = x + (size_t)b * C * HW + hw;
+        float* pg = grad + (size_t)b * C * HW + hw;
+        float mx = px[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, px[(size_t)c * HW]);
+        float den = 0.0f;
+        for (int c = 0; c < C; ++c) den += expf(px[(size_t)c * HW] - mx);
+        float dot = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float v = expf(px[(size_t)c * HW] - mx) / den;
+            dot += v * (kind == 0 ? dfent(v) : 2.0f * v);
+        }
+        for (int c = 0; c < C; ++c) {
+            const float v = expf(px[(size_t)c * HW] - mx) / den;
+            pg[(size_t)c * HW] = up * v * ((kind == 0 ? dfent(v) : 2.0f * v) - dot);
+        }
+    }
+}
+// entropy_map: out_c = -f(v_c) / log2(C)
+__global__ void entropy_map_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C,
+                                       long long HW) {
+    const float inv = 1.0f / log2f((float)C);
+    const long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / HW, hw = i - b * HW;
+        const float* px = x + (size_t)b * C * HW + hw;
+        float* po = out + (size_t)b * C * HW + hw;
+        float mx = px[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, px[(size_t)c * HW]);
+        float den = 0.0f;
+        for (int c = 0; c < C; ++c) den += expf(px[(size_t)c * HW] - mx);
+        for (int c = 0; c < C; ++c) {
+            const float v = expf(px[(size_t)c * HW] - mx) / den;
+            po[(size_t)c * HW] = -fent(v) * inv;
+        }
+    }
+}
+// gx_j = -(1/log2 C) * v_j * (g_j f'_j - sum_i g_i f'_i v_i)
+__global__ void entropy_map_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+                                       float* __restrict__ grad, int B, int C, long long HW) {
+    const float inv = 1.0f / log2f((float)C);
+    const long long total = (long long)B * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / HW, hw = i - b * HW;
+        const size_t base = (size_t)b * C * HW + hw;
+        const float* px = x + base;
+        float mx = px[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, px[(size_t)c * HW]);
+        float den = 0.0f;
+        for (int c = 0; c < C; ++c) den += expf(px[(size_t)c * HW] - mx);
+        float dot = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const float v = expf(px[(size_t)c * HW] - mx) / den;
+            dot += gout[base + (size_t)c * HW] * dfent(v) * v;
+        }
+        for (int c = 0; c < C; ++c) {
+            const float v = expf(px[(size_t)c * HW] - mx) / den;
+            grad[base + (size_t)c * HW] = -inv * v * (gout[base + (size_t)c * HW] * dfent(v) - dot);
+        }
+    }
+}
+
+// ---------------- BCE with logits against a constant label, mean reduction ----------------
+__global__ __launch_bounds__(kT) void bce_const_fwd_kernel(const float* __restrict__ x, float label, long long n,
+                                                           float* __restrict__ out) {
+    __shared__ double red[16];
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < n; i += kT) {
+        const float v = x[i];
+        acc += (double)(fmaxf(v, 0.0f) - v * label + log1pf(expf(-fabsf(v))));
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) out[0] = (float)(acc / (double)n);
+}
+__global__ void bce_const_bwd_kernel(const float* __restrict__ x, float label, const float* __restrict__ upstream,
+                                     long long n, float* __restrict__ grad) {
+    const float up = upstream[0] / (float)n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        grad[i] = (sigmoidf_(x[i]) - label) * up;
+}
+
+// y = clamp(sigmoid(x)); x <- sigmoid(x) in place (x.sigmoid_())
+__global__ void sigmoid_clamp_kernel(float* __restrict__ x, float* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float s = sigmoidf_(x[i]);
+        x[i] = s;
+        y[i] = fminf(fmaxf(s, kLo), kHi);
+    }
+}
+// feat [B,ch,HW], ind [B,M] -> out [B,M,ch]
+__global__ void gather_feat_kernel(const float* __restrict__ feat, const long long* __restrict__ ind,
+                                   float* __restrict__ out, int B, int M, int ch, long long HW) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * M * ch; i += gridDim.x * blockDim.x) {
+        const int c = i % ch, bm = i / ch, b = bm / M;
+        out[i] = feat[((size_t)b * ch + c) * HW + ind[bm]];
+    }
+}
+
+constexpr int kLossBlocks = 1024;
+
+}  // namespace
+}  // namespace cnuda
+
+using namespace cnuda;
+
+extern "C" size_t cnuda_loss_workspace_bytes(void) { return (size_t)kLossBlocks * 3 * sizeof(double) + 512; }
+
+static double* ws_ptr(void* ws) { return reinterpret_cast<double*>(((uintptr_t)ws + 255) & ~(uintptr_t)255); }
+
+extern "C" int cnuda_focal_loss_forward(const float* logits, const float* gt, float* prob, float* out2, long long n,
+                                        float weight, void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(logits && gt && prob && out2 && n > 0, "cnuda_focal_loss_forward: bad arguments");
+    CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_loss_workspace_bytes(), "cnuda_focal_loss_forward: workspace");
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = stream_grid(n, kT);
+    if (blocks > kLossBlocks) blocks = kLossBlocks;
+    double* partial = ws_ptr(workspace);
+    hipLaunchKernelGGL(focal_fwd_kernel, dim3(blocks), dim3(kT), 0, st, logits, gt, prob, partial, n);
+    hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(kT), 0, st, partial, blocks, weight, out2);
+    return check_launch("cnuda_focal_loss_forward");
+}
+extern "C" int cnuda_focal_loss_backward(const float* logits, const float* gt, const float* out2,
+                                         const float* upstream, float* grad_logits, long long n, float weight,
+                                         cnuda_stream_t stream) {
+    CNUDA_REQUIRE(logits && gt && out2 && upstream && grad_logits && n > 0, "cnuda_focal_loss_backward: bad arguments");
+    hipLaunchKernelGGL(focal_bwd_kernel, dim3(stream_grid(n, kT)), dim3(kT), 0, (hipStream_t)stream, logits, gt, out2,
+                       upstream, weight, grad_logits, n);
+    return check_launch("cnuda_focal_loss_backward");
+}
+
+extern "C" int cnuda_reg_l1_forward(const float* feat, const uint8_t* mask, const int64_t* ind, float* target,
+                                    float* out2, int B, int M, int ch, long long HW, int periodic, float weight,
+                                    float angle_weight, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(feat && mask && ind && target && out2 && B > 0 && M > 0 && HW > 0, "cnuda_reg_l1_forward: bad arguments");
+    CNUDA_REQUIRE(ch >= 1 && (!periodic || ch == 3), "cnuda_reg_l1_forward: periodic loss needs 3 channels, got %d", ch);
+    hipLaunchKernelGGL(regl1_fwd_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, feat, mask,
+                       (const long long*)ind, target, B, M, ch, (int)HW, periodic ? 1 : 0, weight, angle_weight, out2);
+    return check_launch("cnuda_reg_l1_forward");
+}
+extern "C" int cnuda_reg_l1_backward(const float* feat, const uint8_t* mask, const int64_t* ind, const float* target,
+                                     const float* out2, const float* upstream, float* grad_feat, int B, int M, int ch,
+                                     long long HW, int periodic, float weight, float angle_weight,
+                                     cnuda_stream_t stream) {
+    CNUDA_REQUIRE(feat && mask && ind && target && out2 && upstream && grad_feat && B > 0 && M > 0 && HW > 0,
+                  "cnuda_reg_l1_backward: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(grad_feat, 0, (size_t)B * ch * HW * sizeof(float), st) != hipSuccess)
+        return check_launch("cnuda_reg_l1_backward(memset)");
+    hipLaunchKernelGGL(regl1_bwd_kernel, dim3(stream_grid((long long)B * M * ch, kT)), dim3(kT), 0, st, feat, mask,
+                       (const long long*)ind, target, out2, upstream, B, M, ch, (int)HW, periodic ? 1 : 0, weight,
+                       angle_weight, grad_feat);
+    return check_launch("cnuda_reg_l1_backward");
+}
+
+// kind 0: EntropyLoss  = -sum f(v) / (n*h*w*log2 c);  kind 1: MaxSquareLoss = -mean(v^2)/2
+static double softmax_loss_scale(int kind, int B, int C, long long HW) {
+    if (kind == 0) return -1.0 / ((double)B * (double)HW * (double)log2f((float)C));
+    return -1.0 / (2.0 * (double)B * (double)C * (double)HW);
+}
+extern "C" int cnuda_softmax_loss_forward(const float* logits, float* out1, int B, int C, long long HW, int kind,
+                                          void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(logits && out1 && B > 0 && C > 0 && HW > 0 && (kind == 0 || kind == 1),
+                  "cnuda_softmax_loss_forward: bad arguments");
+    CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_loss_workspace_bytes(), "cnuda_softmax_loss_forward: workspace");
+    hipStream_t st = (hipStream_t)stream;
+    int blocks = stream_grid((long long)B * HW, kT);
+    if (blocks > kLossBlocks) blocks = kLossBlocks;
+    double* partial = ws_ptr(workspace);
+    hipLaunchKernelGGL(softmax_loss_fwd_kernel, dim3(blocks), dim3(kT), 0, st, logits, partial, B, C, HW, kind);
+    hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(kT), 0, st, partial, blocks,
+                       softmax_loss_scale(kind, B, C, HW), out1);
+    return check_launch("cnuda_softmax_loss_forward");
+}
+extern "C" int cnuda_softmax_loss_backward(const float* logits, const float* upstream, float* grad_logits, int B, int C,
+                                           long long HW, int kind, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(logits && upstream && grad_logits && B > 0 && C > 0 && HW > 0 && (kind == 0 || kind == 1),
+                  "cnuda_softmax_loss_backward: bad arguments");
+    hipLaunchKernelGGL(softmax_loss_bwd_kernel, dim3(stream_grid((long long)B * HW, kT)), dim3(kT), 0,
+                       (hipStream_t)stream, logits, upstream, (float)softmax_loss_scale(kind, B, C, HW), grad_logits, B,
+                       C, HW, kind);
+    return check_launch("cnuda_softmax_loss_backward");
+}
+extern "C" int cnuda_entropy_map_forward(const float* logits, float* out, int B, int C, long long HW,
+                                         cnuda_stream_t stream) {
+    CNUDA_REQUIRE(logits && out && B > 0 && C > 0 && HW > 0, "cnuda_entropy_map_forward: bad arguments");
+    hipLaunchKernelGGL(entropy_map_fwd_kernel, dim3(stream_grid((long long)B * HW, kT)), dim3(kT), 0,
+                       (hipStream_t)stream, logits, out, B, C, HW);
+    return check_launch("cnuda_entropy_map_forward");
+}
+extern "C" int cnuda_entropy_map_backward(const float* logits, const float* grad_out, float* grad_logits, int B, int C,
+                                          long long HW, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(logits && grad_out && grad_logits && B > 0 && C > 0 && HW > 0, "cnuda_entropy_map_backward: bad arguments");
+    hipLaunchKernelGGL(entropy_map_bwd_kernel, dim3(stream_grid((long long)B * HW, kT)), dim3(kT), 0,
+                       (hipStream_t)stream, logits, grad_out, grad_logits, B, C, HW);
+    return check_launch("cnuda_entropy_map_backward");
+}
+extern "C" int cnuda_bce_const_forward(const float* logits, float label, float* out1, long long n,
+                                       cnuda_stream_t stream) {
+    CNUDA_REQUIRE(logits && out1 && n > 0, "cnuda_bce_const_forward: bad arguments");
+    hipLaunchKernelGGL(bce_const_fwd_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, logits, label, n, out1);
+    return check_launch("cnuda_bce_const_forward");
+}
+extern "C" int cnuda_bce_const_backward(const float* logits, float label, const float* upstream, float* grad_logits,
+                                        long long n, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(logits && upstream && grad_logits && n > 0, "cnuda_bce_const_backward: bad arguments");
+    hipLaunchKernelGGL(bce_const_bwd_kernel, dim3(stream_grid(n, kT)), dim3(kT), 0, (hipStream_t)stream, logits, label,
+                       upstream, n, grad_logits);
+    return check_launch("cnuda_bce_const_backward");
+}
+extern "C" int cnuda_sigmoid_clamp_(float* x, float* y, long long n, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && y && n > 0, "cnuda_sigmoid_clamp_: bad arguments");
+    hipLaunchKernelGGL(sigmoid_clamp_kernel, dim3(stream_grid(n, kT)), dim3(kT), 0, (hipStream_t)stream, x, y, n);
+    return check_launch("cnuda_sigmoid_clamp_");
+}
+extern "C" int cnuda_gather_feat(const float* feat, const int64_t* ind, float* out, int B, int M, int ch, long long HW,
+                                 cnuda_stream_t stream) {
+    CNUDA_REQUIRE(feat && ind && out && B > 0 && M > 0 && ch > 0 && HW > 0, "cnuda_gather_feat: bad arguments");
+    hipLaunchKernelGGL(gather_feat_kernel, dim3(stream_grid((long long)B * M * ch, kT)), dim3(kT), 0,
+                       (hipStream_t)stream, feat, (const long long*)ind, out, B, M, ch, HW);
+    return check_launch("cnuda_gather_feat");
+}

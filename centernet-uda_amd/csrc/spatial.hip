@@ -1,0 +1,291 @@
+// HBM-bound spatial / elementwise kernels of the DLA-34 graph (NCHW fp32):
+//   max-pool k=s (Tree.downsample, backends/dla.py:202-203), depthwise
+//   ConvTranspose2d k=2f s=f p=f/2 (IDAUp.up, dla.py:385-388), channel
+//   concat / slice (Root, dla.py:162), elementwise add (IDAUp, dla.py:399),
+//   ReLU / LeakyReLU gradients, and the offset|mask split + sigmoid of
+//   DCN.forward (libs/DCNv2/dcn_v2.py:119-122).
+#include "common.h"
+
+namespace cnuda {
+namespace {
+
+constexpr int kT = 256;
+
+// ---- max pool, window k x k, stride k, no padding ---------------------------------
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes, int H, int W,
+                                   int Ho, int Wo, int k) {
+    const long long total = planes * Ho * Wo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho);
+        const long long p = i / ((long long)Wo * Ho);
+        const float* src = x + (size_t)p * H * W + (size_t)(oy * k) * W + ox * k;
+        float m = src[0];
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) {
+                const float v = src[dy * W + dx];
+                if (v > m || v != v) m = v;   // first maximum wins, NaN propagates (ATen's rule)
+            }
+        y[i] = m;
+    }
+}
+// gx is written completely (zeros where not the arg-max); one thread per output cell
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
+                                   long long planes, int H, int W, int Ho, int Wo, int k) {
+    const long long total = planes * Ho * Wo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho);
+        const long long p = i / ((long long)Wo * Ho);
+        const size_t base = (size_t)p * H * W + (size_t)(oy * k) * W + ox * k;
+        float m = x[base];
+        int arg = 0;
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) {
+                const float v = x[base + dy * W + dx];
+                if (v > m || v != v) { m = v; arg = dy * W + dx; }
+            }
+        const float g = gy[i];
+        for (int dy = 0; dy < k; ++dy)
+            for (int dx = 0; dx < k; ++dx) gx[base + dy * W + dx] = (dy * W + dx == arg) ? g : 0.0f;
+    }
+}
+// rows/cols of x not covered by any window (H % k != 0) get zero gradient
+__global__ void maxpool_bwd_tail_kernel(float* __restrict__ gx, long long planes, int H, int W, int Hc, int Wc) {
+    const long long total = planes * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W), yy = (int)((i / W) % H);
+        if (yy >= Hc || xx >= Wc) gx[i] = 0.0f;
+    }
+}
+
+// ---- depthwise transposed conv: k = 2f, stride f, padding f/2 (any k,s,p accepted) ----
+// y[b,c,oy,ox] = sum_{ky,kx} x[b,c,(oy+p-ky)/s,(ox+p-kx)/s] * w[c,ky,kx]   (exact divisions only)
+__global__ void dwconvt_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                   int B, int C, int H, int W, int Ho, int Wo, int k, int s, int p) {
+    const long long total = (long long)B * C * Ho * Wo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho);
+        const long long pl = i / ((long long)Wo * Ho);
+        const int c = (int)(pl % C);
+        const float* xp = x + (size_t)pl * H * W;
+        const float* wp = w + (size_t)c * k * k;
+        float acc = 0.0f;
+        // valid ky: (oy + p - ky) % s == 0  ->  ky = (oy + p) % s + t*s
+        for (int ky = (oy + p) % s; ky < k; ky += s) {
+            const int iy = (oy + p - ky) / s;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = (ox + p) % s; kx < k; kx += s) {
+                const int ix = (ox + p - kx) / s;
+                if (ix < 0 || ix >= W) continue;
+                acc += xp[iy * W + ix] * wp[ky * k + kx];
+            }
+        }
+        y[i] = acc;
+    }
+}
+// gx[b,c,iy,ix] = sum_{ky,kx} gy[b,c,iy*s-p+ky, ix*s-p+kx] * w[c,ky,kx]
+__global__ void dwconvt_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                        float* __restrict__ gx, int B, int C, int H, int W, int Ho, int Wo, int k,
+                                        int s, int p) {
+    const long long total = (long long)B * C * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % W), iy = (int)((i / W) % H);
+        const long long pl = i / ((long long)W * H);
+        const int c = (int)(pl % C);
+        const float* gp = gy + (size_t)pl * Ho * Wo;
+        const float* wp = w + (size_t)c * k * k;
+        float acc = 0.0f;
+        for (int ky = 0; ky < k; ++ky) {
+            const int oy = iy * s - p + ky;
+            if (oy < 0 || oy >= Ho) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ox = ix * s - p + kx;
+                if (ox < 0 || ox >= Wo) continue;
+                acc += gp[oy * Wo + ox] * wp[ky * k + kx];
+            }
+        }
+        gx[i] = acc;
+    }
+}
+// gw[c,ky,kx] = sum_{b,iy,ix} x[b,c,iy,ix] * gy[b,c,iy*s-p+ky, ix*s-p+kx]
+// one workgroup per (c, tap-group); fixed-order block reduction (reproducible)
+__global__ __launch_bounds__(kT) void dwconvt_bwd_weight_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ gy, float* __restrict__ gw,
+                                                                int B, int C, int H, int W, int Ho, int Wo, int k, int s,
+                                                                int p) {
+    __shared__ float red[16];
+    const int c = blockIdx.x, tap = blockIdx.y;
+    const int ky = tap / k, kx = tap - ky * k;
+    float acc = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float* xp = x + ((size_t)b * C + c) * H * W;
+        const float* gp = gy + ((size_t)b * C + c) * Ho * Wo;
+        for (int i = threadIdx.x; i < H * W; i += kT) {
+            const int iy = i / W, ix = i - iy * W;
+            const int oy = iy * s - p + ky, ox = ix * s - p + kx;
+            if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) acc += xp[i] * gp[oy * Wo + ox];
+        }
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) gw[(size_t)c * k * k + tap] = acc;
+}
+
+// ---- elementwise ------------------------------------------------------------
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                           long long n4, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+    for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+// gx = gy * (y > 0 ? 1 : slope)      (ReLU: slope 0; LeakyReLU(0.2): slope 0.2)
+__global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gx,
+                               long long n, float slope) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        gx[i] = y[i] > 0.0f ? gy[i] : gy[i] * slope;
+}
+// copy a [B, Cs, HW] block between tensors with Csrc / Cdst channels at channel offsets
+__global__ void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int Cn,
+                                     long long HW, int Csrc, int src_off, int Cdst, int dst_off) {
+    const long long total = (long long)B * Cn * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long hw = i % HW;
+        const int c = (int)((i / HW) % Cn), b = (int)(i / (HW * Cn));
+        dst[((size_t)b * Cdst + dst_off + c) * HW + hw] = src[((size_t)b * Csrc + src_off + c) * HW + hw];
+    }
+}
+// om [B, 3T, HW] -> offset [B, 2T, HW] (channels 0..2T-1 unchanged) and mask = sigmoid(channels 2T..3T-1)
+__global__ void split_offset_mask_kernel(const float* __restrict__ om, float* __restrict__ offset,
+                                         float* __restrict__ mask, int B, int T, long long HW) {
+    const long long total = (long long)B * 3 * T * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long hw = i % HW;
+        const int c = (int)((i / HW) % (3 * T)), b = (int)(i / (HW * 3 * T));
+        const float v = om[i];
+        if (c < 2 * T)
+            offset[((size_t)b * 2 * T + c) * HW + hw] = v;
+        else
+            mask[((size_t)b * T + (c - 2 * T)) * HW + hw] = 1.0f / (1.0f + expf(-v));
+    }
+}
+__global__ void split_offset_mask_bwd_kernel(const float* __restrict__ goff, const float* __restrict__ gmask,
+                                             const float* __restrict__ mask, float* __restrict__ gom, int B, int T,
+                                             long long HW) {
+    const long long total = (long long)B * 3 * T * HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long hw = i % HW;
+        const int c = (int)((i / HW) % (3 * T)), b = (int)(i / (HW * 3 * T));
+        if (c < 2 * T) {
+            gom[i] = goff[((size_t)b * 2 * T + c) * HW + hw];
+        } else {
+            const size_t j = ((size_t)b * T + (c - 2 * T)) * HW + hw;
+            const float m = mask[j];
+            gom[i] = gmask[j] * m * (1.0f - m);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace cnuda
+
+using namespace cnuda;
+
+extern "C" int cnuda_maxpool2d_forward(const float* x, float* y, int B, int C, int H, int W, int k,
+                                       cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && y && B > 0 && C > 0 && k > 0 && H >= k && W >= k, "cnuda_maxpool2d_forward: bad arguments");
+    const int Ho = H / k, Wo = W / k;
+    const long long planes = (long long)B * C;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_grid(planes * Ho * Wo, kT)), dim3(kT), 0, (hipStream_t)stream, x,
+                       y, planes, H, W, Ho, Wo, k);
+    return check_launch("cnuda_maxpool2d_forward");
+}
+extern "C" int cnuda_maxpool2d_backward(const float* x, const float* grad_y, float* grad_x, int B, int C, int H, int W,
+                                        int k, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && grad_y && grad_x && B > 0 && C > 0 && k > 0 && H >= k && W >= k,
+                  "cnuda_maxpool2d_backward: bad arguments");
+    const int Ho = H / k, Wo = W / k;
+    const long long planes = (long long)B * C;
+    hipStream_t st = (hipStream_t)stream;
+    if (Ho * k != H || Wo * k != W)
+        hipLaunchKernelGGL(maxpool_bwd_tail_kernel, dim3(stream_grid(planes * H * W, kT)), dim3(kT), 0, st, grad_x,
+                           planes, H, W, Ho * k, Wo * k);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid(planes * Ho * Wo, kT)), dim3(kT), 0, st, x, grad_y, grad_x,
+                       planes, H, W, Ho, Wo, k);
+    return check_launch("cnuda_maxpool2d_backward");
+}
+
+extern "C" int cnuda_dwconvt2d_forward(const float* x, const float* w, float* y, int B, int C, int H, int W, int k,
+                                       int s, int p, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && w && y && B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && s > 0 && p >= 0,
+                  "cnuda_dwconvt2d_forward: bad arguments");
+    const int Ho = (H - 1) * s - 2 * p + k, Wo = (W - 1) * s - 2 * p + k;
+    CNUDA_REQUIRE(Ho > 0 && Wo > 0, "cnuda_dwconvt2d_forward: empty output");
+    hipLaunchKernelGGL(dwconvt_fwd_kernel, dim3(stream_grid((long long)B * C * Ho * Wo, kT)), dim3(kT), 0,
+                       (hipStream_t)stream, x, w, y, B, C, H, W, Ho, Wo, k, s, p);
+    return check_launch("cnuda_dwconvt2d_forward");
+}
+extern "C" int cnuda_dwconvt2d_backward(const float* x, const float* w, const float* grad_y, float* grad_x,
+                                        float* grad_w, int B, int C, int H, int W, int k, int s, int p,
+                                        cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && w && grad_y && B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && s > 0 && p >= 0,
+                  "cnuda_dwconvt2d_backward: bad arguments");
+    const int Ho = (H - 1) * s - 2 * p + k, Wo = (W - 1) * s - 2 * p + k;
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_x)
+        hipLaunchKernelGGL(dwconvt_bwd_data_kernel, dim3(stream_grid((long long)B * C * H * W, kT)), dim3(kT), 0, st,
+                           grad_y, w, grad_x, B, C, H, W, Ho, Wo, k, s, p);
+    if (grad_w)
+        hipLaunchKernelGGL(dwconvt_bwd_weight_kernel, dim3(C, k * k), dim3(kT), 0, st, x, grad_y, grad_w, B, C, H, W, Ho,
+                           Wo, k, s, p);
+    return check_launch("cnuda_dwconvt2d_backward");
+}
+
+extern "C" int cnuda_add(const float* a, const float* b, float* out, long long n, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(a && b && out && n > 0, "cnuda_add: bad arguments");
+    const bool aligned = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0;
+    const long long n4 = aligned ? n / 4 : 0;
+    hipLaunchKernelGGL(add_kernel, dim3(stream_grid(n4 > 0 ? n4 : n, kT)), dim3(kT), 0, (hipStream_t)stream, a, b, out,
+                       n4, n);
+    return check_launch("cnuda_add");
+}
+extern "C" int cnuda_act_backward(const float* grad_y, const float* y, float* grad_x, long long n, float slope,
+                                  cnuda_stream_t stream) {
+    CNUDA_REQUIRE(grad_y && y && grad_x && n > 0, "cnuda_act_backward: bad arguments");
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(n, kT)), dim3(kT), 0, (hipStream_t)stream, grad_y, y, grad_x, n,
+                       slope);
+    return check_launch("cnuda_act_backward");
+}
+extern "C" int cnuda_copy_channels(const float* src, float* dst, int B, int Cn, long long HW, int Csrc, int src_off,
+                                   int Cdst, int dst_off, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(src && dst && B > 0 && Cn > 0 && HW > 0, "cnuda_copy_channels: bad arguments");
+    CNUDA_REQUIRE(src_off >= 0 && dst_off >= 0 && src_off + Cn <= Csrc && dst_off + Cn <= Cdst,
+                  "cnuda_copy_channels: channel range out of bounds");
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(stream_grid((long long)B * Cn * HW, kT)), dim3(kT), 0,
+                       (hipStream_t)stream, src, dst, B, Cn, HW, Csrc, src_off, Cdst, dst_off);
+    return check_launch("cnuda_copy_channels");
+}
+extern "C" int cnuda_split_offset_mask(const float* om, float* offset, float* mask, int B, int taps, long long HW,
+                                       cnuda_stream_t stream) {
+    CNUDA_REQUIRE(om && offset && mask && B > 0 && taps > 0 && HW > 0, "cnuda_split_offset_mask: bad arguments");
+    hipLaunchKernelGGL(split_offset_mask_kernel, dim3(stream_grid((long long)B * 3 * taps * HW, kT)), dim3(kT), 0,
+                       (hipStream_t)stream, om, offset, mask, B, taps, HW);
+    return check_launch("cnuda_split_offset_mask");
+}
+extern "C" int cnuda_split_offset_mask_backward(const float* grad_offset, const float* grad_mask, const float* mask,
+                                                float* grad_om, int B, int taps, long long HW, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(grad_offset && grad_mask && mask && grad_om && B > 0 && taps > 0 && HW > 0,
+                  "cnuda_split_offset_mask_backward: bad arguments");
+    hipLaunchKernelGGL(split_offset_mask_bwd_kernel, dim3(stream_grid((long long)B * 3 * taps * HW, kT)), dim3(kT), 0,
+                       (hipStream_t)stream, grad_offset, grad_mask, mask, grad_om, B, taps, HW);
+    return check_launch("cnuda_split_offset_mask_backward");
+}

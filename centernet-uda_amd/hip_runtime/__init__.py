@@ -52,14 +52,50 @@ _I = c_int
 _P = c_void_p
 
 
+_LL = ctypes.c_longlong
+_F = c_float
+_WS = [_P, c_size_t, _P]          # workspace, workspace_bytes, stream
+
+
 class _Sig:
     """restype, argtypes for every exported symbol (mirrors include/centernet_uda_hip.h)."""
     cnuda_decode_workspace_bytes = (c_size_t, [_I] * 5)
-    cnuda_decode_detection = (_I, [_P] * 5 + [_I] * 8 + [_P, c_size_t, _P])
+    cnuda_decode_detection = (_I, [_P] * 5 + [_I] * 8 + _WS)
     cnuda_nms = (_I, [_P, _P] + [_I] * 5 + [_P])
     cnuda_dcn_v2_workspace_bytes = (c_size_t, [_I] * 14)
-    cnuda_dcn_v2_forward = (_I, [_P] * 6 + [_I] * 14 + [_P, c_size_t, _P])
-    cnuda_dcn_v2_backward = (_I, [_P] * 11 + [_I] * 14 + [_P, c_size_t, _P])
+    cnuda_dcn_v2_forward = (_I, [_P] * 6 + [_I] * 14 + _WS)
+    cnuda_dcn_v2_backward = (_I, [_P] * 11 + [_I] * 14 + _WS)
+    cnuda_conv2d_workspace_bytes = (c_size_t, [_I] * 11)
+    cnuda_conv2d_forward = (_I, [_P] * 4 + [_I] * 11 + [_F] + _WS)
+    cnuda_conv2d_backward_data = (_I, [_P] * 3 + [_I] * 11 + _WS)
+    cnuda_conv2d_backward_weight = (_I, [_P] * 4 + [_I] * 11 + _WS)
+    cnuda_bn_workspace_bytes = (c_size_t, [_I, _I, _LL])
+    cnuda_bn_train_forward = (_I, [_P] * 9 + [_F, _F, _I, _I, _I, _LL] + _WS)
+    cnuda_bn_eval_forward = (_I, [_P] * 7 + [_F, _I, _I, _I, _LL, _P])
+    cnuda_bn_backward = (_I, [_P] * 10 + [_I, _I, _I, _LL] + _WS)
+    cnuda_maxpool2d_forward = (_I, [_P] * 2 + [_I] * 5 + [_P])
+    cnuda_maxpool2d_backward = (_I, [_P] * 3 + [_I] * 5 + [_P])
+    cnuda_dwconvt2d_forward = (_I, [_P] * 3 + [_I] * 7 + [_P])
+    cnuda_dwconvt2d_backward = (_I, [_P] * 5 + [_I] * 7 + [_P])
+    cnuda_add = (_I, [_P] * 3 + [_LL, _P])
+    cnuda_act_backward = (_I, [_P] * 3 + [_LL, _F, _P])
+    cnuda_copy_channels = (_I, [_P, _P, _I, _I, _LL, _I, _I, _I, _I, _P])
+    cnuda_split_offset_mask = (_I, [_P] * 3 + [_I, _I, _LL, _P])
+    cnuda_split_offset_mask_backward = (_I, [_P] * 4 + [_I, _I, _LL, _P])
+    cnuda_loss_workspace_bytes = (c_size_t, [])
+    cnuda_focal_loss_forward = (_I, [_P] * 4 + [_LL, _F] + _WS)
+    cnuda_focal_loss_backward = (_I, [_P] * 5 + [_LL, _F, _P])
+    cnuda_reg_l1_forward = (_I, [_P] * 5 + [_I, _I, _I, _LL, _I, _F, _F, _P])
+    cnuda_reg_l1_backward = (_I, [_P] * 7 + [_I, _I, _I, _LL, _I, _F, _F, _P])
+    cnuda_softmax_loss_forward = (_I, [_P, _P, _I, _I, _LL, _I] + _WS)
+    cnuda_softmax_loss_backward = (_I, [_P] * 3 + [_I, _I, _LL, _I, _P])
+    cnuda_entropy_map_forward = (_I, [_P, _P, _I, _I, _LL, _P])
+    cnuda_entropy_map_backward = (_I, [_P] * 3 + [_I, _I, _LL, _P])
+    cnuda_bce_const_forward = (_I, [_P, _F, _P, _LL, _P])
+    cnuda_bce_const_backward = (_I, [_P, _F, _P, _P, _LL, _P])
+    cnuda_sigmoid_clamp_ = (_I, [_P, _P, _LL, _P])
+    cnuda_gather_feat = (_I, [_P] * 3 + [_I, _I, _I, _LL, _P])
+    cnuda_adam_step = (_I, [_P] * 4 + [_LL] + [_F] * 5 + [_I, _P])
 
 
 def check(rc, what=''):

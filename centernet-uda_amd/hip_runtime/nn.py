@@ -1,0 +1,96 @@
+"""nn.Module wrappers over hip_runtime.ops with the parameter / buffer names of
+their torch.nn counterparts, so state_dicts stay interchangeable with the
+reference's checkpoints (utils/helper.py:95-117)."""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+class Conv2d(nn.Module):
+    """Dense convolution on the implicit-GEMM MFMA kernels; optional fused
+    bias + ReLU / LeakyReLU epilogue (`act_slope`: <0 none, 0 ReLU, 0.2 leaky)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, act_slope=-1.0):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _pair(kernel_size), _pair(stride), _pair(padding)
+        self.act_slope = float(act_slope)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # nn.Conv2d's default: kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in)) for both tensors
+        fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+        bound = 1.0 / math.sqrt(fan_in)
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.uniform_(-bound, bound)
+
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.act_slope)
+
+    def extra_repr(self):
+        return '%d, %d, kernel_size=%s, stride=%s, padding=%s, bias=%s, act_slope=%g' % (
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding,
+            self.bias is not None, self.act_slope)
+
+
+class BatchNorm2d(nn.Module):
+    """BatchNorm2d whose forward can absorb the residual add and ReLU that follow it."""
+
+    def __init__(self, num_features, momentum=0.1, eps=1e-5):
+        super().__init__()
+        self.num_features, self.momentum, self.eps = num_features, momentum, eps
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, residual=None, relu=False):
+        if x.shape[1] != self.num_features:
+            raise RuntimeError("BatchNorm2d: expected %d channels, got %d" % (self.num_features, x.shape[1]))
+        if self.training:
+            self.num_batches_tracked += 1
+        return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                  self.momentum, self.eps, residual, relu)
+
+
+class MaxPool2d(nn.Module):
+    def __init__(self, kernel_size):
+        super().__init__()
+        self.kernel_size = int(kernel_size)
+
+    def forward(self, x):
+        return ops.max_pool2d(x, self.kernel_size)
+
+
+class DepthwiseConvTranspose2d(nn.Module):
+    """nn.ConvTranspose2d(C, C, k, stride, padding, groups=C, bias=False); weight [C,1,k,k]."""
+
+    def __init__(self, channels, kernel_size, stride, padding):
+        super().__init__()
+        self.channels, self.kernel_size, self.stride, self.padding = channels, kernel_size, stride, padding
+        self.weight = nn.Parameter(torch.empty(channels, 1, kernel_size, kernel_size))
+        with torch.no_grad():
+            self.weight.uniform_(-1.0 / kernel_size, 1.0 / kernel_size)
+
+    def forward(self, x):
+        return ops.depthwise_conv_transpose2d(x, self.weight, self.stride, self.padding)
+
+
+class Slot(nn.Module):
+    """Parameter-free placeholder that keeps Sequential indices aligned with the
+    reference's module lists (e.g. the ReLU at index 1 of a head, dla.py:476-483)."""
+
+    def forward(self, x):
+        return x

@@ -1,0 +1,493 @@
+"""torch.autograd plumbing around the C ABI.  Every op here launches hand-written
+gfx950 kernels from libcenternet_uda_hip.so on torch's current HIP stream;
+torch contributes tensors (device memory), the autograd tape and nothing else.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import check, f32c, lib, ptr, require_gpu, stream, workspace
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+def _ws(nbytes, like):
+    w = workspace(nbytes, like.device)
+    return ptr(w), w.numel()
+
+
+# ---------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------
+def _conv_geom(x, weight, stride, padding):
+    B, C, H, W = x.shape
+    Co, Ck, kh, kw = weight.shape
+    if Ck != C:
+        raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (C, Ck))
+    (sh, sw), (ph, pw) = _pair(stride), _pair(padding)
+    return (B, C, H, W, Co, kh, kw, sh, sw, ph, pw)
+
+
+class _Conv2d(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, act_slope):
+        require_gpu(x, weight, bias)
+        x, weight = f32c(x), f32c(weight)
+        bias = None if bias is None else f32c(bias)
+        g = _conv_geom(x, weight, stride, padding)
+        B, C, H, W, Co, kh, kw, sh, sw, ph, pw = g
+        Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+        y = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+        L = lib()
+        wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g), x)
+        check(L.cnuda_conv2d_forward(ptr(x), ptr(weight), ptr(bias), ptr(y), *g, float(act_slope),
+                                     wp, wn, stream()), 'conv2d_forward')
+        ctx.geom, ctx.act_slope, ctx.has_bias = g, act_slope, bias is not None
+        ctx.save_for_backward(x, weight, y if act_slope >= 0 else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        g = ctx.geom
+        L = lib()
+        gy = f32c(gy)
+        if ctx.act_slope >= 0:
+            t = torch.empty_like(gy)
+            check(L.cnuda_act_backward(ptr(gy), ptr(y), ptr(t), gy.numel(), float(ctx.act_slope), stream()))
+            gy = t
+        wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g), x)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            check(L.cnuda_conv2d_backward_data(ptr(gy), ptr(weight), ptr(gx), *g, wp, wn, stream()),
+                  'conv2d_backward_data')
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw = torch.empty_like(weight)
+            if ctx.has_bias:
+                gb = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device)
+            check(L.cnuda_conv2d_backward_weight(ptr(x), ptr(gy), ptr(gw), ptr(gb), *g, wp, wn, stream()),
+                  'conv2d_backward_weight')
+        return gx, gw, gb, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0):
+    """y = act(conv2d(x, weight) + bias); act_slope < 0 none, 0 ReLU, 0.2 LeakyReLU(0.2)."""
+    return _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope))
+
+
+# ---------------------------------------------------------------------------
+# batch norm (+ residual add + ReLU)
+# ---------------------------------------------------------------------------
+class _BatchNormAct(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu):
+        require_gpu(x, gamma, beta, residual)
+        x = f32c(x)
+        residual = None if residual is None else f32c(residual)
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        L = lib()
+        wp, wn = _ws(L.cnuda_bn_workspace_bytes(B, C, HW), x)
+        check(L.cnuda_bn_train_forward(ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(mean), ptr(invstd),
+                                       ptr(running_mean), ptr(running_var), float(momentum), float(eps),
+                                       1 if relu else 0, B, C, HW, wp, wn, stream()), 'bn_train_forward')
+        ctx.relu, ctx.dims, ctx.has_res = relu, (B, C, HW), residual is not None
+        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        B, C, HW = ctx.dims
+        gy = f32c(gy)
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if ctx.has_res else None
+        gg = torch.empty_like(gamma)
+        gb = torch.empty_like(gamma)
+        L = lib()
+        wp, wn = _ws(L.cnuda_bn_workspace_bytes(B, C, HW), x)
+        check(L.cnuda_bn_backward(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), ptr(gx), ptr(gres),
+                                  ptr(gg), ptr(gb), 1 if ctx.relu else 0, B, C, HW, wp, wn, stream()), 'bn_backward')
+        return gx, gg, gb, gres, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
+                   residual=None, relu=False):
+    if training:
+        return _BatchNormAct.apply(x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu)
+    if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad):
+        raise RuntimeError("batch_norm_act: eval-mode BN has no backward in this build "
+                           "(the reference evaluates under torch.no_grad(), train.py:172)")
+    require_gpu(x, gamma, beta, residual)
+    x = f32c(x)
+    residual = None if residual is None else f32c(residual)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    check(lib().cnuda_bn_eval_forward(ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                      ptr(residual), ptr(y), float(eps), 1 if relu else 0, B, C, HW, stream()),
+          'bn_eval_forward')
+    return y
+
+
+# ---------------------------------------------------------------------------
+# spatial
+# ---------------------------------------------------------------------------
+class _MaxPool(Function):
+    @staticmethod
+    def forward(ctx, x, k):
+        require_gpu(x)
+        x = f32c(x)
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, H // k, W // k), dtype=torch.float32, device=x.device)
+        check(lib().cnuda_maxpool2d_forward(ptr(x), ptr(y), B, C, H, W, k, stream()), 'maxpool2d_forward')
+        ctx.k = k
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        check(lib().cnuda_maxpool2d_backward(ptr(x), ptr(f32c(gy)), ptr(gx), B, C, H, W, ctx.k, stream()),
+              'maxpool2d_backward')
+        return gx, None
+
+
+def max_pool2d(x, k):
+    return _MaxPool.apply(x, int(k))
+
+
+class _DwConvT(Function):
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        require_gpu(x, weight)
+        x, weight = f32c(x), f32c(weight)
+        B, C, H, W = x.shape
+        k = weight.shape[2]
+        if weight.shape[0] != C or weight.shape[1] != 1 or weight.shape[3] != k:
+            raise RuntimeError("depthwise conv_transpose2d: weight %s does not fit %d channels"
+                               % (tuple(weight.shape), C))
+        Ho, Wo = (H - 1) * stride - 2 * padding + k, (W - 1) * stride - 2 * padding + k
+        y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        check(lib().cnuda_dwconvt2d_forward(ptr(x), ptr(weight), ptr(y), B, C, H, W, k, stride, padding, stream()),
+              'dwconvt2d_forward')
+        ctx.geom = (B, C, H, W, k, stride, padding)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        check(lib().cnuda_dwconvt2d_backward(ptr(x), ptr(weight), ptr(f32c(gy)), ptr(gx), ptr(gw), *ctx.geom,
+                                             stream()), 'dwconvt2d_backward')
+        return gx, gw, None, None
+
+
+def depthwise_conv_transpose2d(x, weight, stride, padding):
+    return _DwConvT.apply(x, weight, int(stride), int(padding))
+
+
+class _Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        require_gpu(a, b)
+        if a.shape != b.shape:
+            raise RuntimeError("add: shapes %s and %s differ" % (tuple(a.shape), tuple(b.shape)))
+        a, b = f32c(a), f32c(b)
+        out = torch.empty_like(a)
+        check(lib().cnuda_add(ptr(a), ptr(b), ptr(out), a.numel(), stream()), 'add')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _Cat(Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        require_gpu(*xs)
+        xs = [f32c(t) for t in xs]
+        B, _, H, W = xs[0].shape
+        chans = [t.shape[1] for t in xs]
+        out = torch.empty((B, sum(chans), H, W), dtype=torch.float32, device=xs[0].device)
+        off, L = 0, lib()
+        for t, c in zip(xs, chans):
+            if t.shape[0] != B or t.shape[2] != H or t.shape[3] != W:
+                raise RuntimeError("cat: mismatching shapes")
+            check(L.cnuda_copy_channels(ptr(t), ptr(out), B, c, H * W, c, 0, sum(chans), off, stream()), 'cat')
+            off += c
+        ctx.chans = chans
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        g = f32c(g)
+        B, Ct, H, W = g.shape
+        outs, off, L = [], 0, lib()
+        for i, c in enumerate(ctx.chans):
+            if ctx.needs_input_grad[i]:
+                t = torch.empty((B, c, H, W), dtype=torch.float32, device=g.device)
+                check(L.cnuda_copy_channels(ptr(g), ptr(t), B, c, H * W, Ct, off, c, 0, stream()), 'cat_backward')
+                outs.append(t)
+            else:
+                outs.append(None)
+            off += c
+        return tuple(outs)
+
+
+def cat_channels(xs):
+    return _Cat.apply(*xs)
+
+
+class _SplitOffsetMask(Function):
+    @staticmethod
+    def forward(ctx, om):
+        require_gpu(om)
+        om = f32c(om)
+        B, C3, H, W = om.shape
+        if C3 % 3:
+            raise RuntimeError("conv_offset_mask output must have 3*taps channels, got %d" % C3)
+        T = C3 // 3
+        offset = torch.empty((B, 2 * T, H, W), dtype=torch.float32, device=om.device)
+        mask = torch.empty((B, T, H, W), dtype=torch.float32, device=om.device)
+        check(lib().cnuda_split_offset_mask(ptr(om), ptr(offset), ptr(mask), B, T, H * W, stream()),
+              'split_offset_mask')
+        ctx.save_for_backward(mask)
+        return offset, mask
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, goff, gmask):
+        (mask,) = ctx.saved_tensors
+        B, T, H, W = mask.shape
+        gom = torch.empty((B, 3 * T, H, W), dtype=torch.float32, device=mask.device)
+        check(lib().cnuda_split_offset_mask_backward(ptr(f32c(goff)), ptr(f32c(gmask)), ptr(mask), ptr(gom), B, T,
+                                                     H * W, stream()), 'split_offset_mask_backward')
+        return gom
+
+
+def split_offset_mask(om):
+    return _SplitOffsetMask.apply(om)
+
+
+# ---------------------------------------------------------------------------
+# losses
+# ---------------------------------------------------------------------------
+def _loss_ws(like):
+    return _ws(lib().cnuda_loss_workspace_bytes(), like)
+
+
+class _Focal(Function):
+    """(loss, prob) = focal(clamp(sigmoid(logits)), gt)."""
+
+    @staticmethod
+    def forward(ctx, logits, gt, weight):
+        require_gpu(logits, gt)
+        logits, gt = f32c(logits), f32c(gt)
+        if logits.shape != gt.shape:
+            raise RuntimeError("focal loss: prediction %s vs target %s" % (tuple(logits.shape), tuple(gt.shape)))
+        prob = torch.empty_like(logits)
+        out2 = torch.empty(2, dtype=torch.float32, device=logits.device)
+        wp, wn = _loss_ws(logits)
+        check(lib().cnuda_focal_loss_forward(ptr(logits), ptr(gt), ptr(prob), ptr(out2), logits.numel(),
+                                             float(weight), wp, wn, stream()), 'focal_loss_forward')
+        ctx.weight = weight
+        ctx.save_for_backward(logits, gt, out2)
+        ctx.mark_non_differentiable(prob)
+        return out2[0].clone(), prob
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss, _gprob):
+        logits, gt, out2 = ctx.saved_tensors
+        grad = torch.empty_like(logits)
+        up = f32c(gloss.reshape(1))
+        check(lib().cnuda_focal_loss_backward(ptr(logits), ptr(gt), ptr(out2), ptr(up), ptr(grad), logits.numel(),
+                                              float(ctx.weight), stream()), 'focal_loss_backward')
+        return grad, None, None
+
+
+def focal_loss(logits, gt, weight=1.0):
+    return _Focal.apply(logits, gt, weight)
+
+
+class _RegL1(Function):
+    @staticmethod
+    def forward(ctx, feat, mask, ind, target, periodic, weight, angle_weight):
+        require_gpu(feat, mask, ind, target)
+        feat = f32c(feat)
+        if mask.dtype != torch.uint8 or ind.dtype != torch.int64 or target.dtype != torch.float32:
+            raise RuntimeError("reg_l1: expected reg_mask uint8, ind int64, target float32 "
+                               "(datasets/coco.py:168-174), got %s/%s/%s" % (mask.dtype, ind.dtype, target.dtype))
+        if not (mask.is_contiguous() and ind.is_contiguous() and target.is_contiguous()):
+            raise RuntimeError("reg_l1: batch tensors must be contiguous (target is updated in place)")
+        B, ch, H, W = feat.shape
+        M = ind.shape[1]
+        out2 = torch.empty(2, dtype=torch.float32, device=feat.device)
+        check(lib().cnuda_reg_l1_forward(ptr(feat), ptr(mask), ptr(ind), ptr(target), ptr(out2), B, M, ch, H * W,
+                                         1 if periodic else 0, float(weight), float(angle_weight), stream()),
+              'reg_l1_forward')
+        ctx.args = (B, M, ch, H * W, 1 if periodic else 0, float(weight), float(angle_weight))
+        ctx.save_for_backward(feat, mask, ind, target, out2)
+        return out2[0].clone()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss):
+        feat, mask, ind, target, out2 = ctx.saved_tensors
+        grad = torch.empty_like(feat)
+        up = f32c(gloss.reshape(1))
+        check(lib().cnuda_reg_l1_backward(ptr(feat), ptr(mask), ptr(ind), ptr(target), ptr(out2), ptr(up), ptr(grad),
+                                          *ctx.args, stream()), 'reg_l1_backward')
+        return grad, None, None, None, None, None, None
+
+
+def reg_l1_loss(feat, mask, ind, target, periodic=False, weight=1.0, angle_weight=1.0):
+    # `target` is a plain batch tensor (never requires grad); it is masked in place (Q2).
+    return _RegL1.apply(feat, mask, ind, target, periodic, weight, angle_weight)
+
+
+class _SoftmaxLoss(Function):
+    @staticmethod
+    def forward(ctx, logits, kind):
+        require_gpu(logits)
+        logits = f32c(logits)
+        B, C = logits.shape[0], logits.shape[1]
+        HW = logits.numel() // (B * C)
+        out = torch.empty(1, dtype=torch.float32, device=logits.device)
+        wp, wn = _loss_ws(logits)
+        check(lib().cnuda_softmax_loss_forward(ptr(logits), ptr(out), B, C, HW, kind, wp, wn, stream()),
+              'softmax_loss_forward')
+        ctx.args = (B, C, HW, kind)
+        ctx.save_for_backward(logits)
+        return out[0].clone()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss):
+        (logits,) = ctx.saved_tensors
+        grad = torch.empty_like(logits)
+        up = f32c(gloss.reshape(1))
+        check(lib().cnuda_softmax_loss_backward(ptr(logits), ptr(up), ptr(grad), *ctx.args, stream()),
+              'softmax_loss_backward')
+        return grad, None
+
+
+def entropy_loss(hm_logits):
+    return _SoftmaxLoss.apply(hm_logits, 0)
+
+
+def max_square_loss(hm_logits):
+    return _SoftmaxLoss.apply(hm_logits, 1)
+
+
+class _EntropyMap(Function):
+    @staticmethod
+    def forward(ctx, logits):
+        require_gpu(logits)
+        logits = f32c(logits)
+        B, C = logits.shape[0], logits.shape[1]
+        HW = logits.numel() // (B * C)
+        out = torch.empty_like(logits)
+        check(lib().cnuda_entropy_map_forward(ptr(logits), ptr(out), B, C, HW, stream()), 'entropy_map_forward')
+        ctx.args = (B, C, HW)
+        ctx.save_for_backward(logits)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (logits,) = ctx.saved_tensors
+        grad = torch.empty_like(logits)
+        check(lib().cnuda_entropy_map_backward(ptr(logits), ptr(f32c(g)), ptr(grad), *ctx.args, stream()),
+              'entropy_map_backward')
+        return grad
+
+
+def entropy_map(hm):
+    return _EntropyMap.apply(hm)
+
+
+class _BceConst(Function):
+    @staticmethod
+    def forward(ctx, logits, label):
+        require_gpu(logits)
+        logits = f32c(logits)
+        out = torch.empty(1, dtype=torch.float32, device=logits.device)
+        check(lib().cnuda_bce_const_forward(ptr(logits), float(label), ptr(out), logits.numel(), stream()),
+              'bce_const_forward')
+        ctx.label = float(label)
+        ctx.save_for_backward(logits)
+        return out[0].clone()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss):
+        (logits,) = ctx.saved_tensors
+        grad = torch.empty_like(logits)
+        up = f32c(gloss.reshape(1))
+        check(lib().cnuda_bce_const_backward(ptr(logits), ctx.label, ptr(up), ptr(grad), logits.numel(), stream()),
+              'bce_const_backward')
+        return grad, None
+
+
+def bce_with_logits_const(logits, label):
+    return _BceConst.apply(logits, label)
+
+
+# ---------------------------------------------------------------------------
+# small helpers without gradients
+# ---------------------------------------------------------------------------
+def sigmoid_clamp_(x):
+    """x <- sigmoid(x) in place; returns clamp(x, 1e-4, 1-1e-4) (utils/tensor.py:5-7)."""
+    require_gpu(x)
+    if x.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("sigmoid_clamp_ is an in-place, gradient-free helper; "
+                           "training code goes through focal_loss / reg_l1_loss")
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise RuntimeError("sigmoid_clamp_: expected a contiguous float32 tensor")
+    y = torch.empty_like(x)
+    check(lib().cnuda_sigmoid_clamp_(ptr(x), ptr(y), x.numel(), stream()), 'sigmoid_clamp_')
+    return y
+
+
+def gather_feat(feat, ind):
+    """feat [B,ch,H,W], ind [B,M] int64 -> [B,M,ch] (no gradient; the losses gather internally)."""
+    require_gpu(feat, ind)
+    feat = f32c(feat.detach())
+    B, ch, H, W = feat.shape
+    M = ind.shape[1]
+    out = torch.empty((B, M, ch), dtype=torch.float32, device=feat.device)
+    check(lib().cnuda_gather_feat(ptr(feat), ptr(ind.contiguous()), ptr(out), B, M, ch, H * W, stream()),
+          'gather_feat')
+    return out
+
+
+def adam_step_(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+    require_gpu(param, grad, exp_avg, exp_avg_sq)
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if not t.is_contiguous() or t.dtype != torch.float32 or t.numel() != param.numel():
+            raise RuntimeError("adam_step_: flat contiguous float32 tensors of equal length required")
+    check(lib().cnuda_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr),
+                                float(beta1), float(beta2), float(eps), float(weight_decay), int(step), stream()),
+          'adam_step')

@@ -1,0 +1,110 @@
+"""Data parallelism for MI355X: one process per GPU, gradients of the flat arena
+all-reduced by RCCL over xGMI in a few large buckets, launched from
+gradient-ready hooks so that they overlap the remaining backward kernels.
+
+Replaces the reference's single-process `CustomDataParallel(nn.DataParallel)`
+(utils/helper.py:75-80; scatter / replicate / gather / ReduceAddCoalesced
+through device 0).  Semantics: each rank owns its own per-GPU batch and its own
+BatchNorm statistics (as DataParallel's replicas do); gradients are averaged
+over ranks (sum / world_size), i.e. the loss normalisers (`num_pos`,
+`mask.sum()`) are per-rank rather than over the gathered global batch --
+DESIGN.md discusses the difference.
+
+Two (or more) backward() calls per step accumulate locally under `no_sync()`;
+buckets fire during the last backward; `finish_gradient_sync()` launches any
+bucket that did not become ready (parameters without a gradient) and makes the
+compute stream wait for the collectives.
+"""
+import contextlib
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .arena import arena_for
+
+BUCKET_BYTES = 24 << 20      # xGMI links are point-to-point: few, large messages
+
+
+class DataParallel(nn.Module):
+    def __init__(self, module, process_group=None, bucket_bytes=BUCKET_BYTES):
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self._sync = True
+        self._works = []
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.arena = arena_for(params)
+        self.arena.on_ready = self._param_ready
+        # buckets in reverse parameter order (~ the order gradients become ready)
+        self.buckets, cur_end, cur_start = [], self.arena.numel, self.arena.numel
+        limit = max(1, bucket_bytes // 4)
+        self.bucket_of = [0] * len(params)
+        for i in range(len(params) - 1, -1, -1):
+            cur_start = self.arena.offsets[i]
+            self.bucket_of[i] = len(self.buckets)
+            if cur_end - cur_start >= limit or i == 0:
+                self.buckets.append([cur_start, cur_end, 0, False])     # start, end, n_params, launched
+                cur_end = cur_start
+        for b in self.bucket_of:
+            self.buckets[b][2] += 1
+        self._pending = [b[2] for b in self.buckets]
+        if self.world_size > 1:
+            # replicas start identical (DataParallel broadcasts parameters and buffers every forward)
+            dist.broadcast(self.arena.flat_param, src=0, group=self.process_group)
+            for buf in module.buffers():
+                dist.broadcast(buf, src=0, group=self.process_group)
+
+    @property
+    def world_size(self):
+        return dist.get_world_size(self.process_group) if dist.is_available() and dist.is_initialized() else 1
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(self.module, name)       # .down_ratio, .rotated_boxes, ... like CustomDataParallel
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        prev, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = prev
+
+    # -- bucket machinery ----------------------------------------------------------
+    def _reset(self):
+        self._pending = [b[2] for b in self.buckets]
+        for b in self.buckets:
+            b[3] = False
+
+    def _launch(self, k):
+        b = self.buckets[k]
+        if b[3]:
+            return
+        b[3] = True
+        if self.world_size > 1:
+            chunk = self.arena.flat_grad[b[0]:b[1]]
+            self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
+
+    def _param_ready(self, i):
+        if not self._sync:
+            return
+        k = self.bucket_of[i]
+        self._pending[k] -= 1
+        if self._pending[k] == 0:
+            self._launch(k)
+
+    def finish_gradient_sync(self):
+        for k in range(len(self.buckets)):
+            self._launch(k)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.world_size > 1:
+            self.arena.flat_grad.mul_(1.0 / self.world_size)
+        self._reset()

@@ -1,0 +1,133 @@
+"""Baseline (no-UDA) training/eval step plugin -- the reference's `uda.base.Model`
+(uda/base.py:10-157) on the MI355X kernels.
+
+The driver injects `cfg, device, backend, optimizer, centernet_loss, scheduler`
+(train.py:108-116) and calls `init_done, load_model, to, epoch_start, set_phase,
+step, get_detections, epoch_end, save_model`.  Multi-GPU: the reference wraps the
+backend in a single-process nn.DataParallel (utils/helper.py:75-80); here
+`to(device, parallel=True)` wraps it in hip_runtime.parallel.DataParallel -- one
+process per GPU, bucketed RCCL all-reduce of a flat gradient arena overlapped
+with the rest of backward.
+"""
+import contextlib
+import logging
+
+import numpy as np
+import torch
+
+from backends.decode import decode_detection
+from utils.helper import load_model, save_model
+
+log = logging.getLogger(__name__)
+
+
+class Model:
+    def __init__(self):
+        self.cfg = None
+        self.backend = None
+        self.optimizer = None
+        self.centernet_loss = None
+        self.device = None
+        self.scheduler = None
+
+    # -- lifecycle hooks -------------------------------------------------------
+    def init_done(self):
+        pass
+
+    def epoch_start(self):
+        pass
+
+    def epoch_end(self):
+        if self.scheduler is not None:
+            self.scheduler.step()
+
+    def set_phase(self, is_training=True):
+        self.backend.train(is_training)
+
+    def to(self, device, parallel=False):
+        self.backend.to(device)
+        if parallel:
+            from hip_runtime.parallel import DataParallel
+            self.backend = DataParallel(self.backend)
+
+    # -- helpers shared by the subclasses --------------------------------------------
+    def _to_device(self, data):
+        for k in data:
+            data[k] = data[k].to(device=self.device, non_blocking=True)
+
+    def _defer_sync(self, module=None):
+        """Context for every backward() of a step but the last: gradients only
+        accumulate locally; the all-reduce buckets fire during the last one."""
+        module = self.backend if module is None else module
+        return module.no_sync() if hasattr(module, 'no_sync') else contextlib.nullcontext()
+
+    def _finish_backward(self, *modules):
+        for m in (modules or (self.backend,)):
+            if hasattr(m, 'finish_gradient_sync'):
+                m.finish_gradient_sync()
+
+    @staticmethod
+    def _detach_stats(stats):
+        # one device->host sync per step, where the reference has it (uda/base.py:51-52)
+        return {k: v.cpu().detach() for k, v in stats.items()}
+
+    # -- the step ----------------------------------------------------------------
+    def criterion(self, outputs, batch):
+        return self.centernet_loss(outputs["source_domain"], batch)
+
+    def step(self, data, is_training=True):
+        self._to_device(data)
+        if is_training:
+            self.optimizer.zero_grad()
+        outputs = {"source_domain": self.backend(data["input"])}
+        loss, stats = self.criterion(outputs, data)
+        if is_training:
+            loss.backward()
+            self._finish_backward()
+            self.optimizer.step()
+        stats["total_loss"] = loss
+        outputs["stats"] = self._detach_stats(stats)
+        return outputs
+
+    # -- evaluation --------------------------------------------------------------
+    def get_detections(self, outputs, batch):
+        """Decoded predictions and per-image ground truth as numpy (uda/base.py:73-139).
+        `outputs['source_domain']['hm']` already holds clamped probabilities because the
+        loss rebinds it (Q1)."""
+        src = outputs["source_domain"]
+        if 'kps' in src:
+            raise NotImplementedError("keypoint heads are outside this build")
+        rotated = bool(self.cfg.model.backend.params.rotated_boxes)
+        ratio = self.backend.down_ratio
+        dets = decode_detection(src["hm"], src["wh"], src["reg"], K=self.cfg.max_detections, rotated=rotated)
+        dets = dets.detach().cpu().numpy()
+        dets[:, :, :4] *= ratio
+        ids = batch["id"].cpu().numpy()
+        keep = (batch["reg_mask"].detach().cpu().numpy() == 1)
+        gt = batch["gt_dets"].cpu().numpy()
+        areas = batch["gt_areas"].cpu().numpy()
+        gt[:, :, :4] *= ratio
+        box_end, cls_col = (5, 6) if rotated else (4, 5)
+        out = {
+            'pred_boxes': dets[:, :, :box_end],
+            'pred_classes': dets[:, :, cls_col].astype(np.int32),
+            'pred_scores': dets[:, :, box_end],
+            'gt_boxes': [], 'gt_classes': [], 'gt_ids': [], 'gt_areas': [],
+        }
+        for i in range(gt.shape[0]):
+            rows = gt[i, keep[i]]
+            out['gt_boxes'].append(rows[:, :box_end])
+            out['gt_classes'].append(rows[:, cls_col].astype(np.int32))
+            out['gt_ids'].append(ids[i])
+            out['gt_areas'].append(areas[i, keep[i]])
+        return out
+
+    # -- checkpoints ---------------------------------------------------------------
+    def load_model(self, path, resume=False):
+        return load_model(self.backend, self.optimizer, self.scheduler, path, resume)
+
+    def save_model(self, path, epoch, with_optimizer=False):
+        if with_optimizer:
+            save_model(self.backend, path, epoch, self.optimizer, self.scheduler)
+        else:
+            save_model(self.backend, path, epoch)

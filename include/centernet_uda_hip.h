@@ -91,6 +91,128 @@ int cnuda_dcn_v2_backward(const float* input, const float* weight, const float* 
                           int sh, int sw, int ph, int pw, int dh, int dw, int dg,
                           void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Dense convolution (groups 1, dilation 1) -- replaces torch.nn.Conv2d -> cuDNN
+ * on the hot path: backends/dla.py:37-44,153-155,234-235,281-283,478-483 (DLA
+ * trunk, roots, heads), libs/DCNv2/dcn_v2.py:104-110 (offset/mask conv),
+ * backends/resnet.py:43-51 (heads), uda/adversarial_entropy_minimization.py:51-68
+ * (discriminator).  weight is the state_dict layout [Cout, C, kh, kw].
+ * forward: y = act(conv(x, w) + bias); bias may be NULL; act_slope < 0 -> no
+ * activation, 0 -> ReLU, 0.2 -> LeakyReLU(0.2).  backward_weight writes
+ * grad_weight (and grad_bias = channel sums of grad_y when non-NULL).
+ * ---------------------------------------------------------------------- */
+size_t cnuda_conv2d_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw,
+                                    int sh, int sw, int ph, int pw);
+int cnuda_conv2d_forward(const float* x, const float* weight, const float* bias, float* y,
+                         int B, int C, int H, int W, int Cout, int kh, int kw,
+                         int sh, int sw, int ph, int pw, float act_slope,
+                         void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+int cnuda_conv2d_backward_data(const float* grad_y, const float* weight, float* grad_x,
+                               int B, int C, int H, int W, int Cout, int kh, int kw,
+                               int sh, int sw, int ph, int pw,
+                               void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+int cnuda_conv2d_backward_weight(const float* x, const float* grad_y, float* grad_weight, float* grad_bias,
+                                 int B, int C, int H, int W, int Cout, int kh, int kw,
+                                 int sh, int sw, int ph, int pw,
+                                 void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * BatchNorm2d fused with the residual add and ReLU that follow it in DLA-34
+ * (backends/dla.py:48-62,150-168,277-287,351-372; nn.BatchNorm2d(momentum=0.1)).
+ * x, y, residual: [B, C, HW].  residual may be NULL; relu != 0 applies max(.,0).
+ * train_forward updates running_mean/var in place (unbiased variance, may be
+ * NULL) and saves mean / invstd for backward.  backward: grad_y is the gradient
+ * w.r.t. y (post-activation); y is needed only when relu != 0; grad_residual
+ * (nullable) receives the gradient flowing into the residual branch.
+ * ---------------------------------------------------------------------- */
+size_t cnuda_bn_workspace_bytes(int B, int C, long long HW);
+int cnuda_bn_train_forward(const float* x, const float* gamma, const float* beta, const float* residual,
+                           float* y, float* save_mean, float* save_invstd,
+                           float* running_mean, float* running_var, float momentum, float eps, int relu,
+                           int B, int C, long long HW,
+                           void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+int cnuda_bn_eval_forward(const float* x, const float* gamma, const float* beta,
+                          const float* running_mean, const float* running_var, const float* residual,
+                          float* y, float eps, int relu, int B, int C, long long HW, cnuda_stream_t stream);
+int cnuda_bn_backward(const float* grad_y, const float* x, const float* y, const float* gamma,
+                      const float* save_mean, const float* save_invstd,
+                      float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
+                      int relu, int B, int C, long long HW,
+                      void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Spatial / elementwise pieces of the DLA graph.
+ *   maxpool2d: window k, stride k, no padding  (nn.MaxPool2d(stride, stride), dla.py:202-203)
+ *   dwconvt2d: depthwise ConvTranspose2d, weight [C,1,k,k], stride s, padding p, no bias
+ *              (IDAUp.up, dla.py:385-388: k = 2f, s = f, p = f/2); grad_x / grad_w nullable
+ *   add, act_backward (gx = gy * (y > 0 ? 1 : slope)), copy_channels (concat / slice),
+ *   split_offset_mask: DCN.forward's chunk/cat/sigmoid (libs/DCNv2/dcn_v2.py:119-122)
+ * ---------------------------------------------------------------------- */
+int cnuda_maxpool2d_forward(const float* x, float* y, int B, int C, int H, int W, int k, cnuda_stream_t stream);
+int cnuda_maxpool2d_backward(const float* x, const float* grad_y, float* grad_x,
+                             int B, int C, int H, int W, int k, cnuda_stream_t stream);
+int cnuda_dwconvt2d_forward(const float* x, const float* w, float* y,
+                            int B, int C, int H, int W, int k, int s, int p, cnuda_stream_t stream);
+int cnuda_dwconvt2d_backward(const float* x, const float* w, const float* grad_y, float* grad_x, float* grad_w,
+                             int B, int C, int H, int W, int k, int s, int p, cnuda_stream_t stream);
+int cnuda_add(const float* a, const float* b, float* out, long long n, cnuda_stream_t stream);
+int cnuda_act_backward(const float* grad_y, const float* y, float* grad_x, long long n, float slope,
+                       cnuda_stream_t stream);
+int cnuda_copy_channels(const float* src, float* dst, int B, int Cn, long long HW,
+                        int Csrc, int src_off, int Cdst, int dst_off, cnuda_stream_t stream);
+int cnuda_split_offset_mask(const float* om, float* offset, float* mask, int B, int taps, long long HW,
+                            cnuda_stream_t stream);
+int cnuda_split_offset_mask_backward(const float* grad_offset, const float* grad_mask, const float* mask,
+                                     float* grad_om, int B, int taps, long long HW, cnuda_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Losses.  Scalars live in device memory (no host sync; the reference's
+ * `if num_pos == 0` host branch, losses/centernet.py:91, is taken on device).
+ * `upstream` is a device pointer to the scalar gradient of the loss value.
+ *   focal   : losses/centernet.py:69-95 on prob = clamp(sigmoid(logits)) (utils/tensor.py:5-7);
+ *             out2 = {loss, num_pos}; prob receives the clamped probabilities (Q1)
+ *   reg_l1  : losses/centernet.py:98-133 (ch 2, or 3 = rotated) and :192-223 (periodic != 0);
+ *             masks `target` in place and, for the rotated non-periodic angle, replaces it by its
+ *             sigmoid, as the reference does (Q2); out2 = {loss, mask.sum()+1e-4}
+ *   softmax_loss kind 0: losses/entropy.py:10-28; kind 1: losses/max_square.py:6-14
+ *   entropy_map: utils/image.py:121-124;  bce_const: losses/advent.py:10-18
+ * ---------------------------------------------------------------------- */
+size_t cnuda_loss_workspace_bytes(void);
+int cnuda_focal_loss_forward(const float* logits, const float* gt, float* prob, float* out2, long long n,
+                             float weight, void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+int cnuda_focal_loss_backward(const float* logits, const float* gt, const float* out2, const float* upstream,
+                              float* grad_logits, long long n, float weight, cnuda_stream_t stream);
+int cnuda_reg_l1_forward(const float* feat, const uint8_t* mask, const int64_t* ind, float* target, float* out2,
+                         int B, int M, int ch, long long HW, int periodic, float weight, float angle_weight,
+                         cnuda_stream_t stream);
+int cnuda_reg_l1_backward(const float* feat, const uint8_t* mask, const int64_t* ind, const float* target,
+                          const float* out2, const float* upstream, float* grad_feat,
+                          int B, int M, int ch, long long HW, int periodic, float weight, float angle_weight,
+                          cnuda_stream_t stream);
+int cnuda_softmax_loss_forward(const float* logits, float* out1, int B, int C, long long HW, int kind,
+                               void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+int cnuda_softmax_loss_backward(const float* logits, const float* upstream, float* grad_logits,
+                                int B, int C, long long HW, int kind, cnuda_stream_t stream);
+int cnuda_entropy_map_forward(const float* logits, float* out, int B, int C, long long HW, cnuda_stream_t stream);
+int cnuda_entropy_map_backward(const float* logits, const float* grad_out, float* grad_logits,
+                               int B, int C, long long HW, cnuda_stream_t stream);
+int cnuda_bce_const_forward(const float* logits, float label, float* out1, long long n, cnuda_stream_t stream);
+int cnuda_bce_const_backward(const float* logits, float label, const float* upstream, float* grad_logits,
+                             long long n, cnuda_stream_t stream);
+/* x <- sigmoid(x) in place, y = clamp(x, 1e-4, 1-1e-4)  (utils/tensor.py:5-7) */
+int cnuda_sigmoid_clamp_(float* x, float* y, long long n, cnuda_stream_t stream);
+/* feat [B,ch,HW], ind [B,M] -> out [B,M,ch]  (utils/tensor.py:10-25) */
+int cnuda_gather_feat(const float* feat, const int64_t* ind, float* out, int B, int M, int ch, long long HW,
+                      cnuda_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Optimizer -- torch.optim.Adam arithmetic (train.py:88-90) over a flat arena.
+ * step is the 1-based step count used for bias correction.
+ * ---------------------------------------------------------------------- */
+int cnuda_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    cnuda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,33 +103,44 @@ def loss_inputs(name):
 # ---------------------------------------------------------------------------
 # network parameters: closed-form, RNG-free fill keyed by the state_dict name
 # ---------------------------------------------------------------------------
-def _phase(name):
-    return (zlib.crc32(name.encode()) % 100003) / 100003.0 * 2 * math.pi
+def _hash_uniform(name, n):
+    """n pseudo-random float64 in [-1, 1): integer hash of (crc32(name), index).
+    Pure uint64 arithmetic -> bit-identical on every platform."""
+    seed = np.uint64((zlib.crc32(name.encode()) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF)
+    x = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + seed
+    x ^= x >> np.uint64(30)
+    x *= np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(27)
+    x *= np.uint64(0x94D049BB133111EB)
+    x ^= x >> np.uint64(31)
+    return (x >> np.uint64(11)).astype(np.float64) / float(1 << 53) * 2.0 - 1.0
 
 
 def fill_value(name, shape):
-    """float32 array for state_dict entry `name` of `shape`."""
+    """float32 array for state_dict entry `name` of `shape` (well-conditioned:
+    kaiming-scaled pseudo-random kernels, BN statistics near identity)."""
     n = int(np.prod(shape)) if len(shape) else 1
-    i = np.arange(n, dtype=np.float64)
-    wave = np.sin(0.37 * i + _phase(name))
     if name.endswith('num_batches_tracked'):
         return np.zeros(shape, np.int64)
+    u = _hash_uniform(name, n)
     if name.endswith('running_var'):
-        v = 1.0 + 0.3 * wave
+        v = 1.0 + 0.3 * u
     elif name.endswith('running_mean'):
-        v = 0.1 * wave
+        v = 0.1 * u
     elif len(shape) == 1 and name.endswith('.weight'):          # BN gamma
-        v = 1.0 + 0.2 * wave
+        v = 1.0 + 0.2 * u
     elif len(shape) == 1:                                        # biases / BN beta
-        v = 0.05 * wave
+        v = 0.05 * u
         if name == 'hm.2.bias':
             v = v - 2.19
-    else:                                                        # conv kernels
+    else:                                                        # conv kernels: uniform with kaiming variance
         fan_in = int(np.prod(shape[1:]))
-        scale = 1.8 / math.sqrt(fan_in)
+        scale = math.sqrt(6.0 / fan_in)
         if 'conv_offset_mask' in name:
-            scale = 1.2 / math.sqrt(fan_in)                      # offsets ~ +-1 px (Q7)
-        v = scale * wave
+            scale = 1.5 / math.sqrt(fan_in)                      # offsets of about +-1 px (Q7)
+        if '.up_' in name:
+            scale = 2.0 / math.sqrt(fan_in)
+        v = scale * u
     return v.reshape(shape).astype(np.float32)
 
 

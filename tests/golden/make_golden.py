@@ -171,89 +171,119 @@ GRAD_PROBES = [
 ]
 
 
+def _dla_case(dla, rotated, B, S, seed, dtype):
+    """Reference DLASeg at `dtype` (float32 = the reference's arithmetic; float64 =
+    the same module evaluated exactly, used by the tests to express tolerances
+    relative to the reference's own rounding noise)."""
+    model = dla.build(num_classes=6, rotated_boxes=rotated)
+    sd = model.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes).items()})
+    model = model.to(dtype)
+    x = T(gin.image_batch(B, S, S, seed)).to(dtype)
+    res = {}
+    model.eval()
+    with torch.no_grad():
+        out = model(x)
+    for k in out:
+        res['eval_' + k] = out[k].numpy()
+    model.train()
+    out = model(x)
+    res['head_order'] = np.array(list(out.keys()))
+    for k in out:
+        res['train_' + k] = out[k].detach().numpy()
+    scalar = sum((out[k] * torch.cos(torch.arange(out[k].numel(), dtype=dtype)
+                                     .reshape(out[k].shape) * 0.1)).sum() for k in out)
+    scalar.backward()
+    res['scalar'] = scalar.item()
+    params = dict(model.named_parameters())
+    for n in GRAD_PROBES:
+        res['gradsum__' + n] = _checksums(params[n].grad)
+    res['grad_none'] = np.array(sorted(n for n, p in params.items() if p.grad is None))
+    sd2 = model.state_dict()
+    for n in ('base.base_layer.1', 'base.level3.project.1', 'base.level4.project.1',
+              'dla_up.ida_0.node_1.actf.0', 'ida_up.node_2.actf.0'):
+        res['rm__' + n] = sd2[n + '.running_mean'].numpy()
+        res['rv__' + n] = sd2[n + '.running_var'].numpy()
+        res['nbt__' + n] = sd2[n + '.num_batches_tracked'].numpy()
+    meta = {'state_names': np.array(sorted(shapes)), 'n_params': sum(p.numel() for p in model.parameters()),
+            'shapes_json': np.array(repr(sorted((k, v) for k, v in shapes.items())))}
+    return res, meta
+
+
 def make_dla():
     dla = _import_reference_dla()
-    for tag, rotated, B, S, seed in (('axis', False, 2, 64, 41), ('rot', True, 1, 96, 42)):
-        model = dla.build(num_classes=6, rotated_boxes=rotated)
-        sd = model.state_dict()
-        shapes = {k: tuple(v.shape) for k, v in sd.items()}
-        model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes).items()})
-        x = T(gin.image_batch(B, S, S, seed))
-        res = {'state_names': np.array(sorted(shapes)), 'n_params': sum(p.numel() for p in model.parameters())}
-        res['shapes_json'] = np.array(repr(sorted((k, v) for k, v in shapes.items())))
-        # eval forward
-        model.eval()
-        with torch.no_grad():
-            out = model(x)
-        for k in out:
-            res['eval_' + k] = out[k].numpy()
-        # train forward + backward of a fixed scalar
-        model.train()
-        out = model(x)
-        res['head_order'] = np.array(list(out.keys()))
-        for k in out:
-            res['train_' + k] = out[k].detach().numpy()
-        scalar = sum((out[k] * torch.cos(torch.arange(out[k].numel(), dtype=torch.float32)
-                                         .reshape(out[k].shape) * 0.1)).sum() for k in out)
-        scalar.backward()
-        res['scalar'] = scalar.item()
-        params = dict(model.named_parameters())
-        for n in GRAD_PROBES:
-            g = params[n].grad
-            res['gradsum__' + n] = _checksums(g)
-        res['grad_none'] = np.array(sorted(n for n, p in params.items() if p.grad is None))
-        sd2 = model.state_dict()
-        for n in ('base.base_layer.1', 'base.level3.project.1', 'base.level4.project.1',
-                  'dla_up.ida_0.node_1.actf.0', 'ida_up.node_2.actf.0'):
-            res['rm__' + n] = sd2[n + '.running_mean'].numpy()
-            res['rv__' + n] = sd2[n + '.running_var'].numpy()
-            res['nbt__' + n] = sd2[n + '.num_batches_tracked'].numpy()
-        save('dla_' + tag, **res)
+    for tag, rotated, B, S, seed in DLA_CASES:
+        r32, meta = _dla_case(dla, rotated, B, S, seed, torch.float32)
+        r64, _ = _dla_case(dla, rotated, B, S, seed, torch.float64)
+        out = dict(meta)
+        out.update(r32)
+        for k, v in r64.items():
+            if k.startswith(('eval_', 'train_', 'gradsum__', 'scalar')):
+                out['f64_' + k] = v
+        save('dla_' + tag, **out)
     return dla
+
+
+DLA_CASES = (('axis', False, 2, 64, 41), ('rot', True, 2, 96, 42))
+
+
+def _step_case(dla, tag, dtype):
+    from losses.centernet import DetectionLoss
+    from losses.entropy import EntropyLoss
+    from losses.max_square import MaxSquareLoss
+    uda_loss, weight = (EntropyLoss(), 1e-4) if tag == 'entropy' else (MaxSquareLoss(), 0.3)
+    B, S, M = 2, 64, 8
+    model = dla.build(num_classes=6)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes).items()})
+    model = model.to(dtype)
+    model.train()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5, weight_decay=1e-4)
+    crit = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0, periodic=False)
+    batch = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, (3, 2), 2, 51).items()}
+    for k in ('hm', 'wh', 'reg'):
+        batch[k] = batch[k].to(dtype)
+    batch['input'] = T(gin.image_batch(B, S, S, 52)).to(dtype)
+    batch['target_domain_input'] = T(gin.image_batch(B, S, S, 53)).to(dtype)
+    opt.zero_grad()
+    out_s = model(batch['input'])
+    out_t = model(batch['target_domain_input'])
+    c_loss, c_stats = crit(out_s, batch)
+    e_loss, e_stats = uda_loss(out_t, batch)
+    e_loss *= weight
+    c_loss.backward()
+    e_loss.backward()
+    opt.step()
+    stats = {**c_stats, **e_stats}
+    stats['total_loss'] = c_loss + e_loss
+    res = {'stat_' + k: v.item() for k, v in stats.items()}
+    params = dict(model.named_parameters())
+    for n in GRAD_PROBES:
+        if n in params and params[n].grad is not None:
+            res['gradsum__' + n] = _checksums(params[n].grad)
+            res['param__' + n] = _checksums(params[n])
+    sd = model.state_dict()
+    res['rm__base.base_layer.1'] = sd['base.base_layer.1.running_mean'].numpy()
+    res['rv__base.base_layer.1'] = sd['base.base_layer.1.running_var'].numpy()
+    res['nbt__base.base_layer.1'] = sd['base.base_layer.1.num_batches_tracked'].numpy()
+    res['src_hm_after'] = out_s['hm'].detach().numpy()
+    return res
 
 
 def make_step(dla):
     """One `EntropyMinimization.step` (uda/entropy_minimization.py:11-43) and one
     `MaxSquaresMinimization.step` re-enacted with the imported reference pieces
-    (uda.* itself needs hydra, absent here; its step bodies are pure sequencing)."""
-    from losses.centernet import DetectionLoss
-    from losses.entropy import EntropyLoss
-    from losses.max_square import MaxSquareLoss
-    B, S, M = 2, 64, 8
-    for tag, uda_loss, key, weight in (('entropy', EntropyLoss(), 'entropy_loss', 1e-4),
-                                       ('maxsq', MaxSquareLoss(), 'max_square_loss', 0.3)):
-        model = dla.build(num_classes=6)
-        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-        model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes).items()})
-        model.train()
-        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5, weight_decay=1e-4)
-        crit = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0, periodic=False)
-        batch = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, (3, 2), 2, 51).items()}
-        batch['input'] = T(gin.image_batch(B, S, S, 52))
-        batch['target_domain_input'] = T(gin.image_batch(B, S, S, 53))
-        opt.zero_grad()
-        out_s = model(batch['input'])
-        out_t = model(batch['target_domain_input'])
-        c_loss, c_stats = crit(out_s, batch)
-        e_loss, e_stats = uda_loss(out_t, batch)
-        e_loss *= weight
-        c_loss.backward()
-        e_loss.backward()
-        opt.step()
-        stats = {**c_stats, **e_stats}
-        stats['total_loss'] = c_loss + e_loss
-        res = {'stat_' + k: v.item() for k, v in stats.items()}
-        params = dict(model.named_parameters())
-        for n in GRAD_PROBES:
-            if n in params and params[n].grad is not None:
-                res['gradsum__' + n] = _checksums(params[n].grad)
-                res['param__' + n] = _checksums(params[n])
-        sd = model.state_dict()
-        res['rm__base.base_layer.1'] = sd['base.base_layer.1.running_mean'].numpy()
-        res['rv__base.base_layer.1'] = sd['base.base_layer.1.running_var'].numpy()
-        res['nbt__base.base_layer.1'] = sd['base.base_layer.1.num_batches_tracked'].numpy()
-        res['src_hm_after'] = out_s['hm'].detach().numpy()
-        save('step_' + tag, **res)
+    (uda.* itself needs hydra, absent here; its step bodies are pure sequencing),
+    in float32 and, for tolerance calibration, float64."""
+    for tag in ('entropy', 'maxsq'):
+        r32 = _step_case(dla, tag, torch.float32)
+        r64 = _step_case(dla, tag, torch.float64)
+        out = dict(r32)
+        for k, v in r64.items():
+            if k.startswith(('stat_', 'gradsum__', 'src_hm_after')):
+                out['f64_' + k] = v
+        save('step_' + tag, **out)
 
 
 if __name__ == '__main__':

@@ -1,0 +1,154 @@
+"""MI355X parity of the DLA-34 backend and of the UDA step plugins against golden
+vectors produced by the reference module (tests/golden/dla_*.npz, step_*.npz)."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+import inputs as gin
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _checksums(t):
+    t = t.detach().double().reshape(-1).cpu()
+    idx = torch.arange(t.numel(), dtype=torch.float64)
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * torch.cos(0.01 * idx)).sum().item()])
+
+
+def _close(a, b, tol=1e-4):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = max(1.0, np.abs(b).max())
+    assert np.abs(a - b).max() <= tol * scale, (np.abs(a - b).max(), scale)
+
+
+def _close_calibrated(got, ref32, ref64, floor=1e-4, k=8.0, what=''):
+    """A 50-layer fp32 network in train-mode BatchNorm carries rounding noise well
+    above 1e-4 whatever the summation order: the reference's own fp32 result differs
+    from the same module evaluated in fp64 by `noise` (1e-3 on the heads, 1e-2 on
+    gradients for these tiny inputs).  The HIP result must sit as close to the exact
+    (fp64) value as the reference does, within a factor k, and never needs to beat
+    the 1e-4 floor of north_star.  k = 8: the fp32 MFMA is one k-ordered fma chain
+    per output, which measures 3-5x the per-convolution rounding noise of oneDNN's
+    blocked accumulation on the CPU (numerics); every single layer is
+    held to 1e-4 against the oracle in test_gpu_ops.py / test_gpu_dcn.py."""
+    got, ref32, ref64 = [np.asarray(t, np.float64) for t in (got, ref32, ref64)]
+    scale = max(1.0, np.abs(ref64).max())
+    noise = np.abs(ref32 - ref64).max()
+    err = np.abs(got - ref64).max()
+    assert err <= max(floor * scale, k * noise), (what, err, noise, scale)
+
+
+def _model(g, rotated=False):
+    from backends import dla
+    shapes = dict(ast.literal_eval(str(g['shapes_json'])))
+    m = dla.build(num_classes=6, rotated_boxes=rotated)
+    m.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes).items()})
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize('tag,rotated,B,S,seed', [('axis', False, 2, 64, 41), ('rot', True, 2, 96, 42)])
+def test_dla_forward_backward_golden(golden, tag, rotated, B, S, seed):
+    g = golden('dla_' + tag)
+    model = _model(g, rotated)
+    x = T(gin.image_batch(B, S, S, seed)).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        out = model(x)
+    assert list(out) == ['hm', 'wh', 'reg']
+    for k in out:
+        _close_calibrated(out[k].cpu().numpy(), g['eval_' + k], g['f64_eval_' + k], what='eval ' + k)
+    model.train()
+    out = model(x)
+    for k in out:
+        _close_calibrated(out[k].detach().cpu().numpy(), g['train_' + k], g['f64_train_' + k], what=k)
+    scalar = sum((out[k] * torch.cos(torch.arange(out[k].numel(), dtype=torch.float32)
+                                     .reshape(out[k].shape) * 0.1).to(DEV)).sum() for k in out)
+    scalar.backward()
+    _close_calibrated(scalar.item(), g['scalar'], g['f64_scalar'], floor=2e-4, what='scalar')
+    params = dict(model.named_parameters())
+    for key in g.files:
+        if key.startswith('gradsum__'):
+            n = key[len('gradsum__'):]
+            got, w32, w64 = _checksums(params[n].grad), g[key], g['f64_' + key]
+            noise = np.abs(w32 - w64).max()
+            assert np.abs(got - w64).max() <= max(5e-4 * max(1.0, w64[1]), 16 * noise), (n, got, w64, noise)
+    none = sorted(n for n, p in params.items() if p.grad is None)
+    assert none == sorted(str(s) for s in g['grad_none'])           # discarded project branches get no gradient
+    sd = model.state_dict()
+    for key in g.files:
+        if key.startswith('rm__'):
+            n = key[4:]
+            _close(sd[n + '.running_mean'].cpu().numpy(), g[key], 1e-5)
+            _close(sd[n + '.running_var'].cpu().numpy(), g['rv__' + n], 1e-5)
+            assert int(sd[n + '.num_batches_tracked']) == int(g['nbt__' + n])
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+@pytest.mark.parametrize('tag,weight', [('entropy', 1e-4), ('maxsq', 0.3)])
+def test_uda_step_golden(golden, tag, weight):
+    import uda
+    from hip_runtime import optim
+    from losses.centernet import DetectionLoss
+    g = golden('step_' + tag)
+    model = _model(golden('dla_axis'))
+    plugin = uda.EntropyMinimization(weight) if tag == 'entropy' else uda.MaxSquaresMinimization(weight)
+    plugin.backend = model
+    plugin.device = torch.device(DEV)
+    plugin.optimizer = optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5, weight_decay=1e-4)
+    plugin.centernet_loss = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0,
+                                          periodic=False)
+    plugin.init_done()
+    plugin.to(DEV)
+    plugin.set_phase(True)
+    B, S, M = 2, 64, 8
+    data = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, (3, 2), 2, 51).items()}
+    data['input'] = T(gin.image_batch(B, S, S, 52))
+    data['target_domain_input'] = T(gin.image_batch(B, S, S, 53))
+    out = plugin.step(data)
+    stats = out['stats']
+    for k in stats:
+        assert not stats[k].is_cuda and not stats[k].requires_grad
+        _close_calibrated(stats[k].item(), g['stat_' + k], g['f64_stat_' + k], floor=1e-4, what=k)
+    _close_calibrated(out['source_domain']['hm'].detach().cpu().numpy(), g['src_hm_after'],
+                      g['f64_src_hm_after'], what='hm prob')                            # Q1
+    params = dict(model.named_parameters())
+    for fk in g.files:
+        if fk.startswith('gradsum__'):
+            n = fk[len('gradsum__'):]
+            got, want, w64 = _checksums(params[n].grad), g[fk], g['f64_' + fk]
+            noise = np.abs(want - w64).max()
+            assert np.abs(got - w64).max() <= max(1e-3 * max(1.0, w64[1]), 16 * noise), (n, got, w64, noise)
+            gotp, wantp = _checksums(params[n]), g['param__' + n]
+            # Adam's first step moves every element by lr*sign(g): elements whose tiny gradient
+            # changes sign under rounding noise move by 2*lr -- allow 5 % of them
+            flips = 0.05 * params[n].numel() * 2 * 5e-5
+            assert np.abs(gotp - wantp).max() <= 1e-5 * max(1.0, wantp[1]) + flips, (n, gotp, wantp)
+    # discarded project branches: no gradient -> Adam (weight decay!) must leave them untouched
+    shapes = dict(ast.literal_eval(str(golden('dla_axis')['shapes_json'])))
+    n = 'base.level3.project.0.weight'
+    assert torch.equal(params[n].detach().cpu(), T(gin.fill_value(n, shapes[n])))
+    sd = model.state_dict()
+    _close(sd['base.base_layer.1.running_mean'].cpu().numpy(), g['rm__base.base_layer.1'], 1e-5)
+    _close(sd['base.base_layer.1.running_var'].cpu().numpy(), g['rv__base.base_layer.1'], 1e-5)
+    assert int(sd['base.base_layer.1.num_batches_tracked']) == 2                    # Q6
+    # evaluation path: no_grad step + get_detections
+    plugin.set_phase(False)
+    plugin.cfg = _Cfg(max_detections=20, model=_Cfg(backend=_Cfg(params=_Cfg(rotated_boxes=False))))
+    ev = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, (3, 2), 2, 51).items()}
+    ev['input'] = T(gin.image_batch(B, S, S, 52))
+    ev['target_domain_input'] = T(gin.image_batch(B, S, S, 53))
+    ev['id'] = torch.arange(B)
+    ev['gt_dets'] = torch.rand(B, M, 6)
+    ev['gt_areas'] = torch.rand(B, M)
+    with torch.no_grad():
+        o = plugin.step(ev, is_training=False)
+    dets = plugin.get_detections(o, ev)
+    assert dets['pred_boxes'].shape == (B, 20, 4) and dets['pred_scores'].shape == (B, 20)
+    assert [len(b) for b in dets['gt_boxes']] == [3, 2]

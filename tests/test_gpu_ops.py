@@ -1,0 +1,206 @@
+"""MI355X parity of the dense building blocks (implicit-GEMM conv, fused BN,
+pooling, depthwise transposed conv, concat/add, Adam) against the CPU torch
+primitives the oracle (oracle/dla.py) is made of.  fp32 tolerance 1e-4 of the
+tensor's scale (north_star)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL = 1e-4
+
+
+def _close(a, b, tol=TOL):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, b.abs().max().item())
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, (err, scale)
+
+
+CONV_CASES = {
+    # name: B, C, H, W, Co, k, s, p, bias, act
+    'stem7x7': (2, 3, 20, 24, 16, 7, 1, 3, False, -1.0),
+    'c16_3x3': (2, 16, 16, 16, 16, 3, 1, 1, False, -1.0),
+    'c16_s2': (2, 16, 17, 15, 32, 3, 2, 1, False, -1.0),
+    'c64_3x3': (1, 64, 12, 12, 64, 3, 1, 1, False, -1.0),
+    'root1x1': (2, 320, 6, 6, 128, 1, 1, 0, False, -1.0),
+    'offset27': (2, 64, 9, 9, 27, 3, 1, 1, True, -1.0),
+    'head_relu': (2, 64, 8, 8, 256, 3, 1, 1, True, 0.0),
+    'head_out': (2, 256, 8, 8, 6, 1, 1, 0, True, -1.0),
+    'disc4x4': (2, 6, 16, 16, 64, 4, 2, 1, True, 0.2),
+    'disc_last': (2, 512, 4, 4, 1, 4, 2, 1, True, -1.0),
+    'odd': (3, 20, 7, 9, 37, 3, 1, 1, True, -1.0),
+    'c512': (1, 256, 4, 4, 512, 3, 2, 1, False, -1.0),
+}
+
+
+@pytest.mark.parametrize('name', sorted(CONV_CASES))
+def test_conv2d_fwd_bwd(name):
+    from hip_runtime import ops
+    B, C, H, W, Co, k, s, p, bias, act = CONV_CASES[name]
+    g = torch.Generator().manual_seed(abs(hash(name)) % 1000)
+    x = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5).requires_grad_(True)
+    b = torch.randn(Co, generator=g).requires_grad_(True) if bias else None
+    y = F.conv2d(x, w, b, s, p)
+    if act >= 0:
+        y = F.leaky_relu(y, act)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    dx, dw = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    db = b.detach().to(DEV).requires_grad_(True) if bias else None
+    dy = ops.conv2d(dx, dw, db, s, p, act)
+    _close(dy, y)
+    dy.backward(gy.to(DEV))
+    _close(dx.grad, x.grad)
+    _close(dw.grad, w.grad)
+    if bias:
+        _close(db.grad, b.grad)
+
+
+@pytest.mark.parametrize('relu,res', [(False, False), (True, False), (True, True), (False, True)])
+@pytest.mark.parametrize('shape', [(2, 16, 10, 12), (3, 5, 7, 7), (1, 64, 2, 2)])
+def test_batch_norm_train_fwd_bwd_and_running_stats(shape, relu, res):
+    from hip_runtime import ops
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = shape
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    r = torch.randn(shape, generator=g).requires_grad_(True) if res else None
+    rm, rv = torch.randn(C, generator=g) * 0.1, 1 + 0.3 * torch.rand(C, generator=g)
+    rm_d, rv_d = rm.clone().to(DEV), rv.clone().to(DEV)
+    y = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    gy = torch.randn(shape, generator=g)
+    y.backward(gy)
+    leaves = [t.detach().to(DEV).requires_grad_(True) for t in (x, gamma, beta)]
+    dr = r.detach().to(DEV).requires_grad_(True) if res else None
+    dy = ops.batch_norm_act(leaves[0], leaves[1], leaves[2], rm_d, rv_d, True, 0.1, 1e-5, dr, relu)
+    _close(dy, y)
+    dy.backward(gy.to(DEV))
+    _close(leaves[0].grad, x.grad)
+    _close(leaves[1].grad, gamma.grad)
+    _close(leaves[2].grad, beta.grad)
+    if res:
+        _close(dr.grad, r.grad)
+    _close(rm_d, rm, 1e-6)
+    _close(rv_d, rv, 1e-6)
+
+
+def test_batch_norm_eval_and_single_value_error():
+    from hip_runtime import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 8, 5, 5, generator=g)
+    gamma, beta = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g)
+    rm, rv = torch.randn(8, generator=g), torch.rand(8, generator=g) + 0.5
+    want = F.relu(F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5))
+    with torch.no_grad():
+        got = ops.batch_norm_act(x.to(DEV), gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), False, relu=True)
+    _close(got, want)
+    with pytest.raises(RuntimeError):       # nn.BatchNorm2d refuses one value per channel in training
+        ops.batch_norm_act(torch.zeros(1, 4, 1, 1, device=DEV), gamma[:4].to(DEV), beta[:4].to(DEV),
+                           rm[:4].to(DEV), rv[:4].to(DEV), True)
+
+
+@pytest.mark.parametrize('shape,k', [((2, 5, 8, 12), 2), ((1, 3, 9, 7), 2), ((2, 4, 12, 12), 4)])
+def test_maxpool(shape, k):
+    from hip_runtime import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(shape, generator=g).requires_grad_(True)
+    y = F.max_pool2d(x, k, k)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    dx = x.detach().to(DEV).requires_grad_(True)
+    dy = ops.max_pool2d(dx, k)
+    assert torch.equal(dy.cpu(), y.detach())
+    dy.backward(gy.to(DEV))
+    assert torch.equal(dx.grad.cpu(), x.grad)
+
+
+@pytest.mark.parametrize('C,H,W,f', [(8, 5, 6, 2), (64, 4, 4, 4), (3, 3, 5, 8)])
+def test_depthwise_conv_transpose(C, H, W, f):
+    from hip_runtime import ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, C, H, W, generator=g).requires_grad_(True)
+    w = torch.randn(C, 1, 2 * f, 2 * f, generator=g).requires_grad_(True)
+    y = F.conv_transpose2d(x, w, None, stride=f, padding=f // 2, groups=C)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    dx, dw = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    dy = ops.depthwise_conv_transpose2d(dx, dw, f, f // 2)
+    _close(dy, y, 1e-5)
+    dy.backward(gy.to(DEV))
+    _close(dx.grad, x.grad, 1e-5)
+    _close(dw.grad, w.grad)
+
+
+def test_cat_add_split():
+    from hip_runtime import ops
+    g = torch.Generator().manual_seed(7)
+    a, b, c = [torch.randn(2, n, 5, 6, generator=g).requires_grad_(True) for n in (3, 8, 1)]
+    y = torch.cat((a, b, c), 1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    da, db_, dc = [t.detach().to(DEV).requires_grad_(True) for t in (a, b, c)]
+    dy = ops.cat_channels((da, db_, dc))
+    assert torch.equal(dy.cpu(), y.detach())
+    dy.backward(gy.to(DEV))
+    for d, r in ((da, a), (db_, b), (dc, c)):
+        assert torch.equal(d.grad.cpu(), r.grad)
+    s = ops.add(da.detach(), da.detach())
+    assert torch.equal(s.cpu(), (a + a).detach())
+    om = torch.randn(2, 27, 4, 5, generator=g).requires_grad_(True)
+    o1, o2, m = torch.chunk(om, 3, dim=1)
+    off, mask = torch.cat((o1, o2), 1), torch.sigmoid(m)
+    go, gm = torch.randn(off.shape, generator=g), torch.randn(mask.shape, generator=g)
+    torch.autograd.backward([off, mask], [go, gm])
+    dom = om.detach().to(DEV).requires_grad_(True)
+    doff, dmask = ops.split_offset_mask(dom)
+    assert torch.equal(doff.cpu(), off.detach())
+    _close(dmask, mask, 1e-6)
+    torch.autograd.backward([doff, dmask], [go.to(DEV), gm.to(DEV)])
+    _close(dom.grad, om.grad, 1e-6)
+
+
+def test_adam_matches_torch_and_skips_untouched_params():
+    from hip_runtime import optim
+    g = torch.Generator().manual_seed(8)
+    shapes = [(5, 3), (7,), (2, 2, 3), (11,)]
+    ref = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    mine = [t.detach().clone().to(DEV).requires_grad_(True) for t in ref]
+    o_ref = torch.optim.Adam(ref, lr=1e-2, weight_decay=1e-2)
+    o_mine = optim.Adam(mine, lr=1e-2, weight_decay=1e-2)
+    for it in range(4):
+        o_ref.zero_grad()
+        o_mine.zero_grad()
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        for i, (r, m, gr) in enumerate(zip(ref, mine, grads)):
+            if i == 2:
+                continue                       # never receives a gradient -> must not move (weight decay!)
+            (r * gr).sum().backward()
+            (m * gr.to(DEV)).sum().backward()
+        o_ref.step()
+        o_mine.step()
+    for r, m in zip(ref, mine):
+        _close(m, r, 1e-6)
+    assert torch.equal(mine[2].cpu(), ref[2].detach())
+    sd = o_mine.state_dict()
+    assert len(sd['state']) == 4 and sd['param_groups'][0]['lr'] == 1e-2
+
+
+def test_conv_full_size_linearity_64ch_128sq():
+    # cfg-size layer 64->64 3x3 @128x128 (B=4): conv is linear in x -- size-independent property
+    from hip_runtime import ops
+    g = torch.Generator().manual_seed(9)
+    x1 = torch.randn(4, 64, 128, 128, generator=g).to(DEV)
+    x2 = torch.randn(4, 64, 128, 128, generator=g).to(DEV)
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV)
+    f = lambda t: ops.conv2d(t, w, None, 1, 1)
+    _close(f(x1 + 2 * x2), f(x1) + 2 * f(x2), 2e-5)
