@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""Benchmark of the CenterNet-UDA hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W          (N > 1, one rank per GPU)
+
+Metric (BASELINE.json): source images/sec of one full UDA training step of
+CenterNet DLA-34 (+16 DCNv2 layers) at 512x512, per-GPU batch 16 source + 16
+target images, `uda=entropy_minimization` (configs[2]): 2 forwards, detection +
+entropy loss, 2 backwards, Adam step -- uda/entropy_minimization.py:11-43 of
+the reference -- on synthetic COCO-shaped batches already resident in HBM.
+Weak scaling: every rank owns its own 16+16 images; gradients are averaged with
+bucketed RCCL all-reduces overlapped with backward.
+
+One JSON line is printed by rank 0 with `roofline` (dominant kernel, fp32 MFMA
+bound, timed with hipEvents recorded inside the library around that kernel's
+launches during extra, untimed steps of the same workload) and `cpu_baseline`
+(the CPU oracle's step on a bounded sample, host cores of this box).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, 'tests', 'golden'), ROOT, os.path.join(ROOT, 'centernet-uda_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 matrix peak (dense, = vector peak)
+NUM_CLASSES = 6                     # configs/defaults.yaml:16
+MAX_OBJS = 150                      # max_detections
+
+
+def synthetic_batch(B, S, seed, device):
+    """Batch with the schema of datasets/coco.py:168-174,242-251."""
+    import inputs as gin
+    H = W = S // 4
+    rs = np.random.RandomState(seed)
+    n_obj = tuple(int(rs.randint(1, 21)) for _ in range(B))
+    b = gin.detection_batch(B, NUM_CLASSES, H, W, MAX_OBJS, n_obj, 2, seed)
+    data = {k: torch.from_numpy(v) for k, v in b.items()}
+    g = torch.Generator().manual_seed(seed)
+    data['input'] = torch.randn(B, 3, S, S, generator=g)
+    data['target_domain_input'] = torch.randn(B, 3, S, S, generator=g)
+    return {k: v.to(device) for k, v in data.items()}
+
+
+def build_plugin(device, parallel, uda_name='entropy'):
+    import uda
+    from backends import dla
+    from hip_runtime import optim
+    from losses.centernet import DetectionLoss
+    torch.manual_seed(42)                                   # defaults.yaml: seed 42
+    backend = dla.build(num_classes=NUM_CLASSES)
+    # give the DCN offset/mask convs non-zero weights so that deformable sampling is exercised (Q7)
+    with torch.no_grad():
+        for n, p in backend.named_parameters():
+            if 'conv_offset_mask.weight' in n:
+                p.normal_(0, 0.5 / (p.shape[1] * 9) ** 0.5)
+    plugin = uda.EntropyMinimization(1e-4) if uda_name == 'entropy' else uda.MaxSquaresMinimization(0.3)
+    plugin.backend = backend
+    plugin.device = device
+    plugin.centernet_loss = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0,
+                                          periodic=False)
+    plugin.to(device, parallel)
+    plugin.optimizer = optim.Adam([p for p in plugin.backend.parameters() if p.requires_grad],
+                                  lr=5e-5, weight_decay=1e-4)       # entropy_minimization.yaml
+    plugin.init_done()
+    plugin.set_phase(True)
+    return plugin
+
+
+def fresh(batch):
+    # the loss masks batch['wh'/'reg'] in place (Q2): idempotent, so the same resident batch is reused
+    return batch
+
+
+def cpu_baseline(size=256):
+    """The CPU oracle's EntropyMinimization step (torch CPU ops + scalar C DCN loops, the
+    reference's CPU sequence) on 1 source + 1 target image at size x size."""
+    from oracle import dla as odla
+    from oracle import losses as ol
+    from backends import dla
+    torch.manual_seed(0)
+    model = dla.build(num_classes=NUM_CLASSES)
+    state = {}
+    for k, v in model.state_dict().items():
+        t = v.detach().clone()
+        if t.is_floating_point() and 'running_' not in k:
+            if 'conv_offset_mask.weight' in k:
+                t.normal_(0, 0.5 / (t.shape[1] * 9) ** 0.5)
+            t.requires_grad_(True)
+        state[k] = t
+    params = [v for v in state.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-5, weight_decay=1e-4)
+    batch = {k: v for k, v in synthetic_batch(1, size, 7, 'cpu').items()}
+    t0 = time.perf_counter()
+    opt.zero_grad()
+    out_s = odla.forward(state, batch['input'], training=True)
+    out_t = odla.forward(state, batch['target_domain_input'], training=True)
+    c_loss, _, _ = ol.detection_loss(out_s, batch, 1.0, 0.1, 1.0, 1.0, False)
+    e_loss = ol.entropy_loss(out_t['hm']) * 1e-4
+    c_loss.backward()
+    e_loss.backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    scale = (size / 512.0) ** 2
+    return {
+        'value': round(scale / dt, 5), 'unit': 'images/sec (512x512-equivalent source images)',
+        'cores': torch.get_num_threads(), 'kind': 'port',
+        'sample': '1 EntropyMinimization step of the CPU oracle on 1 source + 1 target image at %dx%d '
+                  '(%.2f s; pixel count scaled by %.3f to the 512x512 workload); torch CPU conv/BN '
+                  '(%d threads) + single-thread C DCN loops like the reference CPU extension'
+                  % (size, size, dt, scale, torch.get_num_threads()),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU source batch (and target batch)')
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--uda', default='entropy', choices=['entropy', 'maxsq'])
+    ap.add_argument('--profile-steps', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group(backend='nccl', device_id=device)      # nccl == RCCL on ROCm
+
+    plugin = build_plugin(device, parallel=world > 1, uda_name=args.uda)
+    batch = synthetic_batch(args.batch, args.size, 42 + rank, device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        plugin.step(fresh(batch))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = plugin.step(fresh(batch))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stats = {k: float(v) for k, v in out['stats'].items()}
+
+    roofline = None
+    if rank == 0 and args.profile_steps > 0:
+        import hip_runtime as hr
+        hr.prof_begin()
+        for _ in range(args.profile_steps):
+            plugin.step(fresh(batch))
+        torch.cuda.synchronize()
+        per_kernel = hr.prof_end()
+        if per_kernel:
+            name, d = max(per_kernel.items(), key=lambda kv: kv[1]['ms'])
+            achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            roofline = {
+                'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'launches_per_step': d['launches'] // args.profile_steps,
+                'avg_launch_ms': round(d['ms'] / d['launches'], 4),
+                'algorithmic_gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
+                'kernel_ms_per_step': round(d['ms'] / args.profile_steps, 3),
+                'all_mfma_kernels': {k: {'ms_per_step': round(v['ms'] / args.profile_steps, 3),
+                                         'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2),
+                                         'launches': v['launches'] // args.profile_steps}
+                                     for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]['ms'])},
+            }
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = args.batch * world * args.steps / elapsed
+        # whole-step algorithmic work: 195.5 GFLOP per forwarded 512x512 image, 2 forwards per source image
+        step_tflop = 195.5e9 * (args.size / 512.0) ** 2 * 2 * args.batch / 1e12
+        line = {
+            'metric': 'images/sec CenterNet DLA-34 512x512 UDA step (entropy minimisation)',
+            'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[2]: DLA-34 + DCNv2, %dx%d, per-GPU batch %d source + %d target, '
+                                   'uda=%s_minimization, Adam(lr 5e-5, wd 1e-4), random-init weights'
+                                   % (args.size, args.size, args.batch, args.batch,
+                                      'entropy' if args.uda == 'entropy' else 'max_squares'),
+                       'global_batch': args.batch * world, 'input': [3, args.size, args.size],
+                       'parallelism': 'dp%d' % world},
+            'step_mfma_fraction': round(step_tflop / (ms * 1e-3) / PEAK_FP32_MFMA_TFLOPS, 4),
+            'losses': {k: round(v, 5) for k, v in stats.items()},
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

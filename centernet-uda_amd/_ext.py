@@ -43,6 +43,8 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
     L = hr.lib()
     nbytes = L.cnuda_dcn_v2_workspace_bytes(*geom)
     ws = hr.workspace(nbytes, input.device)
+    if deformable_group == 1:
+        hr.prof_arm('dcn_fwd', B, C, H, W, Co, kernel_h, kernel_w, Ho, Wo)
     hr.check(L.cnuda_dcn_v2_forward(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
                                     hr.ptr(out), *geom, hr.ptr(ws), ws.numel(), hr.stream()),
              'dcn_v2_forward')
@@ -61,6 +63,8 @@ def dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kernel_h, ke
     L = hr.lib()
     nbytes = L.cnuda_dcn_v2_workspace_bytes(*geom)
     ws = hr.workspace(nbytes, input.device)
+    if deformable_group == 1:
+        hr.prof_arm('dcn_bwd', B, C, H, W, Co, kernel_h, kernel_w, grad_output.shape[2], grad_output.shape[3])
     hr.check(L.cnuda_dcn_v2_backward(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
                                      hr.ptr(grad_output), *[hr.ptr(g) for g in grads], *geom,
                                      hr.ptr(ws), ws.numel(), hr.stream()),

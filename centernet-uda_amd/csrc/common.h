@@ -25,6 +25,18 @@ inline int check_launch(const char* what) {
     return 0;
 }
 
+// Optional in-library kernel timer (bench.py's roofline leg): when armed through
+// cnuda_prof_arm(tag), the next ProfScope brackets exactly one main-kernel launch
+// with hipEvents on the launch stream.  Inert (one int compare) otherwise.
+class ProfScope {
+public:
+    explicit ProfScope(hipStream_t st);
+    ~ProfScope();
+private:
+    hipStream_t st_;
+    int rec_;
+};
+
 #define CNUDA_REQUIRE(cond, ...)                 \
     do {                                         \
         if (!(cond)) {                           \

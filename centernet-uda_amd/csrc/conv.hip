@@ -248,6 +248,7 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
                hipStream_t st, const char* who) {
     const int n_tiles = ceil_div(N, IG_BN), m_tiles = Mp / bm;
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
+    ProfScope prof(st);
     if (bm == 128)
         hipLaunchKernelGGL((igemm_fwd_kernel<128, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
     else if (bm == 64)
@@ -322,8 +323,11 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
     Carver cv(workspace, workspace_bytes);
     float* slabs = cv.take<float>((size_t)q.Z * q.Mpw * q.Jp);
     ConvWParams p{g, x, grad_y};
-    hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z), dim3(IG_THREADS), 0,
-                       st, p, slabs, q.Mpw, q.Jp, q.Nf, q.pix_per_split);
+    {
+        ProfScope prof(st);
+        hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z), dim3(IG_THREADS), 0,
+                           st, p, slabs, q.Mpw, q.Jp, q.Nf, q.pix_per_split);
+    }
     if (int rc = check_launch("cnuda_conv2d_backward_weight")) return rc;
     launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, st);
     if (grad_bias) launch_channel_sum(grad_y, grad_bias, B, Cout, (long long)g.Ho * g.Wo, st);

@@ -480,6 +480,7 @@ extern "C" int cnuda_dcn_v2_forward(const float* input, const float* weight, con
     DcnFwdParams p{g, input, offset, mask, bias, output};
     const int n_tiles = ceil_div(q.N, IG_BN), m_tiles = q.Mp / q.bm;
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
+    ProfScope prof(st);
     if (q.bm == 128)
         hipLaunchKernelGGL((igemm_fwd_kernel<128, DcnFwdLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                            n_tiles, m_tiles);
@@ -529,6 +530,7 @@ extern "C" int cnuda_dcn_v2_backward(const float* input, const float* weight, co
     {
         DcnBwdParams p{g, input, offset, mask, grad_output, grad_input, grad_offset, grad_mask};
         const int n_tiles = ceil_div(q.N, IG_BN);
+        ProfScope prof(st);
         hipLaunchKernelGGL(dcn_bwd_data_kernel, dim3(n_tiles * q.T), dim3(IG_THREADS), 0, st, p, A2, q.Mp2, q.Kp2,
                            q.Cpad, q.N, n_tiles);
         if (int rc = check_launch("cnuda_dcn_v2_backward(data)")) return rc;

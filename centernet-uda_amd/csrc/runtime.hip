@@ -1,6 +1,8 @@
 // Error reporting and ABI bookkeeping shared by every entry point.
 #include <stdarg.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace cnuda {
@@ -15,6 +17,62 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 }  // namespace cnuda
+
+namespace cnuda {
+namespace {
+struct ProfRecord { hipEvent_t start, stop; int tag; };
+std::vector<ProfRecord> g_prof_pool;   // pre-created event pairs
+size_t g_prof_used = 0;
+int g_prof_armed = -1;                 // tag for the next main-kernel launch, -1 = off
+}  // namespace
+
+ProfScope::ProfScope(hipStream_t st) : st_(st), rec_(-1) {
+    if (g_prof_armed < 0 || g_prof_used >= g_prof_pool.size()) return;
+    rec_ = (int)g_prof_used++;
+    g_prof_pool[rec_].tag = g_prof_armed;
+    g_prof_armed = -1;
+    (void)hipEventRecord(g_prof_pool[rec_].start, st_);
+}
+ProfScope::~ProfScope() {
+    if (rec_ >= 0) (void)hipEventRecord(g_prof_pool[rec_].stop, st_);
+}
+}  // namespace cnuda
+
+extern "C" int cnuda_prof_enable(int max_records) {
+    using namespace cnuda;
+    for (auto& r : g_prof_pool) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    g_prof_pool.clear();
+    g_prof_used = 0;
+    g_prof_armed = -1;
+    for (int i = 0; i < max_records; ++i) {
+        ProfRecord r;
+        r.tag = -1;
+        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) {
+            set_error("cnuda_prof_enable: hipEventCreate failed");
+            return (int)hipGetLastError();
+        }
+        g_prof_pool.push_back(r);
+    }
+    return 0;
+}
+extern "C" int cnuda_prof_arm(int tag) {
+    cnuda::g_prof_armed = tag;
+    return 0;
+}
+extern "C" int cnuda_prof_collect(int* tags, float* ms, int cap) {
+    using namespace cnuda;
+    int n = 0;
+    for (size_t i = 0; i < g_prof_used && n < cap; ++i) {
+        if (hipEventSynchronize(g_prof_pool[i].stop) != hipSuccess) break;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof_pool[i].start, g_prof_pool[i].stop) != hipSuccess) break;
+        tags[n] = g_prof_pool[i].tag;
+        ms[n] = t;
+        ++n;
+    }
+    g_prof_used = 0;
+    return n;
+}
 
 extern "C" int cnuda_abi_version(void) { return CNUDA_ABI_VERSION; }
 extern "C" const char* cnuda_last_error(void) { return cnuda::g_error; }

@@ -96,6 +96,9 @@ class _Sig:
     cnuda_sigmoid_clamp_ = (_I, [_P, _P, _LL, _P])
     cnuda_gather_feat = (_I, [_P] * 3 + [_I, _I, _I, _LL, _P])
     cnuda_adam_step = (_I, [_P] * 4 + [_LL] + [_F] * 5 + [_I, _P])
+    cnuda_prof_enable = (_I, [_I])
+    cnuda_prof_arm = (_I, [_I])
+    cnuda_prof_collect = (_I, [_P, _P, _I])
 
 
 def check(rc, what=''):
@@ -138,3 +141,62 @@ def workspace(nbytes, device):
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf
+
+
+# ---------------------------------------------------------------------------
+# kernel timer used by bench.py (hipEvents recorded inside the library around the
+# main implicit-GEMM launch of a call, on the launch stream)
+# ---------------------------------------------------------------------------
+class _Prof:
+    enabled = False
+    table = []          # tag -> (kernel name, algorithmic FLOPs of the launch)
+    cap = 0
+
+
+def _bm(m):
+    return 128 if m > 64 else (64 if m > 32 else 32)
+
+
+def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
+    """Called by the conv / DCN ops right before the C-ABI call when profiling is on."""
+    if not _Prof.enabled or len(_Prof.table) >= _Prof.cap:
+        return
+    flops = 2.0 * B * Ho * Wo * Co * C * kh * kw          # 2*Cout*Cin*kh*kw*Ho*Wo per image (SURVEY 8d)
+    fast = 'true' if C % 16 == 0 else 'false'
+    if kind == 'conv_fwd':
+        name = 'igemm_fwd_kernel<%d, ConvFwdLoader<%s>>' % (_bm(Co), fast)
+    elif kind == 'conv_dgrad':
+        name = 'igemm_fwd_kernel<%d, ConvDgradLoader<%s>>' % (_bm(C), 'true' if Co % 16 == 0 else 'false')
+    elif kind == 'conv_wgrad':
+        name = 'igemm_wgrad_kernel<ConvWLoader>'
+    elif kind == 'dcn_fwd':
+        name = 'igemm_fwd_kernel<%d, DcnFwdLoader>' % _bm(Co)
+    elif kind == 'dcn_bwd':
+        name = 'dcn_bwd_data_kernel'
+    else:
+        raise ValueError(kind)
+    _Prof.table.append((name, flops))
+    lib().cnuda_prof_arm(len(_Prof.table) - 1)
+
+
+def prof_begin(max_records=16384):
+    check(lib().cnuda_prof_enable(int(max_records)), 'prof_enable')
+    _Prof.enabled, _Prof.table, _Prof.cap = True, [], int(max_records)
+
+
+def prof_end():
+    """-> {kernel name: {'launches', 'ms', 'flops'}} and disables the timer."""
+    n = len(_Prof.table)
+    tags = (ctypes.c_int * max(n, 1))()
+    ms = (ctypes.c_float * max(n, 1))()
+    got = lib().cnuda_prof_collect(tags, ms, n)
+    out = {}
+    for i in range(got):
+        name, flops = _Prof.table[tags[i]]
+        d = out.setdefault(name, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+        d['launches'] += 1
+        d['ms'] += float(ms[i])
+        d['flops'] += flops
+    _Prof.enabled, _Prof.table = False, []
+    lib().cnuda_prof_enable(0)
+    return out

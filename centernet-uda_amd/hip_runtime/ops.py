@@ -6,7 +6,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from . import check, f32c, lib, ptr, require_gpu, stream, workspace
+from . import check, f32c, lib, prof_arm, ptr, require_gpu, stream, workspace
 
 
 def _pair(v):
@@ -42,6 +42,7 @@ class _Conv2d(Function):
         y = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=x.device)
         L = lib()
         wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g), x)
+        prof_arm('conv_fwd', B, C, H, W, Co, kh, kw, Ho, Wo)
         check(L.cnuda_conv2d_forward(ptr(x), ptr(weight), ptr(bias), ptr(y), *g, float(act_slope),
                                      wp, wn, stream()), 'conv2d_forward')
         ctx.geom, ctx.act_slope, ctx.has_bias = g, act_slope, bias is not None
@@ -61,14 +62,18 @@ class _Conv2d(Function):
             gy = t
         wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g), x)
         gx = gw = gb = None
+        B, C, H, W, Co, kh, kw = g[:7]
+        Ho, Wo = gy.shape[2], gy.shape[3]
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
+            prof_arm('conv_dgrad', B, C, H, W, Co, kh, kw, Ho, Wo)
             check(L.cnuda_conv2d_backward_data(ptr(gy), ptr(weight), ptr(gx), *g, wp, wn, stream()),
                   'conv2d_backward_data')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw = torch.empty_like(weight)
             if ctx.has_bias:
                 gb = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device)
+            prof_arm('conv_wgrad', B, C, H, W, Co, kh, kw, Ho, Wo)
             check(L.cnuda_conv2d_backward_weight(ptr(x), ptr(gy), ptr(gw), ptr(gb), *g, wp, wn, stream()),
                   'conv2d_backward_weight')
         return gx, gw, gb, None, None, None

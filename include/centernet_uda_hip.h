@@ -38,6 +38,15 @@ typedef void* cnuda_stream_t; /* hipStream_t */
 int cnuda_abi_version(void);
 const char* cnuda_last_error(void);
 
+/* Measurement aid (bench.py roofline leg), not part of the reference's surface:
+ * cnuda_prof_enable(n) pre-creates n hipEvent pairs; cnuda_prof_arm(tag) makes
+ * the NEXT convolution / DCN main-kernel launch record a start/stop pair on its
+ * own launch stream; cnuda_prof_collect synchronises on the recorded events and
+ * returns (tag, milliseconds) pairs.  Costs nothing when not armed. */
+int cnuda_prof_enable(int max_records);
+int cnuda_prof_arm(int tag);
+int cnuda_prof_collect(int* tags, float* ms, int cap);
+
 /* ------------------------------------------------------------------------
  * Detection decode -- replaces backends/decode.py:35-76 (decode_detection),
  * :6-13 (_nms), :16-32 (_topk) and the gathers of utils/tensor.py:10-25.
