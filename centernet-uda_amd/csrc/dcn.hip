@@ -31,6 +31,7 @@ struct DcnGeom {
 // bilinear fractions and which corners exist.
 struct Tap {
     int o00, o01, o10, o11;
+    int h0, w0;            // integer corner (floor of the sample position)
     float lh, lw, hh, hw;  // fractions; hh = 1-lh, hw = 1-lw
     float mask;
     bool inside, c00, c01, c10, c11;
@@ -49,6 +50,8 @@ __device__ __forceinline__ Tap make_tap(const DcnGeom& g, const float* __restric
     t.inside = (h > -1.0f) && (w > -1.0f) && (h < (float)g.H) && (w < (float)g.W);
     const float hf = floorf(h), wf = floorf(w);
     const int h0 = (int)hf, w0 = (int)wf;
+    t.h0 = h0;
+    t.w0 = w0;
     t.lh = h - hf;
     t.lw = w - wf;
     t.hh = 1.0f - t.lh;
@@ -147,127 +150,248 @@ struct DcnBwdParams {
     DcnGeom g;
     const float *in, *off, *mask, *gout;
     float *gin, *goff, *gmask;
+    int dbg;   // ablation bits for scratch experiments (0 in production)
 };
+int g_dcn_dbg = 0;
+
+// Structure: workgroup = one tile of 64 output pixels; it loops over 64-channel
+// tiles of C and, inside, over all taps.  Each of the 4 waves owns 16 channels x
+// 64 pixels (four 16x16 MFMA tiles, v_mfma_f32_16x16x4_f32), so the waves write
+// disjoint channel planes of an LDS window that covers the input rows / columns
+// the pixel tile can reach (|dy| < 2, |dx| < 1 beyond the 3x3 footprint).  The
+// bilinear scatter is a plain LDS read-add-write: within a wave LDS operations
+// execute in order, different waves touch different planes, and the only
+// remaining hazard -- two pixels of one 16-lane group landing on the same cell
+// in ONE instruction -- is detected per tap with a claim map and handled by LDS
+// atomics (measured: ds_add_f32 costs ~200 cycles per wave instruction on
+// gfx950, 50x a plain read+write, so it must stay off the common path).  The
+// window is flushed once per channel tile with coalesced global atomics (~7x
+// fewer HBM-side atomics than scattering every corner, and contiguous); corners
+// outside the window (large offsets, odd shapes) go to global memory directly.
+constexpr int DB_BM = 64, DB_BN = 64, DB_WIN = 476;   // window cells per channel (64*476*4 B = 119 KiB)
 
 __global__ __launch_bounds__(IG_THREADS) void dcn_bwd_data_kernel(DcnBwdParams p, const float* __restrict__ A2,
                                                                  int Mp2, int Kp, int Cpad, long long N, int n_tiles) {
-    constexpr int BM = 64;
-    using TL = IgTile<BM>;
-    __shared__ float As[IG_BK * BM];
-    __shared__ float Bs[IG_BK * IG_BN];
-    __shared__ float red[3][IG_BN];
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    extern __shared__ __align__(16) float smem[];
+    float* As = smem;                          // [16][64]  (k, channel)
+    float* Bs = As + IG_BK * DB_BM;            // [16][64]  (k, pixel)
+    float* win = Bs + IG_BK * DB_BN;           // [64][WSZ]
+    float* dump = win + DB_BM * DB_WIN;        // [256] one cell per thread
+    int* claim = reinterpret_cast<int*>(dump + IG_THREADS);   // [4 waves][DB_WIN]
     const DcnGeom& g = p.g;
     const int T = g.kh * g.kw, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wg = xcd_remap(blockIdx.x, n_tiles * T);
-    const int tap = wg % T;
-    const long long n0 = (long long)(wg / T) * IG_BN;
-    const int wm = wid / TL::WN, wn = wid % TL::WN;
-    const int wm_off = wm * 32, wn_off = wn * 64;
+    const int wg = xcd_remap(blockIdx.x, n_tiles);
+    const long long n0 = (long long)wg * DB_BN;
+    const int kq = lane >> 4, il = lane & 15;   // MFMA k index / row-col index
 
-    // B-operand (gout) staging coordinates
-    const int nl = tid & (IG_BN - 1), ksub = tid >> 7;
+    // ---- window geometry (workgroup-uniform) ----
+    int wy0 = 0, wx0 = 0, WR = 0, WC = 0, tile_b = 0;
+    bool use_win = false;
+    if (HoWo % DB_BN == 0) {
+        tile_b = (int)(n0 / HoWo);
+        const int p0 = (int)(n0 - (long long)tile_b * HoWo), p1 = p0 + DB_BN - 1;
+        const int y0 = p0 / g.Wo, y1 = p1 / g.Wo;
+        int x0 = p0 - y0 * g.Wo, x1 = p1 - y1 * g.Wo;
+        if (y1 != y0) { x0 = 0; x1 = g.Wo - 1; }
+        wy0 = y0 * g.sh - g.ph - 2;
+        WR = (y1 - y0) * g.sh + (g.kh - 1) * g.dh + 5;
+        wx0 = x0 * g.sw - g.pw - 1;
+        WC = (x1 - x0) * g.sw + (g.kw - 1) * g.dw + 3;
+        if (wy0 < 0) { WR += wy0; wy0 = 0; }
+        if (wx0 < 0) { WC += wx0; wx0 = 0; }
+        if (wy0 + WR > g.H) WR = g.H - wy0;
+        if (wx0 + WC > g.W) WC = g.W - wx0;
+        use_win = WR > 0 && WC > 0 && WR * WC <= DB_WIN && (WR + 1) * (WC + 1) <= DB_WIN + 128;
+    }
+    const int WSZ = use_win ? WR * WC : 0;
+
+    // ---- B-operand (gout) staging: pixel = tid & 63, k phase = tid >> 6 ----
+    const int nl = tid & (DB_BN - 1), ksub = tid >> 6;
     const long long nb = n0 + nl;
     const bool nb_valid = nb < N;
     const int bb = nb_valid ? (int)(nb / HoWo) : 0;
     const int pb = nb_valid ? (int)(nb - (long long)bb * HoWo) : 0;
     const float* gout_b = p.gout + (size_t)bb * g.Co * HoWo + pb;
 
-    // epilogue coordinates: this lane's two pixels
-    Tap tp[2];
-    bool pv[2];
-    const float* in_b[2];
-    float* gin_b[2];
-    float gm[2] = {0.f, 0.f}, gh[2] = {0.f, 0.f}, gw[2] = {0.f, 0.f};
+    // ---- epilogue coordinates: lane owns pixel (j*16 + il) of each of the four 16-pixel tiles ----
+    bool pv[4];
+    int eb[4], ep[4], eoy[4], eox[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const long long n = n0 + wn_off + j * 32 + (lane & 31);
-        pv[j] = n < N;
-        const long long nn = pv[j] ? n : 0;
-        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
-        const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
-        tp[j] = make_tap(g, p.off + (size_t)b * 2 * T * HoWo, p.mask + (size_t)b * T * HoWo, 0, tap, oy, ox);
-        in_b[j] = p.in + (size_t)b * g.C * HW;
-        gin_b[j] = p.gin + (size_t)b * g.C * HW;
+    for (int j = 0; j < 4; ++j) {
+        const long long ne = n0 + j * 16 + il;
+        pv[j] = ne < N;
+        eb[j] = pv[j] ? (int)(ne / HoWo) : 0;
+        ep[j] = pv[j] ? (int)(ne - (long long)eb[j] * HoWo) : 0;
+        eoy[j] = ep[j] / g.Wo;
+        eox[j] = ep[j] - eoy[j] * g.Wo;
     }
+    int* my_claim = claim + wid * (DB_WIN + 128);
+    const int dcell = (int)(dump - win) + tid;
 
-    for (int c0 = 0; c0 < Cpad; c0 += BM) {
-        f32x16 acc[1][2];
+    for (int i = tid; i < DB_BM * WSZ; i += IG_THREADS) win[i] = 0.0f;
+
+    for (int c0 = 0; c0 < Cpad; c0 += DB_BM) {
+#pragma unroll 1
+        for (int tap = 0; tap < T; ++tap) {
+            f32x4 acc[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.0f;
-        const int mbase = tap * Cpad + c0;
-        for (int k0 = 0; k0 < Kp; k0 += IG_BK) {
-            float ra[BM / 16], rb[8];
-            ig_load_a<BM>(A2, Mp2, k0, mbase, tid, ra);
+                for (int r = 0; r < 4; ++r) acc[j][r] = 0.0f;
+            const int mbase = tap * Cpad + c0;
+            float ra[4], rb[4];
+            auto stage_load = [&](int k0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int o = k0 + ksub + 2 * j;
-                rb[j] = (nb_valid && o < g.Co) ? gout_b[(size_t)o * HoWo] : 0.0f;
+                for (int i = 0; i < 4; ++i) {
+                    const int e = tid + i * IG_THREADS;
+                    ra[i] = A2[(size_t)(k0 + (e >> 6)) * Mp2 + mbase + (e & 63)];
+                    const int o = k0 + ksub + 4 * i;
+                    rb[i] = (nb_valid && o < g.Co) ? gout_b[(size_t)o * HoWo] : 0.0f;
+                }
+            };
+            stage_load(0);
+            for (int k0 = 0; k0 < Kp; k0 += IG_BK) {
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    As[tid + i * IG_THREADS] = ra[i];
+                    Bs[(ksub + 4 * i) * DB_BN + nl] = rb[i];
+                }
+                __syncthreads();
+                if (k0 + IG_BK < Kp) stage_load(k0 + IG_BK);
+#pragma unroll
+                for (int kk = 0; kk < IG_BK; kk += 4) {
+                    const float a = As[(kk + kq) * DB_BM + wid * 16 + il];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float b = Bs[(kk + kq) * DB_BN + j * 16 + il];
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- consume the dcol tile: lane holds channels cl = wid*16 + kq*4 + r (r<4) of pixel j*16+il ----
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const Tap t = make_tap(g, p.off + (size_t)eb[j] * 2 * T * HoWo, p.mask + (size_t)eb[j] * T * HoWo, 0,
+                                       tap, eoy[j], eox[j]);
+                const bool live = pv[j] && t.inside;
+                const int h0 = t.h0 - wy0, w0 = t.w0 - wx0;
+                const bool r0 = use_win && h0 >= 0 && h0 < WR, r1 = use_win && h0 + 1 >= 0 && h0 + 1 < WR;
+                const bool q0 = w0 >= 0 && w0 < WC, q1 = w0 + 1 >= 0 && w0 + 1 < WC;
+                const bool a00 = live && t.c00, a01 = live && t.c01, a10 = live && t.c10, a11 = live && t.c11;
+                const bool i00 = a00 && r0 && q0, i01 = a01 && r0 && q1, i10 = a10 && r1 && q0, i11 = a11 && r1 && q1;
+                const int l00 = i00 ? h0 * WC + w0 : -1, l01 = i01 ? h0 * WC + w0 + 1 : -1;
+                const int l10 = i10 ? (h0 + 1) * WC + w0 : -1, l11 = i11 ? (h0 + 1) * WC + w0 + 1 : -1;
+                const float k00 = a00 ? t.hh * t.hw : 0.f, k01 = a01 ? t.hh * t.lw : 0.f;
+                const float k10 = a10 ? t.lh * t.hw : 0.f, k11 = a11 ? t.lh * t.lw : 0.f;
+                const float mk = live ? t.mask : 0.f;
+                const int o00 = a00 ? t.o00 : 0, o01 = a01 ? t.o01 : 0, o10 = a10 ? t.o10 : 0, o11 = a11 ? t.o11 : 0;
+                const float* in_b = p.in + (size_t)eb[j] * g.C * HW;
+                // collision check: do two pixels of this 16-lane group share a window cell?  The four
+                // corner cells of a pixel are a fixed pattern around (h0, w0), so comparing the anchor
+                // cell of every in-window pixel is enough.  kq == 0 lanes vote (all kq see the same pixels).
+                const int anchor = (live && use_win && h0 >= -1 && h0 < WR && w0 >= -1 && w0 < WC)
+                                       ? (h0 + 1) * (WC + 1) + (w0 + 1) : -1;   // (WR+1) x (WC+1) grid incl. the -1 row/col
+                float v00[4], v01[4], v10[4], v11[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int c = c0 + wid * 16 + kq * 4 + r;
+                    c = c < g.C ? c : g.C - 1;                       // padded rows carry dcol == 0
+                    const float* plane = in_b + (size_t)c * HW;
+                    v00[r] = plane[o00]; v01[r] = plane[o01]; v10[r] = plane[o10]; v11[r] = plane[o11];
+                }
+                float sm = 0.f, sh_ = 0.f, sw_ = 0.f;
+                float dmv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cl = wid * 16 + kq * 4 + r;
+                    const float d = (c0 + cl < g.C) ? acc[j][r] : 0.0f;
+                    const float e00 = a00 ? v00[r] : 0.f, e01 = a01 ? v01[r] : 0.f;
+                    const float e10 = a10 ? v10[r] : 0.f, e11 = a11 ? v11[r] : 0.f;
+                    sm += d * (t.hh * t.hw * e00 + t.hh * t.lw * e01 + t.lh * t.hw * e10 + t.lh * t.lw * e11);
+                    const float dm = d * mk;
+                    dmv[r] = dm;
+                    sh_ += (-t.hw * e00 - t.lw * e01 + t.hw * e10 + t.lw * e11) * dm;
+                    sw_ += (-t.hh * e00 + t.hh * e01 - t.lh * e10 + t.lh * e11) * dm;
+                }
+                // scatter: one corner at a time; the four channels of a corner hit four different planes
+                // (independent); consecutive corners may hit a neighbouring lane's previous cell, so the
+                // compiler must keep LDS program order between them (the hardware does, per wave).
+                // Pixels of this 16-lane group that share an anchor cell would collide inside ONE
+                // instruction: they are serialised by rounds -- every pending pixel claims its anchor,
+                // the pixel whose id survives in the claim map scatters, the others retry.
+                const int wb0 = (wid * 16 + kq * 4) * WSZ;
+                bool pending = true;
+                volatile int* vc = my_claim;
+                do {
+                    bool won = pending;
+                    if (kq == 0 && pending && anchor >= 0) vc[anchor] = il;
+                    if (kq == 0 && pending && anchor >= 0) won = vc[anchor] == il;
+                    won = __shfl((int)won, il, 64) != 0;          // the kq == 0 lane of this pixel decides
+                    won = won && pending;
+                    auto scatter = [&](int l, float k) {
+                        const bool on = won && l >= 0;
+                        float* base = win + (on ? wb0 + l : dcell);
+                        const int stride = on ? WSZ : 0;
+                        float cur[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) cur[r] = base[r * stride];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) base[r * stride] = cur[r] + (on ? k * dmv[r] : 0.f);
+                        asm volatile("" ::: "memory");
+                    };
+                    asm volatile("" ::: "memory");
+                    scatter(l00, k00);
+                    scatter(l01, k01);
+                    scatter(l10, k10);
+                    scatter(l11, k11);
+                    pending = pending && !won;
+                } while (__any(pending));
+                // rare: an existing corner outside the window -> global atomics
+                const bool spill = (a00 && !i00) || (a01 && !i01) || (a10 && !i10) || (a11 && !i11);
+                if (__any(spill)) {
+                    if (spill) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = c0 + wid * 16 + kq * 4 + r;
+                            if (c >= g.C) continue;
+                            const float dm = acc[j][r] * mk;
+                            float* gplane = p.gin + ((size_t)eb[j] * g.C + c) * HW;
+                            if (a00 && !i00) atomicAdd(gplane + o00, k00 * dm);
+                            if (a01 && !i01) atomicAdd(gplane + o01, k01 * dm);
+                            if (a10 && !i10) atomicAdd(gplane + o10, k10 * dm);
+                            if (a11 && !i11) atomicAdd(gplane + o11, k11 * dm);
+                        }
+                    }
+                }
+                // sums over this wave's 16 channels: 4 in-lane + the four kq groups
+                sm += __shfl_xor(sm, 16, 64);  sm += __shfl_xor(sm, 32, 64);
+                sh_ += __shfl_xor(sh_, 16, 64); sh_ += __shfl_xor(sh_, 32, 64);
+                sw_ += __shfl_xor(sw_, 16, 64); sw_ += __shfl_xor(sw_, 32, 64);
+                if (kq == 0 && live) {
+                    atomicAdd(p.gmask + ((size_t)eb[j] * T + tap) * HoWo + ep[j], sm);
+                    atomicAdd(p.goff + ((size_t)eb[j] * 2 * T + 2 * tap) * HoWo + ep[j], sh_);
+                    atomicAdd(p.goff + ((size_t)eb[j] * 2 * T + 2 * tap + 1) * HoWo + ep[j], sw_);
+                }
+            }
+        }
+        // ---- flush this channel tile's window ----
+        if (use_win) {
+            __syncthreads();
+            for (int i = tid; i < DB_BM * WSZ; i += IG_THREADS) {
+                const float v = win[i];
+                if (v != 0.0f) {
+                    const int cl = i / WSZ, pos = i - cl * WSZ;
+                    const int yy = pos / WC, xx = pos - yy * WC;
+                    const int c = c0 + cl;
+                    if (c < g.C)
+                        atomicAdd(p.gin + ((size_t)tile_b * g.C + c) * HW + (size_t)(wy0 + yy) * g.W + wx0 + xx, v);
+                    win[i] = 0.0f;
+                }
             }
             __syncthreads();
-            ig_store_a<BM>(As, tid, ra);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) Bs[(ksub + 2 * j) * IG_BN + nl] = rb[j];
-            __syncthreads();
-            ig_mma_chunk<BM>(As, Bs, acc, wm_off, wn_off, lane);
-        }
-        // consume the dcol tile straight from the accumulators
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (!pv[j] || !tp[j].inside) continue;
-            const Tap& t = tp[j];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = c0 + wm_off + mfma_row(r, lane);
-                if (c >= g.C) continue;
-                const float d = acc[0][j][r];
-                const float* plane = in_b[j] + (size_t)c * HW;
-                float v00, v01, v10, v11;
-                tap_corners(t, plane, v00, v01, v10, v11);
-                gm[j] += d * tap_sample(t, v00, v01, v10, v11);
-                const float dm = d * t.mask;
-                // d(sample)/dy and /dx (dmcn_get_coordinate_weight, im2col_cuda.cu:82-123)
-                gh[j] += (-t.hw * v00 - t.lw * v01 + t.hw * v10 + t.lw * v11) * dm;
-                gw[j] += (-t.hh * v00 + t.hh * v01 - t.lh * v10 + t.lh * v11) * dm;
-                float* gplane = gin_b[j] + (size_t)c * HW;
-                if (t.c00) atomicAdd(gplane + t.o00, t.hh * t.hw * dm);
-                if (t.c01) atomicAdd(gplane + t.o01, t.hh * t.lw * dm);
-                if (t.c10) atomicAdd(gplane + t.o10, t.lh * t.hw * dm);
-                if (t.c11) atomicAdd(gplane + t.o11, t.lh * t.lw * dm);
-            }
-        }
-    }
-    // sum over the two row halves of the lane pair (l, l+32), then over the two
-    // wave rows through LDS; one plain store per (pixel, tap).
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        gm[j] += __shfl_xor(gm[j], 32, 64);
-        gh[j] += __shfl_xor(gh[j], 32, 64);
-        gw[j] += __shfl_xor(gw[j], 32, 64);
-    }
-    __syncthreads();
-    if (wm == 1 && lane < 32) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = wn_off + j * 32 + lane;
-            red[0][col] = gm[j];
-            red[1][col] = gh[j];
-            red[2][col] = gw[j];
-        }
-    }
-    __syncthreads();
-    if (wm == 0 && lane < 32) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = wn_off + j * 32 + lane;
-            const long long n = n0 + col;
-            if (n >= N) continue;
-            const int b = (int)(n / HoWo), pp = (int)(n - (long long)b * HoWo);
-            p.gmask[((size_t)b * T + tap) * HoWo + pp] = gm[j] + red[0][col];
-            p.goff[((size_t)b * 2 * T + 2 * tap) * HoWo + pp] = gh[j] + red[1][col];
-            p.goff[((size_t)b * 2 * T + 2 * tap + 1) * HoWo + pp] = gw[j] + red[2][col];
         }
     }
 }
@@ -450,6 +574,8 @@ DcnPlan make_plan(const DcnGeom& g) {
 
 using namespace cnuda;
 
+extern "C" int cnuda_debug_dcn(int v) { g_dcn_dbg = v; return 0; }
+
 extern "C" size_t cnuda_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw,
                                                int ph, int pw, int dh, int dw, int dg) {
     DcnGeom g;
@@ -528,10 +654,22 @@ extern "C" int cnuda_dcn_v2_backward(const float* input, const float* weight, co
     // (1) column gradient + offset / mask / input gradients
     launch_pack(weight, A2, Cout, C, q.T, PACK_DCOL, q.Kp2, q.Mp2, q.Cpad, st);
     {
-        DcnBwdParams p{g, input, offset, mask, grad_output, grad_input, grad_offset, grad_mask};
-        const int n_tiles = ceil_div(q.N, IG_BN);
+        DcnBwdParams p{g, input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g_dcn_dbg};
+        const int n_tiles = ceil_div(q.N, DB_BN);
+        // grad_offset / grad_mask are summed over channel tiles and waves with a few atomics per pixel
+        (void)hipMemsetAsync(grad_offset, 0, (size_t)B * 2 * T * HoWo * sizeof(float), st);
+        (void)hipMemsetAsync(grad_mask, 0, (size_t)B * T * HoWo * sizeof(float), st);
+        // As + Bs + window + dump cells + claim grids (4 waves x (WR+1)*(WC+1) <= DB_WIN + 128 ints)
+        const size_t lds = (size_t)(IG_BK * DB_BM + IG_BK * DB_BN + DB_BM * DB_WIN + IG_THREADS + 4 * (DB_WIN + 128)) *
+                           sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_bwd_data_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
         ProfScope prof(st);
-        hipLaunchKernelGGL(dcn_bwd_data_kernel, dim3(n_tiles * q.T), dim3(IG_THREADS), 0, st, p, A2, q.Mp2, q.Kp2,
+        hipLaunchKernelGGL(dcn_bwd_data_kernel, dim3(n_tiles), dim3(IG_THREADS), lds, st, p, A2, q.Mp2, q.Kp2,
                            q.Cpad, q.N, n_tiles);
         if (int rc = check_launch("cnuda_dcn_v2_backward(data)")) return rc;
     }
