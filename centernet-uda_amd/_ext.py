@@ -27,7 +27,7 @@ def _out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw):
 
 
 def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w,
-                   pad_h, pad_w, dilation_h, dilation_w, deformable_group):
+                   pad_h, pad_w, dilation_h, dilation_w, deformable_group, _want_columns=False):
     hr.require_gpu(input, weight, bias, offset, mask)
     input, weight, bias, offset, mask = [hr.f32c(t) for t in (input, weight, bias, offset, mask)]
     B, C, H, W, Co = _shapes(input, weight, offset, mask, kernel_h, kernel_w, deformable_group)
@@ -40,19 +40,22 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
     geom = (B, C, H, W, Co, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
             dilation_h, dilation_w, deformable_group)
     out = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=input.device)
+    cols = None
+    if _want_columns and deformable_group == 1:
+        cols = torch.empty((B, T * C, Ho * Wo), dtype=torch.float32, device=input.device)
     L = hr.lib()
     nbytes = L.cnuda_dcn_v2_workspace_bytes(*geom)
     ws = hr.workspace(nbytes, input.device)
     if deformable_group == 1:
         hr.prof_arm('dcn_fwd', B, C, H, W, Co, kernel_h, kernel_w, Ho, Wo)
-    hr.check(L.cnuda_dcn_v2_forward(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
-                                    hr.ptr(out), *geom, hr.ptr(ws), ws.numel(), hr.stream()),
+    hr.check(L.cnuda_dcn_v2_forward_cols(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
+                                         hr.ptr(out), hr.ptr(cols), *geom, hr.ptr(ws), ws.numel(), hr.stream()),
              'dcn_v2_forward')
-    return out
+    return (out, cols) if _want_columns else out
 
 
 def dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h, stride_w,
-                    pad_h, pad_w, dilation_h, dilation_w, deformable_group):
+                    pad_h, pad_w, dilation_h, dilation_w, deformable_group, _columns=None):
     hr.require_gpu(input, weight, bias, offset, mask, grad_output)
     input, weight, bias, offset, mask, grad_output = [
         hr.f32c(t) for t in (input, weight, bias, offset, mask, grad_output)]
@@ -65,8 +68,8 @@ def dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kernel_h, ke
     ws = hr.workspace(nbytes, input.device)
     if deformable_group == 1:
         hr.prof_arm('dcn_bwd', B, C, H, W, Co, kernel_h, kernel_w, grad_output.shape[2], grad_output.shape[3])
-    hr.check(L.cnuda_dcn_v2_backward(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
-                                     hr.ptr(grad_output), *[hr.ptr(g) for g in grads], *geom,
+    hr.check(L.cnuda_dcn_v2_backward_cols(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
+                                     hr.ptr(grad_output), hr.ptr(_columns), *[hr.ptr(g) for g in grads], *geom,
                                      hr.ptr(ws), ws.numel(), hr.stream()),
              'dcn_v2_backward')
     return grads        # [grad_input, grad_offset, grad_mask, grad_weight, grad_bias]

@@ -30,6 +30,7 @@ struct ConvFwdParams {
 template <bool FAST>
 struct ConvFwdLoader {
     using Params = ConvFwdParams;
+    static constexpr bool kHasSideOutput = false;
     const ConvGeom& g;
     const float* x_b;
     int iy0, ix0;
@@ -94,6 +95,7 @@ struct ConvDgradParams {
 template <bool FAST>
 struct ConvDgradLoader {
     using Params = ConvDgradParams;
+    static constexpr bool kHasSideOutput = false;
     const ConvGeom& g;
     const float* gy_b;
     int iy, ix;
@@ -179,6 +181,17 @@ struct ConvWLoader {
         const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
         const int iy0 = oy * g.sh - g.ph, ix0 = ox * g.sw - g.pw;
         const float* x_b = p.x + (size_t)b * g.C * HW;
+        if (g.C % WG_BJ == 0) {
+            // the 64 columns of this workgroup share one tap: one bounds test, no per-element division
+            const int tap = j0 / g.C, c0 = j0 - tap * g.C + jsub;
+            const int r = tap / g.kw, s = tap - r * g.kw;
+            const int iy = iy0 + r, ix = ix0 + s;
+            const bool ok1 = valid && j0 < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            const float* ptr = x_b + (size_t)c0 * HW + (ok1 ? iy * g.W + ix : 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = ok1 ? ptr[(size_t)(4 * i) * HW] : 0.0f;
+            return;
+        }
         int cur = -1, off = 0;
         bool ok = false;
 #pragma unroll
@@ -211,7 +224,13 @@ int fill_geom(ConvGeom& g, int B, int C, int H, int W, int Co, int kh, int kw, i
     return 0;
 }
 
-int pick_bm(int M) { return M > 64 ? 128 : (M > 32 ? 64 : 32); }
+// largest tile that still gives the chip >= ~2 workgroups per CU (small feature maps: 16x16 / 32x32)
+int pick_bm(int M, long long N) {
+    int bm = M > 64 ? 128 : (M > 32 ? 64 : 32);
+    const long long n_tiles = (N + IG_BN - 1) / IG_BN;
+    while (bm > 32 && n_tiles * ((M + bm - 1) / bm) < 512) bm >>= 1;
+    return bm;
+}
 
 struct ConvPlan {
     int T;
@@ -224,10 +243,10 @@ struct ConvPlan {
 ConvPlan make_plan(const ConvGeom& g) {
     ConvPlan q;
     q.T = g.kh * g.kw;
-    q.Kf = q.T * g.C;   q.Kpf = round_up(q.Kf, IG_BK);  q.bmf = pick_bm(g.Co);  q.Mpf = round_up(g.Co, q.bmf);
-    q.Kd = q.T * g.Co;  q.Kpd = round_up(q.Kd, IG_BK);  q.bmd = pick_bm(g.C);   q.Mpd = round_up(g.C, q.bmd);
     q.Nf = (long long)g.B * g.Ho * g.Wo;
     q.Nd = (long long)g.B * g.H * g.W;
+    q.Kf = q.T * g.C;   q.Kpf = round_up(q.Kf, IG_BK);  q.bmf = pick_bm(g.Co, q.Nf);  q.Mpf = round_up(g.Co, q.bmf);
+    q.Kd = q.T * g.Co;  q.Kpd = round_up(q.Kd, IG_BK);  q.bmd = pick_bm(g.C, q.Nd);   q.Mpd = round_up(g.C, q.bmd);
     q.Mpw = round_up(g.Co, WG_BM);
     q.Jp = round_up(q.Kf, WG_BJ);
     const long long tiles = (long long)(q.Mpw / WG_BM) * (q.Jp / WG_BJ);
@@ -239,10 +258,11 @@ ConvPlan make_plan(const ConvGeom& g) {
     q.Z = (int)((q.Nf + q.pix_per_split - 1) / q.pix_per_split);
     q.fwd_bytes = carve_bytes((size_t)q.Kpf * q.Mpf, 4) + 256;
     q.dgrad_bytes = carve_bytes((size_t)q.Kpd * q.Mpd, 4) + 256;
-    q.wgrad_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) + 256;
+    q.wgrad_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) + carve_bytes((size_t)g.Co * g.B, 4) + 256;
     return q;
 }
 
+int g_conv_dbg = 0;
 template <class Loader>
 int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp, int Kp, int M, long long N,
                hipStream_t st, const char* who) {
@@ -250,11 +270,11 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
     ProfScope prof(st);
     if (bm == 128)
-        hipLaunchKernelGGL((igemm_fwd_kernel<128, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        hipLaunchKernelGGL((igemm_fwd_kernel<128, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles, g_conv_dbg);
     else if (bm == 64)
-        hipLaunchKernelGGL((igemm_fwd_kernel<64, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        hipLaunchKernelGGL((igemm_fwd_kernel<64, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles, g_conv_dbg);
     else
-        hipLaunchKernelGGL((igemm_fwd_kernel<32, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        hipLaunchKernelGGL((igemm_fwd_kernel<32, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles, g_conv_dbg);
     return check_launch(who);
 }
 
@@ -262,6 +282,8 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
 }  // namespace cnuda
 
 using namespace cnuda;
+
+extern "C" int cnuda_debug_conv(int v) { g_conv_dbg = v; return 0; }
 
 extern "C" size_t cnuda_conv2d_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw,
                                                int ph, int pw) {
@@ -322,6 +344,7 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
     float* slabs = cv.take<float>((size_t)q.Z * q.Mpw * q.Jp);
+    float* bsum = cv.take<float>((size_t)Cout * B);
     ConvWParams p{g, x, grad_y};
     {
         ProfScope prof(st);
@@ -330,6 +353,6 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
     }
     if (int rc = check_launch("cnuda_conv2d_backward_weight")) return rc;
     launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, st);
-    if (grad_bias) launch_channel_sum(grad_y, grad_bias, B, Cout, (long long)g.Ho * g.Wo, st);
+    if (grad_bias) launch_channel_sum(grad_y, grad_bias, B, Cout, (long long)g.Ho * g.Wo, st, bsum);
     return check_launch("cnuda_conv2d_backward_weight(reduce)");
 }

@@ -88,15 +88,22 @@ struct DcnFwdParams {
     DcnGeom g;
     const float *in, *off, *mask, *bias;
     float* out;
+    float* col;   // optional [B][T*C][Ho*Wo] side output (rows in (tap, channel) order) for the weight gradient
 };
 
 struct DcnFwdLoader {
     using Params = DcnFwdParams;
+    static constexpr bool kHasSideOutput = true;
     const DcnGeom& g;
     const float *in_b, *off_b, *mask_b;
     int oy, ox, K;
     bool valid;
-    __device__ DcnFwdLoader(const Params& p, long long n, bool n_valid) : g(p.g), valid(n_valid) {
+    int cur;   // tap whose sampling state `t` currently holds (K is tap-major: consecutive chunks share it)
+    Tap t;
+    float* col_n;     // this pixel's column in the side output (nullptr: not requested / not the first M tile)
+    int col_stride;
+    __device__ __forceinline__ void disable_col() { col_n = nullptr; }
+    __device__ DcnFwdLoader(const Params& p, long long n, bool n_valid) : g(p.g), valid(n_valid), cur(-1) {
         const int HoWo = g.Ho * g.Wo;
         const long long nn = n_valid ? n : 0;
         const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
@@ -107,10 +114,10 @@ struct DcnFwdLoader {
         off_b = p.off + (size_t)b * 2 * T * HoWo;
         mask_b = p.mask + (size_t)b * T * HoWo;
         K = T * g.C;
+        col_n = (p.col && n_valid) ? p.col + (size_t)b * K * HoWo + pp : nullptr;
+        col_stride = HoWo;
     }
     __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
-        int cur = -1;
-        Tap t;
         const int HW = g.H * g.W;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -124,6 +131,7 @@ struct DcnFwdLoader {
                     tap_corners(t, in_b + (size_t)c * HW, v00, v01, v10, v11);
                     r = tap_sample(t, v00, v01, v10, v11) * t.mask;
                 }
+                if (col_n) col_n[(size_t)k * col_stride] = r;
             }
             v[j] = r;
         }
@@ -428,6 +436,24 @@ struct DcnWLoader {
         const float* in_b = p.in + (size_t)b * g.C * HW;
         const float* off_b = p.off + (size_t)b * 2 * T * HoWo;
         const float* mask_b = p.mask + (size_t)b * T * HoWo;
+        if (g.C % WG_BJ == 0) {
+            // the 64 columns of this workgroup share one tap
+            const int tap = j0 / g.C, c0 = j0 - tap * g.C + jsub;
+            if (!valid || j0 >= K) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = 0.0f;
+                return;
+            }
+            const Tap t = make_tap(g, off_b, mask_b, 0, tap, oy, ox);
+            const float* plane = in_b + (size_t)c0 * HW;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v00, v01, v10, v11;
+                tap_corners(t, plane + (size_t)(4 * i) * HW, v00, v01, v10, v11);
+                v[i] = t.inside ? tap_sample(t, v00, v01, v10, v11) * t.mask : 0.0f;
+            }
+            return;
+        }
         int cur = -1;
         Tap t;
 #pragma unroll
@@ -444,6 +470,42 @@ struct DcnWLoader {
                 }
             }
             v[i] = r;
+        }
+    }
+};
+
+// weight gradient from the column buffer saved by the forward pass: a plain GEMM
+// gout[Co x px] * col[(tap,c) x px]^T with coalesced row reads (no resampling)
+struct DcnColWParams {
+    DcnGeom g;
+    const float *col, *gout;
+};
+struct DcnColWLoader {
+    using Params = DcnColWParams;
+    const Params& p;
+    __device__ DcnColWLoader(const Params& pp) : p(pp) {}
+    __device__ __forceinline__ void load_g(long long n, bool valid, int m0, int msub, float (&v)[16]) {
+        const DcnGeom& g = p.g;
+        const int HoWo = g.Ho * g.Wo;
+        const long long nn = valid ? n : 0;
+        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
+        const float* base = p.gout + (size_t)b * g.Co * HoWo + pp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + msub + 4 * i;
+            v[i] = (valid && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void load_b(long long n, bool valid, int j0, int jsub, float (&v)[16]) {
+        const DcnGeom& g = p.g;
+        const int HoWo = g.Ho * g.Wo, K = g.kh * g.kw * g.C;
+        const long long nn = valid ? n : 0;
+        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
+        const float* base = p.col + (size_t)b * K * HoWo + pp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = j0 + jsub + 4 * i;
+            v[i] = (valid && k < K) ? base[(size_t)k * HoWo] : 0.0f;
         }
     }
 };
@@ -534,7 +596,12 @@ int fill_geom(DcnGeom& g, int B, int C, int H, int W, int Co, int kh, int kw, in
     return 0;
 }
 
-int pick_bm(int M) { return M > 64 ? 128 : (M > 32 ? 64 : 32); }
+int pick_bm(int M, long long N) {
+    int bm = M > 64 ? 128 : (M > 32 ? 64 : 32);
+    const long long n_tiles = (N + IG_BN - 1) / IG_BN;
+    while (bm > 32 && n_tiles * ((M + bm - 1) / bm) < 512) bm >>= 1;
+    return bm;
+}
 
 struct DcnPlan {
     int T, K, Kp, bm, Mp;           // forward pack [Kp][Mp]
@@ -548,7 +615,8 @@ DcnPlan make_plan(const DcnGeom& g) {
     q.T = g.kh * g.kw;
     q.K = q.T * g.C;
     q.Kp = round_up(q.K, IG_BK);
-    q.bm = pick_bm(g.Co);
+    q.N = (long long)g.B * g.Ho * g.Wo;
+    q.bm = pick_bm(g.Co, q.N);
     q.Mp = round_up(g.Co, q.bm);
     q.Cpad = round_up(g.C, 64);
     q.Kp2 = round_up(g.Co, IG_BK);
@@ -565,7 +633,8 @@ DcnPlan make_plan(const DcnGeom& g) {
     q.pix_per_split = ((q.N + z - 1) / z + WG_BP - 1) / WG_BP * WG_BP;
     q.Z = (int)((q.N + q.pix_per_split - 1) / q.pix_per_split);
     q.fwd_bytes = carve_bytes((size_t)q.Kp * q.Mp, 4) + 256;
-    q.bwd_bytes = carve_bytes((size_t)q.Kp2 * q.Mp2, 4) + carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) + 256;
+    q.bwd_bytes = carve_bytes((size_t)q.Kp2 * q.Mp2, 4) + carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) +
+                  carve_bytes((size_t)g.Co * g.B, 4) + 256;
     return q;
 }
 
@@ -588,7 +657,17 @@ extern "C" int cnuda_dcn_v2_forward(const float* input, const float* weight, con
                                     const float* mask, float* output, int B, int C, int H, int W, int Cout, int kh,
                                     int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg, void* workspace,
                                     size_t workspace_bytes, cnuda_stream_t stream) {
+    return cnuda_dcn_v2_forward_cols(input, weight, bias, offset, mask, output, nullptr, B, C, H, W, Cout, kh, kw, sh,
+                                     sw, ph, pw, dh, dw, dg, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cnuda_dcn_v2_forward_cols(const float* input, const float* weight, const float* bias,
+                                         const float* offset, const float* mask, float* output, float* columns, int B,
+                                         int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                                         int dh, int dw, int dg, void* workspace, size_t workspace_bytes,
+                                         cnuda_stream_t stream) {
     CNUDA_REQUIRE(input && weight && bias && offset && mask && output, "cnuda_dcn_v2_forward: null pointer");
+    CNUDA_REQUIRE(!columns || dg == 1, "cnuda_dcn_v2_forward_cols: columns output needs deformable_group == 1");
     DcnGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, "cnuda_dcn_v2_forward")) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -603,7 +682,7 @@ extern "C" int cnuda_dcn_v2_forward(const float* input, const float* weight, con
     Carver cv(workspace, workspace_bytes);
     float* A = cv.take<float>((size_t)q.Kp * q.Mp);
     launch_pack(weight, A, Cout, C, q.T, PACK_FWD, q.Kp, q.Mp, 0, st);
-    DcnFwdParams p{g, input, offset, mask, bias, output};
+    DcnFwdParams p{g, input, offset, mask, bias, output, columns};
     const int n_tiles = ceil_div(q.N, IG_BN), m_tiles = q.Mp / q.bm;
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
     ProfScope prof(st);
@@ -625,6 +704,19 @@ extern "C" int cnuda_dcn_v2_backward(const float* input, const float* weight, co
                                      int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                                      int dh, int dw, int dg, void* workspace, size_t workspace_bytes,
                                      cnuda_stream_t stream) {
+    return cnuda_dcn_v2_backward_cols(input, weight, bias, offset, mask, grad_output, nullptr, grad_input, grad_offset,
+                                      grad_mask, grad_weight, grad_bias, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh,
+                                      dw, dg, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weight, const float* bias,
+                                          const float* offset, const float* mask, const float* grad_output,
+                                          const float* columns, float* grad_input, float* grad_offset,
+                                          float* grad_mask, float* grad_weight, float* grad_bias, int B, int C, int H,
+                                          int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                                          int dw, int dg, void* workspace, size_t workspace_bytes,
+                                          cnuda_stream_t stream) {
+    CNUDA_REQUIRE(!columns || dg == 1, "cnuda_dcn_v2_backward_cols: columns input needs deformable_group == 1");
     CNUDA_REQUIRE(input && weight && offset && mask && grad_output && grad_input && grad_offset && grad_mask &&
                       grad_weight && grad_bias,
                   "cnuda_dcn_v2_backward: null pointer");
@@ -635,8 +727,8 @@ extern "C" int cnuda_dcn_v2_backward(const float* input, const float* weight, co
     const int T = kh * kw, HoWo = g.Ho * g.Wo;
     if (hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), st) != hipSuccess)
         return check_launch("cnuda_dcn_v2_backward(memset)");
-    launch_channel_sum(grad_output, grad_bias, B, Cout, HoWo, st);
     if (dg != 1) {
+        launch_channel_sum(grad_output, grad_bias, B, Cout, HoWo, st);
         (void)hipMemsetAsync(grad_offset, 0, (size_t)B * dg * 2 * T * HoWo * sizeof(float), st);
         (void)hipMemsetAsync(grad_mask, 0, (size_t)B * dg * T * HoWo * sizeof(float), st);
         (void)hipMemsetAsync(grad_weight, 0, (size_t)Cout * C * T * sizeof(float), st);
@@ -651,6 +743,8 @@ extern "C" int cnuda_dcn_v2_backward(const float* input, const float* weight, co
     Carver cv(workspace, workspace_bytes);
     float* A2 = cv.take<float>((size_t)q.Kp2 * q.Mp2);
     float* slabs = cv.take<float>((size_t)q.Z * q.Mpw * q.Jp);
+    float* bsum = cv.take<float>((size_t)Cout * B);
+    launch_channel_sum(grad_output, grad_bias, B, Cout, HoWo, st, bsum);
     // (1) column gradient + offset / mask / input gradients
     launch_pack(weight, A2, Cout, C, q.T, PACK_DCOL, q.Kp2, q.Mp2, q.Cpad, st);
     {
@@ -675,9 +769,15 @@ extern "C" int cnuda_dcn_v2_backward(const float* input, const float* weight, co
     }
     // (2) weight gradient
     {
-        DcnWParams p{g, input, offset, mask, grad_output};
-        hipLaunchKernelGGL((igemm_wgrad_kernel<DcnWLoader>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z), dim3(IG_THREADS),
-                           0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+        if (columns) {
+            DcnColWParams p{g, columns, grad_output};
+            hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+                               dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+        } else {
+            DcnWParams p{g, input, offset, mask, grad_output};
+            hipLaunchKernelGGL((igemm_wgrad_kernel<DcnWLoader>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+                               dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+        }
         if (int rc = check_launch("cnuda_dcn_v2_backward(weight)")) return rc;
         launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, st);
     }

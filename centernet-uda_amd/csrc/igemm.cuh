@@ -95,7 +95,7 @@ __device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, cons
 template <int BM, class Loader>
 __global__ __launch_bounds__(IG_THREADS) void igemm_fwd_kernel(
     typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
-    int n_tiles, int m_tiles) {
+    int n_tiles, int m_tiles, int dbg = 0) {
     using T = IgTile<BM>;
     __shared__ float As[IG_BK * BM];
     __shared__ float Bs[IG_BK * IG_BN];
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_fwd_kernel(
 
     const int nl = tid & (IG_BN - 1), ksub = tid >> 7;  // pixel within tile, k parity
     Loader ld(p, n0 + nl, n0 + nl < N);
+    if constexpr (Loader::kHasSideOutput) { if (m0 != 0) ld.disable_col(); }
 
     f32x16 acc[T::TM][T::TN];
 #pragma unroll
@@ -127,9 +128,9 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_fwd_kernel(
         __syncthreads();
         if (k0 + IG_BK < Kp) {  // prefetch the next chunk under this chunk's MFMAs
             ig_load_a<BM>(A, Mp, k0 + IG_BK, m0, tid, ra);
-            ld.load(k0 + IG_BK, ksub, rb);
+            if (!(dbg & 1)) ld.load(k0 + IG_BK, ksub, rb);
         }
-        ig_mma_chunk<BM>(As, Bs, acc, wm_off, wn_off, lane);
+        if (!(dbg & 2)) ig_mma_chunk<BM>(As, Bs, acc, wm_off, wn_off, lane);
     }
     // epilogue: lane owns pixel column (lane&31) of each tile
 #pragma unroll

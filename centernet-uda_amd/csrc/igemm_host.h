@@ -22,7 +22,9 @@ void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp,
                         int Co, int C, int T, hipStream_t st);
 
 // out[c] = sum over (b, hw) of x[b][c][hw]   (bias gradients)
-void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st);
+// scratch: >= C*B floats of workspace (nullptr -> single-stage kernel)
+void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st,
+                        float* scratch = nullptr);
 
 struct Carver {
     uintptr_t cur, end;

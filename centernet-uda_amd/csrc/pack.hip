@@ -36,7 +36,32 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
     }
 }
 
-// one workgroup per channel; fixed-order tree -> reproducible
+// grid (channel, batch image): fixed-order block tree per (c, b) plane, then a second tiny kernel sums
+// the B partials in order -> reproducible, and B times more workgroups than one per channel
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x,
+                                                                  float* __restrict__ partial, int C, long long HW) {
+    __shared__ float red[16];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float* p = x + ((size_t)b * C + c) * HW;
+    float s = 0.0f;
+    if ((HW & 3) == 0) {
+        for (long long i = threadIdx.x * 4; i < HW; i += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (long long i = threadIdx.x; i < HW; i += 256) s += p[i];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[(size_t)c * gridDim.y + b] = s;
+}
+__global__ void channel_sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int B) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s += partial[(size_t)c * B + b];
+    out[c] = s;
+}
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           int B, int C, long long HW) {
     __shared__ float red[16];
@@ -65,8 +90,13 @@ void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp, in
                        C, T);
 }
 
-void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st) {
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, st, x, out, B, C, HW);
+void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st, float* scratch) {
+    if (scratch && B > 1) {
+        hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(C, B), dim3(256), 0, st, x, scratch, C, HW);
+        hipLaunchKernelGGL(channel_sum_final_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratch, out, C, B);
+    } else {
+        hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, st, x, out, B, C, HW);
+    }
 }
 
 }  // namespace cnuda

@@ -65,6 +65,8 @@ class _Sig:
     cnuda_dcn_v2_workspace_bytes = (c_size_t, [_I] * 14)
     cnuda_dcn_v2_forward = (_I, [_P] * 6 + [_I] * 14 + _WS)
     cnuda_dcn_v2_backward = (_I, [_P] * 11 + [_I] * 14 + _WS)
+    cnuda_dcn_v2_forward_cols = (_I, [_P] * 7 + [_I] * 14 + _WS)
+    cnuda_dcn_v2_backward_cols = (_I, [_P] * 12 + [_I] * 14 + _WS)
     cnuda_conv2d_workspace_bytes = (c_size_t, [_I] * 11)
     cnuda_conv2d_forward = (_I, [_P] * 4 + [_I] * 11 + [_F] + _WS)
     cnuda_conv2d_backward_data = (_I, [_P] * 3 + [_I] * 11 + _WS)

@@ -100,6 +100,28 @@ int cnuda_dcn_v2_backward(const float* input, const float* weight, const float* 
                           int sh, int sw, int ph, int pw, int dh, int dw, int dg,
                           void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 
+/* Same two operations with the sampled column buffer kept between them (the
+ * product's autograd path; deformable_group == 1 only): forward_cols stores
+ * columns[B, kh*kw*C, Ho*Wo] (rows in (tap, channel) order, mask already applied)
+ * as a side output of the implicit GEMM, backward_cols computes grad_weight as a
+ * plain GEMM grad_output x columns^T instead of re-sampling the input.  With
+ * columns == NULL both behave exactly like the entry points above.  The buffer
+ * is what the reference materialises inside every call
+ * (cuda/dcn_v2_cuda.cu:89-102); here it is written once and read once. */
+int cnuda_dcn_v2_forward_cols(const float* input, const float* weight, const float* bias,
+                              const float* offset, const float* mask, float* output, float* columns,
+                              int B, int C, int H, int W, int Cout, int kh, int kw,
+                              int sh, int sw, int ph, int pw, int dh, int dw, int dg,
+                              void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+int cnuda_dcn_v2_backward_cols(const float* input, const float* weight, const float* bias,
+                               const float* offset, const float* mask, const float* grad_output,
+                               const float* columns,
+                               float* grad_input, float* grad_offset, float* grad_mask,
+                               float* grad_weight, float* grad_bias,
+                               int B, int C, int H, int W, int Cout, int kh, int kw,
+                               int sh, int sw, int ph, int pw, int dh, int dw, int dg,
+                               void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Dense convolution (groups 1, dilation 1) -- replaces torch.nn.Conv2d -> cuDNN
  * on the hot path: backends/dla.py:37-44,153-155,234-235,281-283,478-483 (DLA
