@@ -157,36 +157,57 @@ struct ConvWParams {
     ConvGeom g;
     const float *x, *gy;
 };
+template <bool FAST>
 struct ConvWLoader {
     using Params = ConvWParams;
     const Params& p;
-    __device__ ConvWLoader(const Params& pp) : p(pp) {}
-    __device__ __forceinline__ void load_g(long long n, bool valid, int m0, int msub, float (&v)[16]) {
+    // pixel cursor: image index, pixel index inside the image, output row / column
+    long long n_, n_end_;
+    int b_, pp_, oy_, ox_;
+    bool valid_;
+    __device__ __forceinline__ void cursor_init(long long n, long long n_end, int HoWo, int Wo) {
+        n_ = n;
+        n_end_ = n_end;
+        valid_ = n < n_end;
+        const long long nn = valid_ ? n : 0;
+        b_ = (int)(nn / HoWo);
+        pp_ = (int)(nn - (long long)b_ * HoWo);
+        oy_ = pp_ / Wo;
+        ox_ = pp_ - oy_ * Wo;
+    }
+    __device__ __forceinline__ void cursor_advance(int HoWo, int Wo) {
+        n_ += WG_BP;
+        valid_ = n_ < n_end_;
+        pp_ += WG_BP;
+        ox_ += WG_BP;
+        while (ox_ >= Wo) { ox_ -= Wo; ++oy_; }
+        while (pp_ >= HoWo) { pp_ -= HoWo; ++b_; oy_ = pp_ / Wo; ox_ = pp_ - oy_ * Wo; }
+    }
+    __device__ ConvWLoader(const Params& pp, long long n, long long n_end) : p(pp) {
+        cursor_init(n, n_end, p.g.Ho * p.g.Wo, p.g.Wo);
+    }
+    __device__ __forceinline__ void advance() { cursor_advance(p.g.Ho * p.g.Wo, p.g.Wo); }
+    __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[16]) {
         const ConvGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo;
-        const long long nn = valid ? n : 0;
-        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
-        const float* base = p.gy + (size_t)b * g.Co * HoWo + pp;
+        const float* base = p.gy + (size_t)b_ * g.Co * HoWo + pp_;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = m0 + msub + 4 * i;
-            v[i] = (valid && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
+            v[i] = (valid_ && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
         }
     }
-    __device__ __forceinline__ void load_b(long long n, bool valid, int j0, int jsub, float (&v)[16]) {
+    __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[16]) {
         const ConvGeom& g = p.g;
-        const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, K = g.kh * g.kw * g.C;
-        const long long nn = valid ? n : 0;
-        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
-        const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
-        const int iy0 = oy * g.sh - g.ph, ix0 = ox * g.sw - g.pw;
-        const float* x_b = p.x + (size_t)b * g.C * HW;
-        if (g.C % WG_BJ == 0) {
+        const int HW = g.H * g.W, K = g.kh * g.kw * g.C;
+        const int iy0 = oy_ * g.sh - g.ph, ix0 = ox_ * g.sw - g.pw;
+        const float* x_b = p.x + (size_t)b_ * g.C * HW;
+        if (FAST) {
             // the 64 columns of this workgroup share one tap: one bounds test, no per-element division
             const int tap = j0 / g.C, c0 = j0 - tap * g.C + jsub;
             const int r = tap / g.kw, s = tap - r * g.kw;
             const int iy = iy0 + r, ix = ix0 + s;
-            const bool ok1 = valid && j0 < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            const bool ok1 = valid_ && j0 < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
             const float* ptr = x_b + (size_t)c0 * HW + (ok1 ? iy * g.W + ix : 0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) v[i] = ok1 ? ptr[(size_t)(4 * i) * HW] : 0.0f;
@@ -198,7 +219,7 @@ struct ConvWLoader {
         for (int i = 0; i < 16; ++i) {
             const int k = j0 + jsub + 4 * i;
             float val = 0.0f;
-            if (valid && k < K) {
+            if (valid_ && k < K) {
                 const int tap = k / g.C, c = k - tap * g.C;
                 if (tap != cur) {
                     const int r = tap / g.kw, s = tap - r * g.kw;
@@ -245,8 +266,8 @@ ConvPlan make_plan(const ConvGeom& g) {
     q.T = g.kh * g.kw;
     q.Nf = (long long)g.B * g.Ho * g.Wo;
     q.Nd = (long long)g.B * g.H * g.W;
-    q.Kf = q.T * g.C;   q.Kpf = round_up(q.Kf, IG_BK);  q.bmf = pick_bm(g.Co, q.Nf);  q.Mpf = round_up(g.Co, q.bmf);
-    q.Kd = q.T * g.Co;  q.Kpd = round_up(q.Kd, IG_BK);  q.bmd = pick_bm(g.C, q.Nd);   q.Mpd = round_up(g.C, q.bmd);
+    q.Kf = q.T * g.C;   q.Kpf = round_up(q.Kf, IG_KC);  q.bmf = pick_bm(g.Co, q.Nf);  q.Mpf = round_up(g.Co, q.bmf);
+    q.Kd = q.T * g.Co;  q.Kpd = round_up(q.Kd, IG_KC);  q.bmd = pick_bm(g.C, q.Nd);   q.Mpd = round_up(g.C, q.bmd);
     q.Mpw = round_up(g.Co, WG_BM);
     q.Jp = round_up(q.Kf, WG_BJ);
     const long long tiles = (long long)(q.Mpw / WG_BM) * (q.Jp / WG_BJ);
@@ -348,8 +369,12 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
     ConvWParams p{g, x, grad_y};
     {
         ProfScope prof(st);
-        hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z), dim3(IG_THREADS), 0,
-                           st, p, slabs, q.Mpw, q.Jp, q.Nf, q.pix_per_split);
+        if (C % WG_BJ == 0)
+            hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<true>>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+                               dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.Nf, q.pix_per_split);
+        else
+            hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<false>>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+                               dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.Nf, q.pix_per_split);
     }
     if (int rc = check_launch("cnuda_conv2d_backward_weight")) return rc;
     launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, st);

@@ -414,55 +414,57 @@ struct DcnWParams {
 struct DcnWLoader {
     using Params = DcnWParams;
     const Params& p;
-    __device__ DcnWLoader(const Params& pp) : p(pp) {}
-    __device__ __forceinline__ void load_g(long long n, bool valid, int m0, int msub, float (&v)[16]) {
+    // pixel cursor: image index, pixel index inside the image, output row / column
+    long long n_, n_end_;
+    int b_, pp_, oy_, ox_;
+    bool valid_;
+    __device__ __forceinline__ void cursor_init(long long n, long long n_end, int HoWo, int Wo) {
+        n_ = n;
+        n_end_ = n_end;
+        valid_ = n < n_end;
+        const long long nn = valid_ ? n : 0;
+        b_ = (int)(nn / HoWo);
+        pp_ = (int)(nn - (long long)b_ * HoWo);
+        oy_ = pp_ / Wo;
+        ox_ = pp_ - oy_ * Wo;
+    }
+    __device__ __forceinline__ void cursor_advance(int HoWo, int Wo) {
+        n_ += WG_BP;
+        valid_ = n_ < n_end_;
+        pp_ += WG_BP;
+        ox_ += WG_BP;
+        while (ox_ >= Wo) { ox_ -= Wo; ++oy_; }
+        while (pp_ >= HoWo) { pp_ -= HoWo; ++b_; oy_ = pp_ / Wo; ox_ = pp_ - oy_ * Wo; }
+    }
+    __device__ DcnWLoader(const Params& pp, long long n, long long n_end) : p(pp) {
+        cursor_init(n, n_end, p.g.Ho * p.g.Wo, p.g.Wo);
+    }
+    __device__ __forceinline__ void advance() { cursor_advance(p.g.Ho * p.g.Wo, p.g.Wo); }
+    __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[16]) {
         const DcnGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo;
-        const long long nn = valid ? n : 0;
-        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
-        const float* base = p.gout + (size_t)b * g.Co * HoWo + pp;
+        const float* base = p.gout + (size_t)b_ * g.Co * HoWo + pp_;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = m0 + msub + 4 * i;
-            v[i] = (valid && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
+            v[i] = (valid_ && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
         }
     }
-    __device__ __forceinline__ void load_b(long long n, bool valid, int j0, int jsub, float (&v)[16]) {
+    __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[16]) {
         const DcnGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, K = T * g.C;
-        const long long nn = valid ? n : 0;
-        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
-        const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
-        const float* in_b = p.in + (size_t)b * g.C * HW;
-        const float* off_b = p.off + (size_t)b * 2 * T * HoWo;
-        const float* mask_b = p.mask + (size_t)b * T * HoWo;
-        if (g.C % WG_BJ == 0) {
-            // the 64 columns of this workgroup share one tap
-            const int tap = j0 / g.C, c0 = j0 - tap * g.C + jsub;
-            if (!valid || j0 >= K) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = 0.0f;
-                return;
-            }
-            const Tap t = make_tap(g, off_b, mask_b, 0, tap, oy, ox);
-            const float* plane = in_b + (size_t)c0 * HW;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v00, v01, v10, v11;
-                tap_corners(t, plane + (size_t)(4 * i) * HW, v00, v01, v10, v11);
-                v[i] = t.inside ? tap_sample(t, v00, v01, v10, v11) * t.mask : 0.0f;
-            }
-            return;
-        }
+        const float* in_b = p.in + (size_t)b_ * g.C * HW;
+        const float* off_b = p.off + (size_t)b_ * 2 * T * HoWo;
+        const float* mask_b = p.mask + (size_t)b_ * T * HoWo;
         int cur = -1;
         Tap t;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int k = j0 + jsub + 4 * i;
             float r = 0.0f;
-            if (valid && k < K) {
+            if (valid_ && k < K) {
                 const int tap = k / g.C, c = k - tap * g.C;
-                if (tap != cur) { t = make_tap(g, off_b, mask_b, 0, tap, oy, ox); cur = tap; }
+                if (tap != cur) { t = make_tap(g, off_b, mask_b, 0, tap, oy_, ox_); cur = tap; }
                 if (t.inside) {
                     float v00, v01, v10, v11;
                     tap_corners(t, in_b + (size_t)c * HW, v00, v01, v10, v11);
@@ -483,29 +485,50 @@ struct DcnColWParams {
 struct DcnColWLoader {
     using Params = DcnColWParams;
     const Params& p;
-    __device__ DcnColWLoader(const Params& pp) : p(pp) {}
-    __device__ __forceinline__ void load_g(long long n, bool valid, int m0, int msub, float (&v)[16]) {
+    // pixel cursor: image index, pixel index inside the image, output row / column
+    long long n_, n_end_;
+    int b_, pp_, oy_, ox_;
+    bool valid_;
+    __device__ __forceinline__ void cursor_init(long long n, long long n_end, int HoWo, int Wo) {
+        n_ = n;
+        n_end_ = n_end;
+        valid_ = n < n_end;
+        const long long nn = valid_ ? n : 0;
+        b_ = (int)(nn / HoWo);
+        pp_ = (int)(nn - (long long)b_ * HoWo);
+        oy_ = pp_ / Wo;
+        ox_ = pp_ - oy_ * Wo;
+    }
+    __device__ __forceinline__ void cursor_advance(int HoWo, int Wo) {
+        n_ += WG_BP;
+        valid_ = n_ < n_end_;
+        pp_ += WG_BP;
+        ox_ += WG_BP;
+        while (ox_ >= Wo) { ox_ -= Wo; ++oy_; }
+        while (pp_ >= HoWo) { pp_ -= HoWo; ++b_; oy_ = pp_ / Wo; ox_ = pp_ - oy_ * Wo; }
+    }
+    __device__ DcnColWLoader(const Params& pp, long long n, long long n_end) : p(pp) {
+        cursor_init(n, n_end, p.g.Ho * p.g.Wo, p.g.Wo);
+    }
+    __device__ __forceinline__ void advance() { cursor_advance(p.g.Ho * p.g.Wo, p.g.Wo); }
+    __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[16]) {
         const DcnGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo;
-        const long long nn = valid ? n : 0;
-        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
-        const float* base = p.gout + (size_t)b * g.Co * HoWo + pp;
+        const float* base = p.gout + (size_t)b_ * g.Co * HoWo + pp_;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = m0 + msub + 4 * i;
-            v[i] = (valid && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
+            v[i] = (valid_ && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
         }
     }
-    __device__ __forceinline__ void load_b(long long n, bool valid, int j0, int jsub, float (&v)[16]) {
+    __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[16]) {
         const DcnGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo, K = g.kh * g.kw * g.C;
-        const long long nn = valid ? n : 0;
-        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
-        const float* base = p.col + (size_t)b * K * HoWo + pp;
+        const float* base = p.col + (size_t)b_ * K * HoWo + pp_;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int k = j0 + jsub + 4 * i;
-            v[i] = (valid && k < K) ? base[(size_t)k * HoWo] : 0.0f;
+            v[i] = (valid_ && k < K) ? base[(size_t)k * HoWo] : 0.0f;
         }
     }
 };
@@ -614,7 +637,7 @@ DcnPlan make_plan(const DcnGeom& g) {
     DcnPlan q;
     q.T = g.kh * g.kw;
     q.K = q.T * g.C;
-    q.Kp = round_up(q.K, IG_BK);
+    q.Kp = round_up(q.K, IG_KC);
     q.N = (long long)g.B * g.Ho * g.Wo;
     q.bm = pick_bm(g.Co, q.N);
     q.Mp = round_up(g.Co, q.bm);

@@ -24,7 +24,8 @@ namespace cnuda {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int IG_BN = 128;
-constexpr int IG_BK = 16;
+constexpr int IG_BK = 16;   // K granularity of the loaders / packing
+constexpr int IG_KC = 32;   // K depth staged in LDS per barrier pair (two loader calls)
 constexpr int IG_THREADS = 256;
 
 template <int BM> struct IgTile;
@@ -55,7 +56,7 @@ __device__ __forceinline__ void ig_mma_chunk(const float* __restrict__ As, const
     using T = IgTile<BM>;
     const int kl = lane >> 5, il = lane & 31;
 #pragma unroll
-    for (int kk = 0; kk < IG_BK; kk += 2) {
+    for (int kk = 0; kk < IG_KC; kk += 2) {
         float a[T::TM], b[T::TN];
 #pragma unroll
         for (int i = 0; i < T::TM; ++i) a[i] = As[(kk + kl) * BM + wm_off + i * 32 + il];
@@ -72,19 +73,19 @@ __device__ __forceinline__ void ig_mma_chunk(const float* __restrict__ As, const
 // Stage the A tile rows [k0, k0+BK) x cols [m0, m0+BM) of the packed matrix.
 template <int BM>
 __device__ __forceinline__ void ig_load_a(const float* __restrict__ A, int Mp, int k0, int m0, int tid,
-                                          float (&r)[BM / 16]) {
-    // BK*BM floats over 256 threads; consecutive threads -> consecutive m
+                                          float (&r)[BM / 8]) {
+    // KC*BM floats over 256 threads; consecutive threads -> consecutive m
 #pragma unroll
-    for (int i = 0; i < BM / 16; ++i) {
+    for (int i = 0; i < BM / 8; ++i) {
         const int e = tid + i * IG_THREADS;
         const int kk = e / BM, m = e % BM;
         r[i] = A[(size_t)(k0 + kk) * Mp + m0 + m];
     }
 }
 template <int BM>
-__device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, const float (&r)[BM / 16]) {
+__device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, const float (&r)[BM / 8]) {
 #pragma unroll
-    for (int i = 0; i < BM / 16; ++i) As[tid + i * IG_THREADS] = r[i];
+    for (int i = 0; i < BM / 8; ++i) As[tid + i * IG_THREADS] = r[i];
 }
 
 // Generic forward-type kernel.  Loader contract:
@@ -97,8 +98,8 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_fwd_kernel(
     typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
     int n_tiles, int m_tiles, int dbg = 0) {
     using T = IgTile<BM>;
-    __shared__ float As[IG_BK * BM];
-    __shared__ float Bs[IG_BK * IG_BN];
+    __shared__ float As[IG_KC * BM];
+    __shared__ float Bs[IG_KC * IG_BN];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wg = xcd_remap(blockIdx.x, n_tiles * m_tiles);
     const int m0 = (wg % m_tiles) * BM;
@@ -117,18 +118,26 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_fwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    float ra[BM / 16], rb[8];
+    // Kp is a multiple of IG_KC (the pack kernels zero-pad); the loaders return 0 past the real K
+    float ra[BM / 8], rb0[8], rb1[8];
     ig_load_a<BM>(A, Mp, 0, m0, tid, ra);
-    ld.load(0, ksub, rb);
-    for (int k0 = 0; k0 < Kp; k0 += IG_BK) {
+    ld.load(0, ksub, rb0);
+    ld.load(IG_BK, ksub, rb1);
+    for (int k0 = 0; k0 < Kp; k0 += IG_KC) {
         __syncthreads();  // previous chunk's fragment reads are done
         ig_store_a<BM>(As, tid, ra);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Bs[(ksub + 2 * j) * IG_BN + nl] = rb[j];
+        for (int j = 0; j < 8; ++j) {
+            Bs[(ksub + 2 * j) * IG_BN + nl] = rb0[j];
+            Bs[(IG_BK + ksub + 2 * j) * IG_BN + nl] = rb1[j];
+        }
         __syncthreads();
-        if (k0 + IG_BK < Kp) {  // prefetch the next chunk under this chunk's MFMAs
-            ig_load_a<BM>(A, Mp, k0 + IG_BK, m0, tid, ra);
-            if (!(dbg & 1)) ld.load(k0 + IG_BK, ksub, rb);
+        if (k0 + IG_KC < Kp) {  // prefetch the next chunk under this chunk's MFMAs
+            ig_load_a<BM>(A, Mp, k0 + IG_KC, m0, tid, ra);
+            if (!(dbg & 1)) {
+                ld.load(k0 + IG_KC, ksub, rb0);
+                ld.load(k0 + IG_KC + IG_BK, ksub, rb1);
+            }
         }
         if (!(dbg & 2)) ig_mma_chunk<BM>(As, Bs, acc, wm_off, wn_off, lane);
     }
@@ -156,10 +165,11 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_fwd_kernel(
 // reproducible, no float atomics).
 // Tile 64(m) x 64(j), 64 pixels per chunk; LDS images are [pixel][m|j] with an
 // odd row stride so that the pixel-major stores are conflict-free.
-// Loader contract (WLoader):
-//   WLoader(const Params&)                                  per-thread state
-//   void load_b(long long n, bool valid, int j0, int jsub, float (&v)[16])   v[i] = B[j0 + jsub + 4i][n]
-//   void load_g(long long n, bool valid, int m0, int msub, float (&v)[16])   v[i] = G[m0 + msub + 4i][n]
+// Loader contract (WLoader): per-thread cursor over the pixel axis
+//   WLoader(const Params&, long long n, long long n_end)   cursor at pixel n (one-time integer divisions)
+//   void advance()                                          move the cursor WG_BP pixels forward (no division)
+//   void load_b(int j0, int jsub, float (&v)[16])           v[i] = B[j0 + jsub + 4i][cursor]  (0 past n_end)
+//   void load_g(int m0, int msub, float (&v)[16])           v[i] = G[m0 + msub + 4i][cursor]
 // ---------------------------------------------------------------------------
 constexpr int WG_BM = 64, WG_BJ = 64, WG_BP = 64, WG_LD = 65;
 
@@ -175,16 +185,13 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
     if (n_end > N) n_end = N;
     const int pl = tid & 63, sub = tid >> 6;  // pixel within chunk, row phase (0..3)
     const int wm_off = (wid >> 1) * 32, wj_off = (wid & 1) * 32;
-    WLoader ld(p);
+    WLoader ld(p, n_begin + pl, n_end);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     float rg[16], rb[16];
-    {
-        const long long n = n_begin + pl;
-        ld.load_g(n, n < n_end, m0, sub, rg);
-        ld.load_b(n, n < n_end, j0, sub, rb);
-    }
+    ld.load_g(m0, sub, rg);
+    ld.load_b(j0, sub, rb);
     for (long long nb = n_begin; nb < n_end; nb += WG_BP) {
         __syncthreads();
 #pragma unroll
@@ -194,9 +201,9 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
         }
         __syncthreads();
         if (nb + WG_BP < n_end) {
-            const long long n = nb + WG_BP + pl;
-            ld.load_g(n, n < n_end, m0, sub, rg);
-            ld.load_b(n, n < n_end, j0, sub, rb);
+            ld.advance();
+            ld.load_g(m0, sub, rg);
+            ld.load_b(j0, sub, rb);
         }
         const int kl = lane >> 5, il = lane & 31;
 #pragma unroll
