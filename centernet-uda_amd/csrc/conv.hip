@@ -152,12 +152,72 @@ struct ConvDgradLoader {
     };
 };
 
+// Input gradient for stride > 1, one launch per parity class (py, px) of the input pixel: inside a class
+// the set of taps that can reach an output pixel is the same for every pixel ((iy + ph - r) % sh == 0), so
+// the K axis only holds those taps (1 + 2 + 2 + 4 of 9 for 3x3 / stride 2 instead of 9 each -> 4x less work
+// than gathering every tap and masking the misses).
+struct ConvDgradClassParams {
+    ConvGeom g;
+    const float* gy;
+    float* gx;
+    int py, px, Hc, Wc, ntaps;
+    int tap_r[9], tap_s[9];     // kernel coordinates of the class's taps, in packed-K order
+};
+struct ConvDgradClassLoader {
+    using Params = ConvDgradClassParams;
+    static constexpr bool kHasSideOutput = false;
+    const Params& p;
+    const float* gy_b;
+    int iy, ix;
+    bool valid;
+    __device__ ConvDgradClassLoader(const Params& pp, long long n, bool n_valid) : p(pp), valid(n_valid) {
+        const int HcWc = p.Hc * p.Wc;
+        const long long nn = n_valid ? n : 0;
+        const int b = (int)(nn / HcWc), q = (int)(nn - (long long)b * HcWc);
+        const int qy = q / p.Wc, qx = q - qy * p.Wc;
+        iy = p.py + qy * p.g.sh;
+        ix = p.px + qx * p.g.sw;
+        gy_b = p.gy + (size_t)b * p.g.Co * p.g.Ho * p.g.Wo;
+    }
+    __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
+        const ConvGeom& g = p.g;
+        const int HoWo = g.Ho * g.Wo, K = p.ntaps * g.Co;
+        // Co % 16 == 0 is required by the host for this path: one tap per 16-deep chunk
+        const int ti = k0 / g.Co, o0 = k0 - ti * g.Co + ksub;
+        bool ok = valid && k0 < K;
+        int off = 0;
+        if (ok) {
+            const int ty = iy + g.ph - p.tap_r[ti], tx = ix + g.pw - p.tap_s[ti];   // exact multiples by construction
+            const int oy = ty / g.sh, ox = tx / g.sw;
+            ok = ty >= 0 && tx >= 0 && oy < g.Ho && ox < g.Wo;
+            off = oy * g.Wo + ox;
+        }
+        const float* ptr = gy_b + (size_t)o0 * HoWo + (ok ? off : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ok ? ptr[(size_t)(2 * j) * HoWo] : 0.0f;
+    }
+    struct Out {
+        float* base;
+        int HW;
+        __device__ Out(const Params& p, long long n) {
+            HW = p.g.H * p.g.W;
+            const int HcWc = p.Hc * p.Wc;
+            const int b = (int)(n / HcWc), q = (int)(n - (long long)b * HcWc);
+            const int qy = q / p.Wc, qx = q - qy * p.Wc;
+            base = p.gx + (size_t)b * p.g.C * HW + (size_t)(p.py + qy * p.g.sh) * p.g.W + p.px + qx * p.g.sw;
+        }
+        __device__ __forceinline__ void store(const Params&, int m, float v) { base[(size_t)m * HW] = v; }
+    };
+};
+
 // Weight gradient: gw[o][(tap,c)] = sum_{b,p} gy[b][o][p] * x[b][c][window(p, tap)]
 struct ConvWParams {
     ConvGeom g;
     const float *x, *gy;
 };
-template <bool FAST>
+// MODE 2: C % 64 == 0 (the 64 columns of a workgroup share one tap: no per-element index math); 0: generic.
+// (A four-group variant for C % 16 == 0 measured slower than the generic path: more registers, occupancy 3.)
+template <int MODE>
 struct ConvWLoader {
     using Params = ConvWParams;
     const Params& p;
@@ -202,8 +262,7 @@ struct ConvWLoader {
         const int HW = g.H * g.W, K = g.kh * g.kw * g.C;
         const int iy0 = oy_ * g.sh - g.ph, ix0 = ox_ * g.sw - g.pw;
         const float* x_b = p.x + (size_t)b_ * g.C * HW;
-        if (FAST) {
-            // the 64 columns of this workgroup share one tap: one bounds test, no per-element division
+        if (MODE == 2) {
             const int tap = j0 / g.C, c0 = j0 - tap * g.C + jsub;
             const int r = tap / g.kw, s = tap - r * g.kw;
             const int iy = iy0 + r, ix = ix0 + s;
@@ -346,6 +405,32 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
     float* A = cv.take<float>((size_t)q.Kpd * q.Mpd);
+    if ((sh > 1 || sw > 1) && H % sh == 0 && W % sw == 0 && Cout % IG_BK == 0 && kh * kw <= 9) {
+        // one launch per parity class, K restricted to the taps that class can see
+        for (int py = 0; py < sh; ++py)
+            for (int px = 0; px < sw; ++px) {
+                ConvDgradClassParams cp;
+                cp.g = g; cp.gy = grad_y; cp.gx = grad_x; cp.py = py; cp.px = px; cp.Hc = H / sh; cp.Wc = W / sw;
+                cp.ntaps = 0;
+                int taps[9];
+                for (int r = 0; r < kh; ++r)
+                    for (int t = 0; t < kw; ++t)
+                        // (iy + ph - r) must be a multiple of sh for every iy = py + sh*qy: decided by py alone
+                        // (C++ % keeps the dividend's sign; zero is zero either way)
+                        if ((py + ph - r) % sh == 0 && (px + pw - t) % sw == 0) {
+                            cp.tap_r[cp.ntaps] = r; cp.tap_s[cp.ntaps] = t; taps[cp.ntaps] = r * kw + t; ++cp.ntaps;
+                        }
+                const long long Nc = (long long)B * cp.Hc * cp.Wc;
+                // ntaps == 0 (a class no tap reaches): K is all padding, the kernel writes zeros
+                const int Kc = cp.ntaps * Cout, Kpc = round_up(Kc > 0 ? Kc : IG_KC, IG_KC);
+                const int bm = pick_bm(C, Nc), Mp = round_up(C, bm);
+                CNUDA_REQUIRE((size_t)Kpc * Mp * sizeof(float) + 256 <= workspace_bytes, "cnuda_conv2d_backward_data: workspace");
+                launch_pack_taps(weight, A, Cout, C, q.T, taps, cp.ntaps, Kpc, Mp, st);
+                if (int rc = launch_fwd<ConvDgradClassLoader>(bm, cp, A, Mp, Kpc, C, Nc, st, "cnuda_conv2d_backward_data(class)"))
+                    return rc;
+            }
+        return 0;
+    }
     launch_pack(weight, A, Cout, C, q.T, PACK_DGRAD, q.Kpd, q.Mpd, 0, st);
     ConvDgradParams p{g, grad_y, grad_x};
     if (Cout % IG_BK == 0)
@@ -369,12 +454,13 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
     ConvWParams p{g, x, grad_y};
     {
         ProfScope prof(st);
+        const dim3 grid(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z);
         if (C % WG_BJ == 0)
-            hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<true>>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
-                               dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.Nf, q.pix_per_split);
+            hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<2>>), grid, dim3(IG_THREADS), 0, st, p, slabs, q.Mpw,
+                               q.Jp, q.Nf, q.pix_per_split);
         else
-            hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<false>>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
-                               dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.Nf, q.pix_per_split);
+            hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<0>>), grid, dim3(IG_THREADS), 0, st, p, slabs, q.Mpw,
+                               q.Jp, q.Nf, q.pix_per_split);
     }
     if (int rc = check_launch("cnuda_conv2d_backward_weight")) return rc;
     launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, st);

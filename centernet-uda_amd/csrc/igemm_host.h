@@ -17,6 +17,10 @@ inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 void launch_pack(const float* W, float* dst, int Co, int C, int T, PackMode mode,
                  int Kp, int Mp, int Cpad, hipStream_t st);
 
+// dst[k = ti*Co + o][m = c] = W[o][c][taps[ti]], zero padded to [Kp][Mp]
+void launch_pack_taps(const float* W, float* dst, int Co, int C, int T, const int* taps, int ntaps, int Kp, int Mp,
+                      hipStream_t st);
+
 // gw[o][c][tap] = sum_z slabs[z][o][tap*C + c]
 void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp,
                         int Co, int C, int T, hipStream_t st);

@@ -23,6 +23,23 @@ __global__ void pack_kernel(const float* __restrict__ W, float* __restrict__ dst
     }
 }
 
+struct TapList { int n; int tap[9]; };
+// dst[k = ti*Co + o][m = c] = W[o][c][taps.tap[ti]]   (transposed-conv operand restricted to a tap subset)
+__global__ void pack_taps_kernel(const float* __restrict__ W, float* __restrict__ dst, int Co, int C, int T,
+                                 TapList taps, int Kp, int Mp) {
+    const long long total = (long long)Kp * Mp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / Mp), m = (int)(i % Mp);
+        float v = 0.0f;
+        if (k < taps.n * Co && m < C) {
+            const int ti = k / Co, o = k - ti * Co;
+            v = W[((size_t)o * C + m) * T + taps.tap[ti]];
+        }
+        dst[i] = v;
+    }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw, int Z, int Mp, int Jp,
                                    int Co, int C, int T) {
     const long long total = (long long)Co * C * T;
@@ -82,6 +99,15 @@ void launch_pack(const float* W, float* dst, int Co, int C, int T, PackMode mode
     const long long total = (long long)Kp * Mp;
     hipLaunchKernelGGL(pack_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, W, dst, Co, C, T, (int)mode, Kp,
                        Mp, Cpad);
+}
+
+void launch_pack_taps(const float* W, float* dst, int Co, int C, int T, const int* taps, int ntaps, int Kp, int Mp,
+                      hipStream_t st) {
+    TapList tl;
+    tl.n = ntaps;
+    for (int i = 0; i < 9; ++i) tl.tap[i] = i < ntaps ? taps[i] : 0;
+    const long long total = (long long)Kp * Mp;
+    hipLaunchKernelGGL(pack_taps_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, W, dst, Co, C, T, tl, Kp, Mp);
 }
 
 void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp, int Co, int C, int T, hipStream_t st) {

@@ -34,6 +34,9 @@ CONV_CASES = {
     'disc_last': (2, 512, 4, 4, 1, 4, 2, 1, True, -1.0),
     'odd': (3, 20, 7, 9, 37, 3, 1, 1, True, -1.0),
     'c512': (1, 256, 4, 4, 512, 3, 2, 1, False, -1.0),
+    's2_even': (2, 32, 16, 12, 64, 3, 2, 1, False, -1.0),       # parity-class input gradient
+    's2_k1': (2, 16, 8, 8, 32, 1, 2, 0, False, -1.0),           # 1x1 stride 2: three of four classes get zero
+    'c16_wgrad16': (2, 16, 12, 12, 48, 3, 1, 1, False, -1.0),   # C % 16 == 0 wgrad path
 }
 
 
