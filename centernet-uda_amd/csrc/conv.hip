@@ -247,35 +247,42 @@ struct ConvWLoader {
         cursor_init(n, n_end, p.g.Ho * p.g.Wo, p.g.Wo);
     }
     __device__ __forceinline__ void advance() { cursor_advance(p.g.Ho * p.g.Wo, p.g.Wo); }
-    __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[16]) {
+    template <int NV>
+    __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[NV]) {
         const ConvGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo;
         const float* base = p.gy + (size_t)b_ * g.Co * HoWo + pp_;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int m = m0 + msub + 4 * i;
             v[i] = (valid_ && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
         }
     }
-    __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[16]) {
+    template <int NV>
+    __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[NV]) {
         const ConvGeom& g = p.g;
         const int HW = g.H * g.W, K = g.kh * g.kw * g.C;
         const int iy0 = oy_ * g.sh - g.ph, ix0 = ox_ * g.sw - g.pw;
         const float* x_b = p.x + (size_t)b_ * g.C * HW;
         if (MODE == 2) {
-            const int tap = j0 / g.C, c0 = j0 - tap * g.C + jsub;
-            const int r = tap / g.kw, s = tap - r * g.kw;
-            const int iy = iy0 + r, ix = ix0 + s;
-            const bool ok1 = valid_ && j0 < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-            const float* ptr = x_b + (size_t)c0 * HW + (ok1 ? iy * g.W + ix : 0);
+            // every aligned group of 64 columns has one tap (C % 64 == 0): NV/16 bounds tests, no index math
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = ok1 ? ptr[(size_t)(4 * i) * HW] : 0.0f;
+            for (int h = 0; h < NV / 16; ++h) {
+                const int jg = j0 + 64 * h;
+                const int tap = jg / g.C, c0 = jg - tap * g.C + jsub;
+                const int r = tap / g.kw, s = tap - r * g.kw;
+                const int iy = iy0 + r, ix = ix0 + s;
+                const bool ok1 = valid_ && jg < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                const float* ptr = x_b + (size_t)c0 * HW + (ok1 ? iy * g.W + ix : 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[16 * h + i] = ok1 ? ptr[(size_t)(4 * i) * HW] : 0.0f;
+            }
             return;
         }
         int cur = -1, off = 0;
         bool ok = false;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int k = j0 + jsub + 4 * i;
             float val = 0.0f;
             if (valid_ && k < K) {
@@ -316,7 +323,7 @@ struct ConvPlan {
     int T;
     int Kf, Kpf, bmf, Mpf;   // forward:  K = T*C,  M = Co
     int Kd, Kpd, bmd, Mpd;   // dgrad:    K = T*Co, M = C
-    int Mpw, Jp, Z;          // wgrad slabs
+    int Mpw, Jp, Z, wbm, wbj; // wgrad slabs and tile shape
     long long Nf, Nd, pix_per_split;
     size_t fwd_bytes, dgrad_bytes, wgrad_bytes;
 };
@@ -327,9 +334,11 @@ ConvPlan make_plan(const ConvGeom& g) {
     q.Nd = (long long)g.B * g.H * g.W;
     q.Kf = q.T * g.C;   q.Kpf = round_up(q.Kf, IG_KC);  q.bmf = pick_bm(g.Co, q.Nf);  q.Mpf = round_up(g.Co, q.bmf);
     q.Kd = q.T * g.Co;  q.Kpd = round_up(q.Kd, IG_KC);  q.bmd = pick_bm(g.C, q.Nd);   q.Mpd = round_up(g.C, q.bmd);
-    q.Mpw = round_up(g.Co, WG_BM);
-    q.Jp = round_up(q.Kf, WG_BJ);
-    const long long tiles = (long long)(q.Mpw / WG_BM) * (q.Jp / WG_BJ);
+    q.wbm = g.Co <= 32 ? 32 : 64;
+    q.wbj = g.Co <= 32 ? 128 : 64;
+    q.Mpw = round_up(g.Co, q.wbm);
+    q.Jp = round_up(q.Kf, q.wbj);
+    const long long tiles = (long long)(q.Mpw / q.wbm) * (q.Jp / q.wbj);
     long long z = (1024 + tiles - 1) / tiles;
     const long long max_z = (q.Nf + WG_BP - 1) / WG_BP;
     if (z > max_z) z = max_z;
@@ -454,13 +463,23 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
     ConvWParams p{g, x, grad_y};
     {
         ProfScope prof(st);
-        const dim3 grid(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z);
-        if (C % WG_BJ == 0)
-            hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<2>>), grid, dim3(IG_THREADS), 0, st, p, slabs, q.Mpw,
-                               q.Jp, q.Nf, q.pix_per_split);
-        else
-            hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<0>>), grid, dim3(IG_THREADS), 0, st, p, slabs, q.Mpw,
-                               q.Jp, q.Nf, q.pix_per_split);
+        const dim3 grid(q.Jp / q.wbj, q.Mpw / q.wbm, q.Z), blk(IG_THREADS);
+        const bool fast = C % 64 == 0;
+        if (q.wbm == 64) {
+            if (fast)
+                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<2>, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
+                                   q.Nf, q.pix_per_split);
+            else
+                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<0>, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
+                                   q.Nf, q.pix_per_split);
+        } else {
+            if (fast)
+                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<2>, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else
+                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<0>, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+        }
     }
     if (int rc = check_launch("cnuda_conv2d_backward_weight")) return rc;
     launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, st);

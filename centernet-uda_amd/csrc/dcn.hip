@@ -176,14 +176,15 @@ int g_dcn_dbg = 0;
 // window is flushed once per channel tile with coalesced global atomics (~7x
 // fewer HBM-side atomics than scattering every corner, and contiguous); corners
 // outside the window (large offsets, odd shapes) go to global memory directly.
-constexpr int DB_BM = 64, DB_BN = 64, DB_WIN = 476;   // window cells per channel (64*476*4 B = 119 KiB)
+constexpr int DB_BM = 64, DB_BN = 32, DB_WIN = 256;   // window cells per channel (64*256*4 B = 64 KiB -> 2 workgroups / CU)
+constexpr int DB_NT = DB_BN / 16;                      // 16-pixel MFMA tiles per wave
 
 __global__ __launch_bounds__(IG_THREADS) void dcn_bwd_data_kernel(DcnBwdParams p, const float* __restrict__ A2,
                                                                  int Mp2, int Kp, int Cpad, long long N, int n_tiles) {
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     extern __shared__ __align__(16) float smem[];
     float* As = smem;                          // [16][64]  (k, channel)
-    float* Bs = As + IG_BK * DB_BM;            // [16][64]  (k, pixel)
+    float* Bs = As + IG_BK * DB_BM;            // [16][DB_BN]  (k, pixel)
     float* win = Bs + IG_BK * DB_BN;           // [64][WSZ]
     float* dump = win + DB_BM * DB_WIN;        // [256] one cell per thread
     int* claim = reinterpret_cast<int*>(dump + IG_THREADS);   // [4 waves][DB_WIN]
@@ -215,19 +216,21 @@ __global__ __launch_bounds__(IG_THREADS) void dcn_bwd_data_kernel(DcnBwdParams p
     }
     const int WSZ = use_win ? WR * WC : 0;
 
-    // ---- B-operand (gout) staging: pixel = tid & 63, k phase = tid >> 6 ----
-    const int nl = tid & (DB_BN - 1), ksub = tid >> 6;
+    // ---- B-operand (gout) staging: pixel = tid % DB_BN, k phase = tid / DB_BN ----
+    constexpr int KPH = IG_THREADS / DB_BN;     // k rows covered per pass
+    constexpr int BPT = IG_BK / KPH;            // gout elements per thread per chunk
+    const int nl = tid & (DB_BN - 1), ksub = tid / DB_BN;
     const long long nb = n0 + nl;
     const bool nb_valid = nb < N;
     const int bb = nb_valid ? (int)(nb / HoWo) : 0;
     const int pb = nb_valid ? (int)(nb - (long long)bb * HoWo) : 0;
     const float* gout_b = p.gout + (size_t)bb * g.Co * HoWo + pb;
 
-    // ---- epilogue coordinates: lane owns pixel (j*16 + il) of each of the four 16-pixel tiles ----
-    bool pv[4];
-    int eb[4], ep[4], eoy[4], eox[4];
+    // ---- epilogue coordinates: lane owns pixel (j*16 + il) of each 16-pixel tile ----
+    bool pv[DB_NT];
+    int eb[DB_NT], ep[DB_NT], eoy[DB_NT], eox[DB_NT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < DB_NT; ++j) {
         const long long ne = n0 + j * 16 + il;
         pv[j] = ne < N;
         eb[j] = pv[j] ? (int)(ne / HoWo) : 0;
@@ -243,19 +246,22 @@ __global__ __launch_bounds__(IG_THREADS) void dcn_bwd_data_kernel(DcnBwdParams p
     for (int c0 = 0; c0 < Cpad; c0 += DB_BM) {
 #pragma unroll 1
         for (int tap = 0; tap < T; ++tap) {
-            f32x4 acc[4];
+            f32x4 acc[DB_NT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < DB_NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[j][r] = 0.0f;
             const int mbase = tap * Cpad + c0;
-            float ra[4], rb[4];
+            float ra[4], rb[BPT];
             auto stage_load = [&](int k0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int e = tid + i * IG_THREADS;
                     ra[i] = A2[(size_t)(k0 + (e >> 6)) * Mp2 + mbase + (e & 63)];
-                    const int o = k0 + ksub + 4 * i;
+                }
+#pragma unroll
+                for (int i = 0; i < BPT; ++i) {
+                    const int o = k0 + ksub + KPH * i;
                     rb[i] = (nb_valid && o < g.Co) ? gout_b[(size_t)o * HoWo] : 0.0f;
                 }
             };
@@ -263,17 +269,16 @@ __global__ __launch_bounds__(IG_THREADS) void dcn_bwd_data_kernel(DcnBwdParams p
             for (int k0 = 0; k0 < Kp; k0 += IG_BK) {
                 __syncthreads();
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    As[tid + i * IG_THREADS] = ra[i];
-                    Bs[(ksub + 4 * i) * DB_BN + nl] = rb[i];
-                }
+                for (int i = 0; i < 4; ++i) As[tid + i * IG_THREADS] = ra[i];
+#pragma unroll
+                for (int i = 0; i < BPT; ++i) Bs[(ksub + KPH * i) * DB_BN + nl] = rb[i];
                 __syncthreads();
                 if (k0 + IG_BK < Kp) stage_load(k0 + IG_BK);
 #pragma unroll
                 for (int kk = 0; kk < IG_BK; kk += 4) {
                     const float a = As[(kk + kq) * DB_BM + wid * 16 + il];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < DB_NT; ++j) {
                         const float b = Bs[(kk + kq) * DB_BN + j * 16 + il];
                         acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
                     }
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(IG_THREADS) void dcn_bwd_data_kernel(DcnBwdParams p
             }
             // ---- consume the dcol tile: lane holds channels cl = wid*16 + kq*4 + r (r<4) of pixel j*16+il ----
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < DB_NT; ++j) {
                 const Tap t = make_tap(g, p.off + (size_t)eb[j] * 2 * T * HoWo, p.mask + (size_t)eb[j] * T * HoWo, 0,
                                        tap, eoy[j], eox[j]);
                 const bool live = pv[j] && t.inside;
@@ -440,17 +445,19 @@ struct DcnWLoader {
         cursor_init(n, n_end, p.g.Ho * p.g.Wo, p.g.Wo);
     }
     __device__ __forceinline__ void advance() { cursor_advance(p.g.Ho * p.g.Wo, p.g.Wo); }
-    __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[16]) {
+    template <int NV>
+    __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[NV]) {
         const DcnGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo;
         const float* base = p.gout + (size_t)b_ * g.Co * HoWo + pp_;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int m = m0 + msub + 4 * i;
             v[i] = (valid_ && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
         }
     }
-    __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[16]) {
+    template <int NV>
+    __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[NV]) {
         const DcnGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, K = T * g.C;
         const float* in_b = p.in + (size_t)b_ * g.C * HW;
@@ -459,7 +466,7 @@ struct DcnWLoader {
         int cur = -1;
         Tap t;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int k = j0 + jsub + 4 * i;
             float r = 0.0f;
             if (valid_ && k < K) {
@@ -511,22 +518,24 @@ struct DcnColWLoader {
         cursor_init(n, n_end, p.g.Ho * p.g.Wo, p.g.Wo);
     }
     __device__ __forceinline__ void advance() { cursor_advance(p.g.Ho * p.g.Wo, p.g.Wo); }
-    __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[16]) {
+    template <int NV>
+    __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[NV]) {
         const DcnGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo;
         const float* base = p.gout + (size_t)b_ * g.Co * HoWo + pp_;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int m = m0 + msub + 4 * i;
             v[i] = (valid_ && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
         }
     }
-    __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[16]) {
+    template <int NV>
+    __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[NV]) {
         const DcnGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo, K = g.kh * g.kw * g.C;
         const float* base = p.col + (size_t)b_ * K * HoWo + pp_;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int k = j0 + jsub + 4 * i;
             v[i] = (valid_ && k < K) ? base[(size_t)k * HoWo] : 0.0f;
         }
@@ -794,11 +803,11 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
     {
         if (columns) {
             DcnColWParams p{g, columns, grad_output};
-            hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+            hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
                                dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
         } else {
             DcnWParams p{g, input, offset, mask, grad_output};
-            hipLaunchKernelGGL((igemm_wgrad_kernel<DcnWLoader>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+            hipLaunchKernelGGL((igemm_wgrad_kernel<DcnWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
                                dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
         }
         if (int rc = check_launch("cnuda_dcn_v2_backward(weight)")) return rc;
