@@ -40,16 +40,30 @@ __global__ void pack_taps_kernel(const float* __restrict__ W, float* __restrict_
     }
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw, int Z, int Mp, int Jp,
-                                   int Co, int C, int T) {
+// gw[o][c][tap] = sum_z slabs[z][o][tap*C + c].  Workgroup = 64 consecutive outputs x 4 waves; wave w sums
+// slabs w, w+4, w+8, ... (coalesced 256-B rows), the four partial sums are added in wave order through LDS:
+// a fixed summation order (bit-reproducible) with 4x the parallelism of one thread per output.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw,
+                                                          int Z, int Mp, int Jp, int Co, int C, int T) {
+    __shared__ float part[4][64];
     const long long total = (long long)Co * C * T;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int tap = (int)(i % T), c = (int)((i / T) % C), o = (int)(i / ((long long)T * C));
-        const size_t off = (size_t)o * Jp + (size_t)tap * C + c;
-        float s = 0.0f;
-        for (int z = 0; z < Z; ++z) s += slabs[(size_t)z * Mp * Jp + off];
-        gw[i] = s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + lane;
+    float s = 0.0f;
+    if (i < total) {
+        // enumerate in slab order (j = tap*C + c contiguous): coalesced reads, strided (small) writes
+        const int K = T * C;
+        const int j = (int)(i % K), o = (int)(i / K);
+        const size_t off = (size_t)o * Jp + j;
+        for (int z = w; z < Z; z += 4) s += slabs[(size_t)z * Mp * Jp + off];
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < total) {
+        const int K = T * C;
+        const int j = (int)(i % K), o = (int)(i / K);
+        const int tap = j / C, c = j - tap * C;
+        gw[((size_t)o * C + c) * T + tap] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
     }
 }
 
@@ -112,8 +126,8 @@ void launch_pack_taps(const float* W, float* dst, int Co, int C, int T, const in
 
 void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp, int Co, int C, int T, hipStream_t st) {
     const long long total = (long long)Co * C * T;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, slabs, gw, Z, Mp, Jp, Co,
-                       C, T);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, slabs, gw, Z, Mp, Jp,
+                       Co, C, T);
 }
 
 void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st, float* scratch) {
