@@ -37,8 +37,8 @@ struct ConvFwdLoader {
     bool valid;
     __device__ ConvFwdLoader(const Params& p, long long n, bool n_valid) : g(p.g), valid(n_valid) {
         const int HoWo = g.Ho * g.Wo;
-        const long long nn = n_valid ? n : 0;
-        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
+        const int nn = n_valid ? (int)n : 0;   // N < 2^31 is checked on the host: 32-bit index math
+        const int b = nn / HoWo, pp = nn - b * HoWo;
         const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
         iy0 = oy * g.sh - g.ph;
         ix0 = ox * g.sw - g.pw;
@@ -74,7 +74,7 @@ struct ConvFwdLoader {
         int HoWo;
         __device__ Out(const Params& p, long long n) {
             HoWo = p.g.Ho * p.g.Wo;
-            const int b = (int)(n / HoWo), pp = (int)(n - (long long)b * HoWo);
+            const int ni = (int)n, b = ni / HoWo, pp = ni - b * HoWo;
             base = p.y + (size_t)b * p.g.Co * HoWo + pp;
         }
         __device__ __forceinline__ void store(const Params& p, int m, float v) {
@@ -102,8 +102,8 @@ struct ConvDgradLoader {
     bool valid;
     __device__ ConvDgradLoader(const Params& p, long long n, bool n_valid) : g(p.g), valid(n_valid) {
         const int HW = g.H * g.W;
-        const long long nn = n_valid ? n : 0;
-        const int b = (int)(nn / HW), pp = (int)(nn - (long long)b * HW);
+        const int nn = n_valid ? (int)n : 0;   // N < 2^31 is checked on the host: 32-bit index math
+        const int b = nn / HW, pp = nn - b * HW;
         iy = pp / g.W;
         ix = pp - iy * g.W;
         gy_b = p.gy + (size_t)b * g.Co * g.Ho * g.Wo;
@@ -145,7 +145,7 @@ struct ConvDgradLoader {
         int HW;
         __device__ Out(const Params& p, long long n) {
             HW = p.g.H * p.g.W;
-            const int b = (int)(n / HW), pp = (int)(n - (long long)b * HW);
+            const int ni = (int)n, b = ni / HW, pp = ni - b * HW;
             base = p.gx + (size_t)b * p.g.C * HW + pp;
         }
         __device__ __forceinline__ void store(const Params&, int m, float v) { base[(size_t)m * HW] = v; }
@@ -172,8 +172,8 @@ struct ConvDgradClassLoader {
     bool valid;
     __device__ ConvDgradClassLoader(const Params& pp, long long n, bool n_valid) : p(pp), valid(n_valid) {
         const int HcWc = p.Hc * p.Wc;
-        const long long nn = n_valid ? n : 0;
-        const int b = (int)(nn / HcWc), q = (int)(nn - (long long)b * HcWc);
+        const int nn = n_valid ? (int)n : 0;   // N < 2^31 is checked on the host: 32-bit index math
+        const int b = nn / HcWc, q = nn - b * HcWc;
         const int qy = q / p.Wc, qx = q - qy * p.Wc;
         iy = p.py + qy * p.g.sh;
         ix = p.px + qx * p.g.sw;
@@ -202,7 +202,7 @@ struct ConvDgradClassLoader {
         __device__ Out(const Params& p, long long n) {
             HW = p.g.H * p.g.W;
             const int HcWc = p.Hc * p.Wc;
-            const int b = (int)(n / HcWc), q = (int)(n - (long long)b * HcWc);
+            const int ni = (int)n, b = ni / HcWc, q = ni - b * HcWc;
             const int qy = q / p.Wc, qx = q - qy * p.Wc;
             base = p.gx + (size_t)b * p.g.C * HW + (size_t)(p.py + qy * p.g.sh) * p.g.W + p.px + qx * p.g.sw;
         }
@@ -355,6 +355,7 @@ int g_conv_dbg = 0;
 template <class Loader>
 int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp, int Kp, int M, long long N,
                hipStream_t st, const char* who) {
+    CNUDA_REQUIRE(N < (1ll << 31) - IG_BN, "%s: more than 2^31 pixels per call", who);
     const int n_tiles = ceil_div(N, IG_BN), m_tiles = Mp / bm;
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
     ProfScope prof(st);

@@ -105,8 +105,8 @@ struct DcnFwdLoader {
     __device__ __forceinline__ void disable_col() { col_n = nullptr; }
     __device__ DcnFwdLoader(const Params& p, long long n, bool n_valid) : g(p.g), valid(n_valid), cur(-1) {
         const int HoWo = g.Ho * g.Wo;
-        const long long nn = n_valid ? n : 0;
-        const int b = (int)(nn / HoWo), pp = (int)(nn - (long long)b * HoWo);
+        const int nn = n_valid ? (int)n : 0;   // N < 2^31 is checked on the host: 32-bit index math
+        const int b = nn / HoWo, pp = nn - b * HoWo;
         oy = pp / g.Wo;
         ox = pp - oy * g.Wo;
         const int T = g.kh * g.kw;
@@ -141,7 +141,7 @@ struct DcnFwdLoader {
         int HoWo;
         __device__ Out(const Params& p, long long n) {
             HoWo = p.g.Ho * p.g.Wo;
-            const int b = (int)(n / HoWo), pp = (int)(n - (long long)b * HoWo);
+            const int ni = (int)n, b = ni / HoWo, pp = ni - b * HoWo;
             base = p.out + (size_t)b * p.g.Co * HoWo + pp;
         }
         __device__ __forceinline__ void store(const Params& p, int m, float v) {
@@ -710,6 +710,7 @@ extern "C" int cnuda_dcn_v2_forward_cols(const float* input, const float* weight
         return check_launch("cnuda_dcn_v2_forward(dg>1)");
     }
     const DcnPlan q = make_plan(g);
+    CNUDA_REQUIRE(q.N < (1ll << 31) - IG_BN, "cnuda_dcn_v2_forward: more than 2^31 pixels per call");
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_dcn_v2_forward: workspace too small");
     Carver cv(workspace, workspace_bytes);
     float* A = cv.take<float>((size_t)q.Kp * q.Mp);

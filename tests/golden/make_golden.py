@@ -286,15 +286,100 @@ def make_step(dla):
         save('step_' + tag, **out)
 
 
+def _advent_case(dla, dtype):
+    """`AdversarialEntropyMinimization.step` (uda/adversarial_entropy_minimization.py:77-152) re-enacted with
+    the imported reference pieces on a rotated-box model with the periodic angle loss (cfg5 semantics).
+    Not importable as a class here: the module needs hydra, and AdventLoss.forward calls `.to(-1)` on CPU
+    (losses/advent.py:14) -- its arithmetic is the member `crit` against a filled label.  The discriminator is
+    built from the layer list of get_fc_discriminator (:51-68)."""
+    from losses.centernet import DetectionLoss
+    from losses.advent import AdventLoss
+    from utils_image_entropy import entropy_map
+    from torch import nn
+    B, S, M, C = 2, 128, 8, 6
+    model = dla.build(num_classes=C, rotated_boxes=True)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes).items()})
+    ndf = 64
+    D = nn.Sequential(
+        nn.Conv2d(C, ndf, 4, 2, 1), nn.LeakyReLU(0.2, inplace=True),
+        nn.Conv2d(ndf, ndf * 2, 4, 2, 1), nn.LeakyReLU(0.2, inplace=True),
+        nn.Conv2d(ndf * 2, ndf * 4, 4, 2, 1), nn.LeakyReLU(0.2, inplace=True),
+        nn.Conv2d(ndf * 4, ndf * 8, 4, 2, 1), nn.LeakyReLU(0.2, inplace=True),
+        nn.Conv2d(ndf * 8, 1, 4, 2, 1))
+    dshapes = {k: tuple(v.shape) for k, v in D.state_dict().items()}
+    D.load_state_dict({k: T(gin.fill_value('discriminator.' + k, v)) for k, v in dshapes.items()})
+    model, D = model.to(dtype), D.to(dtype)
+    model.train(); D.train()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-5, weight_decay=1e-4)
+    dopt = torch.optim.Adam(D.parameters(), lr=1e-3, weight_decay=1e-4)
+    crit = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0, periodic=True)
+    adv = AdventLoss()
+    bce = lambda y, label: adv.crit(y, torch.full_like(y, float(label)))
+    batch = {k: T(v) for k, v in gin.detection_batch(B, C, S // 4, S // 4, M, (4, 2), 3, 71).items()}
+    for k in ('hm', 'wh', 'reg'):
+        batch[k] = batch[k].to(dtype)
+    x_s, x_t = T(gin.image_batch(B, S, S, 72)).to(dtype), T(gin.image_batch(B, S, S, 73)).to(dtype)
+    w_adv = 1e-4
+    opt.zero_grad(); dopt.zero_grad()
+    for p_ in D.parameters():
+        p_.requires_grad = False
+    out_s, out_t = model(x_s), model(x_t)
+    fool = D(entropy_map(out_t['hm']))
+    loss, stats = crit(out_s, batch)
+    loss.backward()
+    dtf = bce(fool, 0)
+    dtf *= w_adv
+    dtf.backward()
+    for p_ in D.parameters():
+        p_.requires_grad = True
+    source, target = out_s['hm'].detach(), out_t['hm'].detach()
+    ds = bce(D(entropy_map(source)), 0)
+    ds /= 2.0
+    ds.backward()
+    dt = bce(D(entropy_map(target)), 1)
+    dt /= 2.0
+    dt.backward()
+    opt.step(); dopt.step()
+    res = {'stat_' + k: v.item() for k, v in stats.items()}
+    res.update(stat_total_loss=(loss + ds + dt + dtf).item(), stat_dis_soruce=ds.item(), stat_dis_target=dt.item(),
+               stat_dis_fool=dtf.item())
+    for n, p_ in D.named_parameters():
+        res['dgradsum__' + n] = _checksums(p_.grad)
+        res['dparam__' + n] = _checksums(p_)
+    params = dict(model.named_parameters())
+    for n in GRAD_PROBES:
+        if params[n].grad is not None:
+            res['gradsum__' + n] = _checksums(params[n].grad)
+    res['src_hm_after'] = out_s['hm'].detach().numpy()
+    res['wh_target_after'] = batch['wh'].numpy()
+    res['dshapes_json'] = np.array(repr(sorted(dshapes.items())))
+    res['shapes_json'] = np.array(repr(sorted(shapes.items())))
+    return res
+
+
+def make_advent(dla):
+    r32 = _advent_case(dla, torch.float32)
+    r64 = _advent_case(dla, torch.float64)
+    out = dict(r32)
+    for k, v in r64.items():
+        if k.startswith(('stat_', 'gradsum__', 'dgradsum__', 'src_hm_after')):
+            out['f64_' + k] = v
+    save('step_advent', **out)
+
+
 if __name__ == '__main__':
     oracle_dcn.build()
-    which = set(sys.argv[1:]) or {'decode', 'losses', 'dla', 'step'}
+    which = set(sys.argv[1:]) or {'decode', 'losses', 'dla', 'step', 'advent'}
     if 'decode' in which:
         make_decode()
-    if 'losses' in which:
+    if 'losses' in which or 'advent' in which:
         _load_entropy_map()
+    if 'losses' in which:
         make_losses()
-    if 'dla' in which or 'step' in which:
+    if 'dla' in which or 'step' in which or 'advent' in which:
         d = make_dla() if 'dla' in which else _import_reference_dla()
         if 'step' in which:
             make_step(d)
+        if 'advent' in which:
+            make_advent(d)

@@ -152,3 +152,54 @@ def test_uda_step_golden(golden, tag, weight):
     dets = plugin.get_detections(o, ev)
     assert dets['pred_boxes'].shape == (B, 20, 4) and dets['pred_scores'].shape == (B, 20)
     assert [len(b) for b in dets['gt_boxes']] == [3, 2]
+
+
+def test_advent_step_golden(golden):
+    """cfg5 semantics on the GPU plugin: rotated DLA-34, periodic angle loss, ADVENT discriminator
+    (uda/adversarial_entropy_minimization.py:77-152), five backward calls, two fused-Adam optimizers."""
+    import uda
+    from hip_runtime import optim
+    from losses.centernet import DetectionLoss
+    g = golden('step_advent')
+    from backends import dla
+    shapes = dict(ast.literal_eval(str(g['shapes_json'])))
+    dshapes = dict(ast.literal_eval(str(g['dshapes_json'])))
+    model = dla.build(num_classes=6, rotated_boxes=True)
+    model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes).items()})
+    plugin = uda.AdversarialEntropyMinimization(
+        1e-4, optimizer=_Cfg(name='Adam', params=_Cfg(lr=1e-3, weight_decay=1e-4)))
+    plugin.cfg = _Cfg(max_detections=20, model=_Cfg(backend=_Cfg(params=_Cfg(rotated_boxes=True, num_classes=6))))
+    plugin.backend = model
+    plugin.device = torch.device(DEV)
+    plugin.optimizer = optim.Adam(model.parameters(), lr=5e-5, weight_decay=1e-4)
+    plugin.centernet_loss = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0,
+                                          periodic=True)
+    plugin.init_done()
+    assert sorted(plugin.discriminator.state_dict()) == sorted(dshapes)         # checkpoint keys 0,2,4,6,8
+    plugin.discriminator.load_state_dict(
+        {k: T(gin.fill_value('discriminator.' + k, tuple(v))) for k, v in dshapes.items()})
+    plugin.to(DEV)
+    plugin.set_phase(True)
+    B, S, M = 2, 128, 8
+    data = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, (4, 2), 3, 71).items()}
+    data['input'] = T(gin.image_batch(B, S, S, 72))
+    data['target_domain_input'] = T(gin.image_batch(B, S, S, 73))
+    out = plugin.step(data)
+    stats = out['stats']
+    assert set(stats) == {'centernet_loss', 'hm_loss', 'wh_loss', 'off_loss', 'total_loss', 'dis_soruce',
+                          'dis_target', 'dis_fool'}
+    for k in stats:
+        _close_calibrated(stats[k].item(), g['stat_' + k], g['f64_stat_' + k], floor=1e-4, what=k)
+    _close_calibrated(out['source_domain']['hm'].detach().cpu().numpy(), g['src_hm_after'], g['f64_src_hm_after'],
+                      what='hm prob')
+    np.testing.assert_allclose(data['wh'].cpu().numpy(), g['wh_target_after'], rtol=1e-6, atol=1e-6)   # Q2
+    dparams = dict(plugin.discriminator.named_parameters())
+    for n in dshapes:
+        got, w32, w64 = _checksums(dparams[n].grad), g['dgradsum__' + n], g['f64_dgradsum__' + n]
+        noise = np.abs(w32 - w64).max()
+        # the discriminator sees entropy maps that are allowed to differ by 1e-4 (fp32 budget of the backbone);
+        # LeakyReLU sign flips turn that into a few 1e-3 of its gradient sums
+        assert np.abs(got - w64).max() <= max(5e-3 * max(1e-6, w64[1]), 16 * noise), (n, got, w64, noise)
+    for p in plugin.discriminator.parameters():
+        assert p.requires_grad                                      # unfrozen again after the generator phase
+    assert out['source_generator'].shape == (B, 1, 1, 1)

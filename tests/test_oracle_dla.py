@@ -109,3 +109,56 @@ def test_uda_step(golden, tag, weight):
     _close(st['base.base_layer.1.running_mean'].numpy(), g['rm__base.base_layer.1'], 1e-5)
     _close(st['base.base_layer.1.running_var'].numpy(), g['rv__base.base_layer.1'], 1e-5)
     assert int(st['base.base_layer.1.num_batches_tracked']) == 2      # Q6: two BN updates per step
+
+
+def test_advent_step(golden):
+    """S4 (uda/adversarial_entropy_minimization.py:77-152) on the oracle: rotated model, periodic angle loss,
+    discriminator on entropy maps, the sigmoid-source quirk (Q1) and five backward calls."""
+    import torch.nn.functional as F
+    g = golden('step_advent')
+    shapes = dict(ast.literal_eval(str(g['shapes_json'])))
+    dshapes = dict(ast.literal_eval(str(g['dshapes_json'])))
+    st = {}
+    for k, v in gin.fill_state(shapes).items():
+        t = T(v).clone()
+        if t.is_floating_point() and 'running_' not in k:
+            t.requires_grad_(True)
+        st[k] = t
+    dp = {k: T(gin.fill_value('discriminator.' + k, tuple(v))).clone().requires_grad_(True) for k, v in dshapes.items()}
+
+    def D(x):
+        for i in (0, 2, 4, 6):
+            x = F.leaky_relu(F.conv2d(x, dp['%d.weight' % i], dp['%d.bias' % i], 2, 1), 0.2)
+        return F.conv2d(x, dp['8.weight'], dp['8.bias'], 2, 1)
+
+    B, S, M, C = 2, 128, 8, 6
+    batch = {k: T(v) for k, v in gin.detection_batch(B, C, S // 4, S // 4, M, (4, 2), 3, 71).items()}
+    opt = torch.optim.Adam([v for v in st.values() if v.requires_grad], lr=5e-5, weight_decay=1e-4)
+    dopt = torch.optim.Adam(list(dp.values()), lr=1e-3, weight_decay=1e-4)
+    heads = ('hm', 'wh', 'reg')
+    out_s = odla.forward(st, T(gin.image_batch(B, S, S, 72)), heads, training=True)
+    out_t = odla.forward(st, T(gin.image_batch(B, S, S, 73)), heads, training=True)
+    for v in dp.values():
+        v.requires_grad_(False)
+    fool = D(ol.entropy_map(out_t['hm']))
+    loss, stats, prob = ol.detection_loss(out_s, batch, 1.0, 0.1, 1.0, 1.0, True)
+    loss.backward()
+    dtf = ol.advent_loss(fool, 0) * 1e-4
+    dtf.backward()
+    for v in dp.values():
+        v.requires_grad_(True)
+    ds = ol.advent_loss(D(ol.entropy_map(prob.detach())), 0) / 2.0          # Q1: probabilities, not logits
+    ds.backward()
+    dt = ol.advent_loss(D(ol.entropy_map(out_t['hm'].detach())), 1) / 2.0
+    dt.backward()
+    opt.step(); dopt.step()
+    got = dict(stats)
+    got.update(total_loss=loss + ds + dt + dtf, dis_soruce=ds, dis_target=dt, dis_fool=dtf)
+    for k, v in got.items():
+        want = float(g['stat_' + k])
+        assert abs(float(v) - want) <= 2e-4 * max(1e-3, abs(want)), (k, float(v), want)
+    for n, v in dp.items():
+        gs, ws = _checksums(v.grad), g['dgradsum__' + n]
+        assert np.abs(gs - ws).max() <= 2e-3 * max(1e-6, ws[1]), (n, gs, ws)
+        ps, wp = _checksums(v), g['dparam__' + n]
+        assert np.abs(ps - wp).max() <= 1e-4 * max(1.0, wp[1]), (n, ps, wp)
