@@ -25,7 +25,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int IG_BN = 128;
 constexpr int IG_BK = 16;   // K granularity of the loaders / packing
-constexpr int IG_KC = 32;   // K depth staged in LDS per barrier pair (two loader calls)
+constexpr int IG_KC = 16;   // K depth staged in LDS per barrier pair (two loader calls)
 constexpr int IG_THREADS = 256;
 
 template <int BM> struct IgTile;
@@ -73,19 +73,19 @@ __device__ __forceinline__ void ig_mma_chunk(const float* __restrict__ As, const
 // Stage the A tile rows [k0, k0+BK) x cols [m0, m0+BM) of the packed matrix.
 template <int BM>
 __device__ __forceinline__ void ig_load_a(const float* __restrict__ A, int Mp, int k0, int m0, int tid,
-                                          float (&r)[BM / 8]) {
+                                          float (&r)[BM * IG_KC / IG_THREADS]) {
     // KC*BM floats over 256 threads; consecutive threads -> consecutive m
 #pragma unroll
-    for (int i = 0; i < BM / 8; ++i) {
+    for (int i = 0; i < BM * IG_KC / IG_THREADS; ++i) {
         const int e = tid + i * IG_THREADS;
         const int kk = e / BM, m = e % BM;
         r[i] = A[(size_t)(k0 + kk) * Mp + m0 + m];
     }
 }
 template <int BM>
-__device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, const float (&r)[BM / 8]) {
+__device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, const float (&r)[BM * IG_KC / IG_THREADS]) {
 #pragma unroll
-    for (int i = 0; i < BM / 8; ++i) As[tid + i * IG_THREADS] = r[i];
+    for (int i = 0; i < BM * IG_KC / IG_THREADS; ++i) As[tid + i * IG_THREADS] = r[i];
 }
 
 // Generic forward-type kernel.  Loader contract:
@@ -98,8 +98,9 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_fwd_kernel(
     typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
     int n_tiles, int m_tiles, int dbg = 0) {
     using T = IgTile<BM>;
-    __shared__ float As[IG_KC * BM];
-    __shared__ float Bs[IG_KC * IG_BN];
+    // two LDS stages: chunk k+1 is written while chunk k's fragments are still being read, one barrier per chunk
+    __shared__ float As[2][IG_KC * BM];
+    __shared__ float Bs[2][IG_KC * IG_BN];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wg = xcd_remap(blockIdx.x, n_tiles * m_tiles);
     const int m0 = (wg % m_tiles) * BM;
@@ -119,27 +120,35 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_fwd_kernel(
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // Kp is a multiple of IG_KC (the pack kernels zero-pad); the loaders return 0 past the real K
-    float ra[BM / 8], rb0[8], rb1[8];
-    ig_load_a<BM>(A, Mp, 0, m0, tid, ra);
-    ld.load(0, ksub, rb0);
-    ld.load(IG_BK, ksub, rb1);
-    for (int k0 = 0; k0 < Kp; k0 += IG_KC) {
-        __syncthreads();  // previous chunk's fragment reads are done
-        ig_store_a<BM>(As, tid, ra);
+    constexpr int NH = IG_KC / IG_BK;               // loader calls per chunk
+    float ra[BM * IG_KC / IG_THREADS], rb[NH][8];
+    auto stage_store = [&](int buf) {
+        ig_store_a<BM>(As[buf], tid, ra);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            Bs[(ksub + 2 * j) * IG_BN + nl] = rb0[j];
-            Bs[(IG_BK + ksub + 2 * j) * IG_BN + nl] = rb1[j];
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Bs[buf][(h * IG_BK + ksub + 2 * j) * IG_BN + nl] = rb[h][j];
+    };
+    auto stage_load = [&](int k0) {
+        ig_load_a<BM>(A, Mp, k0, m0, tid, ra);
+        if (!(dbg & 1)) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) ld.load(k0 + h * IG_BK, ksub, rb[h]);
+        }
+    };
+    stage_load(0);
+    stage_store(0);
+    if (IG_KC < Kp) stage_load(IG_KC);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < Kp; k0 += IG_KC) {
+        if (!(dbg & 2)) ig_mma_chunk<BM>(As[cur], Bs[cur], acc, wm_off, wn_off, lane);
+        if (k0 + IG_KC < Kp) {
+            stage_store(cur ^ 1);                      // chunk k+1 (its global loads were issued one chunk ago)
+            if (k0 + 2 * IG_KC < Kp) stage_load(k0 + 2 * IG_KC);
         }
         __syncthreads();
-        if (k0 + IG_KC < Kp) {  // prefetch the next chunk under this chunk's MFMAs
-            ig_load_a<BM>(A, Mp, k0 + IG_KC, m0, tid, ra);
-            if (!(dbg & 1)) {
-                ld.load(k0 + IG_KC, ksub, rb0);
-                ld.load(k0 + IG_KC + IG_BK, ksub, rb1);
-            }
-        }
-        if (!(dbg & 2)) ig_mma_chunk<BM>(As, Bs, acc, wm_off, wn_off, lane);
+        cur ^= 1;
     }
     // epilogue: lane owns pixel column (lane&31) of each tile
 #pragma unroll
