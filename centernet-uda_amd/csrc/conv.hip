@@ -247,18 +247,18 @@ struct ConvWLoader {
         cursor_init(n, n_end, p.g.Ho * p.g.Wo, p.g.Wo);
     }
     __device__ __forceinline__ void advance() { cursor_advance(p.g.Ho * p.g.Wo, p.g.Wo); }
-    template <int NV>
+    template <int NV, int STEP>
     __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[NV]) {
         const ConvGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo;
         const float* base = p.gy + (size_t)b_ * g.Co * HoWo + pp_;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int m = m0 + msub + 4 * i;
+            const int m = m0 + msub + STEP * i;
             v[i] = (valid_ && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
         }
     }
-    template <int NV>
+    template <int NV, int STEP>
     __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[NV]) {
         const ConvGeom& g = p.g;
         const int HW = g.H * g.W, K = g.kh * g.kw * g.C;
@@ -266,8 +266,9 @@ struct ConvWLoader {
         const float* x_b = p.x + (size_t)b_ * g.C * HW;
         if (MODE == 2) {
             // every aligned group of 64 columns has one tap (C % 64 == 0): NV/16 bounds tests, no index math
+            constexpr int PER = 64 / STEP;     // values of this thread inside one 64-column group
 #pragma unroll
-            for (int h = 0; h < NV / 16; ++h) {
+            for (int h = 0; h < NV / PER; ++h) {
                 const int jg = j0 + 64 * h;
                 const int tap = jg / g.C, c0 = jg - tap * g.C + jsub;
                 const int r = tap / g.kw, s = tap - r * g.kw;
@@ -275,7 +276,7 @@ struct ConvWLoader {
                 const bool ok1 = valid_ && jg < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
                 const float* ptr = x_b + (size_t)c0 * HW + (ok1 ? iy * g.W + ix : 0);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[16 * h + i] = ok1 ? ptr[(size_t)(4 * i) * HW] : 0.0f;
+                for (int i = 0; i < PER; ++i) v[PER * h + i] = ok1 ? ptr[(size_t)(STEP * i) * HW] : 0.0f;
             }
             return;
         }
@@ -283,7 +284,7 @@ struct ConvWLoader {
         bool ok = false;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int k = j0 + jsub + 4 * i;
+            const int k = j0 + jsub + STEP * i;
             float val = 0.0f;
             if (valid_ && k < K) {
                 const int tap = k / g.C, c = k - tap * g.C;

@@ -445,18 +445,18 @@ struct DcnWLoader {
         cursor_init(n, n_end, p.g.Ho * p.g.Wo, p.g.Wo);
     }
     __device__ __forceinline__ void advance() { cursor_advance(p.g.Ho * p.g.Wo, p.g.Wo); }
-    template <int NV>
+    template <int NV, int STEP>
     __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[NV]) {
         const DcnGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo;
         const float* base = p.gout + (size_t)b_ * g.Co * HoWo + pp_;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int m = m0 + msub + 4 * i;
+            const int m = m0 + msub + STEP * i;
             v[i] = (valid_ && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
         }
     }
-    template <int NV>
+    template <int NV, int STEP>
     __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[NV]) {
         const DcnGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, K = T * g.C;
@@ -467,7 +467,7 @@ struct DcnWLoader {
         Tap t;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int k = j0 + jsub + 4 * i;
+            const int k = j0 + jsub + STEP * i;
             float r = 0.0f;
             if (valid_ && k < K) {
                 const int tap = k / g.C, c = k - tap * g.C;
@@ -518,25 +518,25 @@ struct DcnColWLoader {
         cursor_init(n, n_end, p.g.Ho * p.g.Wo, p.g.Wo);
     }
     __device__ __forceinline__ void advance() { cursor_advance(p.g.Ho * p.g.Wo, p.g.Wo); }
-    template <int NV>
+    template <int NV, int STEP>
     __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[NV]) {
         const DcnGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo;
         const float* base = p.gout + (size_t)b_ * g.Co * HoWo + pp_;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int m = m0 + msub + 4 * i;
+            const int m = m0 + msub + STEP * i;
             v[i] = (valid_ && m < g.Co) ? base[(size_t)m * HoWo] : 0.0f;
         }
     }
-    template <int NV>
+    template <int NV, int STEP>
     __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[NV]) {
         const DcnGeom& g = p.g;
         const int HoWo = g.Ho * g.Wo, K = g.kh * g.kw * g.C;
         const float* base = p.col + (size_t)b_ * K * HoWo + pp_;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int k = j0 + jsub + 4 * i;
+            const int k = j0 + jsub + STEP * i;
             v[i] = (valid_ && k < K) ? base[(size_t)k * HoWo] : 0.0f;
         }
     }

@@ -177,10 +177,10 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_fwd_kernel(
 // Loader contract (WLoader): per-thread cursor over the pixel axis
 //   WLoader(const Params&, long long n, long long n_end)   cursor at pixel n (one-time integer divisions)
 //   void advance()                                          move the cursor WG_BP pixels forward (no division)
-//   template<int NV> void load_b(int j0, int jsub, float (&v)[NV])   v[i] = B[j0 + jsub + 4i][cursor]  (0 past n_end)
-//   template<int NV> void load_g(int m0, int msub, float (&v)[NV])   v[i] = G[m0 + msub + 4i][cursor]
+//   template<int NV, int STEP> void load_b(int j0, int jsub, float (&v)[NV])   v[i] = B[j0 + jsub + STEP*i][cursor]
+//   template<int NV, int STEP> void load_g(int m0, int msub, float (&v)[NV])   v[i] = G[m0 + msub + STEP*i][cursor]
 // ---------------------------------------------------------------------------
-constexpr int WG_BM = 64, WG_BJ = 64, WG_BP = 64;
+constexpr int WG_BM = 64, WG_BJ = 64, WG_BP = 32;   // pixels per chunk (2 LDS stages of 32 instead of 1 of 64)
 
 // BM x BJ = 64 x 64 (waves 2 x 2) or 32 x 128 (waves 1 x 4, for layers with <= 32 output channels:
 // the 16-channel stem / level-0 convs and the 27-channel DCN offset convs would waste 2-4x on a 64-row tile)
@@ -188,42 +188,52 @@ template <class WLoader, int BM, int BJ>
 __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
     typename WLoader::Params p, float* __restrict__ slabs, int Mp, int Jp, long long N, long long pix_per_split) {
     constexpr int GLD = BM + 1, BLD = BJ + 1;          // odd row strides: conflict-free pixel-major stores
-    constexpr int WJ = BJ / 32, NG = BM / 4, NB = BJ / 4;
-    __shared__ float Gs[WG_BP * GLD];
-    __shared__ float Bs[WG_BP * BLD];
+    constexpr int STEP = IG_THREADS / WG_BP;            // rows (channels / columns) covered per pass
+    constexpr int WJ = BJ / 32, NG = BM / STEP, NB = BJ / STEP;
+    // two LDS stages, one barrier per pixel chunk (32 pixels): chunk k+1 is stored while chunk k is consumed
+    __shared__ float Gs[2][WG_BP * GLD];
+    __shared__ float Bs[2][WG_BP * BLD];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j0 = blockIdx.x * BJ, m0 = blockIdx.y * BM;
     const long long n_begin = (long long)blockIdx.z * pix_per_split;
     long long n_end = n_begin + pix_per_split;
     if (n_end > N) n_end = N;
-    const int pl = tid & 63, sub = tid >> 6;  // pixel within chunk, row phase (0..3)
+    const int pl = tid % WG_BP, sub = tid / WG_BP;  // pixel within chunk, row phase (0..STEP-1)
     const int wm_off = (wid / WJ) * 32, wj_off = (wid % WJ) * 32;
     WLoader ld(p, n_begin + pl, n_end);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     float rg[NG], rb[NB];
-    ld.template load_g<NG>(m0, sub, rg);
-    ld.template load_b<NB>(j0, sub, rb);
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) Gs[buf][pl * GLD + sub + STEP * i] = rg[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Bs[buf][pl * BLD + sub + STEP * i] = rb[i];
+    };
+    auto stage_load = [&]() {
+        ld.template load_g<NG, STEP>(m0, sub, rg);
+        ld.template load_b<NB, STEP>(j0, sub, rb);
+    };
+    stage_load();
+    stage_store(0);
+    if (n_begin + WG_BP < n_end) { ld.advance(); stage_load(); }
+    __syncthreads();
+    int cur = 0;
+    const int kl = lane >> 5, il = lane & 31;
     for (long long nb = n_begin; nb < n_end; nb += WG_BP) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NG; ++i) Gs[pl * GLD + sub + 4 * i] = rg[i];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) Bs[pl * BLD + sub + 4 * i] = rb[i];
-        __syncthreads();
-        if (nb + WG_BP < n_end) {
-            ld.advance();
-            ld.template load_g<NG>(m0, sub, rg);
-            ld.template load_b<NB>(j0, sub, rb);
-        }
-        const int kl = lane >> 5, il = lane & 31;
 #pragma unroll
         for (int kk = 0; kk < WG_BP; kk += 2) {
-            const float a = Gs[(kk + kl) * GLD + wm_off + il];
-            const float b = Bs[(kk + kl) * BLD + wj_off + il];
+            const float a = Gs[cur][(kk + kl) * GLD + wm_off + il];
+            const float b = Bs[cur][(kk + kl) * BLD + wj_off + il];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
+        if (nb + WG_BP < n_end) {
+            stage_store(cur ^ 1);
+            if (nb + 2 * WG_BP < n_end) { ld.advance(); stage_load(); }
+        }
+        __syncthreads();
+        cur ^= 1;
     }
     float* slab = slabs + (size_t)blockIdx.z * Mp * Jp;
 #pragma unroll
