@@ -98,8 +98,12 @@ struct DcnFwdLoader {
     const float *in_b, *off_b, *mask_b;
     int oy, ox, K;
     bool valid;
-    int cur;   // tap whose sampling state `t` currently holds (K is tap-major: consecutive chunks share it)
-    Tap t;
+    int cur;   // tap whose sampling state currently sits in the registers below (K is tap-major:
+               // consecutive chunks share it)
+    // per (pixel, tap): clamped corner offsets and corner weights with validity and mask folded in, so
+    // one sampled value is 4 unconditional loads + 4 multiply-adds
+    int q00, q01, q10, q11;
+    float m00, m01, m10, m11;
     float* col_n;     // this pixel's column in the side output (nullptr: not requested / not the first M tile)
     int col_stride;
     __device__ __forceinline__ void disable_col() { col_n = nullptr; }
@@ -117,20 +121,46 @@ struct DcnFwdLoader {
         col_n = (p.col && n_valid) ? p.col + (size_t)b * K * HoWo + pp : nullptr;
         col_stride = HoWo;
     }
+    __device__ __forceinline__ void set_tap(int tap) {
+        const Tap t = make_tap(g, off_b, mask_b, 0, tap, oy, ox);
+        q00 = t.o00; q01 = t.o01; q10 = t.o10; q11 = t.o11;            // already 0 for missing corners
+        const float mk = (valid && t.inside) ? t.mask : 0.0f;
+        m00 = t.c00 ? t.hh * t.hw * mk : 0.0f;
+        m01 = t.c01 ? t.hh * t.lw * mk : 0.0f;
+        m10 = t.c10 ? t.lh * t.hw * mk : 0.0f;
+        m11 = t.c11 ? t.lh * t.lw * mk : 0.0f;
+        cur = tap;
+    }
     __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
         const int HW = g.H * g.W;
+        if (g.C % IG_BK == 0) {
+            // one tap per 16-deep chunk: no per-element index math
+            const int tap = k0 / g.C, c0 = k0 - tap * g.C + ksub;
+            if (k0 >= K) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+                return;
+            }
+            if (tap != cur) set_tap(tap);
+            const float* plane = in_b + (size_t)c0 * HW;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float* pl = plane + (size_t)(2 * j) * HW;
+                const float r = m00 * pl[q00] + m01 * pl[q01] + m10 * pl[q10] + m11 * pl[q11];
+                if (col_n) col_n[(size_t)(k0 + ksub + 2 * j) * col_stride] = r;
+                v[j] = r;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + ksub + 2 * j;
             float r = 0.0f;
-            if (valid && k < K) {
+            if (k < K) {
                 const int tap = k / g.C, c = k - tap * g.C;
-                if (tap != cur) { t = make_tap(g, off_b, mask_b, 0, tap, oy, ox); cur = tap; }
-                if (t.inside) {
-                    float v00, v01, v10, v11;
-                    tap_corners(t, in_b + (size_t)c * HW, v00, v01, v10, v11);
-                    r = tap_sample(t, v00, v01, v10, v11) * t.mask;
-                }
+                if (tap != cur) set_tap(tap);
+                const float* pl = in_b + (size_t)c * HW;
+                r = m00 * pl[q00] + m01 * pl[q01] + m10 * pl[q10] + m11 * pl[q11];
                 if (col_n) col_n[(size_t)k * col_stride] = r;
             }
             v[j] = r;
