@@ -271,7 +271,8 @@ __global__ __launch_bounds__(IG_THREADS) void dcn_bwd_data_kernel(DcnBwdParams p
     int* my_claim = claim + wid * (DB_WIN + 128);
     const int dcell = (int)(dump - win) + tid;
 
-    for (int i = tid; i < DB_BM * WSZ; i += IG_THREADS) win[i] = 0.0f;
+    // every wave zeroes the 16 channel planes it owns (only that wave ever touches them)
+    for (int i = lane; i < 16 * WSZ; i += 64) win[wid * 16 * WSZ + i] = 0.0f;
 
     for (int c0 = 0; c0 < Cpad; c0 += DB_BM) {
 #pragma unroll 1
@@ -420,21 +421,28 @@ __global__ __launch_bounds__(IG_THREADS) void dcn_bwd_data_kernel(DcnBwdParams p
                 }
             }
         }
-        // ---- flush this channel tile's window ----
+        // ---- flush this channel tile's window: every wave flushes (and re-zeroes) the 16 planes it owns,
+        //      so no workgroup barrier is needed; lanes walk the cells, coalesced global atomics ----
         if (use_win) {
-            __syncthreads();
-            for (int i = tid; i < DB_BM * WSZ; i += IG_THREADS) {
-                const float v = win[i];
-                if (v != 0.0f) {
-                    const int cl = i / WSZ, pos = i - cl * WSZ;
+            asm volatile("" ::: "memory");
+#pragma unroll 1
+            for (int q = 0; q < (DB_WIN + 63) / 64; ++q) {
+                const int pos = lane + 64 * q;
+                if (pos < WSZ) {
                     const int yy = pos / WC, xx = pos - yy * WC;
-                    const int c = c0 + cl;
-                    if (c < g.C)
-                        atomicAdd(p.gin + ((size_t)tile_b * g.C + c) * HW + (size_t)(wy0 + yy) * g.W + wx0 + xx, v);
-                    win[i] = 0.0f;
+                    float* gbase = p.gin + (size_t)tile_b * g.C * HW + (size_t)(wy0 + yy) * g.W + wx0 + xx;
+#pragma unroll 4
+                    for (int cc = 0; cc < 16; ++cc) {
+                        const int cl = wid * 16 + cc;
+                        const float v = win[cl * WSZ + pos];
+                        if (v != 0.0f) {
+                            if (c0 + cl < g.C) atomicAdd(gbase + (size_t)(c0 + cl) * HW, v);
+                            win[cl * WSZ + pos] = 0.0f;
+                        }
+                    }
                 }
             }
-            __syncthreads();
+            asm volatile("" ::: "memory");
         }
     }
 }
