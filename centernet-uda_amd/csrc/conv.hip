@@ -384,6 +384,10 @@ extern "C" size_t cnuda_conv2d_workspace_bytes(int B, int C, int H, int W, int C
     size_t m = q.fwd_bytes;
     if (q.dgrad_bytes > m) m = q.dgrad_bytes;
     if (q.wgrad_bytes > m) m = q.wgrad_bytes;
+    if (smallc_supported(C, Cout, kh, kw, sh, sw) || smallc_supported(Cout, C, kh, kw, sh, sw)) {
+        const size_t sm = smallc_workspace_bytes(B, C, H, W, Cout, kh, kw, sh, ph, pw) + carve_bytes((size_t)Cout * B, 4);
+        if (sm > m) m = sm;
+    }
     return m;
 }
 
@@ -393,6 +397,9 @@ extern "C" int cnuda_conv2d_forward(const float* x, const float* weight, const f
     CNUDA_REQUIRE(x && weight && y, "cnuda_conv2d_forward: null pointer");
     ConvGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_forward")) return rc;
+    if (smallc_supported(C, Cout, kh, kw, sh, sw) && !(g_conv_dbg & 64))
+        return smallc_forward(x, weight, bias, y, B, C, H, W, Cout, kh, kw, sh, ph, pw, act_slope, 0, workspace,
+                              workspace_bytes, (hipStream_t)stream);
     const ConvPlan q = make_plan(g);
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_conv2d_forward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -411,6 +418,10 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
     CNUDA_REQUIRE(grad_y && weight && grad_x, "cnuda_conv2d_backward_data: null pointer");
     ConvGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_backward_data")) return rc;
+    if (sh == 1 && sw == 1 && smallc_supported(Cout, C, kh, kw, 1, 1) && kh - 1 - ph >= 0 && kw - 1 - pw >= 0 &&
+        !(g_conv_dbg & 64))
+        return smallc_forward(grad_y, weight, nullptr, grad_x, B, Cout, g.Ho, g.Wo, C, kh, kw, 1, kh - 1 - ph,
+                              kw - 1 - pw, -1.0f, 1, workspace, workspace_bytes, (hipStream_t)stream);
     const ConvPlan q = make_plan(g);
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.dgrad_bytes, "cnuda_conv2d_backward_data: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -456,6 +467,14 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
     CNUDA_REQUIRE(x && grad_y && grad_weight, "cnuda_conv2d_backward_weight: null pointer");
     ConvGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_backward_weight")) return rc;
+    if (smallc_supported(C, Cout, kh, kw, sh, sw) && !(g_conv_dbg & 64)) {
+        hipStream_t st0 = (hipStream_t)stream;
+        if (int rc = smallc_backward_weight(x, grad_y, grad_weight, B, C, H, W, Cout, kh, kw, sh, ph, pw, workspace,
+                                            workspace_bytes, st0))
+            return rc;
+        if (grad_bias) launch_channel_sum(grad_y, grad_bias, B, Cout, (long long)g.Ho * g.Wo, st0);
+        return check_launch("cnuda_conv2d_backward_weight(small)");
+    }
     const ConvPlan q = make_plan(g);
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.wgrad_bytes, "cnuda_conv2d_backward_weight: workspace too small");
     hipStream_t st = (hipStream_t)stream;

@@ -30,6 +30,15 @@ void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp,
 void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st,
                         float* scratch = nullptr);
 
+// small-channel, full-resolution convolutions with LDS halo tiles (smallc.hip)
+bool smallc_supported(int C, int Co, int kh, int kw, int sh, int sw);
+size_t smallc_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int s, int ph, int pw);
+int smallc_forward(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W, int Co,
+                   int kh, int kw, int s, int ph, int pw, float act_slope, int transposed, void* ws, size_t ws_bytes,
+                   hipStream_t st);
+int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, int C, int H, int W, int Co, int kh,
+                           int kw, int s, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t st);
+
 struct Carver {
     uintptr_t cur, end;
     Carver(void* ws, size_t bytes) : cur(((uintptr_t)ws + 255) & ~(uintptr_t)255), end((uintptr_t)ws + bytes) {}

@@ -1,0 +1,409 @@
+// Convolutions with few channels at full image resolution -- the DLA-34 stem (3->16, 7x7 @512x512),
+// level0 (16->16, 3x3) and level1 (16->32, 3x3 stride 2): backends/dla.py:233-241, 277-287.
+// Their K = C*kh*kw is tiny (144-147) while the pixel count is huge, so the generic im2col-style implicit
+// GEMM spends its time re-gathering the same input pixel kh*kw times and pads the 16 output channels to a
+// 32-row MFMA tile.  Here the input tile is staged ONCE in LDS with its halo (zero-filled outside the
+// image) and the GEMM runs on v_mfma_f32_16x16x4_f32 tiles that match 16 output channels exactly:
+//
+//   forward : out[o][px] = sum_k Wp[k][o] * Xh[koff(k) + pix(px)]            k = (tap, c), c fastest
+//             A (weights) lives in registers for the whole workgroup (K/4 values per lane),
+//             B is one conflict-free ds_read_b32 per MFMA (lanes = 16 consecutive pixels).
+//   weight gradient : gw[o][k] = sum_px gy[o][px] * Xh[koff(k) + pix(px)]
+//             A = gy tile from LDS, B = the same halo image read with lanes = 16 consecutive k
+//             (c fastest -> plane stride, odd -> conflict-free); every wave owns a quarter of the
+//             tile's pixels and a private set of accumulators; partial slabs per workgroup, fixed-order
+//             reduction (bit-reproducible).
+// The stride-1 input gradient is the forward kernel on flipped / transposed weights.
+#include "igemm.cuh"
+#include "igemm_host.h"
+
+namespace cnuda {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int SC_MAXK = 160;          // K = C*kh*kw padded to a multiple of 4 (147 -> 148, 144)
+constexpr int SC_MAXKS = SC_MAXK / 4;  // MFMA k-steps
+constexpr int SC_TW = 64;             // output tile: TH rows x 64 columns, one row per wave
+constexpr int SC_TH = 4;
+
+struct SmallGeom {
+    int B, C, H, W, Co, kh, kw, s, ph, pw, Ho, Wo;
+    int K, Kp;              // C*kh*kw and its multiple-of-4 padding
+    int HR, HC, plane;      // halo rows / cols and the (odd) channel-plane stride of the LDS image
+};
+
+// halo image: Xh[c][hy][hx], hy in [0, HR), hx in [0, HC); input row = oy0*s - ph + hy.
+// Wave w stages rows w, w+4, ... of the C*HR halo rows; lanes run along the row (coalesced, no per-element
+// index arithmetic).
+constexpr int SC_ROWS_PER_WAVE = 24;   // C * HR <= 96 halo rows per tile (checked in smallc_supported)
+
+__device__ __forceinline__ void stage_halo(const SmallGeom& g, const float* __restrict__ xb, int iy0, int ix0,
+                                           float* __restrict__ Xh, int tid) {
+    const int lane = tid & 63, wid = tid >> 6;
+    const int rows = g.C * g.HR;
+    // global loads are issued in batches of 12 rows before their LDS stores: two round trips of latency per
+    // tile instead of one per row, at half the staging registers
+    constexpr int HB = SC_ROWS_PER_WAVE / 2;
+    const int ixa = ix0 + lane, ixb = ix0 + lane + 64;
+    const bool oka = ixa >= 0 && ixa < g.W, okb = lane + 64 < g.HC && ixb >= 0 && ixb < g.W;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        if (half * HB * 4 + wid >= rows) break;
+        float v0[HB], v1[HB];
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            const int row = wid + 4 * (half * HB + i);
+            const int c = row / g.HR, hy = row - c * g.HR;       // wave-uniform
+            const int iy = iy0 + hy;
+            const bool rok = row < rows && iy >= 0 && iy < g.H;
+            const float* src = xb + ((size_t)(rok ? c : 0) * g.H + (rok ? iy : 0)) * g.W;
+            v0[i] = (rok && oka) ? src[ixa] : 0.0f;
+            v1[i] = (rok && okb) ? src[ixb] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+            const int row = wid + 4 * (half * HB + i);
+            if (row < rows) {
+                const int c = row / g.HR, hy = row - c * g.HR;
+                float* dst = Xh + c * g.plane + hy * g.HC;
+                dst[lane] = v0[i];
+                if (lane + 64 < g.HC) dst[lane + 64] = v1[i];
+            }
+        }
+    }
+}
+
+// offset of GEMM row k = tap*C + c inside the halo image (relative to the pixel's top-left halo cell)
+__device__ __forceinline__ int k_offset(const SmallGeom& g, int k) {
+    if (k >= g.K) return 0;       // padding rows multiply zero weights
+    const int tap = k / g.C, c = k - tap * g.C;
+    const int r = tap / g.kw, t = tap - r * g.kw;
+    return c * g.plane + r * g.HC + t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward.  grid = (tiles_x, tiles_y, B); Wp is [Kp][16*MT] (packed, zero padded), MT = Co tiles of 16.
+// ---------------------------------------------------------------------------------------------
+constexpr int SC_NV = 8;   // vertical tiles per workgroup (amortises the per-workgroup weight / offset fetch)
+
+template <int MT>
+__global__ __launch_bounds__(IG_THREADS, 2) void smallc_fwd_kernel(SmallGeom g, const float* __restrict__ x,
+                                                               const float* __restrict__ Wp,
+                                                               const int* __restrict__ koff_tab,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               float act_slope) {
+    extern __shared__ __align__(16) float smem[];
+    float* Xh = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int kq = lane >> 4, il = lane & 15;
+    const int ox0 = blockIdx.x * SC_TW, b = blockIdx.z;
+    const float* xb = x + (size_t)b * g.C * g.H * g.W;
+    const int ksteps = g.Kp / 4;
+
+    // A fragments (weights) and halo offsets of this lane's k rows: constant for the whole kernel
+    float areg[MT][SC_MAXKS];
+    int koff[SC_MAXKS];
+#pragma unroll
+    for (int ks = 0; ks < SC_MAXKS; ++ks) {
+        if (ks < ksteps) {
+            const int k = ks * 4 + kq;
+            koff[ks] = koff_tab[k];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) areg[m][ks] = Wp[(size_t)k * (16 * MT) + m * 16 + il];
+        }
+    }
+    const int HoWo = g.Ho * g.Wo;
+#pragma unroll 1
+    for (int vt = 0; vt < SC_NV; ++vt) {
+    const int oy0 = (blockIdx.y * SC_NV + vt) * SC_TH;
+    if (oy0 >= g.Ho) break;
+    __syncthreads();                                // the previous tile's fragment reads are done
+    stage_halo(g, xb, oy0 * g.s - g.ph, ox0 * g.s - g.pw, Xh, tid);
+    __syncthreads();
+
+    const int oy = oy0 + wid;                       // one output row per wave
+    float* yb = y + (size_t)b * g.Co * HoWo + (size_t)oy * g.Wo;
+    if (oy < g.Ho) {
+        constexpr int NP = SC_TW / 16;                  // four 16-pixel tiles along the row, processed together
+        const int pbase0 = (wid * g.s) * g.HC + il * g.s;
+        f32x4 acc[MT][NP];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int pt = 0; pt < NP; ++pt) acc[m][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < SC_MAXKS; ++ks) {
+            if (ks < ksteps) {
+                float bv[NP];
+#pragma unroll
+                for (int pt = 0; pt < NP; ++pt) bv[pt] = Xh[koff[ks] + pbase0 + pt * 16 * g.s];
+#pragma unroll
+                for (int pt = 0; pt < NP; ++pt)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[m][ks], bv[pt], acc[m][pt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int pt = 0; pt < NP; ++pt) {
+            const int ox = ox0 + pt * 16 + il;
+            if (ox < g.Wo) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = m * 16 + kq * 4 + r;
+                        if (o < g.Co) {
+                            float v = acc[m][pt][r];
+                            if (bias) v += bias[o];
+                            if (act_slope >= 0.0f && v < 0.0f) v *= act_slope;
+                            yb[(size_t)o * HoWo + ox] = v;
+                        }
+                    }
+            }
+        }
+    }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient.  grid = (tiles_x, tiles_y, B); slab per workgroup: [16*MT][Kp16] (Kp16 = K padded to 16)
+// ---------------------------------------------------------------------------------------------
+constexpr int SC_MAXNT = SC_MAXK / 16;   // column tiles of 16 k
+
+template <int MT>
+__global__ __launch_bounds__(IG_THREADS) void smallc_wgrad_kernel(SmallGeom g, const float* __restrict__ x,
+                                                                 const float* __restrict__ gy,
+                                                                 const int* __restrict__ koff_tab,
+                                                                 float* __restrict__ slabs, int Kp16) {
+    extern __shared__ __align__(16) float smem[];
+    float* Xh = smem;                                   // [C][plane]
+    float* Gs = Xh + g.C * g.plane + 16;                // [16*MT][SC_TH*SC_TW + 1]  (o, pixel of the tile)
+    constexpr int GLD = SC_TH * SC_TW + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int kq = lane >> 4, il = lane & 15;
+    const int ox0 = blockIdx.x * SC_TW, b = blockIdx.z;
+    const int HoWo = g.Ho * g.Wo;
+    const float* xb = x + (size_t)b * g.C * g.H * g.W;
+    const float* gb = gy + (size_t)b * g.Co * HoWo;
+    const int ntiles = Kp16 / 16;
+
+    // this lane's column k = nt*16 + il of every column tile -> halo offset (B operand, lanes = columns)
+    int koff[SC_MAXNT];
+#pragma unroll
+    for (int nt = 0; nt < SC_MAXNT; ++nt) koff[nt] = nt < ntiles ? koff_tab[nt * 16 + il] : 0;
+
+    f32x4 acc[MT][SC_MAXNT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < SC_MAXNT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int vt = 0; vt < SC_NV; ++vt) {
+    const int oy0 = (blockIdx.y * SC_NV + vt) * SC_TH;
+    if (oy0 >= g.Ho) break;
+    __syncthreads();
+    stage_halo(g, xb, oy0 * g.s - g.ph, ox0 * g.s - g.pw, Xh, tid);
+    // gy tile: Gs[o][row*64 + col], zero outside the image / beyond Co; wave w stages rows (o, ty) w, w+4, ...
+    {
+        float gv[4 * MT * SC_TH];
+#pragma unroll
+        for (int i = 0; i < 4 * MT * SC_TH; ++i) {
+            const int row = wid + 4 * i;
+            const int o = row / SC_TH, ty = row - o * SC_TH;     // wave-uniform
+            const int oy = oy0 + ty, ox = ox0 + lane;
+            gv[i] = (o < g.Co && oy < g.Ho && ox < g.Wo) ? gb[(size_t)o * HoWo + (size_t)oy * g.Wo + ox] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * MT * SC_TH; ++i) {
+            const int row = wid + 4 * i;
+            const int o = row / SC_TH, ty = row - o * SC_TH;
+            Gs[o * GLD + ty * SC_TW + lane] = gv[i];
+        }
+    }
+    __syncthreads();
+
+    // wave `wid` reduces over row `wid` of the tile: 64 pixels = 16 MFMA k-steps of 4 pixels
+#pragma unroll 2
+    for (int ps = 0; ps < SC_TW / 4; ++ps) {
+        const int px = ps * 4 + kq;                       // this lane's pixel (k index of the MFMA)
+        const int pbase = (wid * g.s) * g.HC + px * g.s;
+        float a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = Gs[(m * 16 + il) * GLD + wid * SC_TW + px];
+#pragma unroll
+        for (int nt = 0; nt < SC_MAXNT; ++nt) {
+            if (nt < ntiles) {
+                const float bv = Xh[koff[nt] + pbase];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[m][nt], 0, 0, 0);
+            }
+        }
+    }
+    }
+    // sum the four waves' partials through LDS in a fixed order, then write the workgroup's slab
+    __syncthreads();
+    float* red = smem;                                   // reuse: [4 waves][16*MT][Kp16]
+    const int slab_elems = 16 * MT * Kp16;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < SC_MAXNT; ++nt)
+            if (nt < ntiles)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    red[wid * slab_elems + (m * 16 + kq * 4 + r) * Kp16 + nt * 16 + il] = acc[m][nt][r];
+    __syncthreads();
+    const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float* slab = slabs + wg * slab_elems;
+    for (int e = tid; e < slab_elems; e += IG_THREADS)
+        slab[e] = ((red[e] + red[slab_elems + e]) + red[2 * slab_elems + e]) + red[3 * slab_elems + e];
+}
+
+// gw[o][c][tap] = sum_z slabs[z][o][tap*C + c]; 4 waves x interleaved z (same scheme as slab_reduce_kernel)
+__global__ __launch_bounds__(256) void smallc_slab_reduce_kernel(const float* __restrict__ slabs,
+                                                                 float* __restrict__ gw, int Z, int Mp, int Kp16,
+                                                                 int Co, int C, int T) {
+    __shared__ float part[4][64];
+    const int K = T * C;
+    const long long total = (long long)Co * K;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + lane;
+    float s = 0.0f;
+    int o = 0, k = 0;
+    if (i < total) {
+        o = (int)(i / K);
+        k = (int)(i - (long long)o * K);
+        const size_t off = (size_t)o * Kp16 + k;
+        for (int z = w; z < Z; z += 4) s += slabs[(size_t)z * Mp * Kp16 + off];
+    }
+    part[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < total) {
+        const int tap = k / C, c = k - tap * C;
+        gw[((size_t)o * C + c) * T + tap] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    }
+}
+
+// Wp[k = tap*C + c][m] = W[m][c][tap]  (forward)  or, for the stride-1 input gradient computed as a
+// forward conv of grad_y:  Wp[k = tap*Co + o][m = c] = W[o][c][T-1-tap]   (flipped taps, swapped channels)
+__global__ void smallc_pack_kernel(const float* __restrict__ W, float* __restrict__ Wp, int Co, int C, int T, int Kp,
+                                   int Mp, int transposed) {
+    const int total = Kp * Mp;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int k = i / Mp, m = i - k * Mp;
+        float v = 0.0f;
+        if (!transposed) {
+            if (k < T * C && m < Co) { const int tap = k / C, c = k - tap * C; v = W[((size_t)m * C + c) * T + tap]; }
+        } else {
+            if (k < T * Co && m < C) { const int tap = k / Co, o = k - tap * Co; v = W[((size_t)o * C + m) * T + (T - 1 - tap)]; }
+        }
+        Wp[i] = v;
+    }
+}
+
+__global__ void smallc_koff_kernel(SmallGeom g, int* __restrict__ tab, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) tab[k] = k_offset(g, k);
+}
+
+bool fill_small(SmallGeom& g, int B, int C, int H, int W, int Co, int kh, int kw, int s, int ph, int pw) {
+    g.B = B; g.C = C; g.H = H; g.W = W; g.Co = Co; g.kh = kh; g.kw = kw; g.s = s; g.ph = ph; g.pw = pw;
+    g.Ho = (H + 2 * ph - kh) / s + 1;
+    g.Wo = (W + 2 * pw - kw) / s + 1;
+    g.K = C * kh * kw;
+    g.Kp = (g.K + 3) / 4 * 4;
+    g.HR = (SC_TH - 1) * s + kh;
+    g.HC = (SC_TW - 1) * s + kw;
+    g.plane = g.HR * g.HC;
+    if ((g.plane & 1) == 0) g.plane += 1;    // odd plane stride: lanes that differ in c hit different banks
+    return true;
+}
+
+}  // namespace
+
+// ---- entry points used by conv.hip -----------------------------------------------------------------
+bool smallc_supported(int C, int Co, int kh, int kw, int sh, int sw) {
+    // stride 2 needs a halo tile of ~75 KB (one workgroup per CU): measured slower than the generic kernels
+    return sh == 1 && sw == 1 && C <= 16 && Co <= 32 && C * kh * kw <= SC_MAXK - 12 &&
+           C * (SC_TH - 1 + kh) <= 4 * SC_ROWS_PER_WAVE && SC_TW - 1 + kw <= 128;
+}
+size_t smallc_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int s, int ph, int pw) {
+    SmallGeom g;
+    fill_small(g, B, C, H, W, Co, kh, kw, s, ph, pw);
+    const int mt = (Co + 15) / 16, Kp16 = (g.K + 15) / 16 * 16;
+    const size_t tiles = (size_t)ceil_div(g.Wo, SC_TW) * ceil_div(g.Ho, SC_TH * SC_NV) * B;
+    return carve_bytes((size_t)g.Kp * 16 * mt, 4) + carve_bytes(SC_MAXK, 4) + carve_bytes(tiles * 16 * mt * Kp16, 4) + 512;
+}
+
+int smallc_forward(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W, int Co,
+                   int kh, int kw, int s, int ph, int pw, float act_slope, int transposed, void* ws, size_t ws_bytes,
+                   hipStream_t st) {
+    // transposed: computes the stride-1 input gradient: x := grad_y [B, Co_orig, H, W], w is the ORIGINAL
+    // weight [Co_orig = C here][C_orig = Co here][kh][kw]; the caller passes C/Co already swapped.
+    SmallGeom g;
+    fill_small(g, B, C, H, W, Co, kh, kw, s, ph, pw);
+    const int mt = (Co + 15) / 16;
+    Carver cv(ws, ws_bytes);
+    float* Wp = cv.take<float>((size_t)g.Kp * 16 * mt);
+    int* koff = cv.take<int>(SC_MAXK);
+    CNUDA_REQUIRE(cv.ok(), "smallc_forward: workspace too small");
+    hipLaunchKernelGGL(smallc_koff_kernel, dim3(1), dim3(SC_MAXK), 0, st, g, koff, SC_MAXK);
+    // pack: forward W[Co][C][T]; transposed: original W[C_here... ] see kernel comment
+    if (!transposed)
+        hipLaunchKernelGGL(smallc_pack_kernel, dim3(32), dim3(256), 0, st, w, Wp, Co, C, kh * kw, g.Kp, 16 * mt, 0);
+    else
+        hipLaunchKernelGGL(smallc_pack_kernel, dim3(32), dim3(256), 0, st, w, Wp, /*Co_orig=*/C, /*C_orig=*/Co,
+                           kh * kw, g.Kp, 16 * mt, 1);
+    const size_t lds = (size_t)(g.C * g.plane + 16) * sizeof(float);
+    const dim3 grid(ceil_div(g.Wo, SC_TW), ceil_div(g.Ho, SC_TH * SC_NV), B);
+    ProfScope prof(st);
+    if (mt == 1)
+        hipLaunchKernelGGL(smallc_fwd_kernel<1>, grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope);
+    else
+        hipLaunchKernelGGL(smallc_fwd_kernel<2>, grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope);
+    return check_launch("smallc_forward");
+}
+
+int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, int C, int H, int W, int Co, int kh,
+                           int kw, int s, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t st) {
+    SmallGeom g;
+    fill_small(g, B, C, H, W, Co, kh, kw, s, ph, pw);
+    const int mt = (Co + 15) / 16, Kp16 = (g.K + 15) / 16 * 16;
+    const dim3 grid(ceil_div(g.Wo, SC_TW), ceil_div(g.Ho, SC_TH * SC_NV), B);
+    const size_t tiles = (size_t)grid.x * grid.y * grid.z;
+    Carver cv(ws, ws_bytes);
+    (void)cv.take<float>((size_t)g.Kp * 16 * mt);
+    int* koff = cv.take<int>(SC_MAXK);
+    float* slabs = cv.take<float>(tiles * 16 * mt * Kp16);
+    CNUDA_REQUIRE(cv.ok(), "smallc_backward_weight: workspace too small");
+    hipLaunchKernelGGL(smallc_koff_kernel, dim3(1), dim3(SC_MAXK), 0, st, g, koff, SC_MAXK);
+    const size_t stage = (size_t)(g.C * g.plane + 16) + (size_t)16 * mt * (SC_TH * SC_TW + 1);
+    const size_t red = (size_t)4 * 16 * mt * Kp16;
+    const size_t lds = (stage > red ? stage : red) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(smallc_wgrad_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(smallc_wgrad_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    {
+        ProfScope prof(st);
+        if (mt == 1)
+            hipLaunchKernelGGL(smallc_wgrad_kernel<1>, grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16);
+        else
+            hipLaunchKernelGGL(smallc_wgrad_kernel<2>, grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16);
+    }
+    if (int rc = check_launch("smallc_backward_weight")) return rc;
+    const long long total = (long long)Co * g.K;
+    hipLaunchKernelGGL(smallc_slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, slabs, gw,
+                       (int)tiles, 16 * mt, Kp16, Co, C, kh * kw);
+    return check_launch("smallc_backward_weight(reduce)");
+}
+
+}  // namespace cnuda
