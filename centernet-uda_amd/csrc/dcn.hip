@@ -37,14 +37,27 @@ struct Tap {
     bool inside, c00, c01, c10, c11;
 };
 
+// the three per-(pixel, tap) inputs of the sampling geometry; loaded one tap ahead where latency matters
+struct TapRaw { float dy, dx, mask; };
+__device__ __forceinline__ TapRaw load_tap_raw(const DcnGeom& g, const float* __restrict__ off_b,
+                                               const float* __restrict__ mask_b, int grp, int tap, int p) {
+    const int T = g.kh * g.kw, HoWo = g.Ho * g.Wo;
+    TapRaw r;
+    r.dy = off_b[((size_t)grp * 2 * T + 2 * tap) * HoWo + p];
+    r.dx = off_b[((size_t)grp * 2 * T + 2 * tap + 1) * HoWo + p];
+    r.mask = mask_b[((size_t)grp * T + tap) * HoWo + p];
+    return r;
+}
+__device__ __forceinline__ Tap tap_from_raw(const DcnGeom& g, const TapRaw& raw, int tap, int oy, int ox);
 __device__ __forceinline__ Tap make_tap(const DcnGeom& g, const float* __restrict__ off_b,
                                         const float* __restrict__ mask_b, int grp, int tap, int oy, int ox) {
-    const int T = g.kh * g.kw, HoWo = g.Ho * g.Wo, p = oy * g.Wo + ox;
+    return tap_from_raw(g, load_tap_raw(g, off_b, mask_b, grp, tap, oy * g.Wo + ox), tap, oy, ox);
+}
+__device__ __forceinline__ Tap tap_from_raw(const DcnGeom& g, const TapRaw& raw, int tap, int oy, int ox) {
     const int i = tap / g.kw, j = tap - i * g.kw;
-    const float dy = off_b[((size_t)grp * 2 * T + 2 * tap) * HoWo + p];
-    const float dx = off_b[((size_t)grp * 2 * T + 2 * tap + 1) * HoWo + p];
+    const float dy = raw.dy, dx = raw.dx;
     Tap t;
-    t.mask = mask_b[((size_t)grp * T + tap) * HoWo + p];
+    t.mask = raw.mask;
     const float h = (float)(oy * g.sh - g.ph + i * g.dh) + dy;
     const float w = (float)(ox * g.sw - g.pw + j * g.dw) + dx;
     t.inside = (h > -1.0f) && (w > -1.0f) && (h < (float)g.H) && (w < (float)g.W);
@@ -209,7 +222,7 @@ int g_dcn_dbg = 0;
 constexpr int DB_BM = 64, DB_BN = 32, DB_WIN = 256;   // window cells per channel (64*256*4 B = 64 KiB -> 2 workgroups / CU)
 constexpr int DB_NT = DB_BN / 16;                      // 16-pixel MFMA tiles per wave
 
-__global__ __launch_bounds__(IG_THREADS) void dcn_bwd_data_kernel(DcnBwdParams p, const float* __restrict__ A2,
+__global__ __launch_bounds__(IG_THREADS, 2) void dcn_bwd_data_kernel(DcnBwdParams p, const float* __restrict__ A2,
                                                                  int Mp2, int Kp, int Cpad, long long N, int n_tiles) {
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     extern __shared__ __align__(16) float smem[];
@@ -274,9 +287,41 @@ __global__ __launch_bounds__(IG_THREADS) void dcn_bwd_data_kernel(DcnBwdParams p
     // every wave zeroes the 16 channel planes it owns (only that wave ever touches them)
     for (int i = lane; i < 16 * WSZ; i += 64) win[wid * 16 * WSZ + i] = 0.0f;
 
+    // sampling inputs of tap 0 (then always one tap ahead: their latency hides under the previous tap's work)
+    TapRaw raw_next[DB_NT];
+#pragma unroll
+    for (int j = 0; j < DB_NT; ++j)
+        raw_next[j] = load_tap_raw(g, p.off + (size_t)eb[j] * 2 * T * HoWo, p.mask + (size_t)eb[j] * T * HoWo, 0, 0,
+                                   ep[j]);
+
     for (int c0 = 0; c0 < Cpad; c0 += DB_BM) {
 #pragma unroll 1
         for (int tap = 0; tap < T; ++tap) {
+            // ---- geometry of this tap for the lane's pixels, corner loads issued BEFORE the GEMM loop ----
+            Tap tp[DB_NT];
+            float v00[DB_NT][4], v01[DB_NT][4], v10[DB_NT][4], v11[DB_NT][4];
+#pragma unroll
+            for (int j = 0; j < DB_NT; ++j) {
+                tp[j] = tap_from_raw(g, raw_next[j], tap, eoy[j], eox[j]);
+                const bool live = pv[j] && tp[j].inside;
+                const int o00 = (live && tp[j].c00) ? tp[j].o00 : 0, o01 = (live && tp[j].c01) ? tp[j].o01 : 0;
+                const int o10 = (live && tp[j].c10) ? tp[j].o10 : 0, o11 = (live && tp[j].c11) ? tp[j].o11 : 0;
+                const float* in_b = p.in + (size_t)eb[j] * g.C * HW;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int c = c0 + wid * 16 + kq * 4 + r;
+                    c = c < g.C ? c : g.C - 1;                       // padded rows carry dcol == 0
+                    const float* plane = in_b + (size_t)c * HW;
+                    v00[j][r] = plane[o00]; v01[j][r] = plane[o01]; v10[j][r] = plane[o10]; v11[j][r] = plane[o11];
+                }
+            }
+            {   // next tap's sampling inputs (wraps to tap 0 of the next channel tile)
+                const int nt = tap + 1 < T ? tap + 1 : 0;
+#pragma unroll
+                for (int j = 0; j < DB_NT; ++j)
+                    raw_next[j] = load_tap_raw(g, p.off + (size_t)eb[j] * 2 * T * HoWo,
+                                               p.mask + (size_t)eb[j] * T * HoWo, 0, nt, ep[j]);
+            }
             f32x4 acc[DB_NT];
 #pragma unroll
             for (int j = 0; j < DB_NT; ++j)
@@ -318,8 +363,7 @@ __global__ __launch_bounds__(IG_THREADS) void dcn_bwd_data_kernel(DcnBwdParams p
             // ---- consume the dcol tile: lane holds channels cl = wid*16 + kq*4 + r (r<4) of pixel j*16+il ----
 #pragma unroll
             for (int j = 0; j < DB_NT; ++j) {
-                const Tap t = make_tap(g, p.off + (size_t)eb[j] * 2 * T * HoWo, p.mask + (size_t)eb[j] * T * HoWo, 0,
-                                       tap, eoy[j], eox[j]);
+                const Tap& t = tp[j];
                 const bool live = pv[j] && t.inside;
                 const int h0 = t.h0 - wy0, w0 = t.w0 - wx0;
                 const bool r0 = use_win && h0 >= 0 && h0 < WR, r1 = use_win && h0 + 1 >= 0 && h0 + 1 < WR;
@@ -332,28 +376,19 @@ __global__ __launch_bounds__(IG_THREADS) void dcn_bwd_data_kernel(DcnBwdParams p
                 const float k10 = a10 ? t.lh * t.hw : 0.f, k11 = a11 ? t.lh * t.lw : 0.f;
                 const float mk = live ? t.mask : 0.f;
                 const int o00 = a00 ? t.o00 : 0, o01 = a01 ? t.o01 : 0, o10 = a10 ? t.o10 : 0, o11 = a11 ? t.o11 : 0;
-                const float* in_b = p.in + (size_t)eb[j] * g.C * HW;
                 // collision check: do two pixels of this 16-lane group share a window cell?  The four
                 // corner cells of a pixel are a fixed pattern around (h0, w0), so comparing the anchor
                 // cell of every in-window pixel is enough.  kq == 0 lanes vote (all kq see the same pixels).
                 const int anchor = (live && use_win && h0 >= -1 && h0 < WR && w0 >= -1 && w0 < WC)
                                        ? (h0 + 1) * (WC + 1) + (w0 + 1) : -1;   // (WR+1) x (WC+1) grid incl. the -1 row/col
-                float v00[4], v01[4], v10[4], v11[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int c = c0 + wid * 16 + kq * 4 + r;
-                    c = c < g.C ? c : g.C - 1;                       // padded rows carry dcol == 0
-                    const float* plane = in_b + (size_t)c * HW;
-                    v00[r] = plane[o00]; v01[r] = plane[o01]; v10[r] = plane[o10]; v11[r] = plane[o11];
-                }
                 float sm = 0.f, sh_ = 0.f, sw_ = 0.f;
                 float dmv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int cl = wid * 16 + kq * 4 + r;
                     const float d = (c0 + cl < g.C) ? acc[j][r] : 0.0f;
-                    const float e00 = a00 ? v00[r] : 0.f, e01 = a01 ? v01[r] : 0.f;
-                    const float e10 = a10 ? v10[r] : 0.f, e11 = a11 ? v11[r] : 0.f;
+                    const float e00 = a00 ? v00[j][r] : 0.f, e01 = a01 ? v01[j][r] : 0.f;
+                    const float e10 = a10 ? v10[j][r] : 0.f, e11 = a11 ? v11[j][r] : 0.f;
                     sm += d * (t.hh * t.hw * e00 + t.hh * t.lw * e01 + t.lh * t.hw * e10 + t.lh * t.lw * e11);
                     const float dm = d * mk;
                     dmv[r] = dm;
