@@ -180,9 +180,21 @@ def main():
         if per_kernel:
             name, d = max(per_kernel.items(), key=lambda kv: kv[1]['ms'])
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            traffic, traffic_note = None, None
+            tpath = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
+            if os.path.exists(tpath):
+                # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+                # (separate FETCH_SIZE / WRITE_SIZE runs, KB units; FETCH_SIZE left uncorrected because the
+                # kernel's reads are 4-byte-per-lane gathers, for which the guide gives no calibration)
+                norm = lambda k: k.replace(' ', '')
+                t = {norm(k): v for k, v in json.load(open(tpath)).items()}.get(norm(name))
+                if t:
+                    traffic = round((t['fetch_kb_per_launch'] + t['write_kb_per_launch']) * 1024)
+                    traffic_note = 'bytes/launch, profiles/r1_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE, uncorrected)'
             roofline = {
                 'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                'traffic_note': traffic_note,
                 'launches_per_step': d['launches'] // args.profile_steps,
                 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                 'algorithmic_gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),

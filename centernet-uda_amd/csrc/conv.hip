@@ -429,6 +429,7 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
     float* A = cv.take<float>((size_t)q.Kpd * q.Mpd);
     if ((sh > 1 || sw > 1) && H % sh == 0 && W % sw == 0 && Cout % IG_BK == 0 && kh * kw <= 9) {
         // one launch per parity class, K restricted to the taps that class can see
+        ProfScope prof(st);   // brackets the whole class group (inner scopes find nothing armed)
         for (int py = 0; py < sh; ++py)
             for (int px = 0; px < sw; ++px) {
                 ConvDgradClassParams cp;

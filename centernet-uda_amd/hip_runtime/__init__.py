@@ -155,24 +155,48 @@ class _Prof:
     cap = 0
 
 
-def _bm(m):
-    return 128 if m > 64 else (64 if m > 32 else 32)
+def _bm(m, n):
+    """mirror of pick_bm() in csrc/conv.hip / dcn.hip (tile rows for M output rows and N pixels)."""
+    bm = 128 if m > 64 else (64 if m > 32 else 32)
+    n_tiles = (n + 127) // 128
+    while bm > 32 and n_tiles * ((m + bm - 1) // bm) < 512:
+        bm >>= 1
+    return bm
+
+
+def _smallc(C, Co, kh, kw, stride):
+    return stride == 1 and C <= 16 and Co <= 32 and C * kh * kw <= 148 and C * (3 + kh) <= 96
 
 
 def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
-    """Called by the conv / DCN ops right before the C-ABI call when profiling is on."""
+    """Called by the conv / DCN ops right before the C-ABI call when profiling is on.  The kernel name is
+    the template instance the library will pick (same selection rules), so that bench.py's per-kernel
+    aggregation lines up with rocprofv3's kernel names."""
     if not _Prof.enabled or len(_Prof.table) >= _Prof.cap:
         return
     flops = 2.0 * B * Ho * Wo * Co * C * kh * kw          # 2*Cout*Cin*kh*kw*Ho*Wo per image (SURVEY 8d)
-    fast = 'true' if C % 16 == 0 else 'false'
+    stride = max(1, round(H / max(Ho, 1)))
+    tf = lambda v: 'true' if v else 'false'
     if kind == 'conv_fwd':
-        name = 'igemm_fwd_kernel<%d, ConvFwdLoader<%s>>' % (_bm(Co), fast)
+        if _smallc(C, Co, kh, kw, stride):
+            name = 'smallc_fwd_kernel<%d>' % ((Co + 15) // 16)
+        else:
+            name = 'igemm_fwd_kernel<%d, ConvFwdLoader<%s>>' % (_bm(Co, B * Ho * Wo), tf(C % 16 == 0))
     elif kind == 'conv_dgrad':
-        name = 'igemm_fwd_kernel<%d, ConvDgradLoader<%s>>' % (_bm(C), 'true' if Co % 16 == 0 else 'false')
+        if stride == 1 and _smallc(Co, C, kh, kw, 1):
+            name = 'smallc_fwd_kernel<%d>' % ((C + 15) // 16)
+        elif stride > 1 and H % stride == 0 and W % stride == 0 and Co % 16 == 0 and kh * kw <= 9:
+            name = 'igemm_fwd_kernel<*, ConvDgradClassLoader> (group of stride^2 class launches)'
+        else:
+            name = 'igemm_fwd_kernel<%d, ConvDgradLoader<%s>>' % (_bm(C, B * H * W), tf(Co % 16 == 0))
     elif kind == 'conv_wgrad':
-        name = 'igemm_wgrad_kernel<ConvWLoader>'
+        if _smallc(C, Co, kh, kw, stride):
+            name = 'smallc_wgrad_kernel<%d>' % ((Co + 15) // 16)
+        else:
+            name = 'igemm_wgrad_kernel<ConvWLoader<%d>, %s>' % (2 if C % 64 == 0 else 0,
+                                                                '32, 128' if Co <= 32 else '64, 64')
     elif kind == 'dcn_fwd':
-        name = 'igemm_fwd_kernel<%d, DcnFwdLoader>' % _bm(Co)
+        name = 'igemm_fwd_kernel<%d, DcnFwdLoader>' % _bm(Co, B * Ho * Wo)
     elif kind == 'dcn_bwd':
         name = 'dcn_bwd_data_kernel'
     else:
