@@ -427,7 +427,8 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
     float* A = cv.take<float>((size_t)q.Kpd * q.Mpd);
-    if ((sh > 1 || sw > 1) && H % sh == 0 && W % sw == 0 && Cout % IG_BK == 0 && kh * kw <= 9) {
+    if ((sh > 1 || sw > 1) && H % sh == 0 && W % sw == 0 && Cout % IG_BK == 0 &&
+        ceil_div(kh, sh) * ceil_div(kw, sw) <= 9) {   // taps one class can see (tap_r/tap_s hold 9)
         // one launch per parity class, K restricted to the taps that class can see
         ProfScope prof(st);   // brackets the whole class group (inner scopes find nothing armed)
         for (int py = 0; py < sh; ++py)
@@ -435,7 +436,7 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
                 ConvDgradClassParams cp;
                 cp.g = g; cp.gy = grad_y; cp.gx = grad_x; cp.py = py; cp.px = px; cp.Hc = H / sh; cp.Wc = W / sw;
                 cp.ntaps = 0;
-                int taps[9];
+                int taps[9];   // at most ceil(kh/sh)*ceil(kw/sw) entries
                 for (int r = 0; r < kh; ++r)
                     for (int t = 0; t < kw; ++t)
                         // (iy + ph - r) must be a multiple of sh for every iy = py + sh*qy: decided by py alone

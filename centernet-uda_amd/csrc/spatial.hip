@@ -60,6 +60,64 @@ __global__ void maxpool_bwd_tail_kernel(float* __restrict__ gx, long long planes
     }
 }
 
+// ---- max pool, window k x k, stride s, padding p (-inf): torchvision resnet stem pool k3 s2 p1
+//      (backends/resnet.py:27-30 keeps it in `base`) --------------------------------------------
+__device__ __forceinline__ int window_argmax(const float* __restrict__ src, int H, int W, int oy, int ox, int k, int s,
+                                             int p, float& m) {
+    // scan order (dy, dx) ascending, first maximum wins, NaN propagates: ATen's max_pool2d rule
+    int arg = -1;
+    m = -INFINITY;
+    for (int dy = 0; dy < k; ++dy) {
+        const int iy = oy * s - p + dy;
+        if (iy < 0 || iy >= H) continue;
+        for (int dx = 0; dx < k; ++dx) {
+            const int ix = ox * s - p + dx;
+            if (ix < 0 || ix >= W) continue;
+            const float v = src[iy * W + ix];
+            if (arg < 0 || v > m || v != v) { m = v; arg = iy * W + ix; }
+        }
+    }
+    return arg;
+}
+__global__ void maxpool_win_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes, int H,
+                                       int W, int Ho, int Wo, int k, int s, int p) {
+    const long long total = planes * Ho * Wo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho);
+        const long long pl = i / ((long long)Wo * Ho);
+        float m;
+        window_argmax(x + (size_t)pl * H * W, H, W, oy, ox, k, s, p, m);
+        y[i] = m;
+    }
+}
+// gather form (windows overlap when s < k): each input cell sums grad_y of the windows whose arg-max it is,
+// in ascending window order -- deterministic, no atomics
+__global__ void maxpool_win_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                       float* __restrict__ gx, long long planes, int H, int W, int Ho, int Wo, int k,
+                                       int s, int p) {
+    const long long total = planes * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % W), iy = (int)((i / W) % H);
+        const long long pl = i / ((long long)W * H);
+        const float* src = x + (size_t)pl * H * W;
+        const float* g = gy + (size_t)pl * Ho * Wo;
+        // windows with oy*s - p <= iy <= oy*s - p + k - 1
+        int oy0 = (iy + p - k + s) / s, ox0 = (ix + p - k + s) / s;   // ceil((iy+p-k+1)/s) for non-negative numerators
+        if (iy + p - k + 1 <= 0) oy0 = 0;
+        if (ix + p - k + 1 <= 0) ox0 = 0;
+        const int oy1 = min((iy + p) / s, Ho - 1), ox1 = min((ix + p) / s, Wo - 1);
+        float acc = 0.0f;
+        for (int oy = oy0; oy <= oy1; ++oy)
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                float m;
+                if (window_argmax(src, H, W, oy, ox, k, s, p, m) == iy * W + ix) acc += g[oy * Wo + ox];
+            }
+        gx[i] = acc;
+    }
+}
+
 // ---- depthwise transposed conv: k = 2f, stride f, padding f/2 (any k,s,p accepted) ----
 // y[b,c,oy,ox] = sum_{ky,kx} x[b,c,(oy+p-ky)/s,(ox+p-kx)/s] * w[c,ky,kx]   (exact divisions only)
 __global__ void dwconvt_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
@@ -222,6 +280,28 @@ extern "C" int cnuda_maxpool2d_backward(const float* x, const float* grad_y, flo
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid(planes * Ho * Wo, kT)), dim3(kT), 0, st, x, grad_y, grad_x,
                        planes, H, W, Ho, Wo, k);
     return check_launch("cnuda_maxpool2d_backward");
+}
+
+extern "C" int cnuda_maxpool2d_window_forward(const float* x, float* y, int B, int C, int H, int W, int k, int s, int p,
+                                              cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && y && B > 0 && C > 0 && k > 0 && s > 0 && p >= 0 && 2 * p <= k && H + 2 * p >= k && W + 2 * p >= k,
+                  "cnuda_maxpool2d_window_forward: bad arguments (need 2*padding <= kernel <= padded size)");
+    const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+    const long long planes = (long long)B * C;
+    hipLaunchKernelGGL(maxpool_win_fwd_kernel, dim3(stream_grid(planes * Ho * Wo, kT)), dim3(kT), 0,
+                       (hipStream_t)stream, x, y, planes, H, W, Ho, Wo, k, s, p);
+    return check_launch("cnuda_maxpool2d_window_forward");
+}
+extern "C" int cnuda_maxpool2d_window_backward(const float* x, const float* grad_y, float* grad_x, int B, int C, int H,
+                                               int W, int k, int s, int p, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && grad_y && grad_x && B > 0 && C > 0 && k > 0 && s > 0 && p >= 0 && 2 * p <= k && H + 2 * p >= k &&
+                      W + 2 * p >= k,
+                  "cnuda_maxpool2d_window_backward: bad arguments");
+    const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+    const long long planes = (long long)B * C;
+    hipLaunchKernelGGL(maxpool_win_bwd_kernel, dim3(stream_grid(planes * H * W, kT)), dim3(kT), 0, (hipStream_t)stream,
+                       x, grad_y, grad_x, planes, H, W, Ho, Wo, k, s, p);
+    return check_launch("cnuda_maxpool2d_window_backward");
 }
 
 extern "C" int cnuda_dwconvt2d_forward(const float* x, const float* w, float* y, int B, int C, int H, int W, int k,

@@ -77,6 +77,8 @@ class _Sig:
     cnuda_bn_backward = (_I, [_P] * 10 + [_I, _I, _I, _LL] + _WS)
     cnuda_maxpool2d_forward = (_I, [_P] * 2 + [_I] * 5 + [_P])
     cnuda_maxpool2d_backward = (_I, [_P] * 3 + [_I] * 5 + [_P])
+    cnuda_maxpool2d_window_forward = (_I, [_P] * 2 + [_I] * 7 + [_P])
+    cnuda_maxpool2d_window_backward = (_I, [_P] * 3 + [_I] * 7 + [_P])
     cnuda_dwconvt2d_forward = (_I, [_P] * 3 + [_I] * 7 + [_P])
     cnuda_dwconvt2d_backward = (_I, [_P] * 5 + [_I] * 7 + [_P])
     cnuda_add = (_I, [_P] * 3 + [_LL, _P])
@@ -185,7 +187,8 @@ def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
     elif kind == 'conv_dgrad':
         if stride == 1 and _smallc(Co, C, kh, kw, 1):
             name = 'smallc_fwd_kernel<%d>' % ((C + 15) // 16)
-        elif stride > 1 and H % stride == 0 and W % stride == 0 and Co % 16 == 0 and kh * kw <= 9:
+        elif stride > 1 and H % stride == 0 and W % stride == 0 and Co % 16 == 0 and \
+                (-(-kh // stride)) * (-(-kw // stride)) <= 9:
             name = 'igemm_fwd_kernel<*, ConvDgradClassLoader> (group of stride^2 class launches)'
         else:
             name = 'igemm_fwd_kernel<%d, ConvDgradLoader<%s>>' % (_bm(C, B * H * W), tf(Co % 16 == 0))

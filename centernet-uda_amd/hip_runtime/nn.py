@@ -66,12 +66,33 @@ class BatchNorm2d(nn.Module):
 
 
 class MaxPool2d(nn.Module):
-    def __init__(self, kernel_size):
+    def __init__(self, kernel_size, stride=None, padding=0):
         super().__init__()
         self.kernel_size = int(kernel_size)
+        self.stride = self.kernel_size if stride is None else int(stride)
+        self.padding = int(padding)
 
     def forward(self, x):
-        return ops.max_pool2d(x, self.kernel_size)
+        return ops.max_pool2d(x, self.kernel_size, self.stride, self.padding)
+
+
+class ConvTranspose2d(nn.Module):
+    """nn.ConvTranspose2d(in, out, k, stride, padding, output_padding, bias=False); weight [in, out, k, k]
+    (the up-sampling stages of CenterResNet, backends/resnet.py:86-94)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.output_padding = _pair(padding), _pair(output_padding)
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, *self.kernel_size))
+        # nn.ConvTranspose2d's default init: kaiming_uniform(a=sqrt(5)) with fan_in = weight.size(1) * k * k
+        bound = 1.0 / math.sqrt(out_channels * self.kernel_size[0] * self.kernel_size[1])
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+
+    def forward(self, x):
+        return ops.conv_transpose2d(x, self.weight, self.stride, self.padding, self.output_padding)
 
 
 class DepthwiseConvTranspose2d(nn.Module):

@@ -84,6 +84,65 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0):
     return _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope))
 
 
+class _ConvTranspose2d(Function):
+    """nn.ConvTranspose2d(Cin, Cout, k, stride, padding, bias=False) (backends/resnet.py:86-94): the input
+    gradient of the convolution whose weight is this [Cin, Cout, kh, kw] tensor read as [Cout_conv, Cin_conv, ...];
+    its own gradients are that convolution's forward (grad_x) and weight gradient (roles of x and grad_y
+    swapped) -- the same three C entry points as _Conv2d."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding, output_padding):
+        require_gpu(x, weight)
+        x, weight = f32c(x), f32c(weight)
+        B, Ci, H, W = x.shape
+        if weight.shape[0] != Ci:
+            raise RuntimeError("conv_transpose2d: input has %d channels, weight expects %d" % (Ci, weight.shape[0]))
+        Co, kh, kw = weight.shape[1], weight.shape[2], weight.shape[3]
+        (sh, sw), (ph, pw), (oph, opw) = _pair(stride), _pair(padding), _pair(output_padding)
+        Ho, Wo = (H - 1) * sh - 2 * ph + kh + oph, (W - 1) * sw - 2 * pw + kw + opw
+        # geometry of the convolution  y[B,Co,Ho,Wo] -> x[B,Ci,H,W]
+        g = (B, Co, Ho, Wo, Ci, kh, kw, sh, sw, ph, pw)
+        if (Ho + 2 * ph - kh) // sh + 1 != H or (Wo + 2 * pw - kw) // sw + 1 != W:
+            raise RuntimeError("conv_transpose2d: output_padding %s inconsistent with stride %s" %
+                               ((oph, opw), (sh, sw)))
+        y = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+        L = lib()
+        wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g), x)
+        prof_arm('conv_dgrad', B, Co, Ho, Wo, Ci, kh, kw, H, W)
+        check(L.cnuda_conv2d_backward_data(ptr(x), ptr(weight), ptr(y), *g, wp, wn, stream()),
+              'conv_transpose2d(forward)')
+        ctx.geom = g
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        g = ctx.geom
+        B, Co, Ho, Wo, Ci, kh, kw = g[:7]
+        H, W = x.shape[2], x.shape[3]
+        gy = f32c(gy)
+        L = lib()
+        wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g), x)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            prof_arm('conv_fwd', B, Co, Ho, Wo, Ci, kh, kw, H, W)
+            check(L.cnuda_conv2d_forward(ptr(gy), ptr(weight), None, ptr(gx), *g, -1.0, wp, wn, stream()),
+                  'conv_transpose2d(backward data)')
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(weight)
+            prof_arm('conv_wgrad', B, Co, Ho, Wo, Ci, kh, kw, H, W)
+            check(L.cnuda_conv2d_backward_weight(ptr(gy), ptr(x), ptr(gw), None, *g, wp, wn, stream()),
+                  'conv_transpose2d(backward weight)')
+        return gx, gw, None, None, None
+
+
+def conv_transpose2d(x, weight, stride=1, padding=0, output_padding=0):
+    return _ConvTranspose2d.apply(x, weight, stride, padding, output_padding)
+
+
 # ---------------------------------------------------------------------------
 # batch norm (+ residual add + ReLU)
 # ---------------------------------------------------------------------------
@@ -169,8 +228,39 @@ class _MaxPool(Function):
         return gx, None
 
 
-def max_pool2d(x, k):
-    return _MaxPool.apply(x, int(k))
+class _MaxPoolWindow(Function):
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        require_gpu(x)
+        x = f32c(x)
+        B, C, H, W = x.shape
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        check(lib().cnuda_maxpool2d_window_forward(ptr(x), ptr(y), B, C, H, W, k, s, p, stream()),
+              'maxpool2d_window_forward')
+        ctx.ksp = (k, s, p)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        check(lib().cnuda_maxpool2d_window_backward(ptr(x), ptr(f32c(gy)), ptr(gx), B, C, H, W, *ctx.ksp, stream()),
+              'maxpool2d_window_backward')
+        return gx, None, None, None
+
+
+def max_pool2d(x, k, stride=None, padding=0):
+    """nn.MaxPool2d(k, stride, padding) (floor mode).  stride == k without padding is the DLA downsample
+    (dla.py:202-203); the general window is torchvision's ResNet stem pool."""
+    k = int(k)
+    stride = k if stride is None else int(stride)
+    if stride == k and padding == 0:
+        return _MaxPool.apply(x, k)
+    return _MaxPoolWindow.apply(x, k, stride, int(padding))
 
 
 class _DwConvT(Function):

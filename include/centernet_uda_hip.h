@@ -182,6 +182,12 @@ int cnuda_bn_backward(const float* grad_y, const float* x, const float* y, const
 int cnuda_maxpool2d_forward(const float* x, float* y, int B, int C, int H, int W, int k, cnuda_stream_t stream);
 int cnuda_maxpool2d_backward(const float* x, const float* grad_y, float* grad_x,
                              int B, int C, int H, int W, int k, cnuda_stream_t stream);
+/* general window (kernel k, stride s, padding p with -inf, floor mode): torchvision's ResNet stem pool
+ * nn.MaxPool2d(3, 2, 1), kept inside `base` by backends/resnet.py:27-30.  Backward is a deterministic gather. */
+int cnuda_maxpool2d_window_forward(const float* x, float* y, int B, int C, int H, int W, int k, int s, int p,
+                                   cnuda_stream_t stream);
+int cnuda_maxpool2d_window_backward(const float* x, const float* grad_y, float* grad_x,
+                                    int B, int C, int H, int W, int k, int s, int p, cnuda_stream_t stream);
 int cnuda_dwconvt2d_forward(const float* x, const float* w, float* y,
                             int B, int C, int H, int W, int k, int s, int p, cnuda_stream_t stream);
 int cnuda_dwconvt2d_backward(const float* x, const float* w, const float* grad_y, float* grad_x, float* grad_w,

@@ -368,11 +368,122 @@ def make_advent(dla):
     save('step_advent', **out)
 
 
+# ---------------------------------------------------------------------------
+RESNET_GRAD_PROBES = [
+    'base.0.weight', 'base.1.weight', 'base.4.1.conv2.weight', 'base.5.0.downsample.0.weight',
+    'base.5.0.downsample.1.bias', 'base.6.1.bn2.weight', 'base.7.0.conv1.weight', 'base.7.1.conv2.weight',
+    'deconv_layers.0.weight', 'deconv_layers.4.weight', 'deconv_layers.6.weight', 'deconv_layers.7.bias',
+    'hm.0.weight', 'hm.2.bias', 'wh.2.weight', 'reg.0.bias',
+]
+RESNET_CASES = (('fwd', 2, 128, 61),)          # tag, B, S, seed  (eval + train forward, synthetic backward)
+RESNET_STEP = (2, 256, 16)                     # configs[0]: B=2, 256x256, M objects slots
+
+
+def _import_reference_resnet():
+    """backends/resnet.py with `torch.hub.load` (a GitHub download of pytorch/vision v0.6.0, resnet.py:27-28)
+    bound to the oracle's restated torchvision trunk -- see oracle/resnet.py's header."""
+    from oracle import resnet as oracle_resnet
+    torch.hub.load = lambda repo, name, pretrained=False, **kw: oracle_resnet.torchvision_resnet(
+        int(name.replace('resnet', '')))
+    from backends import resnet
+    return resnet
+
+
+def _resnet_model(resnet, dtype):
+    model = resnet.build(18, num_classes=6, pretrained=False)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes).items()})
+    return model.to(dtype), shapes
+
+
+def _resnet_case(resnet, B, S, seed, dtype):
+    model, shapes = _resnet_model(resnet, dtype)
+    x = T(gin.image_batch(B, S, S, seed)).to(dtype)
+    res = {}
+    model.eval()
+    with torch.no_grad():
+        out = model(x)
+    for k in out:
+        res['eval_' + k] = out[k].numpy()
+    model.train()
+    out = model(x)
+    res['head_order'] = np.array(list(out.keys()))
+    for k in out:
+        res['train_' + k] = out[k].detach().numpy()
+    scalar = sum((out[k] * torch.cos(torch.arange(out[k].numel(), dtype=dtype)
+                                     .reshape(out[k].shape) * 0.1)).sum() for k in out)
+    scalar.backward()
+    res['scalar'] = scalar.item()
+    params = dict(model.named_parameters())
+    for n in RESNET_GRAD_PROBES:
+        res['gradsum__' + n] = _checksums(params[n].grad)
+    sd2 = model.state_dict()
+    for n in ('base.1', 'base.5.0.downsample.1', 'base.7.1.bn2', 'deconv_layers.4'):
+        res['rm__' + n] = sd2[n + '.running_mean'].numpy()
+        res['rv__' + n] = sd2[n + '.running_var'].numpy()
+        res['nbt__' + n] = sd2[n + '.num_batches_tracked'].numpy()
+    meta = {'state_names': np.array(list(shapes)), 'param_names': np.array([n for n, _ in model.named_parameters()]),
+            'n_params': sum(p.numel() for p in model.parameters()),
+            'shapes_json': np.array(repr(sorted((k, v) for k, v in shapes.items())))}
+    return res, meta
+
+
+def _resnet_step(resnet, dtype):
+    """`Model.step` (uda/base.py:31-56) at configs[0]'s real size, re-enacted with the imported backend and
+    DetectionLoss (uda.base itself imports hydra through utils.helper)."""
+    from losses.centernet import DetectionLoss
+    B, S, M = RESNET_STEP
+    model, _ = _resnet_model(resnet, dtype)
+    model.train()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5)
+    crit = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0, periodic=False)
+    batch = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, (5, 3), 2, 71).items()}
+    for k in ('hm', 'wh', 'reg'):
+        batch[k] = batch[k].to(dtype)
+    batch['input'] = T(gin.image_batch(B, S, S, 72)).to(dtype)
+    opt.zero_grad()
+    out = model(batch['input'])
+    loss, stats = crit(out, batch)
+    loss.backward()
+    opt.step()
+    stats['total_loss'] = loss
+    res = {'stat_' + k: v.item() for k, v in stats.items()}
+    params = dict(model.named_parameters())
+    for n in RESNET_GRAD_PROBES:
+        res['gradsum__' + n] = _checksums(params[n].grad)
+        res['param__' + n] = _checksums(params[n])
+    res['hm_after'] = out['hm'].detach().numpy()
+    return res
+
+
+def make_resnet():
+    resnet = _import_reference_resnet()
+    for tag, B, S, seed in RESNET_CASES:
+        r32, meta = _resnet_case(resnet, B, S, seed, torch.float32)
+        r64, _ = _resnet_case(resnet, B, S, seed, torch.float64)
+        out = dict(meta)
+        out.update(r32)
+        for k, v in r64.items():
+            if k.startswith(('eval_', 'train_', 'gradsum__', 'scalar')):
+                out['f64_' + k] = v
+        save('resnet18_' + tag, **out)
+    r32 = _resnet_step(resnet, torch.float32)
+    r64 = _resnet_step(resnet, torch.float64)
+    out = dict(r32)
+    for k, v in r64.items():
+        if k.startswith(('stat_', 'gradsum__')):
+            out['f64_' + k] = v
+    out['hm_after'] = out['hm_after'][:, :, ::4, ::4].copy()       # keep the file small
+    save('resnet18_step', **out)
+
+
 if __name__ == '__main__':
     oracle_dcn.build()
-    which = set(sys.argv[1:]) or {'decode', 'losses', 'dla', 'step', 'advent'}
+    which = set(sys.argv[1:]) or {'decode', 'losses', 'dla', 'step', 'advent', 'resnet'}
     if 'decode' in which:
         make_decode()
+    if 'resnet' in which:
+        make_resnet()
     if 'losses' in which or 'advent' in which:
         _load_entropy_map()
     if 'losses' in which:
