@@ -122,6 +122,45 @@ def cpu_baseline(size=256):
     }
 
 
+def decode_latency(device, with_cpu=True):
+    """BASELINE.json's second metric: `decode_detection` latency at B=16, K=150 on 128x128 maps, C=6 (the
+    reference's default) and C=80 (COCO stress) -- SURVEY 8d.  Inputs resident in HBM, probabilities as
+    `Model.get_detections` hands them over (Q1).  Algorithmic bytes = one read of the heat map + gathered
+    wh/reg + the [B,K,6] result."""
+    from backends.decode import decode_detection
+    res = {}
+    B, H, W, K = 16, 128, 128, 150
+    for C in (6, 80):
+        g = torch.Generator(device='cpu').manual_seed(7 + C)
+        heat = torch.sigmoid(torch.randn(B, C, H, W, generator=g) - 2.19).clamp(1e-4, 1 - 1e-4)
+        wh, reg = torch.rand(B, 2, H, W, generator=g) * 40, torch.rand(B, 2, H, W, generator=g)
+        hd, whd, regd = heat.to(device), wh.to(device), reg.to(device)
+        for _ in range(10):
+            dets = decode_detection(hd, whd, regd, K=K)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 100
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            dets = decode_detection(hd, whd, regd, K=K)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        nbytes = B * C * H * W * 4 + B * K * 4 * 4 + B * K * 6 * 4
+        entry = {'us': round(us, 1), 'algorithmic_bytes': nbytes, 'gb_per_s': round(nbytes / us / 1e3, 1),
+                 'hbm_frac': round(nbytes / (us * 1e-6) / 8e12, 4)}
+        if with_cpu and C == 6:
+            from oracle import decode as oracle_decode       # checker / baseline leg only
+            t0 = time.perf_counter()
+            want = oracle_decode.decode_detection(heat.numpy(), wh.numpy(), reg.numpy(), K=K)
+            entry['cpu_port_us'] = round((time.perf_counter() - t0) * 1e6, 1)
+            got = dets.cpu().numpy()
+            entry['matches_oracle'] = bool(abs(got - want).max() <= 1e-4)
+        res['C%d' % C] = entry
+    res['shape'] = 'B=16, K=150, 128x128 maps, fp32'
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -178,6 +217,8 @@ def main():
         torch.cuda.synchronize()
         per_kernel = hr.prof_end()
         if per_kernel:
+            hbm_kernels = {k: v for k, v in per_kernel.items() if v['flops'] == 0}
+            per_kernel = {k: v for k, v in per_kernel.items() if v['flops'] > 0}
             name, d = max(per_kernel.items(), key=lambda kv: kv[1]['ms'])
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
             traffic, traffic_note = None, None
@@ -203,6 +244,12 @@ def main():
                                          'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2),
                                          'launches': v['launches'] // args.profile_steps}
                                      for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]['ms'])},
+                # the profiled kernels without MFMA work, against the HBM roofline (algorithmic bytes / time)
+                'hbm_kernels': {k: {'ms_per_step': round(v['ms'] / args.profile_steps, 3),
+                                    'gb_per_s': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1),
+                                    'frac_of_8TBps': round(v['bytes'] / (v['ms'] * 1e-3) / 8e12, 4),
+                                    'launches': v['launches'] // args.profile_steps}
+                                for k, v in sorted(hbm_kernels.items(), key=lambda kv: -kv[1]['ms'])},
             }
     if world > 1:
         dist.barrier()
@@ -226,6 +273,7 @@ def main():
             'step_mfma_fraction': round(step_tflop / (ms * 1e-3) / PEAK_FP32_MFMA_TFLOPS, 4),
             'losses': {k: round(v, 5) for k, v in stats.items()},
             'roofline': roofline,
+            'decode_latency': decode_latency(device, with_cpu=not args.no_cpu_baseline) if world == 1 else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()

@@ -27,14 +27,21 @@ inline int check_launch(const char* what) {
 
 // Optional in-library kernel timer (bench.py's roofline leg): when armed through
 // cnuda_prof_arm(tag), the next ProfScope brackets exactly one main-kernel launch
-// with hipEvents on the launch stream.  Inert (one int compare) otherwise.
+// with hipEvents on the launch stream.  An entry point made of several kernels opens a
+// ProfGroup first: every ProfScope inside it is recorded under the armed tag, told apart
+// by `sub` (bits 24.. of the collected tag).  Inert (two int compares) otherwise.
 class ProfScope {
 public:
-    explicit ProfScope(hipStream_t st);
+    explicit ProfScope(hipStream_t st, int sub = 0);
     ~ProfScope();
 private:
     hipStream_t st_;
     int rec_;
+};
+class ProfGroup {
+public:
+    ProfGroup();
+    ~ProfGroup();
 };
 
 #define CNUDA_REQUIRE(cond, ...)                 \

@@ -1,15 +1,16 @@
-// Modulated deformable convolution (DCNv2) for gfx950 -- forward and backward
-// without ever materialising the `columns` buffer of the reference
-// (libs/DCNv2/src/cuda/dcn_v2_cuda.cu:89-102 allocates B*C*9*Ho*Wo floats and
-// round-trips them through HBM twice per direction).
+// Modulated deformable convolution (DCNv2) for gfx950.  The forward samples inside the implicit GEMM's
+// loader (the reference materialises `columns`, libs/DCNv2/src/cuda/dcn_v2_cuda.cu:89-102, B*C*9*Ho*Wo
+// floats, and round-trips them through HBM twice per direction); the sampled columns are an optional
+// side output that the weight gradient reuses.
 //
 //   forward : out[b,o,p] = bias[o] + sum_{tap,c} W[o,c,tap] * mask[b,tap,p] * bilinear(in[b,c], p, tap)
 //             one implicit GEMM on the fp32 MFMA whose B operand is sampled on the fly.
-//   backward: (1) column gradient GEMM  dcol[(tap,c), p] = sum_o W[o,c,tap] * gout[b,o,p]
-//                 fused with its three consumers in the accumulator registers:
-//                 grad_mask, grad_offset (summed over c in-kernel, written once)
-//                 and the bilinear scatter into grad_input (fp32 atomics, as the
-//                 reference does, dcn_v2_im2col_cuda.cu:238-252);
+//   backward: (1) column gradient  dcol[(tap,c), p] = sum_o W[o,c,tap] * gout[b,o,p]  as a plain 1x1
+//                 implicit GEMM on the MFMA, written once to workspace and streamed by two consumers:
+//                 dcn_coord_grad_kernel (grad_offset / grad_mask: one thread per (pixel, tap), channels
+//                 serial, plain stores) and dcn_col2im_kernel (bilinear scatter into grad_input through
+//                 an LDS window; fp32 global atomics only for the window flush, collisions and strays
+//                 -- the reference uses one atomic per corner, dcn_v2_im2col_cuda.cu:238-252);
 //             (2) grad_weight = gout x sampled-columns^T as a split-K GEMM with
 //                 fixed-order slab reduction; (3) grad_bias = channel sums.
 //             The whole batch goes through each kernel once (the reference loops
@@ -194,290 +195,231 @@ struct DcnFwdLoader {
 };
 
 // ---------------------------------------------------------------------------
-// backward (1): fused column-gradient GEMM + grad_offset / grad_mask / grad_input
-// Workgroup = (pixel tile of 128, tap); loops over 64-channel tiles of C.
+// backward (1): the column gradient dcol[b][(tap,c)][p] is produced by a plain
+// 1x1 implicit GEMM over grad_output (weights transposed by dcn_wt_kernel) and consumed by
+// two HBM-streaming kernels that need no MFMA, no workgroup barriers and few registers:
+//   dcn_coord_grad_kernel : one thread per (pixel, tap), channels serial -> grad_offset /
+//                           grad_mask written once (no atomics, no memset) + a 16-byte
+//                           geometry record per (pixel, tap) for the scatter kernel
+//   dcn_col2im_kernel     : bilinear scatter of dcol*mask into grad_input through an LDS
+//                           window; every wave owns four channel planes.
 // ---------------------------------------------------------------------------
-struct DcnBwdParams {
+__global__ void dcn_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int C, int T) {
+    const long long total = (long long)Co * C * T;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int o = (int)(i % Co);
+        const long long r = i / Co;            // r = tap*C + c
+        const int c = (int)(r % C), tap = (int)(r / C);
+        wt[i] = w[((size_t)o * C + c) * T + tap];
+    }
+}
+
+struct DcnGeo { int cell; float lh, lw, mask; };   // cell = h0 << 16 | (w0 & 0xffff); h0 = -32768: tap outside
+static_assert(sizeof(DcnGeo) == 16, "geometry record is one dwordx4");
+
+struct DcnCoordParams {
     DcnGeom g;
-    const float *in, *off, *mask, *gout;
-    float *gin, *goff, *gmask;
-    int dbg;   // ablation bits for scratch experiments (0 in production)
+    const float *in, *off, *mask, *dcol;
+    float *goff, *gmask;
+    DcnGeo* geo;
 };
-int g_dcn_dbg = 0;
-
-// Structure: workgroup = one tile of 64 output pixels; it loops over 64-channel
-// tiles of C and, inside, over all taps.  Each of the 4 waves owns 16 channels x
-// 64 pixels (four 16x16 MFMA tiles, v_mfma_f32_16x16x4_f32), so the waves write
-// disjoint channel planes of an LDS window that covers the input rows / columns
-// the pixel tile can reach (|dy| < 2, |dx| < 1 beyond the 3x3 footprint).  The
-// bilinear scatter is a plain LDS read-add-write: within a wave LDS operations
-// execute in order, different waves touch different planes, and the only
-// remaining hazard -- two pixels of one 16-lane group landing on the same cell
-// in ONE instruction -- is detected per tap with a claim map and handled by LDS
-// atomics (measured: ds_add_f32 costs ~200 cycles per wave instruction on
-// gfx950, 50x a plain read+write, so it must stay off the common path).  The
-// window is flushed once per channel tile with coalesced global atomics (~7x
-// fewer HBM-side atomics than scattering every corner, and contiguous); corners
-// outside the window (large offsets, odd shapes) go to global memory directly.
-constexpr int DB_BM = 64, DB_BN = 32, DB_WIN = 256;   // window cells per channel (64*256*4 B = 64 KiB -> 2 workgroups / CU)
-constexpr int DB_NT = DB_BN / 16;                      // 16-pixel MFMA tiles per wave
-
-__global__ __launch_bounds__(IG_THREADS, 2) void dcn_bwd_data_kernel(DcnBwdParams p, const float* __restrict__ A2,
-                                                                 int Mp2, int Kp, int Cpad, long long N, int n_tiles) {
-    using f32x4 = __attribute__((ext_vector_type(4))) float;
-    extern __shared__ __align__(16) float smem[];
-    float* As = smem;                          // [16][64]  (k, channel)
-    float* Bs = As + IG_BK * DB_BM;            // [16][DB_BN]  (k, pixel)
-    float* win = Bs + IG_BK * DB_BN;           // [64][WSZ]
-    float* dump = win + DB_BM * DB_WIN;        // [256] one cell per thread
-    int* claim = reinterpret_cast<int*>(dump + IG_THREADS);   // [4 waves][DB_WIN]
+// block = (64 pixels, TW tap slots); no barriers
+__global__ __launch_bounds__(1024) void dcn_coord_grad_kernel(DcnCoordParams p, int tiles_per_image) {
     const DcnGeom& g = p.g;
     const int T = g.kh * g.kw, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wg = xcd_remap(blockIdx.x, n_tiles);
-    const long long n0 = (long long)wg * DB_BN;
-    const int kq = lane >> 4, il = lane & 15;   // MFMA k index / row-col index
-
-    // ---- window geometry (workgroup-uniform) ----
-    int wy0 = 0, wx0 = 0, WR = 0, WC = 0, tile_b = 0;
-    bool use_win = false;
-    if (HoWo % DB_BN == 0) {
-        tile_b = (int)(n0 / HoWo);
-        const int p0 = (int)(n0 - (long long)tile_b * HoWo), p1 = p0 + DB_BN - 1;
-        const int y0 = p0 / g.Wo, y1 = p1 / g.Wo;
-        int x0 = p0 - y0 * g.Wo, x1 = p1 - y1 * g.Wo;
-        if (y1 != y0) { x0 = 0; x1 = g.Wo - 1; }
-        wy0 = y0 * g.sh - g.ph - 2;
-        WR = (y1 - y0) * g.sh + (g.kh - 1) * g.dh + 5;
-        wx0 = x0 * g.sw - g.pw - 1;
-        WC = (x1 - x0) * g.sw + (g.kw - 1) * g.dw + 3;
-        if (wy0 < 0) { WR += wy0; wy0 = 0; }
-        if (wx0 < 0) { WC += wx0; wx0 = 0; }
-        if (wy0 + WR > g.H) WR = g.H - wy0;
-        if (wx0 + WC > g.W) WC = g.W - wx0;
-        use_win = WR > 0 && WC > 0 && WR * WC <= DB_WIN && (WR + 1) * (WC + 1) <= DB_WIN + 128;
-    }
-    const int WSZ = use_win ? WR * WC : 0;
-
-    // ---- B-operand (gout) staging: pixel = tid % DB_BN, k phase = tid / DB_BN ----
-    constexpr int KPH = IG_THREADS / DB_BN;     // k rows covered per pass
-    constexpr int BPT = IG_BK / KPH;            // gout elements per thread per chunk
-    const int nl = tid & (DB_BN - 1), ksub = tid / DB_BN;
-    const long long nb = n0 + nl;
-    const bool nb_valid = nb < N;
-    const int bb = nb_valid ? (int)(nb / HoWo) : 0;
-    const int pb = nb_valid ? (int)(nb - (long long)bb * HoWo) : 0;
-    const float* gout_b = p.gout + (size_t)bb * g.Co * HoWo + pb;
-
-    // ---- epilogue coordinates: lane owns pixel (j*16 + il) of each 16-pixel tile ----
-    bool pv[DB_NT];
-    int eb[DB_NT], ep[DB_NT], eoy[DB_NT], eox[DB_NT];
+    const int b = blockIdx.x / tiles_per_image, tile = blockIdx.x - b * tiles_per_image;
+    const int px = tile * 64 + threadIdx.x;
+    if (px >= HoWo) return;
+    const int oy = px / g.Wo, ox = px - oy * g.Wo;
+    const float* in_b = p.in + (size_t)b * g.C * HW;
+    for (int tap = threadIdx.y; tap < T; tap += blockDim.y) {
+        const Tap t = make_tap(g, p.off + (size_t)b * 2 * T * HoWo, p.mask + (size_t)b * T * HoWo, 0, tap, oy, ox);
+        const float* dc = p.dcol + ((size_t)b * T + tap) * g.C * HoWo + px;
+        float sm = 0.f, sh_ = 0.f, sw_ = 0.f;
+        if (t.inside) {
+            // corners that do not exist read cell 0 and are zeroed afterwards: loads stay unconditional and are
+            // issued eight channels at a time before anything is consumed
+            const float f00 = t.c00 ? 1.f : 0.f, f01 = t.c01 ? 1.f : 0.f, f10 = t.c10 ? 1.f : 0.f,
+                        f11 = t.c11 ? 1.f : 0.f;
+            for (int c0 = 0; c0 < g.C; c0 += 8) {
+                float d[8], e00[8], e01[8], e10[8], e11[8];
 #pragma unroll
-    for (int j = 0; j < DB_NT; ++j) {
-        const long long ne = n0 + j * 16 + il;
-        pv[j] = ne < N;
-        eb[j] = pv[j] ? (int)(ne / HoWo) : 0;
-        ep[j] = pv[j] ? (int)(ne - (long long)eb[j] * HoWo) : 0;
-        eoy[j] = ep[j] / g.Wo;
-        eox[j] = ep[j] - eoy[j] * g.Wo;
-    }
-    int* my_claim = claim + wid * (DB_WIN + 128);
-    const int dcell = (int)(dump - win) + tid;
-
-    // every wave zeroes the 16 channel planes it owns (only that wave ever touches them)
-    for (int i = lane; i < 16 * WSZ; i += 64) win[wid * 16 * WSZ + i] = 0.0f;
-
-    // sampling inputs of tap 0 (then always one tap ahead: their latency hides under the previous tap's work)
-    TapRaw raw_next[DB_NT];
-#pragma unroll
-    for (int j = 0; j < DB_NT; ++j)
-        raw_next[j] = load_tap_raw(g, p.off + (size_t)eb[j] * 2 * T * HoWo, p.mask + (size_t)eb[j] * T * HoWo, 0, 0,
-                                   ep[j]);
-
-    for (int c0 = 0; c0 < Cpad; c0 += DB_BM) {
-#pragma unroll 1
-        for (int tap = 0; tap < T; ++tap) {
-            // ---- geometry of this tap for the lane's pixels, corner loads issued BEFORE the GEMM loop ----
-            Tap tp[DB_NT];
-            float v00[DB_NT][4], v01[DB_NT][4], v10[DB_NT][4], v11[DB_NT][4];
-#pragma unroll
-            for (int j = 0; j < DB_NT; ++j) {
-                tp[j] = tap_from_raw(g, raw_next[j], tap, eoy[j], eox[j]);
-                const bool live = pv[j] && tp[j].inside;
-                const int o00 = (live && tp[j].c00) ? tp[j].o00 : 0, o01 = (live && tp[j].c01) ? tp[j].o01 : 0;
-                const int o10 = (live && tp[j].c10) ? tp[j].o10 : 0, o11 = (live && tp[j].c11) ? tp[j].o11 : 0;
-                const float* in_b = p.in + (size_t)eb[j] * g.C * HW;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int c = c0 + wid * 16 + kq * 4 + r;
-                    c = c < g.C ? c : g.C - 1;                       // padded rows carry dcol == 0
+                for (int u = 0; u < 8; ++u) {
+                    const int c = c0 + u < g.C ? c0 + u : g.C - 1;
                     const float* plane = in_b + (size_t)c * HW;
-                    v00[j][r] = plane[o00]; v01[j][r] = plane[o01]; v10[j][r] = plane[o10]; v11[j][r] = plane[o11];
-                }
-            }
-            {   // next tap's sampling inputs (wraps to tap 0 of the next channel tile)
-                const int nt = tap + 1 < T ? tap + 1 : 0;
-#pragma unroll
-                for (int j = 0; j < DB_NT; ++j)
-                    raw_next[j] = load_tap_raw(g, p.off + (size_t)eb[j] * 2 * T * HoWo,
-                                               p.mask + (size_t)eb[j] * T * HoWo, 0, nt, ep[j]);
-            }
-            f32x4 acc[DB_NT];
-#pragma unroll
-            for (int j = 0; j < DB_NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[j][r] = 0.0f;
-            const int mbase = tap * Cpad + c0;
-            float ra[4], rb[BPT];
-            auto stage_load = [&](int k0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = tid + i * IG_THREADS;
-                    ra[i] = A2[(size_t)(k0 + (e >> 6)) * Mp2 + mbase + (e & 63)];
+                    d[u] = dc[(size_t)c * HoWo];
+                    e00[u] = plane[t.o00]; e01[u] = plane[t.o01]; e10[u] = plane[t.o10]; e11[u] = plane[t.o11];
                 }
 #pragma unroll
-                for (int i = 0; i < BPT; ++i) {
-                    const int o = k0 + ksub + KPH * i;
-                    rb[i] = (nb_valid && o < g.Co) ? gout_b[(size_t)o * HoWo] : 0.0f;
-                }
-            };
-            stage_load(0);
-            for (int k0 = 0; k0 < Kp; k0 += IG_BK) {
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < 4; ++i) As[tid + i * IG_THREADS] = ra[i];
-#pragma unroll
-                for (int i = 0; i < BPT; ++i) Bs[(ksub + KPH * i) * DB_BN + nl] = rb[i];
-                __syncthreads();
-                if (k0 + IG_BK < Kp) stage_load(k0 + IG_BK);
-#pragma unroll
-                for (int kk = 0; kk < IG_BK; kk += 4) {
-                    const float a = As[(kk + kq) * DB_BM + wid * 16 + il];
-#pragma unroll
-                    for (int j = 0; j < DB_NT; ++j) {
-                        const float b = Bs[(kk + kq) * DB_BN + j * 16 + il];
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
-                    }
-                }
-            }
-            // ---- consume the dcol tile: lane holds channels cl = wid*16 + kq*4 + r (r<4) of pixel j*16+il ----
-#pragma unroll
-            for (int j = 0; j < DB_NT; ++j) {
-                const Tap& t = tp[j];
-                const bool live = pv[j] && t.inside;
-                const int h0 = t.h0 - wy0, w0 = t.w0 - wx0;
-                const bool r0 = use_win && h0 >= 0 && h0 < WR, r1 = use_win && h0 + 1 >= 0 && h0 + 1 < WR;
-                const bool q0 = w0 >= 0 && w0 < WC, q1 = w0 + 1 >= 0 && w0 + 1 < WC;
-                const bool a00 = live && t.c00, a01 = live && t.c01, a10 = live && t.c10, a11 = live && t.c11;
-                const bool i00 = a00 && r0 && q0, i01 = a01 && r0 && q1, i10 = a10 && r1 && q0, i11 = a11 && r1 && q1;
-                const int l00 = i00 ? h0 * WC + w0 : -1, l01 = i01 ? h0 * WC + w0 + 1 : -1;
-                const int l10 = i10 ? (h0 + 1) * WC + w0 : -1, l11 = i11 ? (h0 + 1) * WC + w0 + 1 : -1;
-                const float k00 = a00 ? t.hh * t.hw : 0.f, k01 = a01 ? t.hh * t.lw : 0.f;
-                const float k10 = a10 ? t.lh * t.hw : 0.f, k11 = a11 ? t.lh * t.lw : 0.f;
-                const float mk = live ? t.mask : 0.f;
-                const int o00 = a00 ? t.o00 : 0, o01 = a01 ? t.o01 : 0, o10 = a10 ? t.o10 : 0, o11 = a11 ? t.o11 : 0;
-                // collision check: do two pixels of this 16-lane group share a window cell?  The four
-                // corner cells of a pixel are a fixed pattern around (h0, w0), so comparing the anchor
-                // cell of every in-window pixel is enough.  kq == 0 lanes vote (all kq see the same pixels).
-                const int anchor = (live && use_win && h0 >= -1 && h0 < WR && w0 >= -1 && w0 < WC)
-                                       ? (h0 + 1) * (WC + 1) + (w0 + 1) : -1;   // (WR+1) x (WC+1) grid incl. the -1 row/col
-                float sm = 0.f, sh_ = 0.f, sw_ = 0.f;
-                float dmv[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int cl = wid * 16 + kq * 4 + r;
-                    const float d = (c0 + cl < g.C) ? acc[j][r] : 0.0f;
-                    const float e00 = a00 ? v00[j][r] : 0.f, e01 = a01 ? v01[j][r] : 0.f;
-                    const float e10 = a10 ? v10[j][r] : 0.f, e11 = a11 ? v11[j][r] : 0.f;
-                    sm += d * (t.hh * t.hw * e00 + t.hh * t.lw * e01 + t.lh * t.hw * e10 + t.lh * t.lw * e11);
-                    const float dm = d * mk;
-                    dmv[r] = dm;
-                    sh_ += (-t.hw * e00 - t.lw * e01 + t.hw * e10 + t.lw * e11) * dm;
-                    sw_ += (-t.hh * e00 + t.hh * e01 - t.lh * e10 + t.lh * e11) * dm;
-                }
-                // scatter: one corner at a time; the four channels of a corner hit four different planes
-                // (independent); consecutive corners may hit a neighbouring lane's previous cell, so the
-                // compiler must keep LDS program order between them (the hardware does, per wave).
-                // Pixels of this 16-lane group that share an anchor cell would collide inside ONE
-                // instruction: they are serialised by rounds -- every pending pixel claims its anchor,
-                // the pixel whose id survives in the claim map scatters, the others retry.
-                const int wb0 = (wid * 16 + kq * 4) * WSZ;
-                bool pending = true;
-                volatile int* vc = my_claim;
-                do {
-                    bool won = pending;
-                    if (kq == 0 && pending && anchor >= 0) vc[anchor] = il;
-                    if (kq == 0 && pending && anchor >= 0) won = vc[anchor] == il;
-                    won = __shfl((int)won, il, 64) != 0;          // the kq == 0 lane of this pixel decides
-                    won = won && pending;
-                    auto scatter = [&](int l, float k) {
-                        const bool on = won && l >= 0;
-                        float* base = win + (on ? wb0 + l : dcell);
-                        const int stride = on ? WSZ : 0;
-                        float cur[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) cur[r] = base[r * stride];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) base[r * stride] = cur[r] + (on ? k * dmv[r] : 0.f);
-                        asm volatile("" ::: "memory");
-                    };
-                    asm volatile("" ::: "memory");
-                    scatter(l00, k00);
-                    scatter(l01, k01);
-                    scatter(l10, k10);
-                    scatter(l11, k11);
-                    pending = pending && !won;
-                } while (__any(pending));
-                // rare: an existing corner outside the window -> global atomics
-                const bool spill = (a00 && !i00) || (a01 && !i01) || (a10 && !i10) || (a11 && !i11);
-                if (__any(spill)) {
-                    if (spill) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int c = c0 + wid * 16 + kq * 4 + r;
-                            if (c >= g.C) continue;
-                            const float dm = acc[j][r] * mk;
-                            float* gplane = p.gin + ((size_t)eb[j] * g.C + c) * HW;
-                            if (a00 && !i00) atomicAdd(gplane + o00, k00 * dm);
-                            if (a01 && !i01) atomicAdd(gplane + o01, k01 * dm);
-                            if (a10 && !i10) atomicAdd(gplane + o10, k10 * dm);
-                            if (a11 && !i11) atomicAdd(gplane + o11, k11 * dm);
-                        }
-                    }
-                }
-                // sums over this wave's 16 channels: 4 in-lane + the four kq groups
-                sm += __shfl_xor(sm, 16, 64);  sm += __shfl_xor(sm, 32, 64);
-                sh_ += __shfl_xor(sh_, 16, 64); sh_ += __shfl_xor(sh_, 32, 64);
-                sw_ += __shfl_xor(sw_, 16, 64); sw_ += __shfl_xor(sw_, 32, 64);
-                if (kq == 0 && live) {
-                    atomicAdd(p.gmask + ((size_t)eb[j] * T + tap) * HoWo + ep[j], sm);
-                    atomicAdd(p.goff + ((size_t)eb[j] * 2 * T + 2 * tap) * HoWo + ep[j], sh_);
-                    atomicAdd(p.goff + ((size_t)eb[j] * 2 * T + 2 * tap + 1) * HoWo + ep[j], sw_);
+                for (int u = 0; u < 8; ++u) {
+                    const float dd = c0 + u < g.C ? d[u] : 0.f;
+                    const float a00 = e00[u] * f00, a01 = e01[u] * f01, a10 = e10[u] * f10, a11 = e11[u] * f11;
+                    sm += dd * tap_sample(t, a00, a01, a10, a11);
+                    const float dm = dd * t.mask;
+                    sh_ += (-t.hw * a00 - t.lw * a01 + t.hw * a10 + t.lw * a11) * dm;
+                    sw_ += (-t.hh * a00 + t.hh * a01 - t.lh * a10 + t.lh * a11) * dm;
                 }
             }
         }
-        // ---- flush this channel tile's window: every wave flushes (and re-zeroes) the 16 planes it owns,
-        //      so no workgroup barrier is needed; lanes walk the cells, coalesced global atomics ----
-        if (use_win) {
-            asm volatile("" ::: "memory");
+        p.gmask[((size_t)b * T + tap) * HoWo + px] = sm;
+        p.goff[((size_t)b * 2 * T + 2 * tap) * HoWo + px] = sh_;
+        p.goff[((size_t)b * 2 * T + 2 * tap + 1) * HoWo + px] = sw_;
+        DcnGeo r;
+        r.cell = t.inside ? (int)(((unsigned)t.h0 << 16) | ((unsigned)t.w0 & 0xffffu)) : (int)0x80000000u;
+        r.lh = t.lh; r.lw = t.lw; r.mask = t.inside ? t.mask : 0.f;
+        p.geo[((size_t)b * T + tap) * HoWo + px] = r;
+    }
+}
+
+constexpr int CI_CG = 16;        // channels per workgroup (4 per wave)
+constexpr int CI_MARGIN = 2;     // window rows / columns beyond the undeformed footprint
+struct DcnCol2imParams {
+    DcnGeom g;
+    const float* dcol;
+    const DcnGeo* geo;
+    float* gin;
+    int TR, TC, tc_shift, tiles_y, tiles_x, ncg, WSZmax, claim_sz;
+};
+// Workgroup = (image, TR x TC tile of output pixels (256), 16 channels).  The four waves never synchronise:
+// wave w owns channel planes 4w..4w+3 of the LDS window, walks all 256 pixels x taps of the tile (64 pixels
+// per step, lanes along x) and does plain LDS read-add-write.  Two lanes can only hit the same cell in one
+// instruction if their (h0, w0) anchors are equal: every lane writes its id into a per-wave claim map at its
+// anchor and reads it back -- the survivor scatters through LDS, the (rare) losers and the corners outside the
+// window use global atomics.
+__global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int n_wg) {
+    extern __shared__ __align__(16) float win[];     // [16][WSZ] + 256 dump cells
+    const DcnGeom& g = p.g;
+    const int T = g.kh * g.kw, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int id = xcd_remap(blockIdx.x, n_wg);
+    const int cg = id % p.ncg; id /= p.ncg;
+    const int tx = id % p.tiles_x; id /= p.tiles_x;
+    const int ty = id % p.tiles_y;
+    const int b = id / p.tiles_y;
+    const int y0 = ty * p.TR, x0 = tx * p.TC;
+    // window (workgroup-uniform), clipped to the plane
+    int wy0 = y0 * g.sh - g.ph - CI_MARGIN, wx0 = x0 * g.sw - g.pw - CI_MARGIN;
+    int WR = (p.TR - 1) * g.sh + (g.kh - 1) * g.dh + 2 * CI_MARGIN + 1;
+    int WC = (p.TC - 1) * g.sw + (g.kw - 1) * g.dw + 2 * CI_MARGIN + 1;
+    if (wy0 < 0) { WR += wy0; wy0 = 0; }
+    if (wx0 < 0) { WC += wx0; wx0 = 0; }
+    if (wy0 + WR > g.H) WR = g.H - wy0;
+    if (wx0 + WC > g.W) WC = g.W - wx0;
+    if (WR < 0 || p.WSZmax == 0) WR = 0;     // WSZmax == 0: window does not fit the LDS -> global atomics only
+    if (WC < 0 || p.WSZmax == 0) WC = 0;
+    const int WSZ = WR * WC;                          // <= p.WSZmax
+    float* wp = win + wid * 4 * WSZ;                  // this wave's four planes
+    float* dump = win + CI_CG * p.WSZmax + tid;
+    volatile unsigned char* claim =
+        reinterpret_cast<unsigned char*>(win + CI_CG * p.WSZmax + 256) + wid * p.claim_sz;   // [(WR+1)*(WC+1)]
+    const int c_w = cg * CI_CG + wid * 4;
+    for (int i = lane; i < 4 * WSZ; i += 64) wp[i] = 0.0f;
+    *dump = 0.0f;
+
+    const int items = 4 * T;                          // (pixel group, tap)
+    const DcnGeo* geo_b = p.geo + (size_t)b * T * HoWo;
+    const float* dcol_b = p.dcol + (size_t)b * T * g.C * HoWo;
+    float* gin_b = p.gin + (size_t)b * g.C * HW;
+    int cc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cc[r] = c_w + r < g.C ? c_w + r : g.C - 1;   // clamped loads; results dropped
+    const bool cv0 = c_w < g.C, cv1 = c_w + 1 < g.C, cv2 = c_w + 2 < g.C, cv3 = c_w + 3 < g.C;
+
+    auto pixel_of = [&](int grp, bool& valid) {
+        const int t = grp * 64 + lane;
+        const int oy = y0 + (t >> p.tc_shift), ox = x0 + (t & (p.TC - 1));
+        valid = oy < g.Ho && ox < g.Wo;
+        return valid ? oy * g.Wo + ox : 0;
+    };
+    DcnGeo rec_n;
+    float d_n[4];
+    bool valid_n;
+    auto fetch = [&](int it) {
+        const int grp = it / T, tap = it - grp * T;
+        const int px = pixel_of(grp, valid_n);
+        rec_n = geo_b[(size_t)tap * HoWo + px];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d_n[r] = dcol_b[((size_t)tap * g.C + cc[r]) * HoWo + px];
+    };
+    fetch(0);
 #pragma unroll 1
-            for (int q = 0; q < (DB_WIN + 63) / 64; ++q) {
-                const int pos = lane + 64 * q;
-                if (pos < WSZ) {
-                    const int yy = pos / WC, xx = pos - yy * WC;
-                    float* gbase = p.gin + (size_t)tile_b * g.C * HW + (size_t)(wy0 + yy) * g.W + wx0 + xx;
-#pragma unroll 4
-                    for (int cc = 0; cc < 16; ++cc) {
-                        const int cl = wid * 16 + cc;
-                        const float v = win[cl * WSZ + pos];
-                        if (v != 0.0f) {
-                            if (c0 + cl < g.C) atomicAdd(gbase + (size_t)(c0 + cl) * HW, v);
-                            win[cl * WSZ + pos] = 0.0f;
-                        }
-                    }
-                }
+    for (int it = 0; it < items; ++it) {
+        const DcnGeo rec = rec_n;
+        float d[4] = {d_n[0], d_n[1], d_n[2], d_n[3]};
+        const bool valid = valid_n;
+        if (it + 1 < items) fetch(it + 1);
+        const int h0 = rec.cell >> 16, w0 = (int)(short)(rec.cell & 0xffff);
+        const bool live = valid && h0 >= -1;
+        const float lh = rec.lh, lw = rec.lw, hh = 1.0f - lh, hw = 1.0f - lw;
+        const bool top = h0 >= 0, bot = h0 + 1 <= g.H - 1, lef = w0 >= 0, rig = w0 + 1 <= g.W - 1;
+        const bool a00 = live && top && lef, a01 = live && top && rig, a10 = live && bot && lef,
+                   a11 = live && bot && rig;
+        const float mk = live ? rec.mask : 0.f;
+        d[0] = cv0 ? d[0] * mk : 0.f; d[1] = cv1 ? d[1] * mk : 0.f;
+        d[2] = cv2 ? d[2] * mk : 0.f; d[3] = cv3 ? d[3] * mk : 0.f;
+        const float k00 = a00 ? hh * hw : 0.f, k01 = a01 ? hh * lw : 0.f, k10 = a10 ? lh * hw : 0.f,
+                    k11 = a11 ? lh * lw : 0.f;
+        const int rh = h0 - wy0, rw = w0 - wx0;
+        const bool r0 = rh >= 0 && rh < WR, r1 = rh + 1 >= 0 && rh + 1 < WR;
+        const bool q0 = rw >= 0 && rw < WC, q1 = rw + 1 >= 0 && rw + 1 < WC;
+        // lanes that may touch the window take part in the uniqueness test
+        const bool near = live && rh >= -1 && rh < WR && rw >= -1 && rw < WC;
+        const int anchor = near ? (rh + 1) * (WC + 1) + (rw + 1) : -1;
+        const int base = rh * WC + rw;
+        const bool w00 = a00 && r0 && q0, w01 = a01 && r0 && q1, w10 = a10 && r1 && q0, w11 = a11 && r1 && q1;
+        auto scatter = [&](bool on, int cell, float k) {
+            float* a = on ? wp + cell : dump;
+            const int stride = on ? WSZ : 0;
+            float cur[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cur[r] = a[r * stride];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r * stride] = cur[r] + (on ? k * d[r] : 0.f);
+            asm volatile("" ::: "memory");     // LDS program order between corners (neighbouring lanes' cells)
+        };
+        // rounds: lanes whose anchor is claimed by another lane of this instruction wait for the next round
+        // (one round unless two pixels of the wave sample the same cell); after three rounds the rest spills
+        bool pending = near, done_lds = false;
+#pragma unroll 1
+        for (int round = 0; round < 3 && __any(pending); ++round) {
+            bool won = false;
+            if (pending) {
+                claim[anchor] = (unsigned char)lane;
+                won = claim[anchor] == (unsigned char)lane;     // same wave, LDS executes in order
             }
             asm volatile("" ::: "memory");
+            scatter(won && w00, base, k00);
+            scatter(won && w01, base + 1, k01);
+            scatter(won && w10, base + WC, k10);
+            scatter(won && w11, base + WC + 1, k11);
+            done_lds = done_lds || won;
+            pending = pending && !won;
+        }
+        const bool i00 = done_lds && w00, i01 = done_lds && w01, i10 = done_lds && w10, i11 = done_lds && w11;
+        const bool s00 = a00 && !i00, s01 = a01 && !i01, s10 = a10 && !i10, s11 = a11 && !i11;
+        if (__any(s00 || s01 || s10 || s11)) {
+            const int o = h0 * g.W + w0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (c_w + r >= g.C) continue;
+                float* plane = gin_b + (size_t)(c_w + r) * HW;
+                if (s00) atomicAdd(plane + o, k00 * d[r]);
+                if (s01) atomicAdd(plane + o + 1, k01 * d[r]);
+                if (s10) atomicAdd(plane + o + g.W, k10 * d[r]);
+                if (s11) atomicAdd(plane + o + g.W + 1, k11 * d[r]);
+            }
+        }
+    }
+    // flush: lanes walk the cells of a row (coalesced), four planes each
+    asm volatile("" ::: "memory");
+    for (int pos = lane; pos < WSZ; pos += 64) {
+        const int yy = pos / WC, xx = pos - yy * WC;
+        float* gcell = gin_b + (size_t)(wy0 + yy) * g.W + wx0 + xx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = wp[r * WSZ + pos];
+            if (v != 0.0f && c_w + r < g.C) atomicAdd(gcell + (size_t)(c_w + r) * HW, v);
         }
     }
 }
@@ -710,10 +652,13 @@ int pick_bm(int M, long long N) {
 
 struct DcnPlan {
     int T, K, Kp, bm, Mp;           // forward pack [Kp][Mp]
-    int Cpad, Kp2, Mp2;             // dcol pack [Kp2 = Co padded][Mp2 = T*Cpad]
     int Mpw, Jp, Z;                 // wgrad slabs [Z][Mpw][Jp]
     long long N, pix_per_split;
     size_t fwd_bytes, bwd_bytes;
+    // split backward: 1x1 GEMM workspace, transposed weights, dcol, geometry records; col2im tiling
+    size_t gemm_bytes;
+    int TR, TC, tc_shift, tiles_y, tiles_x, ncg, WSZmax, claim_sz;
+    size_t col2im_lds;
 };
 DcnPlan make_plan(const DcnGeom& g) {
     DcnPlan q;
@@ -723,9 +668,6 @@ DcnPlan make_plan(const DcnGeom& g) {
     q.N = (long long)g.B * g.Ho * g.Wo;
     q.bm = pick_bm(g.Co, q.N);
     q.Mp = round_up(g.Co, q.bm);
-    q.Cpad = round_up(g.C, 64);
-    q.Kp2 = round_up(g.Co, IG_BK);
-    q.Mp2 = q.T * q.Cpad;
     q.Mpw = round_up(g.Co, WG_BM);
     q.Jp = round_up(q.K, WG_BJ);
     q.N = (long long)g.B * g.Ho * g.Wo;
@@ -738,8 +680,26 @@ DcnPlan make_plan(const DcnGeom& g) {
     q.pix_per_split = ((q.N + z - 1) / z + WG_BP - 1) / WG_BP * WG_BP;
     q.Z = (int)((q.N + q.pix_per_split - 1) / q.pix_per_split);
     q.fwd_bytes = carve_bytes((size_t)q.Kp * q.Mp, 4) + 256;
-    q.bwd_bytes = carve_bytes((size_t)q.Kp2 * q.Mp2, 4) + carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) +
-                  carve_bytes((size_t)g.Co * g.B, 4) + 256;
+    q.gemm_bytes = cnuda_conv2d_workspace_bytes(g.B, g.Co, g.Ho, g.Wo, q.T * g.C, 1, 1, 1, 1, 0, 0);
+    q.bwd_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) +
+                  carve_bytes((size_t)g.Co * g.B, 4) + carve_bytes((size_t)q.T * g.C * g.Co, 4) +
+                  carve_bytes((size_t)g.B * q.T * g.C * g.Ho * g.Wo, 4) +
+                  carve_bytes((size_t)g.B * q.T * g.Ho * g.Wo, sizeof(DcnGeo)) + carve_bytes(q.gemm_bytes, 1) + 256;
+    // col2im tile: 256 output pixels, lanes along x
+    q.TC = 64;
+    while (q.TC > 16 && q.TC / 2 >= g.Wo) q.TC >>= 1;
+    q.TR = 256 / q.TC;
+    q.tc_shift = q.TC == 64 ? 6 : (q.TC == 32 ? 5 : 4);
+    q.tiles_y = ceil_div(g.Ho, q.TR);
+    q.tiles_x = ceil_div(g.Wo, q.TC);
+    q.ncg = ceil_div(g.C, CI_CG);
+    const int wr = (q.TR - 1) * g.sh + (g.kh - 1) * g.dh + 2 * CI_MARGIN + 1;
+    const int wc = (q.TC - 1) * g.sw + (g.kw - 1) * g.dw + 2 * CI_MARGIN + 1;
+    q.WSZmax = wr * wc;
+    q.claim_sz = ((wr + 1) * (wc + 1) + 15) / 16 * 16;
+    // three workgroups per CU need <= 53 KiB each; larger windows (strides, dilations, big kernels) run windowless
+    if ((size_t)CI_CG * q.WSZmax * 4 + 1024 + 4 * (size_t)q.claim_sz > 53 * 1024) { q.WSZmax = 0; q.claim_sz = 16; }
+    q.col2im_lds = ((size_t)CI_CG * q.WSZmax + 256) * sizeof(float) + 4 * (size_t)q.claim_sz;
     return q;
 }
 
@@ -747,8 +707,6 @@ DcnPlan make_plan(const DcnGeom& g) {
 }  // namespace cnuda
 
 using namespace cnuda;
-
-extern "C" int cnuda_debug_dcn(int v) { g_dcn_dbg = v; return 0; }
 
 extern "C" size_t cnuda_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw,
                                                int ph, int pw, int dh, int dw, int dg) {
@@ -847,30 +805,34 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
     const DcnPlan q = make_plan(g);
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.bwd_bytes, "cnuda_dcn_v2_backward: workspace too small");
     Carver cv(workspace, workspace_bytes);
-    float* A2 = cv.take<float>((size_t)q.Kp2 * q.Mp2);
     float* slabs = cv.take<float>((size_t)q.Z * q.Mpw * q.Jp);
     float* bsum = cv.take<float>((size_t)Cout * B);
     launch_channel_sum(grad_output, grad_bias, B, Cout, HoWo, st, bsum);
-    // (1) column gradient + offset / mask / input gradients
-    launch_pack(weight, A2, Cout, C, q.T, PACK_DCOL, q.Kp2, q.Mp2, q.Cpad, st);
+    float* wt = cv.take<float>((size_t)q.T * C * Cout);
+    float* dcol = cv.take<float>((size_t)B * q.T * C * HoWo);
+    DcnGeo* geo = cv.take<DcnGeo>((size_t)B * q.T * HoWo);
+    void* gemm_ws = cv.take<char>(q.gemm_bytes);
     {
-        DcnBwdParams p{g, input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, g_dcn_dbg};
-        const int n_tiles = ceil_div(q.N, DB_BN);
-        // grad_offset / grad_mask are summed over channel tiles and waves with a few atomics per pixel
-        (void)hipMemsetAsync(grad_offset, 0, (size_t)B * 2 * T * HoWo * sizeof(float), st);
-        (void)hipMemsetAsync(grad_mask, 0, (size_t)B * T * HoWo * sizeof(float), st);
-        // As + Bs + window + dump cells + claim grids (4 waves x (WR+1)*(WC+1) <= DB_WIN + 128 ints)
-        const size_t lds = (size_t)(IG_BK * DB_BM + IG_BK * DB_BN + DB_BM * DB_WIN + IG_THREADS + 4 * (DB_WIN + 128)) *
-                           sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dcn_bwd_data_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
+        // (1) dcol = W^T x grad_output as a 1x1 implicit GEMM, then the two streaming consumers
+        ProfGroup prof;       // sub 0: the 1x1 GEMM (its own scope), 1: coord_grad, 2: col2im
+        hipLaunchKernelGGL(dcn_wt_kernel, dim3(stream_grid((long long)q.T * C * Cout, 256)), dim3(256), 0, st, weight,
+                           wt, Cout, C, q.T);
+        if (int rc = cnuda_conv2d_forward(grad_output, wt, nullptr, dcol, B, Cout, g.Ho, g.Wo, q.T * C, 1, 1, 1, 1, 0,
+                                          0, -1.0f, gemm_ws, q.gemm_bytes, stream))
+            return rc;
+        {
+            DcnCoordParams p{g, input, offset, mask, dcol, grad_offset, grad_mask, geo};
+            const int tiles = ceil_div(HoWo, 64), tw = q.T < 16 ? q.T : 16;
+            ProfScope scope(st, 1);
+            hipLaunchKernelGGL(dcn_coord_grad_kernel, dim3(B * tiles), dim3(64, tw), 0, st, p, tiles);
         }
-        ProfScope prof(st);
-        hipLaunchKernelGGL(dcn_bwd_data_kernel, dim3(n_tiles), dim3(IG_THREADS), lds, st, p, A2, q.Mp2, q.Kp2,
-                           q.Cpad, q.N, n_tiles);
+        {
+            DcnCol2imParams p{g, dcol, geo, grad_input, q.TR, q.TC, q.tc_shift, q.tiles_y, q.tiles_x,
+                              q.ncg, q.WSZmax, q.claim_sz};
+            const int n_wg = B * q.tiles_y * q.tiles_x * q.ncg;
+            ProfScope scope(st, 2);
+            hipLaunchKernelGGL(dcn_col2im_kernel, dim3(n_wg), dim3(256), q.col2im_lds, st, p, n_wg);
+        }
         if (int rc = check_launch("cnuda_dcn_v2_backward(data)")) return rc;
     }
     // (2) weight gradient

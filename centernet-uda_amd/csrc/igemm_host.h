@@ -8,7 +8,6 @@ namespace cnuda {
 enum PackMode {
     PACK_FWD = 0,    // dst[k = tap*C + c][m = o]        (forward / wgrad column order)
     PACK_DGRAD = 1,  // dst[k = tap*Co + o][m = c]       (transposed conv)
-    PACK_DCOL = 2,   // dst[k = o][m = tap*Cpad + c]     (DCN column gradient)
 };
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }

@@ -182,7 +182,6 @@ __global__ void regl1_bwd_kernel(const float* __restrict__ feat, const unsigned 
 
 // ---------------- softmax-over-channels losses ----------------
 // f(v) = v*log2(v + 1e-30);   f'(v) = log2(v + eps) + v / ((v + eps) ln 2)
-constexpr int kMaxC = 128;
 __device__ __forceinline__ float fent(float v) { return v * log2f(v + 1e-30f); }
 __device__ __forceinline__ float dfent(float v) { return log2f(v + 1e-30f) + v / ((v + 1e-30f) * 0.6931471805599453f); }
 

@@ -14,10 +14,8 @@ __global__ void pack_kernel(const float* __restrict__ W, float* __restrict__ dst
         int o = -1, c = -1, tap = -1;
         if (mode == PACK_FWD) {
             if (k < T * C && m < Co) { tap = k / C; c = k % C; o = m; }
-        } else if (mode == PACK_DGRAD) {
-            if (k < T * Co && m < C) { tap = k / Co; o = k % Co; c = m; }
         } else {
-            if (k < Co && m < T * Cpad) { o = k; tap = m / Cpad; c = m % Cpad; if (c >= C) o = -1; }
+            if (k < T * Co && m < C) { tap = k / Co; o = k % Co; c = m; }
         }
         dst[i] = (o >= 0) ? W[((size_t)o * C + c) * T + tap] : 0.0f;
     }

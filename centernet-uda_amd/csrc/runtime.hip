@@ -24,18 +24,25 @@ struct ProfRecord { hipEvent_t start, stop; int tag; };
 std::vector<ProfRecord> g_prof_pool;   // pre-created event pairs
 size_t g_prof_used = 0;
 int g_prof_armed = -1;                 // tag for the next main-kernel launch, -1 = off
+int g_prof_group = -1;                 // tag shared by every scope of a multi-kernel entry point
 }  // namespace
 
-ProfScope::ProfScope(hipStream_t st) : st_(st), rec_(-1) {
-    if (g_prof_armed < 0 || g_prof_used >= g_prof_pool.size()) return;
+ProfScope::ProfScope(hipStream_t st, int sub) : st_(st), rec_(-1) {
+    const int tag = g_prof_armed >= 0 ? g_prof_armed : g_prof_group;
+    if (tag < 0 || g_prof_used >= g_prof_pool.size()) return;
     rec_ = (int)g_prof_used++;
-    g_prof_pool[rec_].tag = g_prof_armed;
+    g_prof_pool[rec_].tag = tag | (sub << 24);
     g_prof_armed = -1;
     (void)hipEventRecord(g_prof_pool[rec_].start, st_);
 }
 ProfScope::~ProfScope() {
     if (rec_ >= 0) (void)hipEventRecord(g_prof_pool[rec_].stop, st_);
 }
+ProfGroup::ProfGroup() {
+    g_prof_group = g_prof_armed;
+    g_prof_armed = -1;
+}
+ProfGroup::~ProfGroup() { g_prof_group = -1; }
 }  // namespace cnuda
 
 extern "C" int cnuda_prof_enable(int max_records) {
@@ -44,6 +51,7 @@ extern "C" int cnuda_prof_enable(int max_records) {
     g_prof_pool.clear();
     g_prof_used = 0;
     g_prof_armed = -1;
+    g_prof_group = -1;
     for (int i = 0; i < max_records; ++i) {
         ProfRecord r;
         r.tag = -1;

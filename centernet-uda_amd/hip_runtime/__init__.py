@@ -153,7 +153,7 @@ def workspace(nbytes, device):
 # ---------------------------------------------------------------------------
 class _Prof:
     enabled = False
-    table = []          # tag -> (kernel name, algorithmic FLOPs of the launch)
+    table = []          # tag -> [(kernel name, algorithmic FLOPs, algorithmic HBM bytes) per sub-kernel]
     cap = 0
 
 
@@ -201,10 +201,20 @@ def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
     elif kind == 'dcn_fwd':
         name = 'igemm_fwd_kernel<%d, DcnFwdLoader>' % _bm(Co, B * Ho * Wo)
     elif kind == 'dcn_bwd':
-        name = 'dcn_bwd_data_kernel'
+        # three kernels, timed separately (ProfGroup in csrc/dcn.hip): the column-gradient GEMM (a 1x1
+        # convolution over grad_output with 9*C output channels: all of the entry point's MFMA work), then
+        # the two HBM-streaming consumers with their algorithmic bytes
+        T, px = kh * kw, B * Ho * Wo
+        name = 'igemm_fwd_kernel<%d, ConvFwdLoader<%s>>' % (_bm(T * C, px), tf(Co % 16 == 0))
+        coord_bytes = 4.0 * px * (T * C + 3 * T + 3 * T + 4 * T) + 4.0 * B * C * H * W
+        col2im_bytes = 4.0 * px * T * C + 16.0 * px * T * ((C + 15) // 16) + 4.0 * B * C * H * W
+        _Prof.table.append([(name, flops, 0.0), ('dcn_coord_grad_kernel', 0.0, coord_bytes),
+                            ('dcn_col2im_kernel', 0.0, col2im_bytes)])
+        lib().cnuda_prof_arm(len(_Prof.table) - 1)
+        return
     else:
         raise ValueError(kind)
-    _Prof.table.append((name, flops))
+    _Prof.table.append([(name, flops, 0.0)])
     lib().cnuda_prof_arm(len(_Prof.table) - 1)
 
 
@@ -214,18 +224,19 @@ def prof_begin(max_records=16384):
 
 
 def prof_end():
-    """-> {kernel name: {'launches', 'ms', 'flops'}} and disables the timer."""
-    n = len(_Prof.table)
+    """-> {kernel name: {'launches', 'ms', 'flops', 'bytes'}} and disables the timer."""
+    n = sum(len(e) for e in _Prof.table)          # one record per (armed call, sub-kernel)
     tags = (ctypes.c_int * max(n, 1))()
     ms = (ctypes.c_float * max(n, 1))()
     got = lib().cnuda_prof_collect(tags, ms, n)
     out = {}
     for i in range(got):
-        name, flops = _Prof.table[tags[i]]
-        d = out.setdefault(name, {'launches': 0, 'ms': 0.0, 'flops': 0.0})
+        name, flops, nbytes = _Prof.table[tags[i] & 0xffffff][tags[i] >> 24]
+        d = out.setdefault(name, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
         d['launches'] += 1
         d['ms'] += float(ms[i])
         d['flops'] += flops
+        d['bytes'] += nbytes
     _Prof.enabled, _Prof.table = False, []
     lib().cnuda_prof_enable(0)
     return out

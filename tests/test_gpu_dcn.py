@@ -1,5 +1,7 @@
 """MI355X parity of `_ext.dcn_v2_forward/backward` (HIP) against the CPU oracle,
 plus the reference's own known-answer tests run through the HIP path."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -43,13 +45,16 @@ CASES = {
     'k1': dict(B=2, C=16, Co=8, H=6, W=7, k=1, p=0),
     'dg2': dict(B=2, C=8, Co=6, H=10, W=10, dg=2),                   # testcpu.py:169-180 uses dg=2
     'c512': dict(B=1, C=512, Co=256, H=4, W=4),                      # ida_0.proj_1 shape at 128^2 input
+    'wide_rows': dict(B=1, C=20, Co=16, H=10, W=130, off_scale=0.7),  # 64-pixel row tiles, ragged last column tile
+    'wide_rows_smooth': dict(B=1, C=16, Co=16, H=6, W=96, off_scale=0.05),
+    'stride2_wide': dict(B=1, C=16, Co=8, H=12, W=70, s=2),          # col2im window too large for the LDS -> windowless
 }
 
 
 @pytest.mark.parametrize('name', sorted(CASES))
 def test_forward_backward_vs_oracle(name):
     import _ext
-    (x, w, b, off, m, go), geom = _case(hash(name) % 1000, **CASES[name])
+    (x, w, b, off, m, go), geom = _case(zlib.crc32(name.encode()) % 1000, **CASES[name])
     want = od.dcn_v2_forward(x, w, b, off, m, *geom)
     wg = od.dcn_v2_backward(x, w, b, off, m, go, *geom)
     dx, dw_, db, doff, dm, dgo = [t.to(DEV) for t in (x, w, b, off, m, go)]
