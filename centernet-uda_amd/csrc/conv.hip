@@ -91,16 +91,17 @@ struct ConvDgradParams {
     ConvGeom g;
     const float* gy;
     float* gx;
+    int cop;   // output channels per tap on the K axis: Co rounded up to the 16-deep chunk, so that a chunk
+               // never straddles two taps (padded rows carry zero weights; their loads are clamped to Co-1)
 };
-template <bool FAST>
 struct ConvDgradLoader {
     using Params = ConvDgradParams;
     static constexpr bool kHasSideOutput = false;
     const ConvGeom& g;
     const float* gy_b;
-    int iy, ix;
+    int iy, ix, cop;
     bool valid;
-    __device__ ConvDgradLoader(const Params& p, long long n, bool n_valid) : g(p.g), valid(n_valid) {
+    __device__ ConvDgradLoader(const Params& p, long long n, bool n_valid) : g(p.g), cop(p.cop), valid(n_valid) {
         const int HW = g.H * g.W;
         const int nn = n_valid ? (int)n : 0;   // N < 2^31 is checked on the host: 32-bit index math
         const int b = nn / HW, pp = nn - b * HW;
@@ -118,26 +119,15 @@ struct ConvDgradLoader {
         return true;
     }
     __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
-        const int HoWo = g.Ho * g.Wo, K = g.kh * g.kw * g.Co;
-        if (FAST) {
-            const int tap = k0 / g.Co, o0 = k0 - tap * g.Co + ksub;
-            int off = 0;
-            const bool ok = valid && k0 < K && locate(tap, off);
-            const float* ptr = gy_b + (size_t)o0 * HoWo + off;
+        const int HoWo = g.Ho * g.Wo, K = g.kh * g.kw * cop;
+        const int tap = k0 / cop, o0 = k0 - tap * cop + ksub;
+        int off = 0;
+        const bool ok = valid && k0 < K && locate(tap, off);
+        const float* ptr = gy_b + off;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = ok ? ptr[(size_t)(2 * j) * HoWo] : 0.0f;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + ksub + 2 * j;
-                float val = 0.0f;
-                if (valid && k < K) {
-                    const int tap = k / g.Co, o = k - tap * g.Co;
-                    int off;
-                    if (locate(tap, off)) val = gy_b[(size_t)o * HoWo + off];
-                }
-                v[j] = val;
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int o = o0 + 2 * j < g.Co ? o0 + 2 * j : g.Co - 1;
+            v[j] = ok ? ptr[(size_t)o * HoWo] : 0.0f;
         }
     }
     struct Out {
@@ -334,7 +324,7 @@ ConvPlan make_plan(const ConvGeom& g) {
     q.Nf = (long long)g.B * g.Ho * g.Wo;
     q.Nd = (long long)g.B * g.H * g.W;
     q.Kf = q.T * g.C;   q.Kpf = round_up(q.Kf, IG_KC);  q.bmf = pick_bm(g.Co, q.Nf);  q.Mpf = round_up(g.Co, q.bmf);
-    q.Kd = q.T * g.Co;  q.Kpd = round_up(q.Kd, IG_KC);  q.bmd = pick_bm(g.C, q.Nd);   q.Mpd = round_up(g.C, q.bmd);
+    q.Kd = q.T * round_up(g.Co, IG_BK);  q.Kpd = round_up(q.Kd, IG_KC);  q.bmd = pick_bm(g.C, q.Nd);   q.Mpd = round_up(g.C, q.bmd);
     q.wbm = g.Co <= 32 ? 32 : 64;
     q.wbj = g.Co <= 32 ? 128 : 64;
     q.Mpw = round_up(g.Co, q.wbm);
@@ -455,11 +445,9 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
             }
         return 0;
     }
-    launch_pack(weight, A, Cout, C, q.T, PACK_DGRAD, q.Kpd, q.Mpd, 0, st);
-    ConvDgradParams p{g, grad_y, grad_x};
-    if (Cout % IG_BK == 0)
-        return launch_fwd<ConvDgradLoader<true>>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
-    return launch_fwd<ConvDgradLoader<false>>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
+    launch_pack(weight, A, Cout, C, q.T, PACK_DGRAD, q.Kpd, q.Mpd, round_up(Cout, IG_BK), st);
+    ConvDgradParams p{g, grad_y, grad_x, round_up(Cout, IG_BK)};
+    return launch_fwd<ConvDgradLoader>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
 }
 
 extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y, float* grad_weight, float* grad_bias,

@@ -7,7 +7,7 @@ namespace cnuda {
 
 enum PackMode {
     PACK_FWD = 0,    // dst[k = tap*C + c][m = o]        (forward / wgrad column order)
-    PACK_DGRAD = 1,  // dst[k = tap*Co + o][m = c]       (transposed conv)
+    PACK_DGRAD = 1,  // dst[k = tap*Cpad + o][m = c]     (transposed conv; Cpad = Co rounded up to 16)
 };
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }

@@ -14,8 +14,8 @@ __global__ void pack_kernel(const float* __restrict__ W, float* __restrict__ dst
         int o = -1, c = -1, tap = -1;
         if (mode == PACK_FWD) {
             if (k < T * C && m < Co) { tap = k / C; c = k % C; o = m; }
-        } else {
-            if (k < T * Co && m < C) { tap = k / Co; o = k % Co; c = m; }
+        } else {   // PACK_DGRAD: Cpad = Co rounded up to the K chunk, rows o >= Co stay zero
+            if (k < T * Cpad && m < C) { tap = k / Cpad; o = k % Cpad; c = m; if (o >= Co) o = -1; }
         }
         dst[i] = (o >= 0) ? W[((size_t)o * C + c) * T + tap] : 0.0f;
     }

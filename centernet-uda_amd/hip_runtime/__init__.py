@@ -191,7 +191,7 @@ def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
                 (-(-kh // stride)) * (-(-kw // stride)) <= 9:
             name = 'igemm_fwd_kernel<*, ConvDgradClassLoader> (group of stride^2 class launches)'
         else:
-            name = 'igemm_fwd_kernel<%d, ConvDgradLoader<%s>>' % (_bm(C, B * H * W), tf(Co % 16 == 0))
+            name = 'igemm_fwd_kernel<%d, ConvDgradLoader>' % _bm(C, B * H * W)
     elif kind == 'conv_wgrad':
         if _smallc(C, Co, kh, kw, stride):
             name = 'smallc_wgrad_kernel<%d>' % ((Co + 15) // 16)
