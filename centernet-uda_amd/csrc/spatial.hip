@@ -120,31 +120,93 @@ __global__ void maxpool_win_bwd_kernel(const float* __restrict__ x, const float*
 
 // ---- depthwise transposed conv: k = 2f, stride f, padding f/2 (any k,s,p accepted) ----
 // y[b,c,oy,ox] = sum_{ky,kx} x[b,c,(oy+p-ky)/s,(ox+p-kx)/s] * w[c,ky,kx]   (exact divisions only)
-__global__ void dwconvt_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
-                                   int B, int C, int H, int W, int Ho, int Wo, int k, int s, int p) {
-    const long long total = (long long)B * C * Ho * Wo;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho);
-        const long long pl = i / ((long long)Wo * Ho);
-        const int c = (int)(pl % C);
-        const float* xp = x + (size_t)pl * H * W;
-        const float* wp = w + (size_t)c * k * k;
-        float acc = 0.0f;
-        // valid ky: (oy + p - ky) % s == 0  ->  ky = (oy + p) % s + t*s
-        for (int ky = (oy + p) % s; ky < k; ky += s) {
-            const int iy = (oy + p - ky) / s;
-            if (iy < 0 || iy >= H) continue;
-            for (int kx = (ox + p) % s; kx < k; kx += s) {
-                const int ix = (ox + p - kx) / s;
-                if (ix < 0 || ix >= W) continue;
-                acc += xp[iy * W + ix] * wp[ky * k + kx];
+// grid = (output tiles of 256, planes): 32-bit index math, the channel's kernel in LDS; store-bound
+__global__ __launch_bounds__(kT) void dwconvt_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
+                                                         int k, int s, int p) {
+    __shared__ float ws[1024];
+    const int pl = blockIdx.y, c = pl % C;
+    for (int i = threadIdx.x; i < k * k; i += kT) ws[i] = w[(size_t)c * k * k + i];
+    __syncthreads();
+    const int o = blockIdx.x * kT + threadIdx.x;
+    if (o >= Ho * Wo) return;
+    const int oy = o / Wo, ox = o - oy * Wo;
+    const float* xp = x + (size_t)pl * H * W;
+    float acc = 0.0f;
+    // valid ky: (oy + p - ky) % s == 0  ->  ky = (oy + p) % s + t*s
+    for (int ky = (oy + p) % s; ky < k; ky += s) {
+        const int iy = (oy + p - ky) / s;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = (ox + p) % s; kx < k; kx += s) {
+            const int ix = (ox + p - kx) / s;
+            if (ix < 0 || ix >= W) continue;
+            acc += xp[iy * W + ix] * ws[ky * k + kx];
+        }
+    }
+    y[(size_t)pl * Ho * Wo + o] = acc;
+}
+// Both gradients read the same K x K window of gy around an input pixel:
+//   gx[b,c,iy,ix]  = sum_{ky,kx} gy[b,c,iy*s-p+ky, ix*s-p+kx] * w[c,ky,kx]
+//   gw[c,ky,kx]    = sum_{b,iy,ix} x[b,c,iy,ix] * gy[b,c,iy*s-p+ky, ix*s-p+kx]
+// one workgroup per plane (c, b): gx written directly, K*K partial sums reduced in the block (fixed order)
+// into part[c][b][K*K]; dwconvt_wsum_kernel adds the B partials in order (reproducible, no atomics).
+template <int K>
+__global__ __launch_bounds__(kT) void dwconvt_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ gy, float* __restrict__ gx,
+                                                         float* __restrict__ part, int B, int C, int H, int W, int Ho,
+                                                         int Wo, int s, int p) {
+    __shared__ float ws[K * K];
+    __shared__ float red[4][K * K];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const size_t pl = (size_t)b * C + c;
+    for (int i = threadIdx.x; i < K * K; i += kT) ws[i] = w[(size_t)c * K * K + i];
+    __syncthreads();
+    const float* xp = x + pl * H * W;
+    const float* gp = gy + pl * Ho * Wo;
+    float acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = 0.0f;
+    for (int i = threadIdx.x; i < H * W; i += kT) {
+        const int iy = i / W, ix = i - iy * W;
+        const float xv = part ? xp[i] : 0.0f;
+        const int oy0 = iy * s - p, ox0 = ix * s - p;
+        float g = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int oy = oy0 + ky;
+            const bool rok = oy >= 0 && oy < Ho;
+            const float* row = gp + (rok ? oy : 0) * Wo;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int ox = ox0 + kx;
+                const bool ok = rok && ox >= 0 && ox < Wo;
+                const float v = ok ? row[ox] : 0.0f;
+                g += v * ws[ky * K + kx];
+                acc[ky * K + kx] += xv * v;
             }
         }
-        y[i] = acc;
+        if (gx) gx[pl * H * W + i] = g;
     }
+    if (!part) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+        const float v = wave_sum(acc[t]);
+        if (lane == 0) red[wid][t] = v;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < K * K; t += kT)
+        part[((size_t)c * B + b) * K * K + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
 }
-// gx[b,c,iy,ix] = sum_{ky,kx} gy[b,c,iy*s-p+ky, ix*s-p+kx] * w[c,ky,kx]
+__global__ void dwconvt_wsum_kernel(const float* __restrict__ part, float* __restrict__ gw, int B, int C, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * T) return;
+    const int c = i / T, t = i - c * T;
+    float acc = 0.0f;
+    for (int b = 0; b < B; ++b) acc += part[((size_t)c * B + b) * T + t];
+    gw[i] = acc;
+}
+// generic kernel sizes: one thread per input pixel / one workgroup per (c, tap)
 __global__ void dwconvt_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ w,
                                         float* __restrict__ gx, int B, int C, int H, int W, int Ho, int Wo, int k,
                                         int s, int p) {
@@ -169,8 +231,6 @@ __global__ void dwconvt_bwd_data_kernel(const float* __restrict__ gy, const floa
         gx[i] = acc;
     }
 }
-// gw[c,ky,kx] = sum_{b,iy,ix} x[b,c,iy,ix] * gy[b,c,iy*s-p+ky, ix*s-p+kx]
-// one workgroup per (c, tap-group); fixed-order block reduction (reproducible)
 __global__ __launch_bounds__(kT) void dwconvt_bwd_weight_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ gy, float* __restrict__ gw,
                                                                 int B, int C, int H, int W, int Ho, int Wo, int k, int s,
@@ -306,21 +366,43 @@ extern "C" int cnuda_maxpool2d_window_backward(const float* x, const float* grad
 
 extern "C" int cnuda_dwconvt2d_forward(const float* x, const float* w, float* y, int B, int C, int H, int W, int k,
                                        int s, int p, cnuda_stream_t stream) {
-    CNUDA_REQUIRE(x && w && y && B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && s > 0 && p >= 0,
-                  "cnuda_dwconvt2d_forward: bad arguments");
+    CNUDA_REQUIRE(x && w && y && B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && k <= 32 && s > 0 && p >= 0,
+                  "cnuda_dwconvt2d_forward: bad arguments (kernel size 1..32)");
     const int Ho = (H - 1) * s - 2 * p + k, Wo = (W - 1) * s - 2 * p + k;
     CNUDA_REQUIRE(Ho > 0 && Wo > 0, "cnuda_dwconvt2d_forward: empty output");
-    hipLaunchKernelGGL(dwconvt_fwd_kernel, dim3(stream_grid((long long)B * C * Ho * Wo, kT)), dim3(kT), 0,
-                       (hipStream_t)stream, x, w, y, B, C, H, W, Ho, Wo, k, s, p);
+    CNUDA_REQUIRE((long long)B * C <= 65535, "cnuda_dwconvt2d_forward: more than 65535 planes");
+    hipLaunchKernelGGL(dwconvt_fwd_kernel, dim3(ceil_div((long long)Ho * Wo, kT), B * C), dim3(kT), 0,
+                       (hipStream_t)stream, x, w, y, C, H, W, Ho, Wo, k, s, p);
     return check_launch("cnuda_dwconvt2d_forward");
+}
+extern "C" size_t cnuda_dwconvt2d_workspace_bytes(int B, int C, int k) {
+    return (size_t)(B > 0 ? B : 0) * (C > 0 ? C : 0) * k * k * sizeof(float) + 256;
 }
 extern "C" int cnuda_dwconvt2d_backward(const float* x, const float* w, const float* grad_y, float* grad_x,
                                         float* grad_w, int B, int C, int H, int W, int k, int s, int p,
-                                        cnuda_stream_t stream) {
+                                        void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
     CNUDA_REQUIRE(x && w && grad_y && B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && s > 0 && p >= 0,
                   "cnuda_dwconvt2d_backward: bad arguments");
     const int Ho = (H - 1) * s - 2 * p + k, Wo = (W - 1) * s - 2 * p + k;
     hipStream_t st = (hipStream_t)stream;
+    if ((k == 4 || k == 8) && C <= 65535 && B <= 65535) {
+        float* part = nullptr;
+        if (grad_w) {
+            CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_dwconvt2d_workspace_bytes(B, C, k),
+                          "cnuda_dwconvt2d_backward: workspace too small");
+            part = (float*)workspace;
+        }
+        if (k == 4)
+            hipLaunchKernelGGL(dwconvt_bwd_kernel<4>, dim3(C, B), dim3(kT), 0, st, x, w, grad_y, grad_x, part, B, C, H, W,
+                               Ho, Wo, s, p);
+        else
+            hipLaunchKernelGGL(dwconvt_bwd_kernel<8>, dim3(C, B), dim3(kT), 0, st, x, w, grad_y, grad_x, part, B, C, H, W,
+                               Ho, Wo, s, p);
+        if (grad_w)
+            hipLaunchKernelGGL(dwconvt_wsum_kernel, dim3(ceil_div((long long)C * k * k, 256)), dim3(256), 0, st, part,
+                               grad_w, B, C, k * k);
+        return check_launch("cnuda_dwconvt2d_backward");
+    }
     if (grad_x)
         hipLaunchKernelGGL(dwconvt_bwd_data_kernel, dim3(stream_grid((long long)B * C * H * W, kT)), dim3(kT), 0, st,
                            grad_y, w, grad_x, B, C, H, W, Ho, Wo, k, s, p);

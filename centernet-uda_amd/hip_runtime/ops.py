@@ -287,8 +287,11 @@ class _DwConvT(Function):
         x, weight = ctx.saved_tensors
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
-        check(lib().cnuda_dwconvt2d_backward(ptr(x), ptr(weight), ptr(f32c(gy)), ptr(gx), ptr(gw), *ctx.geom,
-                                             stream()), 'dwconvt2d_backward')
+        L = lib()
+        B, C, _, _, k = ctx.geom[:5]
+        wp, wn = _ws(L.cnuda_dwconvt2d_workspace_bytes(B, C, k), x)
+        check(L.cnuda_dwconvt2d_backward(ptr(x), ptr(weight), ptr(f32c(gy)), ptr(gx), ptr(gw), *ctx.geom,
+                                         wp, wn, stream()), 'dwconvt2d_backward')
         return gx, gw, None, None
 
 

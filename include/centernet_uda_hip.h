@@ -190,8 +190,10 @@ int cnuda_maxpool2d_window_backward(const float* x, const float* grad_y, float* 
                                     int B, int C, int H, int W, int k, int s, int p, cnuda_stream_t stream);
 int cnuda_dwconvt2d_forward(const float* x, const float* w, float* y,
                             int B, int C, int H, int W, int k, int s, int p, cnuda_stream_t stream);
+size_t cnuda_dwconvt2d_workspace_bytes(int B, int C, int k);   /* per-image partial weight gradients */
 int cnuda_dwconvt2d_backward(const float* x, const float* w, const float* grad_y, float* grad_x, float* grad_w,
-                             int B, int C, int H, int W, int k, int s, int p, cnuda_stream_t stream);
+                             int B, int C, int H, int W, int k, int s, int p,
+                             void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 int cnuda_add(const float* a, const float* b, float* out, long long n, cnuda_stream_t stream);
 int cnuda_act_backward(const float* grad_y, const float* y, float* grad_x, long long n, float slope,
                        cnuda_stream_t stream);
