@@ -41,12 +41,12 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
             dilation_h, dilation_w, deformable_group)
     out = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=input.device)
     cols = None
-    if _want_columns and deformable_group == 1:
+    if _want_columns and deformable_group == 1 and W >= 2:
         cols = torch.empty((B, T * C, Ho * Wo), dtype=torch.float32, device=input.device)
     L = hr.lib()
     nbytes = L.cnuda_dcn_v2_workspace_bytes(*geom)
     ws = hr.workspace(nbytes, input.device)
-    if deformable_group == 1:
+    if deformable_group == 1 and W >= 2:
         hr.prof_arm('dcn_fwd', B, C, H, W, Co, kernel_h, kernel_w, Ho, Wo)
     hr.check(L.cnuda_dcn_v2_forward_cols(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
                                          hr.ptr(out), hr.ptr(cols), *geom, hr.ptr(ws), ws.numel(), hr.stream()),

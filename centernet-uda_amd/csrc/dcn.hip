@@ -114,10 +114,11 @@ struct DcnFwdLoader {
     bool valid;
     int cur;   // tap whose sampling state currently sits in the registers below (K is tap-major:
                // consecutive chunks share it)
-    // per (pixel, tap): clamped corner offsets and corner weights with validity and mask folded in, so
-    // one sampled value is 4 unconditional loads + 4 multiply-adds
-    int q00, q01, q10, q11;
-    float m00, m01, m10, m11;
+    // per (pixel, tap): the two corner ROWS as clamped offsets of a horizontally adjacent pair, and the four
+    // corner weights with validity and mask folded in: one sampled value is 2 unconditional 8-byte loads
+    // (4-byte aligned; the buffer path takes them) + 4 multiply-adds
+    int qT, qB;
+    float m00, m01, m10, m11;     // weights of (top-left, top-right, bottom-left, bottom-right) of the loaded pairs
     float* col_n;     // this pixel's column in the side output (nullptr: not requested / not the first M tile)
     int col_stride;
     __device__ __forceinline__ void disable_col() { col_n = nullptr; }
@@ -135,15 +136,31 @@ struct DcnFwdLoader {
         col_n = (p.col && n_valid) ? p.col + (size_t)b * K * HoWo + pp : nullptr;
         col_stride = HoWo;
     }
+    struct __attribute__((packed, aligned(4))) Pair { float l, r; };
     __device__ __forceinline__ void set_tap(int tap) {
         const Tap t = make_tap(g, off_b, mask_b, 0, tap, oy, ox);
-        q00 = t.o00; q01 = t.o01; q10 = t.o10; q11 = t.o11;            // already 0 for missing corners
         const float mk = (valid && t.inside) ? t.mask : 0.0f;
-        m00 = t.c00 ? t.hh * t.hw * mk : 0.0f;
-        m01 = t.c01 ? t.hh * t.lw * mk : 0.0f;
-        m10 = t.c10 ? t.lh * t.hw * mk : 0.0f;
-        m11 = t.c11 ? t.lh * t.lw * mk : 0.0f;
+        const float w00 = t.c00 ? t.hh * t.hw * mk : 0.0f, w01 = t.c01 ? t.hh * t.lw * mk : 0.0f;
+        const float w10 = t.c10 ? t.lh * t.hw * mk : 0.0f, w11 = t.c11 ? t.lh * t.lw * mk : 0.0f;
+        // the pair starts at column clamp(w0, 0, W-2) (host guarantees W >= 2): at the left edge (w0 == -1) the
+        // existing right corner is the pair's LEFT element, at the right edge (w0 == W-1) the existing left
+        // corner is the pair's RIGHT element; missing corners carry zero weight
+        const bool inside = valid && t.inside;
+        const int w0 = inside ? t.w0 : 0, h0 = inside ? t.h0 : 0;
+        const int wa = w0 < 0 ? 0 : (w0 > g.W - 2 ? g.W - 2 : w0);
+        const bool ledge = w0 < 0, redge = w0 > g.W - 2;
+        m00 = ledge ? w01 : (redge ? 0.0f : w00);
+        m01 = ledge ? 0.0f : (redge ? w00 : w01);
+        m10 = ledge ? w11 : (redge ? 0.0f : w10);
+        m11 = ledge ? 0.0f : (redge ? w10 : w11);
+        const int ht = h0 < 0 ? 0 : h0, hb = h0 + 1 > g.H - 1 ? g.H - 1 : h0 + 1;
+        qT = ht * g.W + wa;
+        qB = hb * g.W + wa;
         cur = tap;
+    }
+    __device__ __forceinline__ float sample(const float* __restrict__ pl) const {
+        const Pair a = *reinterpret_cast<const Pair*>(pl + qT), b = *reinterpret_cast<const Pair*>(pl + qB);
+        return m00 * a.l + m01 * a.r + m10 * b.l + m11 * b.r;
     }
     __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
         const int HW = g.H * g.W;
@@ -160,7 +177,7 @@ struct DcnFwdLoader {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float* pl = plane + (size_t)(2 * j) * HW;
-                const float r = m00 * pl[q00] + m01 * pl[q01] + m10 * pl[q10] + m11 * pl[q11];
+                const float r = sample(pl);
                 if (col_n) col_n[(size_t)(k0 + ksub + 2 * j) * col_stride] = r;
                 v[j] = r;
             }
@@ -174,7 +191,7 @@ struct DcnFwdLoader {
                 const int tap = k / g.C, c = k - tap * g.C;
                 if (tap != cur) set_tap(tap);
                 const float* pl = in_b + (size_t)c * HW;
-                r = m00 * pl[q00] + m01 * pl[q01] + m10 * pl[q10] + m11 * pl[q11];
+                r = sample(pl);
                 if (col_n) col_n[(size_t)k * col_stride] = r;
             }
             v[j] = r;
@@ -730,11 +747,12 @@ extern "C" int cnuda_dcn_v2_forward_cols(const float* input, const float* weight
                                          int dh, int dw, int dg, void* workspace, size_t workspace_bytes,
                                          cnuda_stream_t stream) {
     CNUDA_REQUIRE(input && weight && bias && offset && mask && output, "cnuda_dcn_v2_forward: null pointer");
-    CNUDA_REQUIRE(!columns || dg == 1, "cnuda_dcn_v2_forward_cols: columns output needs deformable_group == 1");
+    CNUDA_REQUIRE(!columns || (dg == 1 && W >= 2),
+                  "cnuda_dcn_v2_forward_cols: columns output needs deformable_group == 1 and width >= 2");
     DcnGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, "cnuda_dcn_v2_forward")) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (dg != 1) {
+    if (dg != 1 || W < 2) {   // the MFMA path samples horizontally adjacent pairs
         DcnNaiveParams p{g, input, weight, bias, offset, mask, nullptr, output, nullptr, nullptr, nullptr, nullptr};
         hipLaunchKernelGGL(dcn_naive_fwd_kernel, dim3(stream_grid((long long)B * Cout * g.Ho * g.Wo, 256)), dim3(256),
                            0, st, p);

@@ -45,6 +45,8 @@ CASES = {
     'k1': dict(B=2, C=16, Co=8, H=6, W=7, k=1, p=0),
     'dg2': dict(B=2, C=8, Co=6, H=10, W=10, dg=2),                   # testcpu.py:169-180 uses dg=2
     'c512': dict(B=1, C=512, Co=256, H=4, W=4),                      # ida_0.proj_1 shape at 128^2 input
+    'width1': dict(B=1, C=4, Co=4, H=5, W=1),                          # no horizontal neighbour: generic kernels
+    'width2': dict(B=2, C=16, Co=16, H=5, W=2, off_scale=1.0),
     'wide_rows': dict(B=1, C=20, Co=16, H=10, W=130, off_scale=0.7),  # 64-pixel row tiles, ragged last column tile
     'wide_rows_smooth': dict(B=1, C=16, Co=16, H=6, W=96, off_scale=0.05),
     'stride2_wide': dict(B=1, C=16, Co=8, H=12, W=70, s=2),          # col2im window too large for the LDS -> windowless
