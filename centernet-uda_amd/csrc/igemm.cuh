@@ -94,7 +94,7 @@ __device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, cons
 // Epilogue contract:
 //   void store(const Params&, int m, long long n, float value)
 template <int BM, class Loader>
-__global__ __launch_bounds__(IG_THREADS) void igemm_fwd_kernel(
+__global__ __launch_bounds__(IG_THREADS, (BM == 128 ? 3 : 1)) void igemm_fwd_kernel(
     typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
     int n_tiles, int m_tiles, int dbg = 0) {
     using T = IgTile<BM>;
