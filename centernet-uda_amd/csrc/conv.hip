@@ -342,7 +342,6 @@ ConvPlan make_plan(const ConvGeom& g) {
     return q;
 }
 
-int g_conv_dbg = 0;
 template <class Loader>
 int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp, int Kp, int M, long long N,
                hipStream_t st, const char* who) {
@@ -351,11 +350,11 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
     ProfScope prof(st);
     if (bm == 128)
-        hipLaunchKernelGGL((igemm_fwd_kernel<128, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles, g_conv_dbg);
+        hipLaunchKernelGGL((igemm_fwd_kernel<128, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
     else if (bm == 64)
-        hipLaunchKernelGGL((igemm_fwd_kernel<64, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles, g_conv_dbg);
+        hipLaunchKernelGGL((igemm_fwd_kernel<64, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
     else
-        hipLaunchKernelGGL((igemm_fwd_kernel<32, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles, g_conv_dbg);
+        hipLaunchKernelGGL((igemm_fwd_kernel<32, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
     return check_launch(who);
 }
 
@@ -364,7 +363,6 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
 
 using namespace cnuda;
 
-extern "C" int cnuda_debug_conv(int v) { g_conv_dbg = v; return 0; }
 
 extern "C" size_t cnuda_conv2d_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw,
                                                int ph, int pw) {
@@ -387,7 +385,7 @@ extern "C" int cnuda_conv2d_forward(const float* x, const float* weight, const f
     CNUDA_REQUIRE(x && weight && y, "cnuda_conv2d_forward: null pointer");
     ConvGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_forward")) return rc;
-    if (smallc_supported(C, Cout, kh, kw, sh, sw) && !(g_conv_dbg & 64))
+    if (smallc_supported(C, Cout, kh, kw, sh, sw))
         return smallc_forward(x, weight, bias, y, B, C, H, W, Cout, kh, kw, sh, ph, pw, act_slope, 0, workspace,
                               workspace_bytes, (hipStream_t)stream);
     const ConvPlan q = make_plan(g);
@@ -408,8 +406,7 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
     CNUDA_REQUIRE(grad_y && weight && grad_x, "cnuda_conv2d_backward_data: null pointer");
     ConvGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_backward_data")) return rc;
-    if (sh == 1 && sw == 1 && smallc_supported(Cout, C, kh, kw, 1, 1) && kh - 1 - ph >= 0 && kw - 1 - pw >= 0 &&
-        !(g_conv_dbg & 64))
+    if (sh == 1 && sw == 1 && smallc_supported(Cout, C, kh, kw, 1, 1) && kh - 1 - ph >= 0 && kw - 1 - pw >= 0)
         return smallc_forward(grad_y, weight, nullptr, grad_x, B, Cout, g.Ho, g.Wo, C, kh, kw, 1, kh - 1 - ph,
                               kw - 1 - pw, -1.0f, 1, workspace, workspace_bytes, (hipStream_t)stream);
     const ConvPlan q = make_plan(g);
@@ -457,7 +454,7 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
     CNUDA_REQUIRE(x && grad_y && grad_weight, "cnuda_conv2d_backward_weight: null pointer");
     ConvGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_backward_weight")) return rc;
-    if (smallc_supported(C, Cout, kh, kw, sh, sw) && !(g_conv_dbg & 64)) {
+    if (smallc_supported(C, Cout, kh, kw, sh, sw)) {
         hipStream_t st0 = (hipStream_t)stream;
         if (int rc = smallc_backward_weight(x, grad_y, grad_weight, B, C, H, W, Cout, kh, kw, sh, ph, pw, workspace,
                                             workspace_bytes, st0))

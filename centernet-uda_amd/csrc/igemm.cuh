@@ -96,7 +96,7 @@ __device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, cons
 template <int BM, class Loader>
 __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? 3 : 1)) void igemm_fwd_kernel(
     typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
-    int n_tiles, int m_tiles, int dbg = 0) {
+    int n_tiles, int m_tiles) {
     using T = IgTile<BM>;
     // two LDS stages: chunk k+1 is written while chunk k's fragments are still being read, one barrier per chunk
     __shared__ float As[2][IG_KC * BM];
@@ -131,10 +131,8 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? 3 : 1)) void igemm_fwd_ker
     };
     auto stage_load = [&](int k0) {
         ig_load_a<BM>(A, Mp, k0, m0, tid, ra);
-        if (!(dbg & 1)) {
 #pragma unroll
-            for (int h = 0; h < NH; ++h) ld.load(k0 + h * IG_BK, ksub, rb[h]);
-        }
+        for (int h = 0; h < NH; ++h) ld.load(k0 + h * IG_BK, ksub, rb[h]);
     };
     stage_load(0);
     stage_store(0);
@@ -142,7 +140,7 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? 3 : 1)) void igemm_fwd_ker
     __syncthreads();
     int cur = 0;
     for (int k0 = 0; k0 < Kp; k0 += IG_KC) {
-        if (!(dbg & 2)) ig_mma_chunk<BM>(As[cur], Bs[cur], acc, wm_off, wn_off, lane);
+        ig_mma_chunk<BM>(As[cur], Bs[cur], acc, wm_off, wn_off, lane);
         if (k0 + IG_KC < Kp) {
             stage_store(cur ^ 1);                      // chunk k+1 (its global loads were issued one chunk ago)
             if (k0 + 2 * IG_KC < Kp) stage_load(k0 + 2 * IG_KC);
