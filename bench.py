@@ -38,13 +38,13 @@ NUM_CLASSES = 6                     # configs/defaults.yaml:16
 MAX_OBJS = 150                      # max_detections
 
 
-def synthetic_batch(B, S, seed, device):
-    """Batch with the schema of datasets/coco.py:168-174,242-251."""
+def synthetic_batch(B, S, seed, device, rotated=False):
+    """Batch with the schema of datasets/coco.py:168-174,242-251 (rotated: :303-312,384-393) -- SURVEY 8d."""
     import inputs as gin
     H = W = S // 4
     rs = np.random.RandomState(seed)
     n_obj = tuple(int(rs.randint(1, 21)) for _ in range(B))
-    b = gin.detection_batch(B, NUM_CLASSES, H, W, MAX_OBJS, n_obj, 2, seed)
+    b = gin.detection_batch(B, NUM_CLASSES, H, W, MAX_OBJS, n_obj, 3 if rotated else 2, seed)
     data = {k: torch.from_numpy(v) for k, v in b.items()}
     g = torch.Generator().manual_seed(seed)
     data['input'] = torch.randn(B, 3, S, S, generator=g)
@@ -52,27 +52,45 @@ def synthetic_batch(B, S, seed, device):
     return {k: v.to(device) for k, v in data.items()}
 
 
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+UDA_WORKLOADS = {
+    # --uda      BASELINE.json config, plugin factory, rotated boxes, periodic angle loss, Adam weight decay
+    'none': ('configs[1]', lambda uda: uda.base.Model(), False, False, 0.0),
+    'entropy': ('configs[2]', lambda uda: uda.EntropyMinimization(1e-4), False, False, 1e-4),
+    'maxsq': ('configs[3]', lambda uda: uda.MaxSquaresMinimization(0.3), False, False, 1e-4),
+    'advent': ('configs[4]', lambda uda: uda.AdversarialEntropyMinimization(
+        1e-3, optimizer=_Cfg(name='Adam', params=_Cfg(lr=1e-4, weight_decay=0.0))), True, True, 1e-4),
+}
+
+
 def build_plugin(device, parallel, uda_name='entropy'):
     import uda
+    import uda.base
     from backends import dla
     from hip_runtime import optim
     from losses.centernet import DetectionLoss
+    _, factory, rotated, periodic, wd = UDA_WORKLOADS[uda_name]
     torch.manual_seed(42)                                   # defaults.yaml: seed 42
-    backend = dla.build(num_classes=NUM_CLASSES)
+    backend = dla.build(num_classes=NUM_CLASSES, rotated_boxes=rotated)
     # give the DCN offset/mask convs non-zero weights so that deformable sampling is exercised (Q7)
     with torch.no_grad():
         for n, p in backend.named_parameters():
             if 'conv_offset_mask.weight' in n:
                 p.normal_(0, 0.5 / (p.shape[1] * 9) ** 0.5)
-    plugin = uda.EntropyMinimization(1e-4) if uda_name == 'entropy' else uda.MaxSquaresMinimization(0.3)
+    plugin = factory(uda)
+    plugin.cfg = _Cfg(max_detections=MAX_OBJS,
+                      model=_Cfg(backend=_Cfg(params=_Cfg(rotated_boxes=rotated, num_classes=NUM_CLASSES))))
     plugin.backend = backend
     plugin.device = device
     plugin.centernet_loss = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0,
-                                          periodic=False)
-    plugin.to(device, parallel)
-    plugin.optimizer = optim.Adam([p for p in plugin.backend.parameters() if p.requires_grad],
-                                  lr=5e-5, weight_decay=1e-4)       # entropy_minimization.yaml
+                                          periodic=periodic)
+    # the optimizer is created before init_done()/to(): train.py:88-90,119-134
+    plugin.optimizer = optim.Adam([p for p in backend.parameters() if p.requires_grad], lr=5e-5, weight_decay=wd)
     plugin.init_done()
+    plugin.to(device, parallel)
     plugin.set_phase(True)
     return plugin
 
@@ -168,7 +186,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU source batch (and target batch)')
     ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--uda', default='entropy', choices=['entropy', 'maxsq'])
+    ap.add_argument('--uda', default='entropy', choices=sorted(UDA_WORKLOADS),
+                    help="BASELINE.json configs[1..4]: none / entropy (default, the headline) / maxsq / advent (use --size 640)")
     ap.add_argument('--profile-steps', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -187,7 +206,7 @@ def main():
         dist.init_process_group(backend='nccl', device_id=device)      # nccl == RCCL on ROCm
 
     plugin = build_plugin(device, parallel=world > 1, uda_name=args.uda)
-    batch = synthetic_batch(args.batch, args.size, 42 + rank, device)
+    batch = synthetic_batch(args.batch, args.size, 42 + rank, device, rotated=UDA_WORKLOADS[args.uda][2])
 
     def barrier():
         if world > 1:
@@ -258,16 +277,21 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
         # whole-step algorithmic work: 195.5 GFLOP per forwarded 512x512 image, 2 forwards per source image
-        step_tflop = 195.5e9 * (args.size / 512.0) ** 2 * 2 * args.batch / 1e12
+        step_tflop = 195.5e9 * (args.size / 512.0) ** 2 * (1 if args.uda == 'none' else 2) * args.batch / 1e12
         line = {
-            'metric': 'images/sec CenterNet DLA-34 512x512 UDA step (entropy minimisation)',
+            'metric': 'images/sec CenterNet DLA-34 512x512 UDA step (entropy minimisation)' if args.uda == 'entropy'
+            else 'images/sec CenterNet DLA-34 %dx%d train step (uda=%s)' % (args.size, args.size, args.uda),
             'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'configs[2]: DLA-34 + DCNv2, %dx%d, per-GPU batch %d source + %d target, '
-                                   'uda=%s_minimization, Adam(lr 5e-5, wd 1e-4), random-init weights'
-                                   % (args.size, args.size, args.batch, args.batch,
-                                      'entropy' if args.uda == 'entropy' else 'max_squares'),
+            'config': {'workload': '%s: DLA-34 + DCNv2%s, %dx%d, per-GPU batch %d source%s, uda=%s, '
+                                   'Adam(lr 5e-5), random-init weights'
+                                   % (UDA_WORKLOADS[args.uda][0], ' rotated-box head' if args.uda == 'advent' else '',
+                                      args.size, args.size, args.batch,
+                                      '' if args.uda == 'none' else ' + %d target' % args.batch,
+                                      {'none': 'none', 'entropy': 'entropy_minimization',
+                                       'maxsq': 'max_squares_minimization',
+                                       'advent': 'adversarial_entropy_minimization'}[args.uda]),
                        'global_batch': args.batch * world, 'input': [3, args.size, args.size],
                        'parallelism': 'dp%d' % world},
             'step_mfma_fraction': round(step_tflop / (ms * 1e-3) / PEAK_FP32_MFMA_TFLOPS, 4),
