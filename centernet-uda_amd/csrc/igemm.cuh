@@ -49,24 +49,44 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // row m of D tile element `reg` for this lane
 __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// One K chunk of MFMAs.  The operand fragments of k-step s+1 are read from LDS BEFORE the MFMAs of step s are
+// issued (explicit two-deep register pipeline): left to itself the compiler emits read -> s_waitcnt lgkmcnt(0) ->
+// MFMA per step, and the ~100-cycle LDS round trip then idles the matrix pipe between steps (measured with
+// SQ_VALU_MFMA_BUSY_CYCLES: 46 / 56 / 67 % busy for the 32 / 64 / 128-row tiles = 1 / 2 / 4 MFMAs per wait).
 template <int BM>
 __device__ __forceinline__ void ig_mma_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
                                              f32x16 (&acc)[IgTile<BM>::TM][IgTile<BM>::TN],
                                              int wm_off, int wn_off, int lane) {
     using T = IgTile<BM>;
     const int kl = lane >> 5, il = lane & 31;
+    const float* ap = As + kl * BM + wm_off + il;
+    const float* bp = Bs + kl * IG_BN + wn_off + il;
+    float a[2][T::TM], b[2][T::TN];
+    auto frag = [&](int kk, float (&fa)[T::TM], float (&fb)[T::TN]) {
 #pragma unroll
-    for (int kk = 0; kk < IG_KC; kk += 2) {
-        float a[T::TM], b[T::TN];
+        for (int i = 0; i < T::TM; ++i) fa[i] = ap[kk * BM + i * 32];
 #pragma unroll
-        for (int i = 0; i < T::TM; ++i) a[i] = As[(kk + kl) * BM + wm_off + i * 32 + il];
-#pragma unroll
-        for (int j = 0; j < T::TN; ++j) b[j] = Bs[(kk + kl) * IG_BN + wn_off + j * 32 + il];
+        for (int j = 0; j < T::TN; ++j) fb[j] = bp[kk * IG_BN + j * 32];
+    };
+    auto mma = [&](const float (&fa)[T::TM], const float (&fb)[T::TN]) {
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
 #pragma unroll
             for (int j = 0; j < T::TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    // sched_barrier(0): nothing is rescheduled across it, so the reads stay ahead of the MFMAs they overlap
+    frag(0, a[0], b[0]);
+#pragma unroll
+    for (int kk = 0; kk < IG_KC; kk += 4) {
+        frag(kk + 2, a[1], b[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a[0], b[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 4 < IG_KC) frag(kk + 4, a[0], b[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a[1], b[1]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -220,11 +240,28 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
     int cur = 0;
     const int kl = lane >> 5, il = lane & 31;
     for (long long nb = n_begin; nb < n_end; nb += WG_BP) {
+        {   // fragments of the next two k-steps are in flight while this pair's MFMAs run (see ig_mma_chunk)
+            const float* gp = Gs[cur] + kl * GLD + wm_off + il;
+            const float* bp = Bs[cur] + kl * BLD + wj_off + il;
+            float a[2][2], b[2][2];
+            a[0][0] = gp[0]; b[0][0] = bp[0]; a[0][1] = gp[2 * GLD]; b[0][1] = bp[2 * BLD];
 #pragma unroll
-        for (int kk = 0; kk < WG_BP; kk += 2) {
-            const float a = Gs[cur][(kk + kl) * GLD + wm_off + il];
-            const float b = Bs[cur][(kk + kl) * BLD + wj_off + il];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            for (int kk = 0; kk < WG_BP; kk += 8) {
+                a[1][0] = gp[(kk + 4) * GLD]; b[1][0] = bp[(kk + 4) * BLD];
+                a[1][1] = gp[(kk + 6) * GLD]; b[1][1] = bp[(kk + 6) * BLD];
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][0], b[0][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][1], b[0][1], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 8 < WG_BP) {
+                    a[0][0] = gp[(kk + 8) * GLD]; b[0][0] = bp[(kk + 8) * BLD];
+                    a[0][1] = gp[(kk + 10) * GLD]; b[0][1] = bp[(kk + 10) * BLD];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][0], b[1][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][1], b[1][1], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (nb + WG_BP < n_end) {
             stage_store(cur ^ 1);
