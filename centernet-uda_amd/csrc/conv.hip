@@ -326,7 +326,7 @@ ConvPlan make_plan(const ConvGeom& g) {
     q.Kf = q.T * g.C;   q.Kpf = round_up(q.Kf, IG_KC);  q.bmf = pick_bm(g.Co, q.Nf);  q.Mpf = round_up(g.Co, q.bmf);
     q.Kd = q.T * round_up(g.Co, IG_BK);  q.Kpd = round_up(q.Kd, IG_KC);  q.bmd = pick_bm(g.C, q.Nd);   q.Mpd = round_up(g.C, q.bmd);
     q.wbm = g.Co <= 32 ? 32 : 64;
-    q.wbj = g.Co <= 32 ? 128 : 64;
+    q.wbj = (g.Co <= 32 || (g.C % 64 == 0 && q.Kf % 128 == 0)) ? 128 : 64;   // 64 x 128: +8-13 % where nothing is padded
     q.Mpw = round_up(g.Co, q.wbm);
     q.Jp = round_up(q.Kf, q.wbj);
     const long long tiles = (long long)(q.Mpw / q.wbm) * (q.Jp / q.wbj);
@@ -474,7 +474,10 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
         const dim3 grid(q.Jp / q.wbj, q.Mpw / q.wbm, q.Z), blk(IG_THREADS);
         const bool fast = C % 64 == 0;
         if (q.wbm == 64) {
-            if (fast)
+            if (fast && q.wbj == 128)
+                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<2>, 64, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else if (fast)
                 hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<2>, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
                                    q.Nf, q.pix_per_split);
             else

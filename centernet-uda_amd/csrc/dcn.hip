@@ -857,8 +857,12 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
     {
         if (columns) {
             DcnColWParams p{g, columns, grad_output};
-            hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
-                               dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+            if (q.Jp % 128 == 0)
+                hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
+                                   dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+            else
+                hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+                                   dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
         } else {
             DcnWParams p{g, input, offset, mask, grad_output};
             hipLaunchKernelGGL((igemm_wgrad_kernel<DcnWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),

@@ -200,14 +200,16 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? 3 : 1)) void igemm_fwd_ker
 // ---------------------------------------------------------------------------
 constexpr int WG_BM = 64, WG_BJ = 64, WG_BP = 32;   // pixels per chunk (2 LDS stages of 32 instead of 1 of 64)
 
-// BM x BJ = 64 x 64 (waves 2 x 2) or 32 x 128 (waves 1 x 4, for layers with <= 32 output channels:
+// BM x BJ = 64 x 128 (waves 2 x 2, two accumulator tiles each: when the column count is a multiple of 128),
+// 64 x 64 (waves 2 x 2) or 32 x 128 (waves 1 x 4, for layers with <= 32 output channels:
 // the 16-channel stem / level-0 convs and the 27-channel DCN offset convs would waste 2-4x on a 64-row tile)
 template <class WLoader, int BM, int BJ>
 __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
     typename WLoader::Params p, float* __restrict__ slabs, int Mp, int Jp, long long N, long long pix_per_split) {
     constexpr int GLD = BM + 1, BLD = BJ + 1;          // odd row strides: conflict-free pixel-major stores
     constexpr int STEP = IG_THREADS / WG_BP;            // rows (channels / columns) covered per pass
-    constexpr int WJ = BJ / 32, NG = BM / STEP, NB = BJ / STEP;
+    constexpr int TJ = (BM / 32) * (BJ / 32) / 4;       // 32x32 accumulator tiles per wave, side by side along j
+    constexpr int WJ = BJ / 32 / TJ, NG = BM / STEP, NB = BJ / STEP;
     // two LDS stages, one barrier per pixel chunk (32 pixels): chunk k+1 is stored while chunk k is consumed
     __shared__ float Gs[2][WG_BP * GLD];
     __shared__ float Bs[2][WG_BP * BLD];
@@ -217,11 +219,13 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
     long long n_end = n_begin + pix_per_split;
     if (n_end > N) n_end = N;
     const int pl = tid % WG_BP, sub = tid / WG_BP;  // pixel within chunk, row phase (0..STEP-1)
-    const int wm_off = (wid / WJ) * 32, wj_off = (wid % WJ) * 32;
+    const int wm_off = (wid / WJ) * 32, wj_off = (wid % WJ) * 32 * TJ;
     WLoader ld(p, n_begin + pl, n_end);
-    f32x16 acc;
+    f32x16 acc[TJ];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int t = 0; t < TJ; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     float rg[NG], rb[NB];
     auto stage_store = [&](int buf) {
 #pragma unroll
@@ -243,23 +247,29 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
         {   // fragments of the next two k-steps are in flight while this pair's MFMAs run (see ig_mma_chunk)
             const float* gp = Gs[cur] + kl * GLD + wm_off + il;
             const float* bp = Bs[cur] + kl * BLD + wj_off + il;
-            float a[2][2], b[2][2];
-            a[0][0] = gp[0]; b[0][0] = bp[0]; a[0][1] = gp[2 * GLD]; b[0][1] = bp[2 * BLD];
+            float a[2][2], b[2][2][TJ];
+            auto frag = [&](int kk, float (&fa)[2], float (&fb)[2][TJ]) {
+                fa[0] = gp[kk * GLD]; fa[1] = gp[(kk + 2) * GLD];
+#pragma unroll
+                for (int t = 0; t < TJ; ++t) { fb[0][t] = bp[kk * BLD + t * 32]; fb[1][t] = bp[(kk + 2) * BLD + t * 32]; }
+            };
+            auto mma = [&](const float (&fa)[2], const float (&fb)[2][TJ]) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int t = 0; t < TJ; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h], fb[h][t], acc[t], 0, 0, 0);
+            };
+            frag(0, a[0], b[0]);
 #pragma unroll
             for (int kk = 0; kk < WG_BP; kk += 8) {
-                a[1][0] = gp[(kk + 4) * GLD]; b[1][0] = bp[(kk + 4) * BLD];
-                a[1][1] = gp[(kk + 6) * GLD]; b[1][1] = bp[(kk + 6) * BLD];
+                frag(kk + 4, a[1], b[1]);
                 __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][0], b[0][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][1], b[0][1], acc, 0, 0, 0);
+                mma(a[0], b[0]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk + 8 < WG_BP) {
-                    a[0][0] = gp[(kk + 8) * GLD]; b[0][0] = bp[(kk + 8) * BLD];
-                    a[0][1] = gp[(kk + 10) * GLD]; b[0][1] = bp[(kk + 10) * BLD];
-                }
+                if (kk + 8 < WG_BP) frag(kk + 8, a[0], b[0]);
                 __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][0], b[1][0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][1], b[1][1], acc, 0, 0, 0);
+                mma(a[1], b[1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -272,11 +282,13 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
     }
     float* slab = slabs + (size_t)blockIdx.z * Mp * Jp;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm_off + mfma_row(r, lane);
-        const int j = j0 + wj_off + (lane & 31);
-        slab[(size_t)m * Jp + j] = acc[r];
-    }
+    for (int t = 0; t < TJ; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm_off + mfma_row(r, lane);
+            const int j = j0 + wj_off + t * 32 + (lane & 31);
+            slab[(size_t)m * Jp + j] = acc[t][r];
+        }
 }
 
 }  // namespace cnuda

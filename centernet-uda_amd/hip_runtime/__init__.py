@@ -197,8 +197,9 @@ def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
         if _smallc(C, Co, kh, kw, stride):
             name = 'smallc_wgrad_kernel<%d>' % ((Co + 15) // 16)
         else:
-            name = 'igemm_wgrad_kernel<ConvWLoader<%d>, %s>' % (2 if C % 64 == 0 else 0,
-                                                                '32, 128' if Co <= 32 else '64, 64')
+            wide = Co <= 32 or (C % 64 == 0 and (C * kh * kw) % 128 == 0)
+            name = 'igemm_wgrad_kernel<ConvWLoader<%d>, %d, %d>' % (2 if C % 64 == 0 else 0, 32 if Co <= 32 else 64,
+                                                                    128 if wide else 64)
     elif kind == 'dcn_fwd':
         name = 'igemm_fwd_kernel<%d, DcnFwdLoader>' % _bm(Co, B * Ho * Wo)
     elif kind == 'dcn_bwd':
