@@ -56,8 +56,8 @@ class Adam(torch.optim.Optimizer):
         return loss
 
     def load_state_dict(self, state_dict):
+        a = self._ensure()            # before the base class fills self.state: _ensure() rebinds every entry
         super().load_state_dict(state_dict)
-        a = self._ensure()
         steps = [int(s['step']) for s in self.state.values() if 'step' in s]
         self._step = max(steps) if steps else 0
         for p, o in zip(a.params, a.offsets):
