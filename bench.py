@@ -179,6 +179,32 @@ def decode_latency(device, with_cpu=True):
     return res
 
 
+def inference_throughput(device, backend, size, batch):
+    """the export.CenterNet wrapper (eval forward -> clamped sigmoid -> decode -> x down_ratio) on the
+    trained backend of this run; images/s and latency per batch with inputs resident in HBM."""
+    from export import CenterNet
+    was_training = backend.training
+    model = CenterNet(backend, MAX_OBJS).eval()
+    x = torch.randn(batch, 3, size, size, device=device)
+    for _ in range(3):
+        model(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 10
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        model(x)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    backend.train(was_training)
+    # forward only: 65.58 GFLOP per 512x512 image (SURVEY 8d)
+    tf = 65.58e9 * (size / 512.0) ** 2 * batch / (ms * 1e-3) / 1e12
+    return {'images_per_s': round(batch / (ms * 1e-3), 1), 'ms_per_batch': round(ms, 3), 'batch': batch,
+            'mfma_fraction': round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+            'what': 'export.CenterNet: eval forward + decode (K=%d), fp32, BatchNorm not folded' % MAX_OBJS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -298,6 +324,8 @@ def main():
             'losses': {k: round(v, 5) for k, v in stats.items()},
             'roofline': roofline,
             'decode_latency': decode_latency(device, with_cpu=not args.no_cpu_baseline) if world == 1 else None,
+            'inference': inference_throughput(device, getattr(plugin.backend, 'module', plugin.backend), args.size,
+                                              args.batch) if world == 1 else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()

@@ -1,0 +1,60 @@
+"""MI355X: the inference wrapper (export.py:19-56) -- eval forward, clamped sigmoid, decode, down_ratio scaling,
+output split -- against the oracle's decode applied to the same head tensors."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+import inputs as gin
+from oracle import decode as oracle_decode
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize('rotated', [False, True])
+def test_centernet_wrapper_matches_oracle_decode(golden, rotated):
+    from backends import dla
+    from export import CenterNet
+    g = golden('dla_rot' if rotated else 'dla_axis')
+    shapes = dict(ast.literal_eval(str(g['shapes_json'])))
+    backend = dla.build(num_classes=6, rotated_boxes=rotated)
+    backend.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes).items()})
+    backend = backend.to(DEV).eval()
+    x = T(gin.image_batch(2, 96, 96, 91)).to(DEV)
+    K = 20
+    model = CenterNet(backend, K, is_rotated=rotated)
+    boxes, scores, classes = model(x)
+    assert boxes.shape == (2, K, 5 if rotated else 4) and scores.shape == (2, K) and classes.shape == (2, K)
+    assert not boxes.requires_grad
+    with torch.no_grad():
+        out = backend(x)
+    hm = np.clip(1.0 / (1.0 + np.exp(-out['hm'].double().cpu().numpy())), 1e-4, 1 - 1e-4).astype(np.float32)
+    want = oracle_decode.decode_detection(hm, out['wh'].cpu().numpy(), out['reg'].cpu().numpy(), K=K, rotated=rotated)
+    want[:, :, :4] *= backend.down_ratio
+    nb = 5 if rotated else 4
+    # scores come from float32 sigmoids on both sides: equal to 1 ulp; a swap of two detections would show up as
+    # a class / box mismatch far above the tolerance
+    np.testing.assert_allclose(scores.cpu().numpy(), want[:, :, nb], rtol=0, atol=2e-7)
+    np.testing.assert_array_equal(classes.cpu().numpy(), want[:, :, nb + 1])
+    np.testing.assert_allclose(boxes.cpu().numpy(), want[:, :, :nb], rtol=1e-6, atol=1e-4)
+
+
+def test_build_model_reads_the_experiment_folder(tmp_path):
+    from export import CenterNet, build_model
+    from utils.helper import save_model
+    from backends import resnet
+    src = resnet.build(18, num_classes=3, pretrained=False)
+    with torch.no_grad():
+        src.hm[2].bias.fill_(-1.5)
+    save_model(src, tmp_path / 'model_last.pth', epoch=4)
+    spec = {'name': 'resnet', 'params': {'num_layers': 18, 'num_classes': 3, 'pretrained': False, 'rotated_boxes': False}}
+    model = build_model(tmp_path, spec, without_decode_detections=False, max_detections=10)
+    assert isinstance(model, CenterNet) and model.max_detections == 10 and model.is_rotated is False
+    assert torch.all(model.backend.hm[2].bias == -1.5)
+    boxes, scores, classes = model.to(DEV).eval()(torch.randn(1, 3, 64, 64, device=DEV))
+    assert boxes.shape == (1, 10, 4) and torch.all(scores[:, :-1] >= scores[:, 1:])
+    backend = build_model(tmp_path / 'missing', spec, without_decode_detections=True, max_detections=10)
+    assert isinstance(backend, resnet.CenterResNet)
