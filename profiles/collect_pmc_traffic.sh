@@ -15,7 +15,7 @@ for C in ('FETCH_SIZE','WRITE_SIZE'):
         n=r['Kernel_Name'].replace('cnuda::(anonymous namespace)::','').replace('cnuda::','').split('(')[0].replace('void ','')
         agg[n][0]+=float(r['Counter_Value']); agg[n][1]+=1
     res[C]=agg
-names=sorted(res['FETCH_SIZE'], key=lambda n:-res['FETCH_SIZE'][n][0])[:14]
+names=sorted(res['FETCH_SIZE'], key=lambda n:-res['FETCH_SIZE'][n][0])[:40]
 out={}
 for n in names:
     f,c=res['FETCH_SIZE'][n]; w,c2=res['WRITE_SIZE'].get(n,[0,1])
