@@ -254,22 +254,42 @@ __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* 
     const int M = count;
     if (M >= K && M <= kPool) {
         // every key outside the pool has score <= 0 < the pool's: the top K are the head of the sorted pool
-        int P = 2;
-        while (P < M) P <<= 1;
-        for (int i = M + tid; i < P; i += kPlaneThreads) pool[i] = 0;
+        for (int i = M + tid; i < kPool; i += kPlaneThreads) pool[i] = 0;
         __syncthreads();
-        for (int size = 2; size <= P; size <<= 1) {
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int t = tid; t < (P >> 1); t += kPlaneThreads) {
-                    const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));     // strides are powers of two
-                    const int hi = lo + stride;
-                    const bool desc = ((lo & size) == 0);
-                    const uint64_t a = pool[lo], b = pool[hi];
-                    if ((a < b) == desc) { pool[lo] = b; pool[hi] = a; }
-                }
+        // Bitonic sort (descending) of the 2048-key pool, two keys per thread in registers (positions 2t, 2t+1):
+        // stride 1 is a compare inside the thread, strides 2..64 exchange with lane t ^ (stride/2) by shuffle, only
+        // strides >= 128 cross waves and go through LDS -- 10 of the 66 stages need workgroup barriers.
+        static_assert(kPool == 2 * kPlaneThreads, "two keys per thread");
+        uint64_t k0 = pool[2 * tid], k1 = pool[2 * tid + 1];
+        const int p0 = 2 * tid;
+        for (int size = 2; size <= kPool; size <<= 1) {
+            const bool desc = (p0 & size) == 0;            // same for both keys of the thread (size >= 2)
+            for (int stride = size >> 1; stride >= 128; stride >>= 1) {
+                __syncthreads();                           // previous readers of the pool are done
+                pool[p0] = k0; pool[p0 + 1] = k1;
                 __syncthreads();
+                const uint64_t o0 = pool[p0 ^ stride], o1 = pool[(p0 + 1) ^ stride];
+                const bool lower = (p0 & stride) == 0;
+                const bool take_max = lower == desc;
+                k0 = take_max ? (k0 > o0 ? k0 : o0) : (k0 < o0 ? k0 : o0);
+                k1 = take_max ? (k1 > o1 ? k1 : o1) : (k1 < o1 ? k1 : o1);
+            }
+            for (int stride = size >> 1 < 64 ? size >> 1 : 64; stride >= 2; stride >>= 1) {
+                const uint64_t o0 = __shfl_xor(k0, stride >> 1, 64), o1 = __shfl_xor(k1, stride >> 1, 64);
+                const bool lower = (p0 & stride) == 0;
+                const bool take_max = lower == desc;
+                k0 = take_max ? (k0 > o0 ? k0 : o0) : (k0 < o0 ? k0 : o0);
+                k1 = take_max ? (k1 > o1 ? k1 : o1) : (k1 < o1 ? k1 : o1);
+            }
+            {   // stride 1: the thread's own pair
+                const uint64_t hi = k0 > k1 ? k0 : k1, lo = k0 > k1 ? k1 : k0;
+                k0 = desc ? hi : lo;
+                k1 = desc ? lo : hi;
             }
         }
+        __syncthreads();
+        pool[p0] = k0; pool[p0 + 1] = k1;
+        __syncthreads();
         for (int i = tid; i < K; i += kPlaneThreads) dst[i] = pool[i];
         return;
     }
