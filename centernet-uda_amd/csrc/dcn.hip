@@ -212,6 +212,86 @@ struct DcnFwdLoader {
 };
 
 // ---------------------------------------------------------------------------
+// forward, two-kernel form for layers whose output channels span several M tiles (small feature maps run
+// 32- or 64-row tiles to fill the chip): the fused loader would re-sample the columns once per M tile, so the
+// columns are sampled ONCE by a streaming kernel (they are the weight gradient's side output anyway) and a
+// plain implicit GEMM reads them back.
+// ---------------------------------------------------------------------------
+struct DcnSampleParams {
+    DcnGeom g;
+    const float *in, *off, *mask;
+    float* col;     // [B][T*C][Ho*Wo]
+};
+// block = (64 pixels, TW tap slots); one thread per (pixel, tap), channels serial in batches of 8
+__global__ __launch_bounds__(1024) void dcn_sample_kernel(DcnSampleParams p, int tiles_per_image) {
+    const DcnGeom& g = p.g;
+    const int T = g.kh * g.kw, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
+    const int b = blockIdx.x / tiles_per_image, tile = blockIdx.x - b * tiles_per_image;
+    const int px = tile * 64 + threadIdx.x;
+    if (px >= HoWo) return;
+    const int oy = px / g.Wo, ox = px - oy * g.Wo;
+    const float* in_b = p.in + (size_t)b * g.C * HW;
+    for (int tap = threadIdx.y; tap < T; tap += blockDim.y) {
+        const Tap t = make_tap(g, p.off + (size_t)b * 2 * T * HoWo, p.mask + (size_t)b * T * HoWo, 0, tap, oy, ox);
+        const float mk = t.inside ? t.mask : 0.0f;
+        const float w00 = t.c00 ? t.hh * t.hw * mk : 0.0f, w01 = t.c01 ? t.hh * t.lw * mk : 0.0f;
+        const float w10 = t.c10 ? t.lh * t.hw * mk : 0.0f, w11 = t.c11 ? t.lh * t.lw * mk : 0.0f;
+        float* dst = p.col + ((size_t)b * T + tap) * g.C * HoWo + px;
+        for (int c0 = 0; c0 < g.C; c0 += 8) {
+            float e00[8], e01[8], e10[8], e11[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float* plane = in_b + (size_t)(c0 + u < g.C ? c0 + u : g.C - 1) * HW;
+                e00[u] = plane[t.o00]; e01[u] = plane[t.o01]; e10[u] = plane[t.o10]; e11[u] = plane[t.o11];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < g.C)
+                    dst[(size_t)(c0 + u) * HoWo] = w00 * e00[u] + w01 * e01[u] + w10 * e10[u] + w11 * e11[u];
+        }
+    }
+}
+
+struct DcnColsParams {
+    DcnGeom g;
+    const float *col, *bias;
+    float* out;
+};
+struct DcnColsLoader {
+    using Params = DcnColsParams;
+    static constexpr bool kHasSideOutput = false;
+    const float* base;
+    int K, HoWo;
+    bool valid;
+    __device__ DcnColsLoader(const Params& p, long long n, bool n_valid) : valid(n_valid) {
+        HoWo = p.g.Ho * p.g.Wo;
+        K = p.g.kh * p.g.kw * p.g.C;
+        const int nn = n_valid ? (int)n : 0;
+        const int b = nn / HoWo, pp = nn - b * HoWo;
+        base = p.col + (size_t)b * K * HoWo + pp;
+    }
+    __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + ksub + 2 * j;
+            v[j] = (valid && k < K) ? base[(size_t)k * HoWo] : 0.0f;
+        }
+    }
+    struct Out {
+        float* base;
+        int HoWo;
+        __device__ Out(const Params& p, long long n) {
+            HoWo = p.g.Ho * p.g.Wo;
+            const int ni = (int)n, b = ni / HoWo, pp = ni - b * HoWo;
+            base = p.out + (size_t)b * p.g.Co * HoWo + pp;
+        }
+        __device__ __forceinline__ void store(const Params& p, int m, float v) {
+            base[(size_t)m * HoWo] = v + p.bias[m];
+        }
+    };
+};
+
+// ---------------------------------------------------------------------------
 // backward (1): the column gradient dcol[b][(tap,c)][p] is produced by a plain
 // 1x1 implicit GEMM over grad_output (weights transposed by dcn_wt_kernel) and consumed by
 // two HBM-streaming kernels that need no MFMA, no workgroup barriers and few registers:
@@ -672,6 +752,7 @@ struct DcnPlan {
     int Mpw, Jp, Z;                 // wgrad slabs [Z][Mpw][Jp]
     long long N, pix_per_split;
     size_t fwd_bytes, bwd_bytes;
+    bool fwd_two_kernels;           // several M tiles: sample the columns once, then a plain GEMM
     // split backward: 1x1 GEMM workspace, transposed weights, dcol, geometry records; col2im tiling
     size_t gemm_bytes;
     int TR, TC, tc_shift, tiles_y, tiles_x, ncg, WSZmax, claim_sz;
@@ -696,7 +777,9 @@ DcnPlan make_plan(const DcnGeom& g) {
     if (z < 1) z = 1;
     q.pix_per_split = ((q.N + z - 1) / z + WG_BP - 1) / WG_BP * WG_BP;
     q.Z = (int)((q.N + q.pix_per_split - 1) / q.pix_per_split);
-    q.fwd_bytes = carve_bytes((size_t)q.Kp * q.Mp, 4) + 256;
+    q.fwd_two_kernels = q.Mp / q.bm > 1;
+    q.fwd_bytes = carve_bytes((size_t)q.Kp * q.Mp, 4) + 256 +
+                  (q.fwd_two_kernels ? carve_bytes((size_t)g.B * q.K * g.Ho * g.Wo, 4) : 0);
     q.gemm_bytes = cnuda_conv2d_workspace_bytes(g.B, g.Co, g.Ho, g.Wo, q.T * g.C, 1, 1, 1, 1, 0, 0);
     q.bwd_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) +
                   carve_bytes((size_t)g.Co * g.B, 4) + carve_bytes((size_t)q.T * g.C * g.Co, 4) +
@@ -764,9 +847,29 @@ extern "C" int cnuda_dcn_v2_forward_cols(const float* input, const float* weight
     Carver cv(workspace, workspace_bytes);
     float* A = cv.take<float>((size_t)q.Kp * q.Mp);
     launch_pack(weight, A, Cout, C, q.T, PACK_FWD, q.Kp, q.Mp, 0, st);
-    DcnFwdParams p{g, input, offset, mask, bias, output, columns};
     const int n_tiles = ceil_div(q.N, IG_BN), m_tiles = q.Mp / q.bm;
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
+    if (q.fwd_two_kernels) {
+        float* cols = columns ? columns : cv.take<float>((size_t)B * q.K * g.Ho * g.Wo);
+        ProfScope prof(st);   // brackets both kernels
+        {
+            DcnSampleParams sp{g, input, offset, mask, cols};
+            const int tiles = ceil_div(g.Ho * g.Wo, 64), tw = q.T < 16 ? q.T : 16;
+            hipLaunchKernelGGL(dcn_sample_kernel, dim3(B * tiles), dim3(64, tw), 0, st, sp, tiles);
+        }
+        DcnColsParams p{g, cols, bias, output};
+        if (q.bm == 128)
+            hipLaunchKernelGGL((igemm_fwd_kernel<128, DcnColsLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+                               n_tiles, m_tiles);
+        else if (q.bm == 64)
+            hipLaunchKernelGGL((igemm_fwd_kernel<64, DcnColsLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+                               n_tiles, m_tiles);
+        else
+            hipLaunchKernelGGL((igemm_fwd_kernel<32, DcnColsLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+                               n_tiles, m_tiles);
+        return check_launch("cnuda_dcn_v2_forward(columns + GEMM)");
+    }
+    DcnFwdParams p{g, input, offset, mask, bias, output, columns};
     ProfScope prof(st);
     if (q.bm == 128)
         hipLaunchKernelGGL((igemm_fwd_kernel<128, DcnFwdLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,

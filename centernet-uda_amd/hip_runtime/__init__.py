@@ -201,7 +201,9 @@ def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
             name = 'igemm_wgrad_kernel<ConvWLoader<%d>, %d, %d>' % (2 if C % 64 == 0 else 0, 32 if Co <= 32 else 64,
                                                                     128 if wide else 64)
     elif kind == 'dcn_fwd':
-        name = 'igemm_fwd_kernel<%d, DcnFwdLoader>' % _bm(Co, B * Ho * Wo)
+        bm = _bm(Co, B * Ho * Wo)
+        name = ('dcn_sample_kernel + igemm_fwd_kernel<%d, DcnColsLoader>' if Co > bm else
+                'igemm_fwd_kernel<%d, DcnFwdLoader>') % bm
     elif kind == 'dcn_bwd':
         # three kernels, timed separately (ProfGroup in csrc/dcn.hip): the column-gradient GEMM (a 1x1
         # convolution over grad_output with 9*C output channels: all of the entry point's MFMA work), then
