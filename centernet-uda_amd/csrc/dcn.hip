@@ -334,29 +334,61 @@ __global__ __launch_bounds__(1024) void dcn_coord_grad_kernel(DcnCoordParams p, 
         const Tap t = make_tap(g, p.off + (size_t)b * 2 * T * HoWo, p.mask + (size_t)b * T * HoWo, 0, tap, oy, ox);
         const float* dc = p.dcol + ((size_t)b * T + tap) * g.C * HoWo + px;
         float sm = 0.f, sh_ = 0.f, sw_ = 0.f;
-        if (t.inside) {
-            // corners that do not exist read cell 0 and are zeroed afterwards: loads stay unconditional and are
-            // issued eight channels at a time before anything is consumed
+        if (t.inside && g.W >= 2) {
+            // The two corners of a row are ONE 8-byte load starting at column clamp(w0, 0, W-2) (halves the L1/TA
+            // requests, which bound this kernel); s*l / s*r say which element of the pair each corner is -- at the
+            // left edge the existing right corner is the pair's left element, at the right edge the existing left
+            // corner is its right element.  The three sums are linear in the corners, so the per-tap coefficients
+            // of (top.l, top.r, bottom.l, bottom.r) are folded once per tap.
+            struct __attribute__((packed, aligned(4))) Pair { float l, r; };
+            const bool ledge = t.w0 < 0, redge = t.w0 > g.W - 2;
+            const int wa = ledge ? 0 : (redge ? g.W - 2 : t.w0);
+            const int ht = t.h0 < 0 ? 0 : t.h0, hb = t.h0 + 1 > g.H - 1 ? g.H - 1 : t.h0 + 1;
+            const int qT = ht * g.W + wa, qB = hb * g.W + wa;
+            // corner value e_xy = pair.l * L + pair.r * R with (L, R) in {(1,0), (0,1), (0,0)}
+            const float l0 = (!ledge && !redge) ? 1.f : 0.f, r0 = redge ? 1.f : 0.f;     // left corner  (column w0)
+            const float l1 = ledge ? 1.f : 0.f, r1 = (!ledge && !redge) ? 1.f : 0.f;     // right corner (column w0+1)
             const float f00 = t.c00 ? 1.f : 0.f, f01 = t.c01 ? 1.f : 0.f, f10 = t.c10 ? 1.f : 0.f,
                         f11 = t.c11 ? 1.f : 0.f;
+            // coefficient of e00, e01, e10, e11 in: sample (A), d/dh (Bh), d/dw (Bw)
+            const float A00 = t.hh * t.hw * f00, A01 = t.hh * t.lw * f01, A10 = t.lh * t.hw * f10, A11 = t.lh * t.lw * f11;
+            const float H00 = -t.hw * f00, H01 = -t.lw * f01, H10 = t.hw * f10, H11 = t.lw * f11;
+            const float W00 = -t.hh * f00, W01 = t.hh * f01, W10 = -t.lh * f10, W11 = t.lh * f11;
+            const float aTl = A00 * l0 + A01 * l1, aTr = A00 * r0 + A01 * r1, aBl = A10 * l0 + A11 * l1, aBr = A10 * r0 + A11 * r1;
+            const float hTl = H00 * l0 + H01 * l1, hTr = H00 * r0 + H01 * r1, hBl = H10 * l0 + H11 * l1, hBr = H10 * r0 + H11 * r1;
+            const float wTl = W00 * l0 + W01 * l1, wTr = W00 * r0 + W01 * r1, wBl = W10 * l0 + W11 * l1, wBr = W10 * r0 + W11 * r1;
             for (int c0 = 0; c0 < g.C; c0 += 8) {
-                float d[8], e00[8], e01[8], e10[8], e11[8];
+                float d[8];
+                Pair pt[8], pb[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int c = c0 + u < g.C ? c0 + u : g.C - 1;
                     const float* plane = in_b + (size_t)c * HW;
                     d[u] = dc[(size_t)c * HoWo];
-                    e00[u] = plane[t.o00]; e01[u] = plane[t.o01]; e10[u] = plane[t.o10]; e11[u] = plane[t.o11];
+                    pt[u] = *reinterpret_cast<const Pair*>(plane + qT);
+                    pb[u] = *reinterpret_cast<const Pair*>(plane + qB);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const float dd = c0 + u < g.C ? d[u] : 0.f;
-                    const float a00 = e00[u] * f00, a01 = e01[u] * f01, a10 = e10[u] * f10, a11 = e11[u] * f11;
-                    sm += dd * tap_sample(t, a00, a01, a10, a11);
+                    sm += dd * (aTl * pt[u].l + aTr * pt[u].r + aBl * pb[u].l + aBr * pb[u].r);
                     const float dm = dd * t.mask;
-                    sh_ += (-t.hw * a00 - t.lw * a01 + t.hw * a10 + t.lw * a11) * dm;
-                    sw_ += (-t.hh * a00 + t.hh * a01 - t.lh * a10 + t.lh * a11) * dm;
+                    sh_ += (hTl * pt[u].l + hTr * pt[u].r + hBl * pb[u].l + hBr * pb[u].r) * dm;
+                    sw_ += (wTl * pt[u].l + wTr * pt[u].r + wBl * pb[u].l + wBr * pb[u].r) * dm;
                 }
+            }
+        } else if (t.inside) {     // width 1: no horizontal neighbour to pair with
+            const float f00 = t.c00 ? 1.f : 0.f, f01 = t.c01 ? 1.f : 0.f, f10 = t.c10 ? 1.f : 0.f,
+                        f11 = t.c11 ? 1.f : 0.f;
+            for (int c = 0; c < g.C; ++c) {
+                const float* plane = in_b + (size_t)c * HW;
+                const float dd = dc[(size_t)c * HoWo];
+                const float a00 = plane[t.o00] * f00, a01 = plane[t.o01] * f01, a10 = plane[t.o10] * f10,
+                            a11 = plane[t.o11] * f11;
+                sm += dd * tap_sample(t, a00, a01, a10, a11);
+                const float dm = dd * t.mask;
+                sh_ += (-t.hw * a00 - t.lw * a01 + t.hw * a10 + t.lw * a11) * dm;
+                sw_ += (-t.hh * a00 + t.hh * a01 - t.lh * a10 + t.lh * a11) * dm;
             }
         }
         p.gmask[((size_t)b * T + tap) * HoWo + px] = sm;
