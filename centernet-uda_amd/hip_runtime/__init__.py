@@ -100,6 +100,7 @@ class _Sig:
     cnuda_bce_const_backward = (_I, [_P, _F, _P, _P, _LL, _P])
     cnuda_sigmoid_clamp_ = (_I, [_P, _P, _LL, _P])
     cnuda_gather_feat = (_I, [_P] * 3 + [_I, _I, _I, _LL, _P])
+    cnuda_encode_targets = (_I, [_P] * 10 + [_I] * 5 + [_P])
     cnuda_adam_step = (_I, [_P] * 4 + [_LL] + [_F] * 5 + [_I, _P])
     cnuda_prof_enable = (_I, [_I])
     cnuda_prof_arm = (_I, [_I])

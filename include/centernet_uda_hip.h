@@ -252,6 +252,20 @@ int cnuda_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     cnuda_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Target encoding for a batch (the step right before the hot path):
+ * datasets/coco.py:191-221 (per-object loop: clip, gaussian radius, centre, ind / wh / reg / reg_mask /
+ * gt_dets / gt_areas) and utils/image.py:8-57 (gaussian_radius, draw_umich_gaussian), all images in one launch.
+ *   boxes [B,M,4] double (x1,y1,x2,y2 in output-map pixels, after augmentation / clip_out_of_image),
+ *   classes [B,M] int32, counts [B] int32 (objects per image, <= M).  Every output is fully overwritten
+ *   (zeros where the reference leaves np.zeros): hm [B,C,H,W] f32, reg_mask [B,M] u8, ind [B,M] i64,
+ *   wh / reg [B,M,2] f32, gt_dets [B,M,6] f32, gt_areas [B,M] f32 (= w*h: annotations without "area").
+ * ---------------------------------------------------------------------- */
+int cnuda_encode_targets(const double* boxes, const int* classes, const int* counts,
+                         float* hm, unsigned char* reg_mask, long long* ind, float* wh, float* reg,
+                         float* gt_dets, float* gt_areas,
+                         int B, int C, int H, int W, int M, cnuda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,3 +152,26 @@ def fill_state(shapes):
 def image_batch(B, H, W, seed):
     rs = np.random.RandomState(seed)
     return rs.standard_normal((B, 3, H, W)).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# target encoding: boxes at output resolution, some degenerate / out of range on purpose
+# ---------------------------------------------------------------------------
+TARGET_CASES = {
+    # name: (num_classes, H, W, max_detections, n_boxes, seed)
+    'cfg3': (6, 128, 128, 150, 20, 301),
+    'wide': (3, 40, 160, 32, 32, 302),            # more boxes than slots are never passed: n <= M
+    'tiny': (2, 8, 8, 6, 6, 303),
+}
+
+
+def target_boxes(name):
+    C, H, W, M, n, seed = TARGET_CASES[name]
+    rs = np.random.RandomState(seed)
+    cx, cy = rs.uniform(-4, W + 4, n), rs.uniform(-4, H + 4, n)
+    bw, bh = rs.uniform(0.5, 0.6 * W, n), rs.uniform(0.5, 0.6 * H, n)
+    boxes = np.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1)
+    boxes[1] = [W + 3.0, 2.0, W + 9.0, 5.0]        # completely outside: clipped to zero width -> skipped
+    boxes[2, 2] = boxes[2, 0]                      # zero width
+    classes = rs.randint(0, C, n).astype(np.int32)
+    return boxes.astype(np.float64), classes

@@ -477,13 +477,56 @@ def make_resnet():
     save('resnet18_step', **out)
 
 
+# ---------------------------------------------------------------------------
+def make_targets():
+    """datasets/coco.py:191-221 re-enacted with the reference's own utils/image.py functions (the dataset class
+    itself needs pycocotools / imgaug / cv2; utils/image.py is imported with empty stand-ins for its unused
+    cv2 / imgaug imports, see _load_entropy_map)."""
+    _load_entropy_map()
+    import importlib
+    img = importlib.import_module('utils.image')
+    out = {}
+    for name, (C, H, W, M, n, seed) in gin.TARGET_CASES.items():
+        boxes, classes = gin.target_boxes(name)
+        hm = np.zeros((C, H, W), dtype=np.float32)
+        wh = np.zeros((M, 2), dtype=np.float32)
+        reg = np.zeros((M, 2), dtype=np.float32)
+        ind = np.zeros((M), dtype=np.int64)
+        reg_mask = np.zeros((M), dtype=np.uint8)
+        gt_det = np.zeros((M, 6), dtype=np.float32)
+        gt_areas = np.zeros((M), dtype=np.float32)
+        for k in range(n):
+            bbox = np.array(boxes[k])
+            cls_id = int(classes[k])
+            bbox[[0, 2]] = np.clip(bbox[[0, 2]], 0, W - 1)
+            bbox[[1, 3]] = np.clip(bbox[[1, 3]], 0, H - 1)
+            h, w = bbox[3] - bbox[1], bbox[2] - bbox[0]
+            if h > 0 and w > 0:
+                radius = img.gaussian_radius((np.ceil(h), np.ceil(w)))
+                radius = max(0, int(radius))
+                ct = np.array([(bbox[0] + bbox[2]) / 2, (bbox[1] + bbox[3]) / 2], dtype=np.float32)
+                ct_int = ct.astype(np.int32)
+                img.draw_umich_gaussian(hm[cls_id], ct_int, radius)
+                wh[k] = 1. * w, 1. * h
+                ind[k] = ct_int[1] * W + ct_int[0]
+                reg[k] = ct - ct_int
+                reg_mask[k] = 1
+                gt_det[k] = ([ct[0] - w / 2, ct[1] - h / 2, ct[0] + w / 2, ct[1] + h / 2, 1, cls_id])
+                gt_areas[k] = w * h
+        for key, v in dict(hm=hm, wh=wh, reg=reg, ind=ind, reg_mask=reg_mask, gt_dets=gt_det, gt_areas=gt_areas).items():
+            out['%s__%s' % (name, key)] = v
+    save('targets', **out)
+
+
 if __name__ == '__main__':
     oracle_dcn.build()
-    which = set(sys.argv[1:]) or {'decode', 'losses', 'dla', 'step', 'advent', 'resnet'}
+    which = set(sys.argv[1:]) or {'decode', 'losses', 'dla', 'step', 'advent', 'resnet', 'targets'}
     if 'decode' in which:
         make_decode()
     if 'resnet' in which:
         make_resnet()
+    if 'targets' in which:
+        make_targets()
     if 'losses' in which or 'advent' in which:
         _load_entropy_map()
     if 'losses' in which:
