@@ -216,6 +216,7 @@ def main():
                     help="BASELINE.json configs[1..4]: none / entropy (default, the headline) / maxsq / advent (use --size 640)")
     ap.add_argument('--profile-steps', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the decode-latency and inference legs (profiling runs)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -323,9 +324,10 @@ def main():
             'step_mfma_fraction': round(step_tflop / (ms * 1e-3) / PEAK_FP32_MFMA_TFLOPS, 4),
             'losses': {k: round(v, 5) for k, v in stats.items()},
             'roofline': roofline,
-            'decode_latency': decode_latency(device, with_cpu=not args.no_cpu_baseline) if world == 1 else None,
+            'decode_latency': decode_latency(device, with_cpu=not args.no_cpu_baseline)
+            if world == 1 and not args.no_extras else None,
             'inference': inference_throughput(device, getattr(plugin.backend, 'module', plugin.backend), args.size,
-                                              args.batch) if world == 1 else None,
+                                              args.batch) if world == 1 and not args.no_extras else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()

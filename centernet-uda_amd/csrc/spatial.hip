@@ -145,6 +145,44 @@ __global__ __launch_bounds__(kT) void dwconvt_fwd_kernel(const float* __restrict
     }
     y[(size_t)pl * Ho * Wo + o] = acc;
 }
+// k = 2f, s = f, p = f/2 (IDAUp.up, dla.py:385-388) with compile-time f: every output pixel has exactly 2 x 2 taps and
+// all index arithmetic is shifts; one thread produces four consecutive outputs of a row (Wo % 4 == 0)
+template <int F>
+__global__ __launch_bounds__(kT) void dwconvt_fwd_f_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ y, int C, int H, int W) {
+    constexpr int K = 2 * F, P = F / 2;
+    __shared__ float ws[K * K];
+    const int pl = blockIdx.y, c = pl % C;
+    for (int i = threadIdx.x; i < K * K; i += kT) ws[i] = w[(size_t)c * K * K + i];
+    __syncthreads();
+    const int Ho = H * F, Wo = W * F;                       // (H-1)*F - 2*(F/2) + 2F
+    const int q = blockIdx.x * kT + threadIdx.x;           // quad of outputs
+    if (q * 4 >= Ho * Wo) return;
+    const int oy = (q * 4) / Wo, ox0 = q * 4 - oy * Wo;
+    const float* xp = x + (size_t)pl * H * W;
+    // rows: ky = (oy + P) % F + {0, F}  ->  iy = (oy + P) / F - {0, 1}
+    const int ky0 = (oy + P) % F, iy0 = (oy + P) / F;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ox = ox0 + j;
+        const int kx0 = (ox + P) % F, ix0 = (ox + P) / F;
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int iy = iy0 - a;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ix = ix0 - b;
+                if (ix < 0 || ix >= W) continue;
+                acc += xp[iy * W + ix] * ws[(ky0 + a * F) * K + kx0 + b * F];
+            }
+        }
+        o[j] = acc;
+    }
+    *reinterpret_cast<float4*>(y + (size_t)pl * Ho * Wo + (size_t)q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
 // Both gradients read the same K x K window of gy around an input pixel:
 //   gx[b,c,iy,ix]  = sum_{ky,kx} gy[b,c,iy*s-p+ky, ix*s-p+kx] * w[c,ky,kx]
 //   gw[c,ky,kx]    = sum_{b,iy,ix} x[b,c,iy,ix] * gy[b,c,iy*s-p+ky, ix*s-p+kx]
@@ -371,8 +409,16 @@ extern "C" int cnuda_dwconvt2d_forward(const float* x, const float* w, float* y,
     const int Ho = (H - 1) * s - 2 * p + k, Wo = (W - 1) * s - 2 * p + k;
     CNUDA_REQUIRE(Ho > 0 && Wo > 0, "cnuda_dwconvt2d_forward: empty output");
     CNUDA_REQUIRE((long long)B * C <= 65535, "cnuda_dwconvt2d_forward: more than 65535 planes");
-    hipLaunchKernelGGL(dwconvt_fwd_kernel, dim3(ceil_div((long long)Ho * Wo, kT), B * C), dim3(kT), 0,
-                       (hipStream_t)stream, x, w, y, C, H, W, Ho, Wo, k, s, p);
+    const bool upsample = k == 2 * s && p == s / 2 && (s == 2 || s == 4) && Wo % 4 == 0;   // IDAUp's bilinear-style layers
+    if (upsample && s == 2)
+        hipLaunchKernelGGL(dwconvt_fwd_f_kernel<2>, dim3(ceil_div((long long)Ho * Wo / 4, kT), B * C), dim3(kT), 0,
+                           (hipStream_t)stream, x, w, y, C, H, W);
+    else if (upsample)
+        hipLaunchKernelGGL(dwconvt_fwd_f_kernel<4>, dim3(ceil_div((long long)Ho * Wo / 4, kT), B * C), dim3(kT), 0,
+                           (hipStream_t)stream, x, w, y, C, H, W);
+    else
+        hipLaunchKernelGGL(dwconvt_fwd_kernel, dim3(ceil_div((long long)Ho * Wo, kT), B * C), dim3(kT), 0,
+                           (hipStream_t)stream, x, w, y, C, H, W, Ho, Wo, k, s, p);
     return check_launch("cnuda_dwconvt2d_forward");
 }
 extern "C" size_t cnuda_dwconvt2d_workspace_bytes(int B, int C, int k) {

@@ -127,7 +127,7 @@ def test_maxpool(shape, k):
     assert torch.equal(dx.grad.cpu(), x.grad)
 
 
-@pytest.mark.parametrize('C,H,W,f', [(8, 5, 6, 2), (64, 4, 4, 4), (3, 3, 5, 8)])
+@pytest.mark.parametrize('C,H,W,f', [(8, 5, 6, 2), (64, 4, 4, 4), (3, 3, 5, 8), (4, 3, 5, 2), (16, 32, 32, 2), (16, 16, 16, 4)])
 def test_depthwise_conv_transpose(C, H, W, f):
     from hip_runtime import ops
     g = torch.Generator().manual_seed(6)
