@@ -55,14 +55,18 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
 
 
 def dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h, stride_w,
-                    pad_h, pad_w, dilation_h, dilation_w, deformable_group, _columns=None):
+                    pad_h, pad_w, dilation_h, dilation_w, deformable_group, _columns=None, _grad_weight=None,
+                    _grad_bias=None):
     hr.require_gpu(input, weight, bias, offset, mask, grad_output)
     input, weight, bias, offset, mask, grad_output = [
         hr.f32c(t) for t in (input, weight, bias, offset, mask, grad_output)]
     B, C, H, W, Co = _shapes(input, weight, offset, mask, kernel_h, kernel_w, deformable_group)
     geom = (B, C, H, W, Co, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
             dilation_h, dilation_w, deformable_group)
-    grads = [torch.empty_like(t) for t in (input, offset, mask, weight, bias)]
+    grads = [torch.empty_like(t) for t in (input, offset, mask)]
+    # the parameter gradients may be written straight into caller-owned buffers (the arena's gradient sink)
+    grads += [_grad_weight if _grad_weight is not None else torch.empty_like(weight),
+              _grad_bias if _grad_bias is not None else torch.empty_like(bias)]
     L = hr.lib()
     nbytes = L.cnuda_dcn_v2_workspace_bytes(*geom)
     ws = hr.workspace(nbytes, input.device)

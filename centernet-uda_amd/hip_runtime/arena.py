@@ -10,10 +10,33 @@ Parameters that never receive a gradient (the reference's discarded
 level3/level4 `project` branches, its unused `base.fc`; Q8) are tracked with
 `touched` flags so the optimizer skips them exactly like torch.optim does for
 `grad is None`.
+
+Gradient sink.  The kernels' autograd Functions do not hand parameter gradients to autograd (which would add
+each of the 233 tensors into `.grad` with its own tiny kernel, twice per step): `grad_sink(param)` gives them a
+slot of a second flat buffer (`staging`, same layout) to write the gradient of THIS backward pass into; they
+return None for the parameter.  autograd still runs the parameter's post-accumulate hook when the Function
+returns, which is where the slot is recorded; `flat_grad += staging` then happens in a few large launches over
+runs of recorded slots -- per all-reduce bucket as soon as it is complete (data parallel), otherwise once at
+the end of the pass (an engine callback queued from the first hook).
 """
 import torch
 
 _REGISTRY = {}
+_BY_PTR = {}          # data_ptr of a parameter inside some arena -> (arena, index)
+
+
+def grad_sink(param):
+    """-> a float32 view (shaped like `param`) the caller must fill with the gradient of the running backward
+    pass and then NOT return to autograd; or None when `param` is not arena-managed (return the gradient as
+    usual).  A parameter used twice in one pass gets None the second time (autograd accumulates that one)."""
+    hit = _BY_PTR.get(param.data_ptr())
+    if hit is None:
+        return None
+    arena, i = hit
+    if not arena.valid_index(i, param) or arena.sunk[i]:
+        return None
+    return arena._sink(i)
+
 
 
 class ParamArena:
@@ -36,6 +59,9 @@ class ParamArena:
         self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.touched = [False] * len(self.params)
+        self.staging = None             # gradients of the running backward pass (allocated on first use)
+        self.sunk = [False] * len(self.params)      # staging slot written in this pass, not yet added to flat_grad
+        self._flush_queued = False
         self._hooks = []
         self.on_ready = None            # callback(index) used by the data-parallel wrapper
         with torch.no_grad():
@@ -49,10 +75,49 @@ class ParamArena:
                     self.touched[i] = True
                 p.grad = gview
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+                _BY_PTR[p.data_ptr()] = (self, i)
+
+    # -- gradient sink -------------------------------------------------------------
+    def valid_index(self, i, param):
+        return self.params[i] is param or self.params[i].data_ptr() == param.data_ptr()
+
+    def _sink(self, i):
+        if self.staging is None:
+            self.staging = torch.zeros_like(self.flat_grad)      # the alignment gaps stay zero for ever
+        self.sunk[i] = True
+        o, p = self.offsets[i], self.params[i]
+        return self.staging[o:o + p.numel()].view(p.shape)
+
+    def flush(self, lo=0, hi=None):
+        """flat_grad += staging over the sunk parameters whose offsets lie in [lo, hi): one launch per run of
+        neighbouring slots (the alignment gaps between them are included: both buffers hold zeros / don't-care
+        there and the gaps are never read)."""
+        hi = self.numel if hi is None else hi
+        run = None
+        for i, o in enumerate(self.offsets):
+            if o < lo or o >= hi:
+                continue
+            if self.sunk[i]:
+                end = o + self.params[i].numel()
+                run = [o, end] if run is None else [run[0], end]
+                self.sunk[i] = False
+            elif run is not None:
+                self.flat_grad[run[0]:run[1]].add_(self.staging[run[0]:run[1]])
+                run = None
+        if run is not None:
+            self.flat_grad[run[0]:run[1]].add_(self.staging[run[0]:run[1]])
+
+    def _end_of_pass(self):
+        self._flush_queued = False
+        self.flush()
 
     def _make_hook(self, i):
         def hook(param):
             self.touched[i] = True
+            if self.sunk[i] and not self._flush_queued:
+                # runs inside backward(): the engine calls this back when the pass is over
+                self._flush_queued = True
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
             # autograd may rebind .grad (it does not when .grad is defined and no graph is built);
             # keep the arena authoritative
             o, n = self.offsets[i], param.numel()
@@ -70,6 +135,7 @@ class ParamArena:
 
     def zero_grad(self):
         self.flat_grad.zero_()
+        self.sunk = [False] * len(self.params)
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             self.touched[i] = False
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
@@ -95,6 +161,8 @@ class ParamArena:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for k in [k for k, v in _BY_PTR.items() if v[0] is self]:
+            del _BY_PTR[k]
 
 
 def arena_for(params):

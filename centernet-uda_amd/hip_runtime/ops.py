@@ -7,6 +7,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import check, f32c, lib, prof_arm, ptr, require_gpu, stream, workspace
+from .arena import grad_sink
 
 
 def _pair(v):
@@ -16,6 +17,19 @@ def _pair(v):
 def _ws(nbytes, like):
     w = workspace(nbytes, like.device)
     return ptr(w), w.numel()
+
+
+def _param_grad(param, needed=True):
+    """Where a parameter's gradient goes: -> (buffer the kernel writes, value handed back to autograd).
+    Arena-managed parameters get their slot of the arena's staging buffer and autograd gets None (see
+    arena.py, "Gradient sink"); anything else gets a fresh tensor that is returned as usual."""
+    if not needed or param is None:
+        return None, None
+    v = grad_sink(param)
+    if v is not None:
+        return v, None
+    t = torch.empty_like(param)
+    return t, t
 
 
 # ---------------------------------------------------------------------------
@@ -46,13 +60,13 @@ class _Conv2d(Function):
         check(L.cnuda_conv2d_forward(ptr(x), ptr(weight), ptr(bias), ptr(y), *g, float(act_slope),
                                      wp, wn, stream()), 'conv2d_forward')
         ctx.geom, ctx.act_slope, ctx.has_bias = g, act_slope, bias is not None
-        ctx.save_for_backward(x, weight, y if act_slope >= 0 else None)
+        ctx.save_for_backward(x, weight, y if act_slope >= 0 else None, bias)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, weight, y = ctx.saved_tensors
+        x, weight, y, bias = ctx.saved_tensors
         g = ctx.geom
         L = lib()
         gy = f32c(gy)
@@ -70,11 +84,10 @@ class _Conv2d(Function):
             check(L.cnuda_conv2d_backward_data(ptr(gy), ptr(weight), ptr(gx), *g, wp, wn, stream()),
                   'conv2d_backward_data')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw = torch.empty_like(weight)
-            if ctx.has_bias:
-                gb = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device)
+            gw_buf, gw = _param_grad(weight)
+            gb_buf, gb = _param_grad(bias, ctx.has_bias)
             prof_arm('conv_wgrad', B, C, H, W, Co, kh, kw, Ho, Wo)
-            check(L.cnuda_conv2d_backward_weight(ptr(x), ptr(gy), ptr(gw), ptr(gb), *g, wp, wn, stream()),
+            check(L.cnuda_conv2d_backward_weight(ptr(x), ptr(gy), ptr(gw_buf), ptr(gb_buf), *g, wp, wn, stream()),
                   'conv2d_backward_weight')
         return gx, gw, gb, None, None, None
 
@@ -132,9 +145,9 @@ class _ConvTranspose2d(Function):
             check(L.cnuda_conv2d_forward(ptr(gy), ptr(weight), None, ptr(gx), *g, -1.0, wp, wn, stream()),
                   'conv_transpose2d(backward data)')
         if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(weight)
+            gw_buf, gw = _param_grad(weight)
             prof_arm('conv_wgrad', B, Co, Ho, Wo, Ci, kh, kw, H, W)
-            check(L.cnuda_conv2d_backward_weight(ptr(gy), ptr(x), ptr(gw), None, *g, wp, wn, stream()),
+            check(L.cnuda_conv2d_backward_weight(ptr(gy), ptr(x), ptr(gw_buf), None, *g, wp, wn, stream()),
                   'conv_transpose2d(backward weight)')
         return gx, gw, None, None, None
 
@@ -163,23 +176,24 @@ class _BatchNormAct(Function):
                                        ptr(running_mean), ptr(running_var), float(momentum), float(eps),
                                        1 if relu else 0, B, C, HW, wp, wn, stream()), 'bn_train_forward')
         ctx.relu, ctx.dims, ctx.has_res = relu, (B, C, HW), residual is not None
-        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd, beta)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, y, gamma, mean, invstd = ctx.saved_tensors
+        x, y, gamma, mean, invstd, beta = ctx.saved_tensors
         B, C, HW = ctx.dims
         gy = f32c(gy)
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if ctx.has_res else None
-        gg = torch.empty_like(gamma)
-        gb = torch.empty_like(gamma)
+        gg_buf, gg = _param_grad(gamma)
+        gb_buf, gb = _param_grad(beta)
         L = lib()
         wp, wn = _ws(L.cnuda_bn_workspace_bytes(B, C, HW), x)
         check(L.cnuda_bn_backward(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), ptr(gx), ptr(gres),
-                                  ptr(gg), ptr(gb), 1 if ctx.relu else 0, B, C, HW, wp, wn, stream()), 'bn_backward')
+                                  ptr(gg_buf), ptr(gb_buf), 1 if ctx.relu else 0, B, C, HW, wp, wn, stream()),
+              'bn_backward')
         return gx, gg, gb, gres, None, None, None, None, None
 
 
@@ -286,11 +300,11 @@ class _DwConvT(Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        gw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        gw_buf, gw = _param_grad(weight, ctx.needs_input_grad[1])
         L = lib()
         B, C, _, _, k = ctx.geom[:5]
         wp, wn = _ws(L.cnuda_dwconvt2d_workspace_bytes(B, C, k), x)
-        check(L.cnuda_dwconvt2d_backward(ptr(x), ptr(weight), ptr(f32c(gy)), ptr(gx), ptr(gw), *ctx.geom,
+        check(L.cnuda_dwconvt2d_backward(ptr(x), ptr(weight), ptr(f32c(gy)), ptr(gx), ptr(gw_buf), *ctx.geom,
                                          wp, wn, stream()), 'dwconvt2d_backward')
         return gx, gw, None, None
 

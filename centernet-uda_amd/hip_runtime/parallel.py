@@ -87,6 +87,7 @@ class DataParallel(nn.Module):
         if b[3]:
             return
         b[3] = True
+        self.arena.flush(b[0], b[1])                            # this pass's sunk gradients of the bucket
         if dist.is_available() and dist.is_initialized():      # also with one rank: the collective is an identity
             chunk = self.arena.flat_grad[b[0]:b[1]]
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))

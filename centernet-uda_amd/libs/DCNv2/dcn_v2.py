@@ -37,9 +37,12 @@ class _DeformConvFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_output):
         input, offset, mask, weight, bias, cols = ctx.saved_tensors
+        from hip_runtime.arena import grad_sink
+        sw, sb = grad_sink(weight), grad_sink(bias)       # arena slots: written by the kernels, not returned
         g_in, g_off, g_mask, g_w, g_b = _backend.dcn_v2_backward(
-            input, weight, bias, offset, mask, grad_output, *ctx.geom, _columns=cols)
-        return g_in, g_off, g_mask, g_w, g_b, None, None, None, None
+            input, weight, bias, offset, mask, grad_output, *ctx.geom, _columns=cols, _grad_weight=sw, _grad_bias=sb)
+        return g_in, g_off, g_mask, (None if sw is not None else g_w), (None if sb is not None else g_b), \
+            None, None, None, None
 
 
 dcn_v2_conv = _DeformConvFn.apply
