@@ -90,9 +90,10 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
 
 __global__ void bn_finalize_fwd_kernel(const double* __restrict__ partial, float* __restrict__ save_mean,
                                        float* __restrict__ save_invstd, float* __restrict__ running_mean,
-                                       float* __restrict__ running_var, int C, int S, long long count, float momentum,
-                                       float eps) {
+                                       float* __restrict__ running_var, long long* __restrict__ num_batches_tracked,
+                                       int C, int S, long long count, float momentum, float eps) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;     // nn.BatchNorm2d's counter, same launch
     if (c >= C) return;
     double s0 = 0.0, s1 = 0.0;
     for (int s = 0; s < S; ++s) {
@@ -220,8 +221,9 @@ extern "C" size_t cnuda_bn_workspace_bytes(int B, int C, long long HW) {
 
 extern "C" int cnuda_bn_train_forward(const float* x, const float* gamma, const float* beta, const float* residual,
                                       float* y, float* save_mean, float* save_invstd, float* running_mean,
-                                      float* running_var, float momentum, float eps, int relu, int B, int C,
-                                      long long HW, void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+                                      float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                                      int relu, int B, int C, long long HW, void* workspace, size_t workspace_bytes,
+                                      cnuda_stream_t stream) {
     CNUDA_REQUIRE(x && gamma && beta && y && save_mean && save_invstd, "cnuda_bn_train_forward: null pointer");
     CNUDA_REQUIRE(B > 0 && C > 0 && HW > 0, "cnuda_bn_train_forward: empty tensor");
     CNUDA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "cnuda_bn_train_forward: running stats");
@@ -238,7 +240,7 @@ extern "C" int cnuda_bn_train_forward(const float* x, const float* gamma, const 
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, C, HW,
                        sp.chunk, sp.per_plane, sp.S, 0);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, partial, save_mean, save_invstd,
-                       running_mean, running_var, C, sp.S, count, momentum, eps);
+                       running_mean, running_var, num_batches_tracked, C, sp.S, count, momentum, eps);
     const long long planes = (long long)B * C;
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
                        dim3(kBnThreads), 0, st, x, save_mean, save_invstd, gamma, beta, residual, y, C, HW, relu);

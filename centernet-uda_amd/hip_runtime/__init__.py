@@ -72,7 +72,7 @@ class _Sig:
     cnuda_conv2d_backward_data = (_I, [_P] * 3 + [_I] * 11 + _WS)
     cnuda_conv2d_backward_weight = (_I, [_P] * 4 + [_I] * 11 + _WS)
     cnuda_bn_workspace_bytes = (c_size_t, [_I, _I, _LL])
-    cnuda_bn_train_forward = (_I, [_P] * 9 + [_F, _F, _I, _I, _I, _LL] + _WS)
+    cnuda_bn_train_forward = (_I, [_P] * 10 + [_F, _F, _I, _I, _I, _LL] + _WS)
     cnuda_bn_eval_forward = (_I, [_P] * 7 + [_F, _I, _I, _I, _LL, _P])
     cnuda_bn_backward = (_I, [_P] * 10 + [_I, _I, _I, _LL] + _WS)
     cnuda_maxpool2d_forward = (_I, [_P] * 2 + [_I] * 5 + [_P])

@@ -59,10 +59,8 @@ class BatchNorm2d(nn.Module):
     def forward(self, x, residual=None, relu=False):
         if x.shape[1] != self.num_features:
             raise RuntimeError("BatchNorm2d: expected %d channels, got %d" % (self.num_features, x.shape[1]))
-        if self.training:
-            self.num_batches_tracked += 1
         return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                  self.momentum, self.eps, residual, relu)
+                                  self.momentum, self.eps, residual, relu, self.num_batches_tracked)
 
 
 class MaxPool2d(nn.Module):

@@ -161,7 +161,7 @@ def conv_transpose2d(x, weight, stride=1, padding=0, output_padding=0):
 # ---------------------------------------------------------------------------
 class _BatchNormAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, num_batches_tracked):
         require_gpu(x, gamma, beta, residual)
         x = f32c(x)
         residual = None if residual is None else f32c(residual)
@@ -173,7 +173,8 @@ class _BatchNormAct(Function):
         L = lib()
         wp, wn = _ws(L.cnuda_bn_workspace_bytes(B, C, HW), x)
         check(L.cnuda_bn_train_forward(ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(mean), ptr(invstd),
-                                       ptr(running_mean), ptr(running_var), float(momentum), float(eps),
+                                       ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), float(momentum),
+                                       float(eps),
                                        1 if relu else 0, B, C, HW, wp, wn, stream()), 'bn_train_forward')
         ctx.relu, ctx.dims, ctx.has_res = relu, (B, C, HW), residual is not None
         ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd, beta)
@@ -194,13 +195,19 @@ class _BatchNormAct(Function):
         check(L.cnuda_bn_backward(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), ptr(gx), ptr(gres),
                                   ptr(gg_buf), ptr(gb_buf), 1 if ctx.relu else 0, B, C, HW, wp, wn, stream()),
               'bn_backward')
-        return gx, gg, gb, gres, None, None, None, None, None
+        return gx, gg, gb, gres, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
-                   residual=None, relu=False):
+                   residual=None, relu=False, num_batches_tracked=None):
+    """`num_batches_tracked` (int64 scalar buffer, optional) is incremented by the statistics kernel in training
+    mode, like nn.BatchNorm2d.forward does on the host."""
     if training:
-        return _BatchNormAct.apply(x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu)
+        if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or
+                                                not num_batches_tracked.is_cuda):
+            raise RuntimeError("batch_norm_act: num_batches_tracked must be an int64 tensor on the GPU")
+        return _BatchNormAct.apply(x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu,
+                                   num_batches_tracked)
     if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad):
         raise RuntimeError("batch_norm_act: eval-mode BN has no backward in this build "
                            "(the reference evaluates under torch.no_grad(), train.py:172)")

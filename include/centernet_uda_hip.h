@@ -159,7 +159,9 @@ int cnuda_conv2d_backward_weight(const float* x, const float* grad_y, float* gra
 size_t cnuda_bn_workspace_bytes(int B, int C, long long HW);
 int cnuda_bn_train_forward(const float* x, const float* gamma, const float* beta, const float* residual,
                            float* y, float* save_mean, float* save_invstd,
-                           float* running_mean, float* running_var, float momentum, float eps, int relu,
+                           float* running_mean, float* running_var,
+                           long long* num_batches_tracked /* nullable; += 1 like nn.BatchNorm2d.forward */,
+                           float momentum, float eps, int relu,
                            int B, int C, long long HW,
                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 int cnuda_bn_eval_forward(const float* x, const float* gamma, const float* beta,
