@@ -4,10 +4,11 @@
 // nn.BatchNorm2d(momentum=0.1) + `out += residual` + nn.ReLU(inplace=True).
 //
 // Training forward : (1) per-channel sum / sum-of-squares partials over a
-//                    (channel, split) grid, fp64 accumulation; (2) a finalize
-//                    kernel -> mean, invstd, running-stat update (unbiased var,
-//                    momentum) ; (3) one streaming pass y = act(xhat*g + b [+ res]).
-// Backward         : same three-step shape for (sum dy, sum dy*xhat).
+//                    (channel, split) grid, fp64 accumulation; (2) one streaming
+//                    pass y = act(xhat*g + b [+ res]) whose workgroups first fold the
+//                    partials into mean / invstd (and one of them updates the
+//                    running statistics: unbiased var, momentum).
+// Backward         : same two-step shape for (sum dy, sum dy*xhat).
 // All three passes are HBM-bound streaming kernels with 16-byte accesses when
 // the plane size allows.
 #include "common.h"
@@ -88,55 +89,56 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
     }
 }
 
-__global__ void bn_finalize_fwd_kernel(const double* __restrict__ partial, float* __restrict__ save_mean,
-                                       float* __restrict__ save_invstd, float* __restrict__ running_mean,
-                                       float* __restrict__ running_var, long long* __restrict__ num_batches_tracked,
-                                       int C, int S, long long count, float momentum, float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;     // nn.BatchNorm2d's counter, same launch
-    if (c >= C) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int s = 0; s < S; ++s) {
-        s0 += partial[((size_t)c * S + s) * 2 + 0];
-        s1 += partial[((size_t)c * S + s) * 2 + 1];
+// Every workgroup of the apply passes re-derives its channel's statistics from the S fp64 partials (S <= a few
+// hundred loads, one wave) instead of waiting for a separate finalize launch; the workgroup that handles the
+// first chunk of image 0 also writes them out (saved mean / invstd, running statistics, batch counter, or the
+// gamma / beta gradients).
+__device__ __forceinline__ void bn_sum_partials(const double* __restrict__ partial, int c, int S, double& s0, double& s1,
+                                                double* red) {
+    double a0 = 0.0, a1 = 0.0;
+    for (int s = threadIdx.x; s < S; s += kBnThreads) {
+        a0 += partial[((size_t)c * S + s) * 2 + 0];
+        a1 += partial[((size_t)c * S + s) * 2 + 1];
     }
-    const double n = (double)count;
-    const double mu = s0 / n;
-    double var = s1 / n - mu * mu;   // biased; fp64 sums make the subtraction safe
-    if (var < 0.0) var = 0.0;
-    save_mean[c] = (float)mu;
-    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
-        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
-        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
-    }
-}
-
-__global__ void bn_finalize_bwd_kernel(const double* __restrict__ partial, float* __restrict__ ggamma,
-                                       float* __restrict__ gbeta, float* __restrict__ sums, int C, int S) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s0 = 0.0, s1 = 0.0;
-    for (int s = 0; s < S; ++s) {
-        s0 += partial[((size_t)c * S + s) * 2 + 0];
-        s1 += partial[((size_t)c * S + s) * 2 + 1];
-    }
-    gbeta[c] = (float)s0;
-    ggamma[c] = (float)s1;
-    sums[2 * c] = (float)s0;
-    sums[2 * c + 1] = (float)s1;
+    s0 = block_sum(a0, red);
+    s1 = block_sum(a1, red);
 }
 
 // y = act((x - mean) * invstd * gamma + beta [+ residual]); grid (plane, splits)
 __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
-    const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ x, const double* __restrict__ partial, int S, long long count, float momentum, float eps,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ running_mean,
+    float* __restrict__ running_var, long long* __restrict__ num_batches_tracked,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ residual,
     float* __restrict__ y, int C, long long HW, int relu) {
+    __shared__ double red[16];
+    __shared__ float stat[2];
     const long long plane = blockIdx.x;
     const int c = (int)(plane % C);
-    const float sc = invstd[c] * gamma[c];
-    const float sh = beta[c] - mean[c] * sc;
+    double s0, s1;
+    bn_sum_partials(partial, c, S, s0, s1, red);
+    if (threadIdx.x == 0) {
+        const double n = (double)count;
+        const double mu = s0 / n;
+        double var = s1 / n - mu * mu;   // biased; fp64 sums make the subtraction safe
+        if (var < 0.0) var = 0.0;
+        const float m = (float)mu, is = (float)(1.0 / sqrt(var + (double)eps));
+        stat[0] = m;
+        stat[1] = is;
+        if (plane < C && blockIdx.y == 0) {            // image 0, first chunk: the channel's single writer
+            save_mean[c] = m;
+            save_invstd[c] = is;
+            if (running_mean) {
+                const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
+                running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+                running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+            }
+            if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;     // nn.BatchNorm2d's counter
+        }
+    }
+    __syncthreads();
+    const float sc = stat[1] * gamma[c];
+    const float sh = beta[c] - stat[0] * sc;
     const size_t base = (size_t)plane * HW;
     const long long start = (long long)blockIdx.y * kBnThreads * 4 + threadIdx.x * 4;
     const long long stride = (long long)gridDim.y * kBnThreads * 4;
@@ -166,15 +168,48 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-    const float* __restrict__ sums, float* __restrict__ gx, float* __restrict__ gres, int C, long long HW,
-    long long count, int relu) {
+    const double* __restrict__ partial, int S, float* __restrict__ ggamma, float* __restrict__ gbeta,
+    float* __restrict__ gx, float* __restrict__ gres, int C, long long HW, long long count, int relu) {
+    __shared__ double red[16];
+    __shared__ float stat[2];
     const long long plane = blockIdx.x;
     const int c = (int)(plane % C);
+    double s0, s1;
+    bn_sum_partials(partial, c, S, s0, s1, red);
+    if (threadIdx.x == 0) {
+        stat[0] = (float)s0;
+        stat[1] = (float)s1;
+        if (plane < C && blockIdx.y == 0) { gbeta[c] = (float)s0; ggamma[c] = (float)s1; }
+    }
+    __syncthreads();
     const float mu = mean[c], is = invstd[c];
     const float k = gamma[c] * is;
     const float inv_n = 1.0f / (float)count;
-    const float m0 = sums[2 * c] * inv_n, m1 = sums[2 * c + 1] * inv_n;
+    const float m0 = stat[0] * inv_n, m1 = stat[1] * inv_n;
     const size_t base = (size_t)plane * HW;
+    if ((HW & 3) == 0) {
+        const long long start = (long long)blockIdx.y * kBnThreads * 4 + threadIdx.x * 4;
+        const long long stride = (long long)gridDim.y * kBnThreads * 4;
+        for (long long i = start; i < HW; i += stride) {
+            float4 g = *reinterpret_cast<const float4*>(dy + base + i);
+            if (relu) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
+                if (!(yv.x > 0.0f)) g.x = 0.0f;
+                if (!(yv.y > 0.0f)) g.y = 0.0f;
+                if (!(yv.z > 0.0f)) g.z = 0.0f;
+                if (!(yv.w > 0.0f)) g.w = 0.0f;
+            }
+            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
+            float4 o;
+            o.x = k * (g.x - m0 - (xv.x - mu) * is * m1);
+            o.y = k * (g.y - m0 - (xv.y - mu) * is * m1);
+            o.z = k * (g.z - m0 - (xv.z - mu) * is * m1);
+            o.w = k * (g.w - m0 - (xv.w - mu) * is * m1);
+            *reinterpret_cast<float4*>(gx + base + i) = o;
+            if (gres) *reinterpret_cast<float4*>(gres + base + i) = g;
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.y * kBnThreads + threadIdx.x; i < HW; i += (long long)gridDim.y * kBnThreads) {
         float g = dy[base + i];
         if (relu && !(y[base + i] > 0.0f)) g = 0.0f;
@@ -239,11 +274,10 @@ extern "C" int cnuda_bn_train_forward(const float* x, const float* gamma, const 
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, C, HW,
                        sp.chunk, sp.per_plane, sp.S, 0);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, partial, save_mean, save_invstd,
-                       running_mean, running_var, num_batches_tracked, C, sp.S, count, momentum, eps);
     const long long planes = (long long)B * C;
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
-                       dim3(kBnThreads), 0, st, x, save_mean, save_invstd, gamma, beta, residual, y, C, HW, relu);
+                       dim3(kBnThreads), 0, st, x, partial, sp.S, count, momentum, eps, save_mean, save_invstd,
+                       running_mean, running_var, num_batches_tracked, gamma, beta, residual, y, C, HW, relu);
     return check_launch("cnuda_bn_train_forward");
 }
 
@@ -273,14 +307,11 @@ extern "C" int cnuda_bn_backward(const float* grad_y, const float* x, const floa
     const Split sp = pick_split(B, C, HW);
     uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
     double* partial = reinterpret_cast<double*>(base);
-    float* sums = reinterpret_cast<float*>(base + (size_t)C * sp.S * 2 * sizeof(double));
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, grad_y, y, save_mean,
                        save_invstd, partial, C, HW, sp.chunk, sp.per_plane, sp.S, relu);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, partial, grad_gamma, grad_beta,
-                       sums, C, sp.S);
     const long long planes = (long long)B * C;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads)),
-                       dim3(kBnThreads), 0, st, grad_y, x, y, save_mean, save_invstd, gamma, sums, grad_x,
-                       grad_residual, C, HW, count, relu);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
+                       dim3(kBnThreads), 0, st, grad_y, x, y, save_mean, save_invstd, gamma, partial, sp.S, grad_gamma,
+                       grad_beta, grad_x, grad_residual, C, HW, count, relu);
     return check_launch("cnuda_bn_backward");
 }
