@@ -304,50 +304,74 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
 // gx = gy * (y > 0 ? 1 : slope)      (ReLU: slope 0; LeakyReLU(0.2): slope 0.2)
 __global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gx,
                                long long n, float slope) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 g = reinterpret_cast<const float4*>(gy)[i], v = reinterpret_cast<const float4*>(y)[i];
+        reinterpret_cast<float4*>(gx)[i] = make_float4(v.x > 0.0f ? g.x : g.x * slope, v.y > 0.0f ? g.y : g.y * slope,
+                                                       v.z > 0.0f ? g.z : g.z * slope, v.w > 0.0f ? g.w : g.w * slope);
+    }
+    for (long long i = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
         gx[i] = y[i] > 0.0f ? gy[i] : gy[i] * slope;
 }
-// copy a [B, Cs, HW] block between tensors with Csrc / Cdst channels at channel offsets
-__global__ void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int Cn,
-                                     long long HW, int Csrc, int src_off, int Cdst, int dst_off) {
-    const long long total = (long long)B * Cn * HW;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const long long hw = i % HW;
-        const int c = (int)((i / HW) % Cn), b = (int)(i / (HW * Cn));
-        dst[((size_t)b * Cdst + dst_off + c) * HW + hw] = src[((size_t)b * Csrc + src_off + c) * HW + hw];
+// Row-wise kernels: grid (chunks of a row, rows); a row is one (image, channel) plane of HW floats, so the
+// channel bookkeeping is per workgroup and the inner loop is 16-byte copies when HW % 4 == 0.
+// copy a [B, Cn, HW] block between tensors with Csrc / Cdst channels at channel offsets
+__global__ void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cn, long long HW,
+                                     int Csrc, int src_off, int Cdst, int dst_off) {
+    const int row = blockIdx.y, b = row / Cn, c = row - b * Cn;
+    const float* s = src + ((size_t)b * Csrc + src_off + c) * HW;
+    float* d = dst + ((size_t)b * Cdst + dst_off + c) * HW;
+    if ((HW & 3) == 0) {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (HW >> 2); i += (long long)gridDim.x * blockDim.x)
+            reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x)
+            d[i] = s[i];
     }
 }
 // om [B, 3T, HW] -> offset [B, 2T, HW] (channels 0..2T-1 unchanged) and mask = sigmoid(channels 2T..3T-1)
 __global__ void split_offset_mask_kernel(const float* __restrict__ om, float* __restrict__ offset,
-                                         float* __restrict__ mask, int B, int T, long long HW) {
-    const long long total = (long long)B * 3 * T * HW;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const long long hw = i % HW;
-        const int c = (int)((i / HW) % (3 * T)), b = (int)(i / (HW * 3 * T));
-        const float v = om[i];
-        if (c < 2 * T)
-            offset[((size_t)b * 2 * T + c) * HW + hw] = v;
-        else
-            mask[((size_t)b * T + (c - 2 * T)) * HW + hw] = 1.0f / (1.0f + expf(-v));
+                                         float* __restrict__ mask, int T, long long HW) {
+    const int row = blockIdx.y, b = row / (3 * T), c = row - b * 3 * T;
+    const float* s = om + (size_t)row * HW;
+    const bool is_mask = c >= 2 * T;
+    float* d = is_mask ? mask + ((size_t)b * T + (c - 2 * T)) * HW : offset + ((size_t)b * 2 * T + c) * HW;
+    if ((HW & 3) == 0) {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (HW >> 2); i += (long long)gridDim.x * blockDim.x) {
+            float4 v = reinterpret_cast<const float4*>(s)[i];
+            if (is_mask) {
+                v.x = 1.0f / (1.0f + expf(-v.x)); v.y = 1.0f / (1.0f + expf(-v.y));
+                v.z = 1.0f / (1.0f + expf(-v.z)); v.w = 1.0f / (1.0f + expf(-v.w));
+            }
+            reinterpret_cast<float4*>(d)[i] = v;
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x)
+            d[i] = is_mask ? 1.0f / (1.0f + expf(-s[i])) : s[i];
     }
 }
 __global__ void split_offset_mask_bwd_kernel(const float* __restrict__ goff, const float* __restrict__ gmask,
-                                             const float* __restrict__ mask, float* __restrict__ gom, int B, int T,
+                                             const float* __restrict__ mask, float* __restrict__ gom, int T,
                                              long long HW) {
-    const long long total = (long long)B * 3 * T * HW;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const long long hw = i % HW;
-        const int c = (int)((i / HW) % (3 * T)), b = (int)(i / (HW * 3 * T));
-        if (c < 2 * T) {
-            gom[i] = goff[((size_t)b * 2 * T + c) * HW + hw];
-        } else {
-            const size_t j = ((size_t)b * T + (c - 2 * T)) * HW + hw;
-            const float m = mask[j];
-            gom[i] = gmask[j] * m * (1.0f - m);
+    const int row = blockIdx.y, b = row / (3 * T), c = row - b * 3 * T;
+    float* d = gom + (size_t)row * HW;
+    const bool is_mask = c >= 2 * T;
+    const float* g = is_mask ? gmask + ((size_t)b * T + (c - 2 * T)) * HW : goff + ((size_t)b * 2 * T + c) * HW;
+    const float* m = mask + ((size_t)b * T + (is_mask ? c - 2 * T : 0)) * HW;
+    if ((HW & 3) == 0) {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (HW >> 2); i += (long long)gridDim.x * blockDim.x) {
+            float4 v = reinterpret_cast<const float4*>(g)[i];
+            if (is_mask) {
+                const float4 mm = reinterpret_cast<const float4*>(m)[i];
+                v.x = v.x * mm.x * (1.0f - mm.x); v.y = v.y * mm.y * (1.0f - mm.y);
+                v.z = v.z * mm.z * (1.0f - mm.z); v.w = v.w * mm.w * (1.0f - mm.w);
+            }
+            reinterpret_cast<float4*>(d)[i] = v;
         }
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x)
+            d[i] = is_mask ? g[i] * m[i] * (1.0f - m[i]) : g[i];
     }
 }
 
@@ -478,22 +502,28 @@ extern "C" int cnuda_copy_channels(const float* src, float* dst, int B, int Cn, 
     CNUDA_REQUIRE(src && dst && B > 0 && Cn > 0 && HW > 0, "cnuda_copy_channels: bad arguments");
     CNUDA_REQUIRE(src_off >= 0 && dst_off >= 0 && src_off + Cn <= Csrc && dst_off + Cn <= Cdst,
                   "cnuda_copy_channels: channel range out of bounds");
-    hipLaunchKernelGGL(copy_channels_kernel, dim3(stream_grid((long long)B * Cn * HW, kT)), dim3(kT), 0,
-                       (hipStream_t)stream, src, dst, B, Cn, HW, Csrc, src_off, Cdst, dst_off);
+    CNUDA_REQUIRE((long long)B * Cn <= 65535, "cnuda_copy_channels: more than 65535 planes");
+    const int chunks = (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) > 0 ? (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) : 1;
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(chunks, B * Cn), dim3(kT), 0, (hipStream_t)stream, src, dst, Cn, HW,
+                       Csrc, src_off, Cdst, dst_off);
     return check_launch("cnuda_copy_channels");
 }
 extern "C" int cnuda_split_offset_mask(const float* om, float* offset, float* mask, int B, int taps, long long HW,
                                        cnuda_stream_t stream) {
     CNUDA_REQUIRE(om && offset && mask && B > 0 && taps > 0 && HW > 0, "cnuda_split_offset_mask: bad arguments");
-    hipLaunchKernelGGL(split_offset_mask_kernel, dim3(stream_grid((long long)B * 3 * taps * HW, kT)), dim3(kT), 0,
-                       (hipStream_t)stream, om, offset, mask, B, taps, HW);
+    CNUDA_REQUIRE((long long)B * 3 * taps <= 65535, "cnuda_split_offset_mask: more than 65535 planes");
+    const int chunks = (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) > 0 ? (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) : 1;
+    hipLaunchKernelGGL(split_offset_mask_kernel, dim3(chunks, B * 3 * taps), dim3(kT), 0, (hipStream_t)stream, om, offset,
+                       mask, taps, HW);
     return check_launch("cnuda_split_offset_mask");
 }
 extern "C" int cnuda_split_offset_mask_backward(const float* grad_offset, const float* grad_mask, const float* mask,
                                                 float* grad_om, int B, int taps, long long HW, cnuda_stream_t stream) {
     CNUDA_REQUIRE(grad_offset && grad_mask && mask && grad_om && B > 0 && taps > 0 && HW > 0,
                   "cnuda_split_offset_mask_backward: bad arguments");
-    hipLaunchKernelGGL(split_offset_mask_bwd_kernel, dim3(stream_grid((long long)B * 3 * taps * HW, kT)), dim3(kT), 0,
-                       (hipStream_t)stream, grad_offset, grad_mask, mask, grad_om, B, taps, HW);
+    CNUDA_REQUIRE((long long)B * 3 * taps <= 65535, "cnuda_split_offset_mask_backward: more than 65535 planes");
+    const int chunks = (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) > 0 ? (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) : 1;
+    hipLaunchKernelGGL(split_offset_mask_bwd_kernel, dim3(chunks, B * 3 * taps), dim3(kT), 0, (hipStream_t)stream,
+                       grad_offset, grad_mask, mask, grad_om, taps, HW);
     return check_launch("cnuda_split_offset_mask_backward");
 }
