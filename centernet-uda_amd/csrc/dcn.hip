@@ -162,39 +162,56 @@ struct DcnFwdLoader {
         const Pair a = *reinterpret_cast<const Pair*>(pl + qT), b = *reinterpret_cast<const Pair*>(pl + qB);
         return m00 * a.l + m01 * a.r + m10 * b.l + m11 * b.r;
     }
-    __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
+    // Two-phase loading (kHasSideOutput loaders): load_raw() only ISSUES the corner loads of a chunk, finish()
+    // turns them into samples (and writes the column side output) when the kernel stores the chunk to LDS, one
+    // chunk of MFMAs later.  Sampling inside load() consumed every load on the spot -- and its column stores sat
+    // in front of the next chunk's loads in the in-order vmcnt queue -- so the gather latency was exposed in full
+    // (PMC: 65 % of wave cycles parked, matrix pipe 26 % busy).
+    struct Raw {
+        Pair t[8], b[8];
+        int k0;
+        bool live, eager;      // eager: channel count not a multiple of 16 -> values were sampled in load_raw (t[j].l)
+    };
+    __device__ __forceinline__ void load_raw(int k0, int ksub, Raw& r) {
         const int HW = g.H * g.W;
-        if (g.C % IG_BK == 0) {
+        r.k0 = k0 + ksub;
+        r.live = k0 < K;
+        r.eager = g.C % IG_BK != 0;
+        if (!r.eager) {
+            if (!r.live) return;
             // one tap per 16-deep chunk: no per-element index math
             const int tap = k0 / g.C, c0 = k0 - tap * g.C + ksub;
-            if (k0 >= K) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = 0.0f;
-                return;
-            }
             if (tap != cur) set_tap(tap);
             const float* plane = in_b + (size_t)c0 * HW;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float* pl = plane + (size_t)(2 * j) * HW;
-                const float r = sample(pl);
-                if (col_n) col_n[(size_t)(k0 + ksub + 2 * j) * col_stride] = r;
-                v[j] = r;
+                r.t[j] = *reinterpret_cast<const Pair*>(pl + qT);
+                r.b[j] = *reinterpret_cast<const Pair*>(pl + qB);
             }
             return;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + ksub + 2 * j;
-            float r = 0.0f;
+            float v = 0.0f;
             if (k < K) {
                 const int tap = k / g.C, c = k - tap * g.C;
                 if (tap != cur) set_tap(tap);
-                const float* pl = in_b + (size_t)c * HW;
-                r = sample(pl);
-                if (col_n) col_n[(size_t)k * col_stride] = r;
+                v = sample(in_b + (size_t)c * HW);
             }
-            v[j] = r;
+            r.t[j].l = v;
+        }
+    }
+    __device__ __forceinline__ void finish(const Raw& r, float (&v)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = 0.0f;
+            if (r.eager) x = r.t[j].l;
+            else if (r.live) x = m00 * r.t[j].l + m01 * r.t[j].r + m10 * r.b[j].l + m11 * r.b[j].r;
+            const int k = r.k0 + 2 * j;
+            if (col_n && k < K) col_n[(size_t)k * col_stride] = x;
+            v[j] = x;
         }
     }
     struct Out {

@@ -108,9 +108,15 @@ __device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, cons
     for (int i = 0; i < BM * IG_KC / IG_THREADS; ++i) As[tid + i * IG_THREADS] = r[i];
 }
 
+// raw-load storage of two-phase loaders (Loader::kHasSideOutput): Loader::Raw, else an empty placeholder
+template <class Loader, bool TWO_PHASE> struct IgRaw { struct type {}; };
+template <class Loader> struct IgRaw<Loader, true> { using type = typename Loader::Raw; };
+
 // Generic forward-type kernel.  Loader contract:
 //   Loader(const Params&, long long n, bool n_valid)   per-thread pixel setup
 //   void load(int k0, int ksub, float (&v)[8])         v[j] = B[k0 + ksub + 2j][n]
+//   or, when Loader::kHasSideOutput: load_raw(k0, ksub, Raw&) issues the loads of a chunk and finish(Raw&, v) turns
+//   them into values one chunk later, when the kernel stores that chunk to LDS
 // Epilogue contract:
 //   void store(const Params&, int m, long long n, float value)
 template <int BM, class Loader>
@@ -142,8 +148,13 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? 3 : 1)) void igemm_fwd_ker
     // Kp is a multiple of IG_KC (the pack kernels zero-pad); the loaders return 0 past the real K
     constexpr int NH = IG_KC / IG_BK;               // loader calls per chunk
     float ra[BM * IG_KC / IG_THREADS], rb[NH][8];
+    typename IgRaw<Loader, Loader::kHasSideOutput>::type raw[NH];   // two-phase loaders keep raw loads here
     auto stage_store = [&](int buf) {
         ig_store_a<BM>(As[buf], tid, ra);
+        if constexpr (Loader::kHasSideOutput) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) ld.finish(raw[h], rb[h]);
+        }
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -152,7 +163,10 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? 3 : 1)) void igemm_fwd_ker
     auto stage_load = [&](int k0) {
         ig_load_a<BM>(A, Mp, k0, m0, tid, ra);
 #pragma unroll
-        for (int h = 0; h < NH; ++h) ld.load(k0 + h * IG_BK, ksub, rb[h]);
+        for (int h = 0; h < NH; ++h) {
+            if constexpr (Loader::kHasSideOutput) ld.load_raw(k0 + h * IG_BK, ksub, raw[h]);
+            else ld.load(k0 + h * IG_BK, ksub, rb[h]);
+        }
     };
     stage_load(0);
     stage_store(0);
