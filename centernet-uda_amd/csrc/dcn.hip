@@ -204,14 +204,28 @@ struct DcnFwdLoader {
         }
     }
     __device__ __forceinline__ void finish(const Raw& r, float (&v)[8]) {
+        if (!r.eager) {
+            // fast path: the whole chunk is one tap and (K % 16 == 0) entirely inside or outside K
+            if (!r.live) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+                return;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = m00 * r.t[j].l + m01 * r.t[j].r + m10 * r.b[j].l + m11 * r.b[j].r;
+            if (col_n) {
+                float* cp = col_n + (size_t)r.k0 * col_stride;
+                const size_t step = (size_t)2 * col_stride;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cp[j * step] = v[j];
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float x = 0.0f;
-            if (r.eager) x = r.t[j].l;
-            else if (r.live) x = m00 * r.t[j].l + m01 * r.t[j].r + m10 * r.b[j].l + m11 * r.b[j].r;
             const int k = r.k0 + 2 * j;
-            if (col_n && k < K) col_n[(size_t)k * col_stride] = x;
-            v[j] = x;
+            v[j] = r.t[j].l;
+            if (col_n && k < K) col_n[(size_t)k * col_stride] = v[j];
         }
     }
     struct Out {
