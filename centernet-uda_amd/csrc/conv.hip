@@ -113,6 +113,11 @@ struct ConvDgradLoader {
         const int r = tap / g.kw, s = tap - r * g.kw;
         const int ty = iy + g.ph - r, tx = ix + g.pw - s;
         if (ty < 0 || tx < 0) return false;
+        if (g.sh == 1 && g.sw == 1) {          // the common case (stride > 1 mostly takes the class loader): no divisions
+            if (ty >= g.Ho || tx >= g.Wo) return false;
+            off = ty * g.Wo + tx;
+            return true;
+        }
         const int oy = ty / g.sh, ox = tx / g.sw;
         if (oy * g.sh != ty || ox * g.sw != tx || oy >= g.Ho || ox >= g.Wo) return false;
         off = oy * g.Wo + ox;
