@@ -35,6 +35,16 @@ struct ConvFwdLoader {
     const float* x_b;
     int iy0, ix0;
     bool valid;
+    // chunk cursor of the FAST path: chunks arrive in increasing k0, 16 at a time, so (tap, first channel,
+    // kernel row / column) advance by additions -- two integer divisions per chunk and thread otherwise
+    int ck0 = 0, ctap = 0, cc0 = 0, cr = 0, cs = 0;
+    __device__ __forceinline__ void seek(int k0) {
+        while (ck0 < k0) {
+            ck0 += IG_BK;
+            cc0 += IG_BK;
+            if (cc0 >= g.C) { cc0 -= g.C; ++ctap; if (++cs == g.kw) { cs = 0; ++cr; } }
+        }
+    }
     __device__ ConvFwdLoader(const Params& p, long long n, bool n_valid) : g(p.g), valid(n_valid) {
         const int HoWo = g.Ho * g.Wo;
         const int nn = n_valid ? (int)n : 0;   // N < 2^31 is checked on the host: 32-bit index math
@@ -47,9 +57,9 @@ struct ConvFwdLoader {
     __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
         const int HW = g.H * g.W, K = g.kh * g.kw * g.C;
         if (FAST) {
-            const int tap = k0 / g.C, c0 = k0 - tap * g.C + ksub;
-            const int r = tap / g.kw, s = tap - r * g.kw;
-            const int iy = iy0 + r, ix = ix0 + s;
+            seek(k0);
+            const int c0 = cc0 + ksub;
+            const int iy = iy0 + cr, ix = ix0 + cs;
             const bool ok = valid && k0 < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
             const float* ptr = x_b + (size_t)c0 * HW + (ok ? iy * g.W + ix : 0);
 #pragma unroll
@@ -101,6 +111,14 @@ struct ConvDgradLoader {
     const float* gy_b;
     int iy, ix, cop;
     bool valid;
+    int ck0 = 0, ctap = 0, co0 = 0, cr = 0, cs = 0;     // chunk cursor, see ConvFwdLoader::seek
+    __device__ __forceinline__ void seek(int k0) {
+        while (ck0 < k0) {
+            ck0 += IG_BK;
+            co0 += IG_BK;
+            if (co0 >= cop) { co0 -= cop; ++ctap; if (++cs == g.kw) { cs = 0; ++cr; } }
+        }
+    }
     __device__ ConvDgradLoader(const Params& p, long long n, bool n_valid) : g(p.g), cop(p.cop), valid(n_valid) {
         const int HW = g.H * g.W;
         const int nn = n_valid ? (int)n : 0;   // N < 2^31 is checked on the host: 32-bit index math
@@ -109,8 +127,7 @@ struct ConvDgradLoader {
         ix = pp - iy * g.W;
         gy_b = p.gy + (size_t)b * g.Co * g.Ho * g.Wo;
     }
-    __device__ __forceinline__ bool locate(int tap, int& off) const {
-        const int r = tap / g.kw, s = tap - r * g.kw;
+    __device__ __forceinline__ bool locate(int r, int s, int& off) const {
         const int ty = iy + g.ph - r, tx = ix + g.pw - s;
         if (ty < 0 || tx < 0) return false;
         if (g.sh == 1 && g.sw == 1) {          // the common case (stride > 1 mostly takes the class loader): no divisions
@@ -125,9 +142,10 @@ struct ConvDgradLoader {
     }
     __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
         const int HoWo = g.Ho * g.Wo, K = g.kh * g.kw * cop;
-        const int tap = k0 / cop, o0 = k0 - tap * cop + ksub;
+        seek(k0);
+        const int o0 = co0 + ksub;
         int off = 0;
-        const bool ok = valid && k0 < K && locate(tap, off);
+        const bool ok = valid && k0 < K && locate(cr, cs, off);
         const float* ptr = gy_b + off;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {

@@ -114,6 +114,7 @@ struct DcnFwdLoader {
     bool valid;
     int cur;   // tap whose sampling state currently sits in the registers below (K is tap-major:
                // consecutive chunks share it)
+    int ck0 = 0, ctap = 0, cc0 = 0;     // chunk cursor (k0, its tap, its first channel)
     // per (pixel, tap): the two corner ROWS as clamped offsets of a horizontally adjacent pair, and the four
     // corner weights with validity and mask folded in: one sampled value is 2 unconditional 8-byte loads
     // (4-byte aligned; the buffer path takes them) + 4 multiply-adds
@@ -179,8 +180,14 @@ struct DcnFwdLoader {
         r.eager = g.C % IG_BK != 0;
         if (!r.eager) {
             if (!r.live) return;
-            // one tap per 16-deep chunk: no per-element index math
-            const int tap = k0 / g.C, c0 = k0 - tap * g.C + ksub;
+            // one tap per 16-deep chunk: no per-element index math, and (chunks arrive in increasing k0) the
+            // tap / first channel advance by additions
+            while (ck0 < k0) {
+                ck0 += IG_BK;
+                cc0 += IG_BK;
+                if (cc0 >= g.C) { cc0 -= g.C; ++ctap; }
+            }
+            const int tap = ctap, c0 = cc0 + ksub;
             if (tap != cur) set_tap(tap);
             const float* plane = in_b + (size_t)c0 * HW;
 #pragma unroll
