@@ -317,23 +317,26 @@ __global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __rest
 // Row-wise kernels: grid (chunks of a row, rows); a row is one (image, channel) plane of HW floats, so the
 // channel bookkeeping is per workgroup and the inner loop is 16-byte copies when HW % 4 == 0.
 // copy a [B, Cn, HW] block between tensors with Csrc / Cdst channels at channel offsets
-__global__ void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cn, long long HW,
-                                     int Csrc, int src_off, int Cdst, int dst_off) {
-    const int row = blockIdx.y, b = row / Cn, c = row - b * Cn;
-    const float* s = src + ((size_t)b * Csrc + src_off + c) * HW;
-    float* d = dst + ((size_t)b * Cdst + dst_off + c) * HW;
-    if ((HW & 3) == 0) {
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (HW >> 2); i += (long long)gridDim.x * blockDim.x)
-            reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
-    } else {
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x)
-            d[i] = s[i];
+__global__ void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int Cn,
+                                     long long HW, int Csrc, int src_off, int Cdst, int dst_off) {
+    for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int b = row / Cn, c = row - b * Cn;
+        const float* s = src + ((size_t)b * Csrc + src_off + c) * HW;
+        float* d = dst + ((size_t)b * Cdst + dst_off + c) * HW;
+        if ((HW & 3) == 0) {
+            for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (HW >> 2); i += (long long)gridDim.x * blockDim.x)
+                reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+        } else {
+            for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x)
+                d[i] = s[i];
+        }
     }
 }
 // om [B, 3T, HW] -> offset [B, 2T, HW] (channels 0..2T-1 unchanged) and mask = sigmoid(channels 2T..3T-1)
 __global__ void split_offset_mask_kernel(const float* __restrict__ om, float* __restrict__ offset,
-                                         float* __restrict__ mask, int T, long long HW) {
-    const int row = blockIdx.y, b = row / (3 * T), c = row - b * 3 * T;
+                                         float* __restrict__ mask, int rows, int T, long long HW) {
+  for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+    const int b = row / (3 * T), c = row - b * 3 * T;
     const float* s = om + (size_t)row * HW;
     const bool is_mask = c >= 2 * T;
     float* d = is_mask ? mask + ((size_t)b * T + (c - 2 * T)) * HW : offset + ((size_t)b * 2 * T + c) * HW;
@@ -350,11 +353,13 @@ __global__ void split_offset_mask_kernel(const float* __restrict__ om, float* __
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x)
             d[i] = is_mask ? 1.0f / (1.0f + expf(-s[i])) : s[i];
     }
+  }
 }
 __global__ void split_offset_mask_bwd_kernel(const float* __restrict__ goff, const float* __restrict__ gmask,
-                                             const float* __restrict__ mask, float* __restrict__ gom, int T,
-                                             long long HW) {
-    const int row = blockIdx.y, b = row / (3 * T), c = row - b * 3 * T;
+                                             const float* __restrict__ mask, float* __restrict__ gom, int rows,
+                                             int T, long long HW) {
+  for (int row = blockIdx.y; row < rows; row += gridDim.y) {
+    const int b = row / (3 * T), c = row - b * 3 * T;
     float* d = gom + (size_t)row * HW;
     const bool is_mask = c >= 2 * T;
     const float* g = is_mask ? gmask + ((size_t)b * T + (c - 2 * T)) * HW : goff + ((size_t)b * 2 * T + c) * HW;
@@ -373,6 +378,7 @@ __global__ void split_offset_mask_bwd_kernel(const float* __restrict__ goff, con
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x)
             d[i] = is_mask ? g[i] * m[i] * (1.0f - m[i]) : g[i];
     }
+  }
 }
 
 }  // namespace
@@ -502,28 +508,31 @@ extern "C" int cnuda_copy_channels(const float* src, float* dst, int B, int Cn, 
     CNUDA_REQUIRE(src && dst && B > 0 && Cn > 0 && HW > 0, "cnuda_copy_channels: bad arguments");
     CNUDA_REQUIRE(src_off >= 0 && dst_off >= 0 && src_off + Cn <= Csrc && dst_off + Cn <= Cdst,
                   "cnuda_copy_channels: channel range out of bounds");
-    CNUDA_REQUIRE((long long)B * Cn <= 65535, "cnuda_copy_channels: more than 65535 planes");
     const int chunks = (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) > 0 ? (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) : 1;
-    hipLaunchKernelGGL(copy_channels_kernel, dim3(chunks, B * Cn), dim3(kT), 0, (hipStream_t)stream, src, dst, Cn, HW,
-                       Csrc, src_off, Cdst, dst_off);
+    const long long rows = (long long)B * Cn;
+    CNUDA_REQUIRE(rows < (1ll << 31), "cnuda_copy_channels: too many planes");
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(chunks, (unsigned)(rows < 65535 ? rows : 65535)), dim3(kT), 0,
+                       (hipStream_t)stream, src, dst, (int)rows, Cn, HW, Csrc, src_off, Cdst, dst_off);
     return check_launch("cnuda_copy_channels");
 }
 extern "C" int cnuda_split_offset_mask(const float* om, float* offset, float* mask, int B, int taps, long long HW,
                                        cnuda_stream_t stream) {
     CNUDA_REQUIRE(om && offset && mask && B > 0 && taps > 0 && HW > 0, "cnuda_split_offset_mask: bad arguments");
-    CNUDA_REQUIRE((long long)B * 3 * taps <= 65535, "cnuda_split_offset_mask: more than 65535 planes");
     const int chunks = (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) > 0 ? (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) : 1;
-    hipLaunchKernelGGL(split_offset_mask_kernel, dim3(chunks, B * 3 * taps), dim3(kT), 0, (hipStream_t)stream, om, offset,
-                       mask, taps, HW);
+    const long long rows = (long long)B * 3 * taps;
+    CNUDA_REQUIRE(rows < (1ll << 31), "cnuda_split_offset_mask: too many planes");
+    hipLaunchKernelGGL(split_offset_mask_kernel, dim3(chunks, (unsigned)(rows < 65535 ? rows : 65535)), dim3(kT), 0,
+                       (hipStream_t)stream, om, offset, mask, (int)rows, taps, HW);
     return check_launch("cnuda_split_offset_mask");
 }
 extern "C" int cnuda_split_offset_mask_backward(const float* grad_offset, const float* grad_mask, const float* mask,
                                                 float* grad_om, int B, int taps, long long HW, cnuda_stream_t stream) {
     CNUDA_REQUIRE(grad_offset && grad_mask && mask && grad_om && B > 0 && taps > 0 && HW > 0,
                   "cnuda_split_offset_mask_backward: bad arguments");
-    CNUDA_REQUIRE((long long)B * 3 * taps <= 65535, "cnuda_split_offset_mask_backward: more than 65535 planes");
     const int chunks = (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) > 0 ? (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) : 1;
-    hipLaunchKernelGGL(split_offset_mask_bwd_kernel, dim3(chunks, B * 3 * taps), dim3(kT), 0, (hipStream_t)stream,
-                       grad_offset, grad_mask, mask, grad_om, taps, HW);
+    const long long rows = (long long)B * 3 * taps;
+    CNUDA_REQUIRE(rows < (1ll << 31), "cnuda_split_offset_mask_backward: too many planes");
+    hipLaunchKernelGGL(split_offset_mask_bwd_kernel, dim3(chunks, (unsigned)(rows < 65535 ? rows : 65535)), dim3(kT), 0,
+                       (hipStream_t)stream, grad_offset, grad_mask, mask, grad_om, (int)rows, taps, HW);
     return check_launch("cnuda_split_offset_mask_backward");
 }
