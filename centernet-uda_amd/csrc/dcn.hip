@@ -455,7 +455,7 @@ struct DcnCol2imParams {
 // anchor and reads it back -- the survivor scatters through LDS, the (rare) losers and the corners outside the
 // window use global atomics.
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int n_wg) {
-    extern __shared__ __align__(16) float win[];     // [16][WSZ] + 256 dump cells
+    extern __shared__ __align__(16) float win[];     // 4 waves x [WSZ cells][4 channels] + 256 dump cells x 4 + claim maps
     const DcnGeom& g = p.g;
     const int T = g.kh * g.kw, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -476,13 +476,14 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int 
     if (WR < 0 || p.WSZmax == 0) WR = 0;     // WSZmax == 0: window does not fit the LDS -> global atomics only
     if (WC < 0 || p.WSZmax == 0) WC = 0;
     const int WSZ = WR * WC;                          // <= p.WSZmax
-    float* wp = win + wid * 4 * WSZ;                  // this wave's four planes
-    float* dump = win + CI_CG * p.WSZmax + tid;
+    // this wave's window: [cell][4 channels] -- the four channels of a cell are ONE 16-byte LDS access
+    float4* wp = reinterpret_cast<float4*>(win) + (size_t)wid * WSZ;
+    float4* dump = reinterpret_cast<float4*>(win + CI_CG * p.WSZmax) + tid;      // a private cell for inactive lanes
     volatile unsigned char* claim =
-        reinterpret_cast<unsigned char*>(win + CI_CG * p.WSZmax + 256) + wid * p.claim_sz;   // [(WR+1)*(WC+1)]
+        reinterpret_cast<unsigned char*>(win + CI_CG * p.WSZmax + 4 * 256) + wid * p.claim_sz;   // [(WR+1)*(WC+1)]
     const int c_w = cg * CI_CG + wid * 4;
-    for (int i = lane; i < 4 * WSZ; i += 64) wp[i] = 0.0f;
-    *dump = 0.0f;
+    for (int i = lane; i < WSZ; i += 64) wp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    *dump = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const int items = 4 * T;                          // (pixel group, tap)
     const DcnGeo* geo_b = p.geo + (size_t)b * T * HoWo;
@@ -536,13 +537,11 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int 
         const int base = rh * WC + rw;
         const bool w00 = a00 && r0 && q0, w01 = a01 && r0 && q1, w10 = a10 && r1 && q0, w11 = a11 && r1 && q1;
         auto scatter = [&](bool on, int cell, float k) {
-            float* a = on ? wp + cell : dump;
-            const int stride = on ? WSZ : 0;
-            float cur[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cur[r] = a[r * stride];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r * stride] = cur[r] + (on ? k * d[r] : 0.f);
+            float4* a = on ? wp + cell : dump;
+            const float kk = on ? k : 0.f;
+            float4 cur = *a;
+            cur.x += kk * d[0]; cur.y += kk * d[1]; cur.z += kk * d[2]; cur.w += kk * d[3];
+            *a = cur;
             asm volatile("" ::: "memory");     // LDS program order between corners (neighbouring lanes' cells)
         };
         // rounds: lanes whose anchor is claimed by another lane of this instruction wait for the next round
@@ -583,11 +582,11 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int 
     for (int pos = lane; pos < WSZ; pos += 64) {
         const int yy = pos / WC, xx = pos - yy * WC;
         float* gcell = gin_b + (size_t)(wy0 + yy) * g.W + wx0 + xx;
+        const float4 v4 = wp[pos];
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = wp[r * WSZ + pos];
-            if (v != 0.0f && c_w + r < g.C) atomicAdd(gcell + (size_t)(c_w + r) * HW, v);
-        }
+        for (int r = 0; r < 4; ++r)
+            if (v[r] != 0.0f && c_w + r < g.C) atomicAdd(gcell + (size_t)(c_w + r) * HW, v[r]);
     }
 }
 
@@ -868,8 +867,8 @@ DcnPlan make_plan(const DcnGeom& g) {
     q.WSZmax = wr * wc;
     q.claim_sz = ((wr + 1) * (wc + 1) + 15) / 16 * 16;
     // three workgroups per CU need <= 53 KiB each; larger windows (strides, dilations, big kernels) run windowless
-    if ((size_t)CI_CG * q.WSZmax * 4 + 1024 + 4 * (size_t)q.claim_sz > 53 * 1024) { q.WSZmax = 0; q.claim_sz = 16; }
-    q.col2im_lds = ((size_t)CI_CG * q.WSZmax + 256) * sizeof(float) + 4 * (size_t)q.claim_sz;
+    if ((size_t)CI_CG * q.WSZmax * 4 + 4096 + 4 * (size_t)q.claim_sz > 53 * 1024) { q.WSZmax = 0; q.claim_sz = 16; }
+    q.col2im_lds = ((size_t)CI_CG * q.WSZmax + 4 * 256) * sizeof(float) + 4 * (size_t)q.claim_sz;
     return q;
 }
 
