@@ -227,10 +227,17 @@ def main():
                          % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
-    device = torch.device('cuda', local_rank)
+    # test knobs (a one-GPU box cannot host two RCCL ranks): CNUDA_BENCH_ONE_DEVICE=1 puts every rank on cuda:0,
+    # CNUDA_BENCH_BACKEND=gloo swaps the collective backend; the driver's runs use neither
+    one_device = os.environ.get('CNUDA_BENCH_ONE_DEVICE') == '1'
+    backend = os.environ.get('CNUDA_BENCH_BACKEND', 'nccl')
+    device = torch.device('cuda', 0 if one_device else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group(backend='nccl', device_id=device)      # nccl == RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=device)      # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     plugin = build_plugin(device, parallel=world > 1, uda_name=args.uda)
     batch = synthetic_batch(args.batch, args.size, 42 + rank, device, rotated=UDA_WORKLOADS[args.uda][2])
@@ -255,13 +262,16 @@ def main():
     stats = {k: float(v) for k, v in out['stats'].items()}
 
     roofline = None
-    if rank == 0 and args.profile_steps > 0:
+    if args.profile_steps > 0:
+        # extra, untimed steps with the in-library kernel timer.  EVERY rank runs them (the gradient all-reduce
+        # inside step() is collective); only rank 0 records and reports.
         import hip_runtime as hr
-        hr.prof_begin()
+        if rank == 0:
+            hr.prof_begin()
         for _ in range(args.profile_steps):
             plugin.step(fresh(batch))
         torch.cuda.synchronize()
-        per_kernel = hr.prof_end()
+        per_kernel = hr.prof_end() if rank == 0 else None
         if per_kernel:
             hbm_kernels = {k: v for k, v in per_kernel.items() if v['flops'] == 0}
             per_kernel = {k: v for k, v in per_kernel.items() if v['flops'] > 0}

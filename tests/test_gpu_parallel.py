@@ -68,3 +68,51 @@ def test_one_rank_rccl_group_matches_plain_step():
         assert not wrapped.backend._works                                          # every async collective was waited for
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, 'tests', 'golden'), root, os.path.join(root, 'centernet-uda_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)      # two ranks cannot share a GPU under RCCL
+    try:
+        plugin = _plugin(True)
+        data = _batch()
+        # different images per rank (the partition of section 8e): shift the batch of rank 1
+        if rank == 1:
+            data['input'] = data['input'].flip(0).contiguous()
+            data['target_domain_input'] = data['target_domain_input'] * 0.5
+        out = plugin.step(data)
+        arena = plugin.backend.arena
+        q.put((rank, {k: float(v) for k, v in out['stats'].items()},
+               arena.flat_grad.double().abs().sum().item(), arena.flat_param.double().sum().item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_gpu_through_gloo():
+    """World size 2 on the real kernels (both ranks on cuda:0, collective over gloo): after the step both replicas
+    hold the same averaged gradient and the same parameters, although they saw different images."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, s0, g0, w0), (_, s1, g1, w1) = res
+    assert s0['centernet_loss'] != s1['centernet_loss']            # different shards ...
+    assert g0 == g1 and w0 == w1                                   # ... identical gradients and parameters after the exchange
+    assert g0 > 0
