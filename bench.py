@@ -307,10 +307,32 @@ def main():
                                     'launches': v['launches'] // args.profile_steps}
                                 for k, v in sorted(hbm_kernels.items(), key=lambda kv: -kv[1]['ms'])},
             }
+    split_leg = None
+    if world == 1 and not args.no_extras:
+        # the same step with the convolution GEMMs on the bf16 matrix pipe (exact three-way operand split, six
+        # partial products, f32 accumulation: DESIGN.md section 4a); reported beside the headline, never as it
+        import hip_runtime as hr
+        mode0 = hr.get_matrix_mode()
+        if mode0 == 0:
+            hr.set_matrix_mode(1)
+            for _ in range(2):
+                plugin.step(fresh(batch))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                plugin.step(fresh(batch))
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t1
+            hr.set_matrix_mode(mode0)
+            split_leg = {'ms_per_step': round(e1 / args.steps * 1e3, 3),
+                         'value': round(args.batch * args.steps / e1, 3), 'unit': 'images/sec',
+                         'note': 'cnuda_set_matrix_mode(1) for conv forward / input-gradient / DCN column-gradient '
+                                 'GEMMs; weight-gradient and DCN forward GEMMs stay on the f32 MFMA'}
     if world > 1:
         dist.barrier()
 
     if rank == 0:
+        import hip_runtime as hr
         ms = elapsed / args.steps * 1e3
         value = args.batch * world * args.steps / elapsed
         # whole-step algorithmic work: 195.5 GFLOP per forwarded 512x512 image, 2 forwards per source image
@@ -320,7 +342,8 @@ def main():
             else 'images/sec CenterNet DLA-34 %dx%d train step (uda=%s)' % (args.size, args.size, args.uda),
             'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32' if hr.get_matrix_mode() == 0 else 'f32 (bf16 x3 split operands)',
+            'data': 'synthetic', 'matrix_mode': hr.get_matrix_mode(),
             'config': {'workload': '%s: DLA-34 + DCNv2%s, %dx%d, per-GPU batch %d source%s, uda=%s, '
                                    'Adam(lr 5e-5), random-init weights'
                                    % (UDA_WORKLOADS[args.uda][0], ' rotated-box head' if args.uda == 'advent' else '',
@@ -338,6 +361,7 @@ def main():
             if world == 1 and not args.no_extras else None,
             'inference': inference_throughput(device, getattr(plugin.backend, 'module', plugin.backend), args.size,
                                               args.batch) if world == 1 and not args.no_extras else None,
+            'matrix_mode_split': split_leg,
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()

@@ -52,6 +52,10 @@ public:
         }                                        \
     } while (0)
 
+// Matrix-pipe mode of the implicit GEMMs: 0 = f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split operands on the bf16
+// MFMA (igemm.cuh, "X3").  Process-wide; set through cnuda_set_matrix_mode() or CNUDA_MATRIX_MODE at load time.
+int matrix_mode();
+
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // grid cap for grid-stride memory-bound kernels: 256 CUs x 8 resident blocks

@@ -359,8 +359,8 @@ ConvPlan make_plan(const ConvGeom& g) {
     if (z < 1) z = 1;
     q.pix_per_split = ((q.Nf + z - 1) / z + WG_BP - 1) / WG_BP * WG_BP;
     q.Z = (int)((q.Nf + q.pix_per_split - 1) / q.pix_per_split);
-    q.fwd_bytes = carve_bytes((size_t)q.Kpf * q.Mpf, 4) + 256;
-    q.dgrad_bytes = carve_bytes((size_t)q.Kpd * q.Mpd, 4) + 256;
+    q.fwd_bytes = carve_bytes(ig_a_bytes(q.Kpf, q.Mpf), 1) + 256;
+    q.dgrad_bytes = carve_bytes(ig_a_bytes(q.Kpd, q.Mpd), 1) + 256;
     q.wgrad_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) + carve_bytes((size_t)g.Co * g.B, 4) + 256;
     return q;
 }
@@ -372,6 +372,20 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     const int n_tiles = ceil_div(N, IG_BN), m_tiles = Mp / bm;
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
     ProfScope prof(st);
+    if (matrix_mode() == 1) {
+        // the caller's A buffer has ig_a_bytes() of room: split image behind the f32 matrix
+        float* A3 = const_cast<float*>(A) + (size_t)Kp * Mp;
+        hipLaunchKernelGGL(split_a_kernel, dim3(stream_grid((long long)(Kp / 16) * 2 * Mp, 256)), dim3(256), 0, st, A,
+                           reinterpret_cast<u32x4*>(A3), Kp, Mp);
+        A = A3;
+        if (bm == 128)
+            hipLaunchKernelGGL((igemm_fwd_kernel<128, Loader, true>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        else if (bm == 64)
+            hipLaunchKernelGGL((igemm_fwd_kernel<64, Loader, true>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        else
+            hipLaunchKernelGGL((igemm_fwd_kernel<32, Loader, true>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        return check_launch(who);
+    }
     if (bm == 128)
         hipLaunchKernelGGL((igemm_fwd_kernel<128, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
     else if (bm == 64)
@@ -415,7 +429,7 @@ extern "C" int cnuda_conv2d_forward(const float* x, const float* weight, const f
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_conv2d_forward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
-    float* A = cv.take<float>((size_t)q.Kpf * q.Mpf);
+    float* A = reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf)));
     launch_pack(weight, A, Cout, C, q.T, PACK_FWD, q.Kpf, q.Mpf, 0, st);
     ConvFwdParams p{g, x, bias, y, act_slope};
     if (C % IG_BK == 0)
@@ -436,7 +450,7 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.dgrad_bytes, "cnuda_conv2d_backward_data: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
-    float* A = cv.take<float>((size_t)q.Kpd * q.Mpd);
+    float* A = reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpd, q.Mpd)));
     if ((sh > 1 || sw > 1) && H % sh == 0 && W % sw == 0 && Cout % IG_BK == 0 &&
         ceil_div(kh, sh) * ceil_div(kw, sw) <= 9) {   // taps one class can see (tap_r/tap_s hold 9)
         // one launch per parity class, K restricted to the taps that class can see
@@ -458,7 +472,7 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
                 // ntaps == 0 (a class no tap reaches): K is all padding, the kernel writes zeros
                 const int Kc = cp.ntaps * Cout, Kpc = round_up(Kc > 0 ? Kc : IG_KC, IG_KC);
                 const int bm = pick_bm(C, Nc), Mp = round_up(C, bm);
-                CNUDA_REQUIRE((size_t)Kpc * Mp * sizeof(float) + 256 <= workspace_bytes, "cnuda_conv2d_backward_data: workspace");
+                CNUDA_REQUIRE(ig_a_bytes(Kpc, Mp) + 256 <= workspace_bytes, "cnuda_conv2d_backward_data: workspace");
                 launch_pack_taps(weight, A, Cout, C, q.T, taps, cp.ntaps, Kpc, Mp, st);
                 if (int rc = launch_fwd<ConvDgradClassLoader>(bm, cp, A, Mp, Kpc, C, Nc, st, "cnuda_conv2d_backward_data(class)"))
                     return rc;

@@ -90,6 +90,115 @@ __device__ __forceinline__ void ig_mma_chunk(const float* __restrict__ As, const
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Split-operand mode (X3).  Every f32 operand x is cut into three bf16 pieces x = x1 + x2 + x3 by TRUNCATION
+// (8 + 8 + 8 mantissa bits: the cut is exact, no bit of x is dropped) and the product a*b is evaluated on the
+// bf16 MFMA (v_mfma_f32_32x32x16_bf16, f32 accumulate, 16x the f32 MFMA rate) as the six leading partial
+// products a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1; the three dropped ones are below 2^-23 |a*b|, the size of
+// one f32 rounding.  LDS images are [piece][k half][row] of 16-byte cells (8 bf16 = the k positions one lane
+// feeds to the MFMA), so the cell writes and the fragment reads are both lane-consecutive ds_*_b128.
+// K order inside a 16-deep chunk is permuted (position 8h + j holds k = h + 2j, the loaders' own order); A and
+// B use the same permutation, so the sum is unchanged.
+// ---------------------------------------------------------------------------
+using bf16x8 = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;   // one 16-byte cell (a native vector: stays in registers)
+
+// NV floats -> three bf16 pieces each, packed pairwise (NV/2 dwords per piece)
+template <int NV>
+__device__ __forceinline__ void x3_split(const float (&v)[NV], unsigned (&o)[3][NV / 2]) {
+    unsigned pc[3][NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const unsigned u1 = __float_as_uint(v[j]) & 0xFFFF0000u;
+        const float r1 = v[j] - __uint_as_float(u1);             // exact
+        const unsigned u2 = __float_as_uint(r1) & 0xFFFF0000u;
+        const float r2 = r1 - __uint_as_float(u2);               // exact, at most 8 significant bits
+        pc[0][j] = u1; pc[1][j] = u2; pc[2][j] = __float_as_uint(r2);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < NV / 2; ++j)     // low half = element 2j, high half = element 2j+1 (their top 16 bits)
+            o[q][j] = __builtin_amdgcn_perm(pc[q][2 * j + 1], pc[q][2 * j], 0x07060302u);
+}
+
+// operand fragments of one chunk: [tile][piece]
+template <int BM> struct IgFragX3 { u32x4 a[IgTile<BM>::TM][3], b[IgTile<BM>::TN][3]; };
+
+template <int BM>
+__device__ __forceinline__ void ig_read_frag_x3(const u32x4* __restrict__ As, const u32x4* __restrict__ Bs,
+                                                u32x4 (&a)[IgTile<BM>::TM][3], u32x4 (&b)[IgTile<BM>::TN][3],
+                                                int wm_off, int wn_off, int lane) {
+    using T = IgTile<BM>;
+    const int kl = lane >> 5, il = lane & 31;
+    // As: [3][2][BM], Bs: [3][2][IG_BN]; order = the order the MFMAs below first need them in
+#pragma unroll
+    for (int q = 2; q >= 0; --q) {
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i) a[i][q] = As[(q * 2 + kl) * BM + wm_off + i * 32 + il];
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) b[j][2 - q] = Bs[((2 - q) * 2 + kl) * IG_BN + wn_off + j * 32 + il];
+    }
+}
+template <int BM>
+__device__ __forceinline__ void ig_mma_frag_x3(const u32x4 (&a)[IgTile<BM>::TM][3], const u32x4 (&b)[IgTile<BM>::TN][3],
+                                               f32x16 (&acc)[IgTile<BM>::TM][IgTile<BM>::TN]) {
+    using T = IgTile<BM>;
+    auto mm = [&](const u32x4& x, const u32x4& y, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
+    };
+    // smallest partial products first; the tiles rotate so that consecutive MFMAs hit different accumulators
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        constexpr int qa[6] = {2, 1, 0, 1, 0, 0}, qb[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j) mm(a[i][qa[t]], b[j][qb[t]], acc[i][j]);
+    }
+}
+
+// A operand of the X3 kernels: split once per launch by split_a_kernel into 16-byte cells
+//   A3[chunk c][piece q][k half h][m]  = bf16 piece q of A[16c + h + 2j][m], j = 0..7
+// so that a workgroup's A tile of one chunk is 6*BM consecutive-in-m cells copied verbatim to LDS.
+template <int BM> constexpr int ig_a3_per() { return (6 * BM + IG_THREADS - 1) / IG_THREADS; }   // 3 / 2 / 1 cells per thread
+template <int BM>
+__device__ __forceinline__ void ig_load_a_x3(const u32x4* __restrict__ A3, int Mp, int k0, int m0, int tid,
+                                             u32x4 (&r)[ig_a3_per<BM>()]) {
+    const u32x4* base = A3 + (size_t)(k0 >> 4) * 6 * Mp + m0;
+#pragma unroll
+    for (int i = 0; i < ig_a3_per<BM>(); ++i) {
+        const int e = tid + i * IG_THREADS;
+        // (cells past 6*BM: clamp the address, the store below skips them)
+        const int ec = (6 * BM) % IG_THREADS == 0 ? e : (e < 6 * BM ? e : tid);
+        r[i] = base[(size_t)(ec / BM) * Mp + ec % BM];
+    }
+}
+template <int BM>
+__device__ __forceinline__ void ig_store_a_x3(u32x4* __restrict__ As, int tid, const u32x4 (&r)[ig_a3_per<BM>()]) {
+#pragma unroll
+    for (int i = 0; i < ig_a3_per<BM>(); ++i) {
+        const int e = tid + i * IG_THREADS;
+        if ((6 * BM) % IG_THREADS == 0 || e < 6 * BM) As[e] = r[i];
+    }
+}
+static __global__ void split_a_kernel(const float* __restrict__ A, u32x4* __restrict__ A3, int Kp, int Mp) {
+    const long long total = (long long)(Kp / 16) * 2 * Mp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i % Mp), h = (int)(i / Mp) & 1, c = (int)(i / (2 * Mp));
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = A[(size_t)(16 * c + h + 2 * j) * Mp + m];
+        unsigned o[3][4];
+        x3_split<8>(v, o);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) A3[((size_t)(c * 3 + q) * 2 + h) * Mp + m] = u32x4{o[q][0], o[q][1], o[q][2], o[q][3]};
+    }
+}
+// bytes of a packed A operand buffer: the f32 [Kp][Mp] matrix followed by room for its split image
+inline size_t ig_a_bytes(size_t Kp, size_t Mp) { return Kp * Mp * 10; }
+
 // Stage the A tile rows [k0, k0+BK) x cols [m0, m0+BM) of the packed matrix.
 template <int BM>
 __device__ __forceinline__ void ig_load_a(const float* __restrict__ A, int Mp, int k0, int m0, int tid,
@@ -119,14 +228,16 @@ template <class Loader> struct IgRaw<Loader, true> { using type = typename Loade
 //   them into values one chunk later, when the kernel stores that chunk to LDS
 // Epilogue contract:
 //   void store(const Params&, int m, long long n, float value)
-template <int BM, class Loader>
-__global__ __launch_bounds__(IG_THREADS, (BM == 128 ? 3 : 1)) void igemm_fwd_kernel(
+template <int BM, class Loader, bool X3 = false>
+__global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void igemm_fwd_kernel(
     typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
     int n_tiles, int m_tiles) {
     using T = IgTile<BM>;
     // two LDS stages: chunk k+1 is written while chunk k's fragments are still being read, one barrier per chunk
-    __shared__ float As[2][IG_KC * BM];
-    __shared__ float Bs[2][IG_KC * IG_BN];
+    // (X3: three bf16 pieces per operand, 1.5x the bytes)
+    constexpr int LDS_A = X3 ? 3 * 2 * BM * 4 : IG_KC * BM, LDS_B = X3 ? 3 * 2 * IG_BN * 4 : IG_KC * IG_BN;   // floats
+    __shared__ __attribute__((aligned(16))) float As[2][LDS_A];
+    __shared__ __attribute__((aligned(16))) float Bs[2][LDS_B];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wg = xcd_remap(blockIdx.x, n_tiles * m_tiles);
     const int m0 = (wg % m_tiles) * BM;
@@ -148,26 +259,107 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? 3 : 1)) void igemm_fwd_ker
     // Kp is a multiple of IG_KC (the pack kernels zero-pad); the loaders return 0 past the real K
     constexpr int NH = IG_KC / IG_BK;               // loader calls per chunk
     float ra[BM * IG_KC / IG_THREADS], rb[NH][8];
+    u32x4 ra3[ig_a3_per<BM>()];                     // X3: the pre-split A cells of a chunk
     typename IgRaw<Loader, Loader::kHasSideOutput>::type raw[NH];   // two-phase loaders keep raw loads here
     auto stage_store = [&](int buf) {
-        ig_store_a<BM>(As[buf], tid, ra);
+        if constexpr (X3) ig_store_a_x3<BM>(reinterpret_cast<u32x4*>(As[buf]), tid, ra3);
+        else ig_store_a<BM>(As[buf], tid, ra);
         if constexpr (Loader::kHasSideOutput) {
 #pragma unroll
             for (int h = 0; h < NH; ++h) ld.finish(raw[h], rb[h]);
         }
+        if constexpr (X3) {
+            static_assert(NH == 1, "X3 stages one 16-deep MFMA step per chunk");
+            unsigned o[3][4];
+            x3_split<8>(rb[0], o);
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
+            for (int pc = 0; pc < 3; ++pc)
+                reinterpret_cast<u32x4*>(Bs[buf])[(pc * 2 + ksub) * IG_BN + nl] = u32x4{o[pc][0], o[pc][1], o[pc][2], o[pc][3]};
+        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Bs[buf][(h * IG_BK + ksub + 2 * j) * IG_BN + nl] = rb[h][j];
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Bs[buf][(h * IG_BK + ksub + 2 * j) * IG_BN + nl] = rb[h][j];
+        }
     };
     auto stage_load = [&](int k0) {
-        ig_load_a<BM>(A, Mp, k0, m0, tid, ra);
+        if constexpr (X3) ig_load_a_x3<BM>(reinterpret_cast<const u32x4*>(A), Mp, k0, m0, tid, ra3);
+        else ig_load_a<BM>(A, Mp, k0, m0, tid, ra);
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             if constexpr (Loader::kHasSideOutput) ld.load_raw(k0 + h * IG_BK, ksub, raw[h]);
             else ld.load(k0 + h * IG_BK, ksub, rb[h]);
         }
     };
+    if constexpr (X3) {
+        // Fully pipelined: per iteration k a wave (1) issues the LDS reads of chunk k+1's fragments into the spare
+        // register set, (2) runs the MFMAs of chunk k from the set read one iteration ago, (3) splits and stores
+        // chunk k+2 (global loads issued one iteration ago) into the LDS stage chunk k came from (free: its
+        // fragments have been in registers since the last barrier), (4) issues the global loads of chunk k+3; one
+        // barrier.  The body is straight-line (loads past the last chunk are clamped to it and
+        // what they stage is never consumed), so the scheduler may thread (3) through the MFMA stream: an MFMA
+        // holds the SIMD's vector issue for 8 of its 32 cycles, the other 24 take ~6 VALU instructions.
+        const int nchunk = Kp / IG_KC, klast = Kp - IG_KC;
+        auto kclamp = [&](int c) { const int k = c * IG_KC; return k < klast ? k : klast; };
+        auto frag_read = [&](int st, u32x4 (&fa)[T::TM][3], u32x4 (&fb)[T::TN][3]) {
+            ig_read_frag_x3<BM>(reinterpret_cast<const u32x4*>(As[st]), reinterpret_cast<const u32x4*>(Bs[st]), fa, fb,
+                                wm_off, wn_off, lane);
+        };
+        u32x4 fa0[T::TM][3], fb0[T::TN][3], fa1[T::TM][3], fb1[T::TN][3];
+        stage_load(0);
+        stage_store(0);
+        stage_load(kclamp(1));
+        __syncthreads();
+        frag_read(0, fa0, fb0);
+        stage_store(1);
+        stage_load(kclamp(2));
+        __syncthreads();
+        auto step = [&](int c, u32x4 (&ca)[T::TM][3], u32x4 (&cb)[T::TN][3], u32x4 (&na)[T::TM][3], u32x4 (&nb)[T::TN][3]) {
+            frag_read((c + 1) & 1, na, nb);
+            ig_mma_frag_x3<BM>(ca, cb, acc);
+            stage_store(c & 1);
+#pragma unroll
+            for (int i = 0; i < 6 * T::TM * T::TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, BM == 128 ? 3 : (BM == 64 ? 5 : 6), 0);   // VALU beside it
+            }
+            stage_load(kclamp(c + 3));
+            __syncthreads();
+        };
+        // The bf16 MFMA's accumulate does not round to nearest: every step loses a little toward zero (measured
+        // -3e-6 of the result after 2304 coherent K terms, linear in K; the f32 MFMA shows none).  So the MFMAs
+        // accumulate into a partial sum that is folded into the result with rounded f32 adds every X3_FOLD chunks:
+        // the bias then scales with the partial sum's size and stays below one ulp of the result.
+        constexpr int X3_FOLD = 8;
+        f32x16 total[T::TM][T::TN];
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) total[i][j][r] = 0.0f;
+        auto fold = [&]() {
+#pragma unroll
+            for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { total[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.0f; }
+        };
+        int c = 0;
+        for (; c + 1 < nchunk; c += 2) {
+            step(c, fa0, fb0, fa1, fb1);
+            step(c + 1, fa1, fb1, fa0, fb0);
+            if (((c + 2) & (X3_FOLD - 1)) == 0) fold();
+        }
+        if (c < nchunk) ig_mma_frag_x3<BM>(fa0, fb0, acc);
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += total[i][j][r];
+    } else {
     stage_load(0);
     stage_store(0);
     if (IG_KC < Kp) stage_load(IG_KC);
@@ -181,6 +373,7 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? 3 : 1)) void igemm_fwd_ker
         }
         __syncthreads();
         cur ^= 1;
+    }
     }
     // epilogue: lane owns pixel column (lane&31) of each tile
 #pragma unroll

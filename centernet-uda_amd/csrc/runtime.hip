@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "common.h"
+#include <stdlib.h>
 
 namespace cnuda {
 namespace {
@@ -81,6 +82,26 @@ extern "C" int cnuda_prof_collect(int* tags, float* ms, int cap) {
     g_prof_used = 0;
     return n;
 }
+
+namespace cnuda {
+namespace {
+int mode_from_env() {
+    const char* e = getenv("CNUDA_MATRIX_MODE");
+    return (e && e[0] == '1') ? 1 : 0;
+}
+int g_matrix_mode = mode_from_env();
+}  // namespace
+int matrix_mode() { return g_matrix_mode; }
+}  // namespace cnuda
+extern "C" int cnuda_set_matrix_mode(int mode) {
+    if (mode != 0 && mode != 1) {
+        cnuda::set_error("cnuda_set_matrix_mode: mode must be 0 (f32 MFMA) or 1 (split bf16 MFMA), got %d", mode);
+        return CNUDA_ERR_INVALID_ARGUMENT;
+    }
+    cnuda::g_matrix_mode = mode;
+    return 0;
+}
+extern "C" int cnuda_get_matrix_mode(void) { return cnuda::g_matrix_mode; }
 
 extern "C" int cnuda_abi_version(void) { return CNUDA_ABI_VERSION; }
 extern "C" const char* cnuda_last_error(void) { return cnuda::g_error; }

@@ -102,6 +102,8 @@ class _Sig:
     cnuda_gather_feat = (_I, [_P] * 3 + [_I, _I, _I, _LL, _P])
     cnuda_encode_targets = (_I, [_P] * 10 + [_I] * 5 + [_P])
     cnuda_adam_step = (_I, [_P] * 4 + [_LL] + [_F] * 5 + [_I, _P])
+    cnuda_set_matrix_mode = (_I, [_I])
+    cnuda_get_matrix_mode = (_I, [])
     cnuda_prof_enable = (_I, [_I])
     cnuda_prof_arm = (_I, [_I])
     cnuda_prof_collect = (_I, [_P, _P, _I])
@@ -159,6 +161,16 @@ class _Prof:
     cap = 0
 
 
+def set_matrix_mode(mode):
+    """0: f32 MFMA (default).  1: exact three-way bf16 split of every f32 operand, six partial products on the
+    bf16 MFMA, f32 accumulation (include/centernet_uda_hip.h, cnuda_set_matrix_mode).  Process-wide."""
+    check(lib().cnuda_set_matrix_mode(int(mode)), 'set_matrix_mode')
+
+
+def get_matrix_mode():
+    return int(lib().cnuda_get_matrix_mode())
+
+
 def _bm(m, n):
     """mirror of pick_bm() in csrc/conv.hip / dcn.hip (tile rows for M output rows and N pixels)."""
     bm = 128 if m > 64 else (64 if m > 32 else 32)
@@ -211,6 +223,8 @@ def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
         # the two HBM-streaming consumers with their algorithmic bytes
         T, px = kh * kw, B * Ho * Wo
         name = 'igemm_fwd_kernel<%d, ConvFwdLoader<%s>>' % (_bm(T * C, px), tf(Co % 16 == 0))
+        if get_matrix_mode() == 1:
+            name += ' [split bf16 x3]'
         coord_bytes = 4.0 * px * (T * C + 3 * T + 3 * T + 4 * T) + 4.0 * B * C * H * W
         col2im_bytes = 4.0 * px * T * C + 16.0 * px * T * ((C + 15) // 16) + 4.0 * B * C * H * W
         _Prof.table.append([(name, flops, 0.0), ('dcn_coord_grad_kernel', 0.0, coord_bytes),
@@ -219,6 +233,8 @@ def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
         return
     else:
         raise ValueError(kind)
+    if kind in ('conv_fwd', 'conv_dgrad') and name.startswith('igemm_fwd') and get_matrix_mode() == 1:
+        name += ' [split bf16 x3]'
     _Prof.table.append([(name, flops, 0.0)])
     lib().cnuda_prof_arm(len(_Prof.table) - 1)
 

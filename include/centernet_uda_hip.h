@@ -38,6 +38,15 @@ typedef void* cnuda_stream_t; /* hipStream_t */
 int cnuda_abi_version(void);
 const char* cnuda_last_error(void);
 
+/* Matrix-pipe mode of the convolution / DCN implicit GEMMs (process-wide; no counterpart in the reference,
+ * whose cuDNN / cuBLAS calls pick their own algorithm, backends/dla.py:26,34 and dcn_v2_cuda.cu:95-110):
+ *   0  f32 MFMA: exact f32 products and f32 accumulation (default);
+ *   1  every f32 operand is cut exactly into three bf16 pieces and the product is formed from the six leading
+ *      piece products on the bf16 MFMA with f32 accumulation (error per product below 2^-23, one f32 rounding).
+ * Initial value from the environment variable CNUDA_MATRIX_MODE.  Returns 0 or CNUDA_ERR_INVALID_ARGUMENT. */
+int cnuda_set_matrix_mode(int mode);
+int cnuda_get_matrix_mode(void);
+
 /* Measurement aid (bench.py roofline leg), not part of the reference's surface:
  * cnuda_prof_enable(n) pre-creates n hipEvent pairs; cnuda_prof_arm(tag) makes
  * the NEXT convolution / DCN main-kernel launch record a start/stop pair on its
