@@ -199,22 +199,30 @@ static __global__ void split_a_kernel(const float* __restrict__ A, u32x4* __rest
 // bytes of a packed A operand buffer: the f32 [Kp][Mp] matrix followed by room for its split image
 inline size_t ig_a_bytes(size_t Kp, size_t Mp) { return Kp * Mp * 10; }
 
-// Stage the A tile rows [k0, k0+BK) x cols [m0, m0+BM) of the packed matrix.
+// Stage the A tile rows [k0, k0+BK) x cols [m0, m0+BM) of the packed matrix: 16-byte loads and LDS stores
+// (four consecutive m per thread; Mp and m0 are multiples of 32, the buffers 256-byte aligned).
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+template <int BM> constexpr int ig_a_per() { return (BM * IG_KC / 4 + IG_THREADS - 1) / IG_THREADS; }   // 2 / 1 / 1 (half the threads)
 template <int BM>
 __device__ __forceinline__ void ig_load_a(const float* __restrict__ A, int Mp, int k0, int m0, int tid,
-                                          float (&r)[BM * IG_KC / IG_THREADS]) {
-    // KC*BM floats over 256 threads; consecutive threads -> consecutive m
+                                          f32x4 (&r)[ig_a_per<BM>()]) {
+    constexpr int CELLS = BM * IG_KC / 4;
 #pragma unroll
-    for (int i = 0; i < BM * IG_KC / IG_THREADS; ++i) {
+    for (int i = 0; i < ig_a_per<BM>(); ++i) {
         const int e = tid + i * IG_THREADS;
-        const int kk = e / BM, m = e % BM;
-        r[i] = A[(size_t)(k0 + kk) * Mp + m0 + m];
+        const int ec = CELLS % IG_THREADS == 0 ? e : (e < CELLS ? e : e - CELLS);      // idle threads re-read a valid cell
+        const int kk = ec / (BM / 4), m = (ec % (BM / 4)) * 4;
+        r[i] = *reinterpret_cast<const f32x4*>(A + (size_t)(k0 + kk) * Mp + m0 + m);
     }
 }
 template <int BM>
-__device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, const float (&r)[BM * IG_KC / IG_THREADS]) {
+__device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, const f32x4 (&r)[ig_a_per<BM>()]) {
+    constexpr int CELLS = BM * IG_KC / 4;
 #pragma unroll
-    for (int i = 0; i < BM * IG_KC / IG_THREADS; ++i) As[tid + i * IG_THREADS] = r[i];
+    for (int i = 0; i < ig_a_per<BM>(); ++i) {
+        const int e = tid + i * IG_THREADS;
+        if (CELLS % IG_THREADS == 0 || e < CELLS) reinterpret_cast<f32x4*>(As)[e] = r[i];
+    }
 }
 
 // raw-load storage of two-phase loaders (Loader::kHasSideOutput): Loader::Raw, else an empty placeholder
@@ -258,7 +266,8 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void ig
 
     // Kp is a multiple of IG_KC (the pack kernels zero-pad); the loaders return 0 past the real K
     constexpr int NH = IG_KC / IG_BK;               // loader calls per chunk
-    float ra[BM * IG_KC / IG_THREADS], rb[NH][8];
+    f32x4 ra[ig_a_per<BM>()];
+    float rb[NH][8];
     u32x4 ra3[ig_a3_per<BM>()];                     // X3: the pre-split A cells of a chunk
     typename IgRaw<Loader, Loader::kHasSideOutput>::type raw[NH];   // two-phase loaders keep raw loads here
     auto stage_store = [&](int buf) {
