@@ -432,12 +432,13 @@ class _Focal(Function):
                                              float(weight), wp, wn, stream()), 'focal_loss_forward')
         ctx.weight = weight
         ctx.save_for_backward(logits, gt, out2)
-        ctx.mark_non_differentiable(prob)
-        return out2[0].clone(), prob
+        den = out2[1].clone()                      # num_pos
+        ctx.mark_non_differentiable(prob, den)
+        return out2[0].clone(), prob, den
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gloss, _gprob):
+    def backward(ctx, gloss, _gprob, _gden):
         logits, gt, out2 = ctx.saved_tensors
         grad = torch.empty_like(logits)
         up = f32c(gloss.reshape(1))
@@ -446,8 +447,11 @@ class _Focal(Function):
         return grad, None, None
 
 
-def focal_loss(logits, gt, weight=1.0):
-    return _Focal.apply(logits, gt, weight)
+def focal_loss(logits, gt, weight=1.0, return_den=False):
+    """-> (loss, prob[, num_pos]).  num_pos (a device scalar) is the divisor the loss used (0: none, sum of the
+    negative terms only)."""
+    loss, prob, den = _Focal.apply(logits, gt, weight)
+    return (loss, prob, den) if return_den else (loss, prob)
 
 
 class _RegL1(Function):
@@ -468,11 +472,13 @@ class _RegL1(Function):
               'reg_l1_forward')
         ctx.args = (B, M, ch, H * W, 1 if periodic else 0, float(weight), float(angle_weight))
         ctx.save_for_backward(feat, mask, ind, target, out2)
-        return out2[0].clone()
+        den = out2[1].clone()                      # expanded-mask sum + 1e-4
+        ctx.mark_non_differentiable(den)
+        return out2[0].clone(), den
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gloss):
+    def backward(ctx, gloss, _gden):
         feat, mask, ind, target, out2 = ctx.saved_tensors
         grad = torch.empty_like(feat)
         up = f32c(gloss.reshape(1))
@@ -481,9 +487,10 @@ class _RegL1(Function):
         return grad, None, None, None, None, None, None
 
 
-def reg_l1_loss(feat, mask, ind, target, periodic=False, weight=1.0, angle_weight=1.0):
+def reg_l1_loss(feat, mask, ind, target, periodic=False, weight=1.0, angle_weight=1.0, return_den=False):
     # `target` is a plain batch tensor (never requires grad); it is masked in place (Q2).
-    return _RegL1.apply(feat, mask, ind, target, periodic, weight, angle_weight)
+    loss, den = _RegL1.apply(feat, mask, ind, target, periodic, weight, angle_weight)
+    return (loss, den) if return_den else loss
 
 
 class _SoftmaxLoss(Function):

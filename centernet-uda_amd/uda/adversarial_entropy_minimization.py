@@ -62,8 +62,8 @@ class AdversarialEntropyMinimization(Model):
         super().set_phase(is_training)
         self.discriminator.train(is_training)
 
-    def to(self, device, parallel=False):
-        super().to(device, parallel)
+    def to(self, device, parallel=False, global_normalizers=True):
+        super().to(device, parallel, global_normalizers)
         self.discriminator.to(device)
         if parallel:
             from hip_runtime.parallel import DataParallel

@@ -44,11 +44,17 @@ class Model:
     def set_phase(self, is_training=True):
         self.backend.train(is_training)
 
-    def to(self, device, parallel=False):
+    def to(self, device, parallel=False, global_normalizers=True):
+        """parallel: one process per GPU.  global_normalizers (default): the detection loss divides by the
+        num_pos / mask sums of ALL ranks' batches, as the reference's gathered single-process DataParallel loss
+        does (losses/centernet.py DetectionLoss.use_global_normalizers); False: every rank normalises by its
+        own batch (what torch DDP recipes do) and saves the two 12-byte all-reduces per step."""
         self.backend.to(device)
         if parallel:
             from hip_runtime.parallel import DataParallel
             self.backend = DataParallel(self.backend)
+            if global_normalizers and hasattr(self.centernet_loss, 'use_global_normalizers'):
+                self.centernet_loss.use_global_normalizers(self.backend.process_group)
 
     # -- helpers shared by the subclasses --------------------------------------------
     def _to_device(self, data):
