@@ -338,8 +338,8 @@ def main():
         # whole-step algorithmic work: 195.5 GFLOP per forwarded 512x512 image, 2 forwards per source image
         step_tflop = 195.5e9 * (args.size / 512.0) ** 2 * (1 if args.uda == 'none' else 2) * args.batch / 1e12
         line = {
-            'metric': 'images/sec CenterNet DLA-34 512x512 UDA step (entropy minimisation)' if args.uda == 'entropy'
-            else 'images/sec CenterNet DLA-34 %dx%d train step (uda=%s)' % (args.size, args.size, args.uda),
+            'metric': 'images/sec CenterNet DLA-34 512x512 UDA step (entropy minimisation)'
+            if args.uda == 'entropy' and args.size == 512 else 'images/sec CenterNet DLA-34 %dx%d train step (uda=%s)' % (args.size, args.size, args.uda),
             'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32' if hr.get_matrix_mode() == 0 else 'f32 (bf16 x3 split operands)',

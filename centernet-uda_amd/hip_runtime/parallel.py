@@ -6,9 +6,10 @@ Replaces the reference's single-process `CustomDataParallel(nn.DataParallel)`
 (utils/helper.py:75-80; scatter / replicate / gather / ReduceAddCoalesced
 through device 0).  Semantics: each rank owns its own per-GPU batch and its own
 BatchNorm statistics (as DataParallel's replicas do); gradients are averaged
-over ranks (sum / world_size), i.e. the loss normalisers (`num_pos`,
-`mask.sum()`) are per-rank rather than over the gathered global batch --
-DESIGN.md discusses the difference.
+over ranks (sum / world_size).  The reference's loss sees the gathered global
+batch; losses.centernet.DetectionLoss.use_global_normalizers() (the default of
+uda.base.Model.to(parallel=True)) scales every rank's loss so that this average
+is the gradient of that global loss.
 
 Two (or more) backward() calls per step accumulate locally under `no_sync()`;
 buckets fire during the last backward; `finish_gradient_sync()` launches any
