@@ -46,6 +46,17 @@ def _topk(scores, K=40):
 
 
 def decode_detection(heat, wh, reg=None, kps=None, K=100, rotated=False, nms_size=3):
-    if kps is not None:
-        raise NotImplementedError("keypoint decoding (decode.py:69-74) is outside the hot path of this build")
-    return _run(heat, wh, reg, K, rotated, nms_size)[0]
+    """-> detections [B,K,6|7]; with `kps` [B,2J,H,W] also the decoded keypoints [B,K,J,2] (decode.py:69-74)."""
+    dets, inds = _run(heat, wh, reg, K, rotated, nms_size)
+    if kps is None:
+        return dets
+    hr.require_gpu(kps)
+    kps = hr.f32c(kps)
+    B, C, H, W = heat.shape
+    if kps.dim() != 4 or kps.shape[0] != B or tuple(kps.shape[2:]) != (H, W) or kps.shape[1] % 2:
+        raise RuntimeError("decode_detection: kps %s does not match heat %s" % (tuple(kps.shape), tuple(heat.shape)))
+    J = kps.shape[1] // 2
+    out = torch.empty((B, int(K), J, 2), dtype=torch.float32, device=heat.device)
+    hr.check(hr.lib().cnuda_decode_keypoints(hr.ptr(kps), hr.ptr(None if reg is None else hr.f32c(reg)), hr.ptr(inds),
+                                             hr.ptr(out), B, J, int(K), H, W, hr.stream()), 'decode_keypoints')
+    return dets, out

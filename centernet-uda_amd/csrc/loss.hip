@@ -2,7 +2,7 @@
 // Replaces, on device and without host synchronisation:
 //   utils/tensor.py:5-7         _sigmoid (clamp(sigmoid, 1e-4, 1-1e-4))
 //   losses/centernet.py:69-95   FocalLoss._neg_loss (incl. the num_pos == 0 branch, Q11)
-//   losses/centernet.py:98-133  RegL1Loss (+ rotated), :192-223 PeriodicRegL1Loss
+//   losses/centernet.py:98-133  RegL1Loss (+ rotated), :192-223 PeriodicRegL1Loss, :136-189 KPSL1Loss
 //   losses/entropy.py:10-28     EntropyLoss      losses/max_square.py:6-14 MaxSquareLoss
 //   utils/image.py:121-124      entropy_map      losses/advent.py:10-18    BCE-with-logits vs constant
 // Every loss is a pair (forward -> scalar(s) in device memory, backward ->
@@ -314,6 +314,107 @@ __global__ void sigmoid_clamp_kernel(float* __restrict__ x, float* __restrict__ 
         y[i] = fminf(fmaxf(s, kLo), kHi);
     }
 }
+
+// ---------------- keypoint L1 (+ pair-distance term) ----------------
+// losses/centernet.py:136-189 (KPSL1Loss).  feat [B,2J,HW]; mask [B,M,2J] u8; target [B,M,2J] is masked in
+// place like the reference's `target *= mask`; pairs [P][2] keypoint indices (kps_weight_indices) or P = 0.
+//   loss  = sum |pred*m - tg*m| / (sum m + 1e-4) * weight
+//         + sum_{b,m,p} |d(pred_a, pred_b) - d(tg_a, tg_b)| / (sum m + 1e-4) * distance_weight
+//   d = L1 norm (use_l1) or sqrt(|.|^2 + 1e4)  (the literal 1e4 of :178-179)
+// out[0] = loss, out[1] = sum m + 1e-4.  Single workgroup (B*M*2J is tens of thousands at most).
+__device__ __forceinline__ float kps_dist(float ax, float ay, float bx, float by, int use_l1) {
+    const float dx = ax - bx, dy = ay - by;
+    return use_l1 ? fabsf(dx) + fabsf(dy) : sqrtf((dx * dx + dy * dy) + 1e4f);
+}
+__global__ __launch_bounds__(kT) void kpsl1_fwd_kernel(const float* __restrict__ feat, const unsigned char* __restrict__ mask,
+                                                       const long long* __restrict__ ind, float* __restrict__ target,
+                                                       const int* __restrict__ pairs, int B, int M, int J, int HW, int P,
+                                                       int use_l1, float weight, float distance_weight,
+                                                       float* __restrict__ out) {
+    __shared__ double red[16];
+    const int ch = 2 * J;
+    double s_l1 = 0.0, s_m = 0.0, s_d = 0.0;
+    for (int i = threadIdx.x; i < B * M * ch; i += kT) {
+        const int c = i % ch, bm = i / ch, b = bm / M;
+        const float m = mask[i] ? 1.0f : 0.0f;
+        const float pred = feat[((size_t)b * ch + c) * HW + ind[bm]] * m;
+        const float tg = target[i] * m;
+        target[i] = tg;                                   // in place, like the reference
+        s_m += (double)m;
+        s_l1 += (double)fabsf(pred - tg);
+    }
+    __syncthreads();                                      // the pair term reads the masked targets
+    for (int i = threadIdx.x; i < B * M * P; i += kT) {
+        const int pr = i % P, bm = i / P, b = bm / M;
+        const int ja = pairs[2 * pr], jb = pairs[2 * pr + 1];
+        const size_t fb = (size_t)b * ch * HW + ind[bm], tb = (size_t)bm * ch;
+        auto pm = [&](int c) { return feat[fb + (size_t)c * HW] * (mask[tb + c] ? 1.0f : 0.0f); };
+        const float pd = kps_dist(pm(2 * ja), pm(2 * ja + 1), pm(2 * jb), pm(2 * jb + 1), use_l1);
+        const float td = kps_dist(target[tb + 2 * ja], target[tb + 2 * ja + 1], target[tb + 2 * jb], target[tb + 2 * jb + 1], use_l1);
+        s_d += (double)fabsf(pd - td);
+    }
+    s_l1 = block_sum(s_l1, red);
+    s_m = block_sum(s_m, red);
+    s_d = block_sum(s_d, red);
+    if (threadIdx.x == 0) {
+        const float denom = (float)s_m + 1e-4f;
+        float loss = (float)s_l1 / denom * weight;
+        if (P > 0) loss += (float)s_d / denom * distance_weight;
+        out[0] = loss;
+        out[1] = denom;
+    }
+}
+__device__ __forceinline__ float sgnf(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+// scatter-add into a zero-initialised grad [B, 2J, HW]; `target` already masked
+__global__ void kpsl1_bwd_kernel(const float* __restrict__ feat, const unsigned char* __restrict__ mask,
+                                 const long long* __restrict__ ind, const float* __restrict__ target,
+                                 const int* __restrict__ pairs, const float* __restrict__ fwd_out,
+                                 const float* __restrict__ upstream, int B, int M, int J, int HW, int P, int use_l1,
+                                 float weight, float distance_weight, float* __restrict__ grad) {
+    const int ch = 2 * J;
+    const float up = upstream[0] / fwd_out[1];
+    const int n1 = B * M * ch, n2 = B * M * P;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += gridDim.x * blockDim.x) {
+        if (i < n1) {
+            const int c = i % ch, bm = i / ch, b = bm / M;
+            if (!mask[i]) continue;
+            const float pred = feat[((size_t)b * ch + c) * HW + ind[bm]];
+            atomicAdd(grad + ((size_t)b * ch + c) * HW + ind[bm], sgnf(pred - target[i]) * weight * up);
+        } else {
+            const int k = i - n1, pr = k % P, bm = k / P, b = bm / M;
+            const int ja = pairs[2 * pr], jb = pairs[2 * pr + 1];
+            const size_t fb = (size_t)b * ch * HW + ind[bm], tb = (size_t)bm * ch;
+            const int cs[4] = {2 * ja, 2 * ja + 1, 2 * jb, 2 * jb + 1};
+            float mk[4], pv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { mk[t] = mask[tb + cs[t]] ? 1.0f : 0.0f; pv[t] = feat[fb + (size_t)cs[t] * HW] * mk[t]; }
+            const float pd = kps_dist(pv[0], pv[1], pv[2], pv[3], use_l1);
+            const float td = kps_dist(target[tb + cs[0]], target[tb + cs[1]], target[tb + cs[2]], target[tb + cs[3]], use_l1);
+            const float e = sgnf(pd - td) * distance_weight * up;
+            const float dx = pv[0] - pv[2], dy = pv[1] - pv[3];
+            const float gx = use_l1 ? sgnf(dx) : dx / pd, gy = use_l1 ? sgnf(dy) : dy / pd;   // d(pd)/d(a) = -d(pd)/d(b)
+            const float g[4] = {gx, gy, -gx, -gy};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (mk[t] != 0.0f && e * g[t] != 0.0f) atomicAdd(grad + fb + (size_t)cs[t] * HW, e * g[t]);
+        }
+    }
+}
+// keypoint branch of the decode (backends/decode.py:44-51,69-74)
+__global__ void decode_kps_kernel(const float* __restrict__ kps, const float* __restrict__ reg,
+                                  const long long* __restrict__ inds, float* __restrict__ out, int B, int J, int K,
+                                  int H, int W) {
+    const int HW = H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * K * J; i += gridDim.x * blockDim.x) {
+        const int j = i % J, bk = i / J, b = bk / K;
+        const long long id = inds[bk];
+        float xs = (float)(int)(id % W), ys = (float)(int)(id / W);
+        if (reg) { xs += reg[((size_t)b * 2 + 0) * HW + id]; ys += reg[((size_t)b * 2 + 1) * HW + id]; }
+        else { xs += 0.5f; ys += 0.5f; }
+        out[(size_t)i * 2 + 0] = kps[((size_t)b * 2 * J + 2 * j) * HW + id] + xs;
+        out[(size_t)i * 2 + 1] = kps[((size_t)b * 2 * J + 2 * j + 1) * HW + id] + ys;
+    }
+}
 // feat [B,ch,HW], ind [B,M] -> out [B,M,ch]
 __global__ void gather_feat_kernel(const float* __restrict__ feat, const long long* __restrict__ ind,
                                    float* __restrict__ out, int B, int M, int ch, long long HW) {
@@ -377,6 +478,37 @@ extern "C" int cnuda_reg_l1_backward(const float* feat, const uint8_t* mask, con
                        (const long long*)ind, target, out2, upstream, B, M, ch, (int)HW, periodic ? 1 : 0, weight,
                        angle_weight, grad_feat);
     return check_launch("cnuda_reg_l1_backward");
+}
+
+extern "C" int cnuda_kps_l1_forward(const float* feat, const uint8_t* mask, const int64_t* ind, float* target,
+                                    const int32_t* pairs, float* out2, int B, int M, int J, long long HW, int n_pairs,
+                                    int use_l1, float weight, float distance_weight, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(feat && mask && ind && target && out2 && B > 0 && M > 0 && J > 0 && HW > 0 && n_pairs >= 0 &&
+                      (n_pairs == 0 || pairs), "cnuda_kps_l1_forward: bad arguments");
+    hipLaunchKernelGGL(kpsl1_fwd_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, feat, mask, (const long long*)ind,
+                       target, (const int*)pairs, B, M, J, (int)HW, n_pairs, use_l1 ? 1 : 0, weight, distance_weight, out2);
+    return check_launch("cnuda_kps_l1_forward");
+}
+extern "C" int cnuda_kps_l1_backward(const float* feat, const uint8_t* mask, const int64_t* ind, const float* target,
+                                     const int32_t* pairs, const float* out2, const float* upstream, float* grad_feat,
+                                     int B, int M, int J, long long HW, int n_pairs, int use_l1, float weight,
+                                     float distance_weight, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(feat && mask && ind && target && out2 && upstream && grad_feat && B > 0 && M > 0 && J > 0 && HW > 0 &&
+                      n_pairs >= 0 && (n_pairs == 0 || pairs), "cnuda_kps_l1_backward: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(grad_feat, 0, (size_t)B * 2 * J * HW * sizeof(float), st) != hipSuccess)
+        return check_launch("cnuda_kps_l1_backward(memset)");
+    hipLaunchKernelGGL(kpsl1_bwd_kernel, dim3(stream_grid((long long)B * M * (2 * J + n_pairs), kT)), dim3(kT), 0, st, feat,
+                       mask, (const long long*)ind, target, (const int*)pairs, out2, upstream, B, M, J, (int)HW, n_pairs,
+                       use_l1 ? 1 : 0, weight, distance_weight, grad_feat);
+    return check_launch("cnuda_kps_l1_backward");
+}
+extern "C" int cnuda_decode_keypoints(const float* kps, const float* reg, const int64_t* inds, float* out, int B, int J,
+                                      int K, int H, int W, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(kps && inds && out && B > 0 && J > 0 && K > 0 && H > 0 && W > 0, "cnuda_decode_keypoints: bad arguments");
+    hipLaunchKernelGGL(decode_kps_kernel, dim3(stream_grid((long long)B * K * J, kT)), dim3(kT), 0, (hipStream_t)stream,
+                       kps, reg, (const long long*)inds, out, B, J, K, H, W);
+    return check_launch("cnuda_decode_keypoints");
 }
 
 // kind 0: EntropyLoss  = -sum f(v) / (n*h*w*log2 c);  kind 1: MaxSquareLoss = -mean(v^2)/2

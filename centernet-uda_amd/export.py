@@ -28,14 +28,19 @@ class CenterNet(nn.Module):
     @torch.no_grad()
     def forward(self, x):
         out = self.backend(x)
-        if 'kps' in out:
-            raise NotImplementedError("keypoint heads are outside this build")
-        dets = decode_detection(ops.sigmoid_clamp_(out['hm']), out['wh'], out['reg'], K=self.max_detections,
+        has_kps = 'kps' in out
+        dets = decode_detection(ops.sigmoid_clamp_(out['hm']), out['wh'], out['reg'],
+                                kps=out['kps'] if has_kps else None, K=self.max_detections,
                                 rotated=self.is_rotated, nms_size=self.nms)
+        extra = ()
+        if has_kps:
+            dets, kps = dets
+            kps[..., 0:2] *= self.backend.down_ratio
+            extra = (kps,)
         dets[:, :, :4] *= self.backend.down_ratio
         if self.is_rotated:
-            return dets[:, :, :5], dets[:, :, 5], dets[:, :, 6]
-        return dets[:, :, :4], dets[:, :, 4], dets[:, :, 5]
+            return (dets[:, :, :5], dets[:, :, 5], dets[:, :, 6]) + extra
+        return (dets[:, :, :4], dets[:, :, 4], dets[:, :, 5]) + extra
 
 
 def build_model(experiment, model_spec, without_decode_detections, max_detections, nms=3, use_last=True):

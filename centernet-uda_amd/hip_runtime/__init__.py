@@ -92,6 +92,9 @@ class _Sig:
     cnuda_focal_loss_backward = (_I, [_P] * 5 + [_LL, _F, _P])
     cnuda_reg_l1_forward = (_I, [_P] * 5 + [_I, _I, _I, _LL, _I, _F, _F, _P])
     cnuda_reg_l1_backward = (_I, [_P] * 7 + [_I, _I, _I, _LL, _I, _F, _F, _P])
+    cnuda_kps_l1_forward = (_I, [_P] * 6 + [_I, _I, _I, _LL, _I, _I, _F, _F, _P])
+    cnuda_kps_l1_backward = (_I, [_P] * 8 + [_I, _I, _I, _LL, _I, _I, _F, _F, _P])
+    cnuda_decode_keypoints = (_I, [_P] * 4 + [_I] * 5 + [_P])
     cnuda_softmax_loss_forward = (_I, [_P, _P, _I, _I, _LL, _I] + _WS)
     cnuda_softmax_loss_backward = (_I, [_P] * 3 + [_I, _I, _LL, _I, _P])
     cnuda_entropy_map_forward = (_I, [_P, _P, _I, _I, _LL, _P])

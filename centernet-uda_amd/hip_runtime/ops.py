@@ -493,6 +493,50 @@ def reg_l1_loss(feat, mask, ind, target, periodic=False, weight=1.0, angle_weigh
     return (loss, den) if return_den else loss
 
 
+class _KpsL1(Function):
+    @staticmethod
+    def forward(ctx, feat, mask, ind, target, pairs, use_l1, weight, distance_weight):
+        require_gpu(feat, mask, ind, target)
+        feat = f32c(feat)
+        if mask.dtype != torch.uint8 or ind.dtype != torch.int64 or target.dtype != torch.float32:
+            raise RuntimeError("kps_l1: expected kp_reg_mask uint8, ind int64, kps float32 "
+                               "(datasets/coco.py:183-189), got %s/%s/%s" % (mask.dtype, ind.dtype, target.dtype))
+        if not (mask.is_contiguous() and ind.is_contiguous() and target.is_contiguous()):
+            raise RuntimeError("kps_l1: batch tensors must be contiguous (target is updated in place)")
+        B, ch, H, W = feat.shape
+        M = ind.shape[1]
+        if ch % 2 or tuple(target.shape) != (B, M, ch) or tuple(mask.shape) != (B, M, ch):
+            raise RuntimeError("kps_l1: output %s vs kps %s / kp_reg_mask %s"
+                               % (tuple(feat.shape), tuple(target.shape), tuple(mask.shape)))
+        P = 0 if pairs is None else pairs.shape[0]
+        out2 = torch.empty(2, dtype=torch.float32, device=feat.device)
+        ctx.args = (B, M, ch // 2, H * W, P, 1 if use_l1 else 0, float(weight), float(distance_weight))
+        check(lib().cnuda_kps_l1_forward(ptr(feat), ptr(mask), ptr(ind), ptr(target), ptr(pairs), ptr(out2), *ctx.args,
+                                         stream()), 'kps_l1_forward')
+        ctx.pairs = pairs
+        ctx.save_for_backward(feat, mask, ind, target, out2)
+        den = out2[1].clone()
+        ctx.mark_non_differentiable(den)
+        return out2[0].clone(), den
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss, _gden):
+        feat, mask, ind, target, out2 = ctx.saved_tensors
+        grad = torch.empty_like(feat)
+        up = f32c(gloss.reshape(1))
+        check(lib().cnuda_kps_l1_backward(ptr(feat), ptr(mask), ptr(ind), ptr(target), ptr(ctx.pairs), ptr(out2), ptr(up),
+                                          ptr(grad), *ctx.args, stream()), 'kps_l1_backward')
+        return grad, None, None, None, None, None, None, None
+
+
+def kps_l1_loss(feat, mask, ind, target, pairs=None, use_l1=False, weight=1.0, distance_weight=0.1, return_den=False):
+    """KPSL1Loss (losses/centernet.py:136-189); `pairs` an int32 device tensor [P, 2] or None; `target` is masked
+    in place."""
+    loss, den = _KpsL1.apply(feat, mask, ind, target, pairs, use_l1, weight, distance_weight)
+    return (loss, den) if return_den else loss
+
+
 class _SoftmaxLoss(Function):
     @staticmethod
     def forward(ctx, logits, kind):

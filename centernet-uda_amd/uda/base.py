@@ -101,11 +101,15 @@ class Model:
         `outputs['source_domain']['hm']` already holds clamped probabilities because the
         loss rebinds it (Q1)."""
         src = outputs["source_domain"]
-        if 'kps' in src:
-            raise NotImplementedError("keypoint heads are outside this build")
+        has_kps = 'kps' in src
         rotated = bool(self.cfg.model.backend.params.rotated_boxes)
         ratio = self.backend.down_ratio
-        dets = decode_detection(src["hm"], src["wh"], src["reg"], K=self.cfg.max_detections, rotated=rotated)
+        dets = decode_detection(src["hm"], src["wh"], src["reg"], kps=src["kps"] if has_kps else None,
+                                K=self.cfg.max_detections, rotated=rotated)
+        if has_kps:
+            dets, kps = dets
+            kps[..., 0:2] *= ratio
+            kps = kps.detach().cpu().numpy()
         dets = dets.detach().cpu().numpy()
         dets[:, :, :4] *= ratio
         ids = batch["id"].cpu().numpy()
@@ -126,6 +130,10 @@ class Model:
             out['gt_classes'].append(rows[:, cls_col].astype(np.int32))
             out['gt_ids'].append(ids[i])
             out['gt_areas'].append(areas[i, keep[i]])
+        if has_kps:
+            kps_gt = batch['gt_kps'].cpu().numpy() * ratio
+            out['gt_kps'] = [kps_gt[i, keep[i]] for i in range(gt.shape[0])]
+            out['pred_kps'] = kps
         return out
 
     # -- checkpoints ---------------------------------------------------------------

@@ -76,6 +76,10 @@ int cnuda_decode_detection(const float* heat, const float* wh, const float* reg,
                            float* dets, int64_t* inds,
                            int B, int C, int H, int W, int K, int wh_ch, int rotated, int nms_size,
                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+/* keypoint branch (decode.py:69-74): out [B,K,J,2] = kps[b, 2j + {0,1}, inds[b,k]] + (xs, ys) with
+ * xs = inds % W + reg_x, ys = inds / W + reg_y (reg NULL: + 0.5), the centres of decode.py:44-51 */
+int cnuda_decode_keypoints(const float* kps, const float* reg, const int64_t* inds, float* out,
+                           int B, int J, int K, int H, int W, cnuda_stream_t stream);
 /* _nms alone: out = heat * (1 - ceil(maxpool_k(heat) - heat))  (decode.py:6-13) */
 int cnuda_nms(const float* heat, float* out, int B, int C, int H, int W, int nms_size,
               cnuda_stream_t stream);
@@ -239,6 +243,16 @@ int cnuda_reg_l1_backward(const float* feat, const uint8_t* mask, const int64_t*
                           const float* out2, const float* upstream, float* grad_feat,
                           int B, int M, int ch, long long HW, int periodic, float weight, float angle_weight,
                           cnuda_stream_t stream);
+/* KPSL1Loss (losses/centernet.py:136-189): feat [B,2J,HW], mask [B,M,2J] (kp_reg_mask, datasets/coco.py:183,226-227),
+ * target [B,M,2J] masked in place; pairs [n_pairs][2] int32 = kps_weight_indices (NULL / 0: no distance term);
+ * use_l1 selects the L1 pair distance, else sqrt(|.|^2 + 1e4) (:175-179); out2 = {loss, mask.sum() + 1e-4}. */
+int cnuda_kps_l1_forward(const float* feat, const uint8_t* mask, const int64_t* ind, float* target,
+                         const int32_t* pairs, float* out2, int B, int M, int J, long long HW, int n_pairs,
+                         int use_l1, float weight, float distance_weight, cnuda_stream_t stream);
+int cnuda_kps_l1_backward(const float* feat, const uint8_t* mask, const int64_t* ind, const float* target,
+                          const int32_t* pairs, const float* out2, const float* upstream, float* grad_feat,
+                          int B, int M, int J, long long HW, int n_pairs, int use_l1, float weight,
+                          float distance_weight, cnuda_stream_t stream);
 int cnuda_softmax_loss_forward(const float* logits, float* out1, int B, int C, long long HW, int kind,
                                void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 int cnuda_softmax_loss_backward(const float* logits, const float* upstream, float* grad_logits,

@@ -48,6 +48,41 @@ LOSS_CASES = {
 }
 
 
+# keypoint heads (num_keypoints > 0): datasets/coco.py:183-189,226-227 schema
+KPS_CASES = {
+    # name: (B, C, H, W, M, n_obj per image, J, pairs, use_l1, seed)
+    'pairs_l2': (2, 6, 16, 16, 8, (3, 5), 5, [[0, 1], [1, 2], [3, 4], [0, 4]], False, 61),
+    'pairs_l1': (2, 6, 16, 16, 8, (2, 6), 4, [[0, 3], [2, 1]], True, 62),
+    'nopairs':  (2, 6, 12, 12, 6, (4, 0), 3, None, False, 63),
+}
+
+
+def kps_inputs(name):
+    """-> (head outputs incl. 'kps', batch incl. 'kps' / 'kp_reg_mask', DetectionLoss kwargs)."""
+    B, C, H, W, M, n_obj, J, pairs, use_l1, seed = KPS_CASES[name]
+    batch = detection_batch(B, C, H, W, M, n_obj, 2, seed)
+    rs = np.random.RandomState(seed + 500)
+    kp = rs.uniform(-12, 12, (B, M, 2 * J)).astype(np.float32)          # offsets from the centre, masked or not
+    vis = (rs.uniform(0, 1, (B, M, J)) < 0.7)
+    vis &= batch['reg_mask'][:, :, None].astype(bool)                   # invisible / absent keypoints
+    batch['kps'] = kp
+    batch['kp_reg_mask'] = np.repeat(vis, 2, axis=2).astype(np.uint8)
+    out = dict(hm=(rs.standard_normal((B, C, H, W)) * 1.5 - 1.0).astype(np.float32),
+               wh=(rs.standard_normal((B, 2, H, W)) * 3.0).astype(np.float32),
+               reg=rs.standard_normal((B, 2, H, W)).astype(np.float32),
+               kps=(rs.standard_normal((B, 2 * J, H, W)) * 8.0).astype(np.float32))
+    weights = dict(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, kp_weight=0.5, kp_indices=pairs,
+                   kp_distance_weight=0.3, kp_distance_weight_l1=use_l1)
+    return out, batch, weights
+
+
+def decode_kps_inputs(name):
+    """Keypoint maps for the decode fixture `name` (same heat / wh / reg)."""
+    B, C, H, W, K, rotated, with_reg, seed = DECODE_CASES[name]
+    rs = np.random.RandomState(seed + 700)
+    return (rs.standard_normal((B, 2 * 4, H, W)) * 6.0).astype(np.float32)
+
+
 def gaussian_splat(hm, cx, cy, radius):
     """draw_umich_gaussian semantics (utils/image.py:40-57): max-merge of an
     exp(-(x^2+y^2)/(2 sigma^2)) patch, sigma = diameter/6, exact 1.0 at centre."""

@@ -68,8 +68,15 @@ def make_decode():
                                 reg=None if d['reg'] is None else T(d['reg']).clone(),
                                 K=d['K'], rotated=d['rotated'])
         nz = nmsd.numpy() != 0
+        extra = {}
+        if name in ('small', 'noreg'):          # keypoint branch (decode.py:69-74), with and without `reg`
+            d2, kps = decode_detection(heat.clone(), T(d['wh']).clone(),
+                                       reg=None if d['reg'] is None else T(d['reg']).clone(),
+                                       kps=T(gin.decode_kps_inputs(name)).clone(), K=d['K'], rotated=d['rotated'])
+            assert torch.equal(d2, dets)
+            extra['kps'] = kps.numpy()
         save('decode_' + name, dets=dets.numpy(), inds=inds.numpy(), clses=clses.numpy(),
-             nms_nonzero_count=np.array(nz.sum()), nms_sum=np.array(nmsd.double().sum().item()))
+             nms_nonzero_count=np.array(nz.sum()), nms_sum=np.array(nmsd.double().sum().item()), **extra)
 
 
 # ---------------------------------------------------------------------------
@@ -93,6 +100,16 @@ def make_losses():
              hm_after=out_in['hm'].detach().numpy(),            # Q1: sigmoid-clamped in place
              wh_target_after=batch['wh'].numpy(), reg_target_after=batch['reg'].numpy(),  # Q2
              **{'grad_' + k: v.grad.numpy() for k, v in leaves.items()})
+    for name in gin.KPS_CASES:                   # DetectionLoss with the keypoint term (KPSL1Loss)
+        out_np, batch_np, w = gin.kps_inputs(name)
+        out = {k: T(v).clone().requires_grad_(True) for k, v in out_np.items()}
+        leaves = dict(out)
+        out_in = {k: v * 1.0 for k, v in out.items()}
+        batch = {k: T(v).clone() for k, v in batch_np.items()}
+        loss, stats = DetectionLoss(**w)(out_in, batch)
+        loss.backward()
+        save('losses_kps_' + name, loss=loss.item(), **{'stat_' + k: v.item() for k, v in stats.items()},
+             kps_target_after=batch['kps'].numpy(), **{'grad_' + k: v.grad.numpy() for k, v in leaves.items()})
     # UDA losses on raw logits
     rs = np.random.RandomState(31)
     hm = (rs.standard_normal((2, 6, 16, 16)) * 2.0 - 1.0).astype(np.float32)

@@ -34,6 +34,19 @@ def test_decode_golden(golden, name):
     np.testing.assert_allclose(dets, g['dets'], rtol=1e-5, atol=5e-5)               # fp32 tolerance 1e-4 budget
 
 
+@pytest.mark.parametrize('name', ['small', 'noreg'])
+def test_decode_keypoints_golden(golden, name):
+    from backends.decode import decode_detection
+    d = gin.decode_inputs(name)
+    g = golden('decode_' + name)
+    dets, kps = decode_detection(T(d['heat']), T(d['wh']), T(d['reg']), kps=T(gin.decode_kps_inputs(name)), K=d['K'],
+                                 rotated=d['rotated'])
+    np.testing.assert_allclose(dets.cpu().numpy(), g['dets'], rtol=1e-5, atol=5e-5)
+    np.testing.assert_array_equal(kps.cpu().numpy(), g['kps'])          # a gather and one f32 add: bit-exact
+    with pytest.raises(RuntimeError, match='kps'):
+        decode_detection(T(d['heat']), T(d['wh']), T(d['reg']), kps=T(gin.decode_kps_inputs(name))[:, :3], K=d['K'])
+
+
 def test_public_api_matches_oracle_and_has_reference_signature():
     from backends.decode import decode_detection, _nms, _topk
     d = gin.decode_inputs('small')

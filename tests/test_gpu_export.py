@@ -42,6 +42,27 @@ def test_centernet_wrapper_matches_oracle_decode(golden, rotated):
     np.testing.assert_allclose(boxes.cpu().numpy(), want[:, :, :nb], rtol=1e-6, atol=1e-4)
 
 
+def test_centernet_wrapper_with_keypoint_head():
+    """A backend with num_keypoints > 0 adds a 'kps' head (backends/resnet.py build(); export.py:29-54): the wrapper
+    returns a fourth output, the decoded keypoints scaled by down_ratio."""
+    from backends import resnet
+    from export import CenterNet
+    torch.manual_seed(7)
+    backend = resnet.build(18, num_classes=3, num_keypoints=5, pretrained=False).to(DEV).eval()
+    x = torch.randn(2, 3, 64, 64, device=DEV)
+    K = 12
+    boxes, scores, classes, kps = CenterNet(backend, K)(x)
+    assert kps.shape == (2, K, 5, 2) and boxes.shape == (2, K, 4)
+    with torch.no_grad():
+        out = backend(x)
+    assert out['kps'].shape == (2, 10, 16, 16)
+    hm = np.clip(1.0 / (1.0 + np.exp(-out['hm'].double().cpu().numpy())), 1e-4, 1 - 1e-4).astype(np.float32)
+    want, want_kps = oracle_decode.decode_detection(hm, out['wh'].cpu().numpy(), out['reg'].cpu().numpy(), K=K,
+                                                    kps=out['kps'].cpu().numpy())
+    np.testing.assert_array_equal(classes.cpu().numpy(), want[:, :, 5])
+    np.testing.assert_allclose(kps.cpu().numpy(), want_kps * backend.down_ratio, rtol=1e-6, atol=1e-5)
+
+
 def test_build_model_reads_the_experiment_folder(tmp_path):
     from export import CenterNet, build_model
     from utils.helper import save_model

@@ -42,6 +42,43 @@ def test_detection_loss_golden(golden, name):
         assert np.abs(leaves[k].grad.cpu().numpy() - ref).max() <= 1e-4 * scale, k
 
 
+@pytest.mark.parametrize('name', sorted(gin.KPS_CASES))
+def test_keypoint_detection_loss_golden(golden, name):
+    from losses.centernet import DetectionLoss
+    out_np, batch_np, w = gin.kps_inputs(name)
+    g = golden('losses_kps_' + name)
+    leaves = {k: T(v).to(DEV).requires_grad_(True) for k, v in out_np.items()}
+    out = dict(leaves)
+    batch = {k: T(v).clone().to(DEV) for k, v in batch_np.items()}
+    crit = DetectionLoss(**w)
+    assert crit.with_keypoints
+    loss, stats = crit(out, batch)
+    loss.backward()
+    _rel(loss.item(), g['loss'], 1e-5)
+    assert set(stats) == {'centernet_loss', 'hm_loss', 'wh_loss', 'off_loss', 'kp_loss'}
+    for k, v in stats.items():
+        _rel(v.item(), g['stat_' + k], 1e-5)
+    np.testing.assert_allclose(batch['kps'].cpu().numpy(), g['kps_target_after'], rtol=0, atol=0)   # masked in place
+    for k in leaves:
+        ref = g['grad_' + k]
+        scale = max(1e-6, np.abs(ref).max())
+        assert np.abs(leaves[k].grad.cpu().numpy() - ref).max() <= 1e-4 * scale, k
+
+
+def test_keypoint_loss_argument_errors():
+    from losses.centernet import DetectionLoss, KPSL1Loss
+    with pytest.raises(TypeError):
+        DetectionLoss(1.0, 0.1, 1.0, kp_weight=None, kp_indices=[[0, 1]])       # `loss *= None` in the reference
+    out_np, batch_np, w = gin.kps_inputs('nopairs')
+    crit = KPSL1Loss(1.0, [[0, 7]])                                             # J = 3
+    with pytest.raises(IndexError):
+        crit(T(out_np['kps']).to(DEV), T(batch_np['kp_reg_mask']).to(DEV), T(batch_np['ind']).to(DEV),
+             T(batch_np['kps']).to(DEV))
+    with pytest.raises(RuntimeError, match='kp_reg_mask'):
+        KPSL1Loss(1.0)(T(out_np['kps']).to(DEV), T(batch_np['kp_reg_mask']).float().to(DEV), T(batch_np['ind']).to(DEV),
+                       T(batch_np['kps']).to(DEV))
+
+
 def test_uda_losses_golden(golden):
     from losses.entropy import EntropyLoss
     from losses.max_square import MaxSquareLoss

@@ -22,6 +22,16 @@ def test_decode_matches_reference(golden, name):
     assert abs(float(nm.astype(np.float64).sum()) - float(g['nms_sum'])) < 1e-6 * max(1.0, abs(float(g['nms_sum'])))
 
 
+@pytest.mark.parametrize('name', ['small', 'noreg'])
+def test_decode_keypoints_match_reference(golden, name):
+    d = gin.decode_inputs(name)
+    g = golden('decode_' + name)
+    dets, kps = od.decode_detection(d['heat'], d['wh'], d['reg'], K=d['K'], rotated=d['rotated'],
+                                    kps=gin.decode_kps_inputs(name))
+    assert kps.shape == g['kps'].shape == (dets.shape[0], d['K'], 4, 2)
+    np.testing.assert_array_equal(kps, g['kps'])                # one gather and one f32 add per value: exact
+
+
 def test_tie_order_is_score_desc_index_asc():
     heat = np.zeros((1, 2, 4, 4), np.float32)
     heat[0, 1, 1, 1] = 0.5

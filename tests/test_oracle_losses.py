@@ -30,6 +30,27 @@ def test_detection_loss(golden, name):
         np.testing.assert_allclose(batch_np['wh'] * m, g['wh_target_after'], rtol=0, atol=0)
 
 
+@pytest.mark.parametrize('name', sorted(gin.KPS_CASES))
+def test_keypoint_detection_loss(golden, name):
+    """DetectionLoss with the KPSL1Loss term (losses/centernet.py:136-189, :44-49)."""
+    out_np, batch_np, w = gin.kps_inputs(name)
+    g = golden('losses_kps_' + name)
+    out = {k: T(v).clone().requires_grad_(True) for k, v in out_np.items()}
+    batch = {k: T(v).clone() for k, v in batch_np.items()}
+    det, stats, _ = ol.detection_loss(out, batch, hm_weight=w['hm_weight'], wh_weight=w['wh_weight'],
+                                      off_weight=w['off_weight'])
+    kp = ol.kps_l1(out['kps'], batch['kp_reg_mask'], batch['ind'], batch['kps'], w['kp_weight'], w['kp_indices'],
+                   w['kp_distance_weight'], w['kp_distance_weight_l1'])
+    loss = det + kp
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * max(1, abs(float(g['loss'])))
+    assert abs(kp.item() - float(g['stat_kp_loss'])) <= 1e-5 * max(1, abs(float(g['stat_kp_loss'])))
+    assert float(g['stat_centernet_loss']) == float(g['loss'])      # the reference's `loss += kp_loss` is in place
+    for k in out:
+        np.testing.assert_allclose(out[k].grad.numpy(), g['grad_' + k], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(batch_np['kps'] * batch_np['kp_reg_mask'], g['kps_target_after'], rtol=0, atol=0)
+
+
 def test_uda_losses(golden):
     g = golden('losses_uda')
     for tag, fn in (('entropy', ol.entropy_loss), ('maxsq', ol.max_square_loss)):
