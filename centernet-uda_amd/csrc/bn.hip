@@ -36,6 +36,14 @@ Split pick_split(int B, int C, long long HW) {
     return r;
 }
 
+// fused activation code `relu`: 0 none, 1 ReLU, 2 ReLU6 (torchvision MobileNetV2's nn.ReLU6 = hardtanh(0, 6):
+// gradient passes strictly inside (0, 6))
+__device__ __forceinline__ float bn_act(float v, int relu) {
+    v = fmaxf(v, 0.f);
+    return relu == 2 ? fminf(v, 6.f) : v;
+}
+__device__ __forceinline__ bool bn_pass(float y, int relu) { return y > 0.0f && (relu != 2 || y < 6.0f); }
+
 // partial[(c*S + s)*2 + {0,1}] = sum(v), sum(v*w) over one chunk of one (b, c) plane
 // MODE 0: v = x, w = x                       (forward statistics)
 // MODE 1: v = dy', w = xhat                   (backward), dy' = dy * (y > 0) when relu
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
             a1 += v * v;
         } else {
             float g = gv;
-            if (relu && !(yv > 0.0f)) g = 0.0f;
+            if (relu && !bn_pass(yv, relu)) g = 0.0f;
             const float xh = (xv - mu) * is;
             a0 += (double)g;
             a1 += (double)g * (double)xh;
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
                 const float4 r = *reinterpret_cast<const float4*>(residual + base + i);
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
             }
-            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (relu) { v.x = bn_act(v.x, relu); v.y = bn_act(v.y, relu); v.z = bn_act(v.z, relu); v.w = bn_act(v.w, relu); }
             *reinterpret_cast<float4*>(y + base + i) = v;
         }
     } else {
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
             for (long long i = i0; i < i0 + 4 && i < HW; ++i) {
                 float v = x[base + i] * sc + sh;
                 if (residual) v += residual[base + i];
-                if (relu) v = fmaxf(v, 0.f);
+                if (relu) v = bn_act(v, relu);
                 y[base + i] = v;
             }
     }
@@ -194,10 +202,10 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
             float4 g = *reinterpret_cast<const float4*>(dy + base + i);
             if (relu) {
                 const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
-                if (!(yv.x > 0.0f)) g.x = 0.0f;
-                if (!(yv.y > 0.0f)) g.y = 0.0f;
-                if (!(yv.z > 0.0f)) g.z = 0.0f;
-                if (!(yv.w > 0.0f)) g.w = 0.0f;
+                if (!bn_pass(yv.x, relu)) g.x = 0.0f;
+                if (!bn_pass(yv.y, relu)) g.y = 0.0f;
+                if (!bn_pass(yv.z, relu)) g.z = 0.0f;
+                if (!bn_pass(yv.w, relu)) g.w = 0.0f;
             }
             const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
             float4 o;
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
     }
     for (long long i = (long long)blockIdx.y * kBnThreads + threadIdx.x; i < HW; i += (long long)gridDim.y * kBnThreads) {
         float g = dy[base + i];
-        if (relu && !(y[base + i] > 0.0f)) g = 0.0f;
+        if (relu && !bn_pass(y[base + i], relu)) g = 0.0f;
         const float xh = (x[base + i] - mu) * is;
         gx[base + i] = k * (g - m0 - xh * m1);
         if (gres) gres[base + i] = g;
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_eval_kernel(
     for (long long i = (long long)blockIdx.y * kBnThreads + threadIdx.x; i < HW; i += (long long)gridDim.y * kBnThreads) {
         float v = x[base + i] * sc + sh;
         if (residual) v += residual[base + i];
-        if (relu) v = fmaxf(v, 0.f);
+        if (relu) v = bn_act(v, relu);
         y[base + i] = v;
     }
 }

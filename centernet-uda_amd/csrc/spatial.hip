@@ -381,6 +381,102 @@ __global__ void split_offset_mask_bwd_kernel(const float* __restrict__ goff, con
   }
 }
 
+
+// ---------------- depthwise convolution (groups == channels) ----------------
+// torchvision MobileNetV2's `ConvBNReLU(hidden, hidden, stride, groups=hidden)`: y[b,c,oy,ox] =
+// sum_{r,t} w[c,r,t] * x[b,c,oy*s-p+r, ox*s-p+t].  HBM-streaming: one thread per output / input element, the k*k
+// weights of the plane in registers.  Weight gradient: one workgroup per (channel, image) reduces its plane to
+// k*k partial sums (fp64 block reduction), a second kernel adds the images in order (reproducible).
+template <int K>
+__global__ __launch_bounds__(kT) void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
+                                                        int s, int p) {
+    const int c = blockIdx.x % C;
+    const size_t plane = blockIdx.x;
+    float wk[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wk[i] = w[(size_t)c * K * K + i];
+    const float* xp = x + plane * H * W;
+    float* yp = y + plane * Ho * Wo;
+    for (int o = blockIdx.y * kT + threadIdx.x; o < Ho * Wo; o += gridDim.y * kT) {
+        const int oy = o / Wo, ox = o - oy * Wo;
+        float acc = 0.0f;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int iy = oy * s - p + r;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const int ix = ox * s - p + t;
+                if (ix >= 0 && ix < W) acc += wk[r * K + t] * xp[iy * W + ix];
+            }
+        }
+        yp[o] = acc;
+    }
+}
+template <int K>
+__global__ __launch_bounds__(kT) void dwconv_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                             float* __restrict__ gx, int C, int H, int W, int Ho, int Wo,
+                                                             int s, int p) {
+    const int c = blockIdx.x % C;
+    const size_t plane = blockIdx.x;
+    float wk[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) wk[i] = w[(size_t)c * K * K + i];
+    const float* gp = gy + plane * Ho * Wo;
+    float* xp = gx + plane * H * W;
+    for (int i = blockIdx.y * kT + threadIdx.x; i < H * W; i += gridDim.y * kT) {
+        const int iy = i / W, ix = i - iy * W;
+        float acc = 0.0f;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int ty = iy + p - r;
+            if (ty < 0 || ty % s) continue;
+            const int oy = ty / s;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const int tx = ix + p - t;
+                if (tx < 0 || tx % s) continue;
+                const int ox = tx / s;
+                if (ox < Wo) acc += wk[r * K + t] * gp[oy * Wo + ox];
+            }
+        }
+        xp[i] = acc;
+    }
+}
+// part[(c*B + b)*K*K + tap]
+template <int K>
+__global__ __launch_bounds__(kT) void dwconv_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                               float* __restrict__ part, int B, int C, int H, int W,
+                                                               int Ho, int Wo, int s, int p) {
+    __shared__ double red[16];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float* xp = x + ((size_t)b * C + c) * H * W;
+    const float* gp = gy + ((size_t)b * C + c) * Ho * Wo;
+    float acc[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = 0.0f;
+    for (int o = threadIdx.x; o < Ho * Wo; o += kT) {
+        const int oy = o / Wo, ox = o - oy * Wo;
+        const float g = gp[o];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int iy = oy * s - p + r;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                const int ix = ox * s - p + t;
+                if (ix >= 0 && ix < W) acc[r * K + t] += g * xp[iy * W + ix];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) {
+        const double v = block_sum((double)acc[i], red);
+        if (threadIdx.x == 0) part[((size_t)c * B + b) * K * K + i] = (float)v;
+    }
+}
 }  // namespace
 }  // namespace cnuda
 
@@ -450,6 +546,50 @@ extern "C" int cnuda_dwconvt2d_forward(const float* x, const float* w, float* y,
         hipLaunchKernelGGL(dwconvt_fwd_kernel, dim3(ceil_div((long long)Ho * Wo, kT), B * C), dim3(kT), 0,
                            (hipStream_t)stream, x, w, y, C, H, W, Ho, Wo, k, s, p);
     return check_launch("cnuda_dwconvt2d_forward");
+}
+extern "C" size_t cnuda_dwconv2d_workspace_bytes(int B, int C, int k) {
+    return (size_t)(B > 0 ? B : 0) * (C > 0 ? C : 0) * k * k * sizeof(float) + 256;
+}
+static int dwconv_geom(int B, int C, int H, int W, int k, int s, int p, int& Ho, int& Wo, const char* who) {
+    CNUDA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && s > 0 && p >= 0, "%s: bad arguments", who);
+    CNUDA_REQUIRE(k == 3 || k == 5, "%s: kernel size %d (3 and 5 are built)", who, k);
+    CNUDA_REQUIRE((long long)B * C <= 2147483647ll, "%s: too many planes", who);
+    Ho = (H + 2 * p - k) / s + 1;
+    Wo = (W + 2 * p - k) / s + 1;
+    CNUDA_REQUIRE(Ho > 0 && Wo > 0, "%s: empty output", who);
+    return 0;
+}
+extern "C" int cnuda_dwconv2d_forward(const float* x, const float* w, float* y, int B, int C, int H, int W, int k,
+                                      int s, int p, cnuda_stream_t stream) {
+    int Ho, Wo;
+    if (int rc = dwconv_geom(B, C, H, W, k, s, p, Ho, Wo, "cnuda_dwconv2d_forward")) return rc;
+    CNUDA_REQUIRE(x && w && y, "cnuda_dwconv2d_forward: null pointer");
+    const dim3 grid(B * C, ceil_div(ceil_div(Ho * Wo, kT), 4) > 0 ? ceil_div(ceil_div(Ho * Wo, kT), 4) : 1);
+    if (k == 3) hipLaunchKernelGGL(dwconv_fwd_kernel<3>, grid, dim3(kT), 0, (hipStream_t)stream, x, w, y, C, H, W, Ho, Wo, s, p);
+    else hipLaunchKernelGGL(dwconv_fwd_kernel<5>, grid, dim3(kT), 0, (hipStream_t)stream, x, w, y, C, H, W, Ho, Wo, s, p);
+    return check_launch("cnuda_dwconv2d_forward");
+}
+extern "C" int cnuda_dwconv2d_backward(const float* x, const float* w, const float* grad_y, float* grad_x, float* grad_w,
+                                       int B, int C, int H, int W, int k, int s, int p, void* workspace,
+                                       size_t workspace_bytes, cnuda_stream_t stream) {
+    int Ho, Wo;
+    if (int rc = dwconv_geom(B, C, H, W, k, s, p, Ho, Wo, "cnuda_dwconv2d_backward")) return rc;
+    CNUDA_REQUIRE(x && w && grad_y, "cnuda_dwconv2d_backward: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (grad_x) {
+        const dim3 grid(B * C, ceil_div(ceil_div(H * W, kT), 4) > 0 ? ceil_div(ceil_div(H * W, kT), 4) : 1);
+        if (k == 3) hipLaunchKernelGGL(dwconv_bwd_data_kernel<3>, grid, dim3(kT), 0, st, grad_y, w, grad_x, C, H, W, Ho, Wo, s, p);
+        else hipLaunchKernelGGL(dwconv_bwd_data_kernel<5>, grid, dim3(kT), 0, st, grad_y, w, grad_x, C, H, W, Ho, Wo, s, p);
+    }
+    if (grad_w) {
+        CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_dwconv2d_workspace_bytes(B, C, k), "cnuda_dwconv2d_backward: workspace too small");
+        CNUDA_REQUIRE(C <= 2147483647 && B <= 65535, "cnuda_dwconv2d_backward: batch > 65535");
+        float* part = (float*)workspace;
+        if (k == 3) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<3>, dim3(C, B), dim3(kT), 0, st, x, grad_y, part, B, C, H, W, Ho, Wo, s, p);
+        else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<5>, dim3(C, B), dim3(kT), 0, st, x, grad_y, part, B, C, H, W, Ho, Wo, s, p);
+        hipLaunchKernelGGL(dwconvt_wsum_kernel, dim3(ceil_div((long long)C * k * k, 256)), dim3(256), 0, st, part, grad_w, B, C, k * k);
+    }
+    return check_launch("cnuda_dwconv2d_backward");
 }
 extern "C" size_t cnuda_dwconvt2d_workspace_bytes(int B, int C, int k) {
     return (size_t)(B > 0 ? B : 0) * (C > 0 ? C : 0) * k * k * sizeof(float) + 256;

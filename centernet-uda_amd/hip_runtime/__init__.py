@@ -82,6 +82,9 @@ class _Sig:
     cnuda_dwconvt2d_forward = (_I, [_P] * 3 + [_I] * 7 + [_P])
     cnuda_dwconvt2d_workspace_bytes = (c_size_t, [_I] * 3)
     cnuda_dwconvt2d_backward = (_I, [_P] * 5 + [_I] * 7 + _WS)
+    cnuda_dwconv2d_workspace_bytes = (c_size_t, [_I] * 3)
+    cnuda_dwconv2d_forward = (_I, [_P] * 3 + [_I] * 7 + [_P])
+    cnuda_dwconv2d_backward = (_I, [_P] * 5 + [_I] * 7 + _WS)
     cnuda_add = (_I, [_P] * 3 + [_LL, _P])
     cnuda_act_backward = (_I, [_P] * 3 + [_LL, _F, _P])
     cnuda_copy_channels = (_I, [_P, _P, _I, _I, _LL, _I, _I, _I, _I, _P])

@@ -107,6 +107,21 @@ class DepthwiseConvTranspose2d(nn.Module):
         return ops.depthwise_conv_transpose2d(x, self.weight, self.stride, self.padding)
 
 
+class DepthwiseConv2d(nn.Module):
+    """nn.Conv2d(C, C, k, stride, padding, groups=C, bias=False); weight [C,1,k,k] (torchvision MobileNetV2)."""
+
+    def __init__(self, channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        self.channels, self.kernel_size, self.stride, self.padding = channels, kernel_size, stride, padding
+        self.in_channels = self.out_channels = channels
+        self.weight = nn.Parameter(torch.empty(channels, 1, kernel_size, kernel_size))
+        with torch.no_grad():
+            self.weight.uniform_(-1.0 / kernel_size, 1.0 / kernel_size)
+
+    def forward(self, x):
+        return ops.depthwise_conv2d(x, self.weight, self.stride, self.padding)
+
+
 class Slot(nn.Module):
     """Parameter-free placeholder that keeps Sequential indices aligned with the
     reference's module lists (e.g. the ReLU at index 1 of a head, dla.py:476-483)."""

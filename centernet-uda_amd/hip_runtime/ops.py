@@ -159,6 +159,15 @@ def conv_transpose2d(x, weight, stride=1, padding=0, output_padding=0):
 # ---------------------------------------------------------------------------
 # batch norm (+ residual add + ReLU)
 # ---------------------------------------------------------------------------
+def _act_code(relu):
+    """fused activation of the BN kernels: False / True (ReLU) / 6 (ReLU6)"""
+    if relu is True or relu is False or relu is None:
+        return 1 if relu else 0
+    if relu == 6:
+        return 2
+    raise ValueError("batch_norm_act: relu must be False, True or 6, got %r" % (relu,))
+
+
 class _BatchNormAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, num_batches_tracked):
@@ -175,7 +184,7 @@ class _BatchNormAct(Function):
         check(L.cnuda_bn_train_forward(ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(mean), ptr(invstd),
                                        ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), float(momentum),
                                        float(eps),
-                                       1 if relu else 0, B, C, HW, wp, wn, stream()), 'bn_train_forward')
+                                       _act_code(relu), B, C, HW, wp, wn, stream()), 'bn_train_forward')
         ctx.relu, ctx.dims, ctx.has_res = relu, (B, C, HW), residual is not None
         ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd, beta)
         return y
@@ -193,7 +202,7 @@ class _BatchNormAct(Function):
         L = lib()
         wp, wn = _ws(L.cnuda_bn_workspace_bytes(B, C, HW), x)
         check(L.cnuda_bn_backward(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), ptr(gx), ptr(gres),
-                                  ptr(gg_buf), ptr(gb_buf), 1 if ctx.relu else 0, B, C, HW, wp, wn, stream()),
+                                  ptr(gg_buf), ptr(gb_buf), _act_code(ctx.relu), B, C, HW, wp, wn, stream()),
               'bn_backward')
         return gx, gg, gb, gres, None, None, None, None, None, None
 
@@ -218,7 +227,7 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum
     HW = x.numel() // (B * C)
     y = torch.empty_like(x)
     check(lib().cnuda_bn_eval_forward(ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-                                      ptr(residual), ptr(y), float(eps), 1 if relu else 0, B, C, HW, stream()),
+                                      ptr(residual), ptr(y), float(eps), _act_code(relu), B, C, HW, stream()),
           'bn_eval_forward')
     return y
 
@@ -318,6 +327,43 @@ class _DwConvT(Function):
 
 def depthwise_conv_transpose2d(x, weight, stride, padding):
     return _DwConvT.apply(x, weight, int(stride), int(padding))
+
+
+class _DwConv(Function):
+    """Depthwise convolution (groups == channels), weight [C,1,k,k], no bias."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        require_gpu(x, weight)
+        x, weight = f32c(x), f32c(weight)
+        B, C, H, W = x.shape
+        k = weight.shape[2]
+        if weight.shape[0] != C or weight.shape[1] != 1 or weight.shape[3] != k:
+            raise RuntimeError("depthwise conv2d: weight %s does not fit %d channels" % (tuple(weight.shape), C))
+        Ho, Wo = (H + 2 * padding - k) // stride + 1, (W + 2 * padding - k) // stride + 1
+        y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+        check(lib().cnuda_dwconv2d_forward(ptr(x), ptr(weight), ptr(y), B, C, H, W, k, stride, padding, stream()),
+              'dwconv2d_forward')
+        ctx.geom = (B, C, H, W, k, stride, padding)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw_buf, gw = _param_grad(weight, ctx.needs_input_grad[1])
+        L = lib()
+        B, C, _, _, k = ctx.geom[:5]
+        wp, wn = _ws(L.cnuda_dwconv2d_workspace_bytes(B, C, k), x)
+        check(L.cnuda_dwconv2d_backward(ptr(x), ptr(weight), ptr(f32c(gy)), ptr(gx), ptr(gw_buf), *ctx.geom,
+                                        wp, wn, stream()), 'dwconv2d_backward')
+        return gx, gw, None, None
+
+
+def depthwise_conv2d(x, weight, stride=1, padding=0):
+    return _DwConv.apply(x, weight, int(stride), int(padding))
 
 
 class _Add(Function):

@@ -163,7 +163,8 @@ int cnuda_conv2d_backward_weight(const float* x, const float* grad_y, float* gra
 /* ------------------------------------------------------------------------
  * BatchNorm2d fused with the residual add and ReLU that follow it in DLA-34
  * (backends/dla.py:48-62,150-168,277-287,351-372; nn.BatchNorm2d(momentum=0.1)).
- * x, y, residual: [B, C, HW].  residual may be NULL; relu != 0 applies max(.,0).
+ * x, y, residual: [B, C, HW].  residual may be NULL; relu: 0 none, 1 max(.,0), 2 ReLU6 = min(max(.,0),6)
+ * (gradient strictly inside (0,6), torch's hardtanh backward).
  * train_forward updates running_mean/var in place (unbiased variance, may be
  * NULL) and saves mean / invstd for backward.  backward: grad_y is the gradient
  * w.r.t. y (post-activation); y is needed only when relu != 0; grad_residual
@@ -209,6 +210,15 @@ size_t cnuda_dwconvt2d_workspace_bytes(int B, int C, int k);   /* per-image part
 int cnuda_dwconvt2d_backward(const float* x, const float* w, const float* grad_y, float* grad_x, float* grad_w,
                              int B, int C, int H, int W, int k, int s, int p,
                              void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+/* Depthwise convolution, weight [C,1,k,k] (k = 3 or 5), no bias -- torchvision MobileNetV2's
+ * `nn.Conv2d(hidden, hidden, 3, stride, 1, groups=hidden, bias=False)` inside backends/mobilenetv2.py:31-36's hub
+ * trunk.  backward writes grad_x and/or grad_w (either may be NULL); grad_w needs the workspace. */
+size_t cnuda_dwconv2d_workspace_bytes(int B, int C, int k);
+int cnuda_dwconv2d_forward(const float* x, const float* w, float* y, int B, int C, int H, int W, int k, int s, int p,
+                           cnuda_stream_t stream);
+int cnuda_dwconv2d_backward(const float* x, const float* w, const float* grad_y, float* grad_x, float* grad_w,
+                            int B, int C, int H, int W, int k, int s, int p,
+                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 int cnuda_add(const float* a, const float* b, float* out, long long n, cnuda_stream_t stream);
 int cnuda_act_backward(const float* grad_y, const float* y, float* grad_x, long long n, float slope,
                        cnuda_stream_t stream);

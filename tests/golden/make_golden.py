@@ -495,6 +495,79 @@ def make_resnet():
 
 
 # ---------------------------------------------------------------------------
+MBV2_CASES = [('dcn', dict(use_dcn=True, use_skip=False), 2, 64, 95), ('skip', dict(use_dcn=False, use_skip=True), 2, 96, 96)]
+MBV2_GRAD_PROBES = {
+    'dcn': ['base.0.0.weight', 'base.1.conv.0.0.weight', 'base.3.conv.1.0.weight', 'base.7.conv.2.weight',
+            'base.14.conv.3.bias', 'base.18.0.weight', 'deconv_layers.0.weight', 'deconv_layers.0.conv_offset_mask.weight',
+            'deconv_layers.6.bias', 'deconv_layers.9.weight', 'deconv_layers.16.weight', 'hm.0.weight', 'wh.2.bias'],
+    'skip': ['base.0.0.weight', 'base.6.conv.1.0.weight', 'base.13.conv.2.weight', 'base.17.conv.3.weight',
+             'deconv_layers.0.weight', 'deconv_layers.3.weight', 'deconv_layers.7.weight', 'skip_0.weight', 'skip_3.bias',
+             'reg.0.weight', 'hm.2.bias'],
+}
+
+
+def _import_reference_mobilenetv2():
+    """backends/mobilenetv2.py with `torch.hub.load` (a GitHub download of pytorch/vision v0.6.0, :31-34) bound to
+    the oracle's restated torchvision trunk, and the native `_ext` bound to the CPU DCN oracle (as for dla)."""
+    from oracle import mobilenetv2 as oracle_mb
+    ext = types.ModuleType('_ext')
+    ext.dcn_v2_forward = oracle_dcn.dcn_v2_forward
+    ext.dcn_v2_backward = oracle_dcn.dcn_v2_backward
+    sys.modules['_ext'] = ext
+    torch.hub.load = lambda repo, name, pretrained=False, **kw: oracle_mb.torchvision_mobilenet_v2()
+    from backends import mobilenetv2
+    return mobilenetv2
+
+
+def _mbv2_case(mb, tag, flags, B, S, seed, dtype):
+    model = mb.build(num_classes=6, pretrained=False, **flags)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes).items()})   # conv_offset_mask filled non-zero (Q7)
+    model = model.to(dtype)
+    x = T(gin.image_batch(B, S, S, seed)).to(dtype)
+    res = {}
+    model.eval()
+    with torch.no_grad():
+        out = model(x)
+    for k in out:
+        res['eval_' + k] = out[k].numpy()
+    model.train()
+    out = model(x)
+    res['head_order'] = np.array(list(out.keys()))
+    for k in out:
+        res['train_' + k] = out[k].detach().numpy()
+    scalar = sum((out[k] * torch.cos(torch.arange(out[k].numel(), dtype=dtype)
+                                     .reshape(out[k].shape) * 0.1)).sum() for k in out)
+    scalar.backward()
+    res['scalar'] = scalar.item()
+    params = dict(model.named_parameters())
+    for n in MBV2_GRAD_PROBES[tag]:
+        res['gradsum__' + n] = _checksums(params[n].grad)
+    sd2 = model.state_dict()
+    for n in ('base.0.1', 'base.5.conv.1.1', 'base.18.1', 'deconv_layers.1'):
+        res['rm__' + n] = sd2[n + '.running_mean'].numpy()
+        res['rv__' + n] = sd2[n + '.running_var'].numpy()
+        res['nbt__' + n] = sd2[n + '.num_batches_tracked'].numpy()
+    meta = {'state_names': np.array(list(shapes)), 'param_names': np.array([n for n, _ in model.named_parameters()]),
+            'n_params': sum(p.numel() for p in model.parameters()),
+            'shapes_json': np.array(repr(sorted((k, v) for k, v in shapes.items())))}
+    return res, meta
+
+
+def make_mobilenetv2():
+    mb = _import_reference_mobilenetv2()
+    for tag, flags, B, S, seed in MBV2_CASES:
+        r32, meta = _mbv2_case(mb, tag, flags, B, S, seed, torch.float32)
+        r64, _ = _mbv2_case(mb, tag, flags, B, S, seed, torch.float64)
+        out = dict(meta)
+        out.update(r32)
+        for k, v in r64.items():
+            if k.startswith(('eval_', 'train_', 'gradsum__', 'scalar')):
+                out['f64_' + k] = v
+        save('mbv2_' + tag, **out)
+
+
+# ---------------------------------------------------------------------------
 def make_targets():
     """datasets/coco.py:191-221 re-enacted with the reference's own utils/image.py functions (the dataset class
     itself needs pycocotools / imgaug / cv2; utils/image.py is imported with empty stand-ins for its unused
@@ -537,13 +610,15 @@ def make_targets():
 
 if __name__ == '__main__':
     oracle_dcn.build()
-    which = set(sys.argv[1:]) or {'decode', 'losses', 'dla', 'step', 'advent', 'resnet', 'targets'}
+    which = set(sys.argv[1:]) or {'decode', 'losses', 'dla', 'step', 'advent', 'resnet', 'targets', 'mobilenetv2'}
     if 'decode' in which:
         make_decode()
     if 'resnet' in which:
         make_resnet()
     if 'targets' in which:
         make_targets()
+    if 'mobilenetv2' in which:
+        make_mobilenetv2()
     if 'losses' in which or 'advent' in which:
         _load_entropy_map()
     if 'losses' in which:
