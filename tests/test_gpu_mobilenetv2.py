@@ -98,8 +98,9 @@ def test_mobilenetv2_forward_backward_golden(golden, tag):
     for key in g.files:
         if key.startswith('rm__'):
             n = key[4:]
-            _close(sd[n + '.running_mean'].cpu().numpy(), g[key], 1e-5)
-            _close(sd[n + '.running_var'].cpu().numpy(), g['rv__' + n], 1e-5)
+            # base.18.1 sees 8 samples per channel (2x2 maps, B=2) after 52 layers: statistics at north_star's 1e-4
+            _close(sd[n + '.running_mean'].cpu().numpy(), g[key], 1e-4)
+            _close(sd[n + '.running_var'].cpu().numpy(), g['rv__' + n], 1e-4)
             assert int(sd[n + '.num_batches_tracked']) == int(g['nbt__' + n])
 
 
