@@ -12,7 +12,7 @@ for C in ('FETCH_SIZE','WRITE_SIZE'):
     agg=collections.defaultdict(lambda:[0.0,0])
     for r in csv.DictReader(open(f)):
         if r['Counter_Name']!=C: continue
-        n=r['Kernel_Name'].replace('cnuda::(anonymous namespace)::','').replace('cnuda::','').split('(')[0].replace('void ','')
+        n=r['Kernel_Name'].replace('cnuda::(anonymous namespace)::','').replace('cnuda::','').split('(')[0].replace('void ','').replace(', false>','>')
         agg[n][0]+=float(r['Counter_Value']); agg[n][1]+=1
     res[C]=agg
 names=sorted(res['FETCH_SIZE'], key=lambda n:-res['FETCH_SIZE'][n][0])[:40]
