@@ -1,0 +1,136 @@
+"""MI355X: randomised geometry sweeps of the convolution / transposed-convolution / depthwise / DCN entry points
+against CPU torch (the primitives the oracle is built from).  Seeds are fixed: the cases are the same on every
+run; they exist to catch tile-edge and padding-class mistakes that the hand-picked shapes miss.  1e-4 of scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _close(a, b, tol=1e-4, what=''):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, b.abs().max().item())
+    assert (a - b).abs().max().item() <= tol * scale, (what, (a - b).abs().max().item(), scale)
+
+
+def _conv_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        k = int(rs.choice([1, 1, 3, 3, 3, 4, 5, 7]))
+        s = int(rs.choice([1, 1, 1, 2, 2, 3]))
+        p = int(rs.randint(0, k // 2 + 1))
+        B, C, Co = int(rs.randint(1, 4)), int(rs.choice([1, 3, 5, 16, 17, 32, 48, 64, 70, 130])), int(rs.choice([1, 2, 6, 16, 27, 33, 64, 96, 140]))
+        H, W = int(rs.randint(1, 23)), int(rs.randint(1, 23))
+        if (H + 2 * p - k) // s + 1 < 1 or (W + 2 * p - k) // s + 1 < 1 or H + 2 * p < k or W + 2 * p < k:
+            continue
+        out.append((B, C, H, W, Co, k, s, p, bool(rs.randint(2)), float(rs.choice([-1.0, -1.0, 0.0, 0.2]))))
+    return out
+
+
+@pytest.mark.parametrize('case', _conv_cases(48, 1234), ids=lambda c: 'B%dC%dH%dW%dCo%dk%ds%dp%d%s%s' % (c[:8] + ('b' if c[8] else '', 'a' if c[9] >= 0 else '')))
+@pytest.mark.parametrize('mode', [0, 1])
+def test_conv2d_random_geometry(case, mode):
+    import hip_runtime as hr
+    from hip_runtime import ops
+    B, C, H, W, Co, k, s, p, bias, act = case
+    g = torch.Generator().manual_seed(hash(case) % 100000)
+    x = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5).requires_grad_(True)
+    b = torch.randn(Co, generator=g).requires_grad_(True) if bias else None
+    y = F.conv2d(x, w, b, s, p)
+    if act >= 0:
+        y = F.leaky_relu(y, act)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    before = hr.get_matrix_mode()
+    hr.set_matrix_mode(mode)
+    try:
+        dx, dw = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+        db = b.detach().to(DEV).requires_grad_(True) if bias else None
+        dy = ops.conv2d(dx, dw, db, s, p, act)
+        dy.backward(gy.to(DEV))
+    finally:
+        hr.set_matrix_mode(before)
+    _close(dy, y, what='y')
+    _close(dx.grad, x.grad, what='gx')
+    _close(dw.grad, w.grad, what='gw')
+    if bias:
+        _close(db.grad, b.grad, what='gb')
+
+
+def _convt_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        k, s = int(rs.choice([2, 3, 4, 4])), int(rs.choice([1, 2, 2]))
+        p = int(rs.randint(0, (k - 1) // 2 + 1))
+        op = int(rs.randint(0, s))
+        B, Ci, Co = int(rs.randint(1, 3)), int(rs.choice([3, 16, 20, 64, 130])), int(rs.choice([2, 16, 24, 64, 96]))
+        H, W = int(rs.randint(1, 12)), int(rs.randint(1, 12))
+        if (H - 1) * s - 2 * p + k + op < 1 or (W - 1) * s - 2 * p + k + op < 1:
+            continue
+        out.append((B, Ci, Co, H, W, k, s, p, op))
+    return out
+
+
+@pytest.mark.parametrize('case', _convt_cases(16, 77), ids=lambda c: 'B%dCi%dCo%dH%dW%dk%ds%dp%dop%d' % c)
+def test_conv_transpose2d_random_geometry(case):
+    from hip_runtime import ops
+    B, Ci, Co, H, W, k, s, p, op = case
+    g = torch.Generator().manual_seed(hash(case) % 100000)
+    x = torch.randn(B, Ci, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Ci, Co, k, k, generator=g) / (Ci * k * k / (s * s)) ** 0.5).requires_grad_(True)
+    y = F.conv_transpose2d(x, w, None, s, p, op)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    dx, dw = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    dy = ops.conv_transpose2d(dx, dw, s, p, op)
+    dy.backward(gy.to(DEV))
+    _close(dy, y, what='y')
+    _close(dx.grad, x.grad, what='gx')
+    _close(dw.grad, w.grad, what='gw')
+
+
+def _dcn_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        B, C, Co = int(rs.randint(1, 3)), int(rs.choice([2, 8, 16, 24, 64, 80])), int(rs.choice([2, 4, 16, 27, 64, 72]))
+        H, W = int(rs.randint(1, 15)), int(rs.randint(1, 15))
+        s = int(rs.choice([1, 1, 2]))
+        dg = int(rs.choice([1, 1, 1, 2])) if C % 2 == 0 else 1
+        out.append((B, C, Co, H, W, s, dg, float(rs.choice([0.3, 1.0, 3.0]))))
+    return out
+
+
+@pytest.mark.parametrize('case', _dcn_cases(20, 4321), ids=lambda c: 'B%dC%dCo%dH%dW%ds%ddg%dsig%g' % c)
+def test_dcn_random_geometry_vs_oracle(case):
+    import _ext
+    from oracle import dcn as od
+    od.build()
+    B, C, Co, H, W, s, dg, sigma = case
+    rs = np.random.RandomState(hash(case) % 100000)
+    Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    if Ho < 1 or Wo < 1:
+        pytest.skip('empty output')
+    x = T(rs.standard_normal((B, C, H, W)).astype(np.float32))
+    w = T((rs.standard_normal((Co, C, 3, 3)) / (3 * C ** 0.5)).astype(np.float32))
+    b = T(rs.standard_normal(Co).astype(np.float32))
+    off = T((rs.standard_normal((B, 18 * dg, Ho, Wo)) * sigma).astype(np.float32))
+    m = T(rs.uniform(0, 1, (B, 9 * dg, Ho, Wo)).astype(np.float32))
+    gy = T(rs.standard_normal((B, Co, Ho, Wo)).astype(np.float32))
+    geom = (3, 3, s, s, 1, 1, 1, 1, dg)
+    want_y = od.dcn_v2_forward(x, w, b, off, m, *geom)
+    want = od.dcn_v2_backward(x, w, b, off, m, gy, *geom)
+    d = [t.to(DEV) for t in (x, w, b, off, m)]
+    got_y = _ext.dcn_v2_forward(*d, *geom)
+    got = _ext.dcn_v2_backward(*d, gy.to(DEV), *geom)
+    _close(got_y, want_y, what='y')
+    for name, a, r in zip(('gx', 'goff', 'gmask', 'gw', 'gb'), got, want):
+        _close(a, r, what=name)
