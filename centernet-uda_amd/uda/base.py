@@ -95,6 +95,30 @@ class Model:
         outputs["stats"] = self._detach_stats(stats)
         return outputs
 
+    def step_with_target_term(self, data, is_training, target_term):
+        """The step shared by the single-loss UDA plugins (uda/entropy_minimization.py:11-43,
+        uda/max_squares_minimization.py:11-50): source and target batch both go through the backend in train
+        mode (two BatchNorm updates, Q6); `target_term(target_outputs, data) -> (weighted loss, stats)`; the
+        detection loss and the target term are back-propagated separately and their gradients add up (Q5), the
+        gradient exchange of a parallel run fires during the second pass only."""
+        self._to_device(data)
+        if is_training:
+            self.optimizer.zero_grad()
+        outputs = {name: self.backend(data[key])
+                   for name, key in (("source_domain", "input"), ("target_domain", "target_domain_input"))}
+        det_loss, stats = self.centernet_loss(outputs["source_domain"], data)
+        uda_loss, uda_stats = target_term(outputs["target_domain"], data)
+        if is_training:
+            with self._defer_sync():
+                det_loss.backward()
+            uda_loss.backward()
+            self._finish_backward()
+            self.optimizer.step()
+        stats = dict(stats, **uda_stats)
+        stats["total_loss"] = det_loss + uda_loss
+        outputs["stats"] = self._detach_stats(stats)
+        return outputs
+
     # -- evaluation --------------------------------------------------------------
     def get_detections(self, outputs, batch):
         """Decoded predictions and per-image ground truth as numpy (uda/base.py:73-139).

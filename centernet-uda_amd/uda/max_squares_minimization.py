@@ -1,36 +1,26 @@
-"""Max-squares UDA step (uda/max_squares_minimization.py:6-50): like entropy
-minimisation with MaxSquareLoss on the target domain (weight applied in place, Q4)."""
-from uda.base import Model
+"""Max-squares UDA plugin (uda/max_squares_minimization.py:6-50): detection loss on the source batch plus
+`max_squares_weight` x MaxSquareLoss of the target batch (weight applied in place, Q4).  The step itself is
+uda.base.Model.step_with_target_term."""
 from losses.max_square import MaxSquareLoss
+from uda.base import Model
 
 
 class MaxSquaresMinimization(Model):
     def __init__(self, max_squares_weight):
         super().__init__()
-        self.max_squares_loss = MaxSquareLoss()
         self.max_squares_weight = max_squares_weight
+        self.max_squares_loss = MaxSquareLoss()
+
+    def _target_term(self, target_outputs, data):
+        loss, stats = self.max_squares_loss(target_outputs, data)
+        loss *= self.max_squares_weight       # in place: `stats` holds the same tensor
+        return loss, stats
 
     def criterion(self, outputs, batch):
-        s_loss, s_stats = self.centernet_loss(outputs["source_domain"], batch)
-        t_loss, t_stats = self.max_squares_loss(outputs["target_domain"], batch)
-        t_loss *= self.max_squares_weight
-        return s_loss, t_loss, {**s_stats, **t_stats}
+        """(source loss, weighted target loss, merged stats): the reference's method of this name (:11-20)"""
+        det_loss, stats = self.centernet_loss(outputs["source_domain"], batch)
+        uda_loss, uda_stats = self._target_term(outputs["target_domain"], batch)
+        return det_loss, uda_loss, dict(stats, **uda_stats)
 
     def step(self, data, is_training=True):
-        self._to_device(data)
-        if is_training:
-            self.optimizer.zero_grad()
-        outputs = {
-            "source_domain": self.backend(data["input"]),
-            "target_domain": self.backend(data["target_domain_input"]),
-        }
-        s_loss, t_loss, stats = self.criterion(outputs, data)
-        if is_training:
-            with self._defer_sync():
-                s_loss.backward()
-            t_loss.backward()
-            self._finish_backward()
-            self.optimizer.step()
-        stats["total_loss"] = s_loss + t_loss
-        outputs["stats"] = self._detach_stats(stats)
-        return outputs
+        return self.step_with_target_term(data, is_training, self._target_term)

@@ -12,12 +12,11 @@ def _sigmoid(x):
 
 
 def _gather_feat(feat, ind, mask=None):
-    dim = feat.size(2)
-    idx = ind.unsqueeze(2).expand(ind.size(0), ind.size(1), dim)
-    feat = feat.gather(1, idx)
-    if mask is not None:
-        feat = feat[mask.unsqueeze(2).expand_as(feat)].view(-1, dim)
-    return feat
+    """feat [B,N,ch], ind [B,M] -> rows ind of feat, [B,M,ch]; with a boolean `mask` [B,M] only the selected rows,
+    flattened to [n,ch] (tensor.py:10-18).  Host-side helper on torch indexing; the kernels use
+    `_transpose_and_gather_feat`."""
+    rows = torch.take_along_dim(feat, ind[:, :, None], dim=1)
+    return rows if mask is None else rows[mask.bool()]
 
 
 def _transpose_and_gather_feat(feat, ind):
