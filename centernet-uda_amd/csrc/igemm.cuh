@@ -99,7 +99,8 @@ __device__ __forceinline__ void ig_mma_chunk(const float* __restrict__ As, const
 // one f32 rounding.  LDS images are [piece][k half][row] of 16-byte cells (8 bf16 = the k positions one lane
 // feeds to the MFMA), so the cell writes and the fragment reads are both lane-consecutive ds_*_b128.
 // K order inside a 16-deep chunk is permuted (position 8h + j holds k = h + 2j, the loaders' own order); A and
-// B use the same permutation, so the sum is unchanged.
+// B use the same permutation, so the sum is unchanged.  A non-finite operand turns into NaN (inf - inf in the
+// cut) where the f32 MFMA would give inf or NaN: finite inputs only, like everything else on this path.
 // ---------------------------------------------------------------------------
 using bf16x8 = __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;   // one 16-byte cell (a native vector: stays in registers)
@@ -123,9 +124,7 @@ __device__ __forceinline__ void x3_split(const float (&v)[NV], unsigned (&o)[3][
             o[q][j] = __builtin_amdgcn_perm(pc[q][2 * j + 1], pc[q][2 * j], 0x07060302u);
 }
 
-// operand fragments of one chunk: [tile][piece]
-template <int BM> struct IgFragX3 { u32x4 a[IgTile<BM>::TM][3], b[IgTile<BM>::TN][3]; };
-
+// operand fragments of one chunk are u32x4 [tile][piece]
 template <int BM>
 __device__ __forceinline__ void ig_read_frag_x3(const u32x4* __restrict__ As, const u32x4* __restrict__ Bs,
                                                 u32x4 (&a)[IgTile<BM>::TM][3], u32x4 (&b)[IgTile<BM>::TN][3],
