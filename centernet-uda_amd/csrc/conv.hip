@@ -9,6 +9,7 @@
 // K axis order is (tap, channel): within one 16-deep K chunk the tap is constant
 // whenever C % 16 == 0 (every layer but the 3-channel stem), so the bounds test
 // and address of a gathered element are computed once per chunk.
+#include <stdlib.h>
 #include "igemm.cuh"
 #include "igemm_host.h"
 
@@ -384,6 +385,20 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
             hipLaunchKernelGGL((igemm_fwd_kernel<64, Loader, true>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         else
             hipLaunchKernelGGL((igemm_fwd_kernel<32, Loader, true>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        return check_launch(who);
+    }
+    // wave-specialised variant (igemm.cuh), opt-in through CNUDA_WS=1: +4-8 % on the 64- and 128-row tiles of the
+    // 128..512-channel layers, neutral on the 64-channel ones, -2-4 % on the 32-row tile; < 1 % on the whole step
+    // (measured), so the 4-wave kernel stays the default this round
+    static const int ws_env = getenv("CNUDA_WS") ? atoi(getenv("CNUDA_WS")) : 0;
+    if (ws_env == 1) {
+        const dim3 block2(2 * IG_THREADS);
+        if (bm == 128)
+            hipLaunchKernelGGL((igemm_fwd_ws_kernel<128, Loader>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        else if (bm == 64)
+            hipLaunchKernelGGL((igemm_fwd_ws_kernel<64, Loader>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        else
+            hipLaunchKernelGGL((igemm_fwd_ws_kernel<32, Loader>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         return check_launch(who);
     }
     if (bm == 128)

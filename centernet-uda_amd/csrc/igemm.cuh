@@ -400,6 +400,90 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void ig
 }
 
 // ---------------------------------------------------------------------------
+// Wave-specialised variant of the f32 forward-type kernel: 8 waves per workgroup.  Waves 4-7 (threads 256..511) are
+// PRODUCERS -- they run the Loader, stage the next chunk's A and B tiles into LDS and issue the loads after it;
+// waves 0-3 are CONSUMERS -- fragment reads and MFMAs only, each owning the same TM x TN tiles as in
+// igemm_fwd_kernel.  Every SIMD then hosts vector/memory-only waves next to matrix-only waves, which the hardware
+// runs concurrently, instead of waves that alternate between the two kinds of work.  Same LDS image, same two
+// stages, one barrier per chunk (all 8 waves); the two roles never hold registers at the same time, so the
+// kernel needs fewer registers than the 4-wave one (78 vs 113 for the 128-row tile).
+// ---------------------------------------------------------------------------
+template <int BM, class Loader>
+__global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd_ws_kernel(
+    typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
+    int n_tiles, int m_tiles) {
+    using T = IgTile<BM>;
+    __shared__ __attribute__((aligned(16))) float As[2][IG_KC * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][IG_KC * IG_BN];
+    const bool producer = threadIdx.x >= IG_THREADS;            // wave-uniform
+    const int tid = threadIdx.x & (IG_THREADS - 1), lane = tid & 63, wid = tid >> 6;
+    const int wg = xcd_remap(blockIdx.x, n_tiles * m_tiles);
+    const int m0 = (wg % m_tiles) * BM;
+    const long long n0 = (long long)(wg / m_tiles) * IG_BN;
+    if (producer) {
+        const int nl = tid & (IG_BN - 1), ksub = tid >> 7;
+        Loader ld(p, n0 + nl, n0 + nl < N);
+        if constexpr (Loader::kHasSideOutput) { if (m0 != 0) ld.disable_col(); }
+        f32x4 ra[ig_a_per<BM>()];
+        float rb[8];
+        typename IgRaw<Loader, Loader::kHasSideOutput>::type raw;
+        auto stage_store = [&](int buf) {
+            ig_store_a<BM>(As[buf], tid, ra);
+            if constexpr (Loader::kHasSideOutput) ld.finish(raw, rb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Bs[buf][(ksub + 2 * j) * IG_BN + nl] = rb[j];
+        };
+        auto stage_load = [&](int k0) {
+            ig_load_a<BM>(A, Mp, k0, m0, tid, ra);
+            if constexpr (Loader::kHasSideOutput) ld.load_raw(k0, ksub, raw);
+            else ld.load(k0, ksub, rb);
+        };
+        stage_load(0);
+        stage_store(0);
+        if (IG_KC < Kp) stage_load(IG_KC);
+        __syncthreads();
+        int cur = 0;
+        for (int k0 = 0; k0 < Kp; k0 += IG_KC) {
+            if (k0 + IG_KC < Kp) {
+                stage_store(cur ^ 1);
+                if (k0 + 2 * IG_KC < Kp) stage_load(k0 + 2 * IG_KC);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+        return;
+    }
+    const int wm_off = (wid / T::WN) * (T::TM * 32), wn_off = (wid % T::WN) * (T::TN * 32);
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < Kp; k0 += IG_KC) {
+        ig_mma_chunk<BM>(As[cur], Bs[cur], acc, wm_off, wn_off, lane);
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const long long n = n0 + wn_off + j * 32 + (lane & 31);
+        if (n >= N) continue;
+        typename Loader::Out out(p, n);
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm_off + i * 32 + mfma_row(r, lane);
+                if (m < M) out.store(p, m, acc[i][j][r]);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Weight-gradient-type kernel:  D[m][j] = sum_n  G[m][n] * B[j][n]
 // (m = output channel, j = column of the packed K axis, n = pixel).  The pixel
 // range is split over blockIdx.z; every workgroup writes one fp32 partial slab
