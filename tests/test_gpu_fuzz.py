@@ -134,3 +134,72 @@ def test_dcn_random_geometry_vs_oracle(case):
     _close(got_y, want_y, what='y')
     for name, a, r in zip(('gx', 'goff', 'gmask', 'gw', 'gb'), got, want):
         _close(a, r, what=name)
+
+
+def _bn_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    return [(int(rs.randint(1, 5)), int(rs.choice([1, 3, 16, 27, 64, 130])), int(rs.randint(1, 20)), int(rs.randint(1, 20)),
+             [False, True, 6][int(rs.randint(3))], bool(rs.randint(2))) for _ in range(n)]
+
+
+@pytest.mark.parametrize('case', _bn_cases(24, 99), ids=lambda c: 'B%dC%dH%dW%dact%sres%d' % (c[0], c[1], c[2], c[3], c[4], c[5]))
+def test_batch_norm_random_geometry(case):
+    from hip_runtime import ops
+    B, C, H, W, act, res = case
+    if B * H * W < 2:
+        pytest.skip('one value per channel (torch raises too)')
+    g = torch.Generator().manual_seed(hash(case) % 100000)
+    x = (torch.randn(B, C, H, W, generator=g) * 3 + 1).requires_grad_(True)
+    gamma = (1 + 0.3 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (1 + torch.randn(C, generator=g)).requires_grad_(True)
+    r = torch.randn(B, C, H, W, generator=g).requires_grad_(True) if res else None
+    rm, rv = torch.randn(C, generator=g) * 0.1, 1 + 0.3 * torch.rand(C, generator=g)
+    rm_d, rv_d = rm.clone().to(DEV), rv.clone().to(DEV)
+    y = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    y = y + r if res else y
+    y = F.relu6(y) if act == 6 else (F.relu(y) if act else y)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    lx, lg, lb = [t.detach().to(DEV).requires_grad_(True) for t in (x, gamma, beta)]
+    lr = r.detach().to(DEV).requires_grad_(True) if res else None
+    dy = ops.batch_norm_act(lx, lg, lb, rm_d, rv_d, True, 0.1, 1e-5, lr, act)
+    dy.backward(gy.to(DEV))
+    _close(dy, y, what='y')
+    _close(lx.grad, x.grad, what='gx')
+    _close(lg.grad, gamma.grad, what='ggamma')
+    _close(lb.grad, beta.grad, what='gbeta')
+    if res:
+        _close(lr.grad, r.grad, what='gres')
+    _close(rm_d, rm, 1e-5, 'running_mean')
+    _close(rv_d, rv, 1e-5, 'running_var')
+
+
+def _decode_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        B, C, H, W = int(rs.randint(1, 4)), int(rs.choice([1, 2, 6, 20, 80])), int(rs.randint(2, 70)), int(rs.randint(2, 70))
+        K = int(rs.randint(1, min(H * W, 200) + 1))
+        out.append((B, C, H, W, K, bool(rs.randint(2)), bool(rs.randint(2)), int(rs.randint(1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize('case', _decode_cases(24, 555), ids=lambda c: 'B%dC%dH%dW%dK%drot%dreg%d' % c[:7])
+def test_decode_random_geometry_vs_oracle(case):
+    from backends import decode as hd
+    from oracle import decode as od
+    B, C, H, W, K, rotated, with_reg, seed = case
+    rs = np.random.RandomState(seed)
+    heat = np.unique(rs.uniform(1e-4, 1 - 1e-4, 4 * B * C * H * W).astype(np.float32))      # tie-free scores
+    assert heat.size >= B * C * H * W
+    heat = rs.permutation(heat)[:B * C * H * W].reshape(B, C, H, W)
+    wh = rs.uniform(1, 50, (B, 3 if rotated else 2, H, W)).astype(np.float32)
+    reg = rs.uniform(0, 1, (B, 2, H, W)).astype(np.float32) if with_reg else None
+    want, winds, wcls = od.decode_detection(heat, wh, reg, K=K, rotated=rotated, return_inds=True)
+    dev = lambda a: None if a is None else T(a).to(DEV)
+    dets, inds = hd._run(dev(heat), dev(wh), dev(reg), K, rotated, 3)
+    assert np.array_equal(inds.cpu().numpy(), winds)
+    cc = 6 if rotated else 5
+    assert np.array_equal(dets[..., cc].cpu().numpy().astype(np.int32), wcls)
+    assert np.array_equal(dets[..., cc - 1].cpu().numpy(), want[..., cc - 1])
+    np.testing.assert_allclose(dets.cpu().numpy(), want, rtol=1e-5, atol=5e-5)
