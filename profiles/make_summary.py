@@ -50,5 +50,11 @@ if s:
 c = line.get('cpu_baseline')
 if c:
     out.append('CPU baseline (`kind: %s`): %.4f img/s on %d host threads (%s).\n' % (c['kind'], c['value'], c['cores'], c['sample'][:110]))
+m = os.path.join(HERE, 'r1_pmc_mfma.md')
+if os.path.exists(m):
+    out.append('MFMA-pipe utilisation per kernel from PMC (`profiles/collect_pmc_mfma.sh`: `--pmc SQ_VALU_MFMA_BUSY_CYCLES '
+               'GRBM_GUI_ACTIVE` over two steps; busy cycles / (1024 SIMDs x active cycles per XCD), i.e. against the clock the '
+               'chip actually held):\n')
+    out.append(open(m).read())
 open(os.path.join(HERE, 'r1_final_summary.md'), 'w').write('\n'.join(out))
 print('\n'.join(out[:8]))
