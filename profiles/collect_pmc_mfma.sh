@@ -23,7 +23,7 @@ out = {n: {'launches': a[3], 'ms': a[2] / 1e6, 'mfma_busy_cycles': a[0], 'gui_ac
            'mfma_util': a[0] / (1024.0 * a[1] / 8.0), 'clock_ghz': (a[1] / 8.0) / a[2] if a[2] else None} for n, a in rows}
 go = os.path.dirname(root)
 json.dump(out, open(go + '/pmc_mfma.json', 'w'), indent=1)
-md = ['| kernel | launches (2 steps) | ms | MFMA pipe busy | clock held (GHz) |', '|---|---|---|---|---|']
+md = ['| kernel | launches (2 steps) | ms | MFMA pipe busy | active cycles per XCD ÷ kernel time (GHz, indicative) |', '|---|---|---|---|---|']
 for n, v in out.items():
     md.append('| `%s` | %d | %.2f | %.1f %% | %.2f |' % (n[:80], v['launches'], v['ms'], 100 * v['mfma_util'], v['clock_ghz']))
 open(go + '/pmc_mfma.md', 'w').write('\n'.join(md) + '\n')
