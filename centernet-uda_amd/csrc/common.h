@@ -55,6 +55,9 @@ public:
 // Matrix-pipe mode of the implicit GEMMs: 0 = f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split operands on the bf16
 // MFMA (igemm.cuh, "X3").  Process-wide; set through cnuda_set_matrix_mode() or CNUDA_MATRIX_MODE at load time.
 int matrix_mode();
+// Wave-specialised (producer / consumer, 8-wave) variants of the f32 implicit-GEMM kernels for the 64- and 128-row
+// tiles: on unless CNUDA_WS=0 (read once).  +3-8 % per launch where it applies, ~1.2 % of the benched step.
+bool wave_specialised();
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 

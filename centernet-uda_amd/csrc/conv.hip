@@ -387,11 +387,9 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
             hipLaunchKernelGGL((igemm_fwd_kernel<32, Loader, true>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         return check_launch(who);
     }
-    // wave-specialised variant (igemm.cuh), opt-in through CNUDA_WS=1: +4-8 % on the 64- and 128-row tiles of the
-    // 128..512-channel layers, neutral on the 64-channel ones, -2-4 % on the 32-row tile; < 1 % on the whole step
-    // (measured), so the 4-wave kernel stays the default this round
-    static const int ws_env = getenv("CNUDA_WS") ? atoi(getenv("CNUDA_WS")) : 0;
-    if (ws_env == 1) {
+    // wave-specialised variant (igemm.cuh): +4-8 % on the 64- and 128-row tiles of the 128..512-channel layers,
+    // neutral on the 64-channel ones, -2-4 % on the 32-row tile, which therefore keeps the 4-wave kernel
+    if (wave_specialised() && bm >= 64) {
         const dim3 block2(2 * IG_THREADS);
         if (bm == 128)
             hipLaunchKernelGGL((igemm_fwd_ws_kernel<128, Loader>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
@@ -525,7 +523,15 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
         ProfScope prof(st);
         const dim3 grid(q.Jp / q.wbj, q.Mpw / q.wbm, q.Z), blk(IG_THREADS);
         const bool fast = C % 64 == 0;
-        if (q.wbm == 64) {
+        if (wave_specialised() && fast && q.wbm == 64) {
+            const dim3 blk2(2 * IG_THREADS);
+            if (q.wbj == 128)
+                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWLoader<2>, 64, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else
+                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWLoader<2>, 64, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+        } else if (q.wbm == 64) {
             if (fast && q.wbj == 128)
                 hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<2>, 64, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);

@@ -590,4 +590,102 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
         }
 }
 
+// Wave-specialised weight-gradient kernel (see igemm_fwd_ws_kernel): threads 256..511 run the two loaders and the
+// LDS stores, threads 0..255 only read fragments and issue MFMAs.  Same tiles, LDS image and slab output as
+// igemm_wgrad_kernel.
+template <class WLoader, int BM, int BJ>
+__global__ __launch_bounds__(2 * IG_THREADS) void igemm_wgrad_ws_kernel(
+    typename WLoader::Params p, float* __restrict__ slabs, int Mp, int Jp, long long N, long long pix_per_split) {
+    constexpr int GLD = BM + 1, BLD = BJ + 1;
+    constexpr int STEP = IG_THREADS / WG_BP;
+    constexpr int TJ = (BM / 32) * (BJ / 32) / 4;
+    constexpr int WJ = BJ / 32 / TJ, NG = BM / STEP, NB = BJ / STEP;
+    __shared__ float Gs[2][WG_BP * GLD];
+    __shared__ float Bs[2][WG_BP * BLD];
+    const bool producer = threadIdx.x >= IG_THREADS;            // wave-uniform
+    const int tid = threadIdx.x & (IG_THREADS - 1), lane = tid & 63, wid = tid >> 6;
+    const int j0 = blockIdx.x * BJ, m0 = blockIdx.y * BM;
+    const long long n_begin = (long long)blockIdx.z * pix_per_split;
+    long long n_end = n_begin + pix_per_split;
+    if (n_end > N) n_end = N;
+    if (producer) {
+        const int pl = tid % WG_BP, sub = tid / WG_BP;
+        WLoader ld(p, n_begin + pl, n_end);
+        float rg[NG], rb[NB];
+        auto stage_store = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < NG; ++i) Gs[buf][pl * GLD + sub + STEP * i] = rg[i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) Bs[buf][pl * BLD + sub + STEP * i] = rb[i];
+        };
+        auto stage_load = [&]() {
+            ld.template load_g<NG, STEP>(m0, sub, rg);
+            ld.template load_b<NB, STEP>(j0, sub, rb);
+        };
+        stage_load();
+        stage_store(0);
+        if (n_begin + WG_BP < n_end) { ld.advance(); stage_load(); }
+        __syncthreads();
+        int cur = 0;
+        for (long long nb = n_begin; nb < n_end; nb += WG_BP) {
+            if (nb + WG_BP < n_end) {
+                stage_store(cur ^ 1);
+                if (nb + 2 * WG_BP < n_end) { ld.advance(); stage_load(); }
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+        return;
+    }
+    const int wm_off = (wid / WJ) * 32, wj_off = (wid % WJ) * 32 * TJ;
+    f32x16 acc[TJ];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    __syncthreads();
+    int cur = 0;
+    const int kl = lane >> 5, il = lane & 31;
+    for (long long nb = n_begin; nb < n_end; nb += WG_BP) {
+        const float* gp = Gs[cur] + kl * GLD + wm_off + il;
+        const float* bp = Bs[cur] + kl * BLD + wj_off + il;
+        float a[2][2], b[2][2][TJ];
+        auto frag = [&](int kk, float (&fa)[2], float (&fb)[2][TJ]) {
+            fa[0] = gp[kk * GLD]; fa[1] = gp[(kk + 2) * GLD];
+#pragma unroll
+            for (int t = 0; t < TJ; ++t) { fb[0][t] = bp[kk * BLD + t * 32]; fb[1][t] = bp[(kk + 2) * BLD + t * 32]; }
+        };
+        auto mma = [&](const float (&fa)[2], const float (&fb)[2][TJ]) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < TJ; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h], fb[h][t], acc[t], 0, 0, 0);
+        };
+        frag(0, a[0], b[0]);
+#pragma unroll
+        for (int kk = 0; kk < WG_BP; kk += 8) {
+            frag(kk + 4, a[1], b[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a[0], b[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 8 < WG_BP) frag(kk + 8, a[0], b[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a[1], b[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* slab = slabs + (size_t)blockIdx.z * Mp * Jp;
+#pragma unroll
+    for (int t = 0; t < TJ; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm_off + mfma_row(r, lane);
+            const int j = j0 + wj_off + t * 32 + (lane & 31);
+            slab[(size_t)m * Jp + j] = acc[t][r];
+        }
+}
+
 }  // namespace cnuda

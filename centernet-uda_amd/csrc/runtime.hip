@@ -92,6 +92,10 @@ int mode_from_env() {
 int g_matrix_mode = mode_from_env();
 }  // namespace
 int matrix_mode() { return g_matrix_mode; }
+bool wave_specialised() {
+    static const bool on = !(getenv("CNUDA_WS") && getenv("CNUDA_WS")[0] == '0');
+    return on;
+}
 }  // namespace cnuda
 extern "C" int cnuda_set_matrix_mode(int mode) {
     if (mode != 0 && mode != 1) {

@@ -186,6 +186,19 @@ def _bm(m, n):
     return bm
 
 
+def _ws():
+    """mirror of wave_specialised() in csrc/runtime.hip"""
+    return os.environ.get('CNUDA_WS', '1')[:1] != '0'
+
+
+def _fwd_name(bm, loader):
+    """kernel template instance launch_fwd() picks (csrc/conv.hip): the 8-wave producer / consumer variant for the
+    64- and 128-row tiles in matrix mode 0, the 4-wave kernel otherwise"""
+    if get_matrix_mode() == 1:
+        return 'igemm_fwd_kernel<%d, %s> [split bf16 x3]' % (bm, loader)
+    return ('igemm_fwd_ws_kernel<%d, %s>' if (_ws() and bm >= 64) else 'igemm_fwd_kernel<%d, %s>') % (bm, loader)
+
+
 def _smallc(C, Co, kh, kw, stride):
     return stride == 1 and C <= 16 and Co <= 32 and C * kh * kw <= 148 and C * (3 + kh) <= 96
 
@@ -203,22 +216,23 @@ def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
         if _smallc(C, Co, kh, kw, stride):
             name = 'smallc_fwd_kernel<%d>' % ((Co + 15) // 16)
         else:
-            name = 'igemm_fwd_kernel<%d, ConvFwdLoader<%s>>' % (_bm(Co, B * Ho * Wo), tf(C % 16 == 0))
+            name = _fwd_name(_bm(Co, B * Ho * Wo), 'ConvFwdLoader<%s>' % tf(C % 16 == 0))
     elif kind == 'conv_dgrad':
         if stride == 1 and _smallc(Co, C, kh, kw, 1):
             name = 'smallc_fwd_kernel<%d>' % ((C + 15) // 16)
         elif stride > 1 and H % stride == 0 and W % stride == 0 and Co % 16 == 0 and \
                 (-(-kh // stride)) * (-(-kw // stride)) <= 9:
-            name = 'igemm_fwd_kernel<*, ConvDgradClassLoader> (group of stride^2 class launches)'
+            name = 'igemm_fwd*_kernel<*, ConvDgradClassLoader> (group of stride^2 class launches)'
         else:
-            name = 'igemm_fwd_kernel<%d, ConvDgradLoader>' % _bm(C, B * H * W)
+            name = _fwd_name(_bm(C, B * H * W), 'ConvDgradLoader')
     elif kind == 'conv_wgrad':
         if _smallc(C, Co, kh, kw, stride):
             name = 'smallc_wgrad_kernel<%d>' % ((Co + 15) // 16)
         else:
             wide = Co <= 32 or (C % 64 == 0 and (C * kh * kw) % 128 == 0)
-            name = 'igemm_wgrad_kernel<ConvWLoader<%d>, %d, %d>' % (2 if C % 64 == 0 else 0, 32 if Co <= 32 else 64,
-                                                                    128 if wide else 64)
+            ws = _ws() and C % 64 == 0 and Co > 32
+            name = 'igemm_wgrad%s_kernel<ConvWLoader<%d>, %d, %d>' % ('_ws' if ws else '', 2 if C % 64 == 0 else 0,
+                                                                      32 if Co <= 32 else 64, 128 if wide else 64)
     elif kind == 'dcn_fwd':
         bm = _bm(Co, B * Ho * Wo)
         name = ('dcn_sample_kernel + igemm_fwd_kernel<%d, DcnColsLoader>' if Co > bm else
@@ -228,9 +242,7 @@ def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
         # convolution over grad_output with 9*C output channels: all of the entry point's MFMA work), then
         # the two HBM-streaming consumers with their algorithmic bytes
         T, px = kh * kw, B * Ho * Wo
-        name = 'igemm_fwd_kernel<%d, ConvFwdLoader<%s>>' % (_bm(T * C, px), tf(Co % 16 == 0))
-        if get_matrix_mode() == 1:
-            name += ' [split bf16 x3]'
+        name = _fwd_name(_bm(T * C, px), 'ConvFwdLoader<%s>' % tf(Co % 16 == 0))
         coord_bytes = 4.0 * px * (T * C + 3 * T + 3 * T + 4 * T) + 4.0 * B * C * H * W
         col2im_bytes = 4.0 * px * T * C + 16.0 * px * T * ((C + 15) // 16) + 4.0 * B * C * H * W
         _Prof.table.append([(name, flops, 0.0), ('dcn_coord_grad_kernel', 0.0, coord_bytes),
@@ -239,8 +251,6 @@ def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
         return
     else:
         raise ValueError(kind)
-    if kind in ('conv_fwd', 'conv_dgrad') and name.startswith('igemm_fwd') and get_matrix_mode() == 1:
-        name += ' [split bf16 x3]'
     _Prof.table.append([(name, flops, 0.0)])
     lib().cnuda_prof_arm(len(_Prof.table) - 1)
 
