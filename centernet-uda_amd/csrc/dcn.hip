@@ -1029,13 +1029,7 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
     {
         if (columns) {
             DcnColWParams p{g, columns, grad_output};
-            if (wave_specialised() && q.Jp % 128 == 0)
-                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<DcnColWLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
-                                   dim3(2 * IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
-            else if (wave_specialised())
-                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<DcnColWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
-                                   dim3(2 * IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
-            else if (q.Jp % 128 == 0)
+            if (q.Jp % 128 == 0)
                 hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
                                    dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
             else
