@@ -96,3 +96,32 @@ def test_plugin_signatures_match_reference():
         assert callable(getattr(uda.Model, name))
     assert list(inspect.signature(DCN.__init__).parameters)[1:] == [
         'in_channels', 'out_channels', 'kernel_size', 'stride', 'padding', 'dilation', 'deformable_groups']
+
+
+def test_uda_package_resolves_plugins_lazily_and_names_what_is_missing():
+    import importlib
+    import uda
+    for name in ('Model', 'EntropyMinimization', 'MaxSquaresMinimization', 'AdversarialEntropyMinimization'):
+        cls = getattr(uda, name)                      # what hydra's `uda.<ClassName>` lookup does (train.py:104-106)
+        assert cls.__name__ == name and name in dir(uda)
+        assert issubclass(cls, uda.Model)
+    assert uda.MaxSquaresMinimization is importlib.import_module('uda.max_squares_minimization').MaxSquaresMinimization
+    with pytest.raises(AttributeError, match='rfft'):
+        uda.FDA
+    with pytest.raises(AttributeError):
+        uda.NoSuchPlugin
+
+
+def test_gather_feat_helper_matches_the_reference_formula():
+    """utils/tensor.py:10-18 restated with take_along_dim: same rows, same masked flattening."""
+    import torch
+    from utils.tensor import _gather_feat
+    g = torch.Generator().manual_seed(3)
+    feat = torch.randn(3, 20, 5, generator=g)
+    ind = torch.randint(0, 20, (3, 7), generator=g)
+    mask = torch.rand(3, 7, generator=g) > 0.4
+    dim = feat.size(2)
+    want = feat.gather(1, ind.unsqueeze(2).expand(ind.size(0), ind.size(1), dim))
+    assert torch.equal(_gather_feat(feat, ind), want)
+    assert torch.equal(_gather_feat(feat, ind, mask), want[mask.unsqueeze(2).expand_as(want)].view(-1, dim))
+    assert torch.equal(_gather_feat(feat, ind, mask.to(torch.uint8)), _gather_feat(feat, ind, mask))
