@@ -151,9 +151,13 @@ def _hash_uniform(name, n):
     return (x >> np.uint64(11)).astype(np.float64) / float(1 << 53) * 2.0 - 1.0
 
 
-def fill_value(name, shape):
+def fill_value(name, shape, offset_gain=1.0):
     """float32 array for state_dict entry `name` of `shape` (well-conditioned:
-    kaiming-scaled pseudo-random kernels, BN statistics near identity)."""
+    kaiming-scaled pseudo-random kernels, BN statistics near identity).
+    offset_gain scales the `conv_offset_mask` kernels: 1.0 gives DCN offsets of about +-1 px, at which the
+    reference's own float32 result differs from its float64 result by several 1e-4 end to end (noise-like
+    feature maps sampled at noisy positions); 0.1 keeps the sampling fractional (+-0.1 px) and brings that
+    noise down to 1e-6 .. 3e-5, so that a plain 1e-4 comparison means something."""
     n = int(np.prod(shape)) if len(shape) else 1
     if name.endswith('num_batches_tracked'):
         return np.zeros(shape, np.int64)
@@ -172,16 +176,16 @@ def fill_value(name, shape):
         fan_in = int(np.prod(shape[1:]))
         scale = math.sqrt(6.0 / fan_in)
         if 'conv_offset_mask' in name:
-            scale = 1.5 / math.sqrt(fan_in)                      # offsets of about +-1 px (Q7)
+            scale = 1.5 * offset_gain / math.sqrt(fan_in)        # offsets of about +-1 px (Q7)
         if '.up_' in name:
             scale = 2.0 / math.sqrt(fan_in)
         v = scale * u
     return v.reshape(shape).astype(np.float32)
 
 
-def fill_state(shapes):
+def fill_state(shapes, offset_gain=1.0):
     """shapes: dict name -> shape.  Returns dict name -> np.ndarray."""
-    return {k: fill_value(k, tuple(s)) for k, s in shapes.items()}
+    return {k: fill_value(k, tuple(s), offset_gain) for k, s in shapes.items()}
 
 
 def image_batch(B, H, W, seed):
@@ -210,3 +214,45 @@ def target_boxes(name):
     boxes[2, 2] = boxes[2, 0]                      # zero width
     classes = rs.randint(0, C, n).astype(np.int32)
     return boxes.astype(np.float64), classes
+
+
+# ---------------------------------------------------------------------------
+# evaluation-side batch keys (datasets/coco.py:168-174,242-251: id, gt_dets, gt_areas[, gt_kps])
+# ---------------------------------------------------------------------------
+def eval_extras(B, M, rotated, seed, num_keypoints=0):
+    rs = np.random.RandomState(seed)
+    cols = 7 if rotated else 6
+    gt = rs.uniform(0, 30, (B, M, cols)).astype(np.float32)
+    gt[..., cols - 2] = 1.0                                            # score column
+    gt[..., cols - 1] = rs.randint(0, 6, (B, M))                       # class column
+    out = dict(id=np.arange(100, 100 + B, dtype=np.int64), gt_dets=gt,
+               gt_areas=rs.uniform(1, 900, (B, M)).astype(np.float32))
+    if num_keypoints:
+        out['gt_kps'] = rs.uniform(0, 30, (B, M, num_keypoints, 2)).astype(np.float32)
+    return out
+
+
+GETDET_CASES = {
+    # name: (B, C, H, W, M, n_obj, K, rotated, num_keypoints, seed)
+    'axis': (2, 6, 24, 20, 10, (3, 7), 12, False, 0, 81),
+    'rot': (3, 4, 16, 16, 8, (8, 0, 2), 9, True, 0, 82),
+    'kps': (2, 3, 16, 20, 6, (1, 4), 7, False, 4, 83),
+}
+
+
+def getdet_inputs(name):
+    """-> (outputs['source_domain'] as the loss leaves it: clamped probabilities in 'hm' (Q1), raw wh / reg / kps;
+    batch with reg_mask + the evaluation keys)."""
+    B, C, H, W, M, n_obj, K, rotated, J, seed = GETDET_CASES[name]
+    rs = np.random.RandomState(seed)
+    logits = rs.standard_normal((B, C, H, W)).astype(np.float32) - np.float32(2.19)
+    hm = np.clip((1.0 / (1.0 + np.exp(-logits.astype(np.float64)))).astype(np.float32), np.float32(1e-4), np.float32(1 - 1e-4))
+    wh = rs.uniform(2, 0.6 * W, (B, 3 if rotated else 2, H, W)).astype(np.float32)
+    if rotated:
+        wh[:, 2] = rs.standard_normal((B, H, W)).astype(np.float32)
+    src = dict(hm=hm, wh=wh, reg=rs.uniform(0, 1, (B, 2, H, W)).astype(np.float32))
+    if J:
+        src['kps'] = (rs.standard_normal((B, 2 * J, H, W)) * 5.0).astype(np.float32)
+    batch = detection_batch(B, C, H, W, M, n_obj, 3 if rotated else 2, seed + 1)
+    batch.update(eval_extras(B, M, rotated, seed + 2, J))
+    return src, batch, K, rotated

@@ -246,35 +246,30 @@ DLA_CASES = (('axis', False, 2, 64, 41), ('rot', True, 2, 96, 42))
 
 
 def _step_case(dla, tag, dtype):
+    """The reference's own plugin class (uda/entropy_minimization.py:5-43, uda/max_squares_minimization.py:5-50)
+    driving the imported DLA-34, DetectionLoss and torch.optim.Adam (train.py:88-90)."""
     from losses.centernet import DetectionLoss
-    from losses.entropy import EntropyLoss
-    from losses.max_square import MaxSquareLoss
-    uda_loss, weight = (EntropyLoss(), 1e-4) if tag == 'entropy' else (MaxSquareLoss(), 0.3)
+    uda = _import_reference_uda()
+    plugin = uda.EntropyMinimization(1e-4) if tag == 'entropy' else uda.MaxSquaresMinimization(0.3)
     B, S, M = 2, 64, 8
     model = dla.build(num_classes=6)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes).items()})
     model = model.to(dtype)
-    model.train()
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5, weight_decay=1e-4)
-    crit = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0, periodic=False)
+    plugin.backend = model
+    plugin.device = torch.device('cpu')
+    plugin.optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5, weight_decay=1e-4)
+    plugin.centernet_loss = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0, periodic=False)
+    plugin.init_done()
+    plugin.to('cpu')
+    plugin.set_phase(True)
     batch = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, (3, 2), 2, 51).items()}
     for k in ('hm', 'wh', 'reg'):
         batch[k] = batch[k].to(dtype)
     batch['input'] = T(gin.image_batch(B, S, S, 52)).to(dtype)
     batch['target_domain_input'] = T(gin.image_batch(B, S, S, 53)).to(dtype)
-    opt.zero_grad()
-    out_s = model(batch['input'])
-    out_t = model(batch['target_domain_input'])
-    c_loss, c_stats = crit(out_s, batch)
-    e_loss, e_stats = uda_loss(out_t, batch)
-    e_loss *= weight
-    c_loss.backward()
-    e_loss.backward()
-    opt.step()
-    stats = {**c_stats, **e_stats}
-    stats['total_loss'] = c_loss + e_loss
-    res = {'stat_' + k: v.item() for k, v in stats.items()}
+    out = plugin.step(batch)
+    res = {'stat_' + k: v.item() for k, v in out['stats'].items()}
     params = dict(model.named_parameters())
     for n in GRAD_PROBES:
         if n in params and params[n].grad is not None:
@@ -284,15 +279,14 @@ def _step_case(dla, tag, dtype):
     res['rm__base.base_layer.1'] = sd['base.base_layer.1.running_mean'].numpy()
     res['rv__base.base_layer.1'] = sd['base.base_layer.1.running_var'].numpy()
     res['nbt__base.base_layer.1'] = sd['base.base_layer.1.num_batches_tracked'].numpy()
-    res['src_hm_after'] = out_s['hm'].detach().numpy()
+    res['src_hm_after'] = out['source_domain']['hm'].detach().numpy()
     return res
 
 
 def make_step(dla):
     """One `EntropyMinimization.step` (uda/entropy_minimization.py:11-43) and one
-    `MaxSquaresMinimization.step` re-enacted with the imported reference pieces
-    (uda.* itself needs hydra, absent here; its step bodies are pure sequencing),
-    in float32 and, for tolerance calibration, float64."""
+    `MaxSquaresMinimization.step` of the imported reference classes, in float32 and,
+    for tolerance calibration, float64."""
     for tag in ('entropy', 'maxsq'):
         r32 = _step_case(dla, tag, torch.float32)
         r64 = _step_case(dla, tag, torch.float64)
@@ -383,6 +377,147 @@ def make_advent(dla):
         if k.startswith(('stat_', 'gradsum__', 'dgradsum__', 'src_hm_after')):
             out['f64_' + k] = v
     save('step_advent', **out)
+
+
+# ---------------------------------------------------------------------------
+def _import_reference_uda():
+    """The reference's own step classes (uda/base.py, uda/entropy_minimization.py, uda/max_squares_minimization.py).
+    `utils/helper.py` imports hydra / omegaconf at module scope (configuration packages, absent here, touched only
+    by instantiate_augmenters and by ADVENT's custom-optimizer lookup); they are bound to empty modules the same
+    way torchsummary / cv2 / imgaug are.  No arithmetic on the path lives in them."""
+    for m in ('hydra', 'hydra.utils', 'omegaconf', 'omegaconf.listconfig'):
+        if m not in sys.modules:
+            try:
+                __import__(m)
+            except Exception:
+                sys.modules[m] = types.ModuleType(m)
+    if not hasattr(sys.modules['omegaconf.listconfig'], 'ListConfig'):
+        sys.modules['omegaconf.listconfig'].ListConfig = list
+    if not hasattr(sys.modules['hydra'], 'utils'):
+        sys.modules['hydra'].utils = sys.modules['hydra.utils']
+    _load_entropy_map()                                  # cv2 / imgaug stand-ins for utils/image.py
+    import uda
+    import uda.base
+    return uda
+
+
+def _ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def _cfg(K, rotated):
+    return _ns(max_detections=K, model=_ns(backend=_ns(params=_ns(rotated_boxes=rotated))))
+
+
+def _store_detections(res, prefix, dets):
+    """uda/base.py:121-137's dict -> flat arrays (per-image ground-truth lists concatenated, with their lengths)."""
+    for k in ('pred_boxes', 'pred_classes', 'pred_scores'):
+        res[prefix + k] = np.asarray(dets[k])
+    if 'pred_kps' in dets:
+        res[prefix + 'pred_kps'] = np.asarray(dets['pred_kps'])
+    res[prefix + 'gt_counts'] = np.array([len(b) for b in dets['gt_boxes']])
+    for k in ('gt_boxes', 'gt_classes', 'gt_areas') + (('gt_kps',) if 'gt_kps' in dets else ()):
+        res[prefix + k] = np.concatenate([np.asarray(v) for v in dets[k]], 0)
+        res[prefix + k + '_dtype'] = np.array(str(np.asarray(dets[k][0]).dtype))
+    res[prefix + 'gt_ids'] = np.asarray(dets['gt_ids'])
+    res[prefix + 'pred_classes_dtype'] = np.array(str(dets['pred_classes'].dtype))
+
+
+def make_getdet():
+    """`Model.get_detections` (uda/base.py:73-139) of the imported reference class on synthetic head outputs:
+    the x down_ratio scaling, the reg_mask == 1 row selection, the 4/5 vs 5/6 column split for rotated boxes,
+    the keypoint branch."""
+    uda = _import_reference_uda()
+    for name in gin.GETDET_CASES:
+        src_np, batch_np, K, rotated = gin.getdet_inputs(name)
+        m = uda.base.Model()
+        m.cfg = _cfg(K, rotated)
+        m.backend = _ns(down_ratio=4)
+        res = {}
+        dets = m.get_detections({'source_domain': {k: T(v).clone() for k, v in src_np.items()}},
+                                {k: T(v).clone() for k, v in batch_np.items()})
+        _store_detections(res, '', dets)
+        save('getdet_' + name, **res)
+
+
+BASE_STEP = dict(B=4, S=128, M=16, n_obj=(5, 1, 9, 3), offset_gain=0.1, K=40)
+
+
+def _base_step_case(uda, dla, dtype):
+    """configs[1]: `uda.base.Model` of the imported reference driving DLA-34 -- the evaluation sequence of
+    train.py:204-223 (set_phase(False), `step(data, is_training=False)` under no_grad, `get_detections`), then
+    one training `step` (uda/base.py:31-56).  Well-conditioned variant of the parameter fill
+    (inputs.fill_value, offset_gain = 0.1) at B = 4, 128 x 128 so that float32 agrees with float64 to ~1e-5."""
+    from losses.centernet import DetectionLoss
+    c = BASE_STEP
+    B, S, M = c['B'], c['S'], c['M']
+    model = dla.build(num_classes=6)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes, c['offset_gain']).items()})
+    model = model.to(dtype)
+    plugin = uda.base.Model()
+    plugin.cfg = _cfg(c['K'], False)
+    plugin.backend = model
+    plugin.device = torch.device('cpu')
+    plugin.optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5, weight_decay=1e-4)
+    plugin.centernet_loss = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0, periodic=False)
+    plugin.init_done()
+    plugin.to('cpu')
+
+    def batch(seed):
+        d = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, c['n_obj'], 2, seed).items()}
+        for k in ('hm', 'wh', 'reg'):
+            d[k] = d[k].to(dtype)
+        d['input'] = T(gin.image_batch(B, S, S, seed + 1)).to(dtype)
+        return d
+    # evaluation sequence (train.py:204-223) on the freshly filled model.  It runs BEFORE the training step: after
+    # one Adam step the parameters whose gradient is analytically zero (convolution biases in front of a BatchNorm)
+    # have moved by +-lr on rounding noise alone, and eval-mode outputs of float32 and float64 runs of the
+    # reference itself then differ by 7e-3 -- nothing a 1e-4 comparison could be held to.
+    res = {}
+    plugin.set_phase(False)
+    ev = batch(93)
+    ev.update({k: T(v) for k, v in gin.eval_extras(B, M, False, 95).items()})
+    ev['gt_dets'] = ev['gt_dets'].to(dtype)
+    with torch.no_grad():
+        o = plugin.step(ev, is_training=False)
+    for k, v in o['stats'].items():
+        res['eval_stat_' + k] = v.item()
+    for k in ('hm', 'wh', 'reg'):
+        res['eval_' + k] = o['source_domain'][k].numpy()
+    dets = plugin.get_detections(o, ev)
+    _store_detections(res, 'det_', dets)
+    plugin.set_phase(True)
+    data = batch(91)
+    out = plugin.step(data)
+    res.update({'stat_' + k: v.item() for k, v in out['stats'].items()})
+    res['stat_keys'] = np.array(list(out['stats']))
+    for k in ('hm', 'wh', 'reg'):
+        res['train_' + k] = out['source_domain'][k].detach().numpy()       # hm: clamped probabilities (Q1)
+    res['wh_target_after'] = data['wh'].numpy()                            # Q2
+    params = dict(model.named_parameters())
+    for n in GRAD_PROBES:
+        if params[n].grad is not None:
+            res['gradsum__' + n] = _checksums(params[n].grad)
+            res['param__' + n] = _checksums(params[n])
+    sd = model.state_dict()
+    for n in ('base.base_layer.1', 'base.level5.tree2.bn2', 'ida_up.node_2.actf.0'):
+        res['rm__' + n] = sd[n + '.running_mean'].numpy()
+        res['rv__' + n] = sd[n + '.running_var'].numpy()
+        res['nbt__' + n] = sd[n + '.num_batches_tracked'].numpy()
+    res['shapes_json'] = np.array(repr(sorted(shapes.items())))
+    return res
+
+
+def make_base_step(dla):
+    uda = _import_reference_uda()
+    r32 = _base_step_case(uda, dla, torch.float32)
+    r64 = _base_step_case(uda, dla, torch.float64)
+    out = dict(r32)
+    for k, v in r64.items():
+        if k.startswith(('stat_', 'eval_', 'train_', 'gradsum__')) and k != 'stat_keys':
+            out['f64_' + k] = v
+    save('step_base128', **out)
 
 
 # ---------------------------------------------------------------------------
@@ -610,7 +745,8 @@ def make_targets():
 
 if __name__ == '__main__':
     oracle_dcn.build()
-    which = set(sys.argv[1:]) or {'decode', 'losses', 'dla', 'step', 'advent', 'resnet', 'targets', 'mobilenetv2'}
+    which = set(sys.argv[1:]) or {'decode', 'losses', 'dla', 'step', 'advent', 'resnet', 'targets', 'mobilenetv2',
+                                  'getdet', 'base'}
     if 'decode' in which:
         make_decode()
     if 'resnet' in which:
@@ -623,8 +759,12 @@ if __name__ == '__main__':
         _load_entropy_map()
     if 'losses' in which:
         make_losses()
-    if 'dla' in which or 'step' in which or 'advent' in which:
+    if 'getdet' in which:
+        make_getdet()
+    if 'dla' in which or 'step' in which or 'advent' in which or 'base' in which:
         d = make_dla() if 'dla' in which else _import_reference_dla()
+        if 'base' in which:
+            make_base_step(d)
         if 'step' in which:
             make_step(d)
         if 'advent' in which:

@@ -104,6 +104,41 @@ def test_full_size_linearity_64ch_128sq():
     _close(lhs, rhs, 2e-5)
 
 
+# Independent known answers for fractional offsets (closed forms / plain convolutions, no oracle involved):
+# the same vectors that pin the oracle in tests/test_oracle_dcn.py, through the C ABI on the GPU.
+def _gpu_fwd(x, w, b, off, m, *geom):
+    import _ext
+    return _ext.dcn_v2_forward(*[t.to(DEV) for t in (x, w, b, off, m)], *geom).cpu()
+
+
+def _gpu_bwd(x, w, b, off, m, go, *geom):
+    import _ext
+    return [t.cpu() for t in _ext.dcn_v2_backward(*[t.to(DEV) for t in (x, w, b, off, m, go)], *geom)]
+
+
+@pytest.mark.parametrize('dh,dw', [(0.5, 0.0), (0.0, 0.5), (0.5, 0.5), (-0.5, 0.5), (0.25, -0.75)])
+@pytest.mark.parametrize('size', [(2, 3, 7, 9, 4), (2, 64, 32, 40, 64), (1, 128, 16, 16, 128)])
+def test_known_answer_half_pixel_offsets_are_box_blurs(dh, dw, size):
+    import dcn_known_answers as ka
+    ka.check_uniform_fractional_offset_is_box_blur_then_conv(_gpu_fwd, dh, dw, torch.float32, 2e-5, size=size)
+
+
+def test_known_answer_validity_window_open_at_minus_one_and_H():
+    import dcn_known_answers as ka
+    ka.check_validity_window_is_open(_gpu_fwd, _gpu_bwd, torch.float32, 1e-6)
+
+
+@pytest.mark.parametrize('size', [(2, 3, 12, 11, 2), (2, 64, 40, 36, 64), (1, 16, 20, 70, 32)])
+def test_known_answer_linear_ramp_gradients(size):
+    import dcn_known_answers as ka
+    ka.check_linear_ramp_has_constant_coordinate_gradient(_gpu_fwd, _gpu_bwd, torch.float32, 5e-5, size=size)
+
+
+def test_known_answer_col2im_four_weights():
+    import dcn_known_answers as ka
+    ka.check_col2im_scatters_the_four_bilinear_weights(_gpu_bwd, torch.float32, 1e-6)
+
+
 def test_errors():
     import _ext
     z = lambda *s: torch.zeros(*s, device=DEV)

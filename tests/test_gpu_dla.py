@@ -25,6 +25,16 @@ def _close(a, b, tol=1e-4):
     assert np.abs(a - b).max() <= tol * scale, (np.abs(a - b).max(), scale)
 
 
+def _close_rel(got, ref, tol=1e-4, what=''):
+    """north_star's bar, taken literally: |got - reference| <= 1e-4 x the largest magnitude of the reference
+    tensor (no floor of 1: a loss of 1e-4 is held to 1e-8)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    print('%-28s err %.2e  scale %.2e  err/scale %.2e' % (what, err, scale, err / max(scale, 1e-300)))
+    assert err <= tol * scale, (what, err, scale)
+
+
 def _close_calibrated(got, ref32, ref64, floor=1e-4, k=8.0, what=''):
     """A 50-layer fp32 network in train-mode BatchNorm carries rounding noise well
     above 1e-4 whatever the summation order: the reference's own fp32 result differs
@@ -36,9 +46,11 @@ def _close_calibrated(got, ref32, ref64, floor=1e-4, k=8.0, what=''):
     blocked accumulation on the CPU (numerics); every single layer is
     held to 1e-4 against the oracle in test_gpu_ops.py / test_gpu_dcn.py."""
     got, ref32, ref64 = [np.asarray(t, np.float64) for t in (got, ref32, ref64)]
-    scale = max(1.0, np.abs(ref64).max())
+    scale = np.abs(ref64).max()                 # relative to the tensor's own magnitude, also for tiny statistics
     noise = np.abs(ref32 - ref64).max()
     err = np.abs(got - ref64).max()
+    print('%-28s err/scale %.2e  reference fp32-vs-fp64 noise/scale %.2e  err/noise %.2f'
+          % (what, err / max(scale, 1e-300), noise / max(scale, 1e-300), err / max(noise, 1e-300)))
     assert err <= max(floor * scale, k * noise), (what, err, noise, scale)
 
 
@@ -152,6 +164,116 @@ def test_uda_step_golden(golden, tag, weight):
     dets = plugin.get_detections(o, ev)
     assert dets['pred_boxes'].shape == (B, 20, 4) and dets['pred_scores'].shape == (B, 20)
     assert [len(b) for b in dets['gt_boxes']] == [3, 2]
+
+
+def _plugin_base(model, K=40, rotated=False):
+    import uda.base as ub
+    from hip_runtime import optim
+    from losses.centernet import DetectionLoss
+    plugin = ub.Model()
+    plugin.cfg = _Cfg(max_detections=K, model=_Cfg(backend=_Cfg(params=_Cfg(rotated_boxes=rotated))))
+    plugin.backend = model
+    plugin.device = torch.device(DEV)
+    plugin.optimizer = optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5, weight_decay=1e-4)
+    plugin.centernet_loss = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0,
+                                          periodic=False)
+    plugin.init_done()
+    plugin.to(DEV)
+    return plugin
+
+
+def test_base_step_dla_configs1_plain_1e4(golden):
+    """configs[1] (DLA-34 + DCNv2, no UDA) through `uda.base.Model`: the evaluation sequence and one training step
+    against the imported reference class (tests/golden/step_base128.npz, B = 4 at 128 x 128, DCN offsets of
+    +-0.1 px: a fixture on which the reference's own float32 and float64 runs agree to 3e-6 (eval) / 2e-5 (train),
+    so north_star's plain 1e-4 is asserted with no calibration)."""
+    from backends import dla
+    from detections_check import compare_detections
+    g = golden('step_base128')
+    shapes = dict(ast.literal_eval(str(g['shapes_json'])))
+    model = dla.build(num_classes=6)
+    model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes, 0.1).items()})
+    plugin = _plugin_base(model.to(DEV))
+    B, S, M, n_obj = 4, 128, 16, (5, 1, 9, 3)
+
+    def batch(seed):
+        d = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, n_obj, 2, seed).items()}
+        d['input'] = T(gin.image_batch(B, S, S, seed + 1))
+        return d
+    # -- evaluation (train.py:204-223) ------------------------------------------------------------
+    plugin.set_phase(False)
+    ev = batch(93)
+    ev.update({k: T(v) for k, v in gin.eval_extras(B, M, False, 95).items()})
+    with torch.no_grad():
+        o = plugin.step(ev, is_training=False)
+    for k in ('centernet_loss', 'hm_loss', 'wh_loss', 'off_loss', 'total_loss'):
+        _close_rel(o['stats'][k].item(), g['eval_stat_' + k], what='eval ' + k)
+    for k in ('hm', 'wh', 'reg'):
+        _close_rel(o['source_domain'][k].cpu().numpy(), g['eval_' + k], what='eval ' + k)
+    # get_detections on the reference's own head outputs: everything bit-equal (indices, classes, scores, boxes)
+    ref_out = {'source_domain': {k: T(g['eval_' + k]).to(DEV) for k in ('hm', 'wh', 'reg')}}
+    ev2 = {k: v.clone() for k, v in ev.items()}
+    compare_detections(plugin.get_detections(ref_out, ev2), g, 'det_')
+    # ... and on the product's own outputs: scores within 1e-4; where the reference's ranking is decided by more
+    # than that, the same detection in the same slot
+    dets = plugin.get_detections(o, ev)
+    ws, wb, wc = g['det_pred_scores'], g['det_pred_boxes'], g['det_pred_classes']
+    assert np.abs(dets['pred_scores'] - ws).max() <= 1e-4
+    gap = np.minimum(np.abs(np.diff(ws, axis=1, prepend=2.0)), np.abs(np.diff(ws, axis=1, append=-1.0)))
+    sure = gap > 2e-4
+    assert sure.mean() > 0.5
+    assert np.array_equal(dets['pred_classes'][sure], wc[sure])
+    assert np.abs(dets['pred_boxes'][sure] - wb[sure]).max() <= 1e-4 * np.abs(wb).max()
+    compare_detections(dets, g, 'det_', exact_order=False)                 # ground-truth side: exact
+    # -- one training step (uda/base.py:31-56) -----------------------------------------------------
+    plugin.set_phase(True)
+    data = batch(91)
+    out = plugin.step(data)
+    assert list(out['stats']) == [str(k) for k in g['stat_keys']]
+    for k, v in out['stats'].items():
+        assert not v.is_cuda and not v.requires_grad
+        _close_rel(v.item(), g['stat_' + k], what='train ' + k)
+    for k in ('hm', 'wh', 'reg'):
+        _close_rel(out['source_domain'][k].detach().cpu().numpy(), g['train_' + k], what='train ' + k)   # hm: Q1
+    np.testing.assert_array_equal(data['wh'].cpu().numpy(), g['wh_target_after'])                        # Q2
+    params = dict(model.named_parameters())
+    for fk in g.files:
+        if fk.startswith('gradsum__'):
+            n = fk[len('gradsum__'):]
+            got, w32, w64 = _checksums(params[n].grad), g[fk], g['f64_' + fk]
+            noise = np.abs(w32 - w64).max()
+            err = np.abs(got - w64).max()
+            print('%-58s err/|g|_1 %.2e  reference noise/|g|_1 %.2e' % (n, err / max(w64[1], 1e-300), noise / max(w64[1], 1e-300)))
+            # gradient check sums: 1e-4 of the gradient's l1 mass where the reference's own float32 run gets that
+            # close to float64, else 8x the reference's own distance
+            assert err <= max(1e-4 * w64[1], 8 * noise), (n, got, w64, noise)
+            gotp, wantp = _checksums(params[n]), g['param__' + n]
+            flips = 0.05 * params[n].numel() * 2 * 5e-5                     # Adam sign flips of ~zero gradients
+            assert np.abs(gotp - wantp).max() <= 1e-5 * max(1.0, wantp[1]) + flips, (n, gotp, wantp)
+    sd = model.state_dict()
+    for fk in g.files:
+        if fk.startswith('rm__'):
+            n = fk[4:]
+            _close_rel(sd[n + '.running_mean'].cpu().numpy(), g[fk], 1e-4, what='running_mean ' + n)
+            _close_rel(sd[n + '.running_var'].cpu().numpy(), g['rv__' + n], 1e-4, what='running_var ' + n)
+            assert int(sd[n + '.num_batches_tracked']) == 1
+
+
+@pytest.mark.parametrize('name', sorted(gin.GETDET_CASES))
+def test_get_detections_golden(golden, name):
+    """P4: `Model.get_detections` (uda/base.py:73-139) with the HIP decode against the dict of the imported
+    reference class: x down_ratio, reg_mask row selection, rotated column split, keypoint branch."""
+    import types
+    import uda.base as ub
+    from detections_check import compare_detections
+    g = golden('getdet_' + name)
+    src, batch, K, rotated = gin.getdet_inputs(name)
+    m = ub.Model()
+    m.cfg = _Cfg(max_detections=K, model=_Cfg(backend=_Cfg(params=_Cfg(rotated_boxes=rotated))))
+    m.backend = types.SimpleNamespace(down_ratio=4)
+    dets = m.get_detections({'source_domain': {k: T(v).to(DEV) for k, v in src.items()}},
+                            {k: T(v).to(DEV) for k, v in batch.items()})
+    compare_detections(dets, g)
 
 
 def test_advent_step_golden(golden):

@@ -2,6 +2,8 @@
 pooling, depthwise transposed conv, concat/add, Adam) against the CPU torch
 primitives the oracle (oracle/dla.py) is made of.  fp32 tolerance 1e-4 of the
 tensor's scale (north_star)."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -44,7 +46,7 @@ CONV_CASES = {
 def test_conv2d_fwd_bwd(name):
     from hip_runtime import ops
     B, C, H, W, Co, k, s, p, bias, act = CONV_CASES[name]
-    g = torch.Generator().manual_seed(abs(hash(name)) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
     x = torch.randn(B, C, H, W, generator=g, requires_grad=True)
     w = (torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5).requires_grad_(True)
     b = torch.randn(Co, generator=g).requires_grad_(True) if bias else None

@@ -1,8 +1,12 @@
 """Pins oracle/dcn.py.  The reference's native DCNv2 cannot be built in this
 image (<TH/TH.h> absent), so the pins are the reference's own known-answer
 tests restated (libs/DCNv2/testcpu.py:32-67 zero-offset identity; :69-97
-gradcheck), an fp64 finite-difference check of the same C code, and
-cross-checks against plain convolution where DCN degenerates to it."""
+gradcheck), an fp64 finite-difference check of the same C code,
+cross-checks against plain convolution where DCN degenerates to it, and
+INDEPENDENT known answers for fractional offsets (tests/dcn_known_answers.py:
+half-pixel offsets = box blur + convolution, the open validity window at -1 / H,
+closed-form coordinate / mask / weight gradients on a linear-ramp image, the four
+bilinear scatter weights of col2im) -- none of which share code with the oracle."""
 import numpy as np
 import pytest
 import torch
@@ -122,3 +126,33 @@ def test_channel_mismatch_raises():
     with pytest.raises(RuntimeError):
         od.dcn_v2_forward(torch.zeros(1, 3, 4, 4), torch.zeros(2, 4, 3, 3), torch.zeros(2),
                           torch.zeros(1, 18, 4, 4), torch.zeros(1, 9, 4, 4), 3, 3, 1, 1, 1, 1, 1, 1, 1)
+
+
+# ---------------------------------------------------------------------------
+# Independent known answers for fractional offsets (closed forms / plain convolutions only; shared with the
+# MI355X tests: tests/dcn_known_answers.py)
+# ---------------------------------------------------------------------------
+import dcn_known_answers as ka  # noqa: E402
+
+_DT = [(torch.float64, 1e-12), (torch.float32, 2e-5)]
+
+
+@pytest.mark.parametrize('dtype,tol', _DT)
+@pytest.mark.parametrize('dh,dw', ka.BOX_OFFSETS)
+def test_uniform_fractional_offset_is_a_box_blur_then_conv(dh, dw, dtype, tol):
+    ka.check_uniform_fractional_offset_is_box_blur_then_conv(od.dcn_v2_forward, dh, dw, dtype, tol)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-13), (torch.float32, 1e-6)])
+def test_validity_window_is_open_at_minus_one_and_at_H(dtype, tol):
+    ka.check_validity_window_is_open(od.dcn_v2_forward, od.dcn_v2_backward, dtype, tol)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-11), (torch.float32, 3e-5)])
+def test_linear_ramp_has_constant_coordinate_gradient(dtype, tol):
+    ka.check_linear_ramp_has_constant_coordinate_gradient(od.dcn_v2_forward, od.dcn_v2_backward, dtype, tol)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-12), (torch.float32, 1e-6)])
+def test_col2im_scatters_the_four_bilinear_weights(dtype, tol):
+    ka.check_col2im_scatters_the_four_bilinear_weights(od.dcn_v2_backward, dtype, tol)

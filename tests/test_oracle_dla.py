@@ -19,10 +19,10 @@ def _checksums(t):
     return np.array([t.sum().item(), t.abs().sum().item(), (t * torch.cos(0.01 * idx)).sum().item()])
 
 
-def _state(g, requires_grad=True):
+def _state(g, requires_grad=True, offset_gain=1.0):
     shapes = dict(ast.literal_eval(str(g['shapes_json'])))
     st = {}
-    for k, v in gin.fill_state(shapes).items():
+    for k, v in gin.fill_state(shapes, offset_gain).items():
         t = T(v).clone()
         if requires_grad and t.is_floating_point() and 'running_' not in k:
             t.requires_grad_(True)
@@ -109,6 +109,60 @@ def test_uda_step(golden, tag, weight):
     _close(st['base.base_layer.1.running_mean'].numpy(), g['rm__base.base_layer.1'], 1e-5)
     _close(st['base.base_layer.1.running_var'].numpy(), g['rv__base.base_layer.1'], 1e-5)
     assert int(st['base.base_layer.1.num_batches_tracked']) == 2      # Q6: two BN updates per step
+
+
+def test_base_step_dla_configs1(golden):
+    """S1 with the DLA backend (configs[1]): the oracle pieces in `uda.base.Model`'s order against the imported
+    reference class (tests/golden/step_base128.npz: evaluation sequence, then one training step)."""
+    from oracle import decode as odec
+    g = golden('step_base128')
+    B, S, M, n_obj, K = 4, 128, 16, (5, 1, 9, 3), 40
+    st = _state(g, offset_gain=0.1)
+
+    def batch(seed):
+        d = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, n_obj, 2, seed).items()}
+        d['input'] = T(gin.image_batch(B, S, S, seed + 1))
+        return d
+    ev = batch(93)
+    with torch.no_grad():
+        out = odla.forward(st, ev['input'], training=False)
+        loss, stats, prob = ol.detection_loss(out, ev, 1.0, 0.1, 1.0, 1.0, False)
+    for k, v in dict(stats, total_loss=loss).items():
+        assert abs(v.item() - float(g['eval_stat_' + k])) <= 1e-5 * max(1.0, abs(float(g['eval_stat_' + k]))), k
+    _close(prob.numpy(), g['eval_hm'], 1e-5)
+    _close(out['wh'].numpy(), g['eval_wh'], 1e-5)
+    _close(out['reg'].numpy(), g['eval_reg'], 1e-5)
+    dets = odec.decode_detection(g['eval_hm'], g['eval_wh'], g['eval_reg'], K=K)
+    dets[:, :, :4] *= 4
+    np.testing.assert_array_equal(dets[:, :, :4], g['det_pred_boxes'])
+    np.testing.assert_array_equal(dets[:, :, 4], g['det_pred_scores'])
+    np.testing.assert_array_equal(dets[:, :, 5].astype(np.int32), g['det_pred_classes'])
+    data = batch(91)
+    opt = torch.optim.Adam([v for v in st.values() if v.requires_grad], lr=5e-5, weight_decay=1e-4)
+    opt.zero_grad()
+    out = odla.forward(st, data['input'], training=True)
+    loss, stats, prob = ol.detection_loss(out, data, 1.0, 0.1, 1.0, 1.0, False)
+    loss.backward()
+    opt.step()
+    assert [str(k) for k in g['stat_keys']] == ['centernet_loss', 'hm_loss', 'wh_loss', 'off_loss', 'total_loss']
+    for k, v in dict(stats, total_loss=loss).items():
+        assert abs(v.item() - float(g['stat_' + k])) <= 1e-4 * max(1.0, abs(float(g['stat_' + k]))), k
+    _close(prob.detach().numpy(), g['train_hm'], 1e-4)
+    _close(out['wh'].detach().numpy(), g['train_wh'], 1e-4)
+    _close(out['reg'].detach().numpy(), g['train_reg'], 1e-4)
+    for fk in g.files:
+        if fk.startswith('gradsum__'):
+            n = fk[len('gradsum__'):]
+            got, want = _checksums(st[n].grad), g[fk]
+            assert np.abs(got - want).max() <= 1e-3 * max(1.0, want[1]), (n, got, want)
+            gotp, wantp = _checksums(st[n]), g['param__' + n]
+            assert np.abs(gotp - wantp).max() <= 1e-5 * max(1.0, wantp[1]), (n, gotp, wantp)
+    for fk in g.files:
+        if fk.startswith('rm__'):
+            n = fk[4:]
+            _close(st[n + '.running_mean'].numpy(), g[fk], 1e-5)
+            _close(st[n + '.running_var'].numpy(), g['rv__' + n], 1e-5)
+            assert int(st[n + '.num_batches_tracked']) == int(g['nbt__' + n]) == 1
 
 
 def test_advent_step(golden):
