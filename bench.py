@@ -96,7 +96,10 @@ def build_plugin(device, parallel, uda_name='entropy'):
 
 
 def fresh(batch):
-    # the loss masks batch['wh'/'reg'] in place (Q2): idempotent, so the same resident batch is reused
+    # the loss masks batch['wh'/'reg'] in place (Q2).  That is idempotent for every workload benched here (two-channel
+    # `wh`, and the periodic angle loss of --uda advent); only the NON-periodic rotated loss also replaces the angle
+    # target by its sigmoid on every call (losses/centernet.py:117) -- not a bench workload -- so the same resident
+    # batch is reused
     return batch
 
 

@@ -20,11 +20,17 @@ writes in place.
 What is reproduced on purpose: the level-3/level-4 `project` branches are
 evaluated although their result is discarded (dla.py:207-213), so their
 BatchNorm running statistics advance exactly like the reference's (and their
-weights receive no gradient); `build` cannot download the ImageNet trunk
-(dla.py:297-309, no network here) -- weights are default-initialised and the
-unused `base.fc` (Q8) is absent unless a checkpoint provides it.
+weights receive no gradient).  `build` starts from the ImageNet trunk like the
+reference (dla.py:297-309,524-526) when the file the reference would download
+(`dla34-ba72cf86.pth`) is found locally -- `$CNUDA_DLA34_WEIGHTS`, else the torch
+hub checkpoint cache -- and then also carries the unused `base.fc` (Q8); there
+is no network path in this build, so without the file it WARNS and keeps the
+default initialisation.
 """
+import logging
 import math
+import os
+import warnings
 
 import torch
 from torch import nn
@@ -32,6 +38,9 @@ from torch import nn
 from hip_runtime import nn as hnn
 from hip_runtime import ops
 from libs.DCNv2.dcn_v2 import DCN
+
+log = logging.getLogger(__name__)
+PRETRAINED_FILE = 'dla34-ba72cf86.pth'          # get_model_url('imagenet', 'dla34', 'ba72cf86'), dla.py:22-25
 
 BN_MOMENTUM = 0.1
 DLA34_LEVELS = (1, 1, 1, 2, 2, 1)
@@ -132,6 +141,14 @@ class DLA(nn.Module):
         self.level4 = Tree(levels[4], c[3], c[4], 2, level_root=True)
         self.level5 = Tree(levels[5], c[4], c[5], 2, level_root=True)
 
+    def load_pretrained_model(self, path):
+        """dla.py:297-309: attaches the classifier `fc` (1x1 conv, never used by forward: Q8) sized from the
+        checkpoint's last entry, then loads strictly."""
+        weights = torch.load(path, map_location='cpu')
+        num_classes = len(weights[list(weights.keys())[-1]])
+        self.fc = hnn.Conv2d(self.channels[-1], num_classes, 1, bias=True)
+        self.load_state_dict(weights)
+
     def forward(self, x):
         x = self.base_layer(x)
         feats = []
@@ -141,11 +158,32 @@ class DLA(nn.Module):
         return feats
 
 
+def pretrained_path():
+    """Where the ImageNet dla34 state dict is looked for: `$CNUDA_DLA34_WEIGHTS`, then the file name
+    model_zoo.load_url() would have cached (dla.py:303-304)."""
+    env = os.environ.get('CNUDA_DLA34_WEIGHTS')
+    return env if env else os.path.join(torch.hub.get_dir(), 'checkpoints', PRETRAINED_FILE)
+
+
 def dla34(pretrained=False):
+    """pretrained: True -> the file must exist (raises, like a failed download); 'auto' -> load it when it is
+    there, warn loudly when it is not; False -> default initialisation."""
+    model = DLA()
     if pretrained:
-        raise RuntimeError("dla34(pretrained=True) needs http://dl.yf.io/dla/models (dla.py:23-25); no network "
-                           "in this build -- load a checkpoint with utils.helper.load_model instead")
-    return DLA()
+        path = pretrained_path()
+        if os.path.isfile(path):
+            model.load_pretrained_model(path)
+        elif pretrained == 'auto':
+            msg = ("dla34: ImageNet weights %s not found -- the trunk is RANDOMLY initialised, whereas the reference's "
+                   "build() always starts from them (backends/dla.py:524-526; no download in this build). Put the "
+                   "file there or set CNUDA_DLA34_WEIGHTS, or load a checkpoint with utils.helper.load_model." % path)
+            log.warning(msg)
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        else:
+            raise RuntimeError("dla34(pretrained=True): %s not found (http://dl.yf.io/dla/models, dla.py:23-25; no "
+                               "network in this build) -- set CNUDA_DLA34_WEIGHTS or load a checkpoint with "
+                               "utils.helper.load_model" % path)
+    return model
 
 
 class DeformConv(nn.Module):
@@ -261,5 +299,5 @@ def build(num_classes, num_keypoints=0, head_conv=256, down_ratio=4, freeze_base
     heads = {'hm': num_classes, 'wh': 3 if rotated_boxes else 2, 'reg': 2}
     if num_keypoints > 0:
         heads['kps'] = num_keypoints * 2
-    return DLASeg('dla34', heads, pretrained=False, down_ratio=down_ratio, final_kernel=1, last_level=5,
+    return DLASeg('dla34', heads, pretrained='auto', down_ratio=down_ratio, final_kernel=1, last_level=5,
                   head_conv=head_conv, freeze_base=freeze_base, rotated_boxes=rotated_boxes)

@@ -96,6 +96,11 @@ __global__ void focal_bwd_kernel(const float* __restrict__ logits, const float* 
 // mode 1: periodic angle
 // out[0] = loss, out[1] = denominator (expanded-mask sum + 1e-4)
 // Single workgroup: B*M is a few thousand at most (M = max_detections).
+// `ind` comes from the data loader (datasets/coco.py:211).  The reference's torch.gather device-asserts on an index
+// outside [0, HW) (e.g. targets encoded for another output size); here such a row never touches memory: the forward
+// kernels read cell 0 instead and poison the loss with NaN (loud, no host sync), the backward kernels skip the row.
+__device__ __forceinline__ bool ind_ok(long long id, long long HW) { return id >= 0 && id < HW; }
+
 __global__ __launch_bounds__(kT) void regl1_fwd_kernel(const float* __restrict__ feat, const unsigned char* __restrict__ mask,
                                                        const long long* __restrict__ ind, float* __restrict__ target,
                                                        int B, int M, int ch, int HW, int mode, float weight,
@@ -105,7 +110,8 @@ __global__ __launch_bounds__(kT) void regl1_fwd_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < B * M; i += kT) {
         const int b = i / M;
         const float m = mask[i] ? 1.0f : 0.0f;
-        const long long id = ind[i];
+        long long id = ind[i];
+        if (!ind_ok(id, HW)) { id = 0; s_wh = (double)NAN; }
         for (int c = 0; c < ch; ++c) {
             const float pred = feat[((size_t)b * ch + c) * HW + id] * m;
             const float tg = target[(size_t)i * ch + c] * m;
@@ -153,6 +159,7 @@ __global__ void regl1_bwd_kernel(const float* __restrict__ feat, const unsigned 
         const int c = i % ch, bm = i / ch, b = bm / M;
         if (!mask[bm]) continue;
         const long long id = ind[bm];
+        if (!ind_ok(id, HW)) continue;
         const float pred = feat[((size_t)b * ch + c) * HW + id];
         const float tg = target[i];
         float g;
@@ -337,7 +344,9 @@ __global__ __launch_bounds__(kT) void kpsl1_fwd_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < B * M * ch; i += kT) {
         const int c = i % ch, bm = i / ch, b = bm / M;
         const float m = mask[i] ? 1.0f : 0.0f;
-        const float pred = feat[((size_t)b * ch + c) * HW + ind[bm]] * m;
+        long long id = ind[bm];
+        if (!ind_ok(id, HW)) { id = 0; s_l1 = (double)NAN; }
+        const float pred = feat[((size_t)b * ch + c) * HW + id] * m;
         const float tg = target[i] * m;
         target[i] = tg;                                   // in place, like the reference
         s_m += (double)m;
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(kT) void kpsl1_fwd_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < B * M * P; i += kT) {
         const int pr = i % P, bm = i / P, b = bm / M;
         const int ja = pairs[2 * pr], jb = pairs[2 * pr + 1];
-        const size_t fb = (size_t)b * ch * HW + ind[bm], tb = (size_t)bm * ch;
+        const size_t fb = (size_t)b * ch * HW + (ind_ok(ind[bm], HW) ? ind[bm] : 0), tb = (size_t)bm * ch;
         auto pm = [&](int c) { return feat[fb + (size_t)c * HW] * (mask[tb + c] ? 1.0f : 0.0f); };
         const float pd = kps_dist(pm(2 * ja), pm(2 * ja + 1), pm(2 * jb), pm(2 * jb + 1), use_l1);
         const float td = kps_dist(target[tb + 2 * ja], target[tb + 2 * ja + 1], target[tb + 2 * jb], target[tb + 2 * jb + 1], use_l1);
@@ -377,12 +386,13 @@ __global__ void kpsl1_bwd_kernel(const float* __restrict__ feat, const unsigned 
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += gridDim.x * blockDim.x) {
         if (i < n1) {
             const int c = i % ch, bm = i / ch, b = bm / M;
-            if (!mask[i]) continue;
+            if (!mask[i] || !ind_ok(ind[bm], HW)) continue;
             const float pred = feat[((size_t)b * ch + c) * HW + ind[bm]];
             atomicAdd(grad + ((size_t)b * ch + c) * HW + ind[bm], sgnf(pred - target[i]) * weight * up);
         } else {
             const int k = i - n1, pr = k % P, bm = k / P, b = bm / M;
             const int ja = pairs[2 * pr], jb = pairs[2 * pr + 1];
+            if (!ind_ok(ind[bm], HW)) continue;
             const size_t fb = (size_t)b * ch * HW + ind[bm], tb = (size_t)bm * ch;
             const int cs[4] = {2 * ja, 2 * ja + 1, 2 * jb, 2 * jb + 1};
             float mk[4], pv[4];
@@ -420,7 +430,7 @@ __global__ void gather_feat_kernel(const float* __restrict__ feat, const long lo
                                    float* __restrict__ out, int B, int M, int ch, long long HW) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * M * ch; i += gridDim.x * blockDim.x) {
         const int c = i % ch, bm = i / ch, b = bm / M;
-        out[i] = feat[((size_t)b * ch + c) * HW + ind[bm]];
+        out[i] = ind_ok(ind[bm], HW) ? feat[((size_t)b * ch + c) * HW + ind[bm]] : NAN;
     }
 }
 

@@ -19,10 +19,14 @@ returns, which is where the slot is recorded; `flat_grad += staging` then happen
 runs of recorded slots -- per all-reduce bucket as soon as it is complete (data parallel), otherwise once at
 the end of the pass (an engine callback queued from the first hook).
 """
+import weakref
+
 import torch
 
-_REGISTRY = {}
-_BY_PTR = {}          # data_ptr of a parameter inside some arena -> (arena, index)
+# Neither table keeps an arena (and through it a model's parameters) alive: the optimizer / data-parallel wrapper
+# that asked for the arena owns it, and the parameters' hooks reference it for as long as the parameters live.
+_REGISTRY = weakref.WeakValueDictionary()      # ids of the parameter set -> arena
+_BY_PTR = {}          # data_ptr of a parameter inside some arena -> (weak reference to the arena, index)
 
 
 def grad_sink(param):
@@ -32,7 +36,10 @@ def grad_sink(param):
     hit = _BY_PTR.get(param.data_ptr())
     if hit is None:
         return None
-    arena, i = hit
+    arena, i = hit[0](), hit[1]
+    if arena is None:                               # the arena is gone and the address was reused
+        del _BY_PTR[param.data_ptr()]
+        return None
     if not arena.valid_index(i, param) or arena.sunk[i]:
         return None
     return arena._sink(i)
@@ -46,6 +53,11 @@ class ParamArena:
         self.params = list(params)
         if not self.params:
             raise ValueError("ParamArena: no parameters")
+        # every check comes before the first parameter is re-pointed: a half-built arena must not exist
+        frozen = [i for i, p in enumerate(self.params) if not p.requires_grad]
+        if frozen:
+            raise RuntimeError("ParamArena: %d of %d parameters do not require grad (first at index %d); pass only "
+                               "trainable parameters (arena_for() filters them)" % (len(frozen), len(self.params), frozen[0]))
         dev = self.params[0].device
         # host-side bookkeeping only: works on any device (the gloo tests run it on CPU tensors);
         # the kernels that consume the arena (Adam, RCCL) require the GPU themselves
@@ -62,6 +74,7 @@ class ParamArena:
         self.staging = None             # gradients of the running backward pass (allocated on first use)
         self.sunk = [False] * len(self.params)      # staging slot written in this pass, not yet added to flat_grad
         self._flush_queued = False
+        self._bulk_zeroed = False       # flat_grad was cleared for this pass because every .grad had been set to None
         self._hooks = []
         self.on_ready = None            # callback(index) used by the data-parallel wrapper
         with torch.no_grad():
@@ -75,7 +88,7 @@ class ParamArena:
                     self.touched[i] = True
                 p.grad = gview
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
-                _BY_PTR[p.data_ptr()] = (self, i)
+                _BY_PTR[p.data_ptr()] = (weakref.ref(self), i)
 
     # -- gradient sink -------------------------------------------------------------
     def valid_index(self, i, param):
@@ -109,10 +122,37 @@ class ParamArena:
 
     def _end_of_pass(self):
         self._flush_queued = False
+        self._bulk_zeroed = False
         self.flush()
 
+    def _adopt_cleared_grad(self, i, param):
+        """`param.grad is None` when its hook runs: an optimizer that does not know the arena (stock
+        torch.optim.*, whose zero_grad() defaults to set_to_none=True) dropped the gradient view.  The arena
+        stays authoritative: whatever `flat_grad` still holds for this parameter belongs to an earlier step and
+        is cleared, then `.grad` is bound to the view again -- before this pass's staged gradient is added."""
+        o, n = self.offsets[i], param.numel()
+        if not self._bulk_zeroed:
+            if all(p.grad is None for p in self.params):
+                self.flat_grad.zero_()                          # the usual case: one memset for the whole step
+                self.touched = [False] * len(self.params)
+                self._bulk_zeroed = True
+                if not self._flush_queued:
+                    self._flush_queued = True                   # _end_of_pass() re-arms the bulk clear
+                    torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
+            else:
+                self.flat_grad[o:o + n].zero_()
+        param.grad = self.flat_grad[o:o + n].view(param.shape)
+
     def _make_hook(self, i):
+        wself = weakref.ref(self)       # a hook lives in the parameter's C++ autograd node: a strong reference
+                                        # from there would make arena <-> parameters an uncollectable cycle
+
         def hook(param):
+            self = wself()
+            if self is None:            # the arena's owners (optimizer, wrapper) are gone
+                return
+            if param.grad is None:
+                self._adopt_cleared_grad(i, param)
             self.touched[i] = True
             if self.sunk[i] and not self._flush_queued:
                 # runs inside backward(): the engine calls this back when the pass is over
@@ -161,13 +201,17 @@ class ParamArena:
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        for k in [k for k, v in _BY_PTR.items() if v[0] is self]:
+        for k in [k for k, v in _BY_PTR.items() if v[0]() is self or v[0]() is None]:
             del _BY_PTR[k]
 
 
 def arena_for(params):
-    """One arena per parameter set (the optimizer and the data-parallel wrapper share it)."""
-    params = [p for p in params]
+    """One arena per set of TRAINABLE parameters: the optimizer (which may have been given frozen parameters
+    too, e.g. `model.parameters()` with freeze_base=True) and the data-parallel wrapper (which filters by
+    requires_grad) resolve to the same arena."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        raise ValueError("arena_for: none of the parameters requires grad")
     key = tuple(id(p) for p in params)
     a = _REGISTRY.get(key)
     if a is not None and not a.valid():

@@ -11,9 +11,12 @@ log = logging.getLogger(__name__)
 
 
 class AverageMeter:
-    """Running mean weighted by batch size (utils/helper.py:13-35)."""
+    """Running mean weighted by batch size, with the reference's constructor and text form
+    (utils/helper.py:13-35; the driver builds `AverageMeter(name=k)`, train.py:164,182,243)."""
 
-    def __init__(self):
+    def __init__(self, name, fmt=':f'):
+        self.name = name
+        self.fmt = fmt
         self.reset()
 
     def reset(self):
@@ -23,8 +26,12 @@ class AverageMeter:
         self.val = val
         self.sum += val * n
         self.count += n
-        if self.count > 0:
+        if self.count > 0:                      # the reference divides unguarded; update(x, n=0) would raise there
             self.avg = self.sum / self.count
+
+    def __str__(self):
+        fmtstr = '{name} {val' + self.fmt + '} ({avg' + self.fmt + '})'
+        return fmtstr.format(**self.__dict__)
 
 
 def _unwrap(model):

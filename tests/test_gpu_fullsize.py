@@ -66,14 +66,24 @@ def test_full_size_step_properties():
 
 
 def test_full_size_uda_step_is_reproducible():
-    _, _, o1, p1, b1 = _run('entropy', steps=2)
-    _, _, o2, p2, b2 = _run('entropy', steps=2)
-    for a, b in zip(o1, o2):
-        for k in a['stats']:
-            assert abs(float(a['stats'][k]) - float(b['stats'][k])) <= 1e-5 * max(1e-6, abs(float(a['stats'][k]))), k
-    for k in ('hm', 'wh', 'reg'):
-        x, y = o1[-1]['target_domain'][k], o2[-1]['target_domain'][k]
-        assert (x - y).abs().max().item() <= 1e-4 * y.abs().max().item(), k
+    """Forward passes are deterministic (fixed-order reductions everywhere); the gradients are too up to the float
+    atomics of col2im's stragglers.  Compared after ONE step: Adam turns a sign change of a rounding-noise
+    gradient into a +-lr move, so later steps of two runs legitimately drift apart by ~1e-4."""
+    pl1, _, o1, _, b1 = _run('entropy')
+    g1 = {n: p.grad.detach().clone() for n, p in pl1.backend.named_parameters() if p.grad is not None}
+    pl2, _, o2, _, b2 = _run('entropy')
+    g2 = {n: p.grad.detach().clone() for n, p in pl2.backend.named_parameters() if p.grad is not None}
+    for k in o1[0]['stats']:
+        assert float(o1[0]['stats'][k]) == float(o2[0]['stats'][k]), k
+    for dom in ('source_domain', 'target_domain'):
+        for k in ('hm', 'wh', 'reg'):
+            assert torch.equal(o1[0][dom][k], o2[0][dom][k]), (dom, k)
+    assert sorted(g1) == sorted(g2)
+    for n in g1:
+        scale = g2[n].abs().max().item()
+        if n.endswith('.conv.bias') and 'ida' in n:
+            continue                      # DCN bias in front of a BatchNorm: the gradient is rounding noise only
+        assert (g1[n] - g2[n]).abs().max().item() <= 1e-4 * max(scale, 1e-12), n
     for n in b1:
         if b1[n].is_floating_point():
-            assert (b1[n] - b2[n]).abs().max().item() <= 1e-5 * max(1e-6, b2[n].abs().max().item()), n
+            assert torch.equal(b1[n], b2[n]), n

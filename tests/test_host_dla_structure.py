@@ -49,3 +49,34 @@ def test_build_signature_and_no_cpu_fallback():
     m = dla.build(num_classes=2)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 64, 64))          # CPU tensors are refused, never silently computed
+
+
+def test_build_loads_local_imagenet_trunk_or_warns(tmp_path, monkeypatch):
+    """The reference's build() always starts from the ImageNet dla34 checkpoint (backends/dla.py:524-526,297-309);
+    this build has no download: it loads the file when it is present (and then carries the unused `base.fc`, Q8)
+    and warns loudly when it is not."""
+    import torch
+    from backends import dla
+    monkeypatch.setenv('CNUDA_DLA34_WEIGHTS', str(tmp_path / 'missing.pth'))
+    with pytest.warns(RuntimeWarning, match='RANDOMLY initialised'):
+        m0 = dla.build(num_classes=3)
+    assert not any(k.startswith('base.fc') for k in m0.state_dict())
+    with pytest.raises(RuntimeError):
+        dla.dla34(pretrained=True)
+    # a stand-in for dla34-ba72cf86.pth: the trunk's own keys + the classifier, last entry = fc.bias [1000]
+    trunk = dla.DLA()
+    sd = {k: torch.full_like(v, 0.25) if v.is_floating_point() else v.clone() for k, v in trunk.state_dict().items()}
+    sd['fc.weight'] = torch.zeros(1000, 512, 1, 1)
+    sd['fc.bias'] = torch.zeros(1000)
+    path = tmp_path / dla.PRETRAINED_FILE
+    torch.save(sd, path)
+    monkeypatch.setenv('CNUDA_DLA34_WEIGHTS', str(path))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        m1 = dla.build(num_classes=3, freeze_base=True)
+    got = m1.state_dict()
+    assert got['base.fc.weight'].shape == (1000, 512, 1, 1) and got['base.fc.bias'].shape == (1000,)
+    assert torch.all(got['base.level2.tree1.conv1.weight'] == 0.25)
+    assert all(not p.requires_grad for p in m1.base.parameters())
+    assert m1.hm[2].bias.requires_grad
