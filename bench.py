@@ -66,15 +66,21 @@ UDA_WORKLOADS = {
 }
 
 
-def build_plugin(device, parallel, uda_name='entropy'):
+def build_plugin(device, parallel, uda_name='entropy', backend_name='dla34'):
+    import warnings
     import uda
     import uda.base
-    from backends import dla
+    from backends import dla, resnet
     from hip_runtime import optim
     from losses.centernet import DetectionLoss
     _, factory, rotated, periodic, wd = UDA_WORKLOADS[uda_name]
     torch.manual_seed(42)                                   # defaults.yaml: seed 42
-    backend = dla.build(num_classes=NUM_CLASSES, rotated_boxes=rotated)
+    if backend_name == 'resnet18':                          # configs[0]: configs/defaults.yaml with backend=resnet
+        backend = resnet.build(18, num_classes=NUM_CLASSES, pretrained=False, rotated_boxes=rotated)
+    else:
+        with warnings.catch_warnings():                     # random-init weights are the stated bench condition
+            warnings.simplefilter('ignore', RuntimeWarning)
+            backend = dla.build(num_classes=NUM_CLASSES, rotated_boxes=rotated)
     # give the DCN offset/mask convs non-zero weights so that deformable sampling is exercised (Q7)
     with torch.no_grad():
         for n, p in backend.named_parameters():
@@ -103,14 +109,17 @@ def fresh(batch):
     return batch
 
 
-def cpu_baseline(size=256):
-    """The CPU oracle's EntropyMinimization step (torch CPU ops + scalar C DCN loops, the
-    reference's CPU sequence) on 1 source + 1 target image at size x size."""
+def _cpu_step_fn():
+    """-> step(size, seed) -> seconds: one EntropyMinimization step of the CPU oracle (torch CPU ops + scalar C DCN
+    loops, the reference's CPU sequence: uda/entropy_minimization.py:11-43) on 1 source + 1 target image."""
+    import warnings
     from oracle import dla as odla
     from oracle import losses as ol
     from backends import dla
     torch.manual_seed(0)
-    model = dla.build(num_classes=NUM_CLASSES)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        model = dla.build(num_classes=NUM_CLASSES)
     state = {}
     for k, v in model.state_dict().items():
         t = v.detach().clone()
@@ -119,66 +128,94 @@ def cpu_baseline(size=256):
                 t.normal_(0, 0.5 / (t.shape[1] * 9) ** 0.5)
             t.requires_grad_(True)
         state[k] = t
-    params = [v for v in state.values() if v.requires_grad]
-    opt = torch.optim.Adam(params, lr=5e-5, weight_decay=1e-4)
-    batch = {k: v for k, v in synthetic_batch(1, size, 7, 'cpu').items()}
-    t0 = time.perf_counter()
-    opt.zero_grad()
-    out_s = odla.forward(state, batch['input'], training=True)
-    out_t = odla.forward(state, batch['target_domain_input'], training=True)
-    c_loss, _, _ = ol.detection_loss(out_s, batch, 1.0, 0.1, 1.0, 1.0, False)
-    e_loss = ol.entropy_loss(out_t['hm']) * 1e-4
-    c_loss.backward()
-    e_loss.backward()
-    opt.step()
-    dt = time.perf_counter() - t0
-    scale = (size / 512.0) ** 2
-    return {
-        'value': round(scale / dt, 5), 'unit': 'images/sec (512x512-equivalent source images)',
-        'cores': torch.get_num_threads(), 'kind': 'port',
-        'sample': '1 EntropyMinimization step of the CPU oracle on 1 source + 1 target image at %dx%d '
-                  '(%.2f s; pixel count scaled by %.3f to the 512x512 workload); torch CPU conv/BN '
-                  '(%d threads) + single-thread C DCN loops like the reference CPU extension'
-                  % (size, size, dt, scale, torch.get_num_threads()),
+    opt = torch.optim.Adam([v for v in state.values() if v.requires_grad], lr=5e-5, weight_decay=1e-4)
+
+    def step(size, seed):
+        batch = synthetic_batch(1, size, seed, 'cpu')
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        out_s = odla.forward(state, batch['input'], training=True)
+        out_t = odla.forward(state, batch['target_domain_input'], training=True)
+        c_loss, _, _ = ol.detection_loss(out_s, batch, 1.0, 0.1, 1.0, 1.0, False)
+        e_loss = ol.entropy_loss(out_t['hm']) * 1e-4
+        c_loss.backward()
+        e_loss.backward()
+        opt.step()
+        return time.perf_counter() - t0
+    return step
+
+
+def cpu_baseline(budget_s=150.0):
+    """The reference's CPU path beside the GPU number: one warm-up step (untimed: thread
+    pools, allocator, oneDNN primitive caches), then 3 timed repeats at 256x256 (median, min, max), then -- when
+    the budget allows -- one timed step at the metric's own 512x512, which is what `value` reports; the 256x256
+    median scaled by pixel count is kept beside it to show how well the scaling holds."""
+    step = _cpu_step_fn()
+    t_begin = time.perf_counter()
+    step(128, 5)                                            # warm-up
+    t256 = sorted(step(256, 7 + i) for i in range(3))
+    med256 = t256[1]
+    scaled = (256 / 512.0) ** 2 / med256
+    res = {
+        'unit': 'images/sec (512x512 source images)', 'cores': torch.get_num_threads(), 'kind': 'port',
+        's_per_step_256': {'median': round(med256, 3), 'min': round(t256[0], 3), 'max': round(t256[2], 3), 'repeats': 3},
+        'value_from_256_scaled_by_pixels': round(scaled, 5),
     }
+    spent = time.perf_counter() - t_begin
+    t512 = None
+    if spent + 4.6 * med256 <= budget_s:                    # a 512x512 step costs about 4-4.5x a 256x256 one
+        t512 = step(512, 11)
+        res['s_per_step_512'] = round(t512, 3)
+        res['pixel_scaling_check'] = round((1.0 / t512) / scaled, 3)
+    res['value'] = round(1.0 / t512, 5) if t512 else round(scaled, 5)
+    res['sample'] = ('EntropyMinimization step of the CPU oracle on 1 source + 1 target image: 1 untimed warm-up, '
+                     '3 repeats at 256x256 (median %.2f s, spread %.2f-%.2f s)%s; torch CPU conv/BN (%d threads) + '
+                     'single-thread C DCN loops like the reference CPU extension; `value` = %s'
+                     % (med256, t256[0], t256[2], ', 1 step at 512x512 (%.2f s)' % t512 if t512 else
+                        ' (512x512 step skipped: over the %.0f s budget)' % budget_s, torch.get_num_threads(),
+                        '1 / (seconds per 512x512 step)' if t512 else '256x256 median scaled by pixel count'))
+    return res
 
 
 def decode_latency(device, with_cpu=True):
-    """BASELINE.json's second metric: `decode_detection` latency at B=16, K=150 on 128x128 maps, C=6 (the
-    reference's default) and C=80 (COCO stress) -- SURVEY 8d.  Inputs resident in HBM, probabilities as
-    `Model.get_detections` hands them over (Q1).  Algorithmic bytes = one read of the heat map + gathered
-    wh/reg + the [B,K,6] result."""
+    """BASELINE.json's second metric: `decode_detection` latency at B=16, K=150 on 128x128 maps (cfg2-4) and
+    160x160 maps (cfg5, 640x640 input), C=6 (the reference's default) and C=80 (COCO stress) -- SURVEY 8d.  Inputs
+    resident in HBM, probabilities as `Model.get_detections` hands them over (Q1).  Algorithmic bytes = one read of
+    the heat map + gathered wh/reg + the [B,K,6] result."""
     from backends.decode import decode_detection
     res = {}
-    B, H, W, K = 16, 128, 128, 150
-    for C in (6, 80):
-        g = torch.Generator(device='cpu').manual_seed(7 + C)
-        heat = torch.sigmoid(torch.randn(B, C, H, W, generator=g) - 2.19).clamp(1e-4, 1 - 1e-4)
-        wh, reg = torch.rand(B, 2, H, W, generator=g) * 40, torch.rand(B, 2, H, W, generator=g)
-        hd, whd, regd = heat.to(device), wh.to(device), reg.to(device)
-        for _ in range(10):
-            dets = decode_detection(hd, whd, regd, K=K)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 100
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(n):
-            dets = decode_detection(hd, whd, regd, K=K)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / n
-        nbytes = B * C * H * W * 4 + B * K * 4 * 4 + B * K * 6 * 4
-        entry = {'us': round(us, 1), 'algorithmic_bytes': nbytes, 'gb_per_s': round(nbytes / us / 1e3, 1),
-                 'hbm_frac': round(nbytes / (us * 1e-6) / 8e12, 4)}
-        if with_cpu and C == 6:
-            from oracle import decode as oracle_decode       # checker / baseline leg only
-            t0 = time.perf_counter()
-            want = oracle_decode.decode_detection(heat.numpy(), wh.numpy(), reg.numpy(), K=K)
-            entry['cpu_port_us'] = round((time.perf_counter() - t0) * 1e6, 1)
-            got = dets.cpu().numpy()
-            entry['matches_oracle'] = bool(abs(got - want).max() <= 1e-4)
-        res['C%d' % C] = entry
-    res['shape'] = 'B=16, K=150, 128x128 maps, fp32'
+    B, K = 16, 150
+    for H in (128, 160):
+        W = H
+        for C in (6, 80):
+            g = torch.Generator(device='cpu').manual_seed(7 + C + H)
+            heat = torch.sigmoid(torch.randn(B, C, H, W, generator=g) - 2.19).clamp(1e-4, 1 - 1e-4)
+            wh, reg = torch.rand(B, 2, H, W, generator=g) * 40, torch.rand(B, 2, H, W, generator=g)
+            hd, whd, regd = heat.to(device), wh.to(device), reg.to(device)
+            for _ in range(10):
+                dets = decode_detection(hd, whd, regd, K=K)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 100
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(n):
+                dets = decode_detection(hd, whd, regd, K=K)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / n
+            nbytes = B * C * H * W * 4 + B * K * 4 * 4 + B * K * 6 * 4
+            entry = {'us': round(us, 1), 'algorithmic_bytes': nbytes, 'gb_per_s': round(nbytes / us / 1e3, 1),
+                     'hbm_frac': round(nbytes / (us * 1e-6) / 8e12, 4)}
+            if with_cpu and C == 6:
+                from oracle import decode as oracle_decode       # checker / baseline leg only
+                t0 = time.perf_counter()
+                want = oracle_decode.decode_detection(heat.numpy(), wh.numpy(), reg.numpy(), K=K)
+                entry['cpu_port_us'] = round((time.perf_counter() - t0) * 1e6, 1)
+                got = dets.cpu().numpy()
+                entry['matches_oracle'] = bool(np.array_equal(got[..., 4:], want[..., 4:])
+                                               and abs(got - want).max() <= 1e-4)
+            res['C%d' % C if H == 128 else 'C%d_160' % C] = entry
+    res['shape'] = 'B=16, K=150, fp32; C6 / C80: 128x128 maps, C6_160 / C80_160: 160x160 maps (cfg5)'
     return res
 
 
@@ -208,6 +245,38 @@ def inference_throughput(device, backend, size, batch):
             'what': 'export.CenterNet: eval forward + decode (K=%d), fp32, BatchNorm not folded' % MAX_OBJS}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` -> `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
+    arguments>` as a child process; returns its exit code (non-zero when any rank failed)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '1')
+    return subprocess.call(cmd, env=env)
+
+
+CONFIGS = {
+    # --config N: BASELINE.json configs[N] -> (backend, uda, size, batch)
+    0: ('resnet18', 'none', 256, 2),
+    1: ('dla34', 'none', 512, 16),
+    2: ('dla34', 'entropy', 512, 16),
+    3: ('dla34', 'maxsq', 512, 16),
+    4: ('dla34', 'advent', 640, 16),
+}
+
+
+def apply_config(args):
+    if args.config is not None:
+        args.backend, args.uda, args.size, args.batch = CONFIGS[args.config]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -217,17 +286,27 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--uda', default='entropy', choices=sorted(UDA_WORKLOADS),
                     help="BASELINE.json configs[1..4]: none / entropy (default, the headline) / maxsq / advent (use --size 640)")
+    ap.add_argument('--backend', default='dla34', choices=['dla34', 'resnet18'])
+    ap.add_argument('--config', type=int, default=None, choices=sorted(CONFIGS),
+                    help='BASELINE.json configs[N]: sets --backend/--uda/--size/--batch (2 = the default headline workload)')
+    ap.add_argument('--cpu-baseline-budget', type=float, default=150.0,
+                    help='seconds of host time the cpu_baseline leg may spend (the 512x512 sample is skipped beyond it)')
     ap.add_argument('--profile-steps', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the decode-latency and inference legs (profiling runs)')
     args = ap.parse_args()
 
+    apply_config(args)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started plainly (`python bench.py --gpus N`): spawn the N ranks ourselves.  Decided from the environment
+        # alone, BEFORE anything touches the GPU; the ranks are fresh child processes of torch.distributed.run and
+        # this process only waits for them (never exec from a process that has initialised HIP).
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
-                         % (args.gpus, args.gpus))
+    if args.gpus != world:
+        raise SystemExit('bench.py --gpus %d was launched with WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
     # test knobs (a one-GPU box cannot host two RCCL ranks): CNUDA_BENCH_ONE_DEVICE=1 puts every rank on cuda:0,
@@ -242,7 +321,7 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    plugin = build_plugin(device, parallel=world > 1, uda_name=args.uda)
+    plugin = build_plugin(device, parallel=world > 1, uda_name=args.uda, backend_name=args.backend)
     batch = synthetic_batch(args.batch, args.size, 42 + rank, device, rotated=UDA_WORKLOADS[args.uda][2])
 
     def barrier():
@@ -340,16 +419,20 @@ def main():
         value = args.batch * world * args.steps / elapsed
         # whole-step algorithmic work: 195.5 GFLOP per forwarded 512x512 image, 2 forwards per source image
         step_tflop = 195.5e9 * (args.size / 512.0) ** 2 * (1 if args.uda == 'none' else 2) * args.batch / 1e12
+        arch = 'DLA-34' if args.backend == 'dla34' else 'ResNet-18'
         line = {
             'metric': 'images/sec CenterNet DLA-34 512x512 UDA step (entropy minimisation)'
-            if args.uda == 'entropy' and args.size == 512 else 'images/sec CenterNet DLA-34 %dx%d train step (uda=%s)' % (args.size, args.size, args.uda),
+            if args.uda == 'entropy' and args.size == 512 and args.backend == 'dla34'
+            else 'images/sec CenterNet %s %dx%d train step (uda=%s)' % (arch, args.size, args.size, args.uda),
             'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32' if hr.get_matrix_mode() == 0 else 'f32 (bf16 x3 split operands)',
             'data': 'synthetic', 'matrix_mode': hr.get_matrix_mode(),
-            'config': {'workload': '%s: DLA-34 + DCNv2%s, %dx%d, per-GPU batch %d source%s, uda=%s, '
+            'config': {'workload': '%s: %s%s, %dx%d, per-GPU batch %d source%s, uda=%s, '
                                    'Adam(lr 5e-5), random-init weights'
-                                   % (UDA_WORKLOADS[args.uda][0], ' rotated-box head' if args.uda == 'advent' else '',
+                                   % ('configs[0]' if args.backend == 'resnet18' else UDA_WORKLOADS[args.uda][0],
+                                      'DLA-34 + DCNv2' if args.backend == 'dla34' else 'ResNet-18 (torchvision-0.6 trunk restated) + 3 deconv',
+                                      ' rotated-box head' if args.uda == 'advent' else '',
                                       args.size, args.size, args.batch,
                                       '' if args.uda == 'none' else ' + %d target' % args.batch,
                                       {'none': 'none', 'entropy': 'entropy_minimization',
@@ -357,7 +440,9 @@ def main():
                                        'advent': 'adversarial_entropy_minimization'}[args.uda]),
                        'global_batch': args.batch * world, 'input': [3, args.size, args.size],
                        'parallelism': 'dp%d' % world},
-            'step_mfma_fraction': round(step_tflop / (ms * 1e-3) / PEAK_FP32_MFMA_TFLOPS, 4),
+            # whole-step algorithmic FLOPs are tabulated for DLA-34 only
+            'step_mfma_fraction': round(step_tflop / (ms * 1e-3) / PEAK_FP32_MFMA_TFLOPS, 4)
+            if args.backend == 'dla34' else None,
             'losses': {k: round(v, 5) for k, v in stats.items()},
             'roofline': roofline,
             'decode_latency': decode_latency(device, with_cpu=not args.no_cpu_baseline)
@@ -367,7 +452,7 @@ def main():
             'matrix_mode_split': split_leg,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline()
+            line['cpu_baseline'] = cpu_baseline(args.cpu_baseline_budget)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)

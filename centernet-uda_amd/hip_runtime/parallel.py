@@ -11,6 +11,13 @@ batch; losses.centernet.DetectionLoss.use_global_normalizers() (the default of
 uda.base.Model.to(parallel=True)) scales every rank's loss so that this average
 is the gradient of that global loss.
 
+BatchNorm buffers: nn.DataParallel re-broadcasts device 0's buffers to the replicas on every forward and only
+replica 0's in-place updates persist, so the running statistics the reference evaluates and checkpoints with are
+those of replica 0's shard.  Here every rank updates its own statistics while training (they are not read in train
+mode) and rank 0's are broadcast to all ranks whenever the wrapper switches to eval (`train(False)` / `eval()`,
+i.e. `uda.set_phase(False)`): evaluation on any rank then sees exactly replica 0's statistics, and rank 0 -- the
+rank that writes checkpoints -- holds them by construction.
+
 Two (or more) backward() calls per step accumulate locally under `no_sync()`;
 buckets fire during the last backward; `finish_gradient_sync()` launches any
 bucket that did not become ready (parameters without a gradient) and makes the
@@ -53,8 +60,7 @@ class DataParallel(nn.Module):
         if self.world_size > 1:
             # replicas start identical (DataParallel broadcasts parameters and buffers every forward)
             dist.broadcast(self.arena.flat_param, src=0, group=self.process_group)
-            for buf in module.buffers():
-                dist.broadcast(buf, src=0, group=self.process_group)
+            self.sync_buffers()
 
     @property
     def world_size(self):
@@ -68,6 +74,30 @@ class DataParallel(nn.Module):
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
+
+    def sync_buffers(self):
+        """Every rank's buffers (BatchNorm running statistics, batch counters) := rank 0's; one broadcast per
+        dtype over a flattened copy (330 tensors for DLA-34).  Collective: all ranks must call it."""
+        if self.world_size <= 1:
+            return
+        by_dtype = {}
+        for buf in self.module.buffers():
+            by_dtype.setdefault(buf.dtype, []).append(buf)
+        for bufs in by_dtype.values():
+            flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+            dist.broadcast(flat, src=0, group=self.process_group)
+            off = 0
+            with torch.no_grad():
+                for b in bufs:
+                    b.copy_(flat[off:off + b.numel()].view_as(b))
+                    off += b.numel()
+
+    def train(self, mode=True):
+        was_training = self.training
+        super().train(mode)
+        if was_training and not mode:
+            self.sync_buffers()                 # evaluate (on every rank) with replica 0's statistics
+        return self
 
     @contextlib.contextmanager
     def no_sync(self):

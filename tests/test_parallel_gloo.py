@@ -84,6 +84,15 @@ def _worker(rank, world, port, bucket_bytes, q):
         dp(x1).sum().backward()
         dp.finish_gradient_sync()
         assert net.a.weight.grad.data_ptr() == dp.arena.flat_grad.data_ptr()
+        # running statistics drift apart per rank while training and are rank 0's again at the switch to eval
+        # (nn.DataParallel re-broadcasts device 0's buffers every forward, utils/helper.py:75-80)
+        net.stat.fill_(10.0 * (rank + 1))
+        net.register_buffer('count', torch.tensor(rank + 5, dtype=torch.int64))
+        dp.train()
+        assert float(net.stat[0]) == 10.0 * (rank + 1)            # train -> train: nothing is exchanged
+        dp.eval()
+        assert float(net.stat[0]) == 10.0 and int(net.count) == 5 and not net.training
+        dp.train()
         q.put((rank, 'ok'))
     except Exception as e:                                  # pragma: no cover
         import traceback
