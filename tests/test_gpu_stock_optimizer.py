@@ -36,6 +36,10 @@ def _plugin(golden, stock):
 
 @pytest.mark.parametrize('parallel', [False, True])
 def test_stock_torch_adam_trains_like_the_fused_adam(golden, parallel):
+    """Step 0 must agree to rounding (same gradients bit for bit, parameters within Adam's own rounding); later
+    steps are compared through the losses only: at this fixture size (B = 2 at 64 x 64, 8 samples per channel in
+    the deepest BatchNorm) a one-ulp parameter difference changes the next gradient by 1e-3 -- measured between
+    these very two optimizers -- so element-wise parameter equality after several steps is not a property."""
     B, S, M = 2, 64, 8
     runs = []
     for stock in (False, True):
@@ -45,24 +49,31 @@ def test_stock_torch_adam_trains_like_the_fused_adam(golden, parallel):
             plugin.backend = DataParallel(model)
         hist = []
         for step in range(3):
+            before = {n: p.detach().clone() for n, p in model.named_parameters()}
             data = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, (3, 2), 2, 51 + step).items()}
             data['input'] = T(gin.image_batch(B, S, S, 60 + step))
             data['target_domain_input'] = T(gin.image_batch(B, S, S, 70 + step))
-            hist.append({k: float(v) for k, v in plugin.step(data)['stats'].items()})
-        runs.append((hist, {n: p.detach().clone() for n, p in model.named_parameters()},
-                     {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.named_parameters()}))
-    (h0, p0, g0), (h1, p1, g1) = runs
-    for a, b in zip(h0, h1):
+            stats = {k: float(v) for k, v in plugin.step(data)['stats'].items()}
+            params = {n: p.detach().clone() for n, p in model.named_parameters()}
+            grads = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.named_parameters()}
+            moved = sum(int((params[n] != before[n]).sum()) for n in params)
+            hist.append((stats, params, grads, moved))
+        runs.append(hist)
+    fused, stock = runs
+    # step 0: identical gradients (this step's, nothing stale, nothing missing), parameters equal to Adam's rounding
+    for n, g0 in fused[0][2].items():
+        g1 = stock[0][2][n]
+        assert (g0 is None or float(g0.abs().sum()) == 0.0) == (g1 is None or float(g1.abs().sum()) == 0.0), n
+        if g1 is not None and g0 is not None:
+            assert torch.equal(g0, g1), n
+        assert (fused[0][1][n] - stock[0][1][n]).abs().max().item() <= 2e-7 * (1.0 + fused[0][1][n].abs().max().item()), n
+    for step in range(3):
+        a, b = fused[step][0], stock[step][0]
         for k in a:
-            assert abs(a[k] - b[k]) <= 1e-4 * max(abs(a[k]), 1e-6), (k, a[k], b[k])
-    assert any(g is not None for g in g1.values())
-    for n in p0:
-        assert (g0[n] is None or float(g0[n].abs().sum()) == 0.0) == (g1[n] is None or float(g1[n].abs().sum()) == 0.0), n
-        # Adam moves every element by <= lr per step: three steps of rounding-level disagreement stay far below that
-        d = (p0[n] - p1[n]).abs()
-        assert d.max().item() <= 3 * 2.1 * 5e-5, n
-        if not n.endswith('.conv.bias'):
-            assert (d > 1e-6).float().mean().item() <= 0.02, (n, (d > 1e-6).float().mean().item())
+            assert abs(a[k] - b[k]) <= (1e-6 if step == 0 else 2e-3) * max(abs(a[k]), 1e-6), (step, k, a[k], b[k])
+        # every step really trains: nearly every trainable element moves
+        total = sum(p.numel() for n, p in stock[step][1].items() if stock[step][2][n] is not None)
+        assert stock[step][3] >= 0.9 * total, (step, stock[step][3], total)
 
 
 def test_out_of_range_ind_poisons_the_loss_instead_of_touching_memory():
