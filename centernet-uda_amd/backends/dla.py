@@ -288,11 +288,46 @@ class DLASeg(nn.Module):
                             m.bias.zero_()
             setattr(self, head, fc)
 
-    def forward(self, x):
+    def features(self, x):
+        """The [B, 64, H/4, W/4] map every head reads (dla.py:500-505)."""
         feats = self.dla_up(self.base(x))
         y = list(feats[:self.last_level - self.first_level])
         self.ida_up(y, 0, len(y))
-        return {head: getattr(self, head)(y[-1]) for head in self.heads}
+        return y[-1]
+
+    def forward(self, x):
+        feat = self.features(x)
+        return {head: getattr(self, head)(feat) for head in self.heads}
+
+    def forward_domains(self, source, target, target_grad_heads=('hm',)):
+        """Both domains' forward passes of a UDA step (uda/entropy_minimization.py:18-19) as ONE pass over the
+        concatenated batch: every layer runs once on twice the pixels (half the launches, fuller GEMM tiles on
+        the small feature maps), each BatchNorm normalises the two halves by their own batch statistics and updates
+        its running statistics once per half, source first (hip_runtime.domain_groups; Q6).  Returns
+        (source outputs, target outputs), both with every head like two forward() calls.
+
+        target_grad_heads: the heads whose TARGET output feeds a loss.  The other target heads are evaluated
+        without a tape -- in the reference their outputs exist but no backward pass ever reaches them -- so that
+        the single backward pass of the batched graph does not pay for 16 images of zero gradient there."""
+        import hip_runtime as hr
+        if source.shape != target.shape:
+            raise RuntimeError("forward_domains: source %s and target %s batches differ in shape"
+                               % (tuple(source.shape), tuple(target.shape)))
+        B = source.shape[0]
+        with hr.domain_groups(2 if self.training else 1):
+            feat = self.features(torch.cat([source, target], 0))
+        out_s, out_t = {}, {}
+        f_s, f_t = feat[:B], feat[B:]
+        for head in self.heads:
+            fc = getattr(self, head)
+            if head in target_grad_heads or not torch.is_grad_enabled():
+                y = fc(feat)
+                out_s[head], out_t[head] = y[:B], y[B:]
+            else:
+                out_s[head] = fc(f_s)
+                with torch.no_grad():
+                    out_t[head] = fc(f_t)
+        return out_s, out_t
 
 
 def build(num_classes, num_keypoints=0, head_conv=256, down_ratio=4, freeze_base=False, rotated_boxes=False):

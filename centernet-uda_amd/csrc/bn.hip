@@ -51,17 +51,18 @@ template <int MODE>
 __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ partial,
-    int C, long long HW, long long chunk, int per_plane, int S, int relu) {
+    int C, long long HW, long long chunk, int per_plane, int S, int relu, int imgs_per_group) {
     __shared__ double red[16];
     const int c = blockIdx.x, s = blockIdx.y;
     const int b = s / per_plane, part = s - b * per_plane;
+    const int grp = b / imgs_per_group;
     const size_t base = ((size_t)b * C + c) * HW;
     const long long e0 = (long long)part * chunk;
     long long e1 = e0 + chunk;
     if (e1 > HW) e1 = HW;
     double a0 = 0.0, a1 = 0.0;
     float mu = 0.f, is = 0.f;
-    if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+    if (MODE == 1) { mu = mean[grp * C + c]; is = invstd[grp * C + c]; }
     auto acc = [&](float xv, float gv, float yv) {
         if (MODE == 0) {
             const double v = (double)xv;
@@ -101,10 +102,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
 // hundred loads, one wave) instead of waiting for a separate finalize launch; the workgroup that handles the
 // first chunk of image 0 also writes them out (saved mean / invstd, running statistics, batch counter, or the
 // gamma / beta gradients).
-__device__ __forceinline__ void bn_sum_partials(const double* __restrict__ partial, int c, int S, double& s0, double& s1,
-                                                double* red) {
+// (s_begin, s_end): the partials of one statistics group -- the images [g*Bg, (g+1)*Bg) of a batch that carries
+// several domains (source | target), each normalised by its own statistics like two separate forward calls
+__device__ __forceinline__ void bn_sum_partials(const double* __restrict__ partial, int c, int S, int s_begin, int s_end,
+                                                double& s0, double& s1, double* red) {
     double a0 = 0.0, a1 = 0.0;
-    for (int s = threadIdx.x; s < S; s += kBnThreads) {
+    for (int s = s_begin + threadIdx.x; s < s_end; s += kBnThreads) {
         a0 += partial[((size_t)c * S + s) * 2 + 0];
         a1 += partial[((size_t)c * S + s) * 2 + 1];
     }
@@ -118,30 +121,49 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ running_mean,
     float* __restrict__ running_var, long long* __restrict__ num_batches_tracked,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ residual,
-    float* __restrict__ y, int C, long long HW, int relu) {
+    float* __restrict__ y, int C, long long HW, int relu, int groups, int imgs_per_group, int per_plane) {
     __shared__ double red[16];
     __shared__ float stat[2];
     const long long plane = blockIdx.x;
     const int c = (int)(plane % C);
+    const int b = (int)(plane / C), grp = b / imgs_per_group;
+    const int s_per_group = imgs_per_group * per_plane;
+    const double n = (double)count;                        // values per channel and GROUP
     double s0, s1;
-    bn_sum_partials(partial, c, S, s0, s1, red);
+    bn_sum_partials(partial, c, S, grp * s_per_group, (grp + 1) * s_per_group, s0, s1, red);
     if (threadIdx.x == 0) {
-        const double n = (double)count;
         const double mu = s0 / n;
         double var = s1 / n - mu * mu;   // biased; fp64 sums make the subtraction safe
         if (var < 0.0) var = 0.0;
         const float m = (float)mu, is = (float)(1.0 / sqrt(var + (double)eps));
         stat[0] = m;
         stat[1] = is;
-        if (plane < C && blockIdx.y == 0) {            // image 0, first chunk: the channel's single writer
-            save_mean[c] = m;
-            save_invstd[c] = is;
-            if (running_mean) {
+        if (b == grp * imgs_per_group && blockIdx.y == 0) {   // first image of the group, first chunk: single writer
+            save_mean[grp * C + c] = m;
+            save_invstd[grp * C + c] = is;
+        }
+    }
+    if (plane < C && blockIdx.y == 0 && (running_mean || num_batches_tracked)) {
+        // image 0: the channel's single writer of the running statistics -- one momentum update per group, in
+        // group order (source first, then target: the reference forwards the two domains one after the other)
+        double rm = 0.0, rv = 0.0;
+        if (threadIdx.x == 0 && running_mean) { rm = (double)running_mean[c]; rv = (double)running_var[c]; }
+        for (int g = 0; g < groups; ++g) {
+            double t0, t1;
+            if (g == grp) { t0 = s0; t1 = s1; }
+            else bn_sum_partials(partial, c, S, g * s_per_group, (g + 1) * s_per_group, t0, t1, red);
+            if (threadIdx.x == 0) {
+                const double mu = t0 / n;
+                double var = t1 / n - mu * mu;
+                if (var < 0.0) var = 0.0;
                 const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
-                running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
-                running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+                rm = (1.0 - momentum) * (double)(float)rm + momentum * mu;       // rounded to float between
+                rv = (1.0 - momentum) * (double)(float)rv + momentum * unbiased; // updates, like two calls
             }
-            if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;     // nn.BatchNorm2d's counter
+        }
+        if (threadIdx.x == 0) {
+            if (running_mean) { running_mean[c] = (float)rm; running_var[c] = (float)rv; }
+            if (c == 0 && num_batches_tracked) *num_batches_tracked += groups;     // nn.BatchNorm2d's counter
         }
     }
     __syncthreads();
@@ -177,20 +199,33 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const double* __restrict__ partial, int S, float* __restrict__ ggamma, float* __restrict__ gbeta,
-    float* __restrict__ gx, float* __restrict__ gres, int C, long long HW, long long count, int relu) {
+    float* __restrict__ gx, float* __restrict__ gres, int C, long long HW, long long count, int relu, int groups,
+    int imgs_per_group, int per_plane) {
     __shared__ double red[16];
     __shared__ float stat[2];
     const long long plane = blockIdx.x;
     const int c = (int)(plane % C);
+    const int b = (int)(plane / C), grp = b / imgs_per_group;
+    const int s_per_group = imgs_per_group * per_plane;
     double s0, s1;
-    bn_sum_partials(partial, c, S, s0, s1, red);
+    bn_sum_partials(partial, c, S, grp * s_per_group, (grp + 1) * s_per_group, s0, s1, red);
     if (threadIdx.x == 0) {
         stat[0] = (float)s0;
         stat[1] = (float)s1;
-        if (plane < C && blockIdx.y == 0) { gbeta[c] = (float)s0; ggamma[c] = (float)s1; }
+    }
+    if (plane < C && blockIdx.y == 0) {      // the channel's single writer: gamma / beta gradients over all groups
+        double g0 = s0, g1 = s1;
+        for (int g = 0; g < groups; ++g) {
+            if (g == grp) continue;
+            double t0, t1;
+            bn_sum_partials(partial, c, S, g * s_per_group, (g + 1) * s_per_group, t0, t1, red);
+            g0 += t0;
+            g1 += t1;
+        }
+        if (threadIdx.x == 0) { gbeta[c] = (float)g0; ggamma[c] = (float)g1; }
     }
     __syncthreads();
-    const float mu = mean[c], is = invstd[c];
+    const float mu = mean[grp * C + c], is = invstd[grp * C + c];
     const float k = gamma[c] * is;
     const float inv_n = 1.0f / (float)count;
     const float m0 = stat[0] * inv_n, m1 = stat[1] * inv_n;
@@ -265,14 +300,16 @@ extern "C" size_t cnuda_bn_workspace_bytes(int B, int C, long long HW) {
 extern "C" int cnuda_bn_train_forward(const float* x, const float* gamma, const float* beta, const float* residual,
                                       float* y, float* save_mean, float* save_invstd, float* running_mean,
                                       float* running_var, long long* num_batches_tracked, float momentum, float eps,
-                                      int relu, int B, int C, long long HW, void* workspace, size_t workspace_bytes,
-                                      cnuda_stream_t stream) {
+                                      int relu, int B, int C, long long HW, int groups, void* workspace,
+                                      size_t workspace_bytes, cnuda_stream_t stream) {
     CNUDA_REQUIRE(x && gamma && beta && y && save_mean && save_invstd, "cnuda_bn_train_forward: null pointer");
     CNUDA_REQUIRE(B > 0 && C > 0 && HW > 0, "cnuda_bn_train_forward: empty tensor");
+    CNUDA_REQUIRE(groups >= 1 && B % groups == 0, "cnuda_bn_train_forward: batch %d not divisible into %d groups", B, groups);
     CNUDA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "cnuda_bn_train_forward: running stats");
-    const long long count = (long long)B * HW;
+    const int Bg = B / groups;
+    const long long count = (long long)Bg * HW;
     // nn.BatchNorm2d raises for a single value per channel in training mode
-    CNUDA_REQUIRE(count > 1, "Expected more than 1 value per channel when training, got input size [%d, %d, %lld]", B, C,
+    CNUDA_REQUIRE(count > 1, "Expected more than 1 value per channel when training, got input size [%d, %d, %lld]", Bg, C,
                   HW);
     CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_bn_workspace_bytes(B, C, HW),
                   "cnuda_bn_train_forward: workspace too small");
@@ -281,11 +318,12 @@ extern "C" int cnuda_bn_train_forward(const float* x, const float* gamma, const 
     double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, C, HW,
-                       sp.chunk, sp.per_plane, sp.S, 0);
+                       sp.chunk, sp.per_plane, sp.S, 0, Bg);
     const long long planes = (long long)B * C;
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
                        dim3(kBnThreads), 0, st, x, partial, sp.S, count, momentum, eps, save_mean, save_invstd,
-                       running_mean, running_var, num_batches_tracked, gamma, beta, residual, y, C, HW, relu);
+                       running_mean, running_var, num_batches_tracked, gamma, beta, residual, y, C, HW, relu, groups, Bg,
+                       sp.per_plane);
     return check_launch("cnuda_bn_train_forward");
 }
 
@@ -302,24 +340,26 @@ extern "C" int cnuda_bn_eval_forward(const float* x, const float* gamma, const f
 
 extern "C" int cnuda_bn_backward(const float* grad_y, const float* x, const float* y, const float* gamma,
                                  const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual,
-                                 float* grad_gamma, float* grad_beta, int relu, int B, int C, long long HW,
+                                 float* grad_gamma, float* grad_beta, int relu, int B, int C, long long HW, int groups,
                                  void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
     CNUDA_REQUIRE(grad_y && x && gamma && save_mean && save_invstd && grad_x && grad_gamma && grad_beta,
                   "cnuda_bn_backward: null pointer");
     CNUDA_REQUIRE(!relu || y, "cnuda_bn_backward: relu backward needs the forward output");
     CNUDA_REQUIRE(B > 0 && C > 0 && HW > 0, "cnuda_bn_backward: empty tensor");
+    CNUDA_REQUIRE(groups >= 1 && B % groups == 0, "cnuda_bn_backward: batch %d not divisible into %d groups", B, groups);
     CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_bn_workspace_bytes(B, C, HW),
                   "cnuda_bn_backward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    const long long count = (long long)B * HW;
+    const int Bg = B / groups;
+    const long long count = (long long)Bg * HW;
     const Split sp = pick_split(B, C, HW);
     uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
     double* partial = reinterpret_cast<double*>(base);
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, grad_y, y, save_mean,
-                       save_invstd, partial, C, HW, sp.chunk, sp.per_plane, sp.S, relu);
+                       save_invstd, partial, C, HW, sp.chunk, sp.per_plane, sp.S, relu, Bg);
     const long long planes = (long long)B * C;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
                        dim3(kBnThreads), 0, st, grad_y, x, y, save_mean, save_invstd, gamma, partial, sp.S, grad_gamma,
-                       grad_beta, grad_x, grad_residual, C, HW, count, relu);
+                       grad_beta, grad_x, grad_residual, C, HW, count, relu, groups, Bg, sp.per_plane);
     return check_launch("cnuda_bn_backward");
 }

@@ -14,7 +14,7 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libcenternet_uda_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 _lock = threading.Lock()
@@ -72,9 +72,9 @@ class _Sig:
     cnuda_conv2d_backward_data = (_I, [_P] * 3 + [_I] * 11 + _WS)
     cnuda_conv2d_backward_weight = (_I, [_P] * 4 + [_I] * 11 + _WS)
     cnuda_bn_workspace_bytes = (c_size_t, [_I, _I, _LL])
-    cnuda_bn_train_forward = (_I, [_P] * 10 + [_F, _F, _I, _I, _I, _LL] + _WS)
+    cnuda_bn_train_forward = (_I, [_P] * 10 + [_F, _F, _I, _I, _I, _LL, _I] + _WS)
     cnuda_bn_eval_forward = (_I, [_P] * 7 + [_F, _I, _I, _I, _LL, _P])
-    cnuda_bn_backward = (_I, [_P] * 10 + [_I, _I, _I, _LL] + _WS)
+    cnuda_bn_backward = (_I, [_P] * 10 + [_I, _I, _I, _LL, _I] + _WS)
     cnuda_maxpool2d_forward = (_I, [_P] * 2 + [_I] * 5 + [_P])
     cnuda_maxpool2d_backward = (_I, [_P] * 3 + [_I] * 5 + [_P])
     cnuda_maxpool2d_window_forward = (_I, [_P] * 2 + [_I] * 7 + [_P])
@@ -113,6 +113,34 @@ class _Sig:
     cnuda_prof_enable = (_I, [_I])
     cnuda_prof_arm = (_I, [_I])
     cnuda_prof_collect = (_I, [_P, _P, _I])
+
+
+# ---------------------------------------------------------------------------
+# statistics groups of a batch that carries several domains
+# ---------------------------------------------------------------------------
+_GROUPS = 1
+
+
+class domain_groups:
+    """with domain_groups(2): backend(torch.cat([source, target])) -- every train-mode BatchNorm inside the block
+    normalises the two halves of the batch by their own statistics and updates its running statistics once per
+    half, in order: exactly what two consecutive forward calls do (uda/entropy_minimization.py:18-19, Q6), in half
+    the launches and with twice the pixels per GEMM."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        global _GROUPS
+        self.prev, _GROUPS = _GROUPS, self.n
+
+    def __exit__(self, *exc):
+        global _GROUPS
+        _GROUPS = self.prev
+
+
+def current_groups():
+    return _GROUPS
 
 
 def check(rc, what=''):

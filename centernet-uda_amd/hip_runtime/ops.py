@@ -170,22 +170,25 @@ def _act_code(relu):
 
 class _BatchNormAct(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, num_batches_tracked):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, num_batches_tracked,
+                groups):
         require_gpu(x, gamma, beta, residual)
         x = f32c(x)
         residual = None if residual is None else f32c(residual)
         B, C = x.shape[0], x.shape[1]
+        if B % groups:
+            raise RuntimeError("batch_norm_act: batch of %d images cannot be split into %d domain groups" % (B, groups))
         HW = x.numel() // (B * C)
         y = torch.empty_like(x)
-        mean = torch.empty(C, dtype=torch.float32, device=x.device)
-        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        mean = torch.empty(groups * C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(groups * C, dtype=torch.float32, device=x.device)
         L = lib()
         wp, wn = _ws(L.cnuda_bn_workspace_bytes(B, C, HW), x)
         check(L.cnuda_bn_train_forward(ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(mean), ptr(invstd),
                                        ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), float(momentum),
                                        float(eps),
-                                       _act_code(relu), B, C, HW, wp, wn, stream()), 'bn_train_forward')
-        ctx.relu, ctx.dims, ctx.has_res = relu, (B, C, HW), residual is not None
+                                       _act_code(relu), B, C, HW, groups, wp, wn, stream()), 'bn_train_forward')
+        ctx.relu, ctx.dims, ctx.has_res, ctx.groups = relu, (B, C, HW), residual is not None, groups
         ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd, beta)
         return y
 
@@ -202,21 +205,25 @@ class _BatchNormAct(Function):
         L = lib()
         wp, wn = _ws(L.cnuda_bn_workspace_bytes(B, C, HW), x)
         check(L.cnuda_bn_backward(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), ptr(gx), ptr(gres),
-                                  ptr(gg_buf), ptr(gb_buf), _act_code(ctx.relu), B, C, HW, wp, wn, stream()),
+                                  ptr(gg_buf), ptr(gb_buf), _act_code(ctx.relu), B, C, HW, ctx.groups, wp, wn, stream()),
               'bn_backward')
-        return gx, gg, gb, gres, None, None, None, None, None, None
+        return gx, gg, gb, gres, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
-                   residual=None, relu=False, num_batches_tracked=None):
+                   residual=None, relu=False, num_batches_tracked=None, groups=None):
     """`num_batches_tracked` (int64 scalar buffer, optional) is incremented by the statistics kernel in training
-    mode, like nn.BatchNorm2d.forward does on the host."""
+    mode, like nn.BatchNorm2d.forward does on the host.  `groups` (default: hip_runtime.current_groups()):
+    statistics groups of a batch that carries several domains, see hip_runtime.domain_groups."""
+    if groups is None:
+        from . import current_groups
+        groups = current_groups()
     if training:
         if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or
                                                 not num_batches_tracked.is_cuda):
             raise RuntimeError("batch_norm_act: num_batches_tracked must be an int64 tensor on the GPU")
         return _BatchNormAct.apply(x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu,
-                                   num_batches_tracked)
+                                   num_batches_tracked, int(groups))
     if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad):
         raise RuntimeError("batch_norm_act: eval-mode BN has no backward in this build "
                            "(the reference evaluates under torch.no_grad(), train.py:172)")

@@ -22,6 +22,11 @@ log = logging.getLogger(__name__)
 
 
 class Model:
+    # two-domain plugins: run source and target through the backend as one batch (backends/dla.py
+    # DLASeg.forward_domains) when the backend offers it; False restores the reference's literal call sequence
+    batch_domains = True
+    target_grad_heads = ('hm',)        # heads whose target-domain output feeds a loss (entropy / max-squares: hm)
+
     def __init__(self):
         self.cfg = None
         self.backend = None
@@ -100,18 +105,32 @@ class Model:
         uda/max_squares_minimization.py:11-50): source and target batch both go through the backend in train
         mode (two BatchNorm updates, Q6); `target_term(target_outputs, data) -> (weighted loss, stats)`; the
         detection loss and the target term are back-propagated separately and their gradients add up (Q5), the
-        gradient exchange of a parallel run fires during the second pass only."""
+        gradient exchange of a parallel run fires during the second pass only.  With `batch_domains` (default) and
+        a backend that offers `forward_domains`, the two forward passes are one pass over the concatenated batch and
+        the two backward passes one pass of the summed loss -- same values up to floating-point summation order."""
         self._to_device(data)
         if is_training:
             self.optimizer.zero_grad()
-        outputs = {name: self.backend(data[key])
-                   for name, key in (("source_domain", "input"), ("target_domain", "target_domain_input"))}
+        batched = (self.batch_domains and hasattr(self.backend, 'forward_domains')
+                   and data["input"].shape == data["target_domain_input"].shape)
+        if batched:
+            # one pass over source | target (per-domain BatchNorm statistics, Q6), one backward pass of the summed
+            # loss: the same gradients as the reference's two forward / two backward calls up to summation order
+            src, tgt = self.backend.forward_domains(data["input"], data["target_domain_input"],
+                                                    target_grad_heads=self.target_grad_heads)
+            outputs = {"source_domain": src, "target_domain": tgt}
+        else:
+            outputs = {name: self.backend(data[key])
+                       for name, key in (("source_domain", "input"), ("target_domain", "target_domain_input"))}
         det_loss, stats = self.centernet_loss(outputs["source_domain"], data)
         uda_loss, uda_stats = target_term(outputs["target_domain"], data)
         if is_training:
-            with self._defer_sync():
-                det_loss.backward()
-            uda_loss.backward()
+            if batched:
+                (det_loss + uda_loss).backward()
+            else:
+                with self._defer_sync():
+                    det_loss.backward()
+                uda_loss.backward()
             self._finish_backward()
             self.optimizer.step()
         stats = dict(stats, **uda_stats)

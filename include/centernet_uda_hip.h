@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define CNUDA_ERR_INVALID_ARGUMENT (-1)
-#define CNUDA_ABI_VERSION 1
+#define CNUDA_ABI_VERSION 2
 
 typedef void* cnuda_stream_t; /* hipStream_t */
 
@@ -177,6 +177,11 @@ int cnuda_bn_train_forward(const float* x, const float* gamma, const float* beta
                            long long* num_batches_tracked /* nullable; += 1 like nn.BatchNorm2d.forward */,
                            float momentum, float eps, int relu,
                            int B, int C, long long HW,
+                           int groups /* statistics groups: images [g*B/groups, (g+1)*B/groups) are normalised by their
+                                         own batch statistics (save_mean / save_invstd are [groups][C]) and the running
+                                         statistics take one momentum update per group, in group order -- one call on
+                                         the concatenated source | target batch equals the reference's two forward
+                                         calls (uda/entropy_minimization.py:18-19) */,
                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 int cnuda_bn_eval_forward(const float* x, const float* gamma, const float* beta,
                           const float* running_mean, const float* running_var, const float* residual,
@@ -184,7 +189,7 @@ int cnuda_bn_eval_forward(const float* x, const float* gamma, const float* beta,
 int cnuda_bn_backward(const float* grad_y, const float* x, const float* y, const float* gamma,
                       const float* save_mean, const float* save_invstd,
                       float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
-                      int relu, int B, int C, long long HW,
+                      int relu, int B, int C, long long HW, int groups,
                       void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 
 /* ------------------------------------------------------------------------

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_workspace_queries():
     import hip_runtime as hr
     L = hr.lib()
-    assert L.cnuda_abi_version() == hr.ABI_VERSION == 1
+    assert L.cnuda_abi_version() == hr.ABI_VERSION == 2
     assert L.cnuda_decode_workspace_bytes(16, 6, 128, 128, 150) >= 16 * 6 * 150 * 8
     assert L.cnuda_dcn_v2_workspace_bytes(16, 64, 128, 128, 64, 3, 3, 1, 1, 1, 1, 1, 1, 1) > 0
     assert L.cnuda_dcn_v2_workspace_bytes(16, 63, 128, 128, 64, 3, 3, 1, 1, 1, 1, 1, 1, 2) == 0   # C % dg != 0
