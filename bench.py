@@ -245,6 +245,45 @@ def inference_throughput(device, backend, size, batch):
             'what': 'export.CenterNet: eval forward + decode (K=%d), fp32, BatchNorm not folded' % MAX_OBJS}
 
 
+def csrc_fingerprint():
+    """sha256 (16 hex digits) over the kernel sources: says whether a committed counter profile was collected
+    from the kernels this run executes."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'centernet-uda_amd', 'csrc', '*.hip')) +
+                    glob.glob(os.path.join(ROOT, 'centernet-uda_amd', 'csrc', '*.cuh')) +
+                    glob.glob(os.path.join(ROOT, 'centernet-uda_amd', 'csrc', '*.h'))):
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 counter profile (separate
+    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command, profiles/collect_pmc_traffic.sh).  PMC
+    passes cannot run inside the timed process, so the note says whether that profile was collected from the
+    kernel sources this run executes."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if not files:
+        return None, None
+    path = files[-1]
+    data = json.load(open(path))
+    meta = data.get('_meta', {})
+    norm = lambda k: k.replace(' ', '')
+    t = {norm(k): v for k, v in data.items() if k != '_meta'}.get(norm(kernel_name.split(' (')[0].split(' [')[0]))
+    if not t:
+        return None, '%s has no entry for this kernel' % os.path.basename(path)
+    same = meta.get('csrc_sha16') == csrc_fingerprint()
+    fetch = t['fetch_kb_per_launch'] * (2.0 if meta.get('fetch_doubled_for_wide_reads') else 1.0)
+    note = ('bytes/launch = FETCH_SIZE + WRITE_SIZE from profiles/%s, %s'
+            % (os.path.basename(path),
+               'collected from the kernel sources of this run' if same else
+               'COLLECTED FROM DIFFERENT KERNEL SOURCES (profile %s, this run %s): indicative only'
+               % (meta.get('csrc_sha16', 'unknown: pre-round-2 profile'), csrc_fingerprint())))
+    return round((fetch + t['write_kb_per_launch']) * 1024), note
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` -> `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
     arguments>` as a child process; returns its exit code (non-zero when any rank failed)."""
@@ -359,17 +398,7 @@ def main():
             per_kernel = {k: v for k, v in per_kernel.items() if v['flops'] > 0}
             name, d = max(per_kernel.items(), key=lambda kv: kv[1]['ms'])
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
-            traffic, traffic_note = None, None
-            tpath = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
-            if os.path.exists(tpath):
-                # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-                # (separate FETCH_SIZE / WRITE_SIZE runs, KB units; FETCH_SIZE left uncorrected because the
-                # kernel's reads are 4-byte-per-lane gathers, for which the guide gives no calibration)
-                norm = lambda k: k.replace(' ', '')
-                t = {norm(k): v for k, v in json.load(open(tpath)).items()}.get(norm(name))
-                if t:
-                    traffic = round((t['fetch_kb_per_launch'] + t['write_kb_per_launch']) * 1024)
-                    traffic_note = 'bytes/launch, profiles/r1_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE, uncorrected)'
+            traffic, traffic_note = pmc_traffic(name)
             roofline = {
                 'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,

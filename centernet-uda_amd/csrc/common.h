@@ -30,14 +30,19 @@ inline int check_launch(const char* what) {
 // with hipEvents on the launch stream.  An entry point made of several kernels opens a
 // ProfGroup first: every ProfScope inside it is recorded under the armed tag, told apart
 // by `sub` (bits 24.. of the collected tag).  Inert (two int compares) otherwise.
+// The launcher NAMES what it launched (`name()`: the kernel template instance it selected, printf-style), so the
+// report never depends on a second copy of the selection rules outside the library.
 class ProfScope {
 public:
     explicit ProfScope(hipStream_t st, int sub = 0);
     ~ProfScope();
+    bool active() const { return rec_ >= 0; }
+    void name(const char* fmt, ...);
 private:
     hipStream_t st_;
     int rec_;
 };
+constexpr int kProfNameLen = 96;
 class ProfGroup {
 public:
     ProfGroup();

@@ -31,6 +31,7 @@ struct ConvFwdParams {
 template <bool FAST>
 struct ConvFwdLoader {
     using Params = ConvFwdParams;
+    static const char* name() { return FAST ? "ConvFwdLoader<true>" : "ConvFwdLoader<false>"; }
     static constexpr bool kHasSideOutput = false;
     const ConvGeom& g;
     const float* x_b;
@@ -107,6 +108,7 @@ struct ConvDgradParams {
 };
 struct ConvDgradLoader {
     using Params = ConvDgradParams;
+    static const char* name() { return "ConvDgradLoader"; }
     static constexpr bool kHasSideOutput = false;
     const ConvGeom& g;
     const float* gy_b;
@@ -179,6 +181,7 @@ struct ConvDgradClassParams {
 };
 struct ConvDgradClassLoader {
     using Params = ConvDgradClassParams;
+    static const char* name() { return "ConvDgradClassLoader"; }
     static constexpr bool kHasSideOutput = false;
     const Params& p;
     const float* gy_b;
@@ -234,6 +237,7 @@ struct ConvWParams {
 template <int MODE>
 struct ConvWLoader {
     using Params = ConvWParams;
+    static const char* name() { return MODE == 2 ? "ConvWLoader<2>" : (MODE == 1 ? "ConvWLoader<1>" : "ConvWLoader<0>"); }
     const Params& p;
     // pixel cursor: image index, pixel index inside the image, output row / column
     long long n_, n_end_;
@@ -373,6 +377,9 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     const int n_tiles = ceil_div(N, IG_BN), m_tiles = Mp / bm;
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
     ProfScope prof(st);
+    const bool ws = matrix_mode() == 0 && wave_specialised() && bm >= 64;
+    prof.name(matrix_mode() == 1 ? "igemm_fwd_kernel<%d, %s> [split bf16 x3]"
+                                 : (ws ? "igemm_fwd_ws_kernel<%d, %s>" : "igemm_fwd_kernel<%d, %s>"), bm, Loader::name());
     if (matrix_mode() == 1) {
         // the caller's A buffer has ig_a_bytes() of room: split image behind the f32 matrix
         float* A3 = const_cast<float*>(A) + (size_t)Kp * Mp;
@@ -468,6 +475,7 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
         ceil_div(kh, sh) * ceil_div(kw, sw) <= 9) {   // taps one class can see (tap_r/tap_s hold 9)
         // one launch per parity class, K restricted to the taps that class can see
         ProfScope prof(st);   // brackets the whole class group (inner scopes find nothing armed)
+        prof.name("igemm_fwd*_kernel<*, ConvDgradClassLoader> x %d parity classes", sh * sw);
         for (int py = 0; py < sh; ++py)
             for (int px = 0; px < sw; ++px) {
                 ConvDgradClassParams cp;
@@ -523,6 +531,8 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
         ProfScope prof(st);
         const dim3 grid(q.Jp / q.wbj, q.Mpw / q.wbm, q.Z), blk(IG_THREADS);
         const bool fast = C % 64 == 0;
+        prof.name((wave_specialised() && fast && q.wbm == 64) ? "igemm_wgrad_ws_kernel<%s, %d, %d>" : "igemm_wgrad_kernel<%s, %d, %d>",
+                  fast ? "ConvWLoader<2>" : "ConvWLoader<0>", q.wbm, q.wbj);
         if (wave_specialised() && fast && q.wbm == 64) {
             const dim3 blk2(2 * IG_THREADS);
             if (q.wbj == 128)

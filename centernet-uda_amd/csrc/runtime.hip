@@ -1,5 +1,6 @@
 // Error reporting and ABI bookkeeping shared by every entry point.
 #include <stdarg.h>
+#include <string.h>
 
 #include <vector>
 
@@ -21,7 +22,7 @@ void set_error(const char* fmt, ...) {
 
 namespace cnuda {
 namespace {
-struct ProfRecord { hipEvent_t start, stop; int tag; };
+struct ProfRecord { hipEvent_t start, stop; int tag; char name[kProfNameLen]; };
 std::vector<ProfRecord> g_prof_pool;   // pre-created event pairs
 size_t g_prof_used = 0;
 int g_prof_armed = -1;                 // tag for the next main-kernel launch, -1 = off
@@ -33,11 +34,19 @@ ProfScope::ProfScope(hipStream_t st, int sub) : st_(st), rec_(-1) {
     if (tag < 0 || g_prof_used >= g_prof_pool.size()) return;
     rec_ = (int)g_prof_used++;
     g_prof_pool[rec_].tag = tag | (sub << 24);
+    g_prof_pool[rec_].name[0] = 0;
     g_prof_armed = -1;
     (void)hipEventRecord(g_prof_pool[rec_].start, st_);
 }
 ProfScope::~ProfScope() {
     if (rec_ >= 0) (void)hipEventRecord(g_prof_pool[rec_].stop, st_);
+}
+void ProfScope::name(const char* fmt, ...) {
+    if (rec_ < 0) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_prof_pool[rec_].name, kProfNameLen, fmt, ap);
+    va_end(ap);
 }
 ProfGroup::ProfGroup() {
     g_prof_group = g_prof_armed;
@@ -56,6 +65,7 @@ extern "C" int cnuda_prof_enable(int max_records) {
     for (int i = 0; i < max_records; ++i) {
         ProfRecord r;
         r.tag = -1;
+        r.name[0] = 0;
         if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) {
             set_error("cnuda_prof_enable: hipEventCreate failed");
             return (int)hipGetLastError();
@@ -68,7 +78,7 @@ extern "C" int cnuda_prof_arm(int tag) {
     cnuda::g_prof_armed = tag;
     return 0;
 }
-extern "C" int cnuda_prof_collect(int* tags, float* ms, int cap) {
+extern "C" int cnuda_prof_collect(int* tags, float* ms, char* names, int cap) {
     using namespace cnuda;
     int n = 0;
     for (size_t i = 0; i < g_prof_used && n < cap; ++i) {
@@ -77,11 +87,13 @@ extern "C" int cnuda_prof_collect(int* tags, float* ms, int cap) {
         if (hipEventElapsedTime(&t, g_prof_pool[i].start, g_prof_pool[i].stop) != hipSuccess) break;
         tags[n] = g_prof_pool[i].tag;
         ms[n] = t;
+        if (names) memcpy(names + (size_t)n * kProfNameLen, g_prof_pool[i].name, kProfNameLen);
         ++n;
     }
     g_prof_used = 0;
     return n;
 }
+extern "C" int cnuda_prof_name_len(void) { return cnuda::kProfNameLen; }
 
 namespace cnuda {
 namespace {

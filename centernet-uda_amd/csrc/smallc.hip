@@ -361,6 +361,7 @@ int smallc_forward(const float* x, const float* w, const float* bias, float* y, 
     const size_t lds = (size_t)(g.C * g.plane + 16) * sizeof(float);
     const dim3 grid(ceil_div(g.Wo, SC_TW), ceil_div(g.Ho, SC_TH * SC_NV), B);
     ProfScope prof(st);
+    prof.name("smallc_fwd_kernel<%d>", mt);
     if (mt == 1)
         hipLaunchKernelGGL(smallc_fwd_kernel<1>, grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope);
     else
@@ -394,6 +395,7 @@ int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, in
     }
     {
         ProfScope prof(st);
+        prof.name("smallc_wgrad_kernel<%d>", mt);
         if (mt == 1)
             hipLaunchKernelGGL(smallc_wgrad_kernel<1>, grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16);
         else

@@ -112,7 +112,8 @@ class _Sig:
     cnuda_get_matrix_mode = (_I, [])
     cnuda_prof_enable = (_I, [_I])
     cnuda_prof_arm = (_I, [_I])
-    cnuda_prof_collect = (_I, [_P, _P, _I])
+    cnuda_prof_collect = (_I, [_P, _P, _P, _I])
+    cnuda_prof_name_len = (_I, [])
 
 
 # ---------------------------------------------------------------------------
@@ -191,7 +192,7 @@ def workspace(nbytes, device):
 # ---------------------------------------------------------------------------
 class _Prof:
     enabled = False
-    table = []          # tag -> [(kernel name, algorithmic FLOPs, algorithmic HBM bytes) per sub-kernel]
+    table = []          # tag -> [(algorithmic FLOPs, algorithmic HBM bytes) per timed sub-kernel of the call]
     cap = 0
 
 
@@ -205,81 +206,26 @@ def get_matrix_mode():
     return int(lib().cnuda_get_matrix_mode())
 
 
-def _bm(m, n):
-    """mirror of pick_bm() in csrc/conv.hip / dcn.hip (tile rows for M output rows and N pixels)."""
-    bm = 128 if m > 64 else (64 if m > 32 else 32)
-    n_tiles = (n + 127) // 128
-    while bm > 32 and n_tiles * ((m + bm - 1) // bm) < 512:
-        bm >>= 1
-    return bm
-
-
-def _ws():
-    """mirror of wave_specialised() in csrc/runtime.hip"""
-    return os.environ.get('CNUDA_WS', '1')[:1] != '0'
-
-
-def _fwd_name(bm, loader):
-    """kernel template instance launch_fwd() picks (csrc/conv.hip): the 8-wave producer / consumer variant for the
-    64- and 128-row tiles in matrix mode 0, the 4-wave kernel otherwise"""
-    if get_matrix_mode() == 1:
-        return 'igemm_fwd_kernel<%d, %s> [split bf16 x3]' % (bm, loader)
-    return ('igemm_fwd_ws_kernel<%d, %s>' if (_ws() and bm >= 64) else 'igemm_fwd_kernel<%d, %s>') % (bm, loader)
-
-
-def _smallc(C, Co, kh, kw, stride):
-    return stride == 1 and C <= 16 and Co <= 32 and C * kh * kw <= 148 and C * (3 + kh) <= 96
-
-
 def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
-    """Called by the conv / DCN ops right before the C-ABI call when profiling is on.  The kernel name is
-    the template instance the library will pick (same selection rules), so that bench.py's per-kernel
-    aggregation lines up with rocprofv3's kernel names."""
+    """Called by the conv / DCN ops right before the C-ABI call when profiling is on: records the call's algorithmic
+    work (FLOPs per SURVEY 8d, bytes for the HBM-streaming kernels) under a tag; the kernel NAME of every timed
+    launch comes back from the library itself (cnuda_prof_collect), which is the only place that knows which
+    template instance it selected."""
     if not _Prof.enabled or len(_Prof.table) >= _Prof.cap:
         return
     flops = 2.0 * B * Ho * Wo * Co * C * kh * kw          # 2*Cout*Cin*kh*kw*Ho*Wo per image (SURVEY 8d)
-    stride = max(1, round(H / max(Ho, 1)))
-    tf = lambda v: 'true' if v else 'false'
-    if kind == 'conv_fwd':
-        if _smallc(C, Co, kh, kw, stride):
-            name = 'smallc_fwd_kernel<%d>' % ((Co + 15) // 16)
-        else:
-            name = _fwd_name(_bm(Co, B * Ho * Wo), 'ConvFwdLoader<%s>' % tf(C % 16 == 0))
-    elif kind == 'conv_dgrad':
-        if stride == 1 and _smallc(Co, C, kh, kw, 1):
-            name = 'smallc_fwd_kernel<%d>' % ((C + 15) // 16)
-        elif stride > 1 and H % stride == 0 and W % stride == 0 and Co % 16 == 0 and \
-                (-(-kh // stride)) * (-(-kw // stride)) <= 9:
-            name = 'igemm_fwd*_kernel<*, ConvDgradClassLoader> (group of stride^2 class launches)'
-        else:
-            name = _fwd_name(_bm(C, B * H * W), 'ConvDgradLoader')
-    elif kind == 'conv_wgrad':
-        if _smallc(C, Co, kh, kw, stride):
-            name = 'smallc_wgrad_kernel<%d>' % ((Co + 15) // 16)
-        else:
-            wide = Co <= 32 or (C % 64 == 0 and (C * kh * kw) % 128 == 0)
-            ws = _ws() and C % 64 == 0 and Co > 32
-            name = 'igemm_wgrad%s_kernel<ConvWLoader<%d>, %d, %d>' % ('_ws' if ws else '', 2 if C % 64 == 0 else 0,
-                                                                      32 if Co <= 32 else 64, 128 if wide else 64)
-    elif kind == 'dcn_fwd':
-        bm = _bm(Co, B * Ho * Wo)
-        name = ('dcn_sample_kernel + igemm_fwd_kernel<%d, DcnColsLoader>' if Co > bm else
-                'igemm_fwd_kernel<%d, DcnFwdLoader>') % bm
-    elif kind == 'dcn_bwd':
-        # three kernels, timed separately (ProfGroup in csrc/dcn.hip): the column-gradient GEMM (a 1x1
-        # convolution over grad_output with 9*C output channels: all of the entry point's MFMA work), then
-        # the two HBM-streaming consumers with their algorithmic bytes
+    if kind == 'dcn_bwd':
+        # three timed kernels (ProfGroup in csrc/dcn.hip): sub 0 the column-gradient GEMM (a 1x1 convolution over
+        # grad_output with 9*C output channels: all of the entry point's MFMA work), then the two HBM-streaming
+        # consumers with their algorithmic bytes
         T, px = kh * kw, B * Ho * Wo
-        name = _fwd_name(_bm(T * C, px), 'ConvFwdLoader<%s>' % tf(Co % 16 == 0))
         coord_bytes = 4.0 * px * (T * C + 3 * T + 3 * T + 4 * T) + 4.0 * B * C * H * W
         col2im_bytes = 4.0 * px * T * C + 16.0 * px * T * ((C + 15) // 16) + 4.0 * B * C * H * W
-        _Prof.table.append([(name, flops, 0.0), ('dcn_coord_grad_kernel', 0.0, coord_bytes),
-                            ('dcn_col2im_kernel', 0.0, col2im_bytes)])
-        lib().cnuda_prof_arm(len(_Prof.table) - 1)
-        return
+        _Prof.table.append([(flops, 0.0), (0.0, coord_bytes), (0.0, col2im_bytes)])
+    elif kind in ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'dcn_fwd'):
+        _Prof.table.append([(flops, 0.0)])
     else:
         raise ValueError(kind)
-    _Prof.table.append([(name, flops, 0.0)])
     lib().cnuda_prof_arm(len(_Prof.table) - 1)
 
 
@@ -291,12 +237,16 @@ def prof_begin(max_records=16384):
 def prof_end():
     """-> {kernel name: {'launches', 'ms', 'flops', 'bytes'}} and disables the timer."""
     n = sum(len(e) for e in _Prof.table)          # one record per (armed call, sub-kernel)
+    L = lib()
+    nl = int(L.cnuda_prof_name_len())
     tags = (ctypes.c_int * max(n, 1))()
     ms = (ctypes.c_float * max(n, 1))()
-    got = lib().cnuda_prof_collect(tags, ms, n)
+    names = ctypes.create_string_buffer(max(n, 1) * nl)
+    got = L.cnuda_prof_collect(tags, ms, names, n)
     out = {}
     for i in range(got):
-        name, flops, nbytes = _Prof.table[tags[i] & 0xffffff][tags[i] >> 24]
+        flops, nbytes = _Prof.table[tags[i] & 0xffffff][tags[i] >> 24]
+        name = names.raw[i * nl:(i + 1) * nl].split(b'\0', 1)[0].decode() or 'unnamed launch'
         d = out.setdefault(name, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
         d['launches'] += 1
         d['ms'] += float(ms[i])

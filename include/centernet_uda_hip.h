@@ -51,10 +51,15 @@ int cnuda_get_matrix_mode(void);
  * cnuda_prof_enable(n) pre-creates n hipEvent pairs; cnuda_prof_arm(tag) makes
  * the NEXT convolution / DCN main-kernel launch record a start/stop pair on its
  * own launch stream; cnuda_prof_collect synchronises on the recorded events and
- * returns (tag, milliseconds) pairs.  Costs nothing when not armed. */
+ * returns (tag, milliseconds, kernel name) triples -- the name is written by the
+ * launcher itself (the kernel template instance it selected for that call), in
+ * `names` as cap strings of cnuda_prof_name_len() bytes (nullable).  An entry point
+ * made of several timed kernels reports them under one tag, told apart by bits 24..
+ * of the tag.  Costs nothing when not armed. */
 int cnuda_prof_enable(int max_records);
 int cnuda_prof_arm(int tag);
-int cnuda_prof_collect(int* tags, float* ms, int cap);
+int cnuda_prof_collect(int* tags, float* ms, char* names, int cap);
+int cnuda_prof_name_len(void);
 
 /* ------------------------------------------------------------------------
  * Detection decode -- replaces backends/decode.py:35-76 (decode_detection),
@@ -93,10 +98,20 @@ int cnuda_nms(const float* heat, float* out, int B, int C, int H, int W, int nms
  * mask, ...).  offset [B, 2*kh*kw*dg, Ho, Wo] with channel 2*tap = dy and
  * 2*tap+1 = dx (cuda/dcn_v2_im2col_cuda.cu:170-174); mask [B, kh*kw*dg, Ho, Wo].
  * A sample is taken iff -1 < y < H and -1 < x < W, corners outside the plane
- * read 0 (:37-48,180).  No `columns` buffer is materialised.
- * backward writes (does not accumulate into) all five gradients; grad_input is
- * summed with fp32 atomics like the reference (:238-252) and is therefore
- * bit-reproducible only up to summation order.
+ * read 0 (:37-48,180).
+ * Scratch: everything lives in the caller's workspace (nothing is allocated inside
+ * a call).  forward samples inside the implicit GEMM's loader and materialises no
+ * `columns` buffer when the output channels fit one tile of the GEMM; layers whose
+ * output channels span several tiles (small feature maps) sample the columns once
+ * into the workspace and run a plain GEMM over them.  backward materialises the
+ * column gradient dcol[B, kh*kw*C, Ho*Wo] in the workspace (one 1x1 implicit GEMM,
+ * two streaming consumers) and a 16-byte geometry record per (pixel, tap).
+ * backward writes (does not accumulate into) all five gradients.  grad_input is
+ * accumulated in LDS windows with plain read-add-write; fp32 global atomics remain
+ * only for the window flush (one per touched cell), for samples that leave their
+ * tile's window and for in-instruction collisions -- far fewer than the reference's
+ * one atomic per corner (:238-252), but grad_input is still bit-reproducible only up
+ * to the order of those; deformable_group > 1 takes a plain atomics path.
  * ---------------------------------------------------------------------- */
 size_t cnuda_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw,
                                     int sh, int sw, int ph, int pw, int dh, int dw, int dg);
