@@ -242,7 +242,8 @@ def inference_throughput(device, backend, size, batch):
     tf = 65.58e9 * (size / 512.0) ** 2 * batch / (ms * 1e-3) / 1e12
     return {'images_per_s': round(batch / (ms * 1e-3), 1), 'ms_per_batch': round(ms, 3), 'batch': batch,
             'mfma_fraction': round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-            'what': 'export.CenterNet: eval forward + decode (K=%d), fp32, BatchNorm not folded' % MAX_OBJS}
+            'what': 'export.CenterNet: eval forward + decode (K=%d), fp32, BatchNorm folded into the conv / DCN '
+                    'weights (bias + skip connection + ReLU in the GEMM epilogues), no tape' % MAX_OBJS}
 
 
 def csrc_fingerprint():

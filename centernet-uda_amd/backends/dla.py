@@ -51,6 +51,59 @@ def _bn(c):
     return hnn.BatchNorm2d(c, momentum=BN_MOMENTUM)
 
 
+# ---------------------------------------------------------------------------
+# BatchNorm folding for inference (export.py: SURVEY 8f row 2).  `fold_batchnorm(model)` gives every conv + BN block
+# a folded weight / bias pair (w * gamma / sqrt(var + eps), beta + (conv_bias - mean) * gamma / sqrt(var + eps));
+# the blocks then run as ONE kernel each -- convolution, bias, skip connection and ReLU in the GEMM epilogue -- when
+# the module is in eval mode and no tape is being recorded.  The state_dict is untouched (folded tensors are plain
+# attributes); `unfold_batchnorm` drops them (call it, or fold again, after the weights change).
+# ---------------------------------------------------------------------------
+def _folded(conv_weight, conv_bias, bn):
+    with torch.no_grad():
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        w = (conv_weight * scale.view(-1, 1, 1, 1)).contiguous()
+        b = bn.bias - bn.running_mean * scale
+        if conv_bias is not None:
+            b = b + conv_bias * scale
+        return w, b.contiguous()
+
+
+_FOLDED_INFERENCE = False
+
+
+class folded_inference:
+    """with folded_inference(): ...  -- the only place the folded weights are used (export.CenterNet.forward enters
+    it after checking that they are current); everywhere else the blocks run their BatchNorm kernels."""
+
+    def __enter__(self):
+        global _FOLDED_INFERENCE
+        self.prev, _FOLDED_INFERENCE = _FOLDED_INFERENCE, True
+
+    def __exit__(self, *exc):
+        global _FOLDED_INFERENCE
+        _FOLDED_INFERENCE = self.prev
+
+
+def _use_folded(module):
+    return (_FOLDED_INFERENCE and getattr(module, '_fold', None) is not None and not module.training
+            and not torch.is_grad_enabled())
+
+
+def fold_batchnorm(model):
+    n = 0
+    for m in model.modules():
+        if hasattr(m, 'fold_batchnorm_'):
+            m.fold_batchnorm_()
+            n += 1
+    return n
+
+
+def unfold_batchnorm(model):
+    for m in model.modules():
+        if hasattr(m, 'fold_batchnorm_'):
+            m._fold = None
+
+
 def _conv(cin, cout, k, stride=1):
     return hnn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
 
@@ -58,18 +111,32 @@ def _conv(cin, cout, k, stride=1):
 class ConvBnRelu(nn.Sequential):
     """children '0' (conv) and '1' (bn); ReLU is fused into the BN kernel."""
 
+    _fold = None
+
     def __init__(self, cin, cout, k, stride=1):
         super().__init__(_conv(cin, cout, k, stride), _bn(cout))
 
+    def fold_batchnorm_(self):
+        self._fold = _folded(self[0].weight, self[0].bias, self[1])
+
     def forward(self, x):
+        if _use_folded(self):
+            return ops.conv2d_infer(x, *self._fold, self[0].stride, self[0].padding, 0.0)
         return self[1](self[0](x), relu=True)
 
 
 class ConvBn(nn.Sequential):
+    _fold = None
+
     def __init__(self, cin, cout):
         super().__init__(_conv(cin, cout, 1), _bn(cout))
 
+    def fold_batchnorm_(self):
+        self._fold = _folded(self[0].weight, self[0].bias, self[1])
+
     def forward(self, x):
+        if _use_folded(self):
+            return ops.conv2d_infer(x, *self._fold, self[0].stride, self[0].padding, -1.0)
         return self[1](self[0](x))
 
 
@@ -79,7 +146,17 @@ class BasicBlock(nn.Module):
         self.conv1, self.bn1 = _conv(cin, cout, 3, stride), _bn(cout)
         self.conv2, self.bn2 = _conv(cout, cout, 3), _bn(cout)
 
+    _fold = None
+
+    def fold_batchnorm_(self):
+        self._fold = _folded(self.conv1.weight, None, self.bn1) + _folded(self.conv2.weight, None, self.bn2)
+
     def forward(self, x, residual=None):
+        if _use_folded(self):
+            w1, b1, w2, b2 = self._fold
+            y = ops.conv2d_infer(x, w1, b1, self.conv1.stride, self.conv1.padding, 0.0)
+            # conv2 + BatchNorm + skip connection + ReLU in one launch (dla.py:48-62)
+            return ops.conv2d_infer(y, w2, b2, 1, 1, 0.0, residual=x if residual is None else residual)
         y = self.bn1(self.conv1(x), relu=True)
         return self.bn2(self.conv2(y), residual=x if residual is None else residual, relu=True)
 
@@ -89,7 +166,14 @@ class Root(nn.Module):
         super().__init__()
         self.conv, self.bn = _conv(cin, cout, 1), _bn(cout)
 
+    _fold = None
+
+    def fold_batchnorm_(self):
+        self._fold = _folded(self.conv.weight, None, self.bn)
+
     def forward(self, *xs):
+        if _use_folded(self):
+            return ops.conv2d_infer(ops.cat_channels(xs), *self._fold, 1, 0, 0.0)
         return self.bn(self.conv(ops.cat_channels(xs)), relu=True)
 
 
@@ -194,7 +278,19 @@ class DeformConv(nn.Module):
         self.actf = nn.Sequential(_bn(cho))
         self.conv = DCN(chi, cho, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1)
 
+    _fold = None
+
+    def fold_batchnorm_(self):
+        self._fold = _folded(self.conv.weight, self.conv.bias, self.actf[0])
+
     def forward(self, x):
+        if _use_folded(self):
+            # offsets / mask from the unchanged 27-channel convolution, then DCN + BatchNorm + ReLU as one launch
+            import _ext
+            c = self.conv
+            offset, mask = ops.split_offset_mask(c.conv_offset_mask(x))
+            return _ext.dcn_v2_forward(x, self._fold[0], self._fold[1], offset, mask, *c.kernel_size, *c.stride,
+                                       *c.padding, *c.dilation, c.deformable_groups, _act_slope=0.0)
         return self.actf[0](self.conv(x), relu=True)
 
 

@@ -25,6 +25,7 @@ struct ConvFwdParams {
     const float *x, *bias;
     float* y;
     float act_slope;   // < 0: none, 0: ReLU, 0.2: LeakyReLU(0.2)
+    const float* residual;   // nullable, shaped like y: y = act(conv + bias + residual) (BatchNorm-folded inference)
 };
 
 // B[k = tap*C + c][n] = x[b][c][oy*sh - ph + r][ox*sw - pw + s]   (0 outside)
@@ -83,14 +84,17 @@ struct ConvFwdLoader {
     }
     struct Out {
         float* base;
+        const float* res;
         int HoWo;
         __device__ Out(const Params& p, long long n) {
             HoWo = p.g.Ho * p.g.Wo;
             const int ni = (int)n, b = ni / HoWo, pp = ni - b * HoWo;
             base = p.y + (size_t)b * p.g.Co * HoWo + pp;
+            res = p.residual ? p.residual + (size_t)b * p.g.Co * HoWo + pp : nullptr;
         }
         __device__ __forceinline__ void store(const Params& p, int m, float v) {
             if (p.bias) v += p.bias[m];
+            if (res) v += res[(size_t)m * HoWo];
             if (p.act_slope >= 0.0f && v < 0.0f) v *= p.act_slope;
             base[(size_t)m * HoWo] = v;
         }
@@ -439,10 +443,18 @@ extern "C" size_t cnuda_conv2d_workspace_bytes(int B, int C, int H, int W, int C
 extern "C" int cnuda_conv2d_forward(const float* x, const float* weight, const float* bias, float* y, int B, int C,
                                     int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, float act_slope,
                                     void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+    return cnuda_conv2d_forward_res(x, weight, bias, nullptr, y, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, act_slope,
+                                    workspace, workspace_bytes, stream);
+}
+
+extern "C" int cnuda_conv2d_forward_res(const float* x, const float* weight, const float* bias, const float* residual,
+                                        float* y, int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw,
+                                        int ph, int pw, float act_slope, void* workspace, size_t workspace_bytes,
+                                        cnuda_stream_t stream) {
     CNUDA_REQUIRE(x && weight && y, "cnuda_conv2d_forward: null pointer");
     ConvGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_forward")) return rc;
-    if (smallc_supported(C, Cout, kh, kw, sh, sw))
+    if (!residual && smallc_supported(C, Cout, kh, kw, sh, sw))
         return smallc_forward(x, weight, bias, y, B, C, H, W, Cout, kh, kw, sh, ph, pw, act_slope, 0, workspace,
                               workspace_bytes, (hipStream_t)stream);
     const ConvPlan q = make_plan(g);
@@ -451,7 +463,7 @@ extern "C" int cnuda_conv2d_forward(const float* x, const float* weight, const f
     Carver cv(workspace, workspace_bytes);
     float* A = reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf)));
     launch_pack(weight, A, Cout, C, q.T, PACK_FWD, q.Kpf, q.Mpf, 0, st);
-    ConvFwdParams p{g, x, bias, y, act_slope};
+    ConvFwdParams p{g, x, bias, y, act_slope, residual};
     if (C % IG_BK == 0)
         return launch_fwd<ConvFwdLoader<true>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
     return launch_fwd<ConvFwdLoader<false>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");

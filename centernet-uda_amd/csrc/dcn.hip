@@ -101,6 +101,7 @@ __device__ __forceinline__ float tap_sample(const Tap& t, float v00, float v01, 
 struct DcnFwdParams {
     DcnGeom g;
     const float *in, *off, *mask, *bias;
+    float act_slope;   // < 0: none; 0: ReLU fused into the epilogue (BatchNorm-folded inference, DeformConv dla.py:369-372)
     float* out;
     float* col;   // optional [B][T*C][Ho*Wo] side output (rows in (tap, channel) order) for the weight gradient
 };
@@ -245,7 +246,9 @@ struct DcnFwdLoader {
             base = p.out + (size_t)b * p.g.Co * HoWo + pp;
         }
         __device__ __forceinline__ void store(const Params& p, int m, float v) {
-            base[(size_t)m * HoWo] = v + p.bias[m];
+            v += p.bias[m];
+            if (p.act_slope >= 0.0f && v < 0.0f) v *= p.act_slope;
+            base[(size_t)m * HoWo] = v;
         }
     };
 };
@@ -294,6 +297,7 @@ __global__ __launch_bounds__(1024) void dcn_sample_kernel(DcnSampleParams p, int
 struct DcnColsParams {
     DcnGeom g;
     const float *col, *bias;
+    float act_slope;
     float* out;
 };
 struct DcnColsLoader {
@@ -326,7 +330,9 @@ struct DcnColsLoader {
             base = p.out + (size_t)b * p.g.Co * HoWo + pp;
         }
         __device__ __forceinline__ void store(const Params& p, int m, float v) {
-            base[(size_t)m * HoWo] = v + p.bias[m];
+            v += p.bias[m];
+            if (p.act_slope >= 0.0f && v < 0.0f) v *= p.act_slope;
+            base[(size_t)m * HoWo] = v;
         }
     };
 };
@@ -906,12 +912,22 @@ extern "C" int cnuda_dcn_v2_forward_cols(const float* input, const float* weight
                                          int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                                          int dh, int dw, int dg, void* workspace, size_t workspace_bytes,
                                          cnuda_stream_t stream) {
+    return cnuda_dcn_v2_forward_act(input, weight, bias, offset, mask, output, columns, -1.0f, B, C, H, W, Cout, kh, kw,
+                                    sh, sw, ph, pw, dh, dw, dg, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight, const float* bias,
+                                        const float* offset, const float* mask, float* output, float* columns,
+                                        float act_slope, int B, int C, int H, int W, int Cout, int kh, int kw, int sh,
+                                        int sw, int ph, int pw, int dh, int dw, int dg, void* workspace,
+                                        size_t workspace_bytes, cnuda_stream_t stream) {
     CNUDA_REQUIRE(input && weight && bias && offset && mask && output, "cnuda_dcn_v2_forward: null pointer");
     CNUDA_REQUIRE(!columns || (dg == 1 && W >= 2),
                   "cnuda_dcn_v2_forward_cols: columns output needs deformable_group == 1 and width >= 2");
     DcnGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, "cnuda_dcn_v2_forward")) return rc;
     hipStream_t st = (hipStream_t)stream;
+    CNUDA_REQUIRE(act_slope < 0.0f || (dg == 1 && W >= 2), "cnuda_dcn_v2_forward_act: fused activation needs deformable_group == 1 and width >= 2");
     if (dg != 1 || W < 2) {   // the MFMA path samples horizontally adjacent pairs
         DcnNaiveParams p{g, input, weight, bias, offset, mask, nullptr, output, nullptr, nullptr, nullptr, nullptr};
         hipLaunchKernelGGL(dcn_naive_fwd_kernel, dim3(stream_grid((long long)B * Cout * g.Ho * g.Wo, 256)), dim3(256),
@@ -935,7 +951,7 @@ extern "C" int cnuda_dcn_v2_forward_cols(const float* input, const float* weight
             const int tiles = ceil_div(g.Ho * g.Wo, 64), tw = q.T < 16 ? q.T : 16;
             hipLaunchKernelGGL(dcn_sample_kernel, dim3(B * tiles), dim3(64, tw), 0, st, sp, tiles);
         }
-        DcnColsParams p{g, cols, bias, output};
+        DcnColsParams p{g, cols, bias, act_slope, output};
         if (q.bm == 128)
             hipLaunchKernelGGL((igemm_fwd_kernel<128, DcnColsLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                                n_tiles, m_tiles);
@@ -947,7 +963,7 @@ extern "C" int cnuda_dcn_v2_forward_cols(const float* input, const float* weight
                                n_tiles, m_tiles);
         return check_launch("cnuda_dcn_v2_forward(columns + GEMM)");
     }
-    DcnFwdParams p{g, input, offset, mask, bias, output, columns};
+    DcnFwdParams p{g, input, offset, mask, bias, act_slope, output, columns};
     ProfScope prof(st);
     prof.name("igemm_fwd_kernel<%d, DcnFwdLoader>%s", q.bm, columns ? " (+ column side output)" : "");
     if (q.bm == 128)

@@ -1,8 +1,9 @@
 """Inference wrapper of the reference's export.py:19-56 on the MI355X kernels.
 
-`CenterNet(backend, max_detections, is_rotated=False, nms=3)(x)` runs the backend (eval-mode
-BatchNorm kernel, no autograd), the clamped sigmoid of the heat map, the fused NMS + top-K decode and the
-`down_ratio` scaling, and returns `(boxes, scores, classes)` exactly like the reference's module:
+`CenterNet(backend, max_detections, is_rotated=False, nms=3)(x)` runs the backend without a tape and -- for the
+DLA backend, in eval mode -- with every BatchNorm folded into the convolution in front of it (one launch per
+conv + BN + skip connection + ReLU block: backends/dla.py `fold_batchnorm`), then the clamped sigmoid of the heat
+map, the fused NMS + top-K decode and the `down_ratio` scaling, and returns `(boxes, scores, classes)` exactly like the reference's module:
 boxes `[B, K, 4]` (`[x1, y1, x2, y2]` in input pixels) or `[B, K, 5]` (`[cx, cy, w, h, angle]`) for rotated
 models.  The ONNX export / simplifier part of export.py is out of scope; `build_model` keeps
 the reference's checkpoint lookup (`model_last.pth` / `model_best.pth` in the experiment folder).
@@ -24,10 +25,29 @@ class CenterNet(nn.Module):
         self.max_detections = max_detections
         self.is_rotated = is_rotated
         self.nms = nms
+        self.fold = True            # False: eval-mode BatchNorm kernels instead of folded weights
+        self._fold_key = None
+
+    def _folding(self):
+        """Context for the backend call: BatchNorm-folded blocks when the backend offers them (backends/dla.py), this
+        wrapper is in eval mode and `fold` is on; the folded copies are rebuilt whenever a parameter or a running
+        statistic may have changed since they were made (hip_runtime.param_state_key)."""
+        import contextlib
+        import hip_runtime as hr
+        target = getattr(self.backend, 'module', self.backend)
+        mod = import_module(type(target).__module__)
+        if self.training or not self.fold or not hasattr(mod, 'fold_batchnorm'):
+            return contextlib.nullcontext()
+        key = hr.param_state_key(target)
+        if key != self._fold_key:
+            mod.fold_batchnorm(target)
+            self._fold_key = key
+        return mod.folded_inference()
 
     @torch.no_grad()
     def forward(self, x):
-        out = self.backend(x)
+        with self._folding():
+            out = self.backend(x)
         has_kps = 'kps' in out
         dets = decode_detection(ops.sigmoid_clamp_(out['hm']), out['wh'], out['reg'],
                                 kps=out['kps'] if has_kps else None, K=self.max_detections,

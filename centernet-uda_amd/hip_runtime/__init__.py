@@ -66,9 +66,11 @@ class _Sig:
     cnuda_dcn_v2_forward = (_I, [_P] * 6 + [_I] * 14 + _WS)
     cnuda_dcn_v2_backward = (_I, [_P] * 11 + [_I] * 14 + _WS)
     cnuda_dcn_v2_forward_cols = (_I, [_P] * 7 + [_I] * 14 + _WS)
+    cnuda_dcn_v2_forward_act = (_I, [_P] * 7 + [_F] + [_I] * 14 + _WS)
     cnuda_dcn_v2_backward_cols = (_I, [_P] * 12 + [_I] * 14 + _WS)
     cnuda_conv2d_workspace_bytes = (c_size_t, [_I] * 11)
     cnuda_conv2d_forward = (_I, [_P] * 4 + [_I] * 11 + [_F] + _WS)
+    cnuda_conv2d_forward_res = (_I, [_P] * 5 + [_I] * 11 + [_F] + _WS)
     cnuda_conv2d_backward_data = (_I, [_P] * 3 + [_I] * 11 + _WS)
     cnuda_conv2d_backward_weight = (_I, [_P] * 4 + [_I] * 11 + _WS)
     cnuda_bn_workspace_bytes = (c_size_t, [_I, _I, _LL])
@@ -114,6 +116,28 @@ class _Sig:
     cnuda_prof_arm = (_I, [_I])
     cnuda_prof_collect = (_I, [_P, _P, _P, _I])
     cnuda_prof_name_len = (_I, [])
+
+
+# ---------------------------------------------------------------------------
+# Parameter epoch: bumped by everything in this package that rewrites parameter memory behind torch's back (the
+# fused Adam kernel, the data-parallel broadcast).  Together with the tensors' own `_version` counters (which torch
+# bumps for its in-place ops: stock optimizers, load_state_dict) it tells derived copies of the weights -- the
+# BatchNorm-folded inference weights -- when they are stale.
+# ---------------------------------------------------------------------------
+_PARAM_EPOCH = 0
+
+
+def bump_param_epoch():
+    global _PARAM_EPOCH
+    _PARAM_EPOCH += 1
+
+
+def param_state_key(module):
+    """Changes whenever a parameter or buffer of `module` may have changed."""
+    v = 0
+    for t in list(module.parameters()) + list(module.buffers()):
+        v += t._version + (t.data_ptr() & 0xffff)
+    return (_PARAM_EPOCH, v)
 
 
 # ---------------------------------------------------------------------------

@@ -97,6 +97,29 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0):
     return _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope))
 
 
+def conv2d_infer(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0, residual=None):
+    """Tape-free y = act(conv2d(x, weight) + bias + residual): the forward kernel with the skip connection in its
+    epilogue -- what a BatchNorm-folded BasicBlock needs (export.py).  No autograd node is created."""
+    require_gpu(x, weight, bias, residual)
+    x, weight = f32c(x.detach()), f32c(weight.detach())
+    bias = None if bias is None else f32c(bias.detach())
+    g = _conv_geom(x, weight, stride, padding)
+    B, C, H, W, Co, kh, kw, sh, sw, ph, pw = g
+    Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    if residual is not None:
+        residual = f32c(residual.detach())
+        if tuple(residual.shape) != (B, Co, Ho, Wo):
+            raise RuntimeError("conv2d_infer: residual %s does not match the output %s"
+                               % (tuple(residual.shape), (B, Co, Ho, Wo)))
+    y = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+    L = lib()
+    wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g), x)
+    prof_arm('conv_fwd', B, C, H, W, Co, kh, kw, Ho, Wo)
+    check(L.cnuda_conv2d_forward_res(ptr(x), ptr(weight), ptr(bias), ptr(residual), ptr(y), *g, float(act_slope),
+                                     wp, wn, stream()), 'conv2d_forward')
+    return y
+
+
 class _ConvTranspose2d(Function):
     """nn.ConvTranspose2d(Cin, Cout, k, stride, padding, bias=False) (backends/resnet.py:86-94): the input
     gradient of the convolution whose weight is this [Cin, Cout, kh, kw] tensor read as [Cout_conv, Cin_conv, ...];

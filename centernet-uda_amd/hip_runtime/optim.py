@@ -53,6 +53,8 @@ class Adam(torch.optim.Optimizer):
                            g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], self._step)
         for p in a.params:
             self.state[p]['step'].fill_(float(self._step))
+        from . import bump_param_epoch
+        bump_param_epoch()          # the kernel wrote the flat arena: torch's version counters did not move
         return loss
 
     def load_state_dict(self, state_dict):

@@ -60,6 +60,8 @@ class DataParallel(nn.Module):
         if self.world_size > 1:
             # replicas start identical (DataParallel broadcasts parameters and buffers every forward)
             dist.broadcast(self.arena.flat_param, src=0, group=self.process_group)
+            from . import bump_param_epoch
+            bump_param_epoch()
             self.sync_buffers()
 
     @property

@@ -128,6 +128,16 @@ int cnuda_dcn_v2_backward(const float* input, const float* weight, const float* 
                           int sh, int sw, int ph, int pw, int dh, int dw, int dg,
                           void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 
+/* forward with a fused epilogue activation: output = act(dcn(...) + bias), act_slope < 0 none, 0 ReLU.  Used by
+ * the BatchNorm-folded inference path (export.py), where the BatchNorm + ReLU of DeformConv (backends/dla.py:369-372)
+ * live in the weights, the bias and this epilogue.  columns nullable as in forward_cols below. */
+int cnuda_dcn_v2_forward_act(const float* input, const float* weight, const float* bias,
+                             const float* offset, const float* mask, float* output, float* columns,
+                             float act_slope,
+                             int B, int C, int H, int W, int Cout, int kh, int kw,
+                             int sh, int sw, int ph, int pw, int dh, int dw, int dg,
+                             void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+
 /* Same two operations with the sampled column buffer kept between them (the
  * product's autograd path; deformable_group == 1 only): forward_cols stores
  * columns[B, kh*kw*C, Ho*Wo] (rows in (tap, channel) order, mask already applied)
@@ -166,6 +176,13 @@ int cnuda_conv2d_forward(const float* x, const float* weight, const float* bias,
                          int B, int C, int H, int W, int Cout, int kh, int kw,
                          int sh, int sw, int ph, int pw, float act_slope,
                          void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+/* forward with a residual input in the epilogue: y = act(conv(x, w) + bias + residual), residual shaped like y
+ * (nullable).  The BatchNorm-folded inference path (export.py) runs a BasicBlock's second convolution, its
+ * BatchNorm, the skip connection and the ReLU (backends/dla.py:48-62) as this one launch. */
+int cnuda_conv2d_forward_res(const float* x, const float* weight, const float* bias, const float* residual, float* y,
+                             int B, int C, int H, int W, int Cout, int kh, int kw,
+                             int sh, int sw, int ph, int pw, float act_slope,
+                             void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 int cnuda_conv2d_backward_data(const float* grad_y, const float* weight, float* grad_x,
                                int B, int C, int H, int W, int Cout, int kh, int kw,
                                int sh, int sw, int ph, int pw,

@@ -25,11 +25,11 @@ def test_centernet_wrapper_matches_oracle_decode(golden, rotated):
     backend = backend.to(DEV).eval()
     x = T(gin.image_batch(2, 96, 96, 91)).to(DEV)
     K = 20
-    model = CenterNet(backend, K, is_rotated=rotated)
+    model = CenterNet(backend, K, is_rotated=rotated).eval()          # BatchNorm-folded inference path
     boxes, scores, classes = model(x)
     assert boxes.shape == (2, K, 5 if rotated else 4) and scores.shape == (2, K) and classes.shape == (2, K)
     assert not boxes.requires_grad
-    with torch.no_grad():
+    with model._folding(), torch.no_grad():                # the same (BatchNorm-folded) head tensors the wrapper decoded
         out = backend(x)
     hm = np.clip(1.0 / (1.0 + np.exp(-out['hm'].double().cpu().numpy())), 1e-4, 1 - 1e-4).astype(np.float32)
     want = oracle_decode.decode_detection(hm, out['wh'].cpu().numpy(), out['reg'].cpu().numpy(), K=K, rotated=rotated)
@@ -79,3 +79,59 @@ def test_build_model_reads_the_experiment_folder(tmp_path):
     assert boxes.shape == (1, 10, 4) and torch.all(scores[:, :-1] >= scores[:, 1:])
     backend = build_model(tmp_path / 'missing', spec, without_decode_detections=True, max_detections=10)
     assert isinstance(backend, resnet.CenterResNet)
+
+
+def test_batchnorm_folding_matches_the_batchnorm_kernels_and_tracks_the_weights(golden):
+    """eval-mode inference with every BatchNorm folded into the convolution in front of it
+    (conv + bias + skip connection + ReLU in one GEMM epilogue; DCN + BN + ReLU likewise) equals the unfolded
+    eval forward to rounding, never records a tape, and follows the weights when they change."""
+    from backends import dla
+    from export import CenterNet
+    from hip_runtime import optim
+    g = golden('dla_axis')
+    shapes = dict(ast.literal_eval(str(g['shapes_json'])))
+    backend = dla.build(num_classes=6)
+    backend.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes, 0.3).items()})
+    backend = backend.to(DEV).eval()
+    x = T(gin.image_batch(2, 128, 128, 92)).to(DEV)
+    with torch.no_grad():
+        want = backend(x)                                  # eval-mode BatchNorm kernels
+    assert all(m._fold is None for m in backend.modules() if hasattr(m, 'fold_batchnorm_'))
+    model = CenterNet(backend, 30).eval()
+    with model._folding():
+        with torch.no_grad():
+            got = backend(x)
+    n_folded = sum(1 for m in backend.modules() if getattr(m, '_fold', None) is not None)
+    assert n_folded >= 40                                 # 16 DeformConv + the trunk's conv/BN blocks
+    for k in want:
+        scale = want[k].abs().max().item()
+        assert (got[k] - want[k]).abs().max().item() <= 1e-4 * scale, k          # measured 2e-5
+        assert not got[k].requires_grad
+    # outside the wrapper's context the blocks run their BatchNorm kernels again (e.g. plugin evaluation)
+    with torch.no_grad():
+        again = backend(x)
+    assert all(torch.equal(again[k], want[k]) for k in want)
+    boxes0, scores0, _ = model(x)
+    # the weights change: a training step through the fused Adam (torch's version counters do not see it)
+    backend.train()
+    opt = optim.Adam([p for p in backend.parameters() if p.requires_grad], lr=1e-2)
+    out = backend(x)
+    sum(v.mean() for v in out.values()).backward()
+    opt.step()
+    backend.eval()
+    with torch.no_grad():
+        want2 = backend(x)
+    assert (want2['hm'] - want['hm']).abs().max().item() > 1e-3      # the step really moved the model
+    with model._folding():
+        with torch.no_grad():
+            got2 = backend(x)
+    for k in want2:
+        assert (got2[k] - want2[k]).abs().max().item() <= 1e-4 * want2[k].abs().max().item(), k
+    # ... and through load_state_dict (torch's in-place copy)
+    backend.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes, 0.3).items()})
+    boxes1, scores1, _ = model(x)
+    assert torch.equal(scores1, scores0) and torch.equal(boxes1, boxes0)
+    # fold = False: the wrapper runs the BatchNorm kernels
+    model.fold = False
+    boxes2, scores2, _ = model(x)
+    assert (scores2 - scores0).abs().max().item() <= 1e-4
