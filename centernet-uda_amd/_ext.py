@@ -27,7 +27,8 @@ def _out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw):
 
 
 def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w,
-                   pad_h, pad_w, dilation_h, dilation_w, deformable_group, _want_columns=False, _act_slope=-1.0):
+                   pad_h, pad_w, dilation_h, dilation_w, deformable_group, _want_columns=False, _act_slope=-1.0,
+                   _pack_token=0, _pack_version=None):
     hr.require_gpu(input, weight, bias, offset, mask)
     input, weight, bias, offset, mask = [hr.f32c(t) for t in (input, weight, bias, offset, mask)]
     B, C, H, W, Co = _shapes(input, weight, offset, mask, kernel_h, kernel_w, deformable_group)
@@ -50,10 +51,11 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
         hr.prof_arm('dcn_fwd', B, C, H, W, Co, kernel_h, kernel_w, Ho, Wo)
     # _act_slope (not part of the reference's signature): fused epilogue activation of the BatchNorm-folded
     # inference path; -1 = none = the reference's operation
-    hr.check(L.cnuda_dcn_v2_forward_act(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
-                                        hr.ptr(out), hr.ptr(cols), float(_act_slope), *geom, hr.ptr(ws), ws.numel(),
-                                        hr.stream()),
-             'dcn_v2_forward')
+    with hr.pack_stamp(_pack_token, weight, _pack_version):     # (private) identity of the weights: pack cache
+        hr.check(L.cnuda_dcn_v2_forward_act(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
+                                            hr.ptr(out), hr.ptr(cols), float(_act_slope), *geom, hr.ptr(ws),
+                                            ws.numel(), hr.stream()),
+                 'dcn_v2_forward')
     return (out, cols) if _want_columns else out
 
 

@@ -58,6 +58,19 @@ def _bn(c):
 # the module is in eval mode and no tape is being recorded.  The state_dict is untouched (folded tensors are plain
 # attributes); `unfold_batchnorm` drops them (call it, or fold again, after the weights change).
 # ---------------------------------------------------------------------------
+_FOLD_GEN = [0]
+
+
+def _fold_stamp(module):
+    """(token, version) under which the library may cache the packed image of a module's folded weights: a token of
+    the folded copy's own, and the generation of the fold (a re-fold may land on a recycled address)."""
+    import hip_runtime as hr
+    if not hasattr(module, '_fold_token'):
+        module._fold_token = hr.new_pack_token()
+    _FOLD_GEN[0] += 1
+    module._fold_gen = _FOLD_GEN[0]
+
+
 def _folded(conv_weight, conv_bias, bn):
     with torch.no_grad():
         scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
@@ -118,10 +131,12 @@ class ConvBnRelu(nn.Sequential):
 
     def fold_batchnorm_(self):
         self._fold = _folded(self[0].weight, self[0].bias, self[1])
+        _fold_stamp(self)
 
     def forward(self, x):
         if _use_folded(self):
-            return ops.conv2d_infer(x, *self._fold, self[0].stride, self[0].padding, 0.0)
+            return ops.conv2d_infer(x, *self._fold, self[0].stride, self[0].padding, 0.0, None, self._fold_token,
+                                    self._fold_gen)
         return self[1](self[0](x), relu=True)
 
 
@@ -133,10 +148,12 @@ class ConvBn(nn.Sequential):
 
     def fold_batchnorm_(self):
         self._fold = _folded(self[0].weight, self[0].bias, self[1])
+        _fold_stamp(self)
 
     def forward(self, x):
         if _use_folded(self):
-            return ops.conv2d_infer(x, *self._fold, self[0].stride, self[0].padding, -1.0)
+            return ops.conv2d_infer(x, *self._fold, self[0].stride, self[0].padding, -1.0, None, self._fold_token,
+                                    self._fold_gen)
         return self[1](self[0](x))
 
 
@@ -150,13 +167,16 @@ class BasicBlock(nn.Module):
 
     def fold_batchnorm_(self):
         self._fold = _folded(self.conv1.weight, None, self.bn1) + _folded(self.conv2.weight, None, self.bn2)
+        _fold_stamp(self)
 
     def forward(self, x, residual=None):
         if _use_folded(self):
             w1, b1, w2, b2 = self._fold
-            y = ops.conv2d_infer(x, w1, b1, self.conv1.stride, self.conv1.padding, 0.0)
+            y = ops.conv2d_infer(x, w1, b1, self.conv1.stride, self.conv1.padding, 0.0, None, self._fold_token,
+                                 self._fold_gen)
             # conv2 + BatchNorm + skip connection + ReLU in one launch (dla.py:48-62)
-            return ops.conv2d_infer(y, w2, b2, 1, 1, 0.0, residual=x if residual is None else residual)
+            return ops.conv2d_infer(y, w2, b2, 1, 1, 0.0, x if residual is None else residual, self._fold_token,
+                                    self._fold_gen)
         y = self.bn1(self.conv1(x), relu=True)
         return self.bn2(self.conv2(y), residual=x if residual is None else residual, relu=True)
 
@@ -170,10 +190,11 @@ class Root(nn.Module):
 
     def fold_batchnorm_(self):
         self._fold = _folded(self.conv.weight, None, self.bn)
+        _fold_stamp(self)
 
     def forward(self, *xs):
         if _use_folded(self):
-            return ops.conv2d_infer(ops.cat_channels(xs), *self._fold, 1, 0, 0.0)
+            return ops.conv2d_infer(ops.cat_channels(xs), *self._fold, 1, 0, 0.0, None, self._fold_token, self._fold_gen)
         return self.bn(self.conv(ops.cat_channels(xs)), relu=True)
 
 
@@ -282,6 +303,7 @@ class DeformConv(nn.Module):
 
     def fold_batchnorm_(self):
         self._fold = _folded(self.conv.weight, self.conv.bias, self.actf[0])
+        _fold_stamp(self)
 
     def forward(self, x):
         if _use_folded(self):
@@ -290,7 +312,8 @@ class DeformConv(nn.Module):
             c = self.conv
             offset, mask = ops.split_offset_mask(c.conv_offset_mask(x))
             return _ext.dcn_v2_forward(x, self._fold[0], self._fold[1], offset, mask, *c.kernel_size, *c.stride,
-                                       *c.padding, *c.dilation, c.deformable_groups, _act_slope=0.0)
+                                       *c.padding, *c.dilation, c.deformable_groups, _act_slope=0.0,
+                                       _pack_token=self._fold_token, _pack_version=self._fold_gen)
         return self.actf[0](self.conv(x), relu=True)
 
 

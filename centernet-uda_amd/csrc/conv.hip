@@ -461,8 +461,8 @@ extern "C" int cnuda_conv2d_forward_res(const float* x, const float* weight, con
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_conv2d_forward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
-    float* A = reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf)));
-    launch_pack(weight, A, Cout, C, q.T, PACK_FWD, q.Kpf, q.Mpf, 0, st);
+    const float* A = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),
+                                 ig_a_bytes(q.Kpf, q.Mpf), Cout, C, q.T, PACK_FWD, q.Kpf, q.Mpf, 0, st);
     ConvFwdParams p{g, x, bias, y, act_slope, residual};
     if (C % IG_BK == 0)
         return launch_fwd<ConvFwdLoader<true>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
@@ -482,7 +482,7 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.dgrad_bytes, "cnuda_conv2d_backward_data: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
-    float* A = reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpd, q.Mpd)));
+    float* Aws = reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpd, q.Mpd)));
     if ((sh > 1 || sw > 1) && H % sh == 0 && W % sw == 0 && Cout % IG_BK == 0 &&
         ceil_div(kh, sh) * ceil_div(kw, sw) <= 9) {   // taps one class can see (tap_r/tap_s hold 9)
         // one launch per parity class, K restricted to the taps that class can see
@@ -506,13 +506,14 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
                 const int Kc = cp.ntaps * Cout, Kpc = round_up(Kc > 0 ? Kc : IG_KC, IG_KC);
                 const int bm = pick_bm(C, Nc), Mp = round_up(C, bm);
                 CNUDA_REQUIRE(ig_a_bytes(Kpc, Mp) + 256 <= workspace_bytes, "cnuda_conv2d_backward_data: workspace");
-                launch_pack_taps(weight, A, Cout, C, q.T, taps, cp.ntaps, Kpc, Mp, st);
+                const float* A = launch_pack_taps(weight, Aws, ig_a_bytes(Kpc, Mp), Cout, C, q.T, taps, cp.ntaps, Kpc, Mp, st);
                 if (int rc = launch_fwd<ConvDgradClassLoader>(bm, cp, A, Mp, Kpc, C, Nc, st, "cnuda_conv2d_backward_data(class)"))
                     return rc;
             }
         return 0;
     }
-    launch_pack(weight, A, Cout, C, q.T, PACK_DGRAD, q.Kpd, q.Mpd, round_up(Cout, IG_BK), st);
+    const float* A = launch_pack(weight, Aws, ig_a_bytes(q.Kpd, q.Mpd), Cout, C, q.T, PACK_DGRAD, q.Kpd, q.Mpd,
+                                 round_up(Cout, IG_BK), st);
     ConvDgradParams p{g, grad_y, grad_x, round_up(Cout, IG_BK)};
     return launch_fwd<ConvDgradLoader>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
 }

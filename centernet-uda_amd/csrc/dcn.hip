@@ -938,8 +938,8 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
     CNUDA_REQUIRE(q.N < (1ll << 31) - IG_BN, "cnuda_dcn_v2_forward: more than 2^31 pixels per call");
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_dcn_v2_forward: workspace too small");
     Carver cv(workspace, workspace_bytes);
-    float* A = cv.take<float>((size_t)q.Kp * q.Mp);
-    launch_pack(weight, A, Cout, C, q.T, PACK_FWD, q.Kp, q.Mp, 0, st);
+    const float* A = launch_pack(weight, cv.take<float>((size_t)q.Kp * q.Mp), (size_t)q.Kp * q.Mp * sizeof(float), Cout,
+                                 C, q.T, PACK_FWD, q.Kp, q.Mp, 0, st);
     const int n_tiles = ceil_div(q.N, IG_BN), m_tiles = q.Mp / q.bm;
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
     if (q.fwd_two_kernels) {

@@ -12,13 +12,17 @@ enum PackMode {
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 
-// W is the reference layout [Co][C][T] (T = kh*kw).  dst is [Kp][Mp], zero padded.
-void launch_pack(const float* W, float* dst, int Co, int C, int T, PackMode mode,
-                 int Kp, int Mp, int Cpad, hipStream_t st);
+// W is the reference layout [Co][C][T] (T = kh*kw).  The packed image is [Kp][Mp], zero padded.  Returns the
+// buffer the GEMM must read: `dst` (the caller's workspace, freshly packed) or -- when the caller announced a
+// weight identity for this call (cnuda_pack_stamp) and a pack cache is attached (cnuda_pack_cache_attach) -- a slot
+// of the cache, packed only when the weights have changed since it was filled.  `room` = bytes available at dst
+// (the split-operand mode keeps a second image behind the f32 matrix: ig_a_bytes()).
+const float* launch_pack(const float* W, float* dst, size_t room, int Co, int C, int T, PackMode mode,
+                         int Kp, int Mp, int Cpad, hipStream_t st);
 
-// dst[k = ti*Co + o][m = c] = W[o][c][taps[ti]], zero padded to [Kp][Mp]
-void launch_pack_taps(const float* W, float* dst, int Co, int C, int T, const int* taps, int ntaps, int Kp, int Mp,
-                      hipStream_t st);
+// dst[k = ti*Co + o][m = c] = W[o][c][taps[ti]], zero padded to [Kp][Mp]; same return convention
+const float* launch_pack_taps(const float* W, float* dst, size_t room, int Co, int C, int T, const int* taps, int ntaps,
+                              int Kp, int Mp, hipStream_t st);
 
 // gw[o][c][tap] = sum_z slabs[z][o][tap*C + c]
 void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp,

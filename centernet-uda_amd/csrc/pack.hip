@@ -1,5 +1,8 @@
 // Small helper kernels around the implicit-GEMM cores: weight packing, split-K
 // slab reduction, per-channel sums.
+#include <mutex>
+#include <unordered_map>
+
 #include "igemm_host.h"
 
 namespace cnuda {
@@ -104,22 +107,86 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     if (threadIdx.x == 0) out[c] = s;
 }
 
-}  // namespace
+// ---------------------------------------------------------------------------
+// Pack cache.  The packed weight image only changes when the weights do (once per optimizer step), yet every
+// convolution call used to rebuild it: 282 tiny launches per training step.  The host layer owns the memory
+// (cnuda_pack_cache_attach: one caller-allocated arena, nothing is allocated in here) and the notion of weight
+// identity: before a call it announces a STAMP = (token of the module that owns the weights, version of the
+// weights) with cnuda_pack_stamp.  A slot is reused iff the same token asked for the same image of the same source
+// buffer before and the version is unchanged; token 0 (the default, and every caller that says nothing) bypasses
+// the cache.  One stamp covers every pack of the entry point that follows it (and of the calls nested in it).
+// ---------------------------------------------------------------------------
+struct PackKey {
+    uint64_t token;
+    const void* src;
+    int mode, Co, C, T, Kp, Mp, extra;
+    bool operator==(const PackKey& o) const {
+        return token == o.token && src == o.src && mode == o.mode && Co == o.Co && C == o.C && T == o.T && Kp == o.Kp &&
+               Mp == o.Mp && extra == o.extra;
+    }
+};
+struct PackKeyHash {
+    size_t operator()(const PackKey& k) const {
+        uint64_t h = k.token * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)k.src;
+        const int v[7] = {k.mode, k.Co, k.C, k.T, k.Kp, k.Mp, k.extra};
+        for (int x : v) h = (h ^ (uint64_t)(unsigned)x) * 0xBF58476D1CE4E5B9ull;
+        return (size_t)(h ^ (h >> 31));
+    }
+};
+struct PackSlot { size_t offset, bytes; uint64_t version; };
+std::mutex g_pack_mutex;                      // forward runs on the caller's thread, backward on autograd's
+std::unordered_map<PackKey, PackSlot, PackKeyHash> g_pack_slots;
+char* g_pack_arena = nullptr;
+size_t g_pack_arena_bytes = 0, g_pack_arena_used = 0;
+thread_local uint64_t g_pack_token = 0, g_pack_version = 0;
 
-void launch_pack(const float* W, float* dst, int Co, int C, int T, PackMode mode, int Kp, int Mp, int Cpad,
-                 hipStream_t st) {
-    const long long total = (long long)Kp * Mp;
-    hipLaunchKernelGGL(pack_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, W, dst, Co, C, T, (int)mode, Kp,
-                       Mp, Cpad);
+// -> cached slot to use (fill == true: pack into it first), or nullptr: use the workspace
+float* pack_slot(const PackKey& key, size_t bytes, bool& fill) {
+    fill = true;
+    if (key.token == 0 || !g_pack_arena) return nullptr;
+    std::lock_guard<std::mutex> lock(g_pack_mutex);
+    auto it = g_pack_slots.find(key);
+    if (it == g_pack_slots.end()) {
+        const size_t need = (bytes + 255) / 256 * 256;
+        if (g_pack_arena_used + need > g_pack_arena_bytes) return nullptr;        // arena full: no caching
+        it = g_pack_slots.emplace(key, PackSlot{g_pack_arena_used, bytes, ~0ull}).first;
+        g_pack_arena_used += need;
+    }
+    if (it->second.bytes < bytes) return nullptr;
+    fill = it->second.version != g_pack_version;
+    it->second.version = g_pack_version;
+    return reinterpret_cast<float*>(g_pack_arena + it->second.offset);
 }
 
-void launch_pack_taps(const float* W, float* dst, int Co, int C, int T, const int* taps, int ntaps, int Kp, int Mp,
-                      hipStream_t st) {
+}  // namespace
+
+const float* launch_pack(const float* W, float* dst, size_t room, int Co, int C, int T, PackMode mode, int Kp, int Mp,
+                         int Cpad, hipStream_t st) {
+    bool fill = true;
+    const PackKey key{g_pack_token, W, (int)mode, Co, C, T, Kp, Mp, Cpad};
+    if (float* slot = pack_slot(key, room, fill)) dst = slot;
+    if (fill) {
+        const long long total = (long long)Kp * Mp;
+        hipLaunchKernelGGL(pack_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, W, dst, Co, C, T, (int)mode, Kp,
+                           Mp, Cpad);
+    }
+    return dst;
+}
+
+const float* launch_pack_taps(const float* W, float* dst, size_t room, int Co, int C, int T, const int* taps, int ntaps,
+                              int Kp, int Mp, hipStream_t st) {
     TapList tl;
     tl.n = ntaps;
-    for (int i = 0; i < 9; ++i) tl.tap[i] = i < ntaps ? taps[i] : 0;
-    const long long total = (long long)Kp * Mp;
-    hipLaunchKernelGGL(pack_taps_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, W, dst, Co, C, T, tl, Kp, Mp);
+    int sig = ntaps;
+    for (int i = 0; i < 9; ++i) { tl.tap[i] = i < ntaps ? taps[i] : 0; sig = sig * 31 + tl.tap[i]; }
+    bool fill = true;
+    const PackKey key{g_pack_token, W, 2, Co, C, T, Kp, Mp, sig};
+    if (float* slot = pack_slot(key, room, fill)) dst = slot;
+    if (fill) {
+        const long long total = (long long)Kp * Mp;
+        hipLaunchKernelGGL(pack_taps_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, W, dst, Co, C, T, tl, Kp, Mp);
+    }
+    return dst;
 }
 
 void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp, int Co, int C, int T, hipStream_t st) {
@@ -138,3 +205,19 @@ void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, 
 }
 
 }  // namespace cnuda
+
+extern "C" int cnuda_pack_cache_attach(void* arena, size_t bytes) {
+    std::lock_guard<std::mutex> lock(cnuda::g_pack_mutex);
+    cnuda::g_pack_slots.clear();
+    cnuda::g_pack_arena = reinterpret_cast<char*>(((uintptr_t)arena + 255) & ~(uintptr_t)255);
+    cnuda::g_pack_arena_bytes = arena ? bytes - (size_t)(cnuda::g_pack_arena - (char*)arena) : 0;
+    cnuda::g_pack_arena_used = 0;
+    if (!arena) cnuda::g_pack_arena = nullptr;
+    return 0;
+}
+extern "C" int cnuda_pack_stamp(unsigned long long token, unsigned long long version) {
+    cnuda::g_pack_token = token;
+    cnuda::g_pack_version = version;
+    return 0;
+}
+extern "C" size_t cnuda_pack_cache_used(void) { return cnuda::g_pack_arena_used; }

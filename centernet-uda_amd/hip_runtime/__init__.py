@@ -112,6 +112,9 @@ class _Sig:
     cnuda_adam_step = (_I, [_P] * 4 + [_LL] + [_F] * 5 + [_I, _P])
     cnuda_set_matrix_mode = (_I, [_I])
     cnuda_get_matrix_mode = (_I, [])
+    cnuda_pack_cache_attach = (_I, [_P, c_size_t])
+    cnuda_pack_stamp = (_I, [ctypes.c_ulonglong, ctypes.c_ulonglong])
+    cnuda_pack_cache_used = (c_size_t, [])
     cnuda_prof_enable = (_I, [_I])
     cnuda_prof_arm = (_I, [_I])
     cnuda_prof_collect = (_I, [_P, _P, _P, _I])
@@ -138,6 +141,45 @@ def param_state_key(module):
     for t in list(module.parameters()) + list(module.buffers()):
         v += t._version + (t.data_ptr() & 0xffff)
     return (_PARAM_EPOCH, v)
+
+
+# ---------------------------------------------------------------------------
+# Pack cache (csrc/pack.hip): the packed weight image of a convolution only changes when the weights do.  Modules
+# that own weights take a token (new_pack_token) and stamp their calls with (token, version of the weight tensor);
+# the library then re-packs only after an optimizer step / load_state_dict.  The arena is one buffer allocated
+# here on first use (CNUDA_PACK_CACHE_MB, default 768; 0 disables).  Functional calls without a token never cache.
+# Loophole, as for torch's own saved-tensor checks: in-place writes through `weight.data` bump no version.
+# ---------------------------------------------------------------------------
+_PACK = {'arena': None, 'next_token': 1, 'off': os.environ.get('CNUDA_PACK_CACHE_MB', '768') == '0'}
+
+
+def new_pack_token():
+    t = _PACK['next_token']
+    _PACK['next_token'] += 1
+    return t
+
+
+class pack_stamp:
+    """with pack_stamp(token, weight[, version]): <one C-ABI call that packs `weight`>"""
+    __slots__ = ('token', 'version', 'device')
+
+    def __init__(self, token, weight, version=None):
+        self.token = 0 if _PACK['off'] else int(token)
+        v = weight._version if version is None else int(version)
+        self.version = ((_PARAM_EPOCH & 0xffffffff) << 32) | (v & 0xffffffff)
+        self.device = weight.device
+
+    def __enter__(self):
+        if self.token:
+            if _PACK['arena'] is None:
+                mb = int(os.environ.get('CNUDA_PACK_CACHE_MB', '768'))
+                _PACK['arena'] = torch.empty(mb << 20, dtype=torch.uint8, device=self.device)
+                check(lib().cnuda_pack_cache_attach(ptr(_PACK['arena']), _PACK['arena'].numel()), 'pack_cache_attach')
+            lib().cnuda_pack_stamp(self.token, self.version)
+
+    def __exit__(self, *exc):
+        if self.token:
+            lib().cnuda_pack_stamp(0, 0)
 
 
 # ---------------------------------------------------------------------------

@@ -24,6 +24,8 @@ class Conv2d(nn.Module):
         self.act_slope = float(act_slope)
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        from . import new_pack_token
+        self._pack_token = new_pack_token()         # identity of these weights for the library's pack cache
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -36,7 +38,7 @@ class Conv2d(nn.Module):
                 self.bias.uniform_(-bound, bound)
 
     def forward(self, x):
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.act_slope)
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.act_slope, self._pack_token)
 
     def extra_repr(self):
         return '%d, %d, kernel_size=%s, stride=%s, padding=%s, bias=%s, act_slope=%g' % (

@@ -6,7 +6,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from . import check, f32c, lib, prof_arm, ptr, require_gpu, stream, workspace
+from . import check, f32c, lib, pack_stamp, prof_arm, ptr, require_gpu, stream, workspace
 from .arena import grad_sink
 
 
@@ -46,7 +46,7 @@ def _conv_geom(x, weight, stride, padding):
 
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, act_slope):
+    def forward(ctx, x, weight, bias, stride, padding, act_slope, pack_token=0):
         require_gpu(x, weight, bias)
         x, weight = f32c(x), f32c(weight)
         bias = None if bias is None else f32c(bias)
@@ -57,9 +57,10 @@ class _Conv2d(Function):
         L = lib()
         wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g), x)
         prof_arm('conv_fwd', B, C, H, W, Co, kh, kw, Ho, Wo)
-        check(L.cnuda_conv2d_forward(ptr(x), ptr(weight), ptr(bias), ptr(y), *g, float(act_slope),
-                                     wp, wn, stream()), 'conv2d_forward')
-        ctx.geom, ctx.act_slope, ctx.has_bias = g, act_slope, bias is not None
+        with pack_stamp(pack_token, weight):
+            check(L.cnuda_conv2d_forward(ptr(x), ptr(weight), ptr(bias), ptr(y), *g, float(act_slope),
+                                         wp, wn, stream()), 'conv2d_forward')
+        ctx.geom, ctx.act_slope, ctx.has_bias, ctx.pack_token = g, act_slope, bias is not None, pack_token
         ctx.save_for_backward(x, weight, y if act_slope >= 0 else None, bias)
         return y
 
@@ -81,23 +82,27 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             prof_arm('conv_dgrad', B, C, H, W, Co, kh, kw, Ho, Wo)
-            check(L.cnuda_conv2d_backward_data(ptr(gy), ptr(weight), ptr(gx), *g, wp, wn, stream()),
-                  'conv2d_backward_data')
+            with pack_stamp(ctx.pack_token, weight):
+                check(L.cnuda_conv2d_backward_data(ptr(gy), ptr(weight), ptr(gx), *g, wp, wn, stream()),
+                      'conv2d_backward_data')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw_buf, gw = _param_grad(weight)
             gb_buf, gb = _param_grad(bias, ctx.has_bias)
             prof_arm('conv_wgrad', B, C, H, W, Co, kh, kw, Ho, Wo)
             check(L.cnuda_conv2d_backward_weight(ptr(x), ptr(gy), ptr(gw_buf), ptr(gb_buf), *g, wp, wn, stream()),
                   'conv2d_backward_weight')
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0):
-    """y = act(conv2d(x, weight) + bias); act_slope < 0 none, 0 ReLU, 0.2 LeakyReLU(0.2)."""
-    return _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope))
+def conv2d(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0, pack_token=0):
+    """y = act(conv2d(x, weight) + bias); act_slope < 0 none, 0 ReLU, 0.2 LeakyReLU(0.2).  pack_token: identity of
+    the module that owns `weight` (hip_runtime.new_pack_token) -- lets the library keep the packed weight image
+    until the weights change; 0 = re-pack on every call."""
+    return _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope), pack_token)
 
 
-def conv2d_infer(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0, residual=None):
+def conv2d_infer(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0, residual=None, pack_token=0,
+                 pack_version=None):
     """Tape-free y = act(conv2d(x, weight) + bias + residual): the forward kernel with the skip connection in its
     epilogue -- what a BatchNorm-folded BasicBlock needs (export.py).  No autograd node is created."""
     require_gpu(x, weight, bias, residual)
@@ -115,8 +120,9 @@ def conv2d_infer(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0, resi
     L = lib()
     wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g), x)
     prof_arm('conv_fwd', B, C, H, W, Co, kh, kw, Ho, Wo)
-    check(L.cnuda_conv2d_forward_res(ptr(x), ptr(weight), ptr(bias), ptr(residual), ptr(y), *g, float(act_slope),
-                                     wp, wn, stream()), 'conv2d_forward')
+    with pack_stamp(pack_token, weight, pack_version):
+        check(L.cnuda_conv2d_forward_res(ptr(x), ptr(weight), ptr(bias), ptr(residual), ptr(y), *g, float(act_slope),
+                                         wp, wn, stream()), 'conv2d_forward')
     return y
 
 

@@ -20,16 +20,18 @@ def _pair(v):
 class _DeformConvFn(torch.autograd.Function):
     # autograd-visible argument order (dcn_v2.py:18-19): input, offset, mask, weight, bias, ...
     @staticmethod
-    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
+    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token=0):
         kh, kw = weight.shape[2], weight.shape[3]
         ctx.geom = (kh, kw) + _pair(stride) + _pair(padding) + _pair(dilation) + (deformable_groups,)
         # keep the sampled columns (a side output of the forward kernel) for the weight gradient:
         # on a 288 GB part re-reading ~0.3 GB per layer beats re-sampling the input
         keep = deformable_groups == 1 and input.shape[3] >= 2 and any(ctx.needs_input_grad[:5])
         if keep:
-            out, cols = _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geom, _want_columns=True)
+            out, cols = _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geom, _want_columns=True,
+                                                _pack_token=pack_token)
         else:
-            out, cols = _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geom), None
+            out, cols = _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geom,
+                                                _pack_token=pack_token), None
         ctx.save_for_backward(input, offset, mask, weight, bias, cols)
         return out
 
@@ -42,7 +44,7 @@ class _DeformConvFn(torch.autograd.Function):
         g_in, g_off, g_mask, g_w, g_b = _backend.dcn_v2_backward(
             input, weight, bias, offset, mask, grad_output, *ctx.geom, _columns=cols, _grad_weight=sw, _grad_bias=sb)
         return g_in, g_off, g_mask, (None if sw is not None else g_w), (None if sb is not None else g_b), \
-            None, None, None, None
+            None, None, None, None, None
 
 
 dcn_v2_conv = _DeformConvFn.apply
@@ -58,6 +60,8 @@ class DCNv2(nn.Module):
         self.deformable_groups = deformable_groups
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels))
+        import hip_runtime as hr
+        self._pack_token = hr.new_pack_token()      # identity of these weights for the library's pack cache
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -71,7 +75,7 @@ class DCNv2(nn.Module):
         taps = self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]
         assert offset.shape[1] == 2 * taps and mask.shape[1] == taps
         return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding,
-                           self.dilation, self.deformable_groups)
+                           self.dilation, self.deformable_groups, self._pack_token)
 
 
 class DCN(DCNv2):
@@ -95,4 +99,4 @@ class DCN(DCNv2):
         # [2*taps, 3*taps) the mask logits
         offset, mask = ops.split_offset_mask(om)
         return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding,
-                           self.dilation, self.deformable_groups)
+                           self.dilation, self.deformable_groups, self._pack_token)

@@ -47,6 +47,19 @@ const char* cnuda_last_error(void);
 int cnuda_set_matrix_mode(int mode);
 int cnuda_get_matrix_mode(void);
 
+/* Pack cache, no counterpart in the reference (cuDNN / cuBLAS keep their own operand layouts).  The implicit GEMMs
+ * read the small weight operand from a zero-padded [Kp][Mp] image that used to be rebuilt by a tiny kernel on every
+ * convolution call although it only changes when the weights do.  cnuda_pack_cache_attach hands the library ONE
+ * caller-owned device arena (nothing is allocated inside the library; NULL detaches and forgets every slot).
+ * cnuda_pack_stamp(token, version), called on the calling thread right before a convolution / DCN entry point,
+ * names the weights that call will pack: `token` identifies their owner (0 = anonymous: never cached), `version`
+ * changes whenever their values may have changed.  A slot is reused iff the same token packed the same source
+ * buffer to the same image before and the version is unchanged; the stamp stays in force until the next
+ * cnuda_pack_stamp on that thread (callers reset it to (0, 0) after the call).  cnuda_pack_cache_used: bytes taken. */
+int cnuda_pack_cache_attach(void* arena, size_t bytes);
+int cnuda_pack_stamp(unsigned long long token, unsigned long long version);
+size_t cnuda_pack_cache_used(void);
+
 /* Measurement aid (bench.py roofline leg), not part of the reference's surface:
  * cnuda_prof_enable(n) pre-creates n hipEvent pairs; cnuda_prof_arm(tag) makes
  * the NEXT convolution / DCN main-kernel launch record a start/stop pair on its

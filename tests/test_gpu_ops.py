@@ -209,3 +209,40 @@ def test_conv_full_size_linearity_64ch_128sq():
     w = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV)
     f = lambda t: ops.conv2d(t, w, None, 1, 1)
     _close(f(x1 + 2 * x2), f(x1) + 2 * f(x2), 2e-5)
+
+
+def test_pack_cache_follows_the_weights():
+    """The library keeps the packed weight image of a module's convolution until the weights change (csrc/pack.hip):
+    results must track in-place updates by torch (version counter), by the fused Adam (parameter epoch) and a
+    replaced Parameter; anonymous functional calls never cache."""
+    import hip_runtime as hr
+    from hip_runtime import nn as hnn, optim
+    g = torch.Generator().manual_seed(21)
+    conv = hnn.Conv2d(32, 48, 3, padding=1, bias=True).to(DEV)
+    x = torch.randn(2, 32, 9, 11, generator=g).to(DEV)
+
+    def ref():
+        return F.conv2d(x.cpu(), conv.weight.detach().cpu(), conv.bias.detach().cpu(), 1, 1)
+    y0 = conv(x)
+    _close(y0, ref())
+    used = hr.lib().cnuda_pack_cache_used()
+    assert used > 0
+    _close(conv(x), ref())                                  # served from the cache
+    assert hr.lib().cnuda_pack_cache_used() == used         # ... no new slot
+    with torch.no_grad():
+        conv.weight.mul_(-0.5)                              # torch in-place: version counter
+    _close(conv(x), ref())
+    opt = optim.Adam(conv.parameters(), lr=0.1)             # fused Adam on the flat arena: parameter epoch
+    conv(x).square().mean().backward()
+    opt.step()
+    _close(conv(x), ref())
+    torch.optim.SGD(conv.parameters(), lr=0.5).step()       # stock optimizer
+    _close(conv(x), ref())
+    conv.weight = torch.nn.Parameter(torch.randn(48, 32, 3, 3, generator=g).to(DEV) * 0.1)
+    _close(conv(x), ref())
+    # backward through cached packs (input-gradient image) after a change
+    xg = x.clone().requires_grad_(True)
+    conv(xg).sum().backward()
+    xr = x.cpu().requires_grad_(True)
+    F.conv2d(xr, conv.weight.detach().cpu(), conv.bias.detach().cpu(), 1, 1).sum().backward()
+    _close(xg.grad, xr.grad)
