@@ -181,16 +181,149 @@ __global__ void nms_kernel(const float* __restrict__ heat, float* __restrict__ o
     }
 }
 
+// Exact top-K of a plane whose NMS'd scores already sit in LDS as order-preserving 32-bit images (`bits[i]`, pixel
+// i): an 8-bit MSB radix search for the K-th largest value (per-wave histograms: no cross-wave atomics; zeros --
+// 8/9 of an NMS'd noise map -- are counted by ballot instead of hammering one bin), then one ordered pass: every
+// value above the threshold is taken, and of the values EQUAL to it the ones with the lowest pixel indices (the
+// order the 64-bit keys define).  Nothing is re-read from global memory and the NMS is not recomputed: plateaus
+// (a trained model's background is clamped to exactly 1e-4, so whole regions survive the NMS) and maps with fewer
+// than K or more than kPool survivors cost the same as any other map.  Result: s.sel[0..K) sorted descending.
+template <int NT>
+__device__ void lds_plane_topk(const uint32_t* __restrict__ bits, int n, int K, int KP, SelectScratch& s,
+                               int* __restrict__ whist /* [NT/64][256] */, int* __restrict__ wcnt /* [2][NT/64] */) {
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t zero_bits = 0x80000000u;            // float_order_bits(+0.0f)
+    __shared__ uint32_t thr_prefix;
+    __shared__ int thr_remaining, thr_done;
+    if (tid == 0) { thr_prefix = 0; thr_remaining = K; thr_done = 0; }
+    uint32_t decided = 0;
+    int shift = 24;
+    for (int pass = 0; pass < 4; ++pass, shift -= 8) {
+        for (int i = tid; i < NW * 256; i += NT) whist[i] = 0;
+        __syncthreads();
+        if (thr_done) break;
+        const uint32_t prefix = thr_prefix;
+        int zeros = 0;
+        for (int i = tid; i < n + (NT - 1); i += NT) {       // (every lane runs every iteration: ballots)
+            const bool in = i < n;
+            const uint32_t v = in ? bits[i] : 0u;
+            const bool live = in && (v & decided) == prefix;
+            const bool z = live && v == zero_bits;
+            zeros += __popcll(__ballot(z));
+            // one round of leader matching first: the lanes that share the first live lane's digit (a plateau: a whole
+            // wave of equal background scores) are counted with one ballot instead of 64 serialised LDS atomics
+            bool todo = live && !z;
+            const int digit = (int)((v >> shift) & 0xff);
+            const unsigned long long act = __ballot(todo);
+            if (act) {
+                const int leader = __ffsll((long long)act) - 1;
+                const int ld = __shfl(digit, leader, 64);
+                const unsigned long long same = __ballot(todo && digit == ld);
+                if (lane == leader) atomicAdd(&whist[wid * 256 + ld], __popcll(same));
+                todo = todo && digit != ld;
+            }
+            if (todo) atomicAdd(&whist[wid * 256 + digit], 1);
+        }
+        if (lane == 0 && zeros) atomicAdd(&whist[wid * 256 + (int)((zero_bits >> shift) & 0xff)], zeros);
+        __syncthreads();
+        for (int b = tid; b < 256; b += NT) {                 // fold the wave histograms into s.hist
+            int t = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += whist[w * 256 + b];
+            s.hist[b] = t;
+        }
+        __syncthreads();
+        if (tid < 64) {      // suffix counts over 256 bins, 4 bins per lane (as block_topk)
+            const int base = (63 - tid) * 4;
+            const int c3 = s.hist[base + 3], c2 = s.hist[base + 2], c1 = s.hist[base + 1], c0 = s.hist[base];
+            const int local = c0 + c1 + c2 + c3;
+            int incl = local;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += t;
+            }
+            const int rem = thr_remaining;
+            int acc = incl - local;
+            const int cs[4] = {c3, c2, c1, c0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cnt = cs[j];
+                if (acc < rem && rem <= acc + cnt) {
+                    thr_prefix = prefix | ((uint32_t)(base + 3 - j) << shift);
+                    thr_remaining = rem - acc;
+                    if (cnt == rem - acc) thr_done = 1;       // the whole bucket is selected
+                }
+                acc += cnt;
+            }
+        }
+        decided |= 0xffu << shift;
+        __syncthreads();
+    }
+    __syncthreads();
+    // values whose decided bits exceed the threshold's are in; of those that equal it, `need` are -- all of them when
+    // the search stopped early (done), else the lowest pixel indices first
+    const uint32_t T = thr_prefix, m = decided;
+    const int need = thr_remaining;
+    const int per_wave = (n + NW - 1) / NW;                  // wave w owns pixels [w*per_wave, (w+1)*per_wave)
+    const int lo = wid * per_wave, hi = min(n, lo + per_wave);
+    int gt = 0, eq = 0;
+    for (int i = lo + lane; i < hi + 63; i += 64) {
+        const uint32_t v = i < hi ? bits[i] & m : 0u;
+        gt += __popcll(__ballot(i < hi && v > T));
+        eq += __popcll(__ballot(i < hi && v == T));
+    }
+    if (lane == 0) { wcnt[wid] = gt; wcnt[NW + wid] = eq; }
+    for (int i = tid; i < KP; i += NT) s.sel[i] = 0;
+    __syncthreads();
+    int gt_base = 0, eq_base = 0, gt_total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        gt_base += w < wid ? wcnt[w] : 0;
+        eq_base += w < wid ? wcnt[NW + w] : 0;
+        gt_total += wcnt[w];
+    }
+    for (int i = lo + lane; i < hi + 63; i += 64) {
+        const bool in = i < hi;
+        const uint32_t full = in ? bits[i] : 0u;
+        const uint32_t v = full & m;
+        const bool g = in && v > T, e = in && v == T;
+        const unsigned long long mg = __ballot(g), me = __ballot(e);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (g) s.sel[gt_base + __popcll(mg & below)] = ((uint64_t)full << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
+        const int er = eq_base + __popcll(me & below);
+        if (e && er < need) s.sel[gt_total + er] = ((uint64_t)full << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
+        gt_base += __popcll(mg);
+        eq_base += __popcll(me);
+    }
+    __syncthreads();
+    // bitonic sort, descending, KP a power of two <= 1024
+    for (int size = 2; size <= KP; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (KP >> 1); t += NT) {
+                const int l2 = (t / stride) * (stride << 1) + (t % stride);
+                const int h2 = l2 + stride;
+                const bool desc = ((l2 & size) == 0);
+                const uint64_t a = s.sel[l2], b = s.sel[h2];
+                if ((a < b) == desc) { s.sel[l2] = b; s.sel[h2] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // Stage 1.
 constexpr int kPlaneThreads = 1024;
 constexpr int kPool = 2048;          // positive-score candidates the fast path sorts
 __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* __restrict__ heat,
                                                                    uint64_t* __restrict__ cand, int H, int W, int K,
-                                                                   int KP, int pad) {
+                                                                   int KP, int pad, int lds_plane) {
     __shared__ SelectScratch s;
     __shared__ uint64_t pool[kPool];
     __shared__ int count;
     __shared__ int wave_count[kPlaneThreads / 64];
+    extern __shared__ uint32_t plane_bits[];          // [HW] order bits of the NMS'd scores (0 bytes: plane too large)
     const int tid = threadIdx.x, lane = tid & 63;
     const int HW = H * W;
     const float* plane = heat + (size_t)blockIdx.x * HW;
@@ -203,6 +336,8 @@ __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* 
     // every wave then writes its keys at its own offsets.
     constexpr int kPer = 16, kWaves = kPlaneThreads / 64;
     const bool quads = pad == 1 && (W & 3) == 0;        // the reference's default 3x3 window on 4-aligned rows
+    const bool lds_bits = lds_plane != 0;              // host: the plane's score bits fit the dynamic LDS
+    __shared__ int wave_count2[2 * (kPlaneThreads / 64)];
     const int wid = tid >> 6;
     int filled = 0;                                   // survivors of the previous super-chunks (uniform)
     for (int s0 = 0; s0 < HW; s0 += kPer * kPlaneThreads) {
@@ -243,6 +378,7 @@ __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* 
             const unsigned long long m = __ballot(pos);
             const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
             const int pix = quads ? s0 + ((u >> 2) * kPlaneThreads + tid) * 4 + (u & 3) : s0 + u * kPlaneThreads + tid;
+            if (lds_bits && pix < HW) plane_bits[pix] = float_order_bits(v[u]);
             if (pos && slot < kPool) pool[slot] = make_key(v[u], (uint32_t)pix);
             base += __popcll(m);
         }
@@ -293,7 +429,15 @@ __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* 
         for (int i = tid; i < K; i += kPlaneThreads) dst[i] = pool[i];
         return;
     }
-    // general case: exact select over all pixels (NMS recomputed per pass from the L1/L2-resident plane)
+    if (lds_bits) {
+        // general case, LDS-resident (see lds_plane_topk): the whole plane's NMS'd scores are already in LDS; the
+        // sorting pool's memory is free again and serves as the per-wave histograms
+        static_assert(sizeof(pool) >= (kPlaneThreads / 64) * 256 * sizeof(int), "histograms fit the pool");
+        lds_plane_topk<kPlaneThreads>(plane_bits, HW, K, KP, s, reinterpret_cast<int*>(pool), wave_count2);
+        for (int i = tid; i < K; i += kPlaneThreads) dst[i] = s.sel[i];
+        return;
+    }
+    // planes too large for the LDS: exact select with the NMS recomputed per pass from the L1/L2-resident plane
     block_topk<kPlaneThreads>([&](int i) { return make_key(nms_value(plane, H, W, i / W, i % W, pad), (uint32_t)i); },
                               HW, K, KP, s);
     for (int i = tid; i < K; i += kPlaneThreads) dst[i] = s.sel[i];
@@ -399,7 +543,18 @@ extern "C" int cnuda_decode_detection(const float* heat, const float* wh, const 
     uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
     uint64_t* cand = reinterpret_cast<uint64_t*>(base);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(plane_topk_kernel, dim3(B * C), dim3(kPlaneThreads), 0, st, heat, cand, H, W, K, KP, pad);
+    // dynamic LDS: the plane's score bits (for the LDS-resident general path) when they fit beside the static
+    // arrays (about 27 KB) in the CU's 160 KB: planes up to 180 x 180
+    const size_t bits_bytes = (size_t)H * W * sizeof(uint32_t);
+    const int lds_plane = bits_bytes <= 128 * 1024 ? 1 : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(plane_topk_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(plane_topk_kernel, dim3(B * C), dim3(kPlaneThreads), lds_plane ? bits_bytes : 0, st, heat, cand,
+                       H, W, K, KP, pad, lds_plane);
     int rc = check_launch("cnuda_decode_detection(stage 1)");
     if (rc) return rc;
     hipLaunchKernelGGL(merge_decode_kernel, dim3(B), dim3(kThreads), 0, st,

@@ -122,3 +122,56 @@ def test_errors():
         decode_detection(heat, torch.zeros(1, 2, 2, 2, device=DEV), K=5)          # K > H*W like torch.topk
     with pytest.raises(RuntimeError):
         decode_detection(torch.zeros(1, 1, 4, 4), torch.zeros(1, 2, 4, 4), K=2)   # CPU tensors: no fallback
+
+
+def _trained_like_map(B, C, H, W, seed, peaks=(0, 40)):
+    """What a trained model hands to the decode: background clamped to exactly 1e-4 (utils/tensor.py:5-7), so
+    whole plateaus survive the NMS (hmax == heat), plus a few peaks -- planes with thousands of tied survivors and
+    planes with fewer than K positive... all of which take the LDS-resident general path of the kernel."""
+    rs = np.random.RandomState(seed)
+    heat = np.full((B, C, H, W), 1e-4, np.float32)
+    for b in range(B):
+        for c in range(C):
+            n = rs.randint(peaks[0], peaks[1] + 1)
+            ys, xs = rs.randint(0, H, n), rs.randint(0, W, n)
+            heat[b, c, ys, xs] = (rs.uniform(0.05, 0.95, n)).astype(np.float32)
+    wh = rs.uniform(2, 40, (B, 2, H, W)).astype(np.float32)
+    reg = rs.uniform(0, 1, (B, 2, H, W)).astype(np.float32)
+    return heat, wh, reg
+
+
+@pytest.mark.parametrize('shape', [(2, 6, 128, 128, 150), (2, 3, 160, 160, 150), (1, 2, 40, 52, 100), (2, 4, 64, 64, 1),
+                                   (1, 1, 33, 35, 64)])
+def test_plateau_and_sparse_maps_take_the_lds_general_path(shape):
+    from backends.decode import decode_detection
+    B, C, H, W, K = shape
+    heat, wh, reg = _trained_like_map(B, C, H, W, 31 + H)
+    got = decode_detection(T(heat), T(wh), reg=T(reg), K=K).cpu().numpy()
+    want = od.decode_detection(heat, wh, reg, K=K)
+    assert np.array_equal(got[..., 4:], want[..., 4:])            # scores and classes: exact, ties by lowest index
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-5)
+
+
+def test_noise_map_at_160_overflows_the_sorting_pool():
+    # 25,600 pixels -> about 2,800 NMS survivors per plane (> the 2,048-key sorting pool): cfg5's map size
+    from backends.decode import decode_detection
+    rs = np.random.RandomState(77)
+    heat = (1.0 / (1.0 + np.exp(-(rs.standard_normal((2, 6, 160, 160)) - 2.19)))).astype(np.float32)
+    wh = rs.uniform(2, 40, (2, 3, 160, 160)).astype(np.float32)
+    reg = rs.uniform(0, 1, (2, 2, 160, 160)).astype(np.float32)
+    got = decode_detection(T(heat), T(wh), reg=T(reg), K=150, rotated=True).cpu().numpy()
+    want = od.decode_detection(heat, wh, reg, K=150, rotated=True)
+    assert np.array_equal(got[..., 5:], want[..., 5:])
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=2e-4)
+
+
+def test_negative_and_zero_scores_general_path():
+    # not the reference's call path (scores are probabilities there), but the kernel defines it: Q9's literal formula
+    from backends.decode import _topk
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((2, 3, 24, 28)).astype(np.float32)
+    x[:, :, 5:9] = 0.0
+    s, i, c, ys, xs = _topk(T(x), K=40)
+    os_, oi, oc, oy, ox = od.topk(x, 40)
+    assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(c.cpu().numpy(), oc)
+    assert np.array_equal(s.cpu().numpy(), os_)
