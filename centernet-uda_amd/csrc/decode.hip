@@ -313,9 +313,47 @@ __device__ void lds_plane_topk(const uint32_t* __restrict__ bits, int n, int K, 
     }
 }
 
+// Bitonic sort (descending) of a 2048-key LDS pool by 1024 threads, two keys per thread in registers (positions 2t,
+// 2t+1): stride 1 is a compare inside the thread, strides 2..64 exchange with lane t ^ (stride/2) by shuffle, only
+// strides >= 128 cross waves and go through LDS -- 10 of the 66 stages need workgroup barriers.  Ends with the
+// sorted keys in `pool` (barrier included).
+constexpr int kPool = 2048;          // positive-score candidates the fast path sorts
+__device__ __forceinline__ void pool_sort_desc(uint64_t* __restrict__ pool, int tid) {
+    uint64_t k0 = pool[2 * tid], k1 = pool[2 * tid + 1];
+    const int p0 = 2 * tid;
+    for (int size = 2; size <= kPool; size <<= 1) {
+        const bool desc = (p0 & size) == 0;            // same for both keys of the thread (size >= 2)
+        for (int stride = size >> 1; stride >= 128; stride >>= 1) {
+            __syncthreads();                           // previous readers of the pool are done
+            pool[p0] = k0; pool[p0 + 1] = k1;
+            __syncthreads();
+            const uint64_t o0 = pool[p0 ^ stride], o1 = pool[(p0 + 1) ^ stride];
+            const bool lower = (p0 & stride) == 0;
+            const bool take_max = lower == desc;
+            k0 = take_max ? (k0 > o0 ? k0 : o0) : (k0 < o0 ? k0 : o0);
+            k1 = take_max ? (k1 > o1 ? k1 : o1) : (k1 < o1 ? k1 : o1);
+        }
+        for (int stride = size >> 1 < 64 ? size >> 1 : 64; stride >= 2; stride >>= 1) {
+            const uint64_t o0 = __shfl_xor(k0, stride >> 1, 64), o1 = __shfl_xor(k1, stride >> 1, 64);
+            const bool lower = (p0 & stride) == 0;
+            const bool take_max = lower == desc;
+            k0 = take_max ? (k0 > o0 ? k0 : o0) : (k0 < o0 ? k0 : o0);
+            k1 = take_max ? (k1 > o1 ? k1 : o1) : (k1 < o1 ? k1 : o1);
+        }
+        {   // stride 1: the thread's own pair
+            const uint64_t hi = k0 > k1 ? k0 : k1, lo = k0 > k1 ? k1 : k0;
+            k0 = desc ? hi : lo;
+            k1 = desc ? lo : hi;
+        }
+    }
+    __syncthreads();
+    pool[p0] = k0; pool[p0 + 1] = k1;
+    __syncthreads();
+}
+
 // Stage 1.
 constexpr int kPlaneThreads = 1024;
-constexpr int kPool = 2048;          // positive-score candidates the fast path sorts
+static_assert(kPool == 2 * kPlaneThreads, "two keys per thread");
 __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* __restrict__ heat,
                                                                    uint64_t* __restrict__ cand, int H, int W, int K,
                                                                    int KP, int pad, int lds_plane) {
@@ -395,37 +433,7 @@ __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* 
         // Bitonic sort (descending) of the 2048-key pool, two keys per thread in registers (positions 2t, 2t+1):
         // stride 1 is a compare inside the thread, strides 2..64 exchange with lane t ^ (stride/2) by shuffle, only
         // strides >= 128 cross waves and go through LDS -- 10 of the 66 stages need workgroup barriers.
-        static_assert(kPool == 2 * kPlaneThreads, "two keys per thread");
-        uint64_t k0 = pool[2 * tid], k1 = pool[2 * tid + 1];
-        const int p0 = 2 * tid;
-        for (int size = 2; size <= kPool; size <<= 1) {
-            const bool desc = (p0 & size) == 0;            // same for both keys of the thread (size >= 2)
-            for (int stride = size >> 1; stride >= 128; stride >>= 1) {
-                __syncthreads();                           // previous readers of the pool are done
-                pool[p0] = k0; pool[p0 + 1] = k1;
-                __syncthreads();
-                const uint64_t o0 = pool[p0 ^ stride], o1 = pool[(p0 + 1) ^ stride];
-                const bool lower = (p0 & stride) == 0;
-                const bool take_max = lower == desc;
-                k0 = take_max ? (k0 > o0 ? k0 : o0) : (k0 < o0 ? k0 : o0);
-                k1 = take_max ? (k1 > o1 ? k1 : o1) : (k1 < o1 ? k1 : o1);
-            }
-            for (int stride = size >> 1 < 64 ? size >> 1 : 64; stride >= 2; stride >>= 1) {
-                const uint64_t o0 = __shfl_xor(k0, stride >> 1, 64), o1 = __shfl_xor(k1, stride >> 1, 64);
-                const bool lower = (p0 & stride) == 0;
-                const bool take_max = lower == desc;
-                k0 = take_max ? (k0 > o0 ? k0 : o0) : (k0 < o0 ? k0 : o0);
-                k1 = take_max ? (k1 > o1 ? k1 : o1) : (k1 < o1 ? k1 : o1);
-            }
-            {   // stride 1: the thread's own pair
-                const uint64_t hi = k0 > k1 ? k0 : k1, lo = k0 > k1 ? k1 : k0;
-                k0 = desc ? hi : lo;
-                k1 = desc ? lo : hi;
-            }
-        }
-        __syncthreads();
-        pool[p0] = k0; pool[p0 + 1] = k1;
-        __syncthreads();
+        pool_sort_desc(pool, tid);
         for (int i = tid; i < K; i += kPlaneThreads) dst[i] = pool[i];
         return;
     }
@@ -454,8 +462,20 @@ __global__ __launch_bounds__(kThreads) void merge_decode_kernel(
     const int n = C * K;
     const uint64_t* cb = cand + (size_t)b * n;
     // second-stage key: same score bits, position c*K+rank as the index
-    block_topk<kThreads>([&](int i) { return (cb[i] & 0xffffffff00000000ull) | (uint64_t)(0xffffffffu - (uint32_t)i); },
-                         n, K, KP, s);
+    auto key2 = [&](int i) { return (cb[i] & 0xffffffff00000000ull) | (uint64_t)(0xffffffffu - (uint32_t)i); };
+    if (n <= kPool) {
+        // few classes (the reference's default 6 x 150 = 900 candidates): one register / shuffle bitonic sort of
+        // the zero-padded candidate list instead of eight radix passes and an LDS sort (about 70 barriers)
+        static_assert(kThreads * 2 == kPool, "two keys per thread");
+        __shared__ uint64_t pool2[kPool];
+        for (int i = threadIdx.x; i < kPool; i += kThreads) pool2[i] = i < n ? key2(i) : 0ull;
+        __syncthreads();
+        pool_sort_desc(pool2, threadIdx.x);
+        for (int i = threadIdx.x; i < K; i += kThreads) s.sel[i] = pool2[i];
+        __syncthreads();
+    } else {
+        block_topk<kThreads>(key2, n, K, KP, s);
+    }
     const int ncol = rotated ? 7 : 6;
     for (int k = threadIdx.x; k < K; k += kThreads) {
         const uint64_t key = s.sel[k];
