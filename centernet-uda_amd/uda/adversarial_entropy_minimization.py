@@ -77,19 +77,30 @@ class AdversarialEntropyMinimization(Model):
         D = self.discriminator
         for p in D.parameters():
             p.requires_grad = False
-        out_s = self.backend(data["input"])
-        out_t = self.backend(data["target_domain_input"])
+        batched = (self.batch_domains and hasattr(self.backend, 'forward_domains')
+                   and data["input"].shape == data["target_domain_input"].shape)
+        if batched:
+            # one pass over source | target (uda/base.py step_with_target_term explains the equivalence); the
+            # target's heat map feeds the discriminator, its other heads feed nothing
+            out_s, out_t = self.backend.forward_domains(data["input"], data["target_domain_input"],
+                                                        target_grad_heads=self.target_grad_heads)
+        else:
+            out_s = self.backend(data["input"])
+            out_t = self.backend(data["target_domain_input"])
         fool_logits = D(entropy_map(out_t["hm"]))
         outputs = {"source_domain": out_s, "target_domain": out_t}
 
         loss, stats = self.centernet_loss(out_s, data)
-        if is_training:
+        if is_training and not batched:
             with self._defer_sync():
                 loss.backward()
         dtf_loss, _ = self.adversarial_loss(fool_logits, self.source_label)
         dtf_loss *= self.adversarial_weight
         if is_training:
-            dtf_loss.backward()              # last backward that reaches the backbone
+            if batched:
+                (loss + dtf_loss).backward() # the two backward calls of the reference (:101,110) as one pass
+            else:
+                dtf_loss.backward()          # last backward that reaches the backbone
             self._finish_backward(self.backend)
 
         for p in D.parameters():

@@ -121,3 +121,52 @@ def test_batched_step_equals_the_sequential_step(golden, kind):
             assert int(bb[n]) == int(bs[n]) == 2, n        # Q6: two BatchNorm updates per step
     # the target heads that feed no loss are evaluated without a tape
     assert ob['target_domain']['hm'].requires_grad and not ob['target_domain']['wh'].requires_grad
+
+
+def test_batched_advent_step_equals_the_sequential_step(golden):
+    """S4 with the two backbone passes batched: (detection loss + fooling loss).backward() in one pass over
+    source | target against the reference's literal five-backward sequence."""
+    import uda
+    from backends import dla
+    from hip_runtime import optim
+    from losses.centernet import DetectionLoss
+    g = golden('step_advent')
+    shapes = dict(ast.literal_eval(str(g['shapes_json'])))
+    dshapes = dict(ast.literal_eval(str(g['dshapes_json'])))
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+    res = []
+    B, S, M = 4, 128, 8
+    for batched in (True, False):
+        model = dla.build(num_classes=6, rotated_boxes=True)
+        model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes, 0.1).items()})
+        plugin = uda.AdversarialEntropyMinimization(1e-2, optimizer=Cfg(name='Adam', params=Cfg(lr=1e-3, weight_decay=1e-4)))
+        plugin.batch_domains = batched
+        plugin.cfg = Cfg(max_detections=20, model=Cfg(backend=Cfg(params=Cfg(rotated_boxes=True, num_classes=6))))
+        plugin.backend = model
+        plugin.device = torch.device(DEV)
+        plugin.optimizer = optim.Adam(model.parameters(), lr=5e-5, weight_decay=1e-4)
+        plugin.centernet_loss = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0, periodic=True)
+        plugin.init_done()
+        plugin.discriminator.load_state_dict({k: T(gin.fill_value('discriminator.' + k, tuple(v))) for k, v in dshapes.items()})
+        plugin.to(DEV)
+        plugin.set_phase(True)
+        data = {k: T(v) for k, v in gin.detection_batch(B, 6, S // 4, S // 4, M, (4, 2, 1, 6), 3, 71).items()}
+        data['input'] = T(gin.image_batch(B, S, S, 72))
+        data['target_domain_input'] = T(gin.image_batch(B, S, S, 73))
+        out = plugin.step(data)
+        res.append((out['stats'], {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
+                    {n: p.grad.detach().clone() for n, p in plugin.discriminator.named_parameters()}))
+    (sb, gb, db), (ss, gs, ds) = res
+    assert set(sb) == set(ss) == {'centernet_loss', 'hm_loss', 'wh_loss', 'off_loss', 'total_loss', 'dis_soruce',
+                                  'dis_target', 'dis_fool'}
+    for k in ss:
+        assert abs(float(sb[k]) - float(ss[k])) <= 1e-5 * max(abs(float(ss[k])), 1e-9), k
+    assert sorted(gb) == sorted(gs)
+    for n in gs:
+        if n.endswith('.conv.bias') and 'ida' in n:
+            continue
+        assert _rel(gb[n], gs[n]) <= 2e-4, (n, _rel(gb[n], gs[n]))
+    for n in ds:
+        assert _rel(db[n], ds[n]) <= 2e-4, n
