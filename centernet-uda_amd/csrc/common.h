@@ -43,6 +43,7 @@ private:
     int rec_;
 };
 constexpr int kProfNameLen = 96;
+bool prof_active();      // the kernel timer is enabled (cnuda_prof_enable(n > 0))
 class ProfGroup {
 public:
     ProfGroup();

@@ -811,6 +811,28 @@ __global__ void dcn_naive_bwd_kernel(DcnNaiveParams p) {
     }
 }
 
+// Side stream of the backward pass.  The weight-gradient GEMM (MFMA-bound) depends only on the call's inputs, the
+// data-gradient chain (column-gradient GEMM -> coord_grad -> col2im) spends two thirds of its time in latency /
+// gather-bound kernels that leave the matrix pipes idle: the two run concurrently on two HIP streams, forked and
+// joined with events (capturable; the caller still sees one stream-ordered operation).  CNUDA_DCN_OVERLAP=0 turns
+// it off.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = false;
+    SideStream() {
+        const char* e = getenv("CNUDA_DCN_OVERLAP");
+        if (e && e[0] == '0') return;
+        ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
+    }
+};
+SideStream& side_stream() {
+    static thread_local SideStream s;      // one per calling thread (forward: caller's, backward: autograd's)
+    return s;
+}
+
 int fill_geom(DcnGeom& g, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
               int dw, int dg, const char* who) {
     CNUDA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Co > 0, "%s: empty tensor", who);
@@ -1023,11 +1045,38 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
     Carver cv(workspace, workspace_bytes);
     float* slabs = cv.take<float>((size_t)q.Z * q.Mpw * q.Jp);
     float* bsum = cv.take<float>((size_t)Cout * B);
-    launch_channel_sum(grad_output, grad_bias, B, Cout, HoWo, st, bsum);
     float* wt = cv.take<float>((size_t)q.T * C * Cout);
     float* dcol = cv.take<float>((size_t)B * q.T * C * HoWo);
     DcnGeo* geo = cv.take<DcnGeo>((size_t)B * q.T * HoWo);
     void* gemm_ws = cv.take<char>(q.gemm_bytes);
+    // weight / bias gradients on the side stream, concurrently with the data-gradient chain below
+    SideStream& side = side_stream();
+    const bool overlap = side.ok && !prof_active();      // (the in-library timer brackets kernels on ONE stream)
+    hipStream_t wst = overlap ? side.stream : st;
+    if (overlap) {
+        (void)hipEventRecord(side.fork, st);
+        (void)hipStreamWaitEvent(wst, side.fork, 0);
+    }
+    launch_channel_sum(grad_output, grad_bias, B, Cout, HoWo, wst, bsum);
+    // (2) weight gradient
+    {
+        if (columns) {
+            DcnColWParams p{g, columns, grad_output};
+            if (q.Jp % 128 == 0)
+                hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
+                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+            else
+                hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+        } else {
+            DcnWParams p{g, input, offset, mask, grad_output};
+            hipLaunchKernelGGL((igemm_wgrad_kernel<DcnWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+                               dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+        }
+        if (int rc = check_launch("cnuda_dcn_v2_backward(weight)")) return rc;
+        launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, wst);
+    }
+    if (overlap) (void)hipEventRecord(side.join, wst);
     {
         // (1) dcol = W^T x grad_output as a 1x1 implicit GEMM, then the two streaming consumers
         ProfGroup prof;       // sub 0: the 1x1 GEMM (its own scope), 1: coord_grad, 2: col2im
@@ -1053,23 +1102,6 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
         }
         if (int rc = check_launch("cnuda_dcn_v2_backward(data)")) return rc;
     }
-    // (2) weight gradient
-    {
-        if (columns) {
-            DcnColWParams p{g, columns, grad_output};
-            if (q.Jp % 128 == 0)
-                hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
-                                   dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
-            else
-                hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
-                                   dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
-        } else {
-            DcnWParams p{g, input, offset, mask, grad_output};
-            hipLaunchKernelGGL((igemm_wgrad_kernel<DcnWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
-                               dim3(IG_THREADS), 0, st, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
-        }
-        if (int rc = check_launch("cnuda_dcn_v2_backward(weight)")) return rc;
-        launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, st);
-    }
+    if (overlap) (void)hipStreamWaitEvent(st, side.join, 0);
     return check_launch("cnuda_dcn_v2_backward");
 }

@@ -53,6 +53,7 @@ ProfGroup::ProfGroup() {
     g_prof_armed = -1;
 }
 ProfGroup::~ProfGroup() { g_prof_group = -1; }
+bool prof_active() { return !g_prof_pool.empty(); }
 }  // namespace cnuda
 
 extern "C" int cnuda_prof_enable(int max_records) {
