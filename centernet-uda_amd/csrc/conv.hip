@@ -98,6 +98,18 @@ struct ConvFwdLoader {
             if (p.act_slope >= 0.0f && v < 0.0f) v *= p.act_slope;
             base[(size_t)m * HoWo] = v;
         }
+        // four consecutive pixels of one image (16-byte epilogue, igemm.cuh)
+        static constexpr bool kVec4 = true;
+        __device__ static bool vec4_ok(const Params& p) { return ((p.g.Ho * p.g.Wo) & 3) == 0; }
+        __device__ __forceinline__ void store4(const Params& p, int m, f32x4 v) {
+            if (p.bias) v += p.bias[m];
+            if (res) v += *reinterpret_cast<const f32x4*>(res + (size_t)m * HoWo);
+            if (p.act_slope >= 0.0f) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (v[e] < 0.0f) v[e] *= p.act_slope;
+            }
+            *reinterpret_cast<f32x4*>(base + (size_t)m * HoWo) = v;
+        }
     };
 };
 
@@ -169,6 +181,11 @@ struct ConvDgradLoader {
             base = p.gx + (size_t)b * p.g.C * HW + pp;
         }
         __device__ __forceinline__ void store(const Params&, int m, float v) { base[(size_t)m * HW] = v; }
+        static constexpr bool kVec4 = true;
+        __device__ static bool vec4_ok(const Params& p) { return ((p.g.H * p.g.W) & 3) == 0; }
+        __device__ __forceinline__ void store4(const Params&, int m, f32x4 v) {
+            *reinterpret_cast<f32x4*>(base + (size_t)m * HW) = v;
+        }
     };
 };
 
@@ -228,6 +245,9 @@ struct ConvDgradClassLoader {
             base = p.gx + (size_t)b * p.g.C * HW + (size_t)(p.py + qy * p.g.sh) * p.g.W + p.px + qx * p.g.sw;
         }
         __device__ __forceinline__ void store(const Params&, int m, float v) { base[(size_t)m * HW] = v; }
+        static constexpr bool kVec4 = false;      // a parity class's pixels are `stride` apart in memory
+        __device__ static bool vec4_ok(const Params&) { return false; }
+        __device__ __forceinline__ void store4(const Params&, int, f32x4) {}
     };
 };
 

@@ -250,6 +250,16 @@ struct DcnFwdLoader {
             if (p.act_slope >= 0.0f && v < 0.0f) v *= p.act_slope;
             base[(size_t)m * HoWo] = v;
         }
+        static constexpr bool kVec4 = true;      // 16-byte epilogue (igemm.cuh)
+        __device__ static bool vec4_ok(const Params& p) { return ((p.g.Ho * p.g.Wo) & 3) == 0; }
+        __device__ __forceinline__ void store4(const Params& p, int m, f32x4 v) {
+            v += p.bias[m];
+            if (p.act_slope >= 0.0f) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (v[e] < 0.0f) v[e] *= p.act_slope;
+            }
+            *reinterpret_cast<f32x4*>(base + (size_t)m * HoWo) = v;
+        }
     };
 };
 
@@ -333,6 +343,16 @@ struct DcnColsLoader {
             v += p.bias[m];
             if (p.act_slope >= 0.0f && v < 0.0f) v *= p.act_slope;
             base[(size_t)m * HoWo] = v;
+        }
+        static constexpr bool kVec4 = true;      // 16-byte epilogue (igemm.cuh)
+        __device__ static bool vec4_ok(const Params& p) { return ((p.g.Ho * p.g.Wo) & 3) == 0; }
+        __device__ __forceinline__ void store4(const Params& p, int m, f32x4 v) {
+            v += p.bias[m];
+            if (p.act_slope >= 0.0f) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (v[e] < 0.0f) v[e] *= p.act_slope;
+            }
+            *reinterpret_cast<f32x4*>(base + (size_t)m * HoWo) = v;
         }
     };
 };

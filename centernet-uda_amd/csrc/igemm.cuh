@@ -224,6 +224,45 @@ __device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, cons
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Epilogue with 16-byte stores.  An MFMA accumulator tile has the pixel axis across LANES (lane & 31 = column), so
+// the straightforward epilogue stores one dword per lane, 16 instructions per 32x32 tile, each covering two 128-byte
+// row segments.  Here every wave stages its tile through LDS (the operand buffers are free after the K loop) and
+// reads it back with four consecutive pixels per lane: a quarter of the store instructions, 16 bytes each
+// (the store tail is issue-bound, not bandwidth-bound: cdna_hip_programming.md T21).  Out::store4(p, m, float4)
+// receives four consecutive pixels n..n+3 of one image row-major plane (the host guarantees that the pixel count per
+// image is a multiple of four, else kVec4 epilogues are not used).
+// ---------------------------------------------------------------------------
+constexpr int IG_EPI_LD = 36;                                  // floats per staged row (32 + pad, 16-byte aligned)
+constexpr int IG_EPI_WAVE = 32 * IG_EPI_LD;                    // floats per wave
+template <int BM, class Loader>
+__device__ __forceinline__ void ig_epilogue_vec4(const typename Loader::Params& p, float* __restrict__ stage,
+                                                 const f32x16 (&acc)[IgTile<BM>::TM][IgTile<BM>::TN], int m0, long long n0,
+                                                 int wm_off, int wn_off, int lane, int M, long long N) {
+    using T = IgTile<BM>;
+    const int col = lane & 31, cg = lane & 7, rsub = lane >> 3;
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const long long n = n0 + wn_off + j * 32 + 4 * cg;
+        typename Loader::Out out(p, n < N ? n : 0);
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[mfma_row(r, lane) * IG_EPI_LD + col] = acc[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // same wave: LDS ops complete in order
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + rsub;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * IG_EPI_LD + 4 * cg);
+                const int m = m0 + wm_off + i * 32 + row;
+                if (m < M && n < N) out.store4(p, m, v);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // reads done before the next tile overwrites
+        }
+    }
+}
+
 // raw-load storage of two-phase loaders (Loader::kHasSideOutput): Loader::Raw, else an empty placeholder
 template <class Loader, bool TWO_PHASE> struct IgRaw { struct type {}; };
 template <class Loader> struct IgRaw<Loader, true> { using type = typename Loader::Raw; };
@@ -243,8 +282,11 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void ig
     // two LDS stages: chunk k+1 is written while chunk k's fragments are still being read, one barrier per chunk
     // (X3: three bf16 pieces per operand, 1.5x the bytes)
     constexpr int LDS_A = X3 ? 3 * 2 * BM * 4 : IG_KC * BM, LDS_B = X3 ? 3 * 2 * IG_BN * 4 : IG_KC * IG_BN;   // floats
-    __shared__ __attribute__((aligned(16))) float As[2][LDS_A];
-    __shared__ __attribute__((aligned(16))) float Bs[2][LDS_B];
+    constexpr int LDS_AB = 2 * LDS_A + 2 * LDS_B;
+    static_assert(LDS_AB >= 4 * IG_EPI_WAVE, "the operand buffers hold the epilogue staging tiles");
+    __shared__ __attribute__((aligned(16))) float smem[LDS_AB];    // operand stages; reused by the vec4 epilogue
+    float (*As)[LDS_A] = reinterpret_cast<float (*)[LDS_A]>(smem);
+    float (*Bs)[LDS_B] = reinterpret_cast<float (*)[LDS_B]>(smem + 2 * LDS_A);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wg = xcd_remap(blockIdx.x, n_tiles * m_tiles);
     const int m0 = (wg % m_tiles) * BM;
@@ -383,6 +425,12 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void ig
         cur ^= 1;
     }
     }
+    if constexpr (Loader::Out::kVec4) {
+        if (Loader::Out::vec4_ok(p)) {      // (uniform; the K loop ended with a barrier: the operand buffers are free)
+            ig_epilogue_vec4<BM, Loader>(p, smem + wid * IG_EPI_WAVE, acc, m0, n0, wm_off, wn_off, lane, M, N);
+            return;
+        }
+    }
     // epilogue: lane owns pixel column (lane&31) of each tile
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
@@ -413,8 +461,11 @@ __global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd
     typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
     int n_tiles, int m_tiles) {
     using T = IgTile<BM>;
-    __shared__ __attribute__((aligned(16))) float As[2][IG_KC * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[2][IG_KC * IG_BN];
+    constexpr int LDS_AB = 2 * IG_KC * BM + 2 * IG_KC * IG_BN;
+    static_assert(LDS_AB >= 4 * IG_EPI_WAVE, "the operand buffers hold the epilogue staging tiles");
+    __shared__ __attribute__((aligned(16))) float smem[LDS_AB];    // operand stages; reused by the vec4 epilogue
+    float (*As)[IG_KC * BM] = reinterpret_cast<float (*)[IG_KC * BM]>(smem);
+    float (*Bs)[IG_KC * IG_BN] = reinterpret_cast<float (*)[IG_KC * IG_BN]>(smem + 2 * IG_KC * BM);
     const bool producer = threadIdx.x >= IG_THREADS;            // wave-uniform
     const int tid = threadIdx.x & (IG_THREADS - 1), lane = tid & 63, wid = tid >> 6;
     const int wg = xcd_remap(blockIdx.x, n_tiles * m_tiles);
@@ -467,6 +518,12 @@ __global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd
         ig_mma_chunk<BM>(As[cur], Bs[cur], acc, wm_off, wn_off, lane);
         __syncthreads();
         cur ^= 1;
+    }
+    if constexpr (Loader::Out::kVec4) {
+        if (Loader::Out::vec4_ok(p)) {      // (the producers wrote their last stage before the last barrier)
+            ig_epilogue_vec4<BM, Loader>(p, smem + wid * IG_EPI_WAVE, acc, m0, n0, wm_off, wn_off, lane, M, N);
+            return;
+        }
     }
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
