@@ -23,7 +23,6 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int SC_MAXK = 160;          // K = C*kh*kw padded to a multiple of 4 (147 -> 148, 144)
-constexpr int SC_MAXKS = SC_MAXK / 4;  // MFMA k-steps
 constexpr int SC_TW = 64;             // output tile: TH rows x 64 columns, one row per wave
 constexpr int SC_TH = 4;
 
@@ -38,12 +37,51 @@ struct SmallGeom {
 // index arithmetic).
 constexpr int SC_ROWS_PER_WAVE = 24;   // C * HR <= 96 halo rows per tile (checked in smallc_supported)
 
+// The halo rows a wave stages: rows wid, wid + 4, ... < C * HR, two values per lane (columns lane, lane + 64).
+// halo_load() only ISSUES the global loads (into registers); halo_store() writes them to LDS.  The kernels load the
+// NEXT tile's halo before the MFMA loop of the current one, so the global latency is hidden behind the matrix work
+// instead of being paid (twice) per tile between two barriers.
+struct HaloRegs { float v0[SC_ROWS_PER_WAVE], v1[SC_ROWS_PER_WAVE]; };
+__device__ __forceinline__ void halo_load(const SmallGeom& g, const float* __restrict__ xb, int iy0, int ix0, int tid,
+                                          HaloRegs& h) {
+    const int lane = tid & 63, wid = tid >> 6;
+    const int rows = g.C * g.HR;
+    const int ixa = ix0 + lane, ixb = ix0 + lane + 64;
+    const bool oka = ixa >= 0 && ixa < g.W, okb = lane + 64 < g.HC && ixb >= 0 && ixb < g.W;
+#pragma unroll
+    for (int i = 0; i < SC_ROWS_PER_WAVE; ++i) {
+        const int row = wid + 4 * i;
+        if (4 * i >= rows) break;                            // (uniform; rows <= 4 * SC_ROWS_PER_WAVE)
+        const int c = row / g.HR, hy = row - c * g.HR;       // wave-uniform
+        const int iy = iy0 + hy;
+        const bool rok = row < rows && iy >= 0 && iy < g.H;
+        const float* src = xb + ((size_t)(rok ? c : 0) * g.H + (rok ? iy : 0)) * g.W;
+        h.v0[i] = (rok && oka) ? src[ixa] : 0.0f;
+        h.v1[i] = (rok && okb) ? src[ixb] : 0.0f;
+    }
+}
+__device__ __forceinline__ void halo_store(const SmallGeom& g, float* __restrict__ Xh, int tid, const HaloRegs& h) {
+    const int lane = tid & 63, wid = tid >> 6;
+    const int rows = g.C * g.HR;
+#pragma unroll
+    for (int i = 0; i < SC_ROWS_PER_WAVE; ++i) {
+        const int row = wid + 4 * i;
+        if (4 * i >= rows) break;
+        if (row < rows) {
+            const int c = row / g.HR, hy = row - c * g.HR;
+            float* dst = Xh + c * g.plane + hy * g.HC;
+            dst[lane] = h.v0[i];
+            if (lane + 64 < g.HC) dst[lane + 64] = h.v1[i];
+        }
+    }
+}
+// load + store in one go (the weight-gradient kernel: its accumulators leave no room for a prefetched halo).  Global
+// loads are issued in batches of 12 rows before their LDS stores: two round trips of latency per tile instead of
+// one per row, at half the staging registers.
 __device__ __forceinline__ void stage_halo(const SmallGeom& g, const float* __restrict__ xb, int iy0, int ix0,
                                            float* __restrict__ Xh, int tid) {
     const int lane = tid & 63, wid = tid >> 6;
     const int rows = g.C * g.HR;
-    // global loads are issued in batches of 12 rows before their LDS stores: two round trips of latency per
-    // tile instead of one per row, at half the staging registers
     constexpr int HB = SC_ROWS_PER_WAVE / 2;
     const int ixa = ix0 + lane, ixb = ix0 + lane + 64;
     const bool oka = ixa >= 0 && ixa < g.W, okb = lane + 64 < g.HC && ixb >= 0 && ixb < g.W;
@@ -86,6 +124,7 @@ __device__ __forceinline__ int k_offset(const SmallGeom& g, int k) {
 // forward.  grid = (tiles_x, tiles_y, B); Wp is [Kp][16*MT] (packed, zero padded), MT = Co tiles of 16.
 // ---------------------------------------------------------------------------------------------
 constexpr int SC_NV = 8;   // vertical tiles per workgroup (amortises the per-workgroup weight / offset fetch)
+constexpr int SC_YLD = SC_TW + 4;   // row stride of the per-wave output staging tile (16-byte aligned rows)
 
 template <int MT>
 __global__ __launch_bounds__(IG_THREADS, 2) void smallc_fwd_kernel(SmallGeom g, const float* __restrict__ x,
@@ -101,26 +140,30 @@ __global__ __launch_bounds__(IG_THREADS, 2) void smallc_fwd_kernel(SmallGeom g, 
     const float* xb = x + (size_t)b * g.C * g.H * g.W;
     const int ksteps = g.Kp / 4;
 
-    // A fragments (weights) and halo offsets of this lane's k rows: constant for the whole kernel
-    float areg[MT][SC_MAXKS];
-    int koff[SC_MAXKS];
-#pragma unroll
-    for (int ks = 0; ks < SC_MAXKS; ++ks) {
-        if (ks < ksteps) {
-            const int k = ks * 4 + kq;
-            koff[ks] = koff_tab[k];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) areg[m][ks] = Wp[(size_t)k * (16 * MT) + m * 16 + il];
-        }
-    }
+    // A operand (weights) and the halo offset of every GEMM row k, constant for the whole kernel, live in LDS: in
+    // registers they took 80-120 VGPRs, which the halo prefetch below needs (one extra conflict-free LDS read per
+    // four MFMAs instead)
+    float* Ws = smem + g.C * g.plane + 16 + 4 * (16 * MT * SC_YLD);         // [Kp][16 * MT]
+    int* Ks = reinterpret_cast<int*>(Ws + g.Kp * 16 * MT);                  // [Kp]
+    for (int i = tid; i < g.Kp * 16 * MT; i += IG_THREADS) Ws[i] = Wp[i];
+    for (int i = tid; i < g.Kp; i += IG_THREADS) Ks[i] = koff_tab[i];
     const int HoWo = g.Ho * g.Wo;
+    // per-wave output staging tile [16 * MT][SC_YLD]: the accumulators have 16 consecutive pixels across lanes (64-byte
+    // runs per store); staged through LDS every lane writes four consecutive pixels and a wave instruction covers
+    // whole 256-byte rows
+    float* Ys = smem + g.C * g.plane + 16 + wid * (16 * MT * SC_YLD);
+    const bool vec = (g.Wo & 3) == 0;
+    HaloRegs halo;
+    halo_load(g, xb, (blockIdx.y * SC_NV) * SC_TH * g.s - g.ph, ox0 * g.s - g.pw, tid, halo);
 #pragma unroll 1
     for (int vt = 0; vt < SC_NV; ++vt) {
     const int oy0 = (blockIdx.y * SC_NV + vt) * SC_TH;
     if (oy0 >= g.Ho) break;
     __syncthreads();                                // the previous tile's fragment reads are done
-    stage_halo(g, xb, oy0 * g.s - g.ph, ox0 * g.s - g.pw, Xh, tid);
+    halo_store(g, Xh, tid, halo);
     __syncthreads();
+    if (vt + 1 < SC_NV && oy0 + SC_TH < g.Ho)       // next tile's halo: in flight under this tile's MFMAs
+        halo_load(g, xb, (oy0 + SC_TH) * g.s - g.ph, ox0 * g.s - g.pw, tid, halo);
 
     const int oy = oy0 + wid;                       // one output row per wave
     float* yb = y + (size_t)b * g.Co * HoWo + (size_t)oy * g.Wo;
@@ -132,19 +175,64 @@ __global__ __launch_bounds__(IG_THREADS, 2) void smallc_fwd_kernel(SmallGeom g, 
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int pt = 0; pt < NP; ++pt) acc[m][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // explicit two-deep software pipeline (the compiler emits read -> wait -> MFMA per step otherwise, and each
+        // step then pays two dependent LDS round trips: row offset, then operand): the operands of step ks + 1 and
+        // the row offset of step ks + 2 are read before the MFMAs of step ks issue
+        auto offs = [&](int ks) { return Ks[(ks < ksteps ? ks : ksteps - 1) * 4 + kq] + pbase0; };
+        auto frag = [&](int ks, int ko, float (&fa)[MT], float (&fb)[NP]) {
+            const int k = (ks < ksteps ? ks : ksteps - 1) * 4 + kq;
 #pragma unroll
-        for (int ks = 0; ks < SC_MAXKS; ++ks) {
-            if (ks < ksteps) {
-                float bv[NP];
+            for (int m = 0; m < MT; ++m) fa[m] = Ws[k * (16 * MT) + m * 16 + il];
 #pragma unroll
-                for (int pt = 0; pt < NP; ++pt) bv[pt] = Xh[koff[ks] + pbase0 + pt * 16 * g.s];
+            for (int pt = 0; pt < NP; ++pt) fb[pt] = Xh[ko + pt * 16 * g.s];
+        };
+        auto mma = [&](const float (&fa)[MT], const float (&fb)[NP]) {
 #pragma unroll
-                for (int pt = 0; pt < NP; ++pt)
+            for (int pt = 0; pt < NP; ++pt)
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
-                        acc[m][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[m][ks], bv[pt], acc[m][pt], 0, 0, 0);
-            }
+                for (int m = 0; m < MT; ++m)
+                    acc[m][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m], fb[pt], acc[m][pt], 0, 0, 0);
+        };
+        float a0[MT], b0[NP], a1[MT], b1[NP];
+        int ko0 = offs(0), ko1 = offs(1);
+        frag(0, ko0, a0, b0);
+        for (int ks = 0; ks < ksteps; ks += 2) {
+            ko0 = offs(ks + 2);
+            frag(ks + 1, ko1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            ko1 = offs(ks + 3);
+            frag(ks + 2, ko0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < ksteps) mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (vec) {
+#pragma unroll
+            for (int pt = 0; pt < NP; ++pt)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Ys[(m * 16 + kq * 4 + r) * SC_YLD + pt * 16 + il] = acc[m][pt][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // same wave: LDS operations complete in order
+            const int c4 = lane & 15, rsub = lane >> 4;
+            const int ox = ox0 + 4 * c4;
+#pragma unroll
+            for (int it = 0; it < 4 * MT; ++it) {
+                const int o = it * 4 + rsub;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Ys + o * SC_YLD + 4 * c4);
+                if (o < g.Co && ox < g.Wo) {
+                    if (bias) v += bias[o];
+                    if (act_slope >= 0.0f) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (v[e] < 0.0f) v[e] *= act_slope;
+                    }
+                    *reinterpret_cast<f32x4*>(yb + (size_t)o * HoWo + ox) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the next tile's staging
+        } else {
 #pragma unroll
         for (int pt = 0; pt < NP; ++pt) {
             const int ox = ox0 + pt * 16 + il;
@@ -162,6 +250,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void smallc_fwd_kernel(SmallGeom g, 
                         }
                     }
             }
+        }
         }
     }
     }
@@ -263,29 +352,35 @@ __global__ __launch_bounds__(IG_THREADS) void smallc_wgrad_kernel(SmallGeom g, c
         slab[e] = ((red[e] + red[slab_elems + e]) + red[2 * slab_elems + e]) + red[3 * slab_elems + e];
 }
 
-// gw[o][c][tap] = sum_z slabs[z][o][tap*C + c]; 4 waves x interleaved z (same scheme as slab_reduce_kernel)
-__global__ __launch_bounds__(256) void smallc_slab_reduce_kernel(const float* __restrict__ slabs,
-                                                                 float* __restrict__ gw, int Z, int Mp, int Kp16,
-                                                                 int Co, int C, int T) {
+// gw[o][c][tap] = sum_z slabs[z][o][tap*C + c] in two fixed-order stages (bit-reproducible): thousands of workgroup
+// slabs (one per tile column of 8 tiles) against a few thousand outputs -- one workgroup per 64 outputs walking all of
+// them took 0.35 ms; stage 1 spreads the slabs over SC_RED_GROUPS workgroups per 64 outputs, stage 2 adds the groups.
+constexpr int SC_RED_GROUPS = 64;
+__global__ __launch_bounds__(256) void smallc_slab_reduce1_kernel(const float* __restrict__ slabs,
+                                                                  float* __restrict__ partial, int Z, int slab_elems) {
     __shared__ float part[4][64];
-    const int K = T * C;
-    const long long total = (long long)Co * K;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long long i = (long long)blockIdx.x * 64 + lane;
+    const int e = blockIdx.x * 64 + lane, grp = blockIdx.y;
+    const int per = (Z + SC_RED_GROUPS - 1) / SC_RED_GROUPS;
+    const int z0 = grp * per, z1 = min(Z, z0 + per);
     float s = 0.0f;
-    int o = 0, k = 0;
-    if (i < total) {
-        o = (int)(i / K);
-        k = (int)(i - (long long)o * K);
-        const size_t off = (size_t)o * Kp16 + k;
-        for (int z = w; z < Z; z += 4) s += slabs[(size_t)z * Mp * Kp16 + off];
-    }
+    if (e < slab_elems)
+        for (int z = z0 + w; z < z1; z += 4) s += slabs[(size_t)z * slab_elems + e];
     part[w][lane] = s;
     __syncthreads();
-    if (w == 0 && i < total) {
-        const int tap = k / C, c = k - tap * C;
-        gw[((size_t)o * C + c) * T + tap] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-    }
+    if (w == 0 && e < slab_elems)
+        partial[(size_t)grp * slab_elems + e] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+__global__ void smallc_slab_reduce2_kernel(const float* __restrict__ partial, float* __restrict__ gw, int slab_elems,
+                                           int Kp16, int Co, int C, int T) {
+    const int K = T * C;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Co * K) return;
+    const int o = i / K, k = i - o * K;
+    float s = 0.0f;
+    for (int g = 0; g < SC_RED_GROUPS; ++g) s += partial[(size_t)g * slab_elems + (size_t)o * Kp16 + k];
+    const int tap = k / C, c = k - tap * C;
+    gw[((size_t)o * C + c) * T + tap] = s;
 }
 
 // Wp[k = tap*C + c][m] = W[m][c][tap]  (forward)  or, for the stride-1 input gradient computed as a
@@ -336,7 +431,8 @@ size_t smallc_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw
     fill_small(g, B, C, H, W, Co, kh, kw, s, ph, pw);
     const int mt = (Co + 15) / 16, Kp16 = (g.K + 15) / 16 * 16;
     const size_t tiles = (size_t)ceil_div(g.Wo, SC_TW) * ceil_div(g.Ho, SC_TH * SC_NV) * B;
-    return carve_bytes((size_t)g.Kp * 16 * mt, 4) + carve_bytes(SC_MAXK, 4) + carve_bytes(tiles * 16 * mt * Kp16, 4) + 512;
+    return carve_bytes((size_t)g.Kp * 16 * mt, 4) + carve_bytes(SC_MAXK, 4) + carve_bytes(tiles * 16 * mt * Kp16, 4) +
+           carve_bytes((size_t)SC_RED_GROUPS * 16 * mt * Kp16, 4) + 512;
 }
 
 int smallc_forward(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W, int Co,
@@ -358,7 +454,8 @@ int smallc_forward(const float* x, const float* w, const float* bias, float* y, 
     else
         hipLaunchKernelGGL(smallc_pack_kernel, dim3(32), dim3(256), 0, st, w, Wp, /*Co_orig=*/C, /*C_orig=*/Co,
                            kh * kw, g.Kp, 16 * mt, 1);
-    const size_t lds = (size_t)(g.C * g.plane + 16) * sizeof(float);
+    // halo image + 4 staging tiles + weights [Kp][16 mt] + row offsets [Kp]
+    const size_t lds = (size_t)(g.C * g.plane + 16 + 4 * 16 * mt * SC_YLD + g.Kp * 16 * mt + g.Kp) * sizeof(float);
     const dim3 grid(ceil_div(g.Wo, SC_TW), ceil_div(g.Ho, SC_TH * SC_NV), B);
     ProfScope prof(st);
     prof.name("smallc_fwd_kernel<%d>", mt);
@@ -380,6 +477,7 @@ int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, in
     (void)cv.take<float>((size_t)g.Kp * 16 * mt);
     int* koff = cv.take<int>(SC_MAXK);
     float* slabs = cv.take<float>(tiles * 16 * mt * Kp16);
+    float* partial = cv.take<float>((size_t)SC_RED_GROUPS * 16 * mt * Kp16);
     CNUDA_REQUIRE(cv.ok(), "smallc_backward_weight: workspace too small");
     hipLaunchKernelGGL(smallc_koff_kernel, dim3(1), dim3(SC_MAXK), 0, st, g, koff, SC_MAXK);
     const size_t stage = (size_t)(g.C * g.plane + 16) + (size_t)16 * mt * (SC_TH * SC_TW + 1);
@@ -402,9 +500,11 @@ int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, in
             hipLaunchKernelGGL(smallc_wgrad_kernel<2>, grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16);
     }
     if (int rc = check_launch("smallc_backward_weight")) return rc;
-    const long long total = (long long)Co * g.K;
-    hipLaunchKernelGGL(smallc_slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, slabs, gw,
-                       (int)tiles, 16 * mt, Kp16, Co, C, kh * kw);
+    const int slab_elems = 16 * mt * Kp16;
+    hipLaunchKernelGGL(smallc_slab_reduce1_kernel, dim3((slab_elems + 63) / 64, SC_RED_GROUPS), dim3(256), 0, st, slabs,
+                       partial, (int)tiles, slab_elems);
+    hipLaunchKernelGGL(smallc_slab_reduce2_kernel, dim3((Co * g.K + 255) / 256), dim3(256), 0, st, partial, gw, slab_elems,
+                       Kp16, Co, C, kh * kw);
     return check_launch("smallc_backward_weight(reduce)");
 }
 

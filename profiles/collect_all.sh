@@ -1,0 +1,18 @@
+# Everything the round's profile set is made of, in one gpurun call:
+#   gpurun --timeout 2400 -- 'bash profiles/collect_all.sh r2'
+# -> gpurun_out/<tag>_bench_line.json, <tag>_bench_kernel_stats.csv, <tag>_pmc_traffic.json, <tag>_pmc_mfma.{json,md},
+#    <tag>_bench_configs.jsonl   (copy them to profiles/ and run profiles/make_summary.py <tag>)
+TAG=${1:-rX}
+R=$GRAFT_REPO_ROOT
+python3 $R/bench.py > $R/gpurun_out/${TAG}_bench_line.json 2> $R/gpurun_out/${TAG}_bench_line.err
+tail -c 300 $R/gpurun_out/${TAG}_bench_line.json
+bash $R/profiles/collect_kernel_stats.sh > $R/gpurun_out/${TAG}_kernel_stats.txt 2>&1
+cp $(ls -t $R/gpurun_out/prof_tmp/*/*kernel_stats.csv | head -1) $R/gpurun_out/${TAG}_bench_kernel_stats.csv
+head -12 $R/gpurun_out/${TAG}_kernel_stats.txt
+bash $R/profiles/collect_pmc_traffic.sh > $R/gpurun_out/${TAG}_pmc_traffic.txt 2>&1
+cp $R/gpurun_out/pmc_traffic.json $R/gpurun_out/${TAG}_pmc_traffic.json
+head -12 $R/gpurun_out/${TAG}_pmc_traffic.txt
+bash $R/profiles/collect_pmc_mfma.sh > $R/gpurun_out/${TAG}_pmc_mfma.txt 2>&1
+cp $R/gpurun_out/pmc_mfma.json $R/gpurun_out/${TAG}_pmc_mfma.json; cp $R/gpurun_out/pmc_mfma.md $R/gpurun_out/${TAG}_pmc_mfma.md
+head -12 $R/gpurun_out/${TAG}_pmc_mfma.txt
+bash $R/profiles/collect_config_lines.sh $TAG
