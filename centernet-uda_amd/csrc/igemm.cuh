@@ -475,32 +475,47 @@ __global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd
         const int nl = tid & (IG_BN - 1), ksub = tid >> 7;
         Loader ld(p, n0 + nl, n0 + nl < N);
         if constexpr (Loader::kHasSideOutput) { if (m0 != 0) ld.disable_col(); }
-        f32x4 ra[ig_a_per<BM>()];
-        float rb[8];
-        typename IgRaw<Loader, Loader::kHasSideOutput>::type raw;
-        auto stage_store = [&](int buf) {
-            ig_store_a<BM>(As[buf], tid, ra);
-            if constexpr (Loader::kHasSideOutput) ld.finish(raw, rb);
+        // TWO register stages: the global loads of a chunk are issued two chunks before they are stored to LDS (the
+        // producers' registers are free -- the kernel's allocation is set by the consumers' accumulators), so a load
+        // may take two chunks of MFMA time under a busy memory system before anybody waits for it
+        static_assert(!Loader::kHasSideOutput, "two-phase loaders keep per-chunk state (the current tap's weights): one chunk in flight only");
+        struct Regs {
+            f32x4 ra[ig_a_per<BM>()];
+            float rb[8];
+            typename IgRaw<Loader, Loader::kHasSideOutput>::type raw;
+        };
+        Regs r0, r1;
+        auto stage_store = [&](int buf, Regs& r) {
+            ig_store_a<BM>(As[buf], tid, r.ra);
+            if constexpr (Loader::kHasSideOutput) ld.finish(r.raw, r.rb);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Bs[buf][(ksub + 2 * j) * IG_BN + nl] = rb[j];
+            for (int j = 0; j < 8; ++j) Bs[buf][(ksub + 2 * j) * IG_BN + nl] = r.rb[j];
         };
-        auto stage_load = [&](int k0) {
-            ig_load_a<BM>(A, Mp, k0, m0, tid, ra);
-            if constexpr (Loader::kHasSideOutput) ld.load_raw(k0, ksub, raw);
-            else ld.load(k0, ksub, rb);
+        auto stage_load = [&](int k0, Regs& r) {
+            ig_load_a<BM>(A, Mp, k0, m0, tid, r.ra);
+            if constexpr (Loader::kHasSideOutput) ld.load_raw(k0, ksub, r.raw);
+            else ld.load(k0, ksub, r.rb);
         };
-        stage_load(0);
-        stage_store(0);
-        if (IG_KC < Kp) stage_load(IG_KC);
+        stage_load(0, r0);
+        stage_store(0, r0);
+        if (IG_KC < Kp) stage_load(IG_KC, r1);
+        if (2 * IG_KC < Kp) stage_load(2 * IG_KC, r0);
         __syncthreads();
         int cur = 0;
-        for (int k0 = 0; k0 < Kp; k0 += IG_KC) {
+        for (int k0 = 0; k0 < Kp; k0 += 2 * IG_KC) {
+            // chunk k0: consumers read stage `cur`; chunk k0 + KC (in r1) goes to the other stage, r1 is refilled
             if (k0 + IG_KC < Kp) {
-                stage_store(cur ^ 1);
-                if (k0 + 2 * IG_KC < Kp) stage_load(k0 + 2 * IG_KC);
+                stage_store(cur ^ 1, r1);
+                if (k0 + 3 * IG_KC < Kp) stage_load(k0 + 3 * IG_KC, r1);
             }
             __syncthreads();
-            cur ^= 1;
+            if (k0 + IG_KC >= Kp) break;
+            // chunk k0 + KC: consumers read stage `cur ^ 1`; chunk k0 + 2 KC (in r0) goes to stage `cur`
+            if (k0 + 2 * IG_KC < Kp) {
+                stage_store(cur, r0);
+                if (k0 + 4 * IG_KC < Kp) stage_load(k0 + 4 * IG_KC, r0);
+            }
+            __syncthreads();
         }
         return;
     }
