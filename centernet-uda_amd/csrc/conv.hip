@@ -422,12 +422,15 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     // neutral on the 64-channel ones, -2-4 % on the 32-row tile, which therefore keeps the 4-wave kernel
     if (wave_specialised() && bm >= 64) {
         const dim3 block2(2 * IG_THREADS);
-        if (bm == 128)
-            hipLaunchKernelGGL((igemm_fwd_ws_kernel<128, Loader>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
-        else if (bm == 64)
-            hipLaunchKernelGGL((igemm_fwd_ws_kernel<64, Loader>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        static const bool deep = !(getenv("CNUDA_FWD_DEEP") && getenv("CNUDA_FWD_DEEP")[0] == '0');
+        if (bm == 128 && deep)
+            hipLaunchKernelGGL((igemm_fwd_ws_kernel<128, Loader, true>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        else if (bm == 128)
+            hipLaunchKernelGGL((igemm_fwd_ws_kernel<128, Loader, false>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        else if (deep)
+            hipLaunchKernelGGL((igemm_fwd_ws_kernel<64, Loader, true>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         else
-            hipLaunchKernelGGL((igemm_fwd_ws_kernel<32, Loader>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+            hipLaunchKernelGGL((igemm_fwd_ws_kernel<64, Loader, false>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         return check_launch(who);
     }
     if (bm == 128)

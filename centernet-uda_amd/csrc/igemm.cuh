@@ -456,7 +456,7 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void ig
 // stages, one barrier per chunk (all 8 waves); the two roles never hold registers at the same time, so the
 // kernel needs fewer registers than the 4-wave one (78 vs 113 for the 128-row tile).
 // ---------------------------------------------------------------------------
-template <int BM, class Loader>
+template <int BM, class Loader, bool DEEP = true>
 __global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd_ws_kernel(
     typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
     int n_tiles, int m_tiles) {
@@ -498,6 +498,20 @@ __global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd
         };
         stage_load(0, r0);
         stage_store(0, r0);
+        if (!DEEP) {                                   // one register stage (A/B measurements)
+            if (IG_KC < Kp) stage_load(IG_KC, r0);
+            __syncthreads();
+            int c1 = 0;
+            for (int k0 = 0; k0 < Kp; k0 += IG_KC) {
+                if (k0 + IG_KC < Kp) {
+                    stage_store(c1 ^ 1, r0);
+                    if (k0 + 2 * IG_KC < Kp) stage_load(k0 + 2 * IG_KC, r0);
+                }
+                __syncthreads();
+                c1 ^= 1;
+            }
+            return;
+        }
         if (IG_KC < Kp) stage_load(IG_KC, r1);
         if (2 * IG_KC < Kp) stage_load(2 * IG_KC, r0);
         __syncthreads();
