@@ -1,60 +1,97 @@
 #!/usr/bin/env python3
-"""Writes profiles/r1_final_summary.md from the committed artefacts of the final measurement:
-r1_final_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of collect_kernel_stats.sh, 10 steps),
-r1_final_bench_line.json (python bench.py) and r1_pmc_traffic.json (collect_pmc_traffic.sh)."""
+"""Writes profiles/<tag>_final_summary.md from the committed artefacts of a round's final measurement
+(`profiles/collect_all.sh <tag>`, copied from gpurun_out/ into profiles/):
+<tag>_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of collect_kernel_stats.sh, 10 steps),
+<tag>_bench_line.json (python bench.py), <tag>_pmc_traffic.json, <tag>_pmc_mfma.md, <tag>_bench_configs.jsonl.
+
+    python profiles/make_summary.py r2          # round 1's files carry the prefix r1_final_ / r1_"""
 import csv
 import json
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-rows = list(csv.DictReader(open(os.path.join(HERE, 'r1_final_bench_kernel_stats.csv'))))
-line = json.load(open(os.path.join(HERE, 'r1_final_bench_line.json')))
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r2'
+ROUND = TAG.lstrip('r')
+
+
+def path(stem, *alts):
+    for s in (stem,) + alts:
+        p = os.path.join(HERE, s)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+rows = list(csv.DictReader(open(path('%s_bench_kernel_stats.csv' % TAG, '%s_final_bench_kernel_stats.csv' % TAG))))
+line = json.load(open(path('%s_bench_line.json' % TAG, '%s_final_bench_line.json' % TAG)))
 STEPS = 10
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 short = lambda n: n.replace('cnuda::(anonymous namespace)::', '').replace('cnuda::', '').replace('void ', '').split('(')[0]
 rf = line['roofline']
 out = []
-out.append('# r1 final -- state at the end of round 1\n')
+out.append('# %s final -- state at the end of round %s\n' % (TAG, ROUND))
 out.append('Command (MI355X box): `profiles/collect_kernel_stats.sh` = `rocprofv3 --kernel-trace --stats --output-format csv -- '
            'python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --profile-steps 0`\n'
            '(%d steps in the trace; DLA-34 + 16 DCNv2, 512x512, 16 source + 16 target images, fp32 (matrix mode 0), entropy '
            'minimisation; `--no-extras` leaves the decode / inference / split-mode legs out of the trace). Kernel names carry the '
            'template default `, false` = f32-MFMA variant.\n' % STEPS)
 out.append('Total kernel time %.1f ms = **%.1f ms/step** under the profiler; un-profiled wall time %.2f ms/step = %.1f source '
-           'images/s (`r1_final_bench_line.json`). The step is GPU-bound (kernel time = wall time).\n'
-           % (tot / 1e6, tot / 1e6 / STEPS, line['ms_per_step'], line['value']))
-out.append('First correct path (`r1a_*`): 388.8 ms/step, 41.3 img/s.\n')
+           'images/s (`%s_bench_line.json`). The step is GPU-bound (kernel time = wall time).\n'
+           % (tot / 1e6, tot / 1e6 / STEPS, line['ms_per_step'], line['value'], TAG))
+if TAG == 'r1':
+    out.append('First correct path (`r1a_*`): 388.8 ms/step, 41.3 img/s.\n')
+else:
+    out.append('End of round 1 (`r1_final_*`): 110.8 ms/step, 144.4 img/s.\n')
 out.append('| kernel | launches/step | ms/step | avg us | % |\n|---|---|---|---|---|')
-for r in rows[:44]:
+for r in rows[:48]:
     out.append('| `%s` | %d | %.2f | %.1f | %.1f |' % (short(r['Name'])[:92], int(r['Calls']) // STEPS,
                                                      float(r['TotalDurationNs']) / 1e6 / STEPS, float(r['AverageNs']) / 1e3,
                                                      100 * float(r['TotalDurationNs']) / tot))
 out.append('')
+out.append('Launches per step: %d.\n' % (sum(int(r['Calls']) for r in rows) // STEPS))
 out.append('Dominant kernel `%s`: avg launch %.4f ms (in-library hipEvents; rocprofv3 above), %.2f algorithmic GFLOP per launch '
            '=> %.1f TFLOP/s = %.1f %% of the %.1f TFLOP/s fp32 MFMA peak; HBM traffic %.0f MB per launch from the PMC passes '
-           '(`r1_pmc_traffic.json`, `profiles/collect_pmc_traffic.sh`: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs, KB per '
+           '(`%s_pmc_traffic.json`, `profiles/collect_pmc_traffic.sh`: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs, KB per '
            'launch, FETCH uncorrected).\n' % (rf['kernel'], rf['avg_launch_ms'], rf['algorithmic_gflop_per_launch'], rf['achieved'],
-                                              100 * rf['frac'], rf['peak'], (rf['traffic'] or 0) / 1e6))
+                                              100 * rf['frac'], rf['peak'], (rf['traffic'] or 0) / 1e6, TAG))
 hb = rf.get('hbm_kernels') or {}
 if hb:
     out.append('HBM-streaming kernels of the DCN backward (algorithmic bytes / time): ' +
                ', '.join('`%s` %.2f ms/step at %.0f GB/s' % (k, v['ms_per_step'], v['gb_per_s']) for k, v in hb.items()) + '.\n')
 d = line.get('decode_latency')
 if d:
-    out.append('Decode (B=16, K=150, 128x128): C=6 %.1f us, C=80 %.1f us (CPU oracle %.0f us). Inference wrapper: %.0f img/s '
-               '(%.2f ms per batch of 16).\n' % (d['C6']['us'], d['C80']['us'], d['C6'].get('cpu_port_us', 0),
-                                                 line['inference']['images_per_s'], line['inference']['ms_per_batch']))
+    parts = []
+    for k, v in d.items():
+        if isinstance(v, dict) and 'us' in v:
+            parts.append('%s %.1f us' % (k, v['us']) + (' (CPU oracle %.0f us)' % v['cpu_port_us'] if v.get('cpu_port_us') else ''))
+    out.append('Decode (B=16, K=150): ' + ', '.join(parts) + '.\n')
+i = line.get('inference')
+if i:
+    out.append('Inference wrapper (`export.CenterNet`, BatchNorm folded): %.0f img/s (%.2f ms per batch of 16).\n'
+               % (i['images_per_s'], i['ms_per_batch']))
 s = line.get('matrix_mode_split')
 if s:
     out.append('Split-operand matrix mode (opt-in, DESIGN.md 4a), same step: %.1f ms = %.1f img/s.\n' % (s['ms_per_step'], s['value']))
 c = line.get('cpu_baseline')
 if c:
-    out.append('CPU baseline (`kind: %s`): %.4f img/s on %d host threads (%s).\n' % (c['kind'], c['value'], c['cores'], c['sample'][:110]))
-m = os.path.join(HERE, 'r1_pmc_mfma.md')
-if os.path.exists(m):
+    out.append('CPU baseline (`kind: %s`): %.4f img/s on %d host threads (%s).\n' % (c['kind'], c['value'], c['cores'], c['sample'][:160]))
+cfgs = path('%s_bench_configs.jsonl' % TAG)
+if cfgs:
+    out.append('Other BASELINE.json configs (`profiles/collect_config_lines.sh`, one `bench.py --config i` line each):\n')
+    out.append('| workload | ms/step | img/s |\n|---|---|---|')
+    for ln in open(cfgs):
+        ln = ln.strip()
+        if not ln.startswith('{'):
+            continue
+        j = json.loads(ln)
+        out.append('| %s | %.2f | %.1f |' % (j['config']['workload'][:120], j['ms_per_step'], j['value']))
+    out.append('')
+m = path('%s_pmc_mfma.md' % TAG)
+if m:
     out.append('MFMA-pipe utilisation per kernel from PMC (`profiles/collect_pmc_mfma.sh`: `--pmc SQ_VALU_MFMA_BUSY_CYCLES '
                'GRBM_GUI_ACTIVE` over two steps; busy cycles / (1024 SIMDs x active cycles per XCD), i.e. against the clock the '
                'chip actually held):\n')
     out.append(open(m).read())
-open(os.path.join(HERE, 'r1_final_summary.md'), 'w').write('\n'.join(out))
+open(os.path.join(HERE, '%s_final_summary.md' % TAG), 'w').write('\n'.join(out))
 print('\n'.join(out[:8]))

@@ -56,7 +56,10 @@ def test_centernet_wrapper_with_keypoint_head():
     with torch.no_grad():
         out = backend(x)
     assert out['kps'].shape == (2, 10, 16, 16)
-    hm = np.clip(1.0 / (1.0 + np.exp(-out['hm'].double().cpu().numpy())), 1e-4, 1 - 1e-4).astype(np.float32)
+    # a random-init backend scores every cell ~0.505: neighbouring candidates are 1 ulp apart, so the oracle gets the
+    # very float32 heat map the wrapper decoded (the sigmoid kernel has its own test) -- the ranking is then bit-exact
+    from hip_runtime import ops
+    hm = ops.sigmoid_clamp_(out['hm'].clone()).cpu().numpy()
     want, want_kps = oracle_decode.decode_detection(hm, out['wh'].cpu().numpy(), out['reg'].cpu().numpy(), K=K,
                                                     kps=out['kps'].cpu().numpy())
     np.testing.assert_array_equal(classes.cpu().numpy(), want[:, :, 5])
