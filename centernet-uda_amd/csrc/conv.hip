@@ -113,6 +113,57 @@ struct ConvFwdLoader {
     };
 };
 
+// The same gather for C % 16 == 0 with buffer addressing (igemm.cuh): per thread one byte offset of the window's
+// corner and a bit per tap that says whether the tap lies inside the image, both computed once per tile; per chunk
+// one add and one select, and the eight channel loads differ by a scalar offset only.  Needs the tensor below
+// 2 GiB and at most 32 taps (the host checks; otherwise ConvFwdLoader<true>).
+struct ConvFwdBufLoader {
+    using Params = ConvFwdParams;
+    static const char* name() { return "ConvFwdBufLoader"; }
+    static constexpr bool kHasSideOutput = false;
+    const ConvGeom& g;
+    buf_rsrc rs;
+    unsigned pix_off;      // byte offset of x[b][0][iy0][ix0] (may lie outside the image: only used with an in-range tap)
+    unsigned tap_ok;       // bit (r * kw + s): tap inside the image for this pixel
+    int ck0 = 0, ctap = 0, cc0 = 0, cr = 0, cs = 0;      // chunk cursor (wave-uniform), see ConvFwdLoader::seek
+    __device__ __forceinline__ void seek(int k0) {
+        while (ck0 < k0) {
+            ck0 += IG_BK;
+            cc0 += IG_BK;
+            if (cc0 >= g.C) { cc0 -= g.C; ++ctap; if (++cs == g.kw) { cs = 0; ++cr; } }
+        }
+    }
+    __device__ ConvFwdBufLoader(const Params& p, long long n, bool n_valid) : g(p.g) {
+        const int HoWo = g.Ho * g.Wo;
+        const int nn = n_valid ? (int)n : 0;
+        const int b = nn / HoWo, pp = nn - b * HoWo;
+        const int oy = pp / g.Wo, ox = pp - oy * g.Wo;
+        const int iy0 = oy * g.sh - g.ph, ix0 = ox * g.sw - g.pw;
+        rs = ig_make_rsrc(p.x, (unsigned)((size_t)g.B * g.C * g.H * g.W * sizeof(float)));
+        pix_off = (unsigned)(((b * g.C * g.H + iy0) * g.W + ix0) * (int)sizeof(float));
+        tap_ok = 0;
+        if (n_valid) {
+            for (int r = 0; r < g.kh; ++r)
+                for (int s = 0; s < g.kw; ++s) {
+                    const int iy = iy0 + r, ix = ix0 + s;
+                    if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) tap_ok |= 1u << (r * g.kw + s);
+                }
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
+        const int HW = g.H * g.W;
+        seek(k0);
+        const int tap = ctap < 32 ? ctap : 31;                               // (k0 >= K: every lane reads the sentinel)
+        const bool in_k = k0 < g.kh * g.kw * g.C;
+        const unsigned voff = (in_k && ((tap_ok >> tap) & 1u)) ? pix_off + (unsigned)((cr * g.W + cs) * (int)sizeof(float))
+                                                                : IG_BUF_OOB;
+        const int c0 = cc0 + __builtin_amdgcn_readfirstlane(ksub);          // ksub = tid >> 7 is wave-uniform
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ig_buf_load(rs, voff, (unsigned)((c0 + 2 * j) * HW) * (unsigned)sizeof(float));
+    }
+    using Out = ConvFwdLoader<true>::Out;
+};
+
 // Input gradient: gx[b][c][iy][ix] = sum_{tap,o} W[o][c][tap] * gy[b][o][(iy+ph-r)/sh][(ix+pw-s)/sw]
 // (terms exist only where the divisions are exact and land inside the output).
 struct ConvDgradParams {
@@ -189,6 +240,57 @@ struct ConvDgradLoader {
     };
 };
 
+// The stride-1 input gradient with buffer addressing (see ConvFwdBufLoader): window corner offset + one bit per tap,
+// computed once per tile; padded output-channel rows (zero weights) read channel Co-1, a scalar clamp.
+struct ConvDgradBufLoader {
+    using Params = ConvDgradParams;
+    static const char* name() { return "ConvDgradBufLoader"; }
+    static constexpr bool kHasSideOutput = false;
+    const ConvGeom& g;
+    buf_rsrc rs;
+    unsigned pix_off, tap_ok;
+    int cop;
+    int ck0 = 0, ctap = 0, co0 = 0, cr = 0, cs = 0;
+    __device__ __forceinline__ void seek(int k0) {
+        while (ck0 < k0) {
+            ck0 += IG_BK;
+            co0 += IG_BK;
+            if (co0 >= cop) { co0 -= cop; ++ctap; if (++cs == g.kw) { cs = 0; ++cr; } }
+        }
+    }
+    __device__ ConvDgradBufLoader(const Params& p, long long n, bool n_valid) : g(p.g), cop(p.cop) {
+        const int HW = g.H * g.W;
+        const int nn = n_valid ? (int)n : 0;
+        const int b = nn / HW, pp = nn - b * HW;
+        const int iy = pp / g.W, ix = pp - iy * g.W;
+        rs = ig_make_rsrc(p.gy, (unsigned)((size_t)g.B * g.Co * g.Ho * g.Wo * sizeof(float)));
+        pix_off = (unsigned)(((b * g.Co * g.Ho + iy + g.ph) * g.Wo + ix + g.pw) * (int)sizeof(float));
+        tap_ok = 0;
+        if (n_valid) {
+            for (int r = 0; r < g.kh; ++r)
+                for (int s = 0; s < g.kw; ++s) {
+                    const int ty = iy + g.ph - r, tx = ix + g.pw - s;
+                    if (ty >= 0 && ty < g.Ho && tx >= 0 && tx < g.Wo) tap_ok |= 1u << (r * g.kw + s);
+                }
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
+        const int HoWo = g.Ho * g.Wo;
+        seek(k0);
+        const int tap = ctap < 32 ? ctap : 31;
+        const bool in_k = k0 < g.kh * g.kw * cop;
+        const unsigned voff = (in_k && ((tap_ok >> tap) & 1u)) ? pix_off - (unsigned)((cr * g.Wo + cs) * (int)sizeof(float))
+                                                                : IG_BUF_OOB;
+        const int o0 = co0 + __builtin_amdgcn_readfirstlane(ksub);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = o0 + 2 * j < g.Co ? o0 + 2 * j : g.Co - 1;
+            v[j] = ig_buf_load(rs, voff, (unsigned)(o * HoWo) * (unsigned)sizeof(float));
+        }
+    }
+    using Out = ConvDgradLoader::Out;
+};
+
 // Input gradient for stride > 1, one launch per parity class (py, px) of the input pixel: inside a class
 // the set of taps that can reach an output pixel is the same for every pixel ((iy + ph - r) % sh == 0), so
 // the K axis only holds those taps (1 + 2 + 2 + 4 of 9 for 3x3 / stride 2 instead of 9 each -> 4x less work
@@ -199,6 +301,7 @@ struct ConvDgradClassParams {
     float* gx;
     int py, px, Hc, Wc, ntaps;
     int tap_r[9], tap_s[9];     // kernel coordinates of the class's taps, in packed-K order
+    int tap_dy[9], tap_dx[9];   // (py + ph - r) / sh, (px + pw - s) / sw: output pixel of tap t = (qy + dy, qx + dx)
 };
 struct ConvDgradClassLoader {
     using Params = ConvDgradClassParams;
@@ -249,6 +352,51 @@ struct ConvDgradClassLoader {
         __device__ static bool vec4_ok(const Params&) { return false; }
         __device__ __forceinline__ void store4(const Params&, int, f32x4) {}
     };
+};
+
+// The parity-class gather with buffer addressing: output pixel of tap t = (qy + dy_t, qx + dx_t) with
+// dy_t = (py + ph - r_t) / sh exact, the same for every pixel of the class -- a per-thread base plus a scalar.
+struct ConvDgradClassBufLoader {
+    using Params = ConvDgradClassParams;
+    static const char* name() { return "ConvDgradClassBufLoader"; }
+    static constexpr bool kHasSideOutput = false;
+    const Params& p;
+    buf_rsrc rs;
+    unsigned pix_off, tap_ok;
+    int ck0 = 0, cti = 0, co0 = 0;      // chunk cursor: tap index in the class's list, first output channel
+    __device__ ConvDgradClassBufLoader(const Params& pp, long long n, bool n_valid) : p(pp) {
+        const ConvGeom& g = p.g;
+        const int HcWc = p.Hc * p.Wc;
+        const int nn = n_valid ? (int)n : 0;
+        const int b = nn / HcWc, q = nn - b * HcWc;
+        const int qy = q / p.Wc, qx = q - qy * p.Wc;
+        rs = ig_make_rsrc(p.gy, (unsigned)((size_t)g.B * g.Co * g.Ho * g.Wo * sizeof(float)));
+        pix_off = (unsigned)(((b * g.Co * g.Ho + qy) * g.Wo + qx) * (int)sizeof(float));
+        tap_ok = 0;
+        if (n_valid) {
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int oy = qy + p.tap_dy[t], ox = qx + p.tap_dx[t];
+                if (oy >= 0 && oy < g.Ho && ox >= 0 && ox < g.Wo) tap_ok |= 1u << t;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
+        const ConvGeom& g = p.g;
+        const int HoWo = g.Ho * g.Wo;
+        while (ck0 < k0) {                                   // Co % 16 == 0 (host): one tap per chunk
+            ck0 += IG_BK;
+            co0 += IG_BK;
+            if (co0 >= g.Co) { co0 -= g.Co; ++cti; }
+        }
+        const int ti = cti < p.ntaps ? cti : 0;            // past the last tap: K padding, every lane reads the sentinel
+        const int tapoff = p.tap_dy[ti] * g.Wo + p.tap_dx[ti];
+        const unsigned voff = (cti < p.ntaps && ((tap_ok >> ti) & 1u)) ? pix_off + (unsigned)(tapoff * (int)sizeof(float))
+                                                                        : IG_BUF_OOB;
+        const int o0 = co0 + __builtin_amdgcn_readfirstlane(ksub);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ig_buf_load(rs, voff, (unsigned)((o0 + 2 * j) * HoWo) * (unsigned)sizeof(float));
+    }
+    using Out = ConvDgradClassLoader::Out;
 };
 
 // Weight gradient: gw[o][(tap,c)] = sum_{b,p} gy[b][o][p] * x[b][c][window(p, tap)]
@@ -394,6 +542,12 @@ ConvPlan make_plan(const ConvGeom& g) {
     return q;
 }
 
+// CNUDA_BUF=0: the pointer-addressed loaders (A/B measurements; tensors of 2 GiB and more always take them)
+bool buffer_addressing() {
+    static const bool on = !(getenv("CNUDA_BUF") && getenv("CNUDA_BUF")[0] == '0');
+    return on;
+}
+
 template <class Loader>
 int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp, int Kp, int M, long long N,
                hipStream_t st, const char* who) {
@@ -423,6 +577,14 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     if (wave_specialised() && bm >= 64) {
         const dim3 block2(2 * IG_THREADS);
         static const bool deep = !(getenv("CNUDA_FWD_DEEP") && getenv("CNUDA_FWD_DEEP")[0] == '0');
+        static const bool kc32 = getenv("CNUDA_FWD_KC") && atoi(getenv("CNUDA_FWD_KC")) == 32;
+        if (kc32 && Kp % 32 == 0) {                    // 32-deep chunks: half the barriers (A/B measurements)
+            if (bm == 128)
+                hipLaunchKernelGGL((igemm_fwd_ws_kernel<128, Loader, true, 32>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+            else
+                hipLaunchKernelGGL((igemm_fwd_ws_kernel<64, Loader, true, 32>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+            return check_launch(who);
+        }
         if (bm == 128 && deep)
             hipLaunchKernelGGL((igemm_fwd_ws_kernel<128, Loader, true>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         else if (bm == 128)
@@ -487,6 +649,8 @@ extern "C" int cnuda_conv2d_forward_res(const float* x, const float* weight, con
     const float* A = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),
                                  ig_a_bytes(q.Kpf, q.Mpf), Cout, C, q.T, PACK_FWD, q.Kpf, q.Mpf, 0, st);
     ConvFwdParams p{g, x, bias, y, act_slope, residual};
+    if (C % IG_BK == 0 && buffer_addressing() && q.T <= 32 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB)
+        return launch_fwd<ConvFwdBufLoader>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
     if (C % IG_BK == 0)
         return launch_fwd<ConvFwdLoader<true>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
     return launch_fwd<ConvFwdLoader<false>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
@@ -506,6 +670,7 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
     float* Aws = reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpd, q.Mpd)));
+    const bool buf_ok = buffer_addressing() && q.T <= 32 && (size_t)B * Cout * g.Ho * g.Wo * sizeof(float) < IG_BUF_OOB;
     if ((sh > 1 || sw > 1) && H % sh == 0 && W % sw == 0 && Cout % IG_BK == 0 &&
         ceil_div(kh, sh) * ceil_div(kw, sw) <= 9) {   // taps one class can see (tap_r/tap_s hold 9)
         // one launch per parity class, K restricted to the taps that class can see
@@ -522,7 +687,9 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
                         // (iy + ph - r) must be a multiple of sh for every iy = py + sh*qy: decided by py alone
                         // (C++ % keeps the dividend's sign; zero is zero either way)
                         if ((py + ph - r) % sh == 0 && (px + pw - t) % sw == 0) {
-                            cp.tap_r[cp.ntaps] = r; cp.tap_s[cp.ntaps] = t; taps[cp.ntaps] = r * kw + t; ++cp.ntaps;
+                            cp.tap_r[cp.ntaps] = r; cp.tap_s[cp.ntaps] = t; taps[cp.ntaps] = r * kw + t;
+                            cp.tap_dy[cp.ntaps] = (py + ph - r) / sh; cp.tap_dx[cp.ntaps] = (px + pw - t) / sw;
+                            ++cp.ntaps;
                         }
                 const long long Nc = (long long)B * cp.Hc * cp.Wc;
                 // ntaps == 0 (a class no tap reaches): K is all padding, the kernel writes zeros
@@ -530,7 +697,8 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
                 const int bm = pick_bm(C, Nc), Mp = round_up(C, bm);
                 CNUDA_REQUIRE(ig_a_bytes(Kpc, Mp) + 256 <= workspace_bytes, "cnuda_conv2d_backward_data: workspace");
                 const float* A = launch_pack_taps(weight, Aws, ig_a_bytes(Kpc, Mp), Cout, C, q.T, taps, cp.ntaps, Kpc, Mp, st);
-                if (int rc = launch_fwd<ConvDgradClassLoader>(bm, cp, A, Mp, Kpc, C, Nc, st, "cnuda_conv2d_backward_data(class)"))
+                if (int rc = buf_ok ? launch_fwd<ConvDgradClassBufLoader>(bm, cp, A, Mp, Kpc, C, Nc, st, "cnuda_conv2d_backward_data(class)")
+                                    : launch_fwd<ConvDgradClassLoader>(bm, cp, A, Mp, Kpc, C, Nc, st, "cnuda_conv2d_backward_data(class)"))
                     return rc;
             }
         return 0;
@@ -538,6 +706,8 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
     const float* A = launch_pack(weight, Aws, ig_a_bytes(q.Kpd, q.Mpd), Cout, C, q.T, PACK_DGRAD, q.Kpd, q.Mpd,
                                  round_up(Cout, IG_BK), st);
     ConvDgradParams p{g, grad_y, grad_x, round_up(Cout, IG_BK)};
+    if (buf_ok && sh == 1 && sw == 1)
+        return launch_fwd<ConvDgradBufLoader>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
     return launch_fwd<ConvDgradLoader>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
 }
 

@@ -53,7 +53,7 @@ __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 
 // issued (explicit two-deep register pipeline): left to itself the compiler emits read -> s_waitcnt lgkmcnt(0) ->
 // MFMA per step, and the ~100-cycle LDS round trip then idles the matrix pipe between steps (measured with
 // SQ_VALU_MFMA_BUSY_CYCLES: 46 / 56 / 67 % busy for the 32 / 64 / 128-row tiles = 1 / 2 / 4 MFMAs per wait).
-template <int BM>
+template <int BM, int KC = IG_KC>
 __device__ __forceinline__ void ig_mma_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
                                              f32x16 (&acc)[IgTile<BM>::TM][IgTile<BM>::TN],
                                              int wm_off, int wn_off, int lane) {
@@ -78,12 +78,12 @@ __device__ __forceinline__ void ig_mma_chunk(const float* __restrict__ As, const
     // sched_barrier(0): nothing is rescheduled across it, so the reads stay ahead of the MFMAs they overlap
     frag(0, a[0], b[0]);
 #pragma unroll
-    for (int kk = 0; kk < IG_KC; kk += 4) {
+    for (int kk = 0; kk < KC; kk += 4) {
         frag(kk + 2, a[1], b[1]);
         __builtin_amdgcn_sched_barrier(0);
         mma(a[0], b[0]);
         __builtin_amdgcn_sched_barrier(0);
-        if (kk + 4 < IG_KC) frag(kk + 4, a[0], b[0]);
+        if (kk + 4 < KC) frag(kk + 4, a[0], b[0]);
         __builtin_amdgcn_sched_barrier(0);
         mma(a[1], b[1]);
         __builtin_amdgcn_sched_barrier(0);
@@ -201,28 +201,70 @@ inline size_t ig_a_bytes(size_t Kp, size_t Mp) { return Kp * Mp * 10; }
 // Stage the A tile rows [k0, k0+BK) x cols [m0, m0+BM) of the packed matrix: 16-byte loads and LDS stores
 // (four consecutive m per thread; Mp and m0 are multiples of 32, the buffers 256-byte aligned).
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-template <int BM> constexpr int ig_a_per() { return (BM * IG_KC / 4 + IG_THREADS - 1) / IG_THREADS; }   // 2 / 1 / 1 (half the threads)
-template <int BM>
+template <int BM, int KC = IG_KC> constexpr int ig_a_per() { return (BM * KC / 4 + IG_THREADS - 1) / IG_THREADS; }   // 2 / 1 / 1 (half the threads)
+template <int BM, int KC = IG_KC>
 __device__ __forceinline__ void ig_load_a(const float* __restrict__ A, int Mp, int k0, int m0, int tid,
-                                          f32x4 (&r)[ig_a_per<BM>()]) {
-    constexpr int CELLS = BM * IG_KC / 4;
+                                          f32x4 (&r)[ig_a_per<BM, KC>()]) {
+    constexpr int CELLS = BM * KC / 4;
 #pragma unroll
-    for (int i = 0; i < ig_a_per<BM>(); ++i) {
+    for (int i = 0; i < ig_a_per<BM, KC>(); ++i) {
         const int e = tid + i * IG_THREADS;
         const int ec = CELLS % IG_THREADS == 0 ? e : (e < CELLS ? e : e - CELLS);      // idle threads re-read a valid cell
         const int kk = ec / (BM / 4), m = (ec % (BM / 4)) * 4;
         r[i] = *reinterpret_cast<const f32x4*>(A + (size_t)(k0 + kk) * Mp + m0 + m);
     }
 }
-template <int BM>
-__device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, const f32x4 (&r)[ig_a_per<BM>()]) {
-    constexpr int CELLS = BM * IG_KC / 4;
+template <int BM, int KC = IG_KC>
+__device__ __forceinline__ void ig_store_a(float* __restrict__ As, int tid, const f32x4 (&r)[ig_a_per<BM, KC>()]) {
+    constexpr int CELLS = BM * KC / 4;
 #pragma unroll
-    for (int i = 0; i < ig_a_per<BM>(); ++i) {
+    for (int i = 0; i < ig_a_per<BM, KC>(); ++i) {
         const int e = tid + i * IG_THREADS;
         if (CELLS % IG_THREADS == 0 || e < CELLS) reinterpret_cast<f32x4*>(As)[e] = r[i];
     }
 }
+
+// ---------------------------------------------------------------------------
+// Buffer addressing.  The f32 MFMA runs on the same lanes as the vector ALU: a VALU instruction issued by ANY wave of
+// a SIMD takes its cycles from the matrix pipe (measured, DESIGN.md section 10: kernel time = MFMA time + the
+// producers' time), so the staging waves must compute addresses on the SCALAR unit.  buffer_load adds a per-lane
+// 32-bit byte offset (VGPR, computed once per tile), a wave-uniform byte offset (SGPR: channel / chunk terms, scalar
+// adds) and range-checks the per-lane part against num_records: a lane whose offset is the sentinel reads 0.0f,
+// which is the padding value, without a compare or a select.
+// ---------------------------------------------------------------------------
+using buf_rsrc = __amdgpu_buffer_rsrc_t;
+constexpr unsigned IG_BUF_OOB = 0x80000000u;                 // per-lane offset past any tensor this path accepts (< 2 GiB)
+__device__ __forceinline__ buf_rsrc ig_make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float ig_buf_load(buf_rsrc r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f32x4 ig_buf_load4(buf_rsrc r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+// A tile through a buffer: the per-thread cell offsets are fixed for the whole launch, (k0, m0) is a scalar offset
+template <int BM, int KC = IG_KC>
+struct IgABuf {
+    buf_rsrc rs;
+    unsigned voff[ig_a_per<BM, KC>()];
+    int Mp;
+    __device__ __forceinline__ IgABuf(const float* A, int Mp_, int Kp, int m0, int tid) : Mp(Mp_) {
+        rs = ig_make_rsrc(A + m0, (unsigned)(((size_t)Kp * Mp_ - m0) * sizeof(float)));
+        constexpr int CELLS = BM * KC / 4;
+#pragma unroll
+        for (int i = 0; i < ig_a_per<BM, KC>(); ++i) {
+            const int e = tid + i * IG_THREADS;
+            const int ec = CELLS % IG_THREADS == 0 ? e : (e < CELLS ? e : e - CELLS);
+            voff[i] = (unsigned)(((ec / (BM / 4)) * Mp_ + (ec % (BM / 4)) * 4) * (int)sizeof(float));
+        }
+    }
+    __device__ __forceinline__ void load(int k0, f32x4 (&r)[ig_a_per<BM, KC>()]) const {
+        const unsigned soff = (unsigned)(k0 * Mp) * (unsigned)sizeof(float);
+#pragma unroll
+        for (int i = 0; i < ig_a_per<BM, KC>(); ++i) r[i] = ig_buf_load4(rs, voff[i], soff);
+    }
+};
 
 
 // ---------------------------------------------------------------------------
@@ -456,16 +498,16 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void ig
 // stages, one barrier per chunk (all 8 waves); the two roles never hold registers at the same time, so the
 // kernel needs fewer registers than the 4-wave one (78 vs 113 for the 128-row tile).
 // ---------------------------------------------------------------------------
-template <int BM, class Loader, bool DEEP = true>
-__global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd_ws_kernel(
-    typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
+template <int BM, class Loader, bool DEEP, int KC>
+__device__ __forceinline__ void igemm_fwd_ws_body(
+    const typename Loader::Params& p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
     int n_tiles, int m_tiles) {
     using T = IgTile<BM>;
-    constexpr int LDS_AB = 2 * IG_KC * BM + 2 * IG_KC * IG_BN;
+    constexpr int LDS_AB = 2 * KC * BM + 2 * KC * IG_BN;
     static_assert(LDS_AB >= 4 * IG_EPI_WAVE, "the operand buffers hold the epilogue staging tiles");
     __shared__ __attribute__((aligned(16))) float smem[LDS_AB];    // operand stages; reused by the vec4 epilogue
-    float (*As)[IG_KC * BM] = reinterpret_cast<float (*)[IG_KC * BM]>(smem);
-    float (*Bs)[IG_KC * IG_BN] = reinterpret_cast<float (*)[IG_KC * IG_BN]>(smem + 2 * IG_KC * BM);
+    float (*As)[KC * BM] = reinterpret_cast<float (*)[KC * BM]>(smem);
+    float (*Bs)[KC * IG_BN] = reinterpret_cast<float (*)[KC * IG_BN]>(smem + 2 * KC * BM);
     const bool producer = threadIdx.x >= IG_THREADS;            // wave-uniform
     const int tid = threadIdx.x & (IG_THREADS - 1), lane = tid & 63, wid = tid >> 6;
     const int wg = xcd_remap(blockIdx.x, n_tiles * m_tiles);
@@ -479,55 +521,63 @@ __global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd
         // producers' registers are free -- the kernel's allocation is set by the consumers' accumulators), so a load
         // may take two chunks of MFMA time under a busy memory system before anybody waits for it
         static_assert(!Loader::kHasSideOutput, "two-phase loaders keep per-chunk state (the current tap's weights): one chunk in flight only");
+        constexpr int NH = KC / IG_BK;                 // loader calls per chunk
         struct Regs {
-            f32x4 ra[ig_a_per<BM>()];
-            float rb[8];
-            typename IgRaw<Loader, Loader::kHasSideOutput>::type raw;
+            f32x4 ra[ig_a_per<BM, KC>()];
+            float rb[NH][8];
+            typename IgRaw<Loader, Loader::kHasSideOutput>::type raw[NH];
         };
         Regs r0, r1;
+        const IgABuf<BM, KC> abuf(A, Mp, Kp, m0, tid);
         auto stage_store = [&](int buf, Regs& r) {
-            ig_store_a<BM>(As[buf], tid, r.ra);
-            if constexpr (Loader::kHasSideOutput) ld.finish(r.raw, r.rb);
+            ig_store_a<BM, KC>(As[buf], tid, r.ra);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) Bs[buf][(ksub + 2 * j) * IG_BN + nl] = r.rb[j];
+            for (int h = 0; h < NH; ++h) {
+                if constexpr (Loader::kHasSideOutput) ld.finish(r.raw[h], r.rb[h]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Bs[buf][(h * IG_BK + ksub + 2 * j) * IG_BN + nl] = r.rb[h][j];
+            }
         };
         auto stage_load = [&](int k0, Regs& r) {
-            ig_load_a<BM>(A, Mp, k0, m0, tid, r.ra);
-            if constexpr (Loader::kHasSideOutput) ld.load_raw(k0, ksub, r.raw);
-            else ld.load(k0, ksub, r.rb);
+            abuf.load(k0, r.ra);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                if constexpr (Loader::kHasSideOutput) ld.load_raw(k0 + h * IG_BK, ksub, r.raw[h]);
+                else ld.load(k0 + h * IG_BK, ksub, r.rb[h]);
+            }
         };
         stage_load(0, r0);
         stage_store(0, r0);
         if (!DEEP) {                                   // one register stage (A/B measurements)
-            if (IG_KC < Kp) stage_load(IG_KC, r0);
+            if (KC < Kp) stage_load(KC, r0);
             __syncthreads();
             int c1 = 0;
-            for (int k0 = 0; k0 < Kp; k0 += IG_KC) {
-                if (k0 + IG_KC < Kp) {
+            for (int k0 = 0; k0 < Kp; k0 += KC) {
+                if (k0 + KC < Kp) {
                     stage_store(c1 ^ 1, r0);
-                    if (k0 + 2 * IG_KC < Kp) stage_load(k0 + 2 * IG_KC, r0);
+                    if (k0 + 2 * KC < Kp) stage_load(k0 + 2 * KC, r0);
                 }
                 __syncthreads();
                 c1 ^= 1;
             }
             return;
         }
-        if (IG_KC < Kp) stage_load(IG_KC, r1);
-        if (2 * IG_KC < Kp) stage_load(2 * IG_KC, r0);
+        if (KC < Kp) stage_load(KC, r1);
+        if (2 * KC < Kp) stage_load(2 * KC, r0);
         __syncthreads();
         int cur = 0;
-        for (int k0 = 0; k0 < Kp; k0 += 2 * IG_KC) {
+        for (int k0 = 0; k0 < Kp; k0 += 2 * KC) {
             // chunk k0: consumers read stage `cur`; chunk k0 + KC (in r1) goes to the other stage, r1 is refilled
-            if (k0 + IG_KC < Kp) {
+            if (k0 + KC < Kp) {
                 stage_store(cur ^ 1, r1);
-                if (k0 + 3 * IG_KC < Kp) stage_load(k0 + 3 * IG_KC, r1);
+                if (k0 + 3 * KC < Kp) stage_load(k0 + 3 * KC, r1);
             }
             __syncthreads();
-            if (k0 + IG_KC >= Kp) break;
+            if (k0 + KC >= Kp) break;
             // chunk k0 + KC: consumers read stage `cur ^ 1`; chunk k0 + 2 KC (in r0) goes to stage `cur`
-            if (k0 + 2 * IG_KC < Kp) {
+            if (k0 + 2 * KC < Kp) {
                 stage_store(cur, r0);
-                if (k0 + 4 * IG_KC < Kp) stage_load(k0 + 4 * IG_KC, r0);
+                if (k0 + 4 * KC < Kp) stage_load(k0 + 4 * KC, r0);
             }
             __syncthreads();
         }
@@ -543,8 +593,8 @@ __global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     __syncthreads();
     int cur = 0;
-    for (int k0 = 0; k0 < Kp; k0 += IG_KC) {
-        ig_mma_chunk<BM>(As[cur], Bs[cur], acc, wm_off, wn_off, lane);
+    for (int k0 = 0; k0 < Kp; k0 += KC) {
+        ig_mma_chunk<BM, KC>(As[cur], Bs[cur], acc, wm_off, wn_off, lane);
         __syncthreads();
         cur ^= 1;
     }
@@ -567,6 +617,13 @@ __global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd
                 if (m < M) out.store(p, m, acc[i][j][r]);
             }
     }
+}
+
+template <int BM, class Loader, bool DEEP = true, int KC = IG_KC>
+__global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd_ws_kernel(
+    typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
+    int n_tiles, int m_tiles) {
+    igemm_fwd_ws_body<BM, Loader, DEEP, KC>(p, A, Mp, Kp, M, N, n_tiles, m_tiles);
 }
 
 // ---------------------------------------------------------------------------

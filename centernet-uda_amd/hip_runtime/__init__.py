@@ -259,6 +259,7 @@ def workspace(nbytes, device):
 class _Prof:
     enabled = False
     table = []          # tag -> [(algorithmic FLOPs, algorithmic HBM bytes) per timed sub-kernel of the call]
+    shapes = []         # tag -> (kind, B, C, H, W, Co, kh, kw, Ho, Wo)
     cap = 0
 
 
@@ -292,16 +293,18 @@ def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
         _Prof.table.append([(flops, 0.0)])
     else:
         raise ValueError(kind)
+    _Prof.shapes.append((kind, B, C, H, W, Co, kh, kw, Ho, Wo))
     lib().cnuda_prof_arm(len(_Prof.table) - 1)
 
 
 def prof_begin(max_records=16384):
     check(lib().cnuda_prof_enable(int(max_records)), 'prof_enable')
-    _Prof.enabled, _Prof.table, _Prof.cap = True, [], int(max_records)
+    _Prof.enabled, _Prof.table, _Prof.shapes, _Prof.cap = True, [], [], int(max_records)
 
 
-def prof_end():
-    """-> {kernel name: {'launches', 'ms', 'flops', 'bytes'}} and disables the timer."""
+def prof_end(by_shape=False):
+    """-> {kernel name: {'launches', 'ms', 'flops', 'bytes'}} and disables the timer.  by_shape: the keys are
+    (kernel name, (kind, B, C, H, W, Co, kh, kw, Ho, Wo)) -- one row per layer shape."""
     n = sum(len(e) for e in _Prof.table)          # one record per (armed call, sub-kernel)
     L = lib()
     nl = int(L.cnuda_prof_name_len())
@@ -313,11 +316,12 @@ def prof_end():
     for i in range(got):
         flops, nbytes = _Prof.table[tags[i] & 0xffffff][tags[i] >> 24]
         name = names.raw[i * nl:(i + 1) * nl].split(b'\0', 1)[0].decode() or 'unnamed launch'
-        d = out.setdefault(name, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+        key = (name, _Prof.shapes[tags[i] & 0xffffff]) if by_shape else name
+        d = out.setdefault(key, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
         d['launches'] += 1
         d['ms'] += float(ms[i])
         d['flops'] += flops
         d['bytes'] += nbytes
-    _Prof.enabled, _Prof.table = False, []
+    _Prof.enabled, _Prof.table, _Prof.shapes = False, [], []
     lib().cnuda_prof_enable(0)
     return out
