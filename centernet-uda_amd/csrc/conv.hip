@@ -492,6 +492,47 @@ struct ConvWLoader {
     }
 };
 
+// ConvWLoader<2> (C % 64 == 0) with buffer addressing: per chunk the cursor advance, one offset for the grad_y rows,
+// one window-corner offset for x and a bounds test per 64-column group; every channel term is a scalar offset.
+struct ConvWBufLoader {
+    using Params = ConvWParams;
+    static const char* name() { return "ConvWBufLoader"; }
+    const Params& p;
+    buf_rsrc rg, rx;
+    IgPixelCursor c;
+    __device__ ConvWBufLoader(const Params& pp, long long n, long long n_end) : p(pp) {
+        const ConvGeom& g = p.g;
+        rg = ig_make_rsrc(p.gy, (unsigned)((size_t)g.B * g.Co * g.Ho * g.Wo * sizeof(float)));
+        rx = ig_make_rsrc(p.x, (unsigned)((size_t)g.B * g.C * g.H * g.W * sizeof(float)));
+        c.init(n, n_end, g.Ho * g.Wo, g.Wo);
+    }
+    __device__ __forceinline__ void advance() { c.advance(p.g.Ho * p.g.Wo, p.g.Wo); }
+    template <int NV, int STEP>
+    __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[NV]) {
+        ig_buf_rows<NV, STEP>(rg, c, p.g.Co, p.g.Ho * p.g.Wo, m0, msub, v);
+    }
+    template <int NV, int STEP>
+    __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[NV]) {
+        const ConvGeom& g = p.g;
+        const int HW = g.H * g.W, K = g.kh * g.kw * g.C;
+        const int iy0 = c.oy_ * g.sh - g.ph, ix0 = c.ox_ * g.sw - g.pw;
+        const unsigned corner = (unsigned)((((c.b_ * g.C + jsub) * g.H + iy0) * g.W + ix0) * (int)sizeof(float));
+        constexpr int PER = 64 / STEP;
+#pragma unroll
+        for (int h = 0; h < NV / PER; ++h) {
+            const int jg = j0 + 64 * h;                       // wave-uniform: one tap per 64 columns
+            const int tap = jg / g.C, c0 = jg - tap * g.C;
+            const int r = tap / g.kw, s = tap - r * g.kw;
+            const int iy = iy0 + r, ix = ix0 + s;
+            const bool ok = c.valid_ && jg < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            const unsigned voff = ok ? corner + (unsigned)((r * g.W + s) * (int)sizeof(float)) : IG_BUF_OOB;
+#pragma unroll
+            for (int i = 0; i < PER; ++i)
+                v[PER * h + i] = ig_buf_load(rx, voff, (unsigned)((c0 + STEP * i) * HW) * (unsigned)sizeof(float));
+        }
+    }
+};
+
 int fill_geom(ConvGeom& g, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
               const char* who) {
     CNUDA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Co > 0, "%s: empty tensor", who);
@@ -737,9 +778,28 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
         ProfScope prof(st);
         const dim3 grid(q.Jp / q.wbj, q.Mpw / q.wbm, q.Z), blk(IG_THREADS);
         const bool fast = C % 64 == 0;
+        const bool buf = fast && buffer_addressing() && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB &&
+                         (size_t)B * Cout * g.Ho * g.Wo * sizeof(float) < IG_BUF_OOB;
         prof.name((wave_specialised() && fast && q.wbm == 64) ? "igemm_wgrad_ws_kernel<%s, %d, %d>" : "igemm_wgrad_kernel<%s, %d, %d>",
-                  fast ? "ConvWLoader<2>" : "ConvWLoader<0>", q.wbm, q.wbj);
-        if (wave_specialised() && fast && q.wbm == 64) {
+                  buf ? "ConvWBufLoader" : (fast ? "ConvWLoader<2>" : "ConvWLoader<0>"), q.wbm, q.wbj);
+        if (buf) {
+            const dim3 blk2(2 * IG_THREADS);
+            if (wave_specialised() && q.wbm == 64 && q.wbj == 128)
+                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else if (wave_specialised() && q.wbm == 64)
+                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else if (q.wbm == 64 && q.wbj == 128)
+                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWBufLoader, 64, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else if (q.wbm == 64)
+                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWBufLoader, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
+                                   q.Nf, q.pix_per_split);
+            else
+                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWBufLoader, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+        } else if (wave_specialised() && fast && q.wbm == 64) {
             const dim3 blk2(2 * IG_THREADS);
             if (q.wbj == 128)
                 hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWLoader<2>, 64, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,

@@ -757,6 +757,30 @@ struct DcnColWLoader {
     }
 };
 
+// the same two row reads with buffer addressing (igemm.cuh: ig_buf_rows)
+struct DcnColWBufLoader {
+    using Params = DcnColWParams;
+    const Params& p;
+    buf_rsrc rg, rc;
+    IgPixelCursor c;
+    __device__ DcnColWBufLoader(const Params& pp, long long n, long long n_end) : p(pp) {
+        const DcnGeom& g = p.g;
+        const size_t px = (size_t)g.B * g.Ho * g.Wo;
+        rg = ig_make_rsrc(p.gout, (unsigned)(px * g.Co * sizeof(float)));
+        rc = ig_make_rsrc(p.col, (unsigned)(px * g.kh * g.kw * g.C * sizeof(float)));
+        c.init(n, n_end, g.Ho * g.Wo, g.Wo);
+    }
+    __device__ __forceinline__ void advance() { c.advance(p.g.Ho * p.g.Wo, p.g.Wo); }
+    template <int NV, int STEP>
+    __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[NV]) {
+        ig_buf_rows<NV, STEP>(rg, c, p.g.Co, p.g.Ho * p.g.Wo, m0, msub, v);
+    }
+    template <int NV, int STEP>
+    __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[NV]) {
+        ig_buf_rows<NV, STEP>(rc, c, p.g.kh * p.g.kw * p.g.C, p.g.Ho * p.g.Wo, j0, jsub, v);
+    }
+};
+
 // ---------------------------------------------------------------------------
 // deformable_group > 1: straightforward kernels (no backend of the reference
 // uses it -- dla.py:358-368 and mobilenetv2.py:147 pass deformable_groups=1 --
@@ -1082,7 +1106,16 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
     {
         if (columns) {
             DcnColWParams p{g, columns, grad_output};
-            if (q.Jp % 128 == 0)
+            static const bool buf_on = !(getenv("CNUDA_BUF") && getenv("CNUDA_BUF")[0] == '0');
+            const bool buf = buf_on && (size_t)B * q.T * C * HoWo * sizeof(float) < IG_BUF_OOB &&
+                             (size_t)B * Cout * HoWo * sizeof(float) < IG_BUF_OOB;
+            if (buf && q.Jp % 128 == 0)
+                hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
+                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+            else if (buf)
+                hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWBufLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+            else if (q.Jp % 128 == 0)
                 hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
                                    dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
             else

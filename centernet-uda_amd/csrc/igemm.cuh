@@ -642,6 +642,44 @@ __global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd
 // ---------------------------------------------------------------------------
 constexpr int WG_BM = 64, WG_BJ = 64, WG_BP = 32;   // pixels per chunk (2 LDS stages of 32 instead of 1 of 64)
 
+// Pixel cursor of the buffer-addressed weight-gradient loaders: (image, pixel inside the image, output row, column)
+// of the thread's pixel in the current 32-pixel chunk, advanced without divisions.
+struct IgPixelCursor {
+    long long n_, n_end_;
+    int b_, pp_, oy_, ox_;
+    bool valid_;
+    __device__ __forceinline__ void init(long long n, long long n_end, int HoWo, int Wo) {
+        n_ = n;
+        n_end_ = n_end;
+        valid_ = n < n_end;
+        const long long nn = valid_ ? n : 0;
+        b_ = (int)(nn / HoWo);
+        pp_ = (int)(nn - (long long)b_ * HoWo);
+        oy_ = pp_ / Wo;
+        ox_ = pp_ - oy_ * Wo;
+    }
+    __device__ __forceinline__ void advance(int HoWo, int Wo) {
+        n_ += WG_BP;
+        valid_ = n_ < n_end_;
+        pp_ += WG_BP;
+        ox_ += WG_BP;
+        while (ox_ >= Wo) { ox_ -= Wo; ++oy_; }
+        while (pp_ >= HoWo) { pp_ -= HoWo; ++b_; oy_ = pp_ / Wo; ox_ = pp_ - oy_ * Wo; }
+    }
+};
+// NV rows (row0 + sub + STEP * i) of a [B][R][HoWo] tensor at the cursor's pixel: one per-lane offset (image, the
+// thread's row phase, pixel), the row stride as a scalar offset.  The range check covers the whole address
+// (measured on gfx950: per-lane + scalar offset against num_records), so rows past R read the next image or, on
+// the last image, 0.0f -- they only feed slab rows / columns that slab_reduce_kernel never reads; a thread whose
+// pixel lies past the split's end reads the sentinel, i.e. 0.0f.
+template <int NV, int STEP>
+__device__ __forceinline__ void ig_buf_rows(buf_rsrc rs, const IgPixelCursor& c, int R, int HoWo, int row0, int sub,
+                                            float (&v)[NV]) {
+    const unsigned voff = c.valid_ ? (unsigned)(((c.b_ * R + sub) * HoWo + c.pp_) * (int)sizeof(float)) : IG_BUF_OOB;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = ig_buf_load(rs, voff, (unsigned)((row0 + STEP * i) * HoWo) * (unsigned)sizeof(float));
+}
+
 // BM x BJ = 64 x 128 (waves 2 x 2, two accumulator tiles each: when the column count is a multiple of 128),
 // 64 x 64 (waves 2 x 2) or 32 x 128 (waves 1 x 4, for layers with <= 32 output channels:
 // the 16-channel stem / level-0 convs and the 27-channel DCN offset convs would waste 2-4x on a 64-row tile)
