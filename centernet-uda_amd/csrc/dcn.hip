@@ -106,12 +106,19 @@ struct DcnFwdParams {
     float* col;   // optional [B][T*C][Ho*Wo] side output (rows in (tap, channel) order) for the weight gradient
 };
 
-struct DcnFwdLoader {
+// BUF: the corner loads and the column stores go through buffer descriptors (igemm.cuh, "Buffer addressing"): the
+// per-lane offset is the corner pair / the pixel's column, the channel / row term a scalar offset -- the 24 address
+// computations per chunk and thread that the pointer form needs would otherwise come out of the matrix pipe's cycles.
+template <bool BUF>
+struct DcnFwdLoaderT {
     using Params = DcnFwdParams;
     static const char* name() { return "DcnFwdLoader"; }
     static constexpr bool kHasSideOutput = true;
     const DcnGeom& g;
     const float *in_b, *off_b, *mask_b;
+    buf_rsrc rin, rcol;
+    unsigned in_boff = 0, col_voff = IG_BUF_OOB;    // BUF: byte offset of the image in `in`, of the pixel's column in `col`
+    bool col_on = false;
     int oy, ox, K;
     bool valid;
     int cur;   // tap whose sampling state currently sits in the registers below (K is tap-major:
@@ -124,8 +131,8 @@ struct DcnFwdLoader {
     float m00, m01, m10, m11;     // weights of (top-left, top-right, bottom-left, bottom-right) of the loaded pairs
     float* col_n;     // this pixel's column in the side output (nullptr: not requested / not the first M tile)
     int col_stride;
-    __device__ __forceinline__ void disable_col() { col_n = nullptr; }
-    __device__ DcnFwdLoader(const Params& p, long long n, bool n_valid) : g(p.g), valid(n_valid), cur(-1) {
+    __device__ __forceinline__ void disable_col() { col_n = nullptr; col_on = false; }
+    __device__ DcnFwdLoaderT(const Params& p, long long n, bool n_valid) : g(p.g), valid(n_valid), cur(-1) {
         const int HoWo = g.Ho * g.Wo;
         const int nn = n_valid ? (int)n : 0;   // N < 2^31 is checked on the host: 32-bit index math
         const int b = nn / HoWo, pp = nn - b * HoWo;
@@ -138,6 +145,13 @@ struct DcnFwdLoader {
         K = T * g.C;
         col_n = (p.col && n_valid) ? p.col + (size_t)b * K * HoWo + pp : nullptr;
         col_stride = HoWo;
+        if constexpr (BUF) {
+            rin = ig_make_rsrc(p.in, (unsigned)((size_t)g.B * g.C * g.H * g.W * sizeof(float)));
+            rcol = ig_make_rsrc(p.col, p.col ? (unsigned)((size_t)g.B * K * HoWo * sizeof(float)) : 0u);
+            in_boff = (unsigned)(b * g.C * g.H * g.W) * (unsigned)sizeof(float);
+            col_on = p.col != nullptr;
+            col_voff = (p.col && n_valid) ? (unsigned)(b * K * HoWo + pp) * (unsigned)sizeof(float) : IG_BUF_OOB;
+        }
     }
     struct __attribute__((packed, aligned(4))) Pair { float l, r; };
     __device__ __forceinline__ void set_tap(int tap) {
@@ -191,6 +205,17 @@ struct DcnFwdLoader {
             }
             const int tap = ctap, c0 = cc0 + ksub;
             if (tap != cur) set_tap(tap);
+            if constexpr (BUF) {
+                const unsigned vT = in_boff + (unsigned)qT * 4u, vB = in_boff + (unsigned)qB * 4u;
+                const int c0s = cc0 + __builtin_amdgcn_readfirstlane(ksub);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned soff = (unsigned)((c0s + 2 * j) * HW) * 4u;
+                    r.t[j] = __builtin_bit_cast(Pair, __builtin_amdgcn_raw_buffer_load_b64(rin, (int)vT, (int)soff, 0));
+                    r.b[j] = __builtin_bit_cast(Pair, __builtin_amdgcn_raw_buffer_load_b64(rin, (int)vB, (int)soff, 0));
+                }
+                return;
+            }
             const float* plane = in_b + (size_t)c0 * HW;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -222,6 +247,16 @@ struct DcnFwdLoader {
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = m00 * r.t[j].l + m01 * r.t[j].r + m10 * r.b[j].l + m11 * r.b[j].r;
+            if constexpr (BUF) {
+                if (col_on) {         // (uniform; a thread past the last pixel stores to the sentinel: dropped)
+                    const int k0s = __builtin_amdgcn_readfirstlane(r.k0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[j]), rcol, (int)col_voff,
+                                                              (int)((unsigned)((k0s + 2 * j) * col_stride) * 4u), 0);
+                }
+                return;
+            }
             if (col_n) {
                 float* cp = col_n + (size_t)r.k0 * col_stride;
                 const size_t step = (size_t)2 * col_stride;
@@ -262,6 +297,9 @@ struct DcnFwdLoader {
         }
     };
 };
+
+using DcnFwdLoader = DcnFwdLoaderT<false>;
+using DcnFwdBufLoader = DcnFwdLoaderT<true>;
 
 // ---------------------------------------------------------------------------
 // forward, two-kernel form for layers whose output channels span several M tiles (small feature maps run
@@ -355,6 +393,34 @@ struct DcnColsLoader {
             *reinterpret_cast<f32x4*>(base + (size_t)m * HoWo) = v;
         }
     };
+};
+
+// the same row reads with buffer addressing: per-lane (image, pixel) offset, the row as a scalar offset
+struct DcnColsBufLoader {
+    using Params = DcnColsParams;
+    static const char* name() { return "DcnColsBufLoader"; }
+    static constexpr bool kHasSideOutput = false;
+    buf_rsrc rs;
+    unsigned voff;
+    int K, HoWo;
+    __device__ DcnColsBufLoader(const Params& p, long long n, bool n_valid) {
+        HoWo = p.g.Ho * p.g.Wo;
+        K = p.g.kh * p.g.kw * p.g.C;
+        const int nn = n_valid ? (int)n : 0;
+        const int b = nn / HoWo, pp = nn - b * HoWo;
+        rs = ig_make_rsrc(p.col, (unsigned)((size_t)p.g.B * K * HoWo * sizeof(float)));
+        voff = n_valid ? (unsigned)(b * K * HoWo + pp) * (unsigned)sizeof(float) : IG_BUF_OOB;
+    }
+    __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
+        const int ks = k0 + __builtin_amdgcn_readfirstlane(ksub);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks + 2 * j;
+            // rows past K (K padding): the scalar offset of row K - 1 and a weight of zero
+            v[j] = ig_buf_load(rs, voff, (unsigned)((k < K ? k : K - 1) * HoWo) * (unsigned)sizeof(float));
+        }
+    }
+    using Out = DcnColsLoader::Out;
 };
 
 // ---------------------------------------------------------------------------
@@ -1008,6 +1074,9 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
                                  C, q.T, PACK_FWD, q.Kp, q.Mp, 0, st);
     const int n_tiles = ceil_div(q.N, IG_BN), m_tiles = q.Mp / q.bm;
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
+    static const bool buf_on = !(getenv("CNUDA_BUF") && getenv("CNUDA_BUF")[0] == '0');
+    const bool buf = buf_on && C % IG_BK == 0 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB &&
+                     (size_t)B * q.K * g.Ho * g.Wo * sizeof(float) < IG_BUF_OOB;
     if (q.fwd_two_kernels) {
         float* cols = columns ? columns : cv.take<float>((size_t)B * q.K * g.Ho * g.Wo);
         ProfScope prof(st);   // brackets both kernels
@@ -1018,7 +1087,16 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
             hipLaunchKernelGGL(dcn_sample_kernel, dim3(B * tiles), dim3(64, tw), 0, st, sp, tiles);
         }
         DcnColsParams p{g, cols, bias, act_slope, output};
-        if (q.bm == 128)
+        if (buf && q.bm == 128)
+            hipLaunchKernelGGL((igemm_fwd_kernel<128, DcnColsBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+                               n_tiles, m_tiles);
+        else if (buf && q.bm == 64)
+            hipLaunchKernelGGL((igemm_fwd_kernel<64, DcnColsBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+                               n_tiles, m_tiles);
+        else if (buf)
+            hipLaunchKernelGGL((igemm_fwd_kernel<32, DcnColsBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+                               n_tiles, m_tiles);
+        else if (q.bm == 128)
             hipLaunchKernelGGL((igemm_fwd_kernel<128, DcnColsLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                                n_tiles, m_tiles);
         else if (q.bm == 64)
@@ -1032,7 +1110,16 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
     DcnFwdParams p{g, input, offset, mask, bias, act_slope, output, columns};
     ProfScope prof(st);
     prof.name("igemm_fwd_kernel<%d, DcnFwdLoader>%s", q.bm, columns ? " (+ column side output)" : "");
-    if (q.bm == 128)
+    if (buf && q.bm == 128)
+        hipLaunchKernelGGL((igemm_fwd_kernel<128, DcnFwdBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+                           n_tiles, m_tiles);
+    else if (buf && q.bm == 64)
+        hipLaunchKernelGGL((igemm_fwd_kernel<64, DcnFwdBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+                           n_tiles, m_tiles);
+    else if (buf)
+        hipLaunchKernelGGL((igemm_fwd_kernel<32, DcnFwdBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+                           n_tiles, m_tiles);
+    else if (q.bm == 128)
         hipLaunchKernelGGL((igemm_fwd_kernel<128, DcnFwdLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                            n_tiles, m_tiles);
     else if (q.bm == 64)

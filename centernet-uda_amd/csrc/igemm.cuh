@@ -353,6 +353,7 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void ig
     float rb[NH][8];
     u32x4 ra3[ig_a3_per<BM>()];                     // X3: the pre-split A cells of a chunk
     typename IgRaw<Loader, Loader::kHasSideOutput>::type raw[NH];   // two-phase loaders keep raw loads here
+    const IgABuf<BM> abuf(A, Mp, Kp, m0, tid);      // (unused by the X3 variant, whose A cells are pre-split)
     auto stage_store = [&](int buf) {
         if constexpr (X3) ig_store_a_x3<BM>(reinterpret_cast<u32x4*>(As[buf]), tid, ra3);
         else ig_store_a<BM>(As[buf], tid, ra);
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void ig
     };
     auto stage_load = [&](int k0) {
         if constexpr (X3) ig_load_a_x3<BM>(reinterpret_cast<const u32x4*>(A), Mp, k0, m0, tid, ra3);
-        else ig_load_a<BM>(A, Mp, k0, m0, tid, ra);
+        else abuf.load(k0, ra);
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             if constexpr (Loader::kHasSideOutput) ld.load_raw(k0 + h * IG_BK, ksub, raw[h]);
