@@ -543,6 +543,12 @@ int fill_geom(ConvGeom& g, int B, int C, int H, int W, int Co, int kh, int kw, i
     return 0;
 }
 
+// CNUDA_BUF=0: the pointer-addressed loaders (A/B measurements; tensors of 2 GiB and more always take them)
+bool buffer_addressing() {
+    static const bool on = !(getenv("CNUDA_BUF") && getenv("CNUDA_BUF")[0] == '0');
+    return on;
+}
+
 // largest tile that still gives the chip >= ~2 workgroups per CU (small feature maps: 16x16 / 32x32)
 int pick_bm(int M, long long N) {
     int bm = M > 64 ? 128 : (M > 32 ? 64 : 32);
@@ -566,8 +572,13 @@ ConvPlan make_plan(const ConvGeom& g) {
     q.Nd = (long long)g.B * g.H * g.W;
     q.Kf = q.T * g.C;   q.Kpf = round_up(q.Kf, IG_KC);  q.bmf = pick_bm(g.Co, q.Nf);  q.Mpf = round_up(g.Co, q.bmf);
     q.Kd = q.T * round_up(g.Co, IG_BK);  q.Kpd = round_up(q.Kd, IG_KC);  q.bmd = pick_bm(g.C, q.Nd);   q.Mpd = round_up(g.C, q.bmd);
-    q.wbm = g.Co <= 32 ? 32 : 64;
     q.wbj = (g.Co <= 32 || (g.C % 64 == 0 && q.Kf % 128 == 0)) ? 128 : 64;   // 64 x 128: +8-13 % where nothing is padded
+    // 128 x 64 where the columns do not fill 128 (K = 9 * 64) but the output channels do: the same two accumulator
+    // tiles per wave and loads per MFMA as 64 x 128 (the 64 -> 256 head convolutions at 128 x 128)
+    static const bool tall = !(getenv("CNUDA_WGRAD_TALL") && getenv("CNUDA_WGRAD_TALL")[0] == '0');
+    const bool wbuf = buffer_addressing() && (size_t)g.B * g.C * g.H * g.W * sizeof(float) < IG_BUF_OOB &&
+                      (size_t)g.B * g.Co * g.Ho * g.Wo * sizeof(float) < IG_BUF_OOB;     // (ConvWBufLoader only)
+    q.wbm = g.Co <= 32 ? 32 : ((tall && wbuf && q.wbj == 64 && g.C % 64 == 0 && g.Co % 128 == 0) ? 128 : 64);
     q.Mpw = round_up(g.Co, q.wbm);
     q.Jp = round_up(q.Kf, q.wbj);
     const long long tiles = (long long)(q.Mpw / q.wbm) * (q.Jp / q.wbj);
@@ -581,12 +592,6 @@ ConvPlan make_plan(const ConvGeom& g) {
     q.dgrad_bytes = carve_bytes(ig_a_bytes(q.Kpd, q.Mpd), 1) + 256;
     q.wgrad_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) + carve_bytes((size_t)g.Co * g.B, 4) + 256;
     return q;
-}
-
-// CNUDA_BUF=0: the pointer-addressed loaders (A/B measurements; tensors of 2 GiB and more always take them)
-bool buffer_addressing() {
-    static const bool on = !(getenv("CNUDA_BUF") && getenv("CNUDA_BUF")[0] == '0');
-    return on;
 }
 
 template <class Loader>
@@ -780,11 +785,17 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
         const bool fast = C % 64 == 0;
         const bool buf = fast && buffer_addressing() && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB &&
                          (size_t)B * Cout * g.Ho * g.Wo * sizeof(float) < IG_BUF_OOB;
-        prof.name((wave_specialised() && fast && q.wbm == 64) ? "igemm_wgrad_ws_kernel<%s, %d, %d>" : "igemm_wgrad_kernel<%s, %d, %d>",
+        prof.name((wave_specialised() && fast && q.wbm >= 64) ? "igemm_wgrad_ws_kernel<%s, %d, %d>" : "igemm_wgrad_kernel<%s, %d, %d>",
                   buf ? "ConvWBufLoader" : (fast ? "ConvWLoader<2>" : "ConvWLoader<0>"), q.wbm, q.wbj);
         if (buf) {
             const dim3 blk2(2 * IG_THREADS);
-            if (wave_specialised() && q.wbm == 64 && q.wbj == 128)
+            if (q.wbm == 128 && wave_specialised())
+                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else if (q.wbm == 128)
+                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWBufLoader, 128, 64>), grid, blk, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else if (wave_specialised() && q.wbm == 64 && q.wbj == 128)
                 hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
             else if (wave_specialised() && q.wbm == 64)
