@@ -500,23 +500,34 @@ struct ConvWBufLoader {
     const Params& p;
     buf_rsrc rg, rx;
     IgPixelCursor c;
+    unsigned gimg, ximg;          // byte offsets of the cursor's image in grad_y / x
     __device__ ConvWBufLoader(const Params& pp, long long n, long long n_end) : p(pp) {
         const ConvGeom& g = p.g;
         rg = ig_make_rsrc(p.gy, (unsigned)((size_t)g.B * g.Co * g.Ho * g.Wo * sizeof(float)));
         rx = ig_make_rsrc(p.x, (unsigned)((size_t)g.B * g.C * g.H * g.W * sizeof(float)));
         c.init(n, n_end, g.Ho * g.Wo, g.Wo);
+        gimg = (unsigned)(c.b_ * g.Co * g.Ho * g.Wo) * 4u;
+        ximg = (unsigned)(c.b_ * g.C * g.H * g.W) * 4u;
     }
-    __device__ __forceinline__ void advance() { c.advance(p.g.Ho * p.g.Wo, p.g.Wo); }
+    __device__ __forceinline__ void advance() {
+        const ConvGeom& g = p.g;
+        c.advance(g.Ho * g.Wo, g.Wo);
+        if (c.crossed_) {          // (rare: a chunk that enters the next image)
+            gimg += (unsigned)(c.crossed_ * g.Co * g.Ho * g.Wo) * 4u;
+            ximg += (unsigned)(c.crossed_ * g.C * g.H * g.W) * 4u;
+        }
+    }
     template <int NV, int STEP>
     __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[NV]) {
-        ig_buf_rows<NV, STEP>(rg, c, p.g.Co, p.g.Ho * p.g.Wo, m0, msub, v);
+        ig_buf_rows<NV, STEP>(rg, c, gimg, p.g.Ho * p.g.Wo, m0, msub, v);
     }
     template <int NV, int STEP>
     __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[NV]) {
         const ConvGeom& g = p.g;
         const int HW = g.H * g.W, K = g.kh * g.kw * g.C;
-        const int iy0 = c.oy_ * g.sh - g.ph, ix0 = c.ox_ * g.sw - g.pw;
-        const unsigned corner = (unsigned)((((c.b_ * g.C + jsub) * g.H + iy0) * g.W + ix0) * (int)sizeof(float));
+        const int iy0 = ig_mad24(c.oy_, g.sh, -g.ph), ix0 = ig_mad24(c.ox_, g.sw, -g.pw);
+        // x[b][jsub][iy0][ix0] (may lie outside the image: only used with an in-range tap)
+        const unsigned corner = ximg + (unsigned)(ig_mad24(jsub, HW, ig_mad24(iy0, g.W, ix0))) * 4u;
         constexpr int PER = 64 / STEP;
 #pragma unroll
         for (int h = 0; h < NV / PER; ++h) {
@@ -524,7 +535,7 @@ struct ConvWBufLoader {
             const int tap = jg / g.C, c0 = jg - tap * g.C;
             const int r = tap / g.kw, s = tap - r * g.kw;
             const int iy = iy0 + r, ix = ix0 + s;
-            const bool ok = c.valid_ && jg < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+            const bool ok = c.valid_ && jg < K && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
             const unsigned voff = ok ? corner + (unsigned)((r * g.W + s) * (int)sizeof(float)) : IG_BUF_OOB;
 #pragma unroll
             for (int i = 0; i < PER; ++i)
@@ -547,6 +558,14 @@ int fill_geom(ConvGeom& g, int B, int C, int H, int W, int Co, int kh, int kw, i
 bool buffer_addressing() {
     static const bool on = !(getenv("CNUDA_BUF") && getenv("CNUDA_BUF")[0] == '0');
     return on;
+}
+
+// ConvWBufLoader: both tensors under 2 GiB (32-bit byte offsets, the sentinel above them) and planes under 2^23
+// elements (24-bit multiplies in the per-chunk address arithmetic)
+bool wgrad_buffer_ok(const ConvGeom& g) {
+    return buffer_addressing() && (size_t)g.B * g.C * g.H * g.W * sizeof(float) < IG_BUF_OOB &&
+           (size_t)g.B * g.Co * g.Ho * g.Wo * sizeof(float) < IG_BUF_OOB && (long long)g.H * g.W < (1 << 23) &&
+           (long long)g.Ho * g.Wo < (1 << 23);
 }
 
 // largest tile that still gives the chip >= ~2 workgroups per CU (small feature maps: 16x16 / 32x32)
@@ -576,8 +595,7 @@ ConvPlan make_plan(const ConvGeom& g) {
     // 128 x 64 where the columns do not fill 128 (K = 9 * 64) but the output channels do: the same two accumulator
     // tiles per wave and loads per MFMA as 64 x 128 (the 64 -> 256 head convolutions at 128 x 128)
     static const bool tall = !(getenv("CNUDA_WGRAD_TALL") && getenv("CNUDA_WGRAD_TALL")[0] == '0');
-    const bool wbuf = buffer_addressing() && (size_t)g.B * g.C * g.H * g.W * sizeof(float) < IG_BUF_OOB &&
-                      (size_t)g.B * g.Co * g.Ho * g.Wo * sizeof(float) < IG_BUF_OOB;     // (ConvWBufLoader only)
+    const bool wbuf = wgrad_buffer_ok(g);     // (ConvWBufLoader only)
     q.wbm = g.Co <= 32 ? 32 : ((tall && wbuf && q.wbj == 64 && g.C % 64 == 0 && g.Co % 128 == 0) ? 128 : 64);
     q.Mpw = round_up(g.Co, q.wbm);
     q.Jp = round_up(q.Kf, q.wbj);
@@ -783,8 +801,7 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
         ProfScope prof(st);
         const dim3 grid(q.Jp / q.wbj, q.Mpw / q.wbm, q.Z), blk(IG_THREADS);
         const bool fast = C % 64 == 0;
-        const bool buf = fast && buffer_addressing() && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB &&
-                         (size_t)B * Cout * g.Ho * g.Wo * sizeof(float) < IG_BUF_OOB;
+        const bool buf = fast && wgrad_buffer_ok(g);
         prof.name((wave_specialised() && fast && q.wbm >= 64) ? "igemm_wgrad_ws_kernel<%s, %d, %d>" : "igemm_wgrad_kernel<%s, %d, %d>",
                   buf ? "ConvWBufLoader" : (fast ? "ConvWLoader<2>" : "ConvWLoader<0>"), q.wbm, q.wbj);
         if (buf) {

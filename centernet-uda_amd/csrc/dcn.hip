@@ -829,21 +829,31 @@ struct DcnColWBufLoader {
     const Params& p;
     buf_rsrc rg, rc;
     IgPixelCursor c;
+    unsigned gimg, cimg;          // byte offsets of the cursor's image in grad_output / the columns
     __device__ DcnColWBufLoader(const Params& pp, long long n, long long n_end) : p(pp) {
         const DcnGeom& g = p.g;
         const size_t px = (size_t)g.B * g.Ho * g.Wo;
         rg = ig_make_rsrc(p.gout, (unsigned)(px * g.Co * sizeof(float)));
         rc = ig_make_rsrc(p.col, (unsigned)(px * g.kh * g.kw * g.C * sizeof(float)));
         c.init(n, n_end, g.Ho * g.Wo, g.Wo);
+        gimg = (unsigned)(c.b_ * g.Co * g.Ho * g.Wo) * 4u;
+        cimg = (unsigned)(c.b_ * g.kh * g.kw * g.C * g.Ho * g.Wo) * 4u;
     }
-    __device__ __forceinline__ void advance() { c.advance(p.g.Ho * p.g.Wo, p.g.Wo); }
+    __device__ __forceinline__ void advance() {
+        const DcnGeom& g = p.g;
+        c.advance(g.Ho * g.Wo, g.Wo);
+        if (c.crossed_) {
+            gimg += (unsigned)(c.crossed_ * g.Co * g.Ho * g.Wo) * 4u;
+            cimg += (unsigned)(c.crossed_ * g.kh * g.kw * g.C * g.Ho * g.Wo) * 4u;
+        }
+    }
     template <int NV, int STEP>
     __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[NV]) {
-        ig_buf_rows<NV, STEP>(rg, c, p.g.Co, p.g.Ho * p.g.Wo, m0, msub, v);
+        ig_buf_rows<NV, STEP>(rg, c, gimg, p.g.Ho * p.g.Wo, m0, msub, v);
     }
     template <int NV, int STEP>
     __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[NV]) {
-        ig_buf_rows<NV, STEP>(rc, c, p.g.kh * p.g.kw * p.g.C, p.g.Ho * p.g.Wo, j0, jsub, v);
+        ig_buf_rows<NV, STEP>(rc, c, cimg, p.g.Ho * p.g.Wo, j0, jsub, v);
     }
 };
 
@@ -1195,7 +1205,7 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
             DcnColWParams p{g, columns, grad_output};
             static const bool buf_on = !(getenv("CNUDA_BUF") && getenv("CNUDA_BUF")[0] == '0');
             const bool buf = buf_on && (size_t)B * q.T * C * HoWo * sizeof(float) < IG_BUF_OOB &&
-                             (size_t)B * Cout * HoWo * sizeof(float) < IG_BUF_OOB;
+                             (size_t)B * Cout * HoWo * sizeof(float) < IG_BUF_OOB && HoWo < (1 << 23);
             if (buf && q.Jp % 128 == 0)
                 hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
                                    dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);

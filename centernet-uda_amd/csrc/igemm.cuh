@@ -644,39 +644,47 @@ __global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd
 constexpr int WG_BM = 64, WG_BJ = 64, WG_BP = 32;   // pixels per chunk (2 LDS stages of 32 instead of 1 of 64)
 
 // Pixel cursor of the buffer-addressed weight-gradient loaders: (image, pixel inside the image, output row, column)
-// of the thread's pixel in the current 32-pixel chunk, advanced without divisions.
+// of the thread's pixel in the current 32-pixel chunk, advanced without divisions or 64-bit arithmetic (these run on
+// the staging waves between MFMAs: every vector instruction here is a matrix-pipe cycle lost).
 struct IgPixelCursor {
-    long long n_, n_end_;
+    int left_;                 // pixels from the thread's pixel to the end of the split (> 0: the pixel is valid)
     int b_, pp_, oy_, ox_;
+    int crossed_;              // images entered by the last advance() (the loaders move their image bases by it)
     bool valid_;
     __device__ __forceinline__ void init(long long n, long long n_end, int HoWo, int Wo) {
-        n_ = n;
-        n_end_ = n_end;
-        valid_ = n < n_end;
+        const long long d = n_end - n;
+        left_ = d > 0x7fffffffll ? 0x7fffffff : (d < 0 ? 0 : (int)d);
+        valid_ = left_ > 0;
         const long long nn = valid_ ? n : 0;
         b_ = (int)(nn / HoWo);
         pp_ = (int)(nn - (long long)b_ * HoWo);
         oy_ = pp_ / Wo;
         ox_ = pp_ - oy_ * Wo;
+        crossed_ = 0;
     }
     __device__ __forceinline__ void advance(int HoWo, int Wo) {
-        n_ += WG_BP;
-        valid_ = n_ < n_end_;
+        left_ = left_ > WG_BP ? left_ - WG_BP : 0;
+        valid_ = left_ > 0;
         pp_ += WG_BP;
         ox_ += WG_BP;
+        crossed_ = 0;
         while (ox_ >= Wo) { ox_ -= Wo; ++oy_; }
-        while (pp_ >= HoWo) { pp_ -= HoWo; ++b_; oy_ = pp_ / Wo; ox_ = pp_ - oy_ * Wo; }
+        while (pp_ >= HoWo) { pp_ -= HoWo; ++b_; ++crossed_; oy_ = pp_ / Wo; ox_ = pp_ - oy_ * Wo; }
     }
 };
-// NV rows (row0 + sub + STEP * i) of a [B][R][HoWo] tensor at the cursor's pixel: one per-lane offset (image, the
-// thread's row phase, pixel), the row stride as a scalar offset.  The range check covers the whole address
-// (measured on gfx950: per-lane + scalar offset against num_records), so rows past R read the next image or, on
-// the last image, 0.0f -- they only feed slab rows / columns that slab_reduce_kernel never reads; a thread whose
+// 24-bit multiply-add (full rate; v_mul_lo_u32 is quarter rate): a, b below 2^24 -- channel / row counts and plane
+// sizes of tensors under 2 GiB
+__device__ __forceinline__ int ig_mad24(int a, int b, int c) { return __mul24(a, b) + c; }
+// NV rows (row0 + sub + STEP * i) of a [B][R][HoWo] tensor at the cursor's pixel.  `image_base` is the byte offset
+// of the cursor's image (kept by the loader: += R * HoWo * 4 per image entered).  The per-lane offset carries the
+// image, the thread's row phase and the pixel, the row stride is a scalar offset.  The range check covers the whole
+// address (measured on gfx950: per-lane + scalar offset against num_records), so rows past R read the next image or,
+// on the last image, 0.0f -- they only feed slab rows / columns that slab_reduce_kernel never reads; a thread whose
 // pixel lies past the split's end reads the sentinel, i.e. 0.0f.
 template <int NV, int STEP>
-__device__ __forceinline__ void ig_buf_rows(buf_rsrc rs, const IgPixelCursor& c, int R, int HoWo, int row0, int sub,
-                                            float (&v)[NV]) {
-    const unsigned voff = c.valid_ ? (unsigned)(((c.b_ * R + sub) * HoWo + c.pp_) * (int)sizeof(float)) : IG_BUF_OOB;
+__device__ __forceinline__ void ig_buf_rows(buf_rsrc rs, const IgPixelCursor& c, unsigned image_base, int HoWo, int row0,
+                                            int sub, float (&v)[NV]) {
+    const unsigned voff = c.valid_ ? image_base + (unsigned)ig_mad24(sub, HoWo, c.pp_) * 4u : IG_BUF_OOB;
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = ig_buf_load(rs, voff, (unsigned)((row0 + STEP * i) * HoWo) * (unsigned)sizeof(float));
 }
