@@ -640,15 +640,9 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     // neutral on the 64-channel ones, -2-4 % on the 32-row tile, which therefore keeps the 4-wave kernel
     if (wave_specialised() && bm >= 64) {
         const dim3 block2(2 * IG_THREADS);
-        static const bool deep = !(getenv("CNUDA_FWD_DEEP") && getenv("CNUDA_FWD_DEEP")[0] == '0');
-        static const bool kc32 = getenv("CNUDA_FWD_KC") && atoi(getenv("CNUDA_FWD_KC")) == 32;
-        if (kc32 && Kp % 32 == 0) {                    // 32-deep chunks: half the barriers (A/B measurements)
-            if (bm == 128)
-                hipLaunchKernelGGL((igemm_fwd_ws_kernel<128, Loader, true, 32>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
-            else
-                hipLaunchKernelGGL((igemm_fwd_ws_kernel<64, Loader, true, 32>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
-            return check_launch(who);
-        }
+        // one producer register stage by default: with buffer addressing the second stage (CNUDA_FWD_DEEP=1) measured
+        // 0.4 ms per step slower -- it costs the third workgroup per CU (86 instead of <= 80 registers)
+        static const bool deep = getenv("CNUDA_FWD_DEEP") && getenv("CNUDA_FWD_DEEP")[0] == '1';
         if (bm == 128 && deep)
             hipLaunchKernelGGL((igemm_fwd_ws_kernel<128, Loader, true>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         else if (bm == 128)
