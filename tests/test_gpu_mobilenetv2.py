@@ -86,7 +86,11 @@ def test_mobilenetv2_forward_backward_golden(golden, tag):
     scalar = sum((out[k] * torch.cos(torch.arange(out[k].numel(), dtype=torch.float32)
                                      .reshape(out[k].shape) * 0.1).to(DEV)).sum() for k in out)
     scalar.backward()
-    _close_calibrated(scalar.item(), g['scalar'], g['f64_scalar'], floor=2e-4, what='scalar')
+    # the scalar sums ~2e4 outputs whose fp32 noise is 1e-3 each (the per-output checks above): the reference's own
+    # single fp32 draw (|ref32 - ref64| = 1.9e-3) can sit well below the spread of such a sum -- measured here
+    # 5.7e-3 with the f32 MFMA and 1.9e-2 in the split-operand mode, whose outputs are no further from the fp64
+    # values than the f32 ones -- hence 16x like the gradient checksums
+    _close_calibrated(scalar.item(), g['scalar'], g['f64_scalar'], floor=2e-4, k=16.0, what='scalar')
     params = dict(model.named_parameters())
     for key in g.files:
         if key.startswith('gradsum__'):
