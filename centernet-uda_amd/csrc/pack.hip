@@ -1,7 +1,10 @@
 // Small helper kernels around the implicit-GEMM cores: weight packing, split-K
 // slab reduction, per-channel sums.
+#include <string.h>
+
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "igemm_host.h"
 
@@ -56,7 +59,16 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
         const int K = T * C;
         const int j = (int)(i % K), o = (int)(i / K);
         const size_t off = (size_t)o * Jp + j;
-        for (int z = w; z < Z; z += 4) s += slabs[(size_t)z * Mp * Jp + off];
+        // same order of additions as a plain loop; the loads of eight slabs are in flight together (the loop is
+        // latency-bound: up to ~60 slabs, 14 dependent round trips per wave otherwise)
+        const size_t zs = (size_t)Mp * Jp;
+        for (int z = w; z < Z; z += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = z + 4 * u < Z ? slabs[(size_t)(z + 4 * u) * zs + off] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (z + 4 * u < Z) s += v[u];
+        }
     }
     part[w][lane] = s;
     __syncthreads();
@@ -133,15 +145,21 @@ struct PackKeyHash {
         return (size_t)(h ^ (h >> 31));
     }
 };
-struct PackSlot { size_t offset, bytes; uint64_t version; };
+struct PackSlot {
+    size_t offset, bytes;
+    uint64_t version;
+    int cpad;            // PACK_DGRAD: channels per tap on the K axis
+    int ntaps, taps[9];  // mode 2 (tap subset)
+};
 std::mutex g_pack_mutex;                      // forward runs on the caller's thread, backward on autograd's
 std::unordered_map<PackKey, PackSlot, PackKeyHash> g_pack_slots;
 char* g_pack_arena = nullptr;
 size_t g_pack_arena_bytes = 0, g_pack_arena_used = 0;
+uint64_t g_pack_generation = 0;               // bumped when a slot is added (the refresh table is rebuilt then)
 thread_local uint64_t g_pack_token = 0, g_pack_version = 0;
 
 // -> cached slot to use (fill == true: pack into it first), or nullptr: use the workspace
-float* pack_slot(const PackKey& key, size_t bytes, bool& fill) {
+float* pack_slot(const PackKey& key, size_t bytes, bool& fill, int cpad = 0, const TapList* taps = nullptr) {
     fill = true;
     if (key.token == 0 || !g_pack_arena) return nullptr;
     std::lock_guard<std::mutex> lock(g_pack_mutex);
@@ -149,10 +167,13 @@ float* pack_slot(const PackKey& key, size_t bytes, bool& fill) {
     if (it == g_pack_slots.end()) {
         const size_t need = (bytes + 255) / 256 * 256;
         if (g_pack_arena_used + need > g_pack_arena_bytes) return nullptr;        // arena full: no caching
-        it = g_pack_slots.emplace(key, PackSlot{g_pack_arena_used, bytes, ~0ull}).first;
+        it = g_pack_slots.emplace(key, PackSlot{g_pack_arena_used, bytes, ~0ull, 0, 0, {0}}).first;
         g_pack_arena_used += need;
+        ++g_pack_generation;
     }
     if (it->second.bytes < bytes) return nullptr;
+    it->second.cpad = cpad;
+    if (taps) { it->second.ntaps = taps->n; for (int i = 0; i < 9; ++i) it->second.taps[i] = taps->tap[i]; }
     fill = it->second.version != g_pack_version;
     it->second.version = g_pack_version;
     return reinterpret_cast<float*>(g_pack_arena + it->second.offset);
@@ -164,7 +185,7 @@ const float* launch_pack(const float* W, float* dst, size_t room, int Co, int C,
                          int Cpad, hipStream_t st) {
     bool fill = true;
     const PackKey key{g_pack_token, W, (int)mode, Co, C, T, Kp, Mp, Cpad};
-    if (float* slot = pack_slot(key, room, fill)) dst = slot;
+    if (float* slot = pack_slot(key, room, fill, Cpad)) dst = slot;
     if (fill) {
         const long long total = (long long)Kp * Mp;
         hipLaunchKernelGGL(pack_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, W, dst, Co, C, T, (int)mode, Kp,
@@ -181,7 +202,7 @@ const float* launch_pack_taps(const float* W, float* dst, size_t room, int Co, i
     for (int i = 0; i < 9; ++i) { tl.tap[i] = i < ntaps ? taps[i] : 0; sig = sig * 31 + tl.tap[i]; }
     bool fill = true;
     const PackKey key{g_pack_token, W, 2, Co, C, T, Kp, Mp, sig};
-    if (float* slot = pack_slot(key, room, fill)) dst = slot;
+    if (float* slot = pack_slot(key, room, fill, 0, &tl)) dst = slot;
     if (fill) {
         const long long total = (long long)Kp * Mp;
         hipLaunchKernelGGL(pack_taps_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, W, dst, Co, C, T, tl, Kp, Mp);
@@ -215,6 +236,106 @@ extern "C" int cnuda_pack_cache_attach(void* arena, size_t bytes) {
     if (!arena) cnuda::g_pack_arena = nullptr;
     return 0;
 }
+// ---------------------------------------------------------------------------
+// Refresh after an optimizer step: every cached image whose source lies in the optimizer's parameter arena and
+// that was current in the epoch that just ended is rebuilt by ONE launch (a table of pack jobs, one workgroup per
+// 2048 elements) and stamped with the new epoch -- instead of ~150 five-microsecond launches spread over the next
+// step, each of which leaves the chip idle.
+// ---------------------------------------------------------------------------
+namespace cnuda {
+namespace {
+struct PackJob {
+    const float* src;
+    float* dst;
+    int mode, Co, C, T, Kp, Mp, cpad, ntaps;
+    int taps[9];
+    unsigned block0;          // first workgroup of this job
+};
+constexpr int PJ_PER_BLOCK = 2048;
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    // the job whose block range holds blockIdx.x (jobs are sorted by block0)
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJob j = jobs[lo];
+    const long long total = (long long)j.Kp * j.Mp;
+    const long long base = (long long)(blockIdx.x - j.block0) * PJ_PER_BLOCK;
+    for (int t = threadIdx.x; t < PJ_PER_BLOCK; t += 256) {
+        const long long i = base + t;
+        if (i >= total) break;
+        const int k = (int)(i / j.Mp), m = (int)(i % j.Mp);
+        float v = 0.0f;
+        if (j.mode == PACK_FWD) {
+            if (k < j.T * j.C && m < j.Co) v = j.src[((size_t)m * j.C + k % j.C) * j.T + k / j.C];
+        } else if (j.mode == PACK_DGRAD) {
+            if (k < j.T * j.cpad && m < j.C) {
+                const int tap = k / j.cpad, o = k % j.cpad;
+                if (o < j.Co) v = j.src[((size_t)o * j.C + m) * j.T + tap];
+            }
+        } else {
+            if (k < j.ntaps * j.Co && m < j.C) {
+                const int ti = k / j.Co, o = k - ti * j.Co;
+                v = j.src[((size_t)o * j.C + m) * j.T + j.taps[ti]];
+            }
+        }
+        j.dst[i] = v;
+    }
+}
+std::vector<PackJob> g_refresh_jobs;
+unsigned g_refresh_blocks = 0;
+}  // namespace
+}  // namespace cnuda
+
+extern "C" int cnuda_pack_refresh(const void* params, size_t params_bytes, unsigned long long old_epoch,
+                                  unsigned long long new_epoch, void* table, size_t table_bytes,
+                                  cnuda_stream_t stream) {
+    using namespace cnuda;
+    std::lock_guard<std::mutex> lock(g_pack_mutex);
+    if (!g_pack_arena || g_pack_slots.empty()) return 0;
+    const char* lo = static_cast<const char*>(params);
+    const char* hi = lo + params_bytes;
+    hipStream_t st = (hipStream_t)stream;
+    // jobs: slots whose source lies inside the arena and whose image was current in the epoch that just ended
+    // (anything else refills lazily on its next use)
+    std::vector<PackSlot*> live;
+    std::vector<PackJob> jobs;
+    unsigned blocks = 0;
+    for (auto& kv : g_pack_slots) {
+        const char* src = static_cast<const char*>(kv.first.src);
+        if (src < lo || src >= hi || kv.first.token == 0) continue;
+        if ((kv.second.version >> 32) != (old_epoch & 0xffffffffull)) continue;
+        live.push_back(&kv.second);
+        PackJob j;
+        memset(&j, 0, sizeof(j));
+        j.src = static_cast<const float*>(kv.first.src);
+        j.dst = reinterpret_cast<float*>(g_pack_arena + kv.second.offset);
+        j.mode = kv.first.mode; j.Co = kv.first.Co; j.C = kv.first.C; j.T = kv.first.T;
+        j.Kp = kv.first.Kp; j.Mp = kv.first.Mp; j.cpad = kv.second.cpad; j.ntaps = kv.second.ntaps;
+        for (int i = 0; i < 9; ++i) j.taps[i] = kv.second.taps[i];
+        j.block0 = blocks;
+        jobs.push_back(j);
+        blocks += (unsigned)(((long long)kv.first.Kp * kv.first.Mp + PJ_PER_BLOCK - 1) / PJ_PER_BLOCK);
+    }
+    if (live.empty()) return 0;
+    // the table only changes when the set of live slots does: upload it then, reuse the device copy otherwise
+    if (jobs.size() != g_refresh_jobs.size() ||
+        memcmp(jobs.data(), g_refresh_jobs.data(), jobs.size() * sizeof(PackJob)) != 0) {
+        CNUDA_REQUIRE(table && jobs.size() * sizeof(PackJob) <= table_bytes,
+                      "cnuda_pack_refresh: job table needs %zu bytes", jobs.size() * sizeof(PackJob));
+        g_refresh_jobs = jobs;        // (the copy below reads this vector: it must outlive the call)
+        if (hipMemcpyAsync(table, g_refresh_jobs.data(), g_refresh_jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice,
+                           st) != hipSuccess)
+            return check_launch("cnuda_pack_refresh(table)");
+        g_refresh_blocks = blocks;
+    }
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(g_refresh_blocks), dim3(256), 0, st, static_cast<const PackJob*>(table),
+                       (int)g_refresh_jobs.size());
+    for (PackSlot* sl : live) sl->version = ((new_epoch & 0xffffffffull) << 32) | (sl->version & 0xffffffffull);
+    return check_launch("cnuda_pack_refresh");
+}
+
 extern "C" int cnuda_pack_stamp(unsigned long long token, unsigned long long version) {
     cnuda::g_pack_token = token;
     cnuda::g_pack_version = version;

@@ -114,6 +114,7 @@ class _Sig:
     cnuda_get_matrix_mode = (_I, [])
     cnuda_pack_cache_attach = (_I, [_P, c_size_t])
     cnuda_pack_stamp = (_I, [ctypes.c_ulonglong, ctypes.c_ulonglong])
+    cnuda_pack_refresh = (_I, [_P, ctypes.c_size_t, ctypes.c_ulonglong, ctypes.c_ulonglong, _P, ctypes.c_size_t, _P])
     cnuda_pack_cache_used = (c_size_t, [])
     cnuda_prof_enable = (_I, [_I])
     cnuda_prof_arm = (_I, [_I])
@@ -130,9 +131,18 @@ class _Sig:
 _PARAM_EPOCH = 0
 
 
-def bump_param_epoch():
+def bump_param_epoch(rewritten=None):
+    """`rewritten`: the flat tensor whose contents just changed (the fused Adam's parameter arena).  Every packed weight
+    image of the pack cache that was built from it in the epoch that ends here is rebuilt by one launch and carried
+    into the new epoch (cnuda_pack_refresh) -- instead of ~150 small pack launches spread over the next step."""
     global _PARAM_EPOCH
+    old = _PARAM_EPOCH
     _PARAM_EPOCH += 1
+    if rewritten is not None and rewritten.is_cuda and _PACK['arena'] is not None and not _PACK['off']:
+        if _PACK.get('table') is None or _PACK['table'].device != rewritten.device:
+            _PACK['table'] = torch.empty(1 << 18, dtype=torch.uint8, device=rewritten.device)
+        check(lib().cnuda_pack_refresh(ptr(rewritten), rewritten.numel() * rewritten.element_size(), old, _PARAM_EPOCH,
+                                       ptr(_PACK['table']), _PACK['table'].numel(), stream()), 'pack_refresh')
 
 
 def param_state_key(module):

@@ -54,7 +54,8 @@ class Adam(torch.optim.Optimizer):
         for p in a.params:
             self.state[p]['step'].fill_(float(self._step))
         from . import bump_param_epoch
-        bump_param_epoch()          # the kernel wrote the flat arena: torch's version counters did not move
+        # the kernel wrote the flat arena: torch's version counters did not move; cached packed weights follow
+        bump_param_epoch(a.flat_param)
         return loss
 
     def load_state_dict(self, state_dict):

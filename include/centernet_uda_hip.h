@@ -59,6 +59,13 @@ int cnuda_get_matrix_mode(void);
 int cnuda_pack_cache_attach(void* arena, size_t bytes);
 int cnuda_pack_stamp(unsigned long long token, unsigned long long version);
 size_t cnuda_pack_cache_used(void);
+/* After an optimizer step that rewrote [params, params + params_bytes) behind the callers' version counters: every
+ * cached image whose source lies in that range and that was current in epoch `old_epoch` (the high 32 bits of the
+ * version it was stamped with) is rebuilt by ONE launch on `stream` and re-stamped with `new_epoch` (low 32 bits
+ * kept).  `table`: >= 96 bytes per cached image of device scratch that stays valid until the next call (the job
+ * list; rewritten only when the set of images changes).  No reference counterpart. */
+int cnuda_pack_refresh(const void* params, size_t params_bytes, unsigned long long old_epoch,
+                       unsigned long long new_epoch, void* table, size_t table_bytes, cnuda_stream_t stream);
 
 /* Measurement aid (bench.py roofline leg), not part of the reference's surface:
  * cnuda_prof_enable(n) pre-creates n hipEvent pairs; cnuda_prof_arm(tag) makes

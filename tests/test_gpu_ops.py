@@ -246,3 +246,39 @@ def test_pack_cache_follows_the_weights():
     xr = x.cpu().requires_grad_(True)
     F.conv2d(xr, conv.weight.detach().cpu(), conv.bias.detach().cpu(), 1, 1).sum().backward()
     _close(xg.grad, xr.grad)
+
+
+def test_pack_refresh_after_the_fused_adam_step():
+    """After optim.Adam.step() every cached packed image built from the parameter arena is rebuilt by one launch and
+    carried into the new parameter epoch (cnuda_pack_refresh): a few training steps of a small stack (3x3, strided,
+    1x1 and transposed-conv input gradients: all three pack kinds) give the same losses and weights, bit for bit, as
+    the same steps with the cache off, and the forward after a step is served without a new slot."""
+    import hip_runtime as hr
+    from hip_runtime import nn as hnn, optim
+
+    def run(cache_off):
+        was = hr._PACK['off']
+        hr._PACK['off'] = cache_off
+        try:
+            torch.manual_seed(5)
+            net = torch.nn.Sequential(hnn.Conv2d(16, 32, 3, padding=1), hnn.Conv2d(32, 64, 3, stride=2, padding=1),
+                                      hnn.Conv2d(64, 27, 3, padding=1), hnn.Conv2d(27, 16, 1)).to(DEV)
+            opt = optim.Adam(net.parameters(), lr=1e-2)
+            x = torch.randn(4, 16, 20, 24, generator=torch.Generator().manual_seed(6)).to(DEV)
+            losses, used = [], []
+            for _ in range(4):
+                opt.zero_grad()
+                loss = net(x).square().mean()
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+                used.append(hr.lib().cnuda_pack_cache_used())
+            return losses, [p.detach().clone() for p in net.parameters()], used
+        finally:
+            hr._PACK['off'] = was
+    l_on, p_on, used = run(False)
+    l_off, p_off, _ = run(True)
+    assert l_on == l_off
+    assert all(torch.equal(a, b) for a, b in zip(p_on, p_off))
+    assert l_on[-1] < l_on[0]                      # the steps did move the weights
+    assert used[0] > 0 and used[1] == used[-1]     # steady state: no new slots after the first step
