@@ -86,11 +86,24 @@ struct ConvFwdLoader {
         float* base;
         const float* res;
         int HoWo;
+        // buffer form of `base` for the plain-store epilogue (igemm.cuh): descriptor over y, per-lane byte offset of
+        // (image, row 0, pixel), bytes per output row
+        buf_rsrc rs;
+        unsigned voff;
+        int row_bytes;
+        static constexpr bool kBufStore = true;
+        __device__ static bool buf_ok(const Params& p) {
+            return !p.bias && !p.residual && p.act_slope < 0.0f &&
+                   (size_t)p.g.B * p.g.Co * p.g.Ho * p.g.Wo * sizeof(float) < IG_BUF_OOB;
+        }
         __device__ Out(const Params& p, long long n) {
             HoWo = p.g.Ho * p.g.Wo;
             const int ni = (int)n, b = ni / HoWo, pp = ni - b * HoWo;
             base = p.y + (size_t)b * p.g.Co * HoWo + pp;
             res = p.residual ? p.residual + (size_t)b * p.g.Co * HoWo + pp : nullptr;
+            rs = ig_make_rsrc(p.y, (unsigned)((size_t)p.g.B * p.g.Co * HoWo * sizeof(float)));
+            voff = (unsigned)(b * p.g.Co * HoWo + pp) * 4u;
+            row_bytes = HoWo * 4;
         }
         __device__ __forceinline__ void store(const Params& p, int m, float v) {
             if (p.bias) v += p.bias[m];
@@ -226,10 +239,20 @@ struct ConvDgradLoader {
     struct Out {
         float* base;
         int HW;
+        buf_rsrc rs;            // buffer form of `base` (see ConvFwdLoader::Out)
+        unsigned voff;
+        int row_bytes;
+        static constexpr bool kBufStore = true;
+        __device__ static bool buf_ok(const Params& p) {
+            return (size_t)p.g.B * p.g.C * p.g.H * p.g.W * sizeof(float) < IG_BUF_OOB;
+        }
         __device__ Out(const Params& p, long long n) {
             HW = p.g.H * p.g.W;
             const int ni = (int)n, b = ni / HW, pp = ni - b * HW;
             base = p.gx + (size_t)b * p.g.C * HW + pp;
+            rs = ig_make_rsrc(p.gx, (unsigned)((size_t)p.g.B * p.g.C * HW * sizeof(float)));
+            voff = (unsigned)(b * p.g.C * HW + pp) * 4u;
+            row_bytes = HW * 4;
         }
         __device__ __forceinline__ void store(const Params&, int m, float v) { base[(size_t)m * HW] = v; }
         static constexpr bool kVec4 = true;
@@ -619,6 +642,16 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     const int n_tiles = ceil_div(N, IG_BN), m_tiles = Mp / bm;
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
     ProfScope prof(st);
+    if constexpr (Loader::Out::kVec4 && !Loader::kHasSideOutput) {
+        // few chunks, several row tiles (the DCN column-gradient GEMM: K = 64, 9*C rows): B-stationary kernel
+        static const bool shortk = !(getenv("CNUDA_SHORTK") && getenv("CNUDA_SHORTK")[0] == '0');
+        if (shortk && matrix_mode() == 0 && bm == 128 && Kp <= 64 && m_tiles >= 2) {
+            prof.name("igemm_fwd_shortk_kernel<128, %s, 64>", Loader::name());
+            hipLaunchKernelGGL((igemm_fwd_shortk_kernel<128, Loader, 64>), dim3(n_tiles), block, 0, st, p, A, Mp, Kp, M, N,
+                               n_tiles, m_tiles);
+            return check_launch(who);
+        }
+    }
     const bool ws = matrix_mode() == 0 && wave_specialised() && bm >= 64;
     prof.name(matrix_mode() == 1 ? "igemm_fwd_kernel<%d, %s> [split bf16 x3]"
                                  : (ws ? "igemm_fwd_ws_kernel<%d, %s>" : "igemm_fwd_kernel<%d, %s>"), bm, Loader::name());

@@ -286,6 +286,7 @@ struct DcnFwdLoaderT {
             base[(size_t)m * HoWo] = v;
         }
         static constexpr bool kVec4 = true;      // 16-byte epilogue (igemm.cuh)
+        static constexpr bool kBufStore = false; // (always adds the bias)
         __device__ static bool vec4_ok(const Params& p) { return ((p.g.Ho * p.g.Wo) & 3) == 0; }
         __device__ __forceinline__ void store4(const Params& p, int m, f32x4 v) {
             v += p.bias[m];
@@ -383,6 +384,7 @@ struct DcnColsLoader {
             base[(size_t)m * HoWo] = v;
         }
         static constexpr bool kVec4 = true;      // 16-byte epilogue (igemm.cuh)
+        static constexpr bool kBufStore = false; // (always adds the bias)
         __device__ static bool vec4_ok(const Params& p) { return ((p.g.Ho * p.g.Wo) & 3) == 0; }
         __device__ __forceinline__ void store4(const Params& p, int m, f32x4 v) {
             v += p.bias[m];
