@@ -271,7 +271,9 @@ def pmc_traffic(kernel_name):
     path = files[-1]
     data = json.load(open(path))
     meta = data.get('_meta', {})
-    norm = lambda k: k.replace(' ', '')
+    import re
+    # (profiler names carry the template defaults the library's own kernel names leave out)
+    norm = lambda k: re.sub(r',(true|false)(,16)?>$', '>', k.replace(' ', ''))
     t = {norm(k): v for k, v in data.items() if k != '_meta'}.get(norm(kernel_name.split(' (')[0].split(' [')[0]))
     if not t:
         return None, '%s has no entry for this kernel' % os.path.basename(path)

@@ -44,7 +44,7 @@ for r in rows:
 launches = sum(int(r['Calls']) for r in rows) // STEPS
 busy = None
 for k, v in mfma.items():
-    if 'igemm_fwd_ws_kernel<128' in k and 'ConvFwdLoader' in k:
+    if 'igemm_fwd_ws_kernel<128' in k and 'ConvFwd' in k:
         busy = v['mfma_util']
 d, inf, cb, sp = line['decode_latency'], line['inference'], line['cpu_baseline'], line['matrix_mode_split']
 

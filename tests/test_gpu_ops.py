@@ -282,3 +282,35 @@ def test_pack_refresh_after_the_fused_adam_step():
     assert all(torch.equal(a, b) for a, b in zip(p_on, p_off))
     assert l_on[-1] < l_on[0]                      # the steps did move the weights
     assert used[0] > 0 and used[1] == used[-1]     # steady state: no new slots after the first step
+
+
+def test_tensors_of_2gib_take_the_pointer_loaders():
+    """The buffer-addressed loaders carry 32-bit byte offsets with a sentinel at 2 GiB (csrc/igemm.cuh); an input of
+    2.2 GiB must fall back to the pointer-addressed loaders by itself.  Checked without a CPU reference: a crop of the
+    big input goes through the buffer path, and away from the crop's border both give the same numbers -- forward, and
+    the input / weight gradients of a loss that only looks at a window inside the crop."""
+    from hip_runtime import ops
+    g = torch.Generator().manual_seed(33)
+    C, Co, S = 32, 32, 4200                                   # 32 * 4200^2 * 4 B = 2.26 GB
+    x = torch.empty(1, C, S, S, device=DEV).uniform_(-1, 1).requires_grad_(True)
+    w = (torch.randn(Co, C, 3, 3, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    assert x.numel() * 4 > 2 ** 31
+    r0, r1 = 1000, 1000 + 96
+    r = torch.randn(1, Co, r1 - r0 - 2, r1 - r0 - 2, generator=g).to(DEV)
+    y_big = ops.conv2d(x, w, None, 1, 1)
+    (y_big[:, :, r0 + 1:r1 - 1, r0 + 1:r1 - 1] * r).sum().backward()
+    gx_big, gw_big = x.grad[:, :, r0:r1, r0:r1].clone(), w.grad.clone()
+    crop = x.detach()[:, :, r0:r1, r0:r1].contiguous().requires_grad_(True)
+    w2 = w.detach().clone().requires_grad_(True)
+    y_crop = ops.conv2d(crop, w2, None, 1, 1)
+    (y_crop[:, :, 1:-1, 1:-1] * r).sum().backward()
+    a, b = y_big.detach()[:, :, r0 + 1:r1 - 1, r0 + 1:r1 - 1], y_crop.detach()[:, :, 1:-1, 1:-1]
+    assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+    assert (gx_big - crop.grad).abs().max().item() <= 1e-5 * crop.grad.abs().max().item()
+    assert (gw_big - w2.grad).abs().max().item() <= 1e-4 * w2.grad.abs().max().item()
+    # the image corner (padding) of the big tensor against a small problem cut from the same corner
+    with torch.no_grad():
+        y0 = ops.conv2d_infer(x.detach()[:, :, :64, :64].contiguous(), w.detach(), None, 1, 1)
+    assert (y_big.detach()[:, :, :63, :63] - y0[:, :, :63, :63]).abs().max().item() <= 1e-5 * y0.abs().max().item()
+    del y_big, y_crop, x, gx_big
+    torch.cuda.empty_cache()
