@@ -620,13 +620,15 @@ ConvPlan make_plan(const ConvGeom& g) {
     static const bool tall = !(getenv("CNUDA_WGRAD_TALL") && getenv("CNUDA_WGRAD_TALL")[0] == '0');
     const bool wbuf = wgrad_buffer_ok(g);     // (ConvWBufLoader only)
     q.wbm = g.Co <= 32 ? 32 : ((tall && wbuf && q.wbj == 64 && g.C % 64 == 0 && g.Co % 128 == 0) ? 128 : 64);
+    // 128 x 128 (2 x 2 accumulator tiles per wave: one fragment dword per MFMA instead of 1.5, 32 loads per 64 MFMAs
+    // instead of 24 per 32 -- the 64 x 128 tile runs into the LDS: ~2300 LDS cycles per 2048-cycle chunk with three
+    // workgroups per CU) where both extents allow it
+    static const bool big = !(getenv("CNUDA_WGRAD_BIG") && getenv("CNUDA_WGRAD_BIG")[0] == '0');
+    if (big && wbuf && q.wbm == 64 && q.wbj == 128 && g.C % 64 == 0 && g.Co % 128 == 0) q.wbm = 128;
     q.Mpw = round_up(g.Co, q.wbm);
     q.Jp = round_up(q.Kf, q.wbj);
     const long long tiles = (long long)(q.Mpw / q.wbm) * (q.Jp / q.wbj);
-    long long z = (1024 + tiles - 1) / tiles;
-    const long long max_z = (q.Nf + WG_BP - 1) / WG_BP;
-    if (z > max_z) z = max_z;
-    if (z < 1) z = 1;
+    const long long z = wgrad_splits(tiles, q.wbm, q.wbj, (q.Nf + WG_BP - 1) / WG_BP);
     q.pix_per_split = ((q.Nf + z - 1) / z + WG_BP - 1) / WG_BP * WG_BP;
     q.Z = (int)((q.Nf + q.pix_per_split - 1) / q.pix_per_split);
     q.fwd_bytes = carve_bytes(ig_a_bytes(q.Kpf, q.Mpf), 1) + 256;
@@ -833,7 +835,26 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
                   buf ? "ConvWBufLoader" : (fast ? "ConvWLoader<2>" : "ConvWLoader<0>"), q.wbm, q.wbj);
         if (buf) {
             const dim3 blk2(2 * IG_THREADS);
-            if (q.wbm == 128 && wave_specialised())
+            static const bool wdeep = getenv("CNUDA_WGRAD_DEEP") && getenv("CNUDA_WGRAD_DEEP")[0] == '1';
+            if (wdeep && wave_specialised() && q.wbm == 128 && q.wbj == 128)
+                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 128, true>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else if (wdeep && wave_specialised() && q.wbm == 64 && q.wbj == 128)
+                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 128, true>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else if (wdeep && wave_specialised() && q.wbm == 128)
+                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 64, true>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else if (wdeep && wave_specialised() && q.wbm == 64)
+                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 64, true>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else if (q.wbm == 128 && q.wbj == 128 && wave_specialised())
+                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else if (q.wbm == 128 && q.wbj == 128)
+                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWBufLoader, 128, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                                   q.Jp, q.Nf, q.pix_per_split);
+            else if (q.wbm == 128 && wave_specialised())
                 hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
             else if (q.wbm == 128)

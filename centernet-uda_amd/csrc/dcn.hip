@@ -997,11 +997,9 @@ DcnPlan make_plan(const DcnGeom& g) {
     q.Jp = round_up(q.K, WG_BJ);
     q.N = (long long)g.B * g.Ho * g.Wo;
     // enough pixel splits to fill the chip (>= ~1024 workgroups), each a multiple of the chunk
-    const long long tiles = (long long)(q.Mpw / WG_BM) * (q.Jp / WG_BJ);
-    long long z = (1024 + tiles - 1) / tiles;
-    const long long max_z = (q.N + WG_BP - 1) / WG_BP;
-    if (z > max_z) z = max_z;
-    if (z < 1) z = 1;
+    const int wbj = q.Jp % 128 == 0 ? 128 : WG_BJ;     // (the launch below picks the 64 x 128 tile the same way)
+    const long long tiles = (long long)(q.Mpw / WG_BM) * (q.Jp / wbj);
+    const long long z = wgrad_splits(tiles, WG_BM, wbj, (q.N + WG_BP - 1) / WG_BP);
     q.pix_per_split = ((q.N + z - 1) / z + WG_BP - 1) / WG_BP * WG_BP;
     q.Z = (int)((q.N + q.pix_per_split - 1) / q.pix_per_split);
     q.fwd_two_kernels = q.Mp / q.bm > 1;

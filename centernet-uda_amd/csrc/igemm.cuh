@@ -810,8 +810,11 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
     typename WLoader::Params p, float* __restrict__ slabs, int Mp, int Jp, long long N, long long pix_per_split) {
     constexpr int GLD = BM + 1, BLD = BJ + 1;          // odd row strides: conflict-free pixel-major stores
     constexpr int STEP = IG_THREADS / WG_BP;            // rows (channels / columns) covered per pass
-    constexpr int TJ = (BM / 32) * (BJ / 32) / 4;       // 32x32 accumulator tiles per wave, side by side along j
+    // 32x32 accumulator tiles per wave: TM x TJ (2 x 2 for the 128 x 128 tile: 4 fragment dwords per 4 MFMAs; else one
+    // row of tiles side by side along j)
+    constexpr int TM = (BM == 128 && BJ == 128) ? 2 : 1, TJ = (BM / 32) * (BJ / 32) / 4 / TM;
     constexpr int WJ = BJ / 32 / TJ, NG = BM / STEP, NB = BJ / STEP;
+    static_assert((BM / 32 / TM) * WJ == 4, "four waves tile the block");
     // two LDS stages, one barrier per pixel chunk (32 pixels): chunk k+1 is stored while chunk k is consumed
     __shared__ float Gs[2][WG_BP * GLD];
     __shared__ float Bs[2][WG_BP * BLD];
@@ -821,13 +824,15 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
     long long n_end = n_begin + pix_per_split;
     if (n_end > N) n_end = N;
     const int pl = tid % WG_BP, sub = tid / WG_BP;  // pixel within chunk, row phase (0..STEP-1)
-    const int wm_off = (wid / WJ) * 32, wj_off = (wid % WJ) * 32 * TJ;
+    const int wm_off = (wid / WJ) * 32 * TM, wj_off = (wid % WJ) * 32 * TJ;
     WLoader ld(p, n_begin + pl, n_end);
-    f32x16 acc[TJ];
+    f32x16 acc[TM][TJ];
 #pragma unroll
-    for (int t = 0; t < TJ; ++t)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int t = 0; t < TJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.0f;
     float rg[NG], rb[NB];
     auto stage_store = [&](int buf) {
 #pragma unroll
@@ -849,18 +854,21 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
         {   // fragments of the next two k-steps are in flight while this pair's MFMAs run (see ig_mma_chunk)
             const float* gp = Gs[cur] + kl * GLD + wm_off + il;
             const float* bp = Bs[cur] + kl * BLD + wj_off + il;
-            float a[2][2], b[2][2][TJ];
-            auto frag = [&](int kk, float (&fa)[2], float (&fb)[2][TJ]) {
-                fa[0] = gp[kk * GLD]; fa[1] = gp[(kk + 2) * GLD];
+            float a[2][2][TM], b[2][2][TJ];
+            auto frag = [&](int kk, float (&fa)[2][TM], float (&fb)[2][TJ]) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { fa[0][i] = gp[kk * GLD + i * 32]; fa[1][i] = gp[(kk + 2) * GLD + i * 32]; }
 #pragma unroll
                 for (int t = 0; t < TJ; ++t) { fb[0][t] = bp[kk * BLD + t * 32]; fb[1][t] = bp[(kk + 2) * BLD + t * 32]; }
             };
-            auto mma = [&](const float (&fa)[2], const float (&fb)[2][TJ]) {
+            auto mma = [&](const float (&fa)[2][TM], const float (&fb)[2][TJ]) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int t = 0; t < TJ; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h], fb[h][t], acc[t], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int t = 0; t < TJ; ++t)
+                            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][i], fb[h][t], acc[i][t], 0, 0, 0);
             };
             frag(0, a[0], b[0]);
 #pragma unroll
@@ -884,25 +892,28 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
     }
     float* slab = slabs + (size_t)blockIdx.z * Mp * Jp;
 #pragma unroll
-    for (int t = 0; t < TJ; ++t)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm_off + mfma_row(r, lane);
-            const int j = j0 + wj_off + t * 32 + (lane & 31);
-            slab[(size_t)m * Jp + j] = acc[t][r];
-        }
+        for (int t = 0; t < TJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm_off + i * 32 + mfma_row(r, lane);
+                const int j = j0 + wj_off + t * 32 + (lane & 31);
+                slab[(size_t)m * Jp + j] = acc[i][t][r];
+            }
 }
 
 // Wave-specialised weight-gradient kernel (see igemm_fwd_ws_kernel): threads 256..511 run the two loaders and the
 // LDS stores, threads 0..255 only read fragments and issue MFMAs.  Same tiles, LDS image and slab output as
 // igemm_wgrad_kernel.
-template <class WLoader, int BM, int BJ>
+template <class WLoader, int BM, int BJ, bool DEEP = false>
 __global__ __launch_bounds__(2 * IG_THREADS) void igemm_wgrad_ws_kernel(
     typename WLoader::Params p, float* __restrict__ slabs, int Mp, int Jp, long long N, long long pix_per_split) {
     constexpr int GLD = BM + 1, BLD = BJ + 1;
     constexpr int STEP = IG_THREADS / WG_BP;
-    constexpr int TJ = (BM / 32) * (BJ / 32) / 4;
+    constexpr int TM = (BM == 128 && BJ == 128) ? 2 : 1, TJ = (BM / 32) * (BJ / 32) / 4 / TM;     // see igemm_wgrad_kernel
     constexpr int WJ = BJ / 32 / TJ, NG = BM / STEP, NB = BJ / STEP;
+    static_assert((BM / 32 / TM) * WJ == 4, "four waves tile the block");
     __shared__ float Gs[2][WG_BP * GLD];
     __shared__ float Bs[2][WG_BP * BLD];
     const bool producer = threadIdx.x >= IG_THREADS;            // wave-uniform
@@ -914,56 +925,86 @@ __global__ __launch_bounds__(2 * IG_THREADS) void igemm_wgrad_ws_kernel(
     if (producer) {
         const int pl = tid % WG_BP, sub = tid / WG_BP;
         WLoader ld(p, n_begin + pl, n_end);
-        float rg[NG], rb[NB];
-        auto stage_store = [&](int buf) {
+        struct Regs { float rg[NG], rb[NB]; };
+        auto stage_store = [&](int buf, const Regs& r) {
 #pragma unroll
-            for (int i = 0; i < NG; ++i) Gs[buf][pl * GLD + sub + STEP * i] = rg[i];
+            for (int i = 0; i < NG; ++i) Gs[buf][pl * GLD + sub + STEP * i] = r.rg[i];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) Bs[buf][pl * BLD + sub + STEP * i] = rb[i];
+            for (int i = 0; i < NB; ++i) Bs[buf][pl * BLD + sub + STEP * i] = r.rb[i];
         };
-        auto stage_load = [&]() {
-            ld.template load_g<NG, STEP>(m0, sub, rg);
-            ld.template load_b<NB, STEP>(j0, sub, rb);
+        auto stage_load = [&](Regs& r) {
+            ld.template load_g<NG, STEP>(m0, sub, r.rg);
+            ld.template load_b<NB, STEP>(j0, sub, r.rb);
         };
-        stage_load();
-        stage_store(0);
-        if (n_begin + WG_BP < n_end) { ld.advance(); stage_load(); }
+        const int nchunk = (int)((n_end - n_begin + WG_BP - 1) / WG_BP);
+        Regs r0, r1;
+        if (DEEP) {
+            // two register stages: the loads of chunk c + 2 are issued before chunk c + 1 is stored, i.e. two chunks of
+            // MFMA time (~1.7 us) before anybody waits for them -- 24-32 loads per thread and chunk from two tensors
+            stage_load(r0);
+            stage_store(0, r0);
+            if (1 < nchunk) { ld.advance(); stage_load(r1); }
+            if (2 < nchunk) { ld.advance(); stage_load(r0); }
+            __syncthreads();
+            for (int c = 0; c < nchunk; c += 2) {
+                if (c + 1 < nchunk) {
+                    stage_store(1, r1);
+                    if (c + 3 < nchunk) { ld.advance(); stage_load(r1); }
+                }
+                __syncthreads();
+                if (c + 1 >= nchunk) break;
+                if (c + 2 < nchunk) {
+                    stage_store(0, r0);
+                    if (c + 4 < nchunk) { ld.advance(); stage_load(r0); }
+                }
+                __syncthreads();
+            }
+            return;
+        }
+        stage_load(r0);
+        stage_store(0, r0);
+        if (1 < nchunk) { ld.advance(); stage_load(r0); }
         __syncthreads();
         int cur = 0;
-        for (long long nb = n_begin; nb < n_end; nb += WG_BP) {
-            if (nb + WG_BP < n_end) {
-                stage_store(cur ^ 1);
-                if (nb + 2 * WG_BP < n_end) { ld.advance(); stage_load(); }
+        for (int c = 0; c < nchunk; ++c) {
+            if (c + 1 < nchunk) {
+                stage_store(cur ^ 1, r0);
+                if (c + 2 < nchunk) { ld.advance(); stage_load(r0); }
             }
             __syncthreads();
             cur ^= 1;
         }
         return;
     }
-    const int wm_off = (wid / WJ) * 32, wj_off = (wid % WJ) * 32 * TJ;
-    f32x16 acc[TJ];
+    const int wm_off = (wid / WJ) * 32 * TM, wj_off = (wid % WJ) * 32 * TJ;
+    f32x16 acc[TM][TJ];
 #pragma unroll
-    for (int t = 0; t < TJ; ++t)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int t = 0; t < TJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.0f;
     __syncthreads();
     int cur = 0;
     const int kl = lane >> 5, il = lane & 31;
     for (long long nb = n_begin; nb < n_end; nb += WG_BP) {
         const float* gp = Gs[cur] + kl * GLD + wm_off + il;
         const float* bp = Bs[cur] + kl * BLD + wj_off + il;
-        float a[2][2], b[2][2][TJ];
-        auto frag = [&](int kk, float (&fa)[2], float (&fb)[2][TJ]) {
-            fa[0] = gp[kk * GLD]; fa[1] = gp[(kk + 2) * GLD];
+        float a[2][2][TM], b[2][2][TJ];
+        auto frag = [&](int kk, float (&fa)[2][TM], float (&fb)[2][TJ]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { fa[0][i] = gp[kk * GLD + i * 32]; fa[1][i] = gp[(kk + 2) * GLD + i * 32]; }
 #pragma unroll
             for (int t = 0; t < TJ; ++t) { fb[0][t] = bp[kk * BLD + t * 32]; fb[1][t] = bp[(kk + 2) * BLD + t * 32]; }
         };
-        auto mma = [&](const float (&fa)[2], const float (&fb)[2][TJ]) {
+        auto mma = [&](const float (&fa)[2][TM], const float (&fb)[2][TJ]) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int t = 0; t < TJ; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h], fb[h][t], acc[t], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int t = 0; t < TJ; ++t)
+                        acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][i], fb[h][t], acc[i][t], 0, 0, 0);
         };
         frag(0, a[0], b[0]);
 #pragma unroll
@@ -982,13 +1023,15 @@ __global__ __launch_bounds__(2 * IG_THREADS) void igemm_wgrad_ws_kernel(
     }
     float* slab = slabs + (size_t)blockIdx.z * Mp * Jp;
 #pragma unroll
-    for (int t = 0; t < TJ; ++t)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm_off + mfma_row(r, lane);
-            const int j = j0 + wj_off + t * 32 + (lane & 31);
-            slab[(size_t)m * Jp + j] = acc[t][r];
-        }
+        for (int t = 0; t < TJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm_off + i * 32 + mfma_row(r, lane);
+                const int j = j0 + wj_off + t * 32 + (lane & 31);
+                slab[(size_t)m * Jp + j] = acc[i][t][r];
+            }
 }
 
 }  // namespace cnuda

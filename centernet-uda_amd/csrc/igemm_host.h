@@ -1,6 +1,8 @@
 // Host-side helpers shared by conv.hip and dcn.hip (packing of the small weight
 // operand, split-K slab reduction, workspace carving).
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace cnuda {
@@ -11,6 +13,18 @@ enum PackMode {
 };
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
+
+// Pixel splits of a weight-gradient launch: the workgroup count (tiles x splits) should fill the chip's resident
+// slots a whole number of times -- 256 CUs x the workgroups of that tile shape one CU holds (set by the tile's LDS
+// image: 64x64 33 KB -> 4, 64x128 / 128x64 / 32x128 50 / 50 / 41 KB -> 3, 128x128 66 KB -> 2).  The flat target of
+// 1024 workgroups left the three-per-CU shapes with 1.33 rounds: a second round on a third of the chip.
+inline long long wgrad_splits(long long tiles, int bm, int bj, long long max_z) {
+    static const int rounds = getenv("CNUDA_WGRAD_ROUNDS") ? atoi(getenv("CNUDA_WGRAD_ROUNDS")) : 1;
+    const int per_cu = (bm == 128 && bj == 128) ? 2 : ((bm == 64 && bj == 64) ? 4 : 3);
+    long long z = rounds > 0 ? (256ll * per_cu * rounds) / tiles : (1024 + tiles - 1) / tiles;   // rounds = 0: round 1's rule
+    if (z > max_z) z = max_z;
+    return z < 1 ? 1 : z;
+}
 
 // W is the reference layout [Co][C][T] (T = kh*kw).  The packed image is [Kp][Mp], zero padded.  Returns the
 // buffer the GEMM must read: `dst` (the caller's workspace, freshly packed) or -- when the caller announced a
