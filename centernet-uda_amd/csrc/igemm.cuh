@@ -291,6 +291,9 @@ __device__ __forceinline__ void ig_epilogue_vec4(const typename Loader::Params& 
         // per 16-byte store instead of ~37 (64-bit address arithmetic), which the matrix pipe of the CU's other
         // workgroup gets back (a quarter of the run time of the K = 64 column-gradient GEMM).
         if (Loader::Out::buf_ok(p)) {
+            // (the compiler cannot see that a wave's tile row is uniform: without this every store becomes a loop over
+            // the "distinct" scalar offsets of the wave)
+            const int mrow0 = __builtin_amdgcn_readfirstlane(m0 + wm_off);
 #pragma unroll
             for (int j = 0; j < T::TN; ++j) {
                 const long long n = n0 + wn_off + j * 32 + 4 * cg;
@@ -304,7 +307,7 @@ __device__ __forceinline__ void ig_epilogue_vec4(const typename Loader::Params& 
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (it * 8 + rsub) * IG_EPI_LD + 4 * cg);
-                        const int mb = m0 + wm_off + i * 32 + it * 8;                 // wave-uniform
+                        const int mb = mrow0 + i * 32 + it * 8;                       // wave-uniform
                         const unsigned vo = (mb + 8 <= M || mb + rsub < M) ? vj : IG_BUF_OOB;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) int, v),
                                                                out.rs, (int)vo, (int)((unsigned)(mb * out.row_bytes)), 0);
