@@ -943,8 +943,12 @@ struct SideStream {
     hipEvent_t fork = nullptr, join = nullptr;
     bool ok = false;
     SideStream() {
+        // OFF unless CNUDA_DCN_OVERLAP=1: with the weight-gradient GEMM on a second queue the column-gradient GEMM's
+        // output is not reproducible (a few per cent of noise in grad_input / grad_offset on the 128-channel layers,
+        // found by tests/test_gpu_fullsize.py once the kernels got faster; every kernel is deterministic on its own,
+        // the workspace regions are disjoint and an early join removes the effect) -- unexplained, so not the default
         const char* e = getenv("CNUDA_DCN_OVERLAP");
-        if (e && e[0] == '0') return;
+        if (!(e && e[0] == '1')) return;
         ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;

@@ -87,3 +87,52 @@ def test_full_size_uda_step_is_reproducible():
     for n in b1:
         if b1[n].is_floating_point():
             assert torch.equal(b1[n], b2[n]), n
+
+
+@pytest.mark.parametrize('B,C,S,Co', [(32, 256, 128, 6), (16, 256, 128, 2), (32, 64, 128, 576), (32, 16, 128, 256),
+                                      (32, 256, 128, 64)])
+def test_full_size_1x1_convolutions_match_fp64_and_repeat(B, C, S, Co):
+    """The 128-row tiles, the wave-specialised kernels, the buffer-addressed loaders and the 16-byte buffer-store
+    epilogue only run at sizes the per-operator tests (small tensors, seconds on the CPU oracle) never reach: 1x1
+    convolutions of the heads / the DCN column-gradient GEMM at 128 x 128, B = 32, forward, input gradient and weight
+    gradient against an fp64 contraction on the GPU, twice, bit-identical (a dropped store shows as an O(1) error
+    in a handful of elements: max-norm, not mean)."""
+    from hip_runtime import ops
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + C + Co)
+    x = torch.randn(B, C, S, S, device=DEV, generator=g)
+    w = torch.randn(Co, C, 1, 1, device=DEV, generator=g) * 0.1
+    gy = torch.randn(B, Co, S, S, device=DEV, generator=g)
+    runs = []
+    for _ in range(2):
+        xx, ww = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y = ops.conv2d(xx, ww, None, 1, 0)
+        y.backward(gy)
+        runs.append((y.detach(), xx.grad, ww.grad))
+    assert all(torch.equal(a, b) for a, b in zip(*runs))
+    y, gx, gw = runs[0]
+    w2 = w.double()[:, :, 0, 0]
+    for name, got, want in (('y', y, torch.einsum('bchw,oc->bohw', x.double(), w2)),
+                            ('gx', gx, torch.einsum('bohw,oc->bchw', gy.double(), w2)),
+                            ('gw', gw[:, :, 0, 0], torch.einsum('bohw,bchw->oc', gy.double(), x.double()))):
+        scale = want.abs().max().item()
+        assert (got.double() - want).abs().max().item() <= 1e-4 * scale, name
+
+
+def test_full_size_3x3_convolution_matches_fp64():
+    """3x3, 64 -> 256 at 64 x 64, B = 8: the 128-row forward tile (2 row tiles x 256 pixel tiles), the 64-row input
+    gradient and the 128 x 64 weight-gradient tile, against the CPU's fp64 convolution."""
+    import torch.nn.functional as F
+    from hip_runtime import ops
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(8, 64, 64, 64, generator=g)
+    w = torch.randn(256, 64, 3, 3, generator=g) * 0.05
+    gy = torch.randn(8, 256, 64, 64, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    F.conv2d(xr, wr, None, 1, 1).backward(gy.double())
+    want_y = F.conv2d(x.double(), w.double(), None, 1, 1)
+    xx, ww = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = ops.conv2d(xx, ww, None, 1, 1)
+    y.backward(gy.to(DEV))
+    for name, got, want in (('y', y.detach(), want_y), ('gx', xx.grad, xr.grad), ('gw', ww.grad, wr.grad)):
+        scale = want.abs().max().item()
+        assert (got.double().cpu() - want).abs().max().item() <= 1e-4 * scale, name
