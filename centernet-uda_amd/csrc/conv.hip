@@ -86,24 +86,11 @@ struct ConvFwdLoader {
         float* base;
         const float* res;
         int HoWo;
-        // buffer form of `base` for the plain-store epilogue (igemm.cuh): descriptor over y, per-lane byte offset of
-        // (image, row 0, pixel), bytes per output row
-        buf_rsrc rs;
-        unsigned voff;
-        int row_bytes;
-        static constexpr bool kBufStore = true;
-        __device__ static bool buf_ok(const Params& p) {
-            return !p.bias && !p.residual && p.act_slope < 0.0f &&
-                   (size_t)p.g.B * p.g.Co * p.g.Ho * p.g.Wo * sizeof(float) < IG_BUF_OOB;
-        }
         __device__ Out(const Params& p, long long n) {
             HoWo = p.g.Ho * p.g.Wo;
             const int ni = (int)n, b = ni / HoWo, pp = ni - b * HoWo;
             base = p.y + (size_t)b * p.g.Co * HoWo + pp;
             res = p.residual ? p.residual + (size_t)b * p.g.Co * HoWo + pp : nullptr;
-            rs = ig_make_rsrc(p.y, (unsigned)((size_t)p.g.B * p.g.Co * HoWo * sizeof(float)));
-            voff = (unsigned)(b * p.g.Co * HoWo + pp) * 4u;
-            row_bytes = HoWo * 4;
         }
         __device__ __forceinline__ void store(const Params& p, int m, float v) {
             if (p.bias) v += p.bias[m];
@@ -239,20 +226,10 @@ struct ConvDgradLoader {
     struct Out {
         float* base;
         int HW;
-        buf_rsrc rs;            // buffer form of `base` (see ConvFwdLoader::Out)
-        unsigned voff;
-        int row_bytes;
-        static constexpr bool kBufStore = true;
-        __device__ static bool buf_ok(const Params& p) {
-            return (size_t)p.g.B * p.g.C * p.g.H * p.g.W * sizeof(float) < IG_BUF_OOB;
-        }
         __device__ Out(const Params& p, long long n) {
             HW = p.g.H * p.g.W;
             const int ni = (int)n, b = ni / HW, pp = ni - b * HW;
             base = p.gx + (size_t)b * p.g.C * HW + pp;
-            rs = ig_make_rsrc(p.gx, (unsigned)((size_t)p.g.B * p.g.C * HW * sizeof(float)));
-            voff = (unsigned)(b * p.g.C * HW + pp) * 4u;
-            row_bytes = HW * 4;
         }
         __device__ __forceinline__ void store(const Params&, int m, float v) { base[(size_t)m * HW] = v; }
         static constexpr bool kVec4 = true;

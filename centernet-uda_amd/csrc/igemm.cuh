@@ -284,40 +284,6 @@ __device__ __forceinline__ void ig_epilogue_vec4(const typename Loader::Params& 
                                                  int wm_off, int wn_off, int lane, int M, long long N) {
     using T = IgTile<BM>;
     const int col = lane & 31, cg = lane & 7, rsub = lane >> 3;
-    if constexpr (Loader::Out::kBufStore) {
-        // Plain stores (no bias / skip connection / activation) through a buffer descriptor: the per-lane offset
-        // (image, pixel, this lane's row of an 8-row group) is computed once per tile column, the row group is a
-        // scalar offset, lanes past the last pixel or row store to the sentinel (dropped) -- ~4 vector instructions
-        // per 16-byte store instead of ~37 (64-bit address arithmetic), which the matrix pipe of the CU's other
-        // workgroup gets back (a quarter of the run time of the K = 64 column-gradient GEMM).
-        if (Loader::Out::buf_ok(p)) {
-            // (the compiler cannot see that a wave's tile row is uniform: without this every store becomes a loop over
-            // the "distinct" scalar offsets of the wave)
-            const int mrow0 = __builtin_amdgcn_readfirstlane(m0 + wm_off);
-#pragma unroll
-            for (int j = 0; j < T::TN; ++j) {
-                const long long n = n0 + wn_off + j * 32 + 4 * cg;
-                typename Loader::Out out(p, n < N ? n : 0);
-                const unsigned vj = n < N ? out.voff + (unsigned)(rsub * out.row_bytes) : IG_BUF_OOB;
-#pragma unroll
-                for (int i = 0; i < T::TM; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) stage[mfma_row(r, lane) * IG_EPI_LD + col] = acc[i][j][r];
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int it = 0; it < 4; ++it) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (it * 8 + rsub) * IG_EPI_LD + 4 * cg);
-                        const int mb = mrow0 + i * 32 + it * 8;                       // wave-uniform
-                        const unsigned vo = (mb + 8 <= M || mb + rsub < M) ? vj : IG_BUF_OOB;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) int, v),
-                                                               out.rs, (int)vo, (int)((unsigned)(mb * out.row_bytes)), 0);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-            }
-            return;
-        }
-    }
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
         const long long n = n0 + wn_off + j * 32 + 4 * cg;

@@ -136,3 +136,49 @@ def test_full_size_3x3_convolution_matches_fp64():
     for name, got, want in (('y', y.detach(), want_y), ('gx', xx.grad, xr.grad), ('gw', ww.grad, wr.grad)):
         scale = want.abs().max().item()
         assert (got.double().cpu() - want).abs().max().item() <= 1e-4 * scale, name
+
+
+def test_kernels_are_unaffected_by_work_on_another_stream():
+    """One process per GPU runs its gradient all-reduce (RCCL kernels) next to the backward pass, and nothing stops a
+    caller from driving two models on two streams: a kernel's result must not depend on what else is resident on the
+    CU.  (A 16-byte epilogue that stored through buffer descriptors passed every single-stream test and dropped a few
+    stores per 100k as soon as a second convolution ran beside it.)  A full-size 1x1 convolution and a DCN layer
+    are repeated while another stream runs convolution forward / backward passes; every result must be bit-identical
+    to the one computed alone (grad_input of the DCN up to the order of col2im's straggler atomics)."""
+    from hip_runtime import ops
+    from libs.DCNv2.dcn_v2 import DCN
+    torch.manual_seed(11)
+    x = torch.randn(32, 128, 64, 64, device=DEV)
+    w = torch.randn(1152, 128, 1, 1, device=DEV) * 0.1
+    m = DCN(64, 64, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(DEV)
+    with torch.no_grad():
+        m.conv_offset_mask.weight.normal_(0, 0.05)
+        m.conv_offset_mask.bias.normal_(0, 0.3)
+    xd, gd = torch.randn(32, 64, 128, 128, device=DEV), torch.randn(32, 64, 128, 128, device=DEV)
+
+    def dcn_once():
+        xi = xd.clone().requires_grad_(True)
+        for p in m.parameters():
+            p.grad = None
+        y = m(xi)
+        y.backward(gd)
+        return y.detach().clone(), xi.grad.clone(), m.weight.grad.clone(), m.conv_offset_mask.weight.grad.clone()
+    ref_y = ops.conv2d_infer(x, w, None, 1, 0).clone()
+    ref_d = dcn_once()
+    x3 = torch.randn(32, 128, 64, 64, device=DEV, requires_grad=True)
+    w3 = (torch.randn(128, 128, 3, 3, device=DEV) * 0.05).requires_grad_(True)
+    g3 = torch.randn(32, 128, 64, 64, device=DEV)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for it in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                y3 = ops.conv2d(x3, w3, None, 1, 1)
+                if it % 2:
+                    y3.backward(g3)
+        y = ops.conv2d_infer(x, w, None, 1, 0)
+        d = dcn_once()
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref_y), it
+        assert torch.equal(d[0], ref_d[0]) and torch.equal(d[2], ref_d[2]) and torch.equal(d[3], ref_d[3]), it
+        assert (d[1] - ref_d[1]).abs().max().item() <= 1e-5 * ref_d[1].abs().max().item(), it
