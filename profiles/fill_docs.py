@@ -23,8 +23,8 @@ rf = line['roofline']
 
 def bucket(name):
     n = name
-    if 'DcnColWLoader' in n: return 'DCN wgrad'
-    if 'DcnFwdLoader' in n or 'DcnColsLoader' in n or 'dcn_sample' in n: return 'DCN forward'
+    if 'DcnColW' in n or 'DcnWLoader' in n: return 'DCN wgrad'
+    if 'DcnFwdLoader' in n or 'DcnCols' in n or 'dcn_sample' in n: return 'DCN forward'
     if 'dcn_coord' in n: return 'DCN coord-grad'
     if 'dcn_col2im' in n: return 'DCN col2im'
     if 'igemm_wgrad' in n or 'smallc_wgrad' in n or 'slab_reduce' in n: return 'conv wgrad'
