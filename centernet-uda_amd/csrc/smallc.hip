@@ -154,7 +154,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void smallc_fwd_kernel(SmallGeom g, 
     float* Ys = smem + g.C * g.plane + 16 + wid * (16 * MT * SC_YLD);
     const bool vec = (g.Wo & 3) == 0;
     HaloRegs halo;
-    halo_load(g, xb, (blockIdx.y * SC_NV) * SC_TH * g.s - g.ph, ox0 * g.s - g.pw, tid, halo);
+    halo_load(g, xb, (blockIdx.y * SC_NV) * SC_TH - g.ph, ox0 - g.pw, tid, halo);
 #pragma unroll 1
     for (int vt = 0; vt < SC_NV; ++vt) {
     const int oy0 = (blockIdx.y * SC_NV + vt) * SC_TH;
@@ -163,13 +163,13 @@ __global__ __launch_bounds__(IG_THREADS, 2) void smallc_fwd_kernel(SmallGeom g, 
     halo_store(g, Xh, tid, halo);
     __syncthreads();
     if (vt + 1 < SC_NV && oy0 + SC_TH < g.Ho)       // next tile's halo: in flight under this tile's MFMAs
-        halo_load(g, xb, (oy0 + SC_TH) * g.s - g.ph, ox0 * g.s - g.pw, tid, halo);
+        halo_load(g, xb, (oy0 + SC_TH) - g.ph, ox0 - g.pw, tid, halo);
 
     const int oy = oy0 + wid;                       // one output row per wave
     float* yb = y + (size_t)b * g.Co * HoWo + (size_t)oy * g.Wo;
     if (oy < g.Ho) {
         constexpr int NP = SC_TW / 16;                  // four 16-pixel tiles along the row, processed together
-        const int pbase0 = (wid * g.s) * g.HC + il * g.s;
+        const int pbase0 = wid * g.HC + il;          // (stride 1 only: smallc_supported)
         f32x4 acc[MT][NP];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void smallc_fwd_kernel(SmallGeom g, 
 #pragma unroll
             for (int m = 0; m < MT; ++m) fa[m] = Ws[k * (16 * MT) + m * 16 + il];
 #pragma unroll
-            for (int pt = 0; pt < NP; ++pt) fb[pt] = Xh[ko + pt * 16 * g.s];
+            for (int pt = 0; pt < NP; ++pt) fb[pt] = Xh[ko + pt * 16];
         };
         auto mma = [&](const float (&fa)[MT], const float (&fb)[NP]) {
 #pragma unroll
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(IG_THREADS) void smallc_wgrad_kernel(SmallGeom g, c
     const int oy0 = (blockIdx.y * SC_NV + vt) * SC_TH;
     if (oy0 >= g.Ho) break;
     __syncthreads();
-    stage_halo(g, xb, oy0 * g.s - g.ph, ox0 * g.s - g.pw, Xh, tid);
+    stage_halo(g, xb, oy0 - g.ph, ox0 - g.pw, Xh, tid);
     // gy tile: Gs[o][row*64 + col], zero outside the image / beyond Co; wave w stages rows (o, ty) w, w+4, ...
     {
         float gv[4 * MT * SC_TH];
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(IG_THREADS) void smallc_wgrad_kernel(SmallGeom g, c
 #pragma unroll 2
     for (int ps = 0; ps < SC_TW / 4; ++ps) {
         const int px = ps * 4 + kq;                       // this lane's pixel (k index of the MFMA)
-        const int pbase = (wid * g.s) * g.HC + px * g.s;
+        const int pbase = wid * g.HC + px;
         float a[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) a[m] = Gs[(m * 16 + il) * GLD + wid * SC_TW + px];
