@@ -10,6 +10,8 @@
 // whenever C % 16 == 0 (every layer but the 3-channel stem), so the bounds test
 // and address of a gathered element are computed once per chunk.
 #include <stdlib.h>
+
+#include <type_traits>
 #include "igemm.cuh"
 #include "igemm_host.h"
 
@@ -621,6 +623,16 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     const int n_tiles = ceil_div(N, IG_BN), m_tiles = Mp / bm;
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
     ProfScope prof(st);
+    if constexpr (std::is_same<Loader, ConvFwdBufLoader>::value || std::is_same<Loader, ConvFwdLoader<true>>::value) {
+        // few chunks, several row tiles (the DCN column-gradient GEMM: a 1x1 forward with K = 64 and 9*C rows)
+        static const bool shortk = !(getenv("CNUDA_SHORTK") && getenv("CNUDA_SHORTK")[0] == '0');
+        if (shortk && matrix_mode() == 0 && bm == 128 && Kp <= 64 && m_tiles >= 2) {
+            prof.name("igemm_fwd_shortk_kernel<128, %s, 64>", Loader::name());
+            hipLaunchKernelGGL((igemm_fwd_shortk_kernel<128, Loader, 64>), dim3(n_tiles), block, 0, st, p, A, Mp, Kp, M, N,
+                               n_tiles, m_tiles);
+            return check_launch(who);
+        }
+    }
     const bool ws = matrix_mode() == 0 && wave_specialised() && bm >= 64;
     prof.name(matrix_mode() == 1 ? "igemm_fwd_kernel<%d, %s> [split bf16 x3]"
                                  : (ws ? "igemm_fwd_ws_kernel<%d, %s>" : "igemm_fwd_kernel<%d, %s>"), bm, Loader::name());

@@ -628,6 +628,88 @@ __global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd
 }
 
 // ---------------------------------------------------------------------------
+// Short-K variant (Kp <= KP = 64: the DCN column-gradient GEMM, a 1x1 convolution with K = 64 and 9*C = 576 output
+// rows).  With four chunks per tile the pipelined kernels spend as long in prologue and epilogue as in the K loop
+// (76-88 TFLOP/s).  Here a workgroup owns one pixel tile for ALL row tiles: the gathered B tile (KP x 128) is staged
+// once and stays in LDS, every row tile copies its whole A tile (KP x BM) next to it, runs its KP/2 k-steps without a
+// barrier in between and stores; two workgroups per CU (64 KB each) cover each other's copy and store phases.
+// ---------------------------------------------------------------------------
+template <int BM, class Loader, int KP>
+__global__ __launch_bounds__(IG_THREADS, 2) void igemm_fwd_shortk_kernel(
+    typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N, int n_tiles, int m_tiles) {
+    using T = IgTile<BM>;
+    static_assert(KP % IG_KC == 0 && KP * BM >= 4 * IG_EPI_WAVE, "the A buffer holds the epilogue staging tiles");
+    __shared__ __attribute__((aligned(16))) float As[KP * BM];      // reused by the vec4 epilogue
+    __shared__ __attribute__((aligned(16))) float Bs[KP * IG_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const long long n0 = (long long)xcd_remap(blockIdx.x, n_tiles) * IG_BN;
+    const int wm_off = (wid / T::WN) * (T::TM * 32), wn_off = (wid % T::WN) * (T::TN * 32);
+    {   // B tile: every chunk gathered once
+        const int nl = tid & (IG_BN - 1), ksub = tid >> 7;
+        Loader ld(p, n0 + nl, n0 + nl < N);
+        float rb[KP / IG_BK][8];
+#pragma unroll
+        for (int c = 0; c < KP / IG_BK; ++c) ld.load(c * IG_BK, ksub, rb[c]);     // (rows past Kp: the loader returns 0)
+#pragma unroll
+        for (int c = 0; c < KP / IG_BK; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Bs[(c * IG_BK + ksub + 2 * j) * IG_BN + nl] = rb[c][j];
+    }
+    constexpr int CELLS = KP * BM / 4, PER = CELLS / IG_THREADS;
+    static_assert(CELLS % IG_THREADS == 0, "whole 16-byte cells per thread");
+    const buf_rsrc ra = ig_make_rsrc(A, (unsigned)((size_t)Kp * Mp * sizeof(float)));
+    f32x4 cell[PER];
+    auto load_a = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + i * IG_THREADS, kk = e / (BM / 4), m = (e % (BM / 4)) * 4;
+            // rows past Kp (Kp < KP): the per-lane offset leaves the buffer, the load returns 0
+            cell[i] = ig_buf_load4(ra, kk < Kp ? (unsigned)((kk * Mp + m) * (int)sizeof(float)) : IG_BUF_OOB,
+                                   (unsigned)(mt * BM) * (unsigned)sizeof(float));
+        }
+    };
+    load_a(0);
+    for (int mt = 0; mt < m_tiles; ++mt) {
+        const int m0 = mt * BM;
+        __syncthreads();                 // the previous row tile's epilogue is done with As (and Bs is complete)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) reinterpret_cast<f32x4*>(As)[tid + i * IG_THREADS] = cell[i];
+        __syncthreads();
+        // the next row tile's A loads go out BEFORE this tile's stores: vmcnt counts in issue order, so a load issued
+        // after the epilogue would wait for every one of its stores to drain
+        if (mt + 1 < m_tiles) load_a(mt + 1);
+        f32x16 acc[T::TM][T::TN];
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < KP / IG_KC; ++c)
+            ig_mma_chunk<BM>(As + c * IG_KC * BM, Bs + c * IG_KC * IG_BN, acc, wm_off, wn_off, lane);
+        __syncthreads();                 // every wave has read its last fragments: As becomes the staging area
+        if (Loader::Out::vec4_ok(p)) {
+            ig_epilogue_vec4<BM, Loader>(p, As + wid * IG_EPI_WAVE, acc, m0, n0, wm_off, wn_off, lane, M, N);
+        } else {
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j) {
+                const long long n = n0 + wn_off + j * 32 + (lane & 31);
+                if (n >= N) continue;
+                typename Loader::Out out(p, n);
+#pragma unroll
+                for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wm_off + i * 32 + mfma_row(r, lane);
+                        if (m < M) out.store(p, m, acc[i][j][r]);
+                    }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Weight-gradient-type kernel:  D[m][j] = sum_n  G[m][n] * B[j][n]
 // (m = output channel, j = column of the packed K axis, n = pixel).  The pixel
 // range is split over blockIdx.z; every workgroup writes one fp32 partial slab
