@@ -154,8 +154,9 @@ def test_errors():
 @pytest.mark.parametrize('B,C,S,Co', [(32, 64, 128, 64), (32, 128, 64, 128)])
 def test_dcn_layer_is_reproducible_at_full_size(B, C, S, Co):
     """Forward, weight gradient and offset-branch gradients of a full-size DCN layer are bit-identical from call to
-    call; grad_input only differs by the order of col2im's straggler atomics (1e-7).  (With the weight-gradient GEMM
-    on a second stream this test sees per-cent noise: csrc/dcn.hip, SideStream.)"""
+    call; grad_input only differs by the order of col2im's straggler atomics (1e-7).  (It caught a 16-byte epilogue
+    that stored through buffer descriptors and lost stores whenever the weight-gradient GEMM ran beside the
+    column-gradient GEMM on the DCN backward's second stream: DESIGN.md section 10.)"""
     from libs.DCNv2.dcn_v2 import DCN
     torch.manual_seed(3)
     m = DCN(C, Co, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(DEV)
