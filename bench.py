@@ -265,10 +265,12 @@ def pmc_traffic(kernel_name):
     passes cannot run inside the timed process, so the note says whether that profile was collected from the
     kernel sources this run executes."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    import re
+    files = glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json'))
     if not files:
         return None, None
-    path = files[-1]
+    # newest = highest ROUND NUMBER (r10 after r2), not the lexicographic maximum
+    path = max(files, key=lambda f: int(re.match(r'r(\d+)', os.path.basename(f)).group(1)))
     data = json.load(open(path))
     meta = data.get('_meta', {})
     import re
