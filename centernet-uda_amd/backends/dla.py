@@ -368,6 +368,24 @@ class DLAUp(nn.Module):
         return out
 
 
+class _TapeFreeTargetHead(torch.autograd.Function):
+    """Marks a target-domain head output that `forward_domains` evaluated without a tape: the value is the head's, the
+    node records nothing and costs nothing -- unless a backward pass reaches it, which means a loss was attached to a
+    head that `target_grad_heads` does not list."""
+
+    @staticmethod
+    def forward(ctx, y, anchor, head):
+        ctx.head = head
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise RuntimeError(
+            "forward_domains evaluated the target-domain head %r without a tape (it is not in target_grad_heads), but a "
+            "loss back-propagates into it.  List it -- e.g. plugin.target_grad_heads = ('hm', %r) -- or set "
+            "plugin.batch_domains = False for the reference's literal two-pass sequence." % (ctx.head, ctx.head))
+
+
 class DLASeg(nn.Module):
     def __init__(self, base_name, heads, pretrained, down_ratio, final_kernel, last_level, head_conv,
                  out_channel=0, freeze_base=False, rotated_boxes=False):
@@ -445,7 +463,10 @@ class DLASeg(nn.Module):
             else:
                 out_s[head] = fc(f_s)
                 with torch.no_grad():
-                    out_t[head] = fc(f_t)
+                    y_t = fc(f_t)
+                # requires_grad like the reference's (uda/entropy_minimization.py:18-19) -- and a loss that does reach
+                # it fails loudly in backward() instead of silently training nothing
+                out_t[head] = _TapeFreeTargetHead.apply(y_t, f_t, head) if f_t.requires_grad else y_t
         return out_s, out_t
 
 

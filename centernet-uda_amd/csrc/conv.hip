@@ -596,14 +596,12 @@ ConvPlan make_plan(const ConvGeom& g) {
     q.wbj = (g.Co <= 32 || (g.C % 64 == 0 && q.Kf % 128 == 0)) ? 128 : 64;   // 64 x 128: +8-13 % where nothing is padded
     // 128 x 64 where the columns do not fill 128 (K = 9 * 64) but the output channels do: the same two accumulator
     // tiles per wave and loads per MFMA as 64 x 128 (the 64 -> 256 head convolutions at 128 x 128)
-    static const bool tall = !(getenv("CNUDA_WGRAD_TALL") && getenv("CNUDA_WGRAD_TALL")[0] == '0');
     const bool wbuf = wgrad_buffer_ok(g);     // (ConvWBufLoader only)
-    q.wbm = g.Co <= 32 ? 32 : ((tall && wbuf && q.wbj == 64 && g.C % 64 == 0 && g.Co % 128 == 0) ? 128 : 64);
+    q.wbm = g.Co <= 32 ? 32 : ((wbuf && q.wbj == 64 && g.C % 64 == 0 && g.Co % 128 == 0) ? 128 : 64);
     // 128 x 128 (2 x 2 accumulator tiles per wave: one fragment dword per MFMA instead of 1.5, 32 loads per 64 MFMAs
     // instead of 24 per 32 -- the 64 x 128 tile runs into the LDS: ~2300 LDS cycles per 2048-cycle chunk with three
     // workgroups per CU) where both extents allow it
-    static const bool big = !(getenv("CNUDA_WGRAD_BIG") && getenv("CNUDA_WGRAD_BIG")[0] == '0');
-    if (big && wbuf && q.wbm == 64 && q.wbj == 128 && g.C % 64 == 0 && g.Co % 128 == 0) q.wbm = 128;
+    if (wbuf && q.wbm == 64 && q.wbj == 128 && g.C % 64 == 0 && g.Co % 128 == 0) q.wbm = 128;
     q.Mpw = round_up(g.Co, q.wbm);
     q.Jp = round_up(q.Kf, q.wbj);
     const long long tiles = (long long)(q.Mpw / q.wbm) * (q.Jp / q.wbj);
@@ -654,17 +652,10 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     // neutral on the 64-channel ones, -2-4 % on the 32-row tile, which therefore keeps the 4-wave kernel
     if (wave_specialised() && bm >= 64) {
         const dim3 block2(2 * IG_THREADS);
-        // one producer register stage by default: with buffer addressing the second stage (CNUDA_FWD_DEEP=1) measured
-        // 0.4 ms per step slower -- it costs the third workgroup per CU (86 instead of <= 80 registers)
-        static const bool deep = getenv("CNUDA_FWD_DEEP") && getenv("CNUDA_FWD_DEEP")[0] == '1';
-        if (bm == 128 && deep)
-            hipLaunchKernelGGL((igemm_fwd_ws_kernel<128, Loader, true>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
-        else if (bm == 128)
-            hipLaunchKernelGGL((igemm_fwd_ws_kernel<128, Loader, false>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
-        else if (deep)
-            hipLaunchKernelGGL((igemm_fwd_ws_kernel<64, Loader, true>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        if (bm == 128)
+            hipLaunchKernelGGL((igemm_fwd_ws_kernel<128, Loader>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         else
-            hipLaunchKernelGGL((igemm_fwd_ws_kernel<64, Loader, false>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+            hipLaunchKernelGGL((igemm_fwd_ws_kernel<64, Loader>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         return check_launch(who);
     }
     if (bm == 128)
@@ -814,20 +805,7 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
                   buf ? "ConvWBufLoader" : (fast ? "ConvWLoader<2>" : "ConvWLoader<0>"), q.wbm, q.wbj);
         if (buf) {
             const dim3 blk2(2 * IG_THREADS);
-            static const bool wdeep = getenv("CNUDA_WGRAD_DEEP") && getenv("CNUDA_WGRAD_DEEP")[0] == '1';
-            if (wdeep && wave_specialised() && q.wbm == 128 && q.wbj == 128)
-                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 128, true>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
-            else if (wdeep && wave_specialised() && q.wbm == 64 && q.wbj == 128)
-                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 128, true>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
-            else if (wdeep && wave_specialised() && q.wbm == 128)
-                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 64, true>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
-            else if (wdeep && wave_specialised() && q.wbm == 64)
-                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 64, true>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
-            else if (q.wbm == 128 && q.wbj == 128 && wave_specialised())
+            if (q.wbm == 128 && q.wbj == 128 && wave_specialised())
                 hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
             else if (q.wbm == 128 && q.wbj == 128)

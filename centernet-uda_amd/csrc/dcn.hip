@@ -116,7 +116,8 @@ struct DcnFwdLoaderT {
     static constexpr bool kHasSideOutput = true;
     const DcnGeom& g;
     const float *in_b, *off_b, *mask_b;
-    buf_rsrc rin, rcol;
+    buf_rsrc rin;
+    float* col_base = nullptr;      // BUF: the column buffer (uniform)
     unsigned in_boff = 0, col_voff = IG_BUF_OOB;    // BUF: byte offset of the image in `in`, of the pixel's column in `col`
     bool col_on = false;
     int oy, ox, K;
@@ -147,7 +148,7 @@ struct DcnFwdLoaderT {
         col_stride = HoWo;
         if constexpr (BUF) {
             rin = ig_make_rsrc(p.in, (unsigned)((size_t)g.B * g.C * g.H * g.W * sizeof(float)));
-            rcol = ig_make_rsrc(p.col, p.col ? (unsigned)((size_t)g.B * K * HoWo * sizeof(float)) : 0u);
+            col_base = p.col;
             in_boff = (unsigned)(b * g.C * g.H * g.W) * (unsigned)sizeof(float);
             col_on = p.col != nullptr;
             col_voff = (p.col && n_valid) ? (unsigned)(b * K * HoWo + pp) * (unsigned)sizeof(float) : IG_BUF_OOB;
@@ -248,12 +249,24 @@ struct DcnFwdLoaderT {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = m00 * r.t[j].l + m01 * r.t[j].r + m10 * r.b[j].l + m11 * r.b[j].r;
             if constexpr (BUF) {
-                if (col_on) {         // (uniform; a thread past the last pixel stores to the sentinel: dropped)
+                // Column side output: GLOBAL stores in the scalar-base form (`global_store_dword v_off, v_data, s[base]`):
+                // the row (k0 + 2j) * HoWo is a wave-uniform 64-bit base built with scalar adds, the lane's part is its
+                // 32-bit column offset -- as free of vector address arithmetic as a buffer store.  NOT buffer stores: a
+                // MUBUF store reads its data registers late, nothing orders that read against a later LDS return into
+                // the same registers (dropped stores under CU sharing), and `v` dies right after
+                // this function -- the register allocator is free to hand it to the next chunk's fragment reads.
+                if (col_on && col_voff != IG_BUF_OOB) {
                     const int k0s = __builtin_amdgcn_readfirstlane(r.k0);
+                    const char* cbase = reinterpret_cast<const char*>(col_base);
+                    unsigned voff = col_voff;
+                    asm volatile("" : "+v"(voff));      // (instruction selection is per basic block: keep the zero-extension here)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[j]), rcol, (int)col_voff,
-                                                              (int)((unsigned)((k0s + 2 * j) * col_stride) * 4u), 0);
+                    for (int j = 0; j < 8; ++j) {
+                        const size_t row = (size_t)(unsigned)((k0s + 2 * j) * col_stride) * 4u;      // uniform
+                        unsigned long long rbase = reinterpret_cast<unsigned long long>(cbase) + row;
+                        asm volatile("" : "+s"(rbase));     // keep base and lane offset apart: scalar-base store form
+                        *reinterpret_cast<__attribute__((address_space(1))) float*>(rbase + (unsigned long long)voff) = v[j];
+                    }
                 }
                 return;
             }
@@ -931,30 +944,6 @@ __global__ void dcn_naive_bwd_kernel(DcnNaiveParams p) {
     }
 }
 
-// Side stream of the backward pass.  The weight-gradient GEMM (MFMA-bound) depends only on the call's inputs, the
-// data-gradient chain (column-gradient GEMM -> coord_grad -> col2im) spends two thirds of its time in latency /
-// gather-bound kernels that leave the matrix pipes idle: the two run concurrently on two HIP streams, forked and
-// joined with events (capturable; the caller still sees one stream-ordered operation).  CNUDA_DCN_OVERLAP=0 turns
-// it off.
-struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool ok = false;
-    SideStream() {
-        // OFF unless CNUDA_DCN_OVERLAP=1: worth 0.5 ms per step when it was written, nothing (-0.4 ms) since the
-        // kernels around it got faster
-        const char* e = getenv("CNUDA_DCN_OVERLAP");
-        if (!(e && e[0] == '1')) return;
-        ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
-    }
-};
-SideStream& side_stream() {
-    static thread_local SideStream s;      // one per calling thread (forward: caller's, backward: autograd's)
-    return s;
-}
-
 int fill_geom(DcnGeom& g, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
               int dw, int dg, const char* who) {
     CNUDA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Co > 0, "%s: empty tensor", who);
@@ -1190,14 +1179,9 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
     float* dcol = cv.take<float>((size_t)B * q.T * C * HoWo);
     DcnGeo* geo = cv.take<DcnGeo>((size_t)B * q.T * HoWo);
     void* gemm_ws = cv.take<char>(q.gemm_bytes);
-    // weight / bias gradients on the side stream, concurrently with the data-gradient chain below
-    SideStream& side = side_stream();
-    const bool overlap = side.ok && !prof_active();      // (the in-library timer brackets kernels on ONE stream)
-    hipStream_t wst = overlap ? side.stream : st;
-    if (overlap) {
-        (void)hipEventRecord(side.fork, st);
-        (void)hipStreamWaitEvent(wst, side.fork, 0);
-    }
+    // (running the weight gradient on a second stream beside the data-gradient chain was tried in round 2: the
+    // kernels do overlap but contend for the same LDS / issue slots -- nothing gained, removed)
+    hipStream_t wst = st;
     launch_channel_sum(grad_output, grad_bias, B, Cout, HoWo, wst, bsum);
     // (2) weight gradient
     {
@@ -1226,7 +1210,6 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
         if (int rc = check_launch("cnuda_dcn_v2_backward(weight)")) return rc;
         launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, wst);
     }
-    if (overlap) (void)hipEventRecord(side.join, wst);
     {
         // (1) dcol = W^T x grad_output as a 1x1 implicit GEMM, then the two streaming consumers
         ProfGroup prof;       // sub 0: the 1x1 GEMM (its own scope), 1: coord_grad, 2: col2im
@@ -1252,6 +1235,5 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
         }
         if (int rc = check_launch("cnuda_dcn_v2_backward(data)")) return rc;
     }
-    if (overlap) (void)hipStreamWaitEvent(st, side.join, 0);
     return check_launch("cnuda_dcn_v2_backward");
 }

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void ig
 // stages, one barrier per chunk (all 8 waves); the two roles never hold registers at the same time, so the
 // kernel needs fewer registers than the 4-wave one (78 vs 113 for the 128-row tile).
 // ---------------------------------------------------------------------------
-template <int BM, class Loader, bool DEEP, int KC>
+template <int BM, class Loader, int KC>
 __device__ __forceinline__ void igemm_fwd_ws_body(
     const typename Loader::Params& p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
     int n_tiles, int m_tiles) {
@@ -518,17 +518,17 @@ __device__ __forceinline__ void igemm_fwd_ws_body(
         const int nl = tid & (IG_BN - 1), ksub = tid >> 7;
         Loader ld(p, n0 + nl, n0 + nl < N);
         if constexpr (Loader::kHasSideOutput) { if (m0 != 0) ld.disable_col(); }
-        // TWO register stages: the global loads of a chunk are issued two chunks before they are stored to LDS (the
-        // producers' registers are free -- the kernel's allocation is set by the consumers' accumulators), so a load
-        // may take two chunks of MFMA time under a busy memory system before anybody waits for it
-        static_assert(!Loader::kHasSideOutput, "two-phase loaders keep per-chunk state (the current tap's weights): one chunk in flight only");
+        // ONE register stage: the loads of chunk k + 2 are issued right after chunk k + 1 went to LDS.  (A second
+        // stage -- loads issued two chunks ahead -- measured 0.4 ms per step slower once buffer addressing made the
+        // loads cheap: it costs the third workgroup per CU, 86 instead of <= 80 registers.  DESIGN.md section 10.)
+        static_assert(!Loader::kHasSideOutput, "two-phase loaders keep per-chunk state (the current tap's weights)");
         constexpr int NH = KC / IG_BK;                 // loader calls per chunk
         struct Regs {
             f32x4 ra[ig_a_per<BM, KC>()];
             float rb[NH][8];
             typename IgRaw<Loader, Loader::kHasSideOutput>::type raw[NH];
         };
-        Regs r0, r1;
+        Regs r0;
         const IgABuf<BM, KC> abuf(A, Mp, Kp, m0, tid);
         auto stage_store = [&](int buf, Regs& r) {
             ig_store_a<BM, KC>(As[buf], tid, r.ra);
@@ -549,38 +549,16 @@ __device__ __forceinline__ void igemm_fwd_ws_body(
         };
         stage_load(0, r0);
         stage_store(0, r0);
-        if (!DEEP) {                                   // one register stage (A/B measurements)
-            if (KC < Kp) stage_load(KC, r0);
-            __syncthreads();
-            int c1 = 0;
-            for (int k0 = 0; k0 < Kp; k0 += KC) {
-                if (k0 + KC < Kp) {
-                    stage_store(c1 ^ 1, r0);
-                    if (k0 + 2 * KC < Kp) stage_load(k0 + 2 * KC, r0);
-                }
-                __syncthreads();
-                c1 ^= 1;
-            }
-            return;
-        }
-        if (KC < Kp) stage_load(KC, r1);
-        if (2 * KC < Kp) stage_load(2 * KC, r0);
+        if (KC < Kp) stage_load(KC, r0);
         __syncthreads();
-        int cur = 0;
-        for (int k0 = 0; k0 < Kp; k0 += 2 * KC) {
-            // chunk k0: consumers read stage `cur`; chunk k0 + KC (in r1) goes to the other stage, r1 is refilled
+        int c1 = 0;
+        for (int k0 = 0; k0 < Kp; k0 += KC) {
             if (k0 + KC < Kp) {
-                stage_store(cur ^ 1, r1);
-                if (k0 + 3 * KC < Kp) stage_load(k0 + 3 * KC, r1);
+                stage_store(c1 ^ 1, r0);
+                if (k0 + 2 * KC < Kp) stage_load(k0 + 2 * KC, r0);
             }
             __syncthreads();
-            if (k0 + KC >= Kp) break;
-            // chunk k0 + KC: consumers read stage `cur ^ 1`; chunk k0 + 2 KC (in r0) goes to stage `cur`
-            if (k0 + 2 * KC < Kp) {
-                stage_store(cur, r0);
-                if (k0 + 4 * KC < Kp) stage_load(k0 + 4 * KC, r0);
-            }
-            __syncthreads();
+            c1 ^= 1;
         }
         return;
     }
@@ -620,11 +598,11 @@ __device__ __forceinline__ void igemm_fwd_ws_body(
     }
 }
 
-template <int BM, class Loader, bool DEEP = true, int KC = IG_KC>
+template <int BM, class Loader, int KC = IG_KC>
 __global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd_ws_kernel(
     typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
     int n_tiles, int m_tiles) {
-    igemm_fwd_ws_body<BM, Loader, DEEP, KC>(p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+    igemm_fwd_ws_body<BM, Loader, KC>(p, A, Mp, Kp, M, N, n_tiles, m_tiles);
 }
 
 // ---------------------------------------------------------------------------
@@ -875,7 +853,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
 // Wave-specialised weight-gradient kernel (see igemm_fwd_ws_kernel): threads 256..511 run the two loaders and the
 // LDS stores, threads 0..255 only read fragments and issue MFMAs.  Same tiles, LDS image and slab output as
 // igemm_wgrad_kernel.
-template <class WLoader, int BM, int BJ, bool DEEP = false>
+template <class WLoader, int BM, int BJ>
 __global__ __launch_bounds__(2 * IG_THREADS) void igemm_wgrad_ws_kernel(
     typename WLoader::Params p, float* __restrict__ slabs, int Mp, int Jp, long long N, long long pix_per_split) {
     constexpr int GLD = BM + 1, BLD = BJ + 1;
@@ -906,30 +884,7 @@ __global__ __launch_bounds__(2 * IG_THREADS) void igemm_wgrad_ws_kernel(
             ld.template load_b<NB, STEP>(j0, sub, r.rb);
         };
         const int nchunk = (int)((n_end - n_begin + WG_BP - 1) / WG_BP);
-        Regs r0, r1;
-        if (DEEP) {
-            // two register stages: the loads of chunk c + 2 are issued before chunk c + 1 is stored, i.e. two chunks of
-            // MFMA time (~1.7 us) before anybody waits for them -- 24-32 loads per thread and chunk from two tensors
-            stage_load(r0);
-            stage_store(0, r0);
-            if (1 < nchunk) { ld.advance(); stage_load(r1); }
-            if (2 < nchunk) { ld.advance(); stage_load(r0); }
-            __syncthreads();
-            for (int c = 0; c < nchunk; c += 2) {
-                if (c + 1 < nchunk) {
-                    stage_store(1, r1);
-                    if (c + 3 < nchunk) { ld.advance(); stage_load(r1); }
-                }
-                __syncthreads();
-                if (c + 1 >= nchunk) break;
-                if (c + 2 < nchunk) {
-                    stage_store(0, r0);
-                    if (c + 4 < nchunk) { ld.advance(); stage_load(r0); }
-                }
-                __syncthreads();
-            }
-            return;
-        }
+        Regs r0;    // one register stage (a second one measured +0.7 ms per step: DESIGN.md section 10)
         stage_load(r0);
         stage_store(0, r0);
         if (1 < nchunk) { ld.advance(); stage_load(r0); }

@@ -19,9 +19,8 @@ inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 // image: 64x64 33 KB -> 4, 64x128 / 128x64 / 32x128 50 / 50 / 41 KB -> 3, 128x128 66 KB -> 2).  The flat target of
 // 1024 workgroups left the three-per-CU shapes with 1.33 rounds: a second round on a third of the chip.
 inline long long wgrad_splits(long long tiles, int bm, int bj, long long max_z) {
-    static const int rounds = getenv("CNUDA_WGRAD_ROUNDS") ? atoi(getenv("CNUDA_WGRAD_ROUNDS")) : 1;
     const int per_cu = (bm == 128 && bj == 128) ? 2 : ((bm == 64 && bj == 64) ? 4 : 3);
-    long long z = rounds > 0 ? (256ll * per_cu * rounds) / tiles : (1024 + tiles - 1) / tiles;   // rounds = 0: round 1's rule
+    long long z = (256ll * per_cu) / tiles;      // exactly one round (two rounds measured the same)
     if (z > max_z) z = max_z;
     return z < 1 ? 1 : z;
 }

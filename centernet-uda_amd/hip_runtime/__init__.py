@@ -145,12 +145,25 @@ def bump_param_epoch(rewritten=None):
                                        ptr(_PACK['table']), _PACK['table'].numel(), stream()), 'pack_refresh')
 
 
+# Buffer epoch: bumped by every train-mode BatchNorm call (the statistics kernel rewrites running_mean / running_var /
+# num_batches_tracked through raw pointers: torch's version counters never see it).  Kept apart from _PARAM_EPOCH on
+# purpose: the packed-weight cache is stamped with the parameter epoch and must not be invalidated by a BN call.
+_BUFFER_EPOCH = 0
+
+
+def bump_buffer_epoch():
+    global _BUFFER_EPOCH
+    _BUFFER_EPOCH += 1
+
+
 def param_state_key(module):
-    """Changes whenever a parameter or buffer of `module` may have changed."""
-    v = 0
-    for t in list(module.parameters()) + list(module.buffers()):
-        v += t._version + (t.data_ptr() & 0xffff)
-    return (_PARAM_EPOCH, v)
+    """Changes whenever a parameter or buffer of `module` may have changed: the parameter epoch (fused Adam, parallel
+    broadcast), the buffer epoch (train-mode BatchNorm forward: AdaBN-style re-estimation of the running statistics
+    with no optimizer step in between), and per tensor its identity, storage address and torch version counter
+    (stock optimizers, load_state_dict, `.to()`)."""
+    per_tensor = tuple((id(t), t.data_ptr(), t._version)
+                       for t in list(module.parameters()) + list(module.buffers()))
+    return (_PARAM_EPOCH, _BUFFER_EPOCH, hash(per_tensor))
 
 
 # ---------------------------------------------------------------------------

@@ -251,6 +251,8 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum
         if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or
                                                 not num_batches_tracked.is_cuda):
             raise RuntimeError("batch_norm_act: num_batches_tracked must be an int64 tensor on the GPU")
+        from . import bump_buffer_epoch
+        bump_buffer_epoch()         # the kernel rewrites the running statistics behind torch's version counters
         return _BatchNormAct.apply(x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu,
                                    num_batches_tracked, int(groups))
     if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad):

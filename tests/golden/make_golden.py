@@ -520,6 +520,99 @@ def make_base_step(dla):
     save('step_base128', **out)
 
 
+UDA_STEP128 = dict(B=4, S=128, M=16, n_obj=(5, 1, 9, 3), offset_gain=0.1, C=6)
+UDA_STEP128_CASES = {
+    # tag: (reference class name, constructor arguments, rotated boxes + periodic angle loss, batch seed)
+    'entropy': ('EntropyMinimization', (1e-4,), False, 111),
+    'maxsq': ('MaxSquaresMinimization', (0.3,), False, 121),
+    'advent': ('AdversarialEntropyMinimization', (1e-4,), True, 131),
+}
+
+
+def _uda_step128_case(uda, dla, tag, dtype):
+    """The benchmarked step and its two siblings at plain tolerance: the reference's OWN plugin classes
+    (uda/entropy_minimization.py:11-43, uda/max_squares_minimization.py:22-50,
+    uda/adversarial_entropy_minimization.py:77-152) driving the imported DLA-34 at B = 4 + 4, 128 x 128, with the
+    well-conditioned parameter fill of `step_base128` (offset_gain = 0.1: DCN offsets of about +-0.1 px).
+    ADVENT: the class runs as imported (its discriminator from get_fc_discriminator, its default Adam); only
+    `AdventLoss.forward` cannot execute on a CPU tensor (`y_t.to(y_pred.get_device())` is `.to(-1)`,
+    losses/advent.py:14) -- it is replaced by the same arithmetic, the member `crit` against a filled label."""
+    from losses.centernet import DetectionLoss
+    c = UDA_STEP128
+    cls, args, rotated, seed = UDA_STEP128_CASES[tag]
+    B, S, M, C = c['B'], c['S'], c['M'], c['C']
+    model = dla.build(num_classes=C, rotated_boxes=rotated)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes, c['offset_gain']).items()})
+    model = model.to(dtype)
+    plugin = getattr(uda, cls)(*args)
+    plugin.cfg = _ns(max_detections=40, model=_ns(backend=_ns(params=_ns(rotated_boxes=rotated, num_classes=C))))
+    plugin.backend = model
+    plugin.device = torch.device('cpu')
+    plugin.optimizer = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5, weight_decay=1e-4)
+    plugin.centernet_loss = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0,
+                                          periodic=rotated)
+    plugin.init_done()
+    res = {}
+    if tag == 'advent':
+        D = plugin.discriminator
+        dshapes = {k: tuple(v.shape) for k, v in D.state_dict().items()}
+        D.load_state_dict({k: T(gin.fill_value('discriminator.' + k, v)) for k, v in dshapes.items()})
+        D.to(dtype)
+        crit = plugin.adversarial_loss.crit
+
+        def advent_forward(y_pred, y_true):
+            loss = crit(y_pred, torch.full_like(y_pred, float(y_true)))
+            return loss, {'advent_loss': loss}
+        plugin.adversarial_loss.forward = advent_forward
+        res['dshapes_json'] = np.array(repr(sorted(dshapes.items())))
+    plugin.to('cpu')
+    plugin.set_phase(True)
+    batch = {k: T(v) for k, v in gin.detection_batch(B, C, S // 4, S // 4, M, c['n_obj'], 3 if rotated else 2,
+                                                     seed).items()}
+    for k in ('hm', 'wh', 'reg'):
+        batch[k] = batch[k].to(dtype)
+    batch['input'] = T(gin.image_batch(B, S, S, seed + 1)).to(dtype)
+    batch['target_domain_input'] = T(gin.image_batch(B, S, S, seed + 2)).to(dtype)
+    out = plugin.step(batch)
+    res.update({'stat_' + k: v.item() for k, v in out['stats'].items()})
+    res['stat_keys'] = np.array(list(out['stats']))
+    for k in ('hm', 'wh', 'reg'):
+        res['src_' + k] = out['source_domain'][k].detach().numpy()          # hm: clamped probabilities (Q1)
+        res['tgt_' + k] = out['target_domain'][k].detach().numpy()          # hm: raw logits (no loss rebinds them)
+    res['wh_target_after'] = batch['wh'].numpy()                            # Q2
+    params = dict(model.named_parameters())
+    for n in GRAD_PROBES:
+        if n in params and params[n].grad is not None:
+            res['gradsum__' + n] = _checksums(params[n].grad)
+            res['param__' + n] = _checksums(params[n])
+    if tag == 'advent':
+        for n, p_ in plugin.discriminator.named_parameters():
+            res['dgradsum__' + n] = _checksums(p_.grad)
+            res['dparam__' + n] = _checksums(p_)
+        res['source_generator'] = out['source_generator'].detach().numpy()
+    sd = model.state_dict()
+    for n in ('base.base_layer.1', 'base.level5.tree2.bn2', 'ida_up.node_2.actf.0'):
+        res['rm__' + n] = sd[n + '.running_mean'].numpy()
+        res['rv__' + n] = sd[n + '.running_var'].numpy()
+        res['nbt__' + n] = sd[n + '.num_batches_tracked'].numpy()
+    res['shapes_json'] = np.array(repr(sorted(shapes.items())))
+    return res
+
+
+def make_uda_step128(dla, tags=None):
+    uda = _import_reference_uda()
+    for tag in (tags or UDA_STEP128_CASES):
+        r32 = _uda_step128_case(uda, dla, tag, torch.float32)
+        r64 = _uda_step128_case(uda, dla, tag, torch.float64)
+        out = dict(r32)
+        for k, v in r64.items():
+            if k.startswith(('stat_', 'src_', 'tgt_', 'gradsum__', 'dgradsum__', 'source_generator', 'rm__', 'rv__')) \
+                    and k != 'stat_keys':
+                out['f64_' + k] = v
+        save('step_%s128' % tag, **out)
+
+
 # ---------------------------------------------------------------------------
 RESNET_GRAD_PROBES = [
     'base.0.weight', 'base.1.weight', 'base.4.1.conv2.weight', 'base.5.0.downsample.0.weight',
@@ -746,7 +839,7 @@ def make_targets():
 if __name__ == '__main__':
     oracle_dcn.build()
     which = set(sys.argv[1:]) or {'decode', 'losses', 'dla', 'step', 'advent', 'resnet', 'targets', 'mobilenetv2',
-                                  'getdet', 'base'}
+                                  'getdet', 'base', 'uda128'}
     if 'decode' in which:
         make_decode()
     if 'resnet' in which:
@@ -755,13 +848,13 @@ if __name__ == '__main__':
         make_targets()
     if 'mobilenetv2' in which:
         make_mobilenetv2()
-    if 'losses' in which or 'advent' in which:
+    if which & {'losses', 'advent', 'uda128'}:
         _load_entropy_map()
     if 'losses' in which:
         make_losses()
     if 'getdet' in which:
         make_getdet()
-    if 'dla' in which or 'step' in which or 'advent' in which or 'base' in which:
+    if which & {'dla', 'step', 'advent', 'base', 'uda128'}:
         d = make_dla() if 'dla' in which else _import_reference_dla()
         if 'base' in which:
             make_base_step(d)
@@ -769,3 +862,5 @@ if __name__ == '__main__':
             make_step(d)
         if 'advent' in which:
             make_advent(d)
+        if 'uda128' in which:
+            make_uda_step128(d)

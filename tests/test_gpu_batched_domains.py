@@ -119,8 +119,12 @@ def test_batched_step_equals_the_sequential_step(golden, kind):
             assert _rel(bb[n], bs[n]) <= 1e-5, n
         else:
             assert int(bb[n]) == int(bs[n]) == 2, n        # Q6: two BatchNorm updates per step
-    # the target heads that feed no loss are evaluated without a tape
-    assert ob['target_domain']['hm'].requires_grad and not ob['target_domain']['wh'].requires_grad
+    # the target heads that feed no loss are evaluated without a tape; like the reference's they still say
+    # requires_grad, and a loss that does reach one fails loudly instead of training nothing
+    assert ob['target_domain']['hm'].requires_grad and ob['target_domain']['wh'].requires_grad
+    import pytest
+    with pytest.raises(RuntimeError, match='target_grad_heads'):
+        ob['target_domain']['wh'].sum().backward()
 
 
 def test_batched_advent_step_equals_the_sequential_step(golden):

@@ -177,3 +177,37 @@ def test_dcn_layer_is_reproducible_at_full_size(B, C, S, Co):
         assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][2], o[2])
         for a, b in ((outs[0][1], o[1]), (outs[0][3], o[3])):
             assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
+
+
+def test_literal_c_abi_entry_points():
+    """The two symbols SURVEY 8b names -- `cnuda_dcn_v2_forward` / `cnuda_dcn_v2_backward`, the binding INTEGRATION.md
+    section A shows (src/dcn_v2.h:10-54) -- called directly through ctypes with raw device pointers, no shim."""
+    import ctypes
+    import hip_runtime as hr
+    (x, w, b, off, m, go), geom = _case(17, 2, 16, 8, 9, 11)
+    want = od.dcn_v2_forward(x, w, b, off, m, *geom)
+    wg = od.dcn_v2_backward(x, w, b, off, m, go, *geom)
+    dx, dw_, db, doff, dm, dgo = [t.to(DEV) for t in (x, w, b, off, m, go)]
+    L = ctypes.CDLL(hr.LIB_PATH)
+    L.cnuda_dcn_v2_workspace_bytes.restype = ctypes.c_size_t
+    L.cnuda_last_error.restype = ctypes.c_char_p
+    B, C, H, W = x.shape
+    dims = [ctypes.c_int(v) for v in (B, C, H, W, w.shape[0]) + geom]
+    nbytes = L.cnuda_dcn_v2_workspace_bytes(*dims)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = torch.empty_like(want, device=DEV)
+    rc = L.cnuda_dcn_v2_forward(P(dx), P(dw_), P(db), P(doff), P(dm), P(out), *dims, P(ws), ctypes.c_size_t(nbytes), st)
+    assert rc == 0, L.cnuda_last_error()
+    _close(out, want)
+    grads = [torch.empty_like(t) for t in (dx, doff, dm, dw_, db)]
+    rc = L.cnuda_dcn_v2_backward(P(dx), P(dw_), P(db), P(doff), P(dm), P(dgo), *[P(g) for g in grads], *dims, P(ws),
+                                 ctypes.c_size_t(nbytes), st)
+    assert rc == 0, L.cnuda_last_error()
+    torch.cuda.synchronize()
+    for got, ref in zip(grads, wg):
+        _close(got, ref)
+    # a workspace that is too small is refused, not overrun
+    rc = L.cnuda_dcn_v2_forward(P(dx), P(dw_), P(db), P(doff), P(dm), P(out), *dims, P(ws), ctypes.c_size_t(16), st)
+    assert rc != 0 and b'workspace' in L.cnuda_last_error()

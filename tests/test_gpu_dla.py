@@ -325,3 +325,85 @@ def test_advent_step_golden(golden):
     for p in plugin.discriminator.parameters():
         assert p.requires_grad                                      # unfrozen again after the generator phase
     assert out['source_generator'].shape == (B, 1, 1, 1)
+
+
+UDA128 = {'entropy': ('EntropyMinimization', (1e-4,), False, 111),
+          'maxsq': ('MaxSquaresMinimization', (0.3,), False, 121),
+          'advent': ('AdversarialEntropyMinimization', (1e-4,), True, 131)}
+
+
+@pytest.mark.parametrize('batch_domains', [True, False], ids=['batched', 'sequential'])
+@pytest.mark.parametrize('tag', sorted(UDA128))
+def test_uda_step128_plain_1e4(golden, tag, batch_domains):
+    """S2 (the benchmarked step), S3, S4 at north_star's plain tolerance: one training step of the product's plugin
+    against the reference's OWN plugin class (uda/entropy_minimization.py:11-43, uda/max_squares_minimization.py:22-50,
+    uda/adversarial_entropy_minimization.py:77-152; tests/golden/step_<tag>128.npz, B = 4 + 4 at 128 x 128, DCN offsets
+    of +-0.1 px -- the reference's own float32 and float64 runs agree to ~2e-5 there).  Stats, both domains' head
+    outputs and the running statistics: |got - ref| <= 1e-4 |ref|max, no calibration; gradient check sums:
+    max(1e-4 of the gradient's l1 mass, 8 x the reference's own float32-vs-float64 distance).  Once through the
+    default batched two-domain path, once with the reference's literal call sequence (batch_domains = False)."""
+    import uda
+    from backends import dla
+    from hip_runtime import optim
+    from losses.centernet import DetectionLoss
+    g = golden('step_%s128' % tag)
+    cls, args, rotated, seed = UDA128[tag]
+    B, S, M, C, n_obj = 4, 128, 16, 6, (5, 1, 9, 3)
+    shapes = dict(ast.literal_eval(str(g['shapes_json'])))
+    model = dla.build(num_classes=C, rotated_boxes=rotated)
+    model.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes, 0.1).items()})
+    plugin = getattr(uda, cls)(*args)
+    plugin.batch_domains = batch_domains
+    plugin.cfg = _Cfg(max_detections=40, model=_Cfg(backend=_Cfg(params=_Cfg(rotated_boxes=rotated, num_classes=C))))
+    plugin.backend = model
+    plugin.device = torch.device(DEV)
+    plugin.optimizer = optim.Adam([p for p in model.parameters() if p.requires_grad], lr=5e-5, weight_decay=1e-4)
+    plugin.centernet_loss = DetectionLoss(hm_weight=1.0, wh_weight=0.1, off_weight=1.0, angle_weight=1.0,
+                                          periodic=rotated)
+    plugin.init_done()
+    if tag == 'advent':
+        dshapes = dict(ast.literal_eval(str(g['dshapes_json'])))
+        assert sorted(plugin.discriminator.state_dict()) == sorted(dshapes)
+        plugin.discriminator.load_state_dict(
+            {k: T(gin.fill_value('discriminator.' + k, tuple(v))) for k, v in dshapes.items()})
+    plugin.to(DEV)
+    plugin.set_phase(True)
+    data = {k: T(v) for k, v in gin.detection_batch(B, C, S // 4, S // 4, M, n_obj, 3 if rotated else 2, seed).items()}
+    data['input'] = T(gin.image_batch(B, S, S, seed + 1))
+    data['target_domain_input'] = T(gin.image_batch(B, S, S, seed + 2))
+    out = plugin.step(data)
+    assert list(out['stats']) == [str(k) for k in g['stat_keys']]
+    for k, v in out['stats'].items():
+        assert not v.is_cuda and not v.requires_grad
+        _close_rel(v.item(), g['stat_' + k], what='stat ' + k)
+    for k in ('hm', 'wh', 'reg'):
+        _close_rel(out['source_domain'][k].detach().cpu().numpy(), g['src_' + k], what='source ' + k)   # hm: Q1
+        _close_rel(out['target_domain'][k].detach().cpu().numpy(), g['tgt_' + k], what='target ' + k)
+    np.testing.assert_array_equal(data['wh'].cpu().numpy(), g['wh_target_after'])                       # Q2
+    params = dict(model.named_parameters())
+
+    def check_gradsums(prefix, named, pprefix):
+        for fk in g.files:
+            if not fk.startswith(prefix):
+                continue
+            n = fk[len(prefix):]
+            got, w32, w64 = _checksums(named[n].grad), g[fk], g['f64_' + fk]
+            noise, err = np.abs(w32 - w64).max(), np.abs(_checksums(named[n].grad) - w64).max()
+            print('%-58s err/|g|_1 %.2e  reference noise/|g|_1 %.2e'
+                  % (n, err / max(w64[1], 1e-300), noise / max(w64[1], 1e-300)))
+            assert err <= max(1e-4 * w64[1], 8 * noise), (n, got, w64, noise)
+            gotp, wantp = _checksums(named[n]), g[pprefix + n]
+            flips = 0.05 * named[n].numel() * 2 * (5e-5 if pprefix == 'param__' else 1e-3)   # Adam sign flips
+            assert np.abs(gotp - wantp).max() <= 1e-5 * max(1.0, wantp[1]) + flips, (n, gotp, wantp)
+    check_gradsums('gradsum__', params, 'param__')
+    if tag == 'advent':
+        check_gradsums('dgradsum__', dict(plugin.discriminator.named_parameters()), 'dparam__')
+        _close_rel(out['source_generator'].detach().cpu().numpy(), g['source_generator'], what='source_generator')
+        assert all(p.requires_grad for p in plugin.discriminator.parameters())
+    sd = model.state_dict()
+    for fk in g.files:
+        if fk.startswith('rm__'):
+            n = fk[4:]
+            _close_rel(sd[n + '.running_mean'].cpu().numpy(), g[fk], what='running_mean ' + n)
+            _close_rel(sd[n + '.running_var'].cpu().numpy(), g['rv__' + n], what='running_var ' + n)
+            assert int(sd[n + '.num_batches_tracked']) == int(g['nbt__' + n]) == 2                   # Q6

@@ -138,3 +138,35 @@ def test_batchnorm_folding_matches_the_batchnorm_kernels_and_tracks_the_weights(
     model.fold = False
     boxes2, scores2, _ = model(x)
     assert (scores2 - scores0).abs().max().item() <= 1e-4
+
+
+def test_folded_weights_follow_running_statistics_re_estimated_without_an_optimizer_step(golden):
+    """AdaBN-style use: train-mode forward passes over target images (running statistics move, no parameter does),
+    then export.  The statistics kernel writes running_mean / running_var through raw pointers, so torch's version
+    counters and the parameter epoch never change -- the folded copies must still be rebuilt
+    (hip_runtime.bump_buffer_epoch)."""
+    from backends import dla
+    from export import CenterNet
+    g = golden('dla_axis')
+    shapes = dict(ast.literal_eval(str(g['shapes_json'])))
+    backend = dla.build(num_classes=6)
+    backend.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes, 0.3).items()})
+    backend = backend.to(DEV).eval()
+    x = T(gin.image_batch(2, 128, 128, 92)).to(DEV)
+    model = CenterNet(backend, 30).eval()
+    with model._folding():
+        with torch.no_grad():
+            before = {k: v.clone() for k, v in backend(x).items()}
+    backend.train()
+    with torch.no_grad():
+        for seed in (93, 94, 95):
+            backend(T(gin.image_batch(2, 128, 128, seed)).to(DEV) * 1.5 + 0.2)
+    backend.eval()
+    with torch.no_grad():
+        want = backend(x)                                  # eval-mode BatchNorm kernels on the new statistics
+    assert (want['hm'] - before['hm']).abs().max().item() > 1e-3
+    with model._folding():
+        with torch.no_grad():
+            got = backend(x)
+    for k in want:
+        assert (got[k] - want[k]).abs().max().item() <= 1e-4 * want[k].abs().max().item(), k

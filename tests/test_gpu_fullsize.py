@@ -182,3 +182,90 @@ def test_kernels_are_unaffected_by_work_on_another_stream():
         assert torch.equal(y, ref_y), it
         assert torch.equal(d[0], ref_d[0]) and torch.equal(d[2], ref_d[2]) and torch.equal(d[3], ref_d[3]), it
         assert (d[1] - ref_d[1]).abs().max().item() <= 1e-5 * ref_d[1].abs().max().item(), it
+
+
+def _dcn_full_case(B, C, Co, S, off_scale, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, S, S, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    b = torch.randn(Co, generator=g)
+    off = torch.randn(B, 18, S, S, generator=g) * off_scale
+    m = torch.sigmoid(torch.randn(B, 9, S, S, generator=g))
+    go = torch.randn(B, Co, S, S, generator=g)
+    return x, w, b, off, m, go
+
+
+# B is the smallest batch at which the launch plan picks the kernels the 32-image bench batch runs: the fused 64-row
+# `DcnFwdLoader` tile (one M tile: >= 512 pixel tiles), its column side output, the weight gradient from the saved
+# columns, the short-K column-gradient GEMM, the LDS-window col2im on 4 x 64 tiles
+@pytest.mark.parametrize('off_scale', [1.0, 6.0], ids=['pm1px', 'pm6px'])
+@pytest.mark.parametrize('B,C,Co,S', [(4, 64, 64, 128), (16, 128, 64, 64)], ids=['64to64_128sq', '128to64_64sq'])
+def test_full_size_dcn_layer_matches_the_oracle(B, C, Co, S, off_scale):
+    """`dcn_v2_cuda.cu:42-341` at the layer shapes the bench runs, VALUES against the CPU oracle (forward, the saved
+    columns, all five gradients, 1e-4 of each tensor's magnitude), through the product's autograd path (which keeps
+    the columns) and through the literal `_ext` entry points (which do not) -- and again while a second stream runs
+    convolutions on the same CUs: everything but grad_input (straggler atomics) must then be bit-identical."""
+    import _ext
+    import hip_runtime as hr
+    from hip_runtime import ops
+    from libs.DCNv2.dcn_v2 import dcn_v2_conv
+    from oracle import dcn as od
+    x, w, b, off, m, go = _dcn_full_case(B, C, Co, S, off_scale, 1000 * C + S + int(off_scale))
+    geom = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    want_y = od.dcn_v2_forward(x, w, b, off, m, *geom)
+    want = od.dcn_v2_backward(x, w, b, off, m, go, *geom)              # input, offset, mask, weight, bias
+    # the reference's columns (rows (c, tap), dcn_v2_im2col_cuda.cu:152-186) of image 0 and B-1, as (tap, c) rows
+    col = torch.empty(C * 9, S * S)
+    want_cols = {}
+    for bi in (0, B - 1):
+        od._fn('im2col', torch.float32)(od._p(x[bi]), od._p(off[bi]), od._p(m[bi]), od._p(col),
+                                        *od._ints(C, S, S, S, S, 3, 3, 1, 1, 1, 1, 1, 1, 1))
+        want_cols[bi] = col.view(C, 9, S * S).permute(1, 0, 2).reshape(9 * C, S * S).clone()
+    dev = [t.to(DEV) for t in (x, w, b, off, m, go)]
+
+    def close(got, ref, what):
+        scale = ref.abs().max().item()
+        err = (got.double().cpu() - ref.double()).abs().max().item()
+        assert err <= 1e-4 * scale, (what, err, scale)
+
+    def autograd_path():
+        leaves = [t.clone().requires_grad_(True) for t in (dev[0], dev[3], dev[4], dev[1], dev[2])]   # x, off, m, w, b
+        y = dcn_v2_conv(*leaves, 1, 1, 1, 1)
+        cols = y.grad_fn.saved_tensors[5]
+        y.backward(dev[5])
+        return [y.detach()] + [l.grad for l in leaves] + [cols.clone()]
+
+    hr.prof_begin()
+    res = autograd_path()
+    names = ' | '.join(hr.prof_end())
+    print(names)
+    assert 'DcnFwdLoader> (+ column side output)' in names, names
+    assert 'dcn_col2im_kernel' in names and 'dcn_coord_grad_kernel' in names, names
+    y, gx, goff, gm, gw, gb, cols = res
+    close(y, want_y, 'forward')
+    for bi, wc in want_cols.items():
+        close(cols[bi], wc, 'saved columns of image %d' % bi)
+    for got, ref, what in zip((gx, goff, gm, gw, gb), want, ('input', 'offset', 'mask', 'weight', 'bias')):
+        close(got, ref, 'grad_' + what)
+    # the literal native entry points (no saved columns: the weight gradient re-samples)
+    close(_ext.dcn_v2_forward(dev[0], dev[1], dev[2], dev[3], dev[4], *geom), want_y, '_ext forward')
+    for got, ref, what in zip(_ext.dcn_v2_backward(*dev, *geom), want, ('input', 'offset', 'mask', 'weight', 'bias')):
+        close(got, ref, '_ext grad_' + what)
+    # ... and with convolutions resident on the same CUs
+    x3 = torch.randn(32, 128, 64, 64, device=DEV, requires_grad=True)
+    w3 = (torch.randn(128, 128, 3, 3, device=DEV) * 0.05).requires_grad_(True)
+    g3 = torch.randn(32, 128, 64, 64, device=DEV)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for it in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                y3 = ops.conv2d(x3, w3, None, 1, 1)
+                if it % 2:
+                    y3.backward(g3)
+        r2 = autograd_path()
+        torch.cuda.synchronize()
+        for i, what in ((0, 'forward'), (2, 'grad_offset'), (3, 'grad_mask'), (4, 'grad_weight'), (5, 'grad_bias'),
+                        (6, 'saved columns')):
+            assert torch.equal(r2[i], res[i]), (it, what)
+        close(r2[1], want[0], 'grad_input beside another stream')
