@@ -438,7 +438,7 @@ struct DcnColsBufLoader {
 
 // ---------------------------------------------------------------------------
 // backward (1): the column gradient dcol[b][(tap,c)][p] is produced by a plain
-// 1x1 implicit GEMM over grad_output (weights transposed by dcn_wt_kernel) and consumed by
+// 1x1 implicit GEMM over grad_output (weights transposed by dcn_prep_kernel) and consumed by
 // two HBM-streaming kernels that need no MFMA, no workgroup barriers and few registers:
 //   dcn_coord_grad_kernel : one thread per (pixel, tap), channels serial -> grad_offset /
 //                           grad_mask written once (no atomics, no memset) + a 16-byte
@@ -446,17 +446,6 @@ struct DcnColsBufLoader {
 //   dcn_col2im_kernel     : bilinear scatter of dcol*mask into grad_input through an LDS
 //                           window; every wave owns four channel planes.
 // ---------------------------------------------------------------------------
-__global__ void dcn_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co, int C, int T) {
-    const long long total = (long long)Co * C * T;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int o = (int)(i % Co);
-        const long long r = i / Co;            // r = tap*C + c
-        const int c = (int)(r % C), tap = (int)(r / C);
-        wt[i] = w[((size_t)o * C + c) * T + tap];
-    }
-}
-
 struct DcnGeo { int cell; float lh, lw, mask; };   // cell = h0 << 16 | (w0 & 0xffff); h0 = -32768: tap outside
 static_assert(sizeof(DcnGeo) == 16, "geometry record is one dwordx4");
 
@@ -561,64 +550,60 @@ struct DcnCol2imParams {
     float* gin;
     int TR, TC, tc_shift, tiles_y, tiles_x, ncg, WSZmax, claim_sz;
 };
-// Workgroup = (image, TR x TC tile of output pixels (256), 16 channels).  The four waves never synchronise:
-// wave w owns channel planes 4w..4w+3 of the LDS window, walks all 256 pixels x taps of the tile (64 pixels
-// per step, lanes along x) and does plain LDS read-add-write.  Two lanes can only hit the same cell in one
-// instruction if their (h0, w0) anchors are equal: every lane writes its id into a per-wave claim map at its
-// anchor and reads it back -- the survivor scatters through LDS, the (rare) losers and the corners outside the
-// window use global atomics.
-__global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int n_wg) {
-    extern __shared__ __align__(16) float win[];     // 4 waves x [WSZ cells][4 channels] + 256 dump cells x 4 + claim maps
-    const DcnGeom& g = p.g;
+// The col2im walk of ONE wave over ONE 16-channel group of a TR x TC pixel tile (256 pixels): the wave owns
+// channel planes c_w..c_w+3 of the LDS window ([cell][4 channels]: the four channels of a cell are ONE 16-byte
+// access), zeroes them, walks all 256 pixels x taps (64 pixels per step, lanes along x) doing plain LDS
+// read-add-write one corner at a time, and flushes every touched cell with one coalesced atomic.  No workgroup
+// synchronisation.  Two lanes hit the same cell in one instruction only if their (h0, w0) anchors are equal:
+//   * fast path (a step whose 64 lanes lie on one output row and whose samples all sit within [-2, 2) cell columns
+//     of their undeformed position): only lanes at most 3 apart can share an anchor, so three DPP shifts rank
+//     every lane among its equals -- no LDS round trip; round r scatters the lanes of rank r;
+//   * otherwise every lane writes its id into a per-wave claim map at its anchor and reads it back; the
+//     survivor scatters, losers retry (<= 3 rounds), leftovers and corners outside the window use global atomics.
+struct DcnScatterCtx {
+    int y0, x0, TC, tc_shift;                 // tile origin, tile width
+    int wy0, wx0, WR, WC, WSZ;                // window, clipped to the plane
+    float4* wp;                               // this wave's window planes
+    float4* dump;                             // a private cell for inactive lanes
+    volatile unsigned char* claim;            // this wave's claim map [(WR+1)*(WC+1)]
+};
+__device__ __forceinline__ void dcn_scatter_window(DcnScatterCtx& x, const DcnGeom& g, int TR, int WSZmax) {
+    x.wy0 = x.y0 * g.sh - g.ph - CI_MARGIN;
+    x.wx0 = x.x0 * g.sw - g.pw - CI_MARGIN;
+    x.WR = (TR - 1) * g.sh + (g.kh - 1) * g.dh + 2 * CI_MARGIN + 1;
+    x.WC = (x.TC - 1) * g.sw + (g.kw - 1) * g.dw + 2 * CI_MARGIN + 1;
+    if (x.wy0 < 0) { x.WR += x.wy0; x.wy0 = 0; }
+    if (x.wx0 < 0) { x.WC += x.wx0; x.wx0 = 0; }
+    if (x.wy0 + x.WR > g.H) x.WR = g.H - x.wy0;
+    if (x.wx0 + x.WC > g.W) x.WC = g.W - x.wx0;
+    if (x.WR < 0 || WSZmax == 0) x.WR = 0;     // WSZmax == 0: window does not fit the LDS -> global atomics only
+    if (x.WC < 0 || WSZmax == 0) x.WC = 0;
+    x.WSZ = x.WR * x.WC;                       // <= WSZmax
+}
+__device__ __forceinline__ void dcn_scatter_group(const DcnScatterCtx& x, const DcnGeom& g, const DcnGeo* __restrict__ geo_b,
+                                                  const float* __restrict__ dcol_b, float* __restrict__ gin_b, int c_w,
+                                                  int lane) {
     const int T = g.kh * g.kw, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    int id = xcd_remap(blockIdx.x, n_wg);
-    const int cg = id % p.ncg; id /= p.ncg;
-    const int tx = id % p.tiles_x; id /= p.tiles_x;
-    const int ty = id % p.tiles_y;
-    const int b = id / p.tiles_y;
-    const int y0 = ty * p.TR, x0 = tx * p.TC;
-    // window (workgroup-uniform), clipped to the plane
-    int wy0 = y0 * g.sh - g.ph - CI_MARGIN, wx0 = x0 * g.sw - g.pw - CI_MARGIN;
-    int WR = (p.TR - 1) * g.sh + (g.kh - 1) * g.dh + 2 * CI_MARGIN + 1;
-    int WC = (p.TC - 1) * g.sw + (g.kw - 1) * g.dw + 2 * CI_MARGIN + 1;
-    if (wy0 < 0) { WR += wy0; wy0 = 0; }
-    if (wx0 < 0) { WC += wx0; wx0 = 0; }
-    if (wy0 + WR > g.H) WR = g.H - wy0;
-    if (wx0 + WC > g.W) WC = g.W - wx0;
-    if (WR < 0 || p.WSZmax == 0) WR = 0;     // WSZmax == 0: window does not fit the LDS -> global atomics only
-    if (WC < 0 || p.WSZmax == 0) WC = 0;
-    const int WSZ = WR * WC;                          // <= p.WSZmax
-    // this wave's window: [cell][4 channels] -- the four channels of a cell are ONE 16-byte LDS access
-    float4* wp = reinterpret_cast<float4*>(win) + (size_t)wid * WSZ;
-    float4* dump = reinterpret_cast<float4*>(win + CI_CG * p.WSZmax) + tid;      // a private cell for inactive lanes
-    volatile unsigned char* claim =
-        reinterpret_cast<unsigned char*>(win + CI_CG * p.WSZmax + 4 * 256) + wid * p.claim_sz;   // [(WR+1)*(WC+1)]
-    const int c_w = cg * CI_CG + wid * 4;
+    const int WR = x.WR, WC = x.WC, WSZ = x.WSZ, wy0 = x.wy0, wx0 = x.wx0;
+    float4* const wp = x.wp;
     for (int i = lane; i < WSZ; i += 64) wp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    *dump = make_float4(0.f, 0.f, 0.f, 0.f);
-
     const int items = 4 * T;                          // (pixel group, tap)
-    const DcnGeo* geo_b = p.geo + (size_t)b * T * HoWo;
-    const float* dcol_b = p.dcol + (size_t)b * T * g.C * HoWo;
-    float* gin_b = p.gin + (size_t)b * g.C * HW;
     int cc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) cc[r] = c_w + r < g.C ? c_w + r : g.C - 1;   // clamped loads; results dropped
     const bool cv0 = c_w < g.C, cv1 = c_w + 1 < g.C, cv2 = c_w + 2 < g.C, cv3 = c_w + 3 < g.C;
-
-    auto pixel_of = [&](int grp, bool& valid) {
-        const int t = grp * 64 + lane;
-        const int oy = y0 + (t >> p.tc_shift), ox = x0 + (t & (p.TC - 1));
-        valid = oy < g.Ho && ox < g.Wo;
-        return valid ? oy * g.Wo + ox : 0;
-    };
+    const bool one_row = x.TC == 64;                  // a step's 64 lanes are 64 consecutive pixels of one row
     DcnGeo rec_n;
     float d_n[4];
     bool valid_n;
+    int ox_n;
     auto fetch = [&](int it) {
         const int grp = it / T, tap = it - grp * T;
-        const int px = pixel_of(grp, valid_n);
+        const int t = grp * 64 + lane;
+        const int oy = x.y0 + (t >> x.tc_shift);
+        ox_n = x.x0 + (t & (x.TC - 1));
+        valid_n = oy < g.Ho && ox_n < g.Wo;
+        const int px = valid_n ? oy * g.Wo + ox_n : 0;
         rec_n = geo_b[(size_t)tap * HoWo + px];
 #pragma unroll
         for (int r = 0; r < 4; ++r) d_n[r] = dcol_b[((size_t)tap * g.C + cc[r]) * HoWo + px];
@@ -629,6 +614,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int 
         const DcnGeo rec = rec_n;
         float d[4] = {d_n[0], d_n[1], d_n[2], d_n[3]};
         const bool valid = valid_n;
+        const int ox = ox_n;
         if (it + 1 < items) fetch(it + 1);
         const int h0 = rec.cell >> 16, w0 = (int)(short)(rec.cell & 0xffff);
         const bool live = valid && h0 >= -1;
@@ -650,30 +636,54 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int 
         const int base = rh * WC + rw;
         const bool w00 = a00 && r0 && q0, w01 = a01 && r0 && q1, w10 = a10 && r1 && q0, w11 = a11 && r1 && q1;
         auto scatter = [&](bool on, int cell, float k) {
-            float4* a = on ? wp + cell : dump;
+            float4* a = on ? wp + cell : x.dump;
             const float kk = on ? k : 0.f;
             float4 cur = *a;
             cur.x += kk * d[0]; cur.y += kk * d[1]; cur.z += kk * d[2]; cur.w += kk * d[3];
             *a = cur;
             asm volatile("" ::: "memory");     // LDS program order between corners (neighbouring lanes' cells)
         };
-        // rounds: lanes whose anchor is claimed by another lane of this instruction wait for the next round
-        // (one round unless two pixels of the wave sample the same cell); after three rounds the rest spills
-        bool pending = near, done_lds = false;
+        bool done_lds = false;
+        // displacement of the sample's cell column from the undeformed one: with every near lane in {-2 .. 1}
+        // (horizontal offsets in [-2, 2)) two lanes can share an anchor only if they are at most 3 lanes apart
+        const int tap = it % T;
+        const int disp = w0 - (ox * g.sw - g.pw + (tap % g.kw) * g.dw);
+        if (one_row && !__any(near && (unsigned)(disp + 2) > 3u)) {
+            // rank = number of EARLIER lanes (distance 1..3) with the same anchor, found with three DPP shifts -- no
+            // LDS round trip; round r scatters the lanes of rank r (LDS instructions of one wave execute in order)
+            const int p1 = __builtin_amdgcn_update_dpp(-2, anchor, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const int p2 = __builtin_amdgcn_update_dpp(-2, p1, 0x138, 0xf, 0xf, false);
+            const int p3 = __builtin_amdgcn_update_dpp(-2, p2, 0x138, 0xf, 0xf, false);
+            const int rank = near ? (int)(p1 == anchor) + (int)(p2 == anchor) + (int)(p3 == anchor) : -1;
 #pragma unroll 1
-        for (int round = 0; round < 3 && __any(pending); ++round) {
-            bool won = false;
-            if (pending) {
-                claim[anchor] = (unsigned char)lane;
-                won = claim[anchor] == (unsigned char)lane;     // same wave, LDS executes in order
+            for (int round = 0; round < 4; ++round) {
+                const bool mine = rank == round;
+                if (round > 0 && !__any(mine)) break;          // ranks are dense: none of rank r -> none above
+                scatter(mine && w00, base, k00);
+                scatter(mine && w01, base + 1, k01);
+                scatter(mine && w10, base + WC, k10);
+                scatter(mine && w11, base + WC + 1, k11);
             }
-            asm volatile("" ::: "memory");
-            scatter(won && w00, base, k00);
-            scatter(won && w01, base + 1, k01);
-            scatter(won && w10, base + WC, k10);
-            scatter(won && w11, base + WC + 1, k11);
-            done_lds = done_lds || won;
-            pending = pending && !won;
+            done_lds = near;
+        } else {
+            // rounds: lanes whose anchor is claimed by another lane of this instruction wait for the next round
+            // (one round unless two pixels of the wave sample the same cell); after three rounds the rest spills
+            bool pending = near;
+#pragma unroll 1
+            for (int round = 0; round < 3 && __any(pending); ++round) {
+                bool won = false;
+                if (pending) {
+                    x.claim[anchor] = (unsigned char)lane;
+                    won = x.claim[anchor] == (unsigned char)lane;     // same wave, LDS executes in order
+                }
+                asm volatile("" ::: "memory");
+                scatter(won && w00, base, k00);
+                scatter(won && w01, base + 1, k01);
+                scatter(won && w10, base + WC, k10);
+                scatter(won && w11, base + WC + 1, k11);
+                done_lds = done_lds || won;
+                pending = pending && !won;
+            }
         }
         const bool i00 = done_lds && w00, i01 = done_lds && w01, i10 = done_lds && w10, i11 = done_lds && w11;
         const bool s00 = a00 && !i00, s01 = a01 && !i01, s10 = a10 && !i10, s11 = a11 && !i11;
@@ -701,6 +711,181 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int 
         for (int r = 0; r < 4; ++r)
             if (v[r] != 0.0f && c_w + r < g.C) atomicAdd(gcell + (size_t)(c_w + r) * HW, v[r]);
     }
+    asm volatile("" ::: "memory");
+}
+
+// Workgroup = (image, TR x TC tile of output pixels (256), 16 channels); the four waves never synchronise.
+__global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int n_wg) {
+    extern __shared__ __align__(16) float win[];     // 4 waves x [WSZ cells][4 channels] + 256 dump cells x 4 + claim maps
+    const DcnGeom& g = p.g;
+    const int T = g.kh * g.kw, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int id = xcd_remap(blockIdx.x, n_wg);
+    const int cg = id % p.ncg; id /= p.ncg;
+    const int tx = id % p.tiles_x; id /= p.tiles_x;
+    const int ty = id % p.tiles_y;
+    const int b = id / p.tiles_y;
+    DcnScatterCtx x;
+    x.y0 = ty * p.TR; x.x0 = tx * p.TC; x.TC = p.TC; x.tc_shift = p.tc_shift;
+    dcn_scatter_window(x, g, p.TR, p.WSZmax);
+    x.wp = reinterpret_cast<float4*>(win) + (size_t)wid * x.WSZ;
+    x.dump = reinterpret_cast<float4*>(win + CI_CG * p.WSZmax) + tid;
+    x.claim = reinterpret_cast<unsigned char*>(win + CI_CG * p.WSZmax + 4 * 256) + wid * p.claim_sz;
+    *x.dump = make_float4(0.f, 0.f, 0.f, 0.f);
+    dcn_scatter_group(x, g, p.geo + (size_t)b * T * HoWo, p.dcol + (size_t)b * T * g.C * HoWo,
+                      p.gin + (size_t)b * g.C * HW, cg * CI_CG + wid * 4, lane);
+}
+
+// ---------------------------------------------------------------------------
+// backward (1b): the two consumers of dcol as ONE launch for the large feature maps (round 3).
+// dcn_coord_grad_kernel is bound by its corner gathers (L1 / texture-address cycles; no LDS), dcn_col2im_kernel by
+// dependent LDS read-add-write chains and its atomic window flush (no gathers): run one after the other each
+// leaves the other's unit idle.  Here a workgroup of 8 waves owns one (image, TR x TC pixel tile) for ALL
+// channels, in two roles that never synchronise:
+//   waves 0-3 (scatter): the col2im walk -- wave w owns channel planes 4w..4w+3 of a 16-channel LDS window, and
+//                        loops over the channel groups (zero, walk 4 x T items, flush) on its own;
+//   waves 4-7 (gather) : the coordinate-gradient walk -- wave v owns pixel group v (64 pixels), taps and
+//                        channels serial, plain stores of grad_offset / grad_mask.
+// The per-(pixel, tap) geometry records both roles read are written by dcn_prep_kernel (with the transposed
+// weights of the column-gradient GEMM: one small launch in front of it).  Small maps (fewer tiles than CUs)
+// keep the two-kernel form, whose grid also spans the channel groups.
+// ---------------------------------------------------------------------------
+struct DcnPrepParams {
+    DcnGeom g;
+    const float *w, *off, *mask;
+    float* wt;
+    DcnGeo* geo;
+    int wt_blocks;
+};
+__global__ __launch_bounds__(256) void dcn_prep_kernel(DcnPrepParams p) {
+    const DcnGeom& g = p.g;
+    const int T = g.kh * g.kw;
+    if ((int)blockIdx.x < p.wt_blocks) {          // wt[(tap*C + c)][o] = w[o][c][tap]
+        const long long total = (long long)g.Co * g.C * T;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)p.wt_blocks * 256) {
+            const int o = (int)(i % g.Co);
+            const long long r = i / g.Co;
+            const int c = (int)(r % g.C), tap = (int)(r / g.C);
+            p.wt[i] = p.w[((size_t)o * g.C + c) * T + tap];
+        }
+        return;
+    }
+    if (!p.geo) return;
+    const int HoWo = g.Ho * g.Wo;
+    const long long total = (long long)g.B * T * HoWo;
+    const long long nb = (long long)gridDim.x - p.wt_blocks;
+    for (long long i = ((long long)blockIdx.x - p.wt_blocks) * 256 + threadIdx.x; i < total; i += nb * 256) {
+        const int px = (int)(i % HoWo);
+        const long long r = i / HoWo;
+        const int tap = (int)(r % T), b = (int)(r / T);
+        const int oy = px / g.Wo, ox = px - oy * g.Wo;
+        const Tap t = make_tap(g, p.off + (size_t)b * 2 * T * HoWo, p.mask + (size_t)b * T * HoWo, 0, tap, oy, ox);
+        DcnGeo rec;
+        rec.cell = t.inside ? (int)(((unsigned)t.h0 << 16) | ((unsigned)t.w0 & 0xffffu)) : (int)0x80000000u;
+        rec.lh = t.lh; rec.lw = t.lw; rec.mask = t.inside ? t.mask : 0.f;
+        p.geo[i] = rec;
+    }
+}
+
+struct DcnBwdDataParams {
+    DcnGeom g;
+    const float *in, *dcol;
+    const DcnGeo* geo;
+    float *gin, *goff, *gmask;
+    int TR, TC, tc_shift, tiles_y, tiles_x, ncg, WSZmax, claim_sz;
+    int nsplit;      // workgroups per tile: workgroup s takes the channel groups [s*ncg/nsplit, (s+1)*ncg/nsplit) and the taps = s (mod nsplit)
+};
+__global__ __launch_bounds__(512, 6) void dcn_bwd_data_kernel(DcnBwdDataParams p, int n_wg) {
+    extern __shared__ __align__(16) float win[];     // as dcn_col2im_kernel: 4 waves x [WSZ][4] + dump cells + claim maps
+    const DcnGeom& g = p.g;
+    const int T = g.kh * g.kw, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
+    int id = xcd_remap(blockIdx.x, n_wg);
+    const int part = id % p.nsplit; id /= p.nsplit;
+    const int tx = id % p.tiles_x; id /= p.tiles_x;
+    const int ty = id % p.tiles_y;
+    const int b = id / p.tiles_y;
+    const int y0 = ty * p.TR, x0 = tx * p.TC;
+    const DcnGeo* geo_b = p.geo + (size_t)b * T * HoWo;
+    const float* dcol_b = p.dcol + (size_t)b * T * g.C * HoWo;
+    auto pixel_of = [&](int grp, bool& valid) {
+        const int t = grp * 64 + lane;
+        const int oy = y0 + (t >> p.tc_shift), ox = x0 + (t & (p.TC - 1));
+        valid = oy < g.Ho && ox < g.Wo;
+        return valid ? oy * g.Wo + ox : 0;
+    };
+    if (threadIdx.x >= 256) {
+        // ---- gather role: grad_offset / grad_mask of pixel group `wid` (dcn_coord_grad_kernel's arithmetic) ----
+        bool valid;
+        const int px = pixel_of(wid, valid);
+        if (!valid) return;
+        const float* in_b = p.in + (size_t)b * g.C * HW;
+        struct __attribute__((packed, aligned(4))) Pair { float l, r; };
+#pragma unroll 1
+        for (int tap = part; tap < T; tap += p.nsplit) {
+            const DcnGeo rec = geo_b[(size_t)tap * HoWo + px];
+            const float* dc = dcol_b + (size_t)tap * g.C * HoWo + px;
+            float sm = 0.f, sh_ = 0.f, sw_ = 0.f;
+            if (rec.cell != (int)0x80000000u) {
+                const int h0 = rec.cell >> 16, w0 = (int)(short)(rec.cell & 0xffff);
+                const float lh = rec.lh, lw = rec.lw, hh = 1.0f - lh, hw = 1.0f - lw;
+                const bool ledge = w0 < 0, redge = w0 > g.W - 2;
+                const int wa = ledge ? 0 : (redge ? g.W - 2 : w0);
+                const int ht = h0 < 0 ? 0 : h0, hb = h0 + 1 > g.H - 1 ? g.H - 1 : h0 + 1;
+                const int qT = ht * g.W + wa, qB = hb * g.W + wa;
+                const float l0 = (!ledge && !redge) ? 1.f : 0.f, r0 = redge ? 1.f : 0.f;
+                const float l1 = ledge ? 1.f : 0.f, r1 = (!ledge && !redge) ? 1.f : 0.f;
+                const bool top = h0 >= 0, bot = h0 + 1 <= g.H - 1, lef = w0 >= 0, rig = w0 + 1 <= g.W - 1;
+                const float f00 = (top && lef) ? 1.f : 0.f, f01 = (top && rig) ? 1.f : 0.f, f10 = (bot && lef) ? 1.f : 0.f,
+                            f11 = (bot && rig) ? 1.f : 0.f;
+                const float A00 = hh * hw * f00, A01 = hh * lw * f01, A10 = lh * hw * f10, A11 = lh * lw * f11;
+                const float H00 = -hw * f00, H01 = -lw * f01, H10 = hw * f10, H11 = lw * f11;
+                const float W00 = -hh * f00, W01 = hh * f01, W10 = -lh * f10, W11 = lh * f11;
+                const float aTl = A00 * l0 + A01 * l1, aTr = A00 * r0 + A01 * r1, aBl = A10 * l0 + A11 * l1, aBr = A10 * r0 + A11 * r1;
+                const float hTl = H00 * l0 + H01 * l1, hTr = H00 * r0 + H01 * r1, hBl = H10 * l0 + H11 * l1, hBr = H10 * r0 + H11 * r1;
+                const float wTl = W00 * l0 + W01 * l1, wTr = W00 * r0 + W01 * r1, wBl = W10 * l0 + W11 * l1, wBr = W10 * r0 + W11 * r1;
+                float uTl = 0.f, uTr = 0.f, uBl = 0.f, uBr = 0.f;
+                for (int c0 = 0; c0 < g.C; c0 += 8) {
+                    float d[8];
+                    Pair pt[8], pb[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = c0 + u < g.C ? c0 + u : g.C - 1;
+                        const float* plane = in_b + (size_t)c * HW;
+                        d[u] = dc[(size_t)c * HoWo];
+                        pt[u] = *reinterpret_cast<const Pair*>(plane + qT);
+                        pb[u] = *reinterpret_cast<const Pair*>(plane + qB);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float dd = c0 + u < g.C ? d[u] : 0.f;
+                        uTl = fmaf(dd, pt[u].l, uTl); uTr = fmaf(dd, pt[u].r, uTr);
+                        uBl = fmaf(dd, pb[u].l, uBl); uBr = fmaf(dd, pb[u].r, uBr);
+                    }
+                }
+                sm = aTl * uTl + aTr * uTr + aBl * uBl + aBr * uBr;
+                sh_ = (hTl * uTl + hTr * uTr + hBl * uBl + hBr * uBr) * rec.mask;
+                sw_ = (wTl * uTl + wTr * uTr + wBl * uBl + wBr * uBr) * rec.mask;
+            }
+            p.gmask[((size_t)b * T + tap) * HoWo + px] = sm;
+            p.goff[((size_t)b * 2 * T + 2 * tap) * HoWo + px] = sh_;
+            p.goff[((size_t)b * 2 * T + 2 * tap + 1) * HoWo + px] = sw_;
+        }
+        return;
+    }
+    // ---- scatter role: dcn_col2im_kernel's walk, channel groups serial ----
+    DcnScatterCtx x;
+    x.y0 = y0; x.x0 = x0; x.TC = p.TC; x.tc_shift = p.tc_shift;
+    dcn_scatter_window(x, g, p.TR, p.WSZmax);
+    x.wp = reinterpret_cast<float4*>(win) + (size_t)wid * x.WSZ;
+    x.dump = reinterpret_cast<float4*>(win + CI_CG * p.WSZmax) + tid;
+    x.claim = reinterpret_cast<unsigned char*>(win + CI_CG * p.WSZmax + 4 * 256) + wid * p.claim_sz;
+    *x.dump = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* gin_b = p.gin + (size_t)b * g.C * HW;
+    const int cg_end = (part + 1) * p.ncg / p.nsplit;
+#pragma unroll 1
+    for (int cg = part * p.ncg / p.nsplit; cg < cg_end; ++cg)
+        dcn_scatter_group(x, g, geo_b, dcol_b, gin_b, cg * CI_CG + wid * 4, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -973,6 +1158,8 @@ struct DcnPlan {
     size_t gemm_bytes;
     int TR, TC, tc_shift, tiles_y, tiles_x, ncg, WSZmax, claim_sz;
     size_t col2im_lds;
+    bool fused_consumers;           // dcn_bwd_data_kernel (large maps) instead of coord_grad + col2im
+    int fused_split;                // its workgroups per tile
 };
 DcnPlan make_plan(const DcnGeom& g) {
     DcnPlan q;
@@ -1014,6 +1201,10 @@ DcnPlan make_plan(const DcnGeom& g) {
     // three workgroups per CU need <= 53 KiB each; larger windows (strides, dilations, big kernels) run windowless
     if ((size_t)CI_CG * q.WSZmax * 4 + 4096 + 4 * (size_t)q.claim_sz > 53 * 1024) { q.WSZmax = 0; q.claim_sz = 16; }
     q.col2im_lds = ((size_t)CI_CG * q.WSZmax + 4 * 256) * sizeof(float) + 4 * (size_t)q.claim_sz;
+    // one workgroup per (image, tile) must still fill the chip (three resident per CU): the 128 x 128 and 64 x 64 maps
+    q.fused_consumers = q.WSZmax > 0 && g.W >= 2 && (long long)g.B * q.tiles_y * q.tiles_x >= 512;
+    q.fused_split = 4;     // measured 1..4 on the 128 x 128 / 64 x 64 layers: 1116/1077/1093/1064 and 716/645/611/584 us
+    if (q.fused_split > q.ncg) q.fused_split = q.ncg;
     return q;
 }
 
@@ -1212,26 +1403,40 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
     }
     {
         // (1) dcol = W^T x grad_output as a 1x1 implicit GEMM, then the two streaming consumers
-        ProfGroup prof;       // sub 0: the 1x1 GEMM (its own scope), 1: coord_grad, 2: col2im
-        hipLaunchKernelGGL(dcn_wt_kernel, dim3(stream_grid((long long)q.T * C * Cout, 256)), dim3(256), 0, st, weight,
-                           wt, Cout, C, q.T);
+        ProfGroup prof;       // sub 0: the 1x1 GEMM (its own scope), 1: coord_grad, 2: col2im, 3: both as one launch
+        {
+            // transposed weights of the 1x1 GEMM + (fused form) the geometry records, one launch
+            const int wt_blocks = stream_grid((long long)q.T * C * Cout, 256);
+            const int geo_blocks = q.fused_consumers ? stream_grid((long long)B * q.T * HoWo, 256) : 0;
+            DcnPrepParams pp{g, weight, offset, mask, wt, q.fused_consumers ? geo : nullptr, wt_blocks};
+            hipLaunchKernelGGL(dcn_prep_kernel, dim3(wt_blocks + geo_blocks), dim3(256), 0, st, pp);
+        }
         if (int rc = cnuda_conv2d_forward(grad_output, wt, nullptr, dcol, B, Cout, g.Ho, g.Wo, q.T * C, 1, 1, 1, 1, 0,
                                           0, -1.0f, gemm_ws, q.gemm_bytes, stream))
             return rc;
-        {
-            DcnCoordParams p{g, input, offset, mask, dcol, grad_offset, grad_mask, geo};
-            const int tiles = ceil_div(HoWo, 64), tw = q.T < 16 ? q.T : 16;
-            ProfScope scope(st, 1);
-            scope.name("dcn_coord_grad_kernel");
-            hipLaunchKernelGGL(dcn_coord_grad_kernel, dim3(B * tiles), dim3(64, tw), 0, st, p, tiles);
-        }
-        {
-            DcnCol2imParams p{g, dcol, geo, grad_input, q.TR, q.TC, q.tc_shift, q.tiles_y, q.tiles_x,
-                              q.ncg, q.WSZmax, q.claim_sz};
-            const int n_wg = B * q.tiles_y * q.tiles_x * q.ncg;
-            ProfScope scope(st, 2);
-            scope.name("dcn_col2im_kernel");
-            hipLaunchKernelGGL(dcn_col2im_kernel, dim3(n_wg), dim3(256), q.col2im_lds, st, p, n_wg);
+        if (q.fused_consumers) {
+            DcnBwdDataParams p{g, input, dcol, geo, grad_input, grad_offset, grad_mask, q.TR, q.TC, q.tc_shift,
+                               q.tiles_y, q.tiles_x, q.ncg, q.WSZmax, q.claim_sz, q.fused_split};
+            const int n_wg = B * q.tiles_y * q.tiles_x * q.fused_split;
+            ProfScope scope(st, 3);
+            scope.name("dcn_bwd_data_kernel");
+            hipLaunchKernelGGL(dcn_bwd_data_kernel, dim3(n_wg), dim3(512), q.col2im_lds, st, p, n_wg);
+        } else {
+            {
+                DcnCoordParams p{g, input, offset, mask, dcol, grad_offset, grad_mask, geo};
+                const int tiles = ceil_div(HoWo, 64), tw = q.T < 16 ? q.T : 16;
+                ProfScope scope(st, 1);
+                scope.name("dcn_coord_grad_kernel");
+                hipLaunchKernelGGL(dcn_coord_grad_kernel, dim3(B * tiles), dim3(64, tw), 0, st, p, tiles);
+            }
+            {
+                DcnCol2imParams p{g, dcol, geo, grad_input, q.TR, q.TC, q.tc_shift, q.tiles_y, q.tiles_x,
+                                  q.ncg, q.WSZmax, q.claim_sz};
+                const int n_wg = B * q.tiles_y * q.tiles_x * q.ncg;
+                ProfScope scope(st, 2);
+                scope.name("dcn_col2im_kernel");
+                hipLaunchKernelGGL(dcn_col2im_kernel, dim3(n_wg), dim3(256), q.col2im_lds, st, p, n_wg);
+            }
         }
         if (int rc = check_launch("cnuda_dcn_v2_backward(data)")) return rc;
     }

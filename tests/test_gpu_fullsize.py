@@ -198,7 +198,7 @@ def _dcn_full_case(B, C, Co, S, off_scale, seed):
 # B is the smallest batch at which the launch plan picks the kernels the 32-image bench batch runs: the fused 64-row
 # `DcnFwdLoader` tile (one M tile: >= 512 pixel tiles), its column side output, the weight gradient from the saved
 # columns, the short-K column-gradient GEMM, the LDS-window col2im on 4 x 64 tiles
-@pytest.mark.parametrize('off_scale', [1.0, 6.0], ids=['pm1px', 'pm6px'])
+@pytest.mark.parametrize('off_scale', [0.3, 1.0, 6.0], ids=['pm03px', 'pm1px', 'pm6px'])   # 0.3: col2im's DPP ranking path
 @pytest.mark.parametrize('B,C,Co,S', [(4, 64, 64, 128), (16, 128, 64, 64)], ids=['64to64_128sq', '128to64_64sq'])
 def test_full_size_dcn_layer_matches_the_oracle(B, C, Co, S, off_scale):
     """`dcn_v2_cuda.cu:42-341` at the layer shapes the bench runs, VALUES against the CPU oracle (forward, the saved
@@ -210,7 +210,7 @@ def test_full_size_dcn_layer_matches_the_oracle(B, C, Co, S, off_scale):
     from hip_runtime import ops
     from libs.DCNv2.dcn_v2 import dcn_v2_conv
     from oracle import dcn as od
-    x, w, b, off, m, go = _dcn_full_case(B, C, Co, S, off_scale, 1000 * C + S + int(off_scale))
+    x, w, b, off, m, go = _dcn_full_case(B, C, Co, S, off_scale, 1000 * C + S + int(10 * off_scale))
     geom = (3, 3, 1, 1, 1, 1, 1, 1, 1)
     want_y = od.dcn_v2_forward(x, w, b, off, m, *geom)
     want = od.dcn_v2_backward(x, w, b, off, m, go, *geom)              # input, offset, mask, weight, bias
