@@ -1373,14 +1373,20 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
     // (running the weight gradient on a second stream beside the data-gradient chain was tried in round 2: the
     // kernels do overlap but contend for the same LDS / issue slots -- nothing gained, removed)
     hipStream_t wst = st;
+    // every timed scope below is recorded under the call's tag; sub 0: the column-gradient 1x1 GEMM (its own scope
+    // inside cnuda_conv2d_forward), 1: coord_grad, 2: col2im, 3: both as one launch, 4: the weight-gradient GEMM
+    ProfGroup prof;
     launch_channel_sum(grad_output, grad_bias, B, Cout, HoWo, wst, bsum);
     // (2) weight gradient
     {
+      {
+        ProfScope wscope(st, 4);
         if (columns) {
             DcnColWParams p{g, columns, grad_output};
             static const bool buf_on = !(getenv("CNUDA_BUF") && getenv("CNUDA_BUF")[0] == '0');
             const bool buf = buf_on && (size_t)B * q.T * C * HoWo * sizeof(float) < IG_BUF_OOB &&
                              (size_t)B * Cout * HoWo * sizeof(float) < IG_BUF_OOB && HoWo < (1 << 23);
+            wscope.name("igemm_wgrad_kernel<%s, 64, %d>", buf ? "DcnColWBufLoader" : "DcnColWLoader", q.Jp % 128 == 0 ? 128 : 64);
             if (buf && q.Jp % 128 == 0)
                 hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
                                    dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
@@ -1395,15 +1401,16 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
                                    dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
         } else {
             DcnWParams p{g, input, offset, mask, grad_output};
+            wscope.name("igemm_wgrad_kernel<DcnWLoader, 64, 64>");
             hipLaunchKernelGGL((igemm_wgrad_kernel<DcnWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
                                dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
         }
+      }
         if (int rc = check_launch("cnuda_dcn_v2_backward(weight)")) return rc;
         launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, wst);
     }
     {
         // (1) dcol = W^T x grad_output as a 1x1 implicit GEMM, then the two streaming consumers
-        ProfGroup prof;       // sub 0: the 1x1 GEMM (its own scope), 1: coord_grad, 2: col2im, 3: both as one launch
         {
             // transposed weights of the 1x1 GEMM + (fused form) the geometry records, one launch
             const int wt_blocks = stream_grid((long long)q.T * C * Cout, 256);

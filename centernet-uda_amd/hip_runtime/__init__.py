@@ -314,7 +314,7 @@ def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
         # (sub 3: both consumers as one launch, dcn_bwd_data_kernel: dcol and the geometry records once each way,
         # the input, grad_offset / grad_mask out, grad_input out)
         fused_bytes = 4.0 * px * T * C + 16.0 * px * T + 12.0 * px * T + 8.0 * B * C * H * W
-        _Prof.table.append([(flops, 0.0), (0.0, coord_bytes), (0.0, col2im_bytes), (0.0, fused_bytes)])
+        _Prof.table.append([(flops, 0.0), (0.0, coord_bytes), (0.0, col2im_bytes), (0.0, fused_bytes), (flops, 0.0)])   # 4: weight gradient
     elif kind in ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'dcn_fwd'):
         _Prof.table.append([(flops, 0.0)])
     else:

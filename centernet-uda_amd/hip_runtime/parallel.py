@@ -41,6 +41,10 @@ class DataParallel(nn.Module):
         self.process_group = process_group
         self._sync = True
         self._works = []
+        # what the exchange step did since the last reset_exchange_stats(): bytes / buckets all-reduced, and the time the
+        # compute stream spent waiting for collectives that had not finished under the backward pass ("exposed")
+        self.measure_exchange = False
+        self._xstats = {'steps': 0, 'bytes': 0, 'buckets': 0, 'events': [], 'host_wait_s': 0.0}
         params = [p for p in module.parameters() if p.requires_grad]
         self.arena = arena_for(params)
         self.arena.on_ready = self._param_ready
@@ -77,6 +81,10 @@ class DataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
+    def forward_domains(self, *args, **kwargs):
+        # explicit (not through __getattr__): anything forward() grows must be mirrored here, not silently skipped
+        return self.module.forward_domains(*args, **kwargs)
+
     def sync_buffers(self):
         """Every rank's buffers (BatchNorm running statistics, batch counters) := rank 0's; one broadcast per
         dtype over a flattened copy (330 tensors for DLA-34).  Collective: all ranks must call it."""
@@ -95,6 +103,9 @@ class DataParallel(nn.Module):
                     off += b.numel()
 
     def train(self, mode=True):
+        """COLLECTIVE when it switches from training to evaluation (sync_buffers broadcasts rank 0's BatchNorm
+        statistics): every rank must make the same train()/eval() transitions -- a driver that validates on rank 0
+        only must still call set_phase(False) on all ranks (or evaluate the unwrapped `.module`)."""
         was_training = self.training
         super().train(mode)
         if was_training and not mode:
@@ -108,6 +119,32 @@ class DataParallel(nn.Module):
             yield
         finally:
             self._sync = prev
+
+    # -- measurement ---------------------------------------------------------------
+    def reset_exchange_stats(self, measure=True):
+        self.measure_exchange = measure
+        self._xstats = {'steps': 0, 'bytes': 0, 'buckets': 0, 'events': [], 'host_wait_s': 0.0}
+
+    def exchange_stats(self):
+        """Per step since reset_exchange_stats(): bytes and buckets all-reduced, and the exposed (not overlapped with
+        backward) all-reduce time: device time between the point where the compute stream starts waiting for the
+        collectives and the point where the last one has finished (events on the compute stream around the waits of
+        finish_gradient_sync); `host_wait_ms` is the host side of the same waits (all of it for a host-blocking
+        backend such as gloo).  Call after a device synchronisation."""
+        x = self._xstats
+        n = max(1, x['steps'])
+        backend = dist.get_backend(self.process_group) if dist.is_available() and dist.is_initialized() else None
+        rccl = None
+        if backend == 'nccl':
+            try:
+                rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = None
+        return {'backend': backend, 'world_size': self.world_size, 'rccl_version': rccl,
+                'bytes_per_step': x['bytes'] // n, 'buckets_per_step': x['buckets'] / n,
+                'bucket_bytes_limit': BUCKET_BYTES,
+                'exposed_allreduce_ms_per_step': (sum(a.elapsed_time(b) for a, b in x['events']) / n) if x['events'] else None,
+                'host_wait_ms_per_step': 1e3 * x['host_wait_s'] / n, 'steps': x['steps']}
 
     # -- bucket machinery ----------------------------------------------------------
     def _reset(self):
@@ -123,6 +160,8 @@ class DataParallel(nn.Module):
         self.arena.flush(b[0], b[1])                            # this pass's sunk gradients of the bucket
         if dist.is_available() and dist.is_initialized():      # also with one rank: the collective is an identity
             chunk = self.arena.flat_grad[b[0]:b[1]]
+            self._xstats['bytes'] += chunk.numel() * chunk.element_size()
+            self._xstats['buckets'] += 1
             self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
 
     def _param_ready(self, i):
@@ -136,8 +175,19 @@ class DataParallel(nn.Module):
     def finish_gradient_sync(self):
         for k in range(len(self.buckets)):
             self._launch(k)
+        measure = self.measure_exchange and self._works and self.arena.flat_grad.is_cuda
+        if measure:
+            import time
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            t0 = time.perf_counter()
         for w in self._works:
             w.wait()
+        if measure:
+            e1.record()
+            self._xstats['events'].append((e0, e1))
+            self._xstats['host_wait_s'] += time.perf_counter() - t0
+        self._xstats['steps'] += 1
         self._works = []
         if self.world_size > 1:
             self.arena.flat_grad.mul_(1.0 / self.world_size)

@@ -49,3 +49,10 @@ def test_plain_two_rank_start_prints_one_json_line():
     assert line['n_gpus'] == 2 and line['steps'] == 2 and line['config']['global_batch'] == 4
     assert line['value'] > 0 and line['scaling'] == 'weak'
     assert line['roofline']['kernel'] and line['roofline']['achieved'] > 0
+    # the N > 1 line proves what the exchange step did: the process group really had two ranks, every parameter
+    # gradient of DLA-34 went through the bucketed all-reduce, and the exposed (non-overlapped) time is reported
+    c = line['collective']
+    assert c['backend'] == 'gloo' and c['world_size'] == 2 and c['steps'] == 2
+    assert c['bytes_per_step'] >= 4 * 18e6 and c['buckets_per_step'] >= 2          # ~18.5 M parameters, 24 MB buckets
+    assert c['host_wait_ms_per_step'] >= 0 and 'exposed_allreduce_ms_per_step' in c
+    assert line['ms_per_step_sd'] >= 0 and line['ms_per_step_min'] <= line['ms_per_step'] * 1.05
