@@ -61,6 +61,8 @@ class DataParallel(nn.Module):
         for b in self.bucket_of:
             self.buckets[b][2] += 1
         self._pending = [b[2] for b in self.buckets]
+        if hasattr(module, 'forward_domains'):          # offered exactly when the wrapped backend offers it
+            self.forward_domains = self._forward_domains
         if self.world_size > 1:
             # replicas start identical (DataParallel broadcasts parameters and buffers every forward)
             dist.broadcast(self.arena.flat_param, src=0, group=self.process_group)
@@ -81,7 +83,7 @@ class DataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
-    def forward_domains(self, *args, **kwargs):
+    def _forward_domains(self, *args, **kwargs):
         # explicit (not through __getattr__): anything forward() grows must be mirrored here, not silently skipped
         return self.module.forward_domains(*args, **kwargs)
 
