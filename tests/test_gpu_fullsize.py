@@ -239,7 +239,7 @@ def test_full_size_dcn_layer_matches_the_oracle(B, C, Co, S, off_scale):
     res = autograd_path()
     names = ' | '.join(hr.prof_end())
     print(names)
-    assert 'DcnFwdLoader> (+ column side output)' in names, names
+    assert '(+ column side output)' in names, names
     assert 'dcn_col2im_kernel' in names and 'dcn_coord_grad_kernel' in names, names
     y, gx, goff, gm, gw, gb, cols = res
     close(y, want_y, 'forward')
