@@ -1,7 +1,4 @@
 cd /tmp && export TMPDIR=/tmp
-# per-kernel figures are taken with the DCN backward's side stream off: concurrent kernels stretch each other's
-# durations (and counters), which says nothing about either kernel
-export CNUDA_DCN_OVERLAP=0
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_tmp -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/prof_tmp.log 2>&1
 tail -1 $GRAFT_REPO_ROOT/gpurun_out/prof_tmp.log | cut -c1-200

@@ -3,9 +3,6 @@
 #   util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)      (cycles at the clock the chip actually held)
 # usage (GPU box): bash profiles/collect_pmc_mfma.sh  -> gpurun_out/pmc_mfma.json, gpurun_out/pmc_mfma.md
 cd /tmp && export TMPDIR=/tmp
-# per-kernel figures are taken with the DCN backward's side stream off: concurrent kernels stretch each other's
-# durations (and counters), which says nothing about either kernel
-export CNUDA_DCN_OVERLAP=0
 O=$GRAFT_REPO_ROOT/gpurun_out/pmc_mfma
 rm -rf $O
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --profile-steps 0 > $O.log 2>&1

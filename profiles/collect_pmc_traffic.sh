@@ -1,7 +1,4 @@
 cd /tmp && export TMPDIR=/tmp
-# per-kernel figures are taken with the DCN backward's side stream off: concurrent kernels stretch each other's
-# durations (and counters), which says nothing about either kernel
-export CNUDA_DCN_OVERLAP=0
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/pmc_$C
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --profile-steps 0 > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1

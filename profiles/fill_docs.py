@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Rewrites the measured-state blocks of DESIGN.md (between <!-- R2_STATE --> markers) and README.md
-(<!-- R2_README_TABLE -->) from the committed artefacts profiles/<tag>_*: nothing in those blocks is typed by hand.
+"""Rewrites the measured-state blocks of DESIGN.md (between <!-- R<n>_STATE --> markers) and README.md
+(<!-- R<n>_README_TABLE -->) from the committed artefacts profiles/<tag>_* (and the previous round's, for the
+comparison column): nothing in those blocks is typed by hand.
 
-    python profiles/fill_docs.py r2"""
+    python profiles/fill_docs.py r3"""
 import csv
 import json
 import os
@@ -11,8 +12,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-TAG = sys.argv[1] if len(sys.argv) > 1 else 'r2'
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r3'
+N = int(TAG.lstrip('r'))
+PREV = 'r%d' % (N - 1)
 STEPS = 10
+prev = json.load(open(os.path.join(HERE, '%s_bench_line.json' % PREV)))
+prev_rows = list(csv.DictReader(open(os.path.join(HERE, '%s_bench_kernel_stats.csv' % PREV))))
+prev_cfgs = {json.loads(l)['config']['workload'].split(':')[0]: json.loads(l) for l in open(os.path.join(HERE, '%s_bench_configs.jsonl' % PREV)) if l.startswith('{')}
 
 line = json.load(open(os.path.join(HERE, '%s_bench_line.json' % TAG)))
 rows = list(csv.DictReader(open(os.path.join(HERE, '%s_bench_kernel_stats.csv' % TAG))))
@@ -25,6 +31,7 @@ def bucket(name):
     n = name
     if 'DcnColW' in n or 'DcnWLoader' in n: return 'DCN wgrad'
     if 'DcnFwdLoader' in n or 'DcnCols' in n or 'dcn_sample' in n: return 'DCN forward'
+    if 'dcn_bwd_data' in n or 'dcn_prep' in n: return 'DCN coord-grad + col2im (one launch)'
     if 'dcn_coord' in n: return 'DCN coord-grad'
     if 'dcn_col2im' in n: return 'DCN col2im'
     if 'igemm_wgrad' in n or 'smallc_wgrad' in n or 'slab_reduce' in n: return 'conv wgrad'
@@ -48,40 +55,50 @@ for k, v in mfma.items():
         busy = v['mfma_util']
 d, inf, cb, sp = line['decode_latency'], line['inference'], line['cpu_baseline'], line['matrix_mode_split']
 
+prev_launches = sum(int(r['Calls']) for r in prev_rows) // STEPS
 state = []
-state.append('Measured state at the end of round %s (MI355X, `profiles/%s_*`, written by `profiles/fill_docs.py`): '
-             '**%.1f ms/step = %.1f source img/s** (round 1: 110.8 ms, 144.4 img/s; different boxes differ by ±1 %%); '
-             'kernel time under rocprofv3 %.1f ms/step in %d launches (round 1: 2,095): the step is GPU-bound. '
-             '`step_mfma_fraction` = %.2f of the nominal fp32 MFMA peak.'
-             % (TAG.lstrip('r'), TAG, line['ms_per_step'], line['value'], tot / 1e6 / STEPS, launches, line['step_mfma_fraction']))
+state.append('Measured state at the end of round %d (MI355X, `profiles/%s_*`, written by `profiles/fill_docs.py`): '
+             '**%.1f ms/step = %.1f source img/s** (sd %.2f ms over the timed steps; round %d: %.1f ms, %.1f img/s; different '
+             'boxes differ by ±1 %%); kernel time under rocprofv3 %.1f ms/step in %d launches (round %d: %d): the step is '
+             'GPU-bound. `step_mfma_fraction` = %.3f of the fp32 MFMA peak on SURVEY\'s nominal 6.26 TFLOP, '
+             '`step_mfma_fraction_executed` = %.3f on the %.2f TFLOP the GEMM launches execute.'
+             % (N, TAG, line['ms_per_step'], line['value'], line.get('ms_per_step_sd', 0.0), N - 1, prev['ms_per_step'],
+                prev['value'], tot / 1e6 / STEPS, launches, N - 1, prev_launches, line['step_mfma_fraction'],
+                line.get('step_mfma_fraction_executed') or 0.0, rf.get('executed_tflop_per_step') or 0.0))
 state.append('Dominant kernel `%s`: %.1f ms over %d launches, %.1f TFLOP/s = `roofline.frac` %.3f%s, %.0f MB of HBM traffic per '
              'launch (PMC).' % (rf['kernel'], rf['kernel_ms_per_step'], rf['launches_per_step'], rf['achieved'], rf['frac'],
                                 (', MFMA pipe busy %.0f %% (PMC)' % (100 * busy)) if busy else '', (rf['traffic'] or 0) / 1e6))
 state.append('Per-step kernel time by bucket: ' + ', '.join('%s %.1f ms' % (k, v) for k, v in sorted(bk.items(), key=lambda kv: -kv[1])) + '.')
-state.append('Other BASELINE configs at full size on one GPU (`bench.py --config i`, `profiles/%s_bench_configs.jsonl`): ' % TAG +
+state.append('Other BASELINE configs at full size on one GPU (`bench.py --config i`, `profiles/%s_bench_configs.jsonl`; the default '
+             'run times them too, `other_configs`): ' % TAG +
              '; '.join('%s %.1f ms = %.1f img/s' % (c['config']['workload'].split(':')[0] + ' (' + c['config']['workload'].split('uda=')[1].split(',')[0] + ', %dx%d)' % tuple(c['config']['input'][1:]),
                                                     c['ms_per_step'], c['value']) for c in cfgs) + '.')
 state.append('Decode (B=16, K=150): 128×128 C=6 %.0f µs, C=80 %.0f µs; 160×160 C=6 %.0f µs, C=80 %.0f µs. Inference wrapper '
              '(`export.CenterNet`, BatchNorm folded, eval forward + decode, fp32): %.0f img/s (%.2f ms per batch of 16). '
-             'Split-operand matrix mode (opt-in, §4a): %.1f ms/step = %.1f img/s. CPU baseline (`kind: %s`, %d threads): '
-             '%.3f img/s.' % (d['C6']['us'], d['C80']['us'], d['C6_160']['us'], d['C80_160']['us'], inf['images_per_s'],
-                              inf['ms_per_batch'], sp['ms_per_step'], sp['value'], cb['kind'], cb['cores'], cb['value']))
+             'Split-operand matrix mode (opt-in, §4a): %.1f ms/step = %.1f img/s. CPU baseline (`kind: %s`, %d threads, '
+             'median of %d 512×512 steps): %.3f img/s.'
+             % (d['C6']['us'], d['C80']['us'], d['C6_160']['us'], d['C80_160']['us'], inf['images_per_s'],
+                inf['ms_per_batch'], sp['ms_per_step'], sp['value'], cb['kind'], cb['cores'],
+                cb.get('s_per_step_512', {}).get('repeats', 1) if isinstance(cb.get('s_per_step_512'), dict) else 1, cb['value']))
 state_txt = '\n'.join(state)
 
-tab = ['| | round 1 | round %s |' % TAG.lstrip('r'), '|---|---|---|',
-       '| UDA step, DLA-34 + DCNv2 512², 16 + 16 images (the headline, `bench.py`) | 110.8 ms = 144.4 img/s | **%.1f ms = %.1f img/s** |' % (line['ms_per_step'], line['value']),
-       '| `roofline` (dominant kernel, fp32 MFMA, peak 157.3 TFLOP/s) | 98.4 TF = 0.63 | %.1f TF = %.3f |' % (rf['achieved'], rf['frac']),
-       '| kernel launches per step | 2,095 | %d |' % launches]
-r1cfg = {'configs[0]': '—', 'configs[1]': '57.7 ms = 277.3 img/s', 'configs[3]': '110.1 ms = 145.3 img/s', 'configs[4]': '180.0 ms = 88.9 img/s'}
+pd, pinf, pcb, psp, prf = prev['decode_latency'], prev['inference'], prev['cpu_baseline'], prev['matrix_mode_split'], prev['roofline']
+tab = ['| | round %d | round %d |' % (N - 1, N), '|---|---|---|',
+       '| UDA step, DLA-34 + DCNv2 512², 16 + 16 images (the headline, `bench.py`) | %.1f ms = %.1f img/s | **%.1f ms = %.1f img/s** |'
+       % (prev['ms_per_step'], prev['value'], line['ms_per_step'], line['value']),
+       '| `roofline` (dominant kernel, fp32 MFMA, peak 157.3 TFLOP/s) | %.1f TF = %.3f | %.1f TF = %.3f |'
+       % (prf['achieved'], prf['frac'], rf['achieved'], rf['frac']),
+       '| kernel launches per step | %d | %d |' % (prev_launches, launches)]
 for c in cfgs:
     name = c['config']['workload'].split(':')[0]
+    pc = prev_cfgs.get(name)
     tab.append('| %s (%s, %d²) | %s | %.1f ms = %.1f img/s |' % (name, c['config']['workload'].split('uda=')[1].split(',')[0], c['config']['input'][1],
-                                                                r1cfg.get(name, '—'), c['ms_per_step'], c['value']))
-tab += ['| decode B=16, K=150, 128² maps: C=6 / C=80 | 38 / 149 µs | %.0f / %.0f µs |' % (d['C6']['us'], d['C80']['us']),
-        '| decode 160² maps (cfg5 shape): C=6 / C=80 | 197 / 1012 µs | %.0f / %.0f µs |' % (d['C6_160']['us'], d['C80_160']['us']),
-        '| inference wrapper (eval forward + decode, batch 16) | 1000 img/s | %.0f img/s |' % inf['images_per_s'],
-        '| split-operand matrix mode (opt-in) | 105.0 ms | %.1f ms |' % sp['ms_per_step'],
-        '| CPU baseline (oracle port, %d host threads; 1 / seconds per 512² step) | 0.010 img/s (pixel-scaled from one 256² step) | %.3f img/s |' % (cb['cores'], cb['value'])]
+                                                                ('%.1f ms = %.1f img/s' % (pc['ms_per_step'], pc['value'])) if pc else '—', c['ms_per_step'], c['value']))
+tab += ['| decode B=16, K=150, 128² maps: C=6 / C=80 | %.0f / %.0f µs | %.0f / %.0f µs |' % (pd['C6']['us'], pd['C80']['us'], d['C6']['us'], d['C80']['us']),
+        '| decode 160² maps (cfg5 shape): C=6 / C=80 | %.0f / %.0f µs | %.0f / %.0f µs |' % (pd['C6_160']['us'], pd['C80_160']['us'], d['C6_160']['us'], d['C80_160']['us']),
+        '| inference wrapper (eval forward + decode, batch 16) | %.0f img/s | %.0f img/s |' % (pinf['images_per_s'], inf['images_per_s']),
+        '| split-operand matrix mode (opt-in) | %.1f ms | %.1f ms |' % (psp['ms_per_step'], sp['ms_per_step']),
+        '| CPU baseline (oracle port, %d host threads; 1 / seconds per 512² step) | %.3f img/s | %.3f img/s |' % (cb['cores'], pcb['value'], cb['value'])]
 tab_txt = '\n'.join(tab)
 
 
@@ -93,7 +110,7 @@ def fill(path, marker, body):
     open(path, 'w').write(pat.sub(lambda m: block, s, count=1))
 
 
-fill(os.path.join(ROOT, 'DESIGN.md'), 'R2_STATE', state_txt)
-fill(os.path.join(ROOT, 'README.md'), 'R2_README_TABLE', tab_txt)
+fill(os.path.join(ROOT, 'DESIGN.md'), 'R%d_STATE' % N, state_txt)
+fill(os.path.join(ROOT, 'README.md'), 'R%d_README_TABLE' % N, tab_txt)
 print(state_txt)
 print(tab_txt)

@@ -11,7 +11,7 @@ import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-TAG = sys.argv[1] if len(sys.argv) > 1 else 'r2'
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r3'
 ROUND = TAG.lstrip('r')
 
 
@@ -42,7 +42,10 @@ out.append('Total kernel time %.1f ms = **%.1f ms/step** under the profiler; un-
 if TAG == 'r1':
     out.append('First correct path (`r1a_*`): 388.8 ms/step, 41.3 img/s.\n')
 else:
-    out.append('End of round 1 (`r1_final_*`): 110.8 ms/step, 144.4 img/s.\n')
+    pl = path('r%d_bench_line.json' % (int(ROUND) - 1), 'r%d_final_bench_line.json' % (int(ROUND) - 1))
+    if pl:
+        pj = json.load(open(pl))
+        out.append('End of round %d (`%s`): %.1f ms/step, %.1f img/s.\n' % (int(ROUND) - 1, os.path.basename(pl), pj['ms_per_step'], pj['value']))
 out.append('| kernel | launches/step | ms/step | avg us | % |\n|---|---|---|---|---|')
 for r in rows[:48]:
     out.append('| `%s` | %d | %.2f | %.1f | %.1f |' % (short(r['Name'])[:92], int(r['Calls']) // STEPS,
@@ -87,6 +90,19 @@ if cfgs:
         j = json.loads(ln)
         out.append('| %s | %.2f | %.1f |' % (j['config']['workload'][:120], j['ms_per_step'], j['value']))
     out.append('')
+dk = path('%s_decode_kernel_stats.csv' % TAG)
+if dk:
+    out.append('Decode-only kernel stats (`profiles/collect_decode_stats.sh`: rocprofv3 --kernel-trace --stats on '
+               '`profiles/decode_only.py`, 120 calls per map shape: C=6 / C=80 at 128x128 and 160x160 mixed):\n')
+    out.append('| kernel | calls | avg us | min us | max us |\n|---|---|---|---|---|')
+    for r in csv.DictReader(open(dk)):
+        out.append('| `%s` | %s | %.1f | %.1f | %.1f |' % (short(r['Name'])[:60], r['Calls'], float(r['AverageNs']) / 1e3,
+                                                         float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3))
+    out.append('')
+dp = path('%s_pmc_dcn_raw.md' % TAG)
+if dp:
+    out.append('Counters for the DCN kernels (`profiles/collect_pmc_dcn.sh`; commentary: `%s_pmc_dcn.md`):\n' % TAG)
+    out.append(open(dp).read())
 m = path('%s_pmc_mfma.md' % TAG)
 if m:
     out.append('MFMA-pipe utilisation per kernel from PMC (`profiles/collect_pmc_mfma.sh`: `--pmc SQ_VALU_MFMA_BUSY_CYCLES '
