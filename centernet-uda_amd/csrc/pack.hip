@@ -127,6 +127,8 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 // weights) with cnuda_pack_stamp.  A slot is reused iff the same token asked for the same image of the same source
 // buffer before and the version is unchanged; token 0 (the default, and every caller that says nothing) bypasses
 // the cache.  One stamp covers every pack of the entry point that follows it (and of the calls nested in it).
+// The arena and its slots are PROCESS-global (one process drives one GPU: DESIGN.md section 7); a module that asks
+// for an image of a new source buffer takes over its own old slot.
 // ---------------------------------------------------------------------------
 struct PackKey {
     uint64_t token;
@@ -164,6 +166,22 @@ float* pack_slot(const PackKey& key, size_t bytes, bool& fill, int cpad = 0, con
     if (key.token == 0 || !g_pack_arena) return nullptr;
     std::lock_guard<std::mutex> lock(g_pack_mutex);
     auto it = g_pack_slots.find(key);
+    if (it == g_pack_slots.end()) {
+        // the same module asking for the same image of a NEW source buffer (a re-fold of BatchNorm allocates fresh
+        // folded weights every time): its old slot is dead -- take it over instead of growing until the arena is full
+        for (auto old = g_pack_slots.begin(); old != g_pack_slots.end(); ++old) {
+            const PackKey& k = old->first;
+            if (k.token == key.token && k.src != key.src && k.mode == key.mode && k.Co == key.Co && k.C == key.C &&
+                k.T == key.T && k.Kp == key.Kp && k.Mp == key.Mp && k.extra == key.extra && old->second.bytes >= bytes) {
+                PackSlot moved = old->second;
+                moved.version = ~0ull;
+                g_pack_slots.erase(old);
+                it = g_pack_slots.emplace(key, moved).first;
+                ++g_pack_generation;
+                break;
+            }
+        }
+    }
     if (it == g_pack_slots.end()) {
         const size_t need = (bytes + 255) / 256 * 256;
         if (g_pack_arena_used + need > g_pack_arena_bytes) return nullptr;        // arena full: no caching
@@ -285,6 +303,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
 }
 std::vector<PackJob> g_refresh_jobs;
 unsigned g_refresh_blocks = 0;
+const void* g_refresh_table = nullptr;        // the device buffer the current job list was uploaded to
 }  // namespace
 }  // namespace cnuda
 
@@ -320,10 +339,12 @@ extern "C" int cnuda_pack_refresh(const void* params, size_t params_bytes, unsig
     }
     if (live.empty()) return 0;
     // the table only changes when the set of live slots does: upload it then, reuse the device copy otherwise
-    if (jobs.size() != g_refresh_jobs.size() ||
+    // (a table that does not fit, or none: nothing is refreshed here -- the parameters are already updated, so this
+    // must not fail the optimizer step; the slots keep their old epoch and refill lazily on their next use)
+    if (!table || jobs.size() * sizeof(PackJob) > table_bytes) return 0;
+    if (table != g_refresh_table || jobs.size() != g_refresh_jobs.size() ||
         memcmp(jobs.data(), g_refresh_jobs.data(), jobs.size() * sizeof(PackJob)) != 0) {
-        CNUDA_REQUIRE(table && jobs.size() * sizeof(PackJob) <= table_bytes,
-                      "cnuda_pack_refresh: job table needs %zu bytes", jobs.size() * sizeof(PackJob));
+        g_refresh_table = table;      // (a caller that re-allocated its table -- another device -- gets a fresh upload)
         g_refresh_jobs = jobs;        // (the copy below reads this vector: it must outlive the call)
         if (hipMemcpyAsync(table, g_refresh_jobs.data(), g_refresh_jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice,
                            st) != hipSuccess)

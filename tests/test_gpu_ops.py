@@ -284,6 +284,49 @@ def test_pack_refresh_after_the_fused_adam_step():
     assert used[0] > 0 and used[1] == used[-1]     # steady state: no new slots after the first step
 
 
+def test_pack_cache_slot_follows_a_module_to_a_new_weight_buffer():
+    """A module that asks for the same image of a NEW source buffer (a re-fold of BatchNorm allocates fresh folded
+    weights, a replaced Parameter) takes over its own old slot: the arena must not grow with every replacement."""
+    import hip_runtime as hr
+    from hip_runtime import nn as hnn
+    g = torch.Generator().manual_seed(23)
+    conv = hnn.Conv2d(32, 48, 3, padding=1, bias=False).to(DEV)
+    x = torch.randn(2, 32, 9, 11, generator=g).to(DEV)
+    conv(x)
+    used = hr.lib().cnuda_pack_cache_used()
+    keep = []
+    for _ in range(5):
+        w = torch.nn.Parameter(torch.randn(48, 32, 3, 3, generator=g).to(DEV) * 0.1)
+        keep.append(w)                                       # (old buffers stay alive: every address is new)
+        conv.weight = w
+        _close(conv(x), F.conv2d(x.cpu(), w.detach().cpu(), None, 1, 1))
+        assert hr.lib().cnuda_pack_cache_used() == used
+
+
+def test_pack_refresh_with_a_table_that_is_too_small_does_not_fail_the_step():
+    """cnuda_pack_refresh runs AFTER the parameters were updated: a job table that does not fit must not turn the
+    optimizer step into an error -- nothing is refreshed, the slots refill lazily, results stay right."""
+    import hip_runtime as hr
+    from hip_runtime import nn as hnn, optim
+    torch.manual_seed(7)
+    net = torch.nn.Sequential(hnn.Conv2d(16, 32, 3, padding=1), hnn.Conv2d(32, 16, 1)).to(DEV)
+    opt = optim.Adam(net.parameters(), lr=1e-2)
+    x = torch.randn(2, 16, 12, 12, device=DEV)
+    table = hr._PACK.get('table')
+    hr._PACK['table'] = torch.empty(16, dtype=torch.uint8, device=DEV)          # room for no job at all
+    try:
+        for _ in range(2):
+            opt.zero_grad()
+            net(x).square().mean().backward()
+            opt.step()                                                          # must not raise
+        y = net(x)
+    finally:
+        hr._PACK['table'] = table
+    want = F.conv2d(F.conv2d(x.cpu(), net[0].weight.detach().cpu(), net[0].bias.detach().cpu(), 1, 1),
+                    net[1].weight.detach().cpu(), net[1].bias.detach().cpu())
+    _close(y, want)
+
+
 def test_tensors_of_2gib_take_the_pointer_loaders():
     """The buffer-addressed loaders carry 32-bit byte offsets with a sentinel at 2 GiB (csrc/igemm.cuh); an input of
     2.2 GiB must fall back to the pointer-addressed loaders by itself.  Checked without a CPU reference: a crop of the
