@@ -299,7 +299,7 @@ def pmc_traffic(kernel_name):
     meta = data.get('_meta', {})
     import re
     # (profiler names carry the template defaults the library's own kernel names leave out)
-    norm = lambda k: re.sub(r',(true|false)(,16)?>$', '>', k.replace(' ', ''))
+    norm = lambda k: re.sub(r'(,(true|false))?(,16)?>$', '>', k.replace(' ', ''))
     t = {norm(k): v for k, v in data.items() if k != '_meta'}.get(norm(kernel_name.split(' (')[0].split(' [')[0]))
     if not t:
         return None, '%s has no entry for this kernel' % os.path.basename(path)
