@@ -553,32 +553,35 @@ struct DcnCol2imParams {
 // The col2im walk of ONE wave over ONE 16-channel group of a TR x TC pixel tile (256 pixels): the wave owns
 // channel planes c_w..c_w+3 of the LDS window ([cell][4 channels]: the four channels of a cell are ONE 16-byte
 // access), zeroes them, walks all 256 pixels x taps (64 pixels per step, lanes along x) doing plain LDS
-// read-add-write one corner at a time, and flushes every touched cell with one coalesced atomic.  No workgroup
-// synchronisation.  Two lanes hit the same cell in one instruction only if their (h0, w0) anchors are equal:
+// read-add-write one corner at a time, and flushes every touched in-image cell with one coalesced atomic.  No
+// workgroup synchronisation.
+// Written for INSTRUCTION COUNT (round 3, in-kernel stamps: an item of this walk cost ~5,000 cycles, ~650 vector +
+// scalar instructions -- the walk was issue-bound, not LDS- or memory-bound):
+//   * the window is the UNCLIPPED rectangle around the tile (cells outside the image exist in LDS and are simply
+//     never flushed), so a sample is either wholly inside the window (two unsigned compares) or a stray -- no
+//     per-corner image / window predicates, no zeroed weights: what lands outside the image is dropped at the flush;
+//   * row bases of the dcol / geometry loads are scalar (the wave id comes through readfirstlane), the lane adds a
+//     32-bit byte offset (`global_load ... v_off, s[base]`); (group, tap) run on counters, products on 24-bit mads;
+//   * the loads of an item are issued two items ahead.
+// Two lanes hit the same cell in one instruction only if their anchors (h0, w0) are equal:
 //   * fast path (a step whose 64 lanes lie on one output row and whose samples all sit within [-2, 2) cell columns
 //     of their undeformed position): only lanes at most 3 apart can share an anchor, so three DPP shifts rank
 //     every lane among its equals -- no LDS round trip; round r scatters the lanes of rank r;
 //   * otherwise every lane writes its id into a per-wave claim map at its anchor and reads it back; the
-//     survivor scatters, losers retry (<= 3 rounds), leftovers and corners outside the window use global atomics.
+//     survivor scatters, losers retry (<= 3 rounds), leftovers and strays use global atomics.
 struct DcnScatterCtx {
     int y0, x0, TC, tc_shift;                 // tile origin, tile width
-    int wy0, wx0, WR, WC, WSZ;                // window, clipped to the plane
+    int wy0, wx0, WR, WC, WSZ;                // window (unclipped; WR = WC = 0: no window, global atomics only)
     float4* wp;                               // this wave's window planes
     float4* dump;                             // a private cell for inactive lanes
-    volatile unsigned char* claim;            // this wave's claim map [(WR+1)*(WC+1)]
+    volatile unsigned char* claim;            // this wave's claim map [WSZ]
 };
 __device__ __forceinline__ void dcn_scatter_window(DcnScatterCtx& x, const DcnGeom& g, int TR, int WSZmax) {
     x.wy0 = x.y0 * g.sh - g.ph - CI_MARGIN;
     x.wx0 = x.x0 * g.sw - g.pw - CI_MARGIN;
-    x.WR = (TR - 1) * g.sh + (g.kh - 1) * g.dh + 2 * CI_MARGIN + 1;
-    x.WC = (x.TC - 1) * g.sw + (g.kw - 1) * g.dw + 2 * CI_MARGIN + 1;
-    if (x.wy0 < 0) { x.WR += x.wy0; x.wy0 = 0; }
-    if (x.wx0 < 0) { x.WC += x.wx0; x.wx0 = 0; }
-    if (x.wy0 + x.WR > g.H) x.WR = g.H - x.wy0;
-    if (x.wx0 + x.WC > g.W) x.WC = g.W - x.wx0;
-    if (x.WR < 0 || WSZmax == 0) x.WR = 0;     // WSZmax == 0: window does not fit the LDS -> global atomics only
-    if (x.WC < 0 || WSZmax == 0) x.WC = 0;
-    x.WSZ = x.WR * x.WC;                       // <= WSZmax
+    x.WR = WSZmax ? (TR - 1) * g.sh + (g.kh - 1) * g.dh + 2 * CI_MARGIN + 1 : 0;
+    x.WC = WSZmax ? (x.TC - 1) * g.sw + (g.kw - 1) * g.dw + 2 * CI_MARGIN + 1 : 0;
+    x.WSZ = x.WR * x.WC;                       // == WSZmax (or 0: the window does not fit the LDS)
 }
 __device__ __forceinline__ void dcn_scatter_group(const DcnScatterCtx& x, const DcnGeom& g, const DcnGeo* __restrict__ geo_b,
                                                   const float* __restrict__ dcol_b, float* __restrict__ gin_b, int c_w,
@@ -591,50 +594,56 @@ __device__ __forceinline__ void dcn_scatter_group(const DcnScatterCtx& x, const 
     int cc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) cc[r] = c_w + r < g.C ? c_w + r : g.C - 1;   // clamped loads; results dropped
-    const bool cv0 = c_w < g.C, cv1 = c_w + 1 < g.C, cv2 = c_w + 2 < g.C, cv3 = c_w + 3 < g.C;
+    const float cvf[4] = {c_w < g.C ? 1.f : 0.f, c_w + 1 < g.C ? 1.f : 0.f, c_w + 2 < g.C ? 1.f : 0.f,
+                          c_w + 3 < g.C ? 1.f : 0.f};
     const bool one_row = x.TC == 64;                  // a step's 64 lanes are 64 consecutive pixels of one row
-    DcnGeo rec_n;
-    float d_n[4];
-    bool valid_n;
-    int ox_n;
-    auto fetch = [&](int it) {
-        const int grp = it / T, tap = it - grp * T;
-        const int t = grp * 64 + lane;
+    struct Item { DcnGeo rec; float d[4]; bool valid; int ox; };
+    int f_grp = 0, f_tap = 0;                         // (group, tap) of the next fetch: items run group-major
+    auto fetch = [&](Item& o) {
+        const int t = f_grp * 64 + lane;
         const int oy = x.y0 + (t >> x.tc_shift);
-        ox_n = x.x0 + (t & (x.TC - 1));
-        valid_n = oy < g.Ho && ox_n < g.Wo;
-        const int px = valid_n ? oy * g.Wo + ox_n : 0;
-        rec_n = geo_b[(size_t)tap * HoWo + px];
+        o.ox = x.x0 + (t & (x.TC - 1));
+        o.valid = oy < g.Ho && o.ox < g.Wo;
+        unsigned px = o.valid ? (unsigned)(__mul24(oy, g.Wo) + o.ox) : 0u;
+        asm volatile("" : "+v"(px));                  // (keeps the zero-extension next to the loads: scalar-base form)
+        const unsigned long long gb = reinterpret_cast<unsigned long long>(geo_b + (size_t)f_tap * HoWo);
+        o.rec = __builtin_bit_cast(DcnGeo, *reinterpret_cast<__attribute__((address_space(1))) const u32x4*>(gb + (unsigned long long)(px * 16u)));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d_n[r] = dcol_b[((size_t)tap * g.C + cc[r]) * HoWo + px];
+        for (int r = 0; r < 4; ++r) {
+            const unsigned long long db = reinterpret_cast<unsigned long long>(dcol_b + (size_t)(f_tap * g.C + cc[r]) * HoWo);
+            o.d[r] = *reinterpret_cast<__attribute__((address_space(1))) const float*>(db + (unsigned long long)(px * 4u));
+        }
+        if (++f_tap == T) { f_tap = 0; ++f_grp; }
     };
-    fetch(0);
+    Item q0i, q1i;                                    // even / odd items in flight
+    fetch(q0i);
+    if (1 < items) fetch(q1i);
+    int c_tapx = 0;                                   // kernel column of the current item's tap
 #pragma unroll 1
-    for (int it = 0; it < items; ++it) {
-        const DcnGeo rec = rec_n;
-        float d[4] = {d_n[0], d_n[1], d_n[2], d_n[3]};
-        const bool valid = valid_n;
-        const int ox = ox_n;
-        if (it + 1 < items) fetch(it + 1);
+    for (int it0 = 0; it0 < items; it0 += 2)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int it = it0 + half;
+        if (it >= items) break;
+        Item& slot = half == 0 ? q0i : q1i;
+        const DcnGeo rec = slot.rec;
+        float d[4] = {slot.d[0], slot.d[1], slot.d[2], slot.d[3]};
+        const bool valid = slot.valid;
+        const int ox = slot.ox;
+        if (it + 2 < items) fetch(slot);
+        const int tapx = c_tapx;
+        if (++c_tapx == g.kw) c_tapx = 0;             // (T = kh * kw taps per group: the column counter wraps with it)
         const int h0 = rec.cell >> 16, w0 = (int)(short)(rec.cell & 0xffff);
-        const bool live = valid && h0 >= -1;
+        const bool live = valid && rec.cell != (int)0x80000000u;
         const float lh = rec.lh, lw = rec.lw, hh = 1.0f - lh, hw = 1.0f - lw;
-        const bool top = h0 >= 0, bot = h0 + 1 <= g.H - 1, lef = w0 >= 0, rig = w0 + 1 <= g.W - 1;
-        const bool a00 = live && top && lef, a01 = live && top && rig, a10 = live && bot && lef,
-                   a11 = live && bot && rig;
-        const float mk = live ? rec.mask : 0.f;
-        d[0] = cv0 ? d[0] * mk : 0.f; d[1] = cv1 ? d[1] * mk : 0.f;
-        d[2] = cv2 ? d[2] * mk : 0.f; d[3] = cv3 ? d[3] * mk : 0.f;
-        const float k00 = a00 ? hh * hw : 0.f, k01 = a01 ? hh * lw : 0.f, k10 = a10 ? lh * hw : 0.f,
-                    k11 = a11 ? lh * lw : 0.f;
+        const float k00 = hh * hw, k01 = hh * lw, k10 = lh * hw, k11 = lh * lw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] *= rec.mask * cvf[r];
         const int rh = h0 - wy0, rw = w0 - wx0;
-        const bool r0 = rh >= 0 && rh < WR, r1 = rh + 1 >= 0 && rh + 1 < WR;
-        const bool q0 = rw >= 0 && rw < WC, q1 = rw + 1 >= 0 && rw + 1 < WC;
-        // lanes that may touch the window take part in the uniqueness test
-        const bool near = live && rh >= -1 && rh < WR && rw >= -1 && rw < WC;
-        const int anchor = near ? (rh + 1) * (WC + 1) + (rw + 1) : -1;
-        const int base = rh * WC + rw;
-        const bool w00 = a00 && r0 && q0, w01 = a01 && r0 && q1, w10 = a10 && r1 && q0, w11 = a11 && r1 && q1;
+        // wholly inside the window (both rows, both columns)?  else a stray
+        const bool near = WSZ > 0 && live && (unsigned)rh < (unsigned)(WR - 1) && (unsigned)rw < (unsigned)(WC - 1);
+        const int base = __mul24(rh, WC) + rw;
+        const int anchor = near ? base : -1;
         auto scatter = [&](bool on, int cell, float k) {
             float4* a = on ? wp + cell : x.dump;
             const float kk = on ? k : 0.f;
@@ -646,8 +655,7 @@ __device__ __forceinline__ void dcn_scatter_group(const DcnScatterCtx& x, const 
         bool done_lds = false;
         // displacement of the sample's cell column from the undeformed one: with every near lane in {-2 .. 1}
         // (horizontal offsets in [-2, 2)) two lanes can share an anchor only if they are at most 3 lanes apart
-        const int tap = it % T;
-        const int disp = w0 - (ox * g.sw - g.pw + (tap % g.kw) * g.dw);
+        const int disp = w0 - (__mul24(ox, g.sw) - g.pw + __mul24(tapx, g.dw));
         if (one_row && !__any(near && (unsigned)(disp + 2) > 3u)) {
             // rank = number of EARLIER lanes (distance 1..3) with the same anchor, found with three DPP shifts -- no
             // LDS round trip; round r scatters the lanes of rank r (LDS instructions of one wave execute in order)
@@ -659,10 +667,10 @@ __device__ __forceinline__ void dcn_scatter_group(const DcnScatterCtx& x, const 
             for (int round = 0; round < 4; ++round) {
                 const bool mine = rank == round;
                 if (round > 0 && !__any(mine)) break;          // ranks are dense: none of rank r -> none above
-                scatter(mine && w00, base, k00);
-                scatter(mine && w01, base + 1, k01);
-                scatter(mine && w10, base + WC, k10);
-                scatter(mine && w11, base + WC + 1, k11);
+                scatter(mine, base, k00);
+                scatter(mine, base + 1, k01);
+                scatter(mine, base + WC, k10);
+                scatter(mine, base + WC + 1, k11);
             }
             done_lds = near;
         } else {
@@ -677,39 +685,47 @@ __device__ __forceinline__ void dcn_scatter_group(const DcnScatterCtx& x, const 
                     won = x.claim[anchor] == (unsigned char)lane;     // same wave, LDS executes in order
                 }
                 asm volatile("" ::: "memory");
-                scatter(won && w00, base, k00);
-                scatter(won && w01, base + 1, k01);
-                scatter(won && w10, base + WC, k10);
-                scatter(won && w11, base + WC + 1, k11);
+                scatter(won, base, k00);
+                scatter(won, base + 1, k01);
+                scatter(won, base + WC, k10);
+                scatter(won, base + WC + 1, k11);
                 done_lds = done_lds || won;
                 pending = pending && !won;
             }
         }
-        const bool i00 = done_lds && w00, i01 = done_lds && w01, i10 = done_lds && w10, i11 = done_lds && w11;
-        const bool s00 = a00 && !i00, s01 = a01 && !i01, s10 = a10 && !i10, s11 = a11 && !i11;
-        if (__any(s00 || s01 || s10 || s11)) {
-            const int o = h0 * g.W + w0;
+        // strays (a corner outside the window) and claim-round leftovers: global atomics, corners checked against the image
+        if (__any(live && !done_lds)) {
+            if (live && !done_lds) {
+                const bool top = h0 >= 0, bot = h0 + 1 <= g.H - 1, lef = w0 >= 0, rig = w0 + 1 <= g.W - 1;
+                const int o = h0 * g.W + w0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (c_w + r >= g.C) continue;
-                float* plane = gin_b + (size_t)(c_w + r) * HW;
-                if (s00) atomicAdd(plane + o, k00 * d[r]);
-                if (s01) atomicAdd(plane + o + 1, k01 * d[r]);
-                if (s10) atomicAdd(plane + o + g.W, k10 * d[r]);
-                if (s11) atomicAdd(plane + o + g.W + 1, k11 * d[r]);
+                for (int r = 0; r < 4; ++r) {
+                    if (c_w + r >= g.C) continue;
+                    float* plane = gin_b + (size_t)(c_w + r) * HW;
+                    if (top && lef) atomicAdd(plane + o, k00 * d[r]);
+                    if (top && rig) atomicAdd(plane + o + 1, k01 * d[r]);
+                    if (bot && lef) atomicAdd(plane + o + g.W, k10 * d[r]);
+                    if (bot && rig) atomicAdd(plane + o + g.W + 1, k11 * d[r]);
+                }
             }
         }
     }
-    // flush: lanes walk the cells of a row (coalesced), four planes each
+    // flush: a wave walks the window row by row (lanes along the row: coalesced), four planes each; cells outside the
+    // image were scratch
     asm volatile("" ::: "memory");
-    for (int pos = lane; pos < WSZ; pos += 64) {
-        const int yy = pos / WC, xx = pos - yy * WC;
-        float* gcell = gin_b + (size_t)(wy0 + yy) * g.W + wx0 + xx;
-        const float4 v4 = wp[pos];
-        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    for (int yy = 0; yy < WR; ++yy) {
+        const int gy = wy0 + yy;
+        if (gy < 0 || gy >= g.H) continue;            // (uniform)
+        for (int xx = lane; xx < WC; xx += 64) {
+            const int gx = wx0 + xx;
+            if (gx < 0 || gx >= g.W) continue;
+            const float4 v4 = wp[yy * WC + xx];
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            float* gcell = gin_b + (size_t)gy * g.W + gx;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (v[r] != 0.0f && c_w + r < g.C) atomicAdd(gcell + (size_t)(c_w + r) * HW, v[r]);
+            for (int r = 0; r < 4; ++r)
+                if (v[r] != 0.0f && c_w + r < g.C) atomicAdd(gcell + (size_t)(c_w + r) * HW, v[r]);
+        }
     }
     asm volatile("" ::: "memory");
 }
@@ -719,7 +735,9 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int 
     extern __shared__ __align__(16) float win[];     // 4 waves x [WSZ cells][4 channels] + 256 dump cells x 4 + claim maps
     const DcnGeom& g = p.g;
     const int T = g.kh * g.kw, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // (wid through readfirstlane: the compiler then KNOWS it is wave-uniform, and everything derived from it -- channel
+    // planes, row bases of the dcol loads, the window base -- is scalar arithmetic instead of per-lane 64-bit math)
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     int id = xcd_remap(blockIdx.x, n_wg);
     const int cg = id % p.ncg; id /= p.ncg;
     const int tx = id % p.tiles_x; id /= p.tiles_x;
@@ -799,7 +817,7 @@ __global__ __launch_bounds__(512, 6) void dcn_bwd_data_kernel(DcnBwdDataParams p
     extern __shared__ __align__(16) float win[];     // as dcn_col2im_kernel: 4 waves x [WSZ][4] + dump cells + claim maps
     const DcnGeom& g = p.g;
     const int T = g.kh * g.kw, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
-    const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: see col2im
     int id = xcd_remap(blockIdx.x, n_wg);
     const int part = id % p.nsplit; id /= p.nsplit;
     const int tx = id % p.tiles_x; id /= p.tiles_x;
