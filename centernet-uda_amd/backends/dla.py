@@ -342,8 +342,8 @@ class IDAUp(nn.Module):
     def forward(self, layers, startp, endp):
         for i in range(startp + 1, endp):
             k = i - startp
-            t = getattr(self, 'up_%d' % k)(getattr(self, 'proj_%d' % k)(layers[i]))
-            layers[i] = getattr(self, 'node_%d' % k)(ops.add(t, layers[i - 1]))
+            t = getattr(self, 'up_%d' % k)(getattr(self, 'proj_%d' % k)(layers[i]), layers[i - 1])   # up(..) + skip
+            layers[i] = getattr(self, 'node_%d' % k)(t)
 
 
 class DLAUp(nn.Module):

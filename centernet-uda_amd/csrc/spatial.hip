@@ -122,8 +122,8 @@ __global__ void maxpool_win_bwd_kernel(const float* __restrict__ x, const float*
 // y[b,c,oy,ox] = sum_{ky,kx} x[b,c,(oy+p-ky)/s,(ox+p-kx)/s] * w[c,ky,kx]   (exact divisions only)
 // grid = (output tiles of 256, planes): 32-bit index math, the channel's kernel in LDS; store-bound
 __global__ __launch_bounds__(kT) void dwconvt_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         float* __restrict__ y, int C, int H, int W, int Ho, int Wo,
-                                                         int k, int s, int p) {
+                                                         const float* __restrict__ skip, float* __restrict__ y, int C,
+                                                         int H, int W, int Ho, int Wo, int k, int s, int p) {
     __shared__ float ws[1024];
     const int pl = blockIdx.y, c = pl % C;
     for (int i = threadIdx.x; i < k * k; i += kT) ws[i] = w[(size_t)c * k * k + i];
@@ -143,13 +143,16 @@ __global__ __launch_bounds__(kT) void dwconvt_fwd_kernel(const float* __restrict
             acc += xp[iy * W + ix] * ws[ky * k + kx];
         }
     }
-    y[(size_t)pl * Ho * Wo + o] = acc;
+    y[(size_t)pl * Ho * Wo + o] = skip ? acc + skip[(size_t)pl * Ho * Wo + o] : acc;
 }
 // k = 2f, s = f, p = f/2 (IDAUp.up, dla.py:385-388) with compile-time f: every output pixel has exactly 2 x 2 taps and
-// all index arithmetic is shifts; one thread produces four consecutive outputs of a row (Wo % 4 == 0)
+// all index arithmetic is shifts; one thread produces four consecutive outputs of a row (Wo % 4 == 0).  `skip` (may be
+// null) is IDAUp's other summand (dla.py:400-401 node(up(project(x)) + layers[i-1])): added after the taps, in the
+// rounding order of the separate add, so the upsampled tensor is written once and never re-read
 template <int F>
 __global__ __launch_bounds__(kT) void dwconvt_fwd_f_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           float* __restrict__ y, int C, int H, int W) {
+                                                           const float* __restrict__ skip, float* __restrict__ y, int C,
+                                                           int H, int W) {
     constexpr int K = 2 * F, P = F / 2;
     __shared__ float ws[K * K];
     const int pl = blockIdx.y, c = pl % C;
@@ -180,6 +183,10 @@ __global__ __launch_bounds__(kT) void dwconvt_fwd_f_kernel(const float* __restri
             }
         }
         o[j] = acc;
+    }
+    if (skip) {
+        const float4 k4 = *reinterpret_cast<const float4*>(skip + (size_t)pl * Ho * Wo + (size_t)q * 4);
+        o[0] += k4.x; o[1] += k4.y; o[2] += k4.z; o[3] += k4.w;
     }
     *reinterpret_cast<float4*>(y + (size_t)pl * Ho * Wo + (size_t)q * 4) = make_float4(o[0], o[1], o[2], o[3]);
 }
@@ -528,8 +535,8 @@ extern "C" int cnuda_maxpool2d_window_backward(const float* x, const float* grad
     return check_launch("cnuda_maxpool2d_window_backward");
 }
 
-extern "C" int cnuda_dwconvt2d_forward(const float* x, const float* w, float* y, int B, int C, int H, int W, int k,
-                                       int s, int p, cnuda_stream_t stream) {
+extern "C" int cnuda_dwconvt2d_add_forward(const float* x, const float* w, const float* skip, float* y, int B, int C,
+                                           int H, int W, int k, int s, int p, cnuda_stream_t stream) {
     CNUDA_REQUIRE(x && w && y && B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && k <= 32 && s > 0 && p >= 0,
                   "cnuda_dwconvt2d_forward: bad arguments (kernel size 1..32)");
     const int Ho = (H - 1) * s - 2 * p + k, Wo = (W - 1) * s - 2 * p + k;
@@ -538,14 +545,18 @@ extern "C" int cnuda_dwconvt2d_forward(const float* x, const float* w, float* y,
     const bool upsample = k == 2 * s && p == s / 2 && (s == 2 || s == 4) && Wo % 4 == 0;   // IDAUp's bilinear-style layers
     if (upsample && s == 2)
         hipLaunchKernelGGL(dwconvt_fwd_f_kernel<2>, dim3(ceil_div((long long)Ho * Wo / 4, kT), B * C), dim3(kT), 0,
-                           (hipStream_t)stream, x, w, y, C, H, W);
+                           (hipStream_t)stream, x, w, skip, y, C, H, W);
     else if (upsample)
         hipLaunchKernelGGL(dwconvt_fwd_f_kernel<4>, dim3(ceil_div((long long)Ho * Wo / 4, kT), B * C), dim3(kT), 0,
-                           (hipStream_t)stream, x, w, y, C, H, W);
+                           (hipStream_t)stream, x, w, skip, y, C, H, W);
     else
         hipLaunchKernelGGL(dwconvt_fwd_kernel, dim3(ceil_div((long long)Ho * Wo, kT), B * C), dim3(kT), 0,
-                           (hipStream_t)stream, x, w, y, C, H, W, Ho, Wo, k, s, p);
+                           (hipStream_t)stream, x, w, skip, y, C, H, W, Ho, Wo, k, s, p);
     return check_launch("cnuda_dwconvt2d_forward");
+}
+extern "C" int cnuda_dwconvt2d_forward(const float* x, const float* w, float* y, int B, int C, int H, int W, int k,
+                                       int s, int p, cnuda_stream_t stream) {
+    return cnuda_dwconvt2d_add_forward(x, w, nullptr, y, B, C, H, W, k, s, p, stream);
 }
 extern "C" size_t cnuda_dwconv2d_workspace_bytes(int B, int C, int k) {
     return (size_t)(B > 0 ? B : 0) * (C > 0 ? C : 0) * k * k * sizeof(float) + 256;

@@ -82,6 +82,7 @@ class _Sig:
     cnuda_maxpool2d_window_forward = (_I, [_P] * 2 + [_I] * 7 + [_P])
     cnuda_maxpool2d_window_backward = (_I, [_P] * 3 + [_I] * 7 + [_P])
     cnuda_dwconvt2d_forward = (_I, [_P] * 3 + [_I] * 7 + [_P])
+    cnuda_dwconvt2d_add_forward = (_I, [_P] * 4 + [_I] * 7 + [_P])
     cnuda_dwconvt2d_workspace_bytes = (c_size_t, [_I] * 3)
     cnuda_dwconvt2d_backward = (_I, [_P] * 5 + [_I] * 7 + _WS)
     cnuda_dwconv2d_workspace_bytes = (c_size_t, [_I] * 3)

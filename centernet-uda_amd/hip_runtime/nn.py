@@ -105,8 +105,8 @@ class DepthwiseConvTranspose2d(nn.Module):
         with torch.no_grad():
             self.weight.uniform_(-1.0 / kernel_size, 1.0 / kernel_size)
 
-    def forward(self, x):
-        return ops.depthwise_conv_transpose2d(x, self.weight, self.stride, self.padding)
+    def forward(self, x, skip=None):
+        return ops.depthwise_conv_transpose2d(x, self.weight, self.stride, self.padding, skip)
 
 
 class DepthwiseConv2d(nn.Module):

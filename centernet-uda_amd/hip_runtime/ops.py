@@ -333,7 +333,7 @@ def max_pool2d(x, k, stride=None, padding=0):
 
 class _DwConvT(Function):
     @staticmethod
-    def forward(ctx, x, weight, stride, padding):
+    def forward(ctx, x, weight, stride, padding, skip=None):
         require_gpu(x, weight)
         x, weight = f32c(x), f32c(weight)
         B, C, H, W = x.shape
@@ -343,8 +343,14 @@ class _DwConvT(Function):
                                % (tuple(weight.shape), C))
         Ho, Wo = (H - 1) * stride - 2 * padding + k, (W - 1) * stride - 2 * padding + k
         y = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
-        check(lib().cnuda_dwconvt2d_forward(ptr(x), ptr(weight), ptr(y), B, C, H, W, k, stride, padding, stream()),
-              'dwconvt2d_forward')
+        if skip is not None:
+            require_gpu(skip)
+            skip = f32c(skip)
+            if skip.shape != y.shape:
+                raise RuntimeError("depthwise conv_transpose2d: summand %s does not fit the output %s"
+                                   % (tuple(skip.shape), tuple(y.shape)))
+        check(lib().cnuda_dwconvt2d_add_forward(ptr(x), ptr(weight), ptr(skip), ptr(y), B, C, H, W, k, stride, padding,
+                                                stream()), 'dwconvt2d_forward')
         ctx.geom = (B, C, H, W, k, stride, padding)
         ctx.save_for_backward(x, weight)
         return y
@@ -360,11 +366,12 @@ class _DwConvT(Function):
         wp, wn = _ws(L.cnuda_dwconvt2d_workspace_bytes(B, C, k), x)
         check(L.cnuda_dwconvt2d_backward(ptr(x), ptr(weight), ptr(f32c(gy)), ptr(gx), ptr(gw_buf), *ctx.geom,
                                          wp, wn, stream()), 'dwconvt2d_backward')
-        return gx, gw, None, None
+        return gx, gw, None, None, (gy if ctx.needs_input_grad[4] else None)
 
 
-def depthwise_conv_transpose2d(x, weight, stride, padding):
-    return _DwConvT.apply(x, weight, int(stride), int(padding))
+def depthwise_conv_transpose2d(x, weight, stride, padding, skip=None):
+    """Depthwise ConvTranspose2d; with `skip` the result is `conv_transpose(x) + skip` written in one pass."""
+    return _DwConvT.apply(x, weight, int(stride), int(padding), skip)
 
 
 class _DwConv(Function):

@@ -263,6 +263,10 @@ int cnuda_maxpool2d_window_backward(const float* x, const float* grad_y, float* 
                                     int B, int C, int H, int W, int k, int s, int p, cnuda_stream_t stream);
 int cnuda_dwconvt2d_forward(const float* x, const float* w, float* y,
                             int B, int C, int H, int W, int k, int s, int p, cnuda_stream_t stream);
+/* y = dwconvt2d(x, w) + skip with skip of the output's shape (nullable): IDAUp's `up(project(x)) + layers[i-1]`
+ * (dla.py:400-401) in one pass over the upsampled map, rounded as the separate add would round */
+int cnuda_dwconvt2d_add_forward(const float* x, const float* w, const float* skip, float* y,
+                                int B, int C, int H, int W, int k, int s, int p, cnuda_stream_t stream);
 size_t cnuda_dwconvt2d_workspace_bytes(int B, int C, int k);   /* per-image partial weight gradients */
 int cnuda_dwconvt2d_backward(const float* x, const float* w, const float* grad_y, float* grad_x, float* grad_w,
                              int B, int C, int H, int W, int k, int s, int p,

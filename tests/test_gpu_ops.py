@@ -146,6 +146,30 @@ def test_depthwise_conv_transpose(C, H, W, f):
     _close(dw.grad, w.grad)
 
 
+@pytest.mark.parametrize('C,H,W,f', [(8, 5, 6, 2), (3, 3, 5, 8), (16, 32, 32, 2), (16, 16, 16, 4)])
+def test_depthwise_conv_transpose_with_summand_is_the_separate_add(C, H, W, f):
+    """IDAUp's `up(project(x)) + layers[i-1]` in one pass: bit-identical to the operator followed by ops.add, and
+    the summand's gradient is the incoming gradient itself."""
+    from hip_runtime import ops
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(2, C, H, W, generator=g).to(DEV)
+    w = torch.randn(C, 1, 2 * f, 2 * f, generator=g).to(DEV)
+    skip = torch.randn(2, C, H * f, W * f, generator=g).to(DEV)
+    gy = torch.randn(2, C, H * f, W * f, generator=g).to(DEV)
+    ref_in = [t.clone().requires_grad_(True) for t in (x, w, skip)]
+    ref = ops.add(ops.depthwise_conv_transpose2d(ref_in[0], ref_in[1], f, f // 2), ref_in[2])
+    ref.backward(gy)
+    got_in = [t.clone().requires_grad_(True) for t in (x, w, skip)]
+    got = ops.depthwise_conv_transpose2d(got_in[0], got_in[1], f, f // 2, got_in[2])
+    assert torch.equal(got, ref)
+    got.backward(gy)
+    for a, b in zip(got_in, ref_in):
+        assert torch.equal(a.grad, b.grad)
+    assert torch.equal(got_in[2].grad, gy)
+    with pytest.raises(RuntimeError, match='summand'):
+        ops.depthwise_conv_transpose2d(x, w, f, f // 2, skip[:, :, 1:])
+
+
 def test_cat_add_split():
     from hip_runtime import ops
     g = torch.Generator().manual_seed(7)
