@@ -165,6 +165,33 @@ def test_noise_map_at_160_overflows_the_sorting_pool():
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=2e-4)
 
 
+@pytest.mark.parametrize('levels', [1, 2, 4, 8, 64, 0])
+def test_isolated_peaks_sharing_score_bits_threshold_path(levels):
+    """The pool path (K <= survivors <= 2,048) selects by a histogram of the top 12 score bits and rank-sorts the keys
+    at or above the K-th key's bin.  1,849 isolated peaks (a 3-pixel lattice, zero background) whose scores take only
+    `levels` distinct values (spread over [0.5, 0.95): 15 bins) put about 1,849 / levels tied keys into that bin: more than 1,024 (falls back to the pool
+    sort), 513..1,024 (one lane per key), 257..512, <= 256; 0 = all scores distinct inside one bin."""
+    from backends.decode import decode_detection
+    rs = np.random.RandomState(91 + levels)
+    B, C, H, W, K = 2, 3, 128, 128, 150
+    heat = np.zeros((B, C, H, W), np.float32)
+    ys, xs = np.meshgrid(np.arange(1, 128, 3), np.arange(1, 128, 3), indexing='ij')
+    n = ys.size
+    for b in range(B):
+        for c in range(C):
+            if levels:
+                vals = (0.5 + 0.45 * rs.randint(0, levels, n) / levels).astype(np.float32)   # spread over 15 bins
+            else:
+                vals = (0.5 + rs.permutation(n) * 1e-6).astype(np.float32)      # all inside [0.5, 0.53125)
+            heat[b, c, ys.ravel(), xs.ravel()] = vals
+    wh = rs.uniform(2, 40, (B, 2, H, W)).astype(np.float32)
+    reg = rs.uniform(0, 1, (B, 2, H, W)).astype(np.float32)
+    got = decode_detection(T(heat), T(wh), reg=T(reg), K=K).cpu().numpy()
+    want = od.decode_detection(heat, wh, reg, K=K)
+    assert np.array_equal(got[..., 4:], want[..., 4:])
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-5)
+
+
 def test_negative_and_zero_scores_general_path():
     # not the reference's call path (scores are probabilities there), but the kernel defines it: Q9's literal formula
     from backends.decode import _topk
