@@ -1,14 +1,12 @@
 // Detection decode for gfx950: 3x3 (or kxk) max-pool NMS + two-stage top-K +
 // box assembly.  Replaces backends/decode.py:6-76 of the reference.
 //
-// Stage 1 (one 512-thread workgroup per (b, c) plane): the plane is read once from HBM (neighbours come from
-// L1).  After the NMS almost every score is exactly 0, so the strictly positive ones are first compacted into
-// LDS (wave ballots, one LDS atomic per wave and 64 pixels); when at least K and at most 2048 survive -- every
-// real heat map -- the K best are simply the head of an in-LDS bitonic sort of those few keys.  Otherwise
-// (flat or pathological maps) an 8-bit MSB radix select over all pixels' 64-bit order keys runs instead (LDS
-// histograms + one-wave suffix scan; its LDS atomics serialise on the all-zero bucket, which is why it is not
-// the common path).  Stage 2 (one workgroup per image) runs the radix select over the C*K candidates and
-// assembles the boxes.
+// Stage 1 (one 1,024-thread workgroup per (b, c) plane): the plane is read once from HBM into LDS, the NMS runs from
+// LDS into registers, and the K best of the strictly positive survivors (after the NMS 8/9 of a map is exactly 0) are
+// found by a 4,096-bin histogram of their leading score bits, a suffix scan for the bin of the K-th largest and a
+// rank sort of the few keys at or above it.  Flat or pathological maps (plateaus at the threshold, fewer than K
+// positive scores) take an exact 8-bit MSB radix select over the NMS'd plane in LDS instead.  Stage 2 (one workgroup
+// per image) selects the K best of the C*K candidates the same way and assembles the boxes.
 //
 // Order key: high 32 bits = order-preserving image of the fp32 score, low 32
 // bits = ~index, so "larger key" == "higher score, or equal score and lower
@@ -21,6 +19,7 @@ namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kMaxK = 1024;
+constexpr int kSelSlack = 64;
 
 __device__ __forceinline__ uint32_t float_order_bits(float v) {
     v += 0.0f;  // -0.0 -> +0.0 so that both zeros tie like they do for torch.topk
@@ -41,33 +40,70 @@ struct SelectScratch {
     int remaining;       // how many keys are still to be taken from the current bucket
     int done;
     int out_count;
-    uint64_t sel[kMaxK];
+    int ranks[kMaxK];                  // rank_sort_desc's counters
+    uint64_t sel[kMaxK + kSelSlack];   // selected keys (+ rank_sort_desc's zero padding)
 };
 
-// Sorts n <= NT unique keys sel[0..n) (LDS) descending, in place, by counting: key q is served by P = NT / pow2(n)
-// adjacent lanes (at most a wave) which compare it with every P-th key -- broadcast LDS reads, no barrier inside the
-// loop -- and add their counts through shuffles; a key's rank is its final position.  n / P iterations and two
-// barriers, where a bitonic network over pow2(n) keys takes log^2 stages with a workgroup barrier each (36 for 256).
-// With `out` the keys of rank < K go straight to out[rank] (global memory) instead.
+// Sorts n <= NT unique keys s.sel[0..n) descending, in place, by counting.  The compare matrix is tiled: a thread
+// keeps kSortKeys keys in registers and streams every P-th key of the array past them (P = threads per key block;
+// eight independent LDS reads per batch, the lanes of one part read one address, neighbouring parts neighbouring
+// banks), then adds its counts to s.ranks with LDS atomics; a key's rank is its final position.  n * n / NT compares
+// and n * n / (kSortKeys * NT) LDS reads per thread, two barriers -- a bitonic network over pow2(n) keys takes log^2
+// stages with a workgroup barrier each (36 for 256 keys).  With `out` the keys of rank < K go straight to out[rank]
+// (global memory) instead.  rank_sort_prepare (any time after n is known and before the barrier that publishes the
+// keys) clears the counters and pads the keys with zeros up to the end of the last batch.
+constexpr int kSortKeys = 4, kSortBatch = 8;
 template <int NT>
-__device__ __forceinline__ void rank_sort_desc(uint64_t* __restrict__ sel, int n, uint64_t* __restrict__ out = nullptr,
-                                               int K = 0) {
+__device__ __forceinline__ int rank_sort_threads(int n) {           // per block of kSortKeys keys
+    return min(NT / ((max(n, 1) + kSortKeys - 1) / kSortKeys), kSelSlack);
+}
+template <int NT>
+__device__ __forceinline__ void rank_sort_prepare(SelectScratch& s, int n) {
+    static_assert(kSortBatch * kSelSlack <= kMaxK && kSortBatch * kSortKeys * NT / kMaxK <= kSelSlack, "padding fits");
+    const int P = rank_sort_threads<NT>(n);
+    for (int i = threadIdx.x; i < n; i += NT) s.ranks[i] = 0;
+    for (int i = n + threadIdx.x; i < n + kSortBatch * P; i += NT) s.sel[i] = 0;
+}
+template <int NT>
+__device__ __forceinline__ void rank_sort_desc(SelectScratch& s, int n, uint64_t* __restrict__ out = nullptr, int K = 0) {
     const int tid = threadIdx.x;
-    int sh = 0;                                           // log2(P)
-    while (sh < 6 && ((n << (sh + 1)) <= NT)) ++sh;
-    const int P = 1 << sh;
-    const int q = tid >> sh, part = tid & (P - 1);
-    const bool have = q < n;
-    const uint64_t key = have ? sel[q] : 0;
-    int rank = 0;
-    for (int j = part; j < n; j += P) rank += sel[j] > key ? 1 : 0;
-    for (int o = 1; o < P; o <<= 1) rank += __shfl_xor(rank, o, 64);
-    if (out) {
-        if (have && part == 0 && rank < K) out[rank] = key;
-        return;
+    const int P = rank_sort_threads<NT>(n);
+    const int qb = tid / P, part = tid - qb * P;
+    const int q0 = qb * kSortKeys;
+    uint64_t key[kSortKeys];
+    int rank[kSortKeys];
+#pragma unroll
+    for (int r = 0; r < kSortKeys; ++r) { key[r] = q0 + r < n ? s.sel[q0 + r] : ~0ull; rank[r] = 0; }
+    if (q0 < n) {
+        for (int j = part; j < n; j += kSortBatch * P) {
+            uint64_t x[kSortBatch];
+#pragma unroll
+            for (int u = 0; u < kSortBatch; ++u) x[u] = s.sel[j + u * P];
+#pragma unroll
+            for (int u = 0; u < kSortBatch; ++u)
+#pragma unroll
+                for (int r = 0; r < kSortKeys; ++r) rank[r] += x[u] > key[r] ? 1 : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < kSortKeys; ++r)
+            if (rank[r]) atomicAdd(&s.ranks[q0 + r], rank[r]);
     }
     __syncthreads();
-    if (have && part == 0) sel[rank] = key;
+    if (out) {
+        if (part == 0) {
+#pragma unroll
+            for (int r = 0; r < kSortKeys; ++r) {
+                const int at = q0 + r < n ? s.ranks[q0 + r] : K;
+                if (at < K) out[at] = key[r];
+            }
+        }
+        return;
+    }
+    if (part == 0) {
+#pragma unroll
+        for (int r = 0; r < kSortKeys; ++r)
+            if (q0 + r < n) s.sel[s.ranks[q0 + r]] = key[r];
+    }
     __syncthreads();
 }
 
@@ -141,7 +177,10 @@ __device__ void block_topk(KeyAt key_at, int n, int K, int KP, SelectScratch& s)
     }
     // the selected keys (exactly K of them: keys are unique) sit unordered in s.sel[0..K), zeros behind them
     static_assert(kMaxK <= NT, "one key per thread at least");
-    rank_sort_desc<NT>(s.sel, min(s.out_count, KP));
+    const int cnt = min(s.out_count, KP);
+    rank_sort_prepare<NT>(s, cnt);
+    __syncthreads();
+    rank_sort_desc<NT>(s, cnt);
 }
 
 __device__ __forceinline__ float nms_value(const float* __restrict__ plane, int H, int W, int y, int x, int pad) {
@@ -302,6 +341,8 @@ __device__ void lds_plane_topk(const uint32_t* __restrict__ bits, int n, int K, 
         gt_total += wcnt[w];
         eq_total += wcnt[NW + w];
     }
+    const int cnt = min(gt_total + min(eq_total, need), KP);
+    rank_sort_prepare<NT>(s, cnt);
     for (int i = lo + lane; i < hi + 63; i += 64) {
         const bool in = i < hi;
         const uint32_t full = in ? bits[i] : 0u;
@@ -316,199 +357,228 @@ __device__ void lds_plane_topk(const uint32_t* __restrict__ bits, int n, int K, 
         eq_base += __popcll(me);
     }
     __syncthreads();
-    rank_sort_desc<NT>(s.sel, min(gt_total + min(eq_total, need), KP));
+    rank_sort_desc<NT>(s, cnt);
 }
 
-// Bitonic sort (descending) of a 2048-key LDS pool by 1024 threads, two keys per thread in registers (positions 2t,
-// 2t+1): stride 1 is a compare inside the thread, strides 2..64 exchange with lane t ^ (stride/2) by shuffle, only
-// strides >= 128 cross waves and go through LDS -- 10 of the 66 stages need workgroup barriers.  Ends with the
-// sorted keys in `pool` (barrier included).
-constexpr int kPool = 2048;          // positive-score candidates the fast path sorts
-__device__ __forceinline__ void pool_sort_desc(uint64_t* __restrict__ pool, int tid) {
-    uint64_t k0 = pool[2 * tid], k1 = pool[2 * tid + 1];
-    const int p0 = 2 * tid;
-    for (int size = 2; size <= kPool; size <<= 1) {
-        const bool desc = (p0 & size) == 0;            // same for both keys of the thread (size >= 2)
-        for (int stride = size >> 1; stride >= 128; stride >>= 1) {
-            __syncthreads();                           // previous readers of the pool are done
-            pool[p0] = k0; pool[p0 + 1] = k1;
-            __syncthreads();
-            const uint64_t o0 = pool[p0 ^ stride], o1 = pool[(p0 + 1) ^ stride];
-            const bool lower = (p0 & stride) == 0;
-            const bool take_max = lower == desc;
-            k0 = take_max ? (k0 > o0 ? k0 : o0) : (k0 < o0 ? k0 : o0);
-            k1 = take_max ? (k1 > o1 ? k1 : o1) : (k1 < o1 ? k1 : o1);
-        }
-        for (int stride = size >> 1 < 64 ? size >> 1 : 64; stride >= 2; stride >>= 1) {
-            const uint64_t o0 = __shfl_xor(k0, stride >> 1, 64), o1 = __shfl_xor(k1, stride >> 1, 64);
-            const bool lower = (p0 & stride) == 0;
-            const bool take_max = lower == desc;
-            k0 = take_max ? (k0 > o0 ? k0 : o0) : (k0 < o0 ? k0 : o0);
-            k1 = take_max ? (k1 > o1 ? k1 : o1) : (k1 < o1 ? k1 : o1);
-        }
-        {   // stride 1: the thread's own pair
-            const uint64_t hi = k0 > k1 ? k0 : k1, lo = k0 > k1 ? k1 : k0;
-            k0 = desc ? hi : lo;
-            k1 = desc ? lo : hi;
-        }
+// ---- threshold by histogram -----------------------------------------------------------------------------------------
+// Both stages pick the K largest of n keys the same way: a 4,096-bin histogram of 12 leading score bits in LDS (one
+// pass, the atomics spread over the bins), a suffix scan for the bin that holds the K-th largest key, and a rank sort
+// of the keys at or above that bin -- a couple of hundred at most on any real map.  When more than kMaxK keys share
+// that bin (plateaus) or fewer than K keys were counted, the exact radix selects above take over.
+constexpr int kBins = 4096;
+// scans hist[0..kBins) from the top bin down with NT = kBins / 4 threads.  Returns through LDS (uniform values): the bin
+// of the K-th largest counted key, the number of keys at or above it (INT_MAX when fewer than K keys were counted).
+template <int NT>
+__device__ __forceinline__ void hist_threshold(const int* __restrict__ hist, int K, int* __restrict__ wave_tot,
+                                               int& bin, int& nsel) {
+    static_assert(NT * 4 == kBins, "four bins per thread");
+    __shared__ int thr_bin, thr_sel;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) { thr_bin = 0; thr_sel = 0x7fffffff; }
+    // thread t owns bins 4 * (NT - 1 - t) .. + 3: the inclusive scan over t counts the keys from the top bin down
+    const int bin_base = (NT - 1 - tid) * 4;
+    const int4 c = reinterpret_cast<const int4*>(hist)[NT - 1 - tid];
+    const int local = c.x + c.y + c.z + c.w;
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    int acc = incl - local;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) acc += w < wid ? wave_tot[w] : 0;
+    const int cs[4] = {c.w, c.z, c.y, c.x};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (acc < K && K <= acc + cs[j]) { thr_bin = bin_base + 3 - j; thr_sel = acc + cs[j]; }
+        acc += cs[j];
     }
     __syncthreads();
-    pool[p0] = k0; pool[p0 + 1] = k1;
-    __syncthreads();
+    bin = thr_bin;
+    nsel = thr_sel;
 }
 
-// Stage 1.
+// Stage 2's selection: the K largest of the n unique keys key_at(0..n), sorted, by threshold + rank sort.  Up to three
+// histogram levels of 12 key bits each, from the sign bit down: a level whose K-th-key bin leaves more than kRankMax
+// keys selected is refined inside that bin by the next 12 bits.  The keys are a concatenation of SORTED lists (stage
+// 1's output), so equal digits come in runs: a run adds its length to its bin with two atomics -- minus its first index
+// at the head, plus its last index + 1 at the tail -- instead of one contended atomic per key.  On success s.sel[0..K)
+// holds the K largest keys in descending order; false (nothing written) when fewer than K keys exist or more than
+// kMaxK keys still tie after 36 bits -- block_topk handles those.
+constexpr int kRankMax = 512;
+template <int NT, typename KeyAt>
+__device__ __forceinline__ bool merge_select(KeyAt key_at, int n, int K, int* __restrict__ hist,
+                                             int* __restrict__ wave_tot, SelectScratch& s) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint64_t mask = 0, prefix = 0;                    // leading bits decided so far, and their value at the threshold
+    int need = K, taken = 0, nsel = 0, shift = 52;
+    bool found = false;
+    if (tid == 0) s.out_count = 0;
+    for (int level = 0; level < 3 && !found; ++level, shift -= 12) {
+        reinterpret_cast<int4*>(hist)[tid] = make_int4(0, 0, 0, 0);
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) {
+            const uint64_t k = key_at(i);
+            if ((k & mask) != prefix) continue;
+            const int d = (int)(k >> shift) & 0xfff;
+            const uint64_t kp = i > 0 ? key_at(i - 1) : 0, kn = i + 1 < n ? key_at(i + 1) : 0;
+            const bool head = !(i > 0 && (kp & mask) == prefix && ((int)(kp >> shift) & 0xfff) == d);
+            const bool tail = !(i + 1 < n && (kn & mask) == prefix && ((int)(kn >> shift) & 0xfff) == d);
+            if (head || tail) atomicAdd(&hist[d], (tail ? i + 1 : 0) - (head ? i : 0));
+        }
+        __syncthreads();
+        int tb, cnt;
+        hist_threshold<NT>(hist, need, wave_tot, tb, cnt);
+        if (cnt == 0x7fffffff) return false;
+        const int at_tb = hist[tb];
+        mask |= 0xfffull << shift;
+        prefix |= (uint64_t)tb << shift;
+        nsel = taken + cnt;
+        found = nsel <= (level == 2 ? kMaxK : kRankMax);
+        taken += cnt - at_tb;                         // the keys above the bin are in for good
+        need -= cnt - at_tb;
+        __syncthreads();                              // every thread has read hist[tb] before the next level clears it
+    }
+    if (!found) return false;
+    rank_sort_prepare<NT>(s, nsel);
+    // selected: the decided bits are at or above the threshold's; a wave takes its slots in s.sel with one atomic
+    int mine = 0;
+    for (int i0 = 0; i0 < n; i0 += NT) {
+        const int i = i0 + tid;
+        mine += __popcll(__ballot(i < n && (key_at(min(i, n - 1)) & mask) >= prefix));
+    }
+    int at = 0;
+    if (lane == 0 && mine) at = atomicAdd(&s.out_count, mine);
+    at = __builtin_amdgcn_readfirstlane(at);
+    for (int i0 = 0; i0 < n; i0 += NT) {
+        const int i = i0 + tid;
+        const uint64_t k = key_at(min(i, n - 1));
+        const bool in = i < n && (k & mask) >= prefix;
+        const unsigned long long m = __ballot(in);
+        if (in) s.sel[at + __popcll(m & ((1ull << lane) - 1ull))] = k;
+        at += __popcll(m);
+    }
+    __syncthreads();
+    rank_sort_desc<NT>(s, nsel);
+    return true;
+}
+
+// Stage 1: one 1,024-thread workgroup per (b, c) plane.
+//   A  the plane is copied from HBM into LDS once (coalesced 16-byte loads);
+//   B  every thread evaluates the NMS of its pixels from LDS into registers (up to 32: planes up to 181 x 181 fit the
+//      128 KB of dynamic LDS); the strictly positive scores are the keys (after the NMS 8/9 of a map is exactly zero;
+//      first histogram level: score bits 30..19, exponent + 4 mantissa bits, 16 bins per octave);
+//   C  hist_threshold;  D  the keys at or above the threshold bin are compacted (wave ballots, one LDS atomic per wave)
+//      and rank-sorted straight into the candidate list.
+// Maps with fewer than K positive scores or a plateau at the threshold (a trained model's background is clamped to
+// exactly 1e-4: whole regions survive the NMS) write the NMS'd score bits over the raw plane and run lds_plane_topk;
+// planes that do not fit the LDS run block_topk with the NMS recomputed from the L1/L2-resident plane.
 constexpr int kPlaneThreads = 1024;
-static_assert(kPool == 2 * kPlaneThreads, "two keys per thread");
+constexpr int kPlanePer = 32;        // pixels per thread held in registers
 __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* __restrict__ heat,
                                                                    uint64_t* __restrict__ cand, int H, int W, int K,
                                                                    int KP, int pad, int lds_plane) {
     __shared__ SelectScratch s;
-    __shared__ uint64_t pool[kPool];
-    __shared__ int count;
-    __shared__ int wave_count[kPlaneThreads / 64];
-    extern __shared__ uint32_t plane_bits[];          // [HW] order bits of the NMS'd scores (0 bytes: plane too large)
+    __shared__ int hist[kBins];                       // later: the per-wave histograms of lds_plane_topk
+    __shared__ int wave_tot[2 * (kPlaneThreads / 64)];
+    extern __shared__ float plane_lds[];              // [HW] the raw plane, then (general path) its NMS'd score bits
     const int tid = threadIdx.x, lane = tid & 63;
     const int HW = H * W;
     const float* plane = heat + (size_t)blockIdx.x * HW;
     uint64_t* dst = cand + (size_t)blockIdx.x * K;
-    if (tid == 0) count = 0;
-    __syncthreads();
-    // compaction of the strictly positive NMS'd scores without LDS atomics (16 waves hitting one LDS counter
-    // serialise: 21 of 28 us in the first version): a super-chunk of 16 pixels per thread is evaluated into
-    // registers, every wave counts its survivors with ballots, the 16 wave totals are scanned through LDS and
-    // every wave then writes its keys at its own offsets.
-    constexpr int kPer = 16, kWaves = kPlaneThreads / 64;
-    const bool quads = pad == 1 && (W & 3) == 0;        // the reference's default 3x3 window on 4-aligned rows
-    const bool lds_bits = lds_plane != 0;              // host: the plane's score bits fit the dynamic LDS
-    __shared__ int wave_count2[2 * (kPlaneThreads / 64)];
-    const int wid = tid >> 6;
-    int filled = 0;                                   // survivors of the previous super-chunks (uniform)
-    for (int s0 = 0; s0 < HW; s0 += kPer * kPlaneThreads) {
-        float v[kPer];
-        int mine = 0;
-        if (quads) {
-            // thread owns 4 quads of consecutive pixels: v[4*q + j] <-> pixel s0 + (q * NT + tid) * 4 + j
-#pragma unroll
-            for (int q = 0; q < kPer / 4; ++q) {
-                const int i = s0 + (q * kPlaneThreads + tid) * 4;
-                float o[4] = {0.f, 0.f, 0.f, 0.f};
-                if (i < HW) { const int y = i / W; nms_quad(plane, H, W, y, i - y * W, o); }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[4 * q + j] = o[j];
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < kPer; ++u) {
-                const int i = s0 + u * kPlaneThreads + tid;
-                const int y = i / W;
-                v[u] = i < HW ? nms_value(plane, H, W, y, i - y * W, pad) : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kPer; ++u) mine += __popcll(__ballot(v[u] > 0.0f));
-        if (lane == 0) wave_count[wid] = mine;
-        __syncthreads();
-        int base = filled, total = 0;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            const int c = wave_count[w];
-            base += w < wid ? c : 0;
-            total += c;
-        }
-#pragma unroll
-        for (int u = 0; u < kPer; ++u) {
-            const bool pos = v[u] > 0.0f;
-            const unsigned long long m = __ballot(pos);
-            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-            const int pix = quads ? s0 + ((u >> 2) * kPlaneThreads + tid) * 4 + (u & 3) : s0 + u * kPlaneThreads + tid;
-            if (lds_bits && pix < HW) plane_bits[pix] = float_order_bits(v[u]);
-            if (pos && slot < kPool) pool[slot] = make_key(v[u], (uint32_t)pix);
-            base += __popcll(m);
-        }
-        filled += total;
-        __syncthreads();                              // wave_count is reused by the next super-chunk
-    }
-    if (tid == 0) count = filled;
-    __syncthreads();
-    const int M = count;
-    if (M >= K && M <= kPool) {
-        // every key outside the pool has score <= 0 < the pool's: the top K are the K largest pool keys.  They are not
-        // found by sorting the pool (66 bitonic stages over 2,048 keys: 31.5 of this kernel's 56 thousand cycles) but
-        // by a threshold: a 4,096-bin histogram of the 12 score bits below the sign (exponent + 4 mantissa bits: 16
-        // bins per octave) laid over the pool's own 16 KB once the keys are in registers, a suffix scan for the bin
-        // holding the K-th key, and a rank sort of the few keys at or above that bin (a noise map: ~190 of 1,800).
-        const int i0 = 2 * tid, i1 = i0 + 1;
-        const uint64_t k0 = i0 < M ? pool[i0] : 0, k1 = i1 < M ? pool[i1] : 0;
-        __syncthreads();
-        int* hist = reinterpret_cast<int*>(pool);
-        static_assert(sizeof(pool) == 4 * kPlaneThreads * sizeof(int), "four bins per thread");
-        reinterpret_cast<int4*>(hist)[tid] = make_int4(0, 0, 0, 0);
-        __syncthreads();
-        const int b0 = (int)(k0 >> 51) & 0xfff, b1 = (int)(k1 >> 51) & 0xfff;
-        if (i0 < M) atomicAdd(&hist[b0], 1);
-        if (i1 < M) atomicAdd(&hist[b1], 1);
-        __syncthreads();
-        // thread t owns bins 4 * (1023 - t) .. + 3: the inclusive scan over t counts the keys from the top bin down
-        const int bin_base = (kPlaneThreads - 1 - tid) * 4;
-        const int4 c = reinterpret_cast<const int4*>(hist)[kPlaneThreads - 1 - tid];
-        const int local = c.x + c.y + c.z + c.w;
-        int incl = local;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) wave_count[wid] = incl;
-        __syncthreads();
-        int acc = incl - local;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) acc += w < wid ? wave_count[w] : 0;
-        __shared__ int thr_bin, thr_sel;
-        {
-            const int cs[4] = {c.w, c.z, c.y, c.x};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (acc < K && K <= acc + cs[j]) { thr_bin = bin_base + 3 - j; thr_sel = acc + cs[j]; }
-                acc += cs[j];
-            }
-        }
-        __syncthreads();
-        const int tb = thr_bin, nsel = thr_sel;
-        if (nsel <= kMaxK) {
-            const bool s0 = i0 < M && b0 >= tb, s1 = i1 < M && b1 >= tb;
-            const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (lane == 0) wave_count2[wid] = __popcll(m0) + __popcll(m1);
-            __syncthreads();
-            int at = 0;
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) at += w < wid ? wave_count2[w] : 0;
-            if (s0) s.sel[at + __popcll(m0 & below)] = k0;
-            if (s1) s.sel[at + __popcll(m0) + __popcll(m1 & below)] = k1;
-            __syncthreads();
-            rank_sort_desc<kPlaneThreads>(s.sel, nsel, dst, K);
-            return;
-        }
-        // a plateau at the threshold (more than kMaxK keys share its 12 bits): sort the whole pool instead
-        pool[i0] = k0;
-        pool[i1] = k1;
-        __syncthreads();
-        pool_sort_desc(pool, tid);
-        for (int i = tid; i < K; i += kPlaneThreads) dst[i] = pool[i];
-        return;
-    }
-    if (lds_bits) {
-        // general case, LDS-resident (see lds_plane_topk): the whole plane's NMS'd scores are already in LDS; the
-        // sorting pool's memory is free again and serves as the per-wave histograms
-        static_assert(sizeof(pool) >= (kPlaneThreads / 64) * 256 * sizeof(int), "histograms fit the pool");
-        lds_plane_topk<kPlaneThreads>(plane_bits, HW, K, KP, s, reinterpret_cast<int*>(pool), wave_count2);
+    if (!lds_plane) {
+        block_topk<kPlaneThreads>([&](int i) { return make_key(nms_value(plane, H, W, i / W, i % W, pad), (uint32_t)i); },
+                                  HW, K, KP, s);
         for (int i = tid; i < K; i += kPlaneThreads) dst[i] = s.sel[i];
         return;
     }
-    // planes too large for the LDS: exact select with the NMS recomputed per pass from the L1/L2-resident plane
-    block_topk<kPlaneThreads>([&](int i) { return make_key(nms_value(plane, H, W, i / W, i % W, pad), (uint32_t)i); },
-                              HW, K, KP, s);
+    // A
+    if ((HW & 3) == 0) {
+        for (int i = tid * 4; i < HW; i += kPlaneThreads * 4)
+            *reinterpret_cast<float4*>(plane_lds + i) = *reinterpret_cast<const float4*>(plane + i);
+    } else {
+        for (int i = tid; i < HW; i += kPlaneThreads) plane_lds[i] = plane[i];
+    }
+    reinterpret_cast<int4*>(hist)[tid] = make_int4(0, 0, 0, 0);
+    if (tid == 0) s.out_count = 0;
+    __syncthreads();
+    // B (a strictly positive float's own bits order like the float: bits 30..19 are the bin)
+    const bool quads = pad == 1 && (W & 3) == 0;        // the reference's default 3x3 window on 4-aligned rows
+    float v[kPlanePer];
+    // pixel of v[u]: quads -- thread owns quads of consecutive pixels, v[4*q + j] <-> (q * NT + tid) * 4 + j
+    auto pixel = [&](int u) { return quads ? ((u >> 2) * kPlaneThreads + tid) * 4 + (u & 3) : u * kPlaneThreads + tid; };
+    const int rounds = (HW + 4 * kPlaneThreads - 1) / (4 * kPlaneThreads);   // groups of 4 registers in use (uniform)
+#pragma unroll
+    for (int q = 0; q < kPlanePer / 4; ++q) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (q < rounds) {
+            if (quads) {
+                const int i = (q * kPlaneThreads + tid) * 4;
+                if (i < HW) { const int y = i / W; nms_quad(plane_lds, H, W, y, i - y * W, o); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = (4 * q + j) * kPlaneThreads + tid;
+                    const int y = i / W;
+                    if (i < HW) o[j] = nms_value(plane_lds, H, W, y, i - y * W, pad);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (o[j] > 0.0f) atomicAdd(&hist[__float_as_uint(o[j]) >> 19], 1);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * q + j] = o[j];
+    }
+    __syncthreads();
+    // C
+    int tb, nsel;
+    hist_threshold<kPlaneThreads>(hist, K, wave_tot, tb, nsel);
+    if (nsel <= kMaxK && tb > 0) {
+        // D: "bin >= tb" is one float compare against the bin's lower edge (bin 0 -- subnormal scores -- is left to the
+        // general path); a wave takes its slots in s.sel with one atomic: the rank sort does not care about the order
+        const float edge = __uint_as_float((uint32_t)tb << 19);
+        rank_sort_prepare<kPlaneThreads>(s, nsel);
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < kPlanePer / 4; ++q) {
+            if (q < rounds) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mine += __popcll(__ballot(v[4 * q + j] >= edge));
+            }
+        }
+        int at = 0;
+        if (lane == 0 && mine) at = atomicAdd(&s.out_count, mine);
+        at = __builtin_amdgcn_readfirstlane(at);
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int q = 0; q < kPlanePer / 4; ++q) {
+            if (q < rounds) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = v[4 * q + j];
+                    const unsigned long long m = __ballot(x >= edge);
+                    if (x >= edge) s.sel[at + __popcll(m & below)] = make_key(x, (uint32_t)pixel(4 * q + j));
+                    at += __popcll(m);
+                }
+            }
+        }
+        __syncthreads();
+        rank_sort_desc<kPlaneThreads>(s, nsel, dst, K);
+        return;
+    }
+    // general case, LDS-resident (see lds_plane_topk): every thread is past its reads of the raw plane (barriers of C)
+#pragma unroll
+    for (int u = 0; u < kPlanePer; ++u) {
+        const int pix = pixel(u);
+        if (pix < HW) reinterpret_cast<uint32_t*>(plane_lds)[pix] = float_order_bits(v[u]);
+    }
+    __syncthreads();
+    static_assert(sizeof(hist) >= (kPlaneThreads / 64) * 256 * sizeof(int), "the per-wave histograms fit");
+    lds_plane_topk<kPlaneThreads>(reinterpret_cast<const uint32_t*>(plane_lds), HW, K, KP, s, hist, wave_tot);
     for (int i = tid; i < K; i += kPlaneThreads) dst[i] = s.sel[i];
 }
 
@@ -516,41 +586,45 @@ __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* 
 __global__ __launch_bounds__(kThreads) void merge_decode_kernel(
     const uint64_t* __restrict__ cand, const float* __restrict__ wh, const float* __restrict__ reg,
     float* __restrict__ dets, int64_t* __restrict__ inds,
-    int C, int H, int W, int K, int KP, int wh_ch, int rotated) {
+    int C, int H, int W, int K, int KP, int wh_ch, int rotated, int lds_cand) {
     __shared__ SelectScratch s;
+    extern __shared__ uint64_t cand_lds[];            // [C*K] this image's candidates (0 bytes: too many, read in place)
     const int b = blockIdx.x;
     const int HW = H * W;
     const int n = C * K;
     const uint64_t* cb = cand + (size_t)b * n;
-    // second-stage key: same score bits, position c*K+rank as the index
-    auto key2 = [&](int i) { return (cb[i] & 0xffffffff00000000ull) | (uint64_t)(0xffffffffu - (uint32_t)i); };
-    if (n <= kPool) {
-        // few classes (the reference's default 6 x 150 = 900 candidates).  Every class list arrives SORTED (stage 1), so
-        // no sort is needed: a candidate's final rank is its rank in its own list plus, for every other list, the number
-        // of entries above it -- one binary search per list in LDS (keys are unique: ranks are too).  Candidates whose
-        // running rank reaches K drop out at once.  (The 66-stage bitonic sort this replaces: 16 -> ~6 us per call.)
-        __shared__ uint64_t pool2[kPool];
-        for (int i = threadIdx.x; i < n; i += kThreads) pool2[i] = key2(i);
-        __syncthreads();
-        for (int i = threadIdx.x; i < n; i += kThreads) {
-            const uint64_t key = pool2[i];
-            const int c = i / K;
-            int rank = i - c * K;
-            for (int cc = 0; cc < C && rank < K; ++cc) {
-                if (cc == c) continue;
-                const uint64_t* list = pool2 + cc * K;
-                int lo = 0, hi = K;                       // first position whose key is below `key`
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (list[mid] > key) lo = mid + 1; else hi = mid;
-                }
-                rank += lo;
+    if (lds_cand) {
+        // one pipelined pass over the candidates (16-byte loads, four in flight per thread): the selection below reads
+        // every key three to five times and the box assembly once more, each a dependent trip to L2 otherwise
+        const int n2 = n >> 1;                        // cb is 16-byte aligned (256-byte workspace base, n * 8 per image
+        const bool aligned = (((size_t)b * n) & 1) == 0;   // ... when b * n is even)
+        if (aligned) {
+            const uint4* src = reinterpret_cast<const uint4*>(cb);
+            uint4* dst4 = reinterpret_cast<uint4*>(cand_lds);
+            for (int i = threadIdx.x; i < n2; i += 4 * kThreads) {
+                uint4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = src[min(i + u * kThreads, n2 - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i + u * kThreads < n2) dst4[i + u * kThreads] = t[u];
             }
-            if (rank < K) s.sel[rank] = key;
+            if ((n & 1) && threadIdx.x == 0) cand_lds[n - 1] = cb[n - 1];
+        } else {
+            for (int i = threadIdx.x; i < n; i += kThreads) cand_lds[i] = cb[i];
         }
         __syncthreads();
-    } else {
-        block_topk<kThreads>(key2, n, K, KP, s);
+    }
+    // (the body twice, so that each copy knows its address space: LDS reads or global loads, not flat ones)
+    auto body = [&](const uint64_t* __restrict__ cb) {
+    // second-stage key: same score bits, position c*K+rank as the index
+    auto key2 = [&](int i) { return (cb[i] & 0xffffffff00000000ull) | (uint64_t)(0xffffffffu - (uint32_t)i); };
+    // the same selection as stage 1, from the sign bit down (candidates of a map with fewer than K positive scores are
+    // zero or, outside the reference's use, negative)
+    {
+        __shared__ int hist[kBins];
+        __shared__ int wave_tot[kThreads / 64];
+        if (!merge_select<kThreads>(key2, n, K, hist, wave_tot, s)) block_topk<kThreads>(key2, n, K, KP, s);
     }
     const int ncol = rotated ? 7 : 6;
     for (int k = threadIdx.x; k < K; k += kThreads) {
@@ -592,6 +666,9 @@ __global__ __launch_bounds__(kThreads) void merge_decode_kernel(
         }
         if (inds) inds[(size_t)b * K + k] = (int64_t)idx;
     }
+    };
+    if (lds_cand) body(cand_lds);
+    else body(cb);
 }
 
 int next_pow2(int v) {
@@ -647,13 +724,18 @@ extern "C" int cnuda_decode_detection(const float* heat, const float* wh, const 
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(plane_topk_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_decode_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL(plane_topk_kernel, dim3(B * C), dim3(kPlaneThreads), lds_plane ? bits_bytes : 0, st, heat, cand,
                        H, W, K, KP, pad, lds_plane);
     int rc = check_launch("cnuda_decode_detection(stage 1)");
     if (rc) return rc;
-    hipLaunchKernelGGL(merge_decode_kernel, dim3(B), dim3(kThreads), 0, st,
-                       cand, wh, reg, dets, inds, C, H, W, K, KP, wh_ch, rotated ? 1 : 0);
+    // stage 2 keeps an image's C*K candidates in LDS when they fit beside its 30 KB of static arrays
+    const size_t cand_bytes = (size_t)C * K * sizeof(uint64_t);
+    const int lds_cand = cand_bytes <= 120 * 1024 ? 1 : 0;
+    hipLaunchKernelGGL(merge_decode_kernel, dim3(B), dim3(kThreads), lds_cand ? cand_bytes : 0, st,
+                       cand, wh, reg, dets, inds, C, H, W, K, KP, wh_ch, rotated ? 1 : 0, lds_cand);
     return check_launch("cnuda_decode_detection(stage 2)");
 }
