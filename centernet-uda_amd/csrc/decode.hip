@@ -40,69 +40,67 @@ struct SelectScratch {
     int remaining;       // how many keys are still to be taken from the current bucket
     int done;
     int out_count;
-    int ranks[kMaxK];                  // rank_sort_desc's counters
     uint64_t sel[kMaxK + kSelSlack];   // selected keys (+ rank_sort_desc's zero padding)
 };
 
 // Sorts n <= NT unique keys s.sel[0..n) descending, in place, by counting.  The compare matrix is tiled: a thread
-// keeps kSortKeys keys in registers and streams every P-th key of the array past them (P = threads per key block;
-// eight independent LDS reads per batch, the lanes of one part read one address, neighbouring parts neighbouring
-// banks), then adds its counts to s.ranks with LDS atomics; a key's rank is its final position.  n * n / NT compares
-// and n * n / (kSortKeys * NT) LDS reads per thread, two barriers -- a bitonic network over pow2(n) keys takes log^2
-// stages with a workgroup barrier each (36 for 256 keys).  With `out` the keys of rank < K go straight to out[rank]
-// (global memory) instead.  rank_sort_prepare (any time after n is known and before the barrier that publishes the
-// keys) clears the counters and pads the keys with zeros up to the end of the last batch.
+// keeps kSortKeys keys in registers and streams every P-th key of the array past them (P, a power of two <= 64, threads
+// per block of kSortKeys keys: adjacent lanes of one wave; eight independent LDS reads per batch, the lanes of one part
+// read one address, neighbouring parts neighbouring banks); the P partial counts are added with shuffles and a key's
+// rank is its final position.  n * n / NT compares and n * n / (kSortKeys * NT) LDS reads per thread and, in place, two
+// barriers -- a bitonic network over pow2(n) keys takes log^2 stages with a workgroup barrier each (36 for 256 keys).
+// With `out` the keys of rank < K go straight to out[rank] (global memory), without any barrier.  The keys must be
+// followed by zeros up to the end of the last batch: rank_sort_prepare, any time after n is known and before the
+// barrier that publishes the keys.
 constexpr int kSortKeys = 4, kSortBatch = 8;
 template <int NT>
-__device__ __forceinline__ int rank_sort_threads(int n) {           // per block of kSortKeys keys
-    return min(NT / ((max(n, 1) + kSortKeys - 1) / kSortKeys), kSelSlack);
+__device__ __forceinline__ int rank_sort_shift(int n) {             // log2(threads per block of kSortKeys keys)
+    const int blocks = (max(n, 1) + kSortKeys - 1) / kSortKeys;
+    int sh = 0;
+    while (sh < 6 && (blocks << (sh + 1)) <= NT) ++sh;
+    return sh;
 }
 template <int NT>
 __device__ __forceinline__ void rank_sort_prepare(SelectScratch& s, int n) {
-    static_assert(kSortBatch * kSelSlack <= kMaxK && kSortBatch * kSortKeys * NT / kMaxK <= kSelSlack, "padding fits");
-    const int P = rank_sort_threads<NT>(n);
-    for (int i = threadIdx.x; i < n; i += NT) s.ranks[i] = 0;
+    static_assert(kMaxK + kSortBatch * (kSortKeys * NT / kMaxK) <= kMaxK + kSelSlack && kSortBatch * 64 <= kMaxK,
+                  "the zero padding fits s.sel");
+    const int P = 1 << rank_sort_shift<NT>(n);
     for (int i = n + threadIdx.x; i < n + kSortBatch * P; i += NT) s.sel[i] = 0;
 }
 template <int NT>
 __device__ __forceinline__ void rank_sort_desc(SelectScratch& s, int n, uint64_t* __restrict__ out = nullptr, int K = 0) {
     const int tid = threadIdx.x;
-    const int P = rank_sort_threads<NT>(n);
-    const int qb = tid / P, part = tid - qb * P;
-    const int q0 = qb * kSortKeys;
+    const int sh = rank_sort_shift<NT>(n), P = 1 << sh;
+    const int q0 = (tid >> sh) * kSortKeys, part = tid & (P - 1);
     uint64_t key[kSortKeys];
     int rank[kSortKeys];
 #pragma unroll
-    for (int r = 0; r < kSortKeys; ++r) { key[r] = q0 + r < n ? s.sel[q0 + r] : ~0ull; rank[r] = 0; }
-    if (q0 < n) {
-        for (int j = part; j < n; j += kSortBatch * P) {
-            uint64_t x[kSortBatch];
+    for (int r = 0; r < kSortKeys; ++r) { key[r] = s.sel[min(q0 + r, kMaxK - 1)]; rank[r] = 0; }
+    for (int j = part; j < n; j += kSortBatch * P) {                 // (threads without keys run along: shuffles below)
+        uint64_t x[kSortBatch];
 #pragma unroll
-            for (int u = 0; u < kSortBatch; ++u) x[u] = s.sel[j + u * P];
+        for (int u = 0; u < kSortBatch; ++u) x[u] = s.sel[j + u * P];
 #pragma unroll
-            for (int u = 0; u < kSortBatch; ++u)
+        for (int u = 0; u < kSortBatch; ++u)
 #pragma unroll
-                for (int r = 0; r < kSortKeys; ++r) rank[r] += x[u] > key[r] ? 1 : 0;
-        }
-#pragma unroll
-        for (int r = 0; r < kSortKeys; ++r)
-            if (rank[r]) atomicAdd(&s.ranks[q0 + r], rank[r]);
+            for (int r = 0; r < kSortKeys; ++r) rank[r] += x[u] > key[r] ? 1 : 0;
     }
-    __syncthreads();
+    for (int o = 1; o < P; o <<= 1)
+#pragma unroll
+        for (int r = 0; r < kSortKeys; ++r) rank[r] += __shfl_xor(rank[r], o, 64);
     if (out) {
         if (part == 0) {
 #pragma unroll
-            for (int r = 0; r < kSortKeys; ++r) {
-                const int at = q0 + r < n ? s.ranks[q0 + r] : K;
-                if (at < K) out[at] = key[r];
-            }
+            for (int r = 0; r < kSortKeys; ++r)
+                if (q0 + r < n && rank[r] < K) out[rank[r]] = key[r];
         }
         return;
     }
+    __syncthreads();
     if (part == 0) {
 #pragma unroll
         for (int r = 0; r < kSortKeys; ++r)
-            if (q0 + r < n) s.sel[s.ranks[q0 + r]] = key[r];
+            if (q0 + r < n) s.sel[rank[r]] = key[r];
     }
     __syncthreads();
 }
@@ -365,20 +363,28 @@ __device__ void lds_plane_topk(const uint32_t* __restrict__ bits, int n, int K, 
 // pass, the atomics spread over the bins), a suffix scan for the bin that holds the K-th largest key, and a rank sort
 // of the keys at or above that bin -- a couple of hundred at most on any real map.  When more than kMaxK keys share
 // that bin (plateaus) or fewer than K keys were counted, the exact radix selects above take over.
-constexpr int kBins = 4096;
-// scans hist[0..kBins) from the top bin down with NT = kBins / 4 threads.  Returns through LDS (uniform values): the bin
-// of the K-th largest counted key, the number of keys at or above it (INT_MAX when fewer than K keys were counted).
-template <int NT>
+constexpr int kBins = 4096;          // stage 1: 12 bits below the sign
+constexpr int kBins2 = 8192;         // stage 2: 13 bits from the sign down (its LDS has the room)
+// scans hist[0..NT * BPT) from the top bin down, BPT bins per thread.  Returns through LDS (uniform values): the bin of
+// the K-th largest counted key, the number of keys at or above it (INT_MAX when fewer than K keys were counted).
+template <int NT, int BPT>
 __device__ __forceinline__ void hist_threshold(const int* __restrict__ hist, int K, int* __restrict__ wave_tot,
                                                int& bin, int& nsel) {
-    static_assert(NT * 4 == kBins, "four bins per thread");
+    static_assert(BPT % 4 == 0, "16-byte reads");
     __shared__ int thr_bin, thr_sel;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) { thr_bin = 0; thr_sel = 0x7fffffff; }
-    // thread t owns bins 4 * (NT - 1 - t) .. + 3: the inclusive scan over t counts the keys from the top bin down
-    const int bin_base = (NT - 1 - tid) * 4;
-    const int4 c = reinterpret_cast<const int4*>(hist)[NT - 1 - tid];
-    const int local = c.x + c.y + c.z + c.w;
+    // thread t owns bins BPT * (NT - 1 - t) .. + BPT - 1: the inclusive scan over t counts the keys from the top bin down
+    const int bin_base = (NT - 1 - tid) * BPT;
+    int c[BPT];
+#pragma unroll
+    for (int g = 0; g < BPT / 4; ++g) {
+        const int4 t = reinterpret_cast<const int4*>(hist + bin_base)[g];
+        c[4 * g] = t.x; c[4 * g + 1] = t.y; c[4 * g + 2] = t.z; c[4 * g + 3] = t.w;
+    }
+    int local = 0;
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) local += c[j];
     int incl = local;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -390,11 +396,10 @@ __device__ __forceinline__ void hist_threshold(const int* __restrict__ hist, int
     int acc = incl - local;
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) acc += w < wid ? wave_tot[w] : 0;
-    const int cs[4] = {c.w, c.z, c.y, c.x};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (acc < K && K <= acc + cs[j]) { thr_bin = bin_base + 3 - j; thr_sel = acc + cs[j]; }
-        acc += cs[j];
+    for (int j = BPT - 1; j >= 0; --j) {
+        if (acc < K && K <= acc + c[j]) { thr_bin = bin_base + j; thr_sel = acc + c[j]; }
+        acc += c[j];
     }
     __syncthreads();
     bin = thr_bin;
@@ -402,39 +407,41 @@ __device__ __forceinline__ void hist_threshold(const int* __restrict__ hist, int
 }
 
 // Stage 2's selection: the K largest of the n unique keys key_at(0..n), sorted, by threshold + rank sort.  Up to three
-// histogram levels of 12 key bits each, from the sign bit down: a level whose K-th-key bin leaves more than kRankMax
-// keys selected is refined inside that bin by the next 12 bits.  The keys are a concatenation of SORTED lists (stage
+// histogram levels of 13 key bits each, from the sign bit down: a level whose K-th-key bin leaves more than kRankMax
+// keys selected is refined inside that bin by the next 13 bits.  The keys are a concatenation of SORTED lists (stage
 // 1's output), so equal digits come in runs: a run adds its length to its bin with two atomics -- minus its first index
 // at the head, plus its last index + 1 at the tail -- instead of one contended atomic per key.  On success s.sel[0..K)
 // holds the K largest keys in descending order; false (nothing written) when fewer than K keys exist or more than
-// kMaxK keys still tie after 36 bits -- block_topk handles those.
+// kMaxK keys still tie after 39 bits -- block_topk handles those.
 constexpr int kRankMax = 512;
 template <int NT, typename KeyAt>
 __device__ __forceinline__ bool merge_select(KeyAt key_at, int n, int K, int* __restrict__ hist,
                                              int* __restrict__ wave_tot, SelectScratch& s) {
     const int tid = threadIdx.x, lane = tid & 63;
     uint64_t mask = 0, prefix = 0;                    // leading bits decided so far, and their value at the threshold
-    int need = K, taken = 0, nsel = 0, shift = 52;
+    int need = K, taken = 0, nsel = 0, shift = 51;
+    constexpr int kDigit = kBins2 - 1, kBPT = kBins2 / NT;
     bool found = false;
     if (tid == 0) s.out_count = 0;
-    for (int level = 0; level < 3 && !found; ++level, shift -= 12) {
-        reinterpret_cast<int4*>(hist)[tid] = make_int4(0, 0, 0, 0);
+    for (int level = 0; level < 3 && !found; ++level, shift -= 13) {
+#pragma unroll
+        for (int g = 0; g < kBPT / 4; ++g) reinterpret_cast<int4*>(hist)[g * NT + tid] = make_int4(0, 0, 0, 0);
         __syncthreads();
         for (int i = tid; i < n; i += NT) {
             const uint64_t k = key_at(i);
             if ((k & mask) != prefix) continue;
-            const int d = (int)(k >> shift) & 0xfff;
+            const int d = (int)(k >> shift) & kDigit;
             const uint64_t kp = i > 0 ? key_at(i - 1) : 0, kn = i + 1 < n ? key_at(i + 1) : 0;
-            const bool head = !(i > 0 && (kp & mask) == prefix && ((int)(kp >> shift) & 0xfff) == d);
-            const bool tail = !(i + 1 < n && (kn & mask) == prefix && ((int)(kn >> shift) & 0xfff) == d);
+            const bool head = !(i > 0 && (kp & mask) == prefix && ((int)(kp >> shift) & kDigit) == d);
+            const bool tail = !(i + 1 < n && (kn & mask) == prefix && ((int)(kn >> shift) & kDigit) == d);
             if (head || tail) atomicAdd(&hist[d], (tail ? i + 1 : 0) - (head ? i : 0));
         }
         __syncthreads();
         int tb, cnt;
-        hist_threshold<NT>(hist, need, wave_tot, tb, cnt);
+        hist_threshold<NT, kBPT>(hist, need, wave_tot, tb, cnt);
         if (cnt == 0x7fffffff) return false;
         const int at_tb = hist[tb];
-        mask |= 0xfffull << shift;
+        mask |= (uint64_t)kDigit << shift;
         prefix |= (uint64_t)tb << shift;
         nsel = taken + cnt;
         found = nsel <= (level == 2 ? kMaxK : kRankMax);
@@ -536,7 +543,7 @@ __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* 
     __syncthreads();
     // C
     int tb, nsel;
-    hist_threshold<kPlaneThreads>(hist, K, wave_tot, tb, nsel);
+    hist_threshold<kPlaneThreads, kBins / kPlaneThreads>(hist, K, wave_tot, tb, nsel);
     if (nsel <= kMaxK && tb > 0) {
         // D: "bin >= tb" is one float compare against the bin's lower edge (bin 0 -- subnormal scores -- is left to the
         // general path); a wave takes its slots in s.sel with one atomic: the rank sort does not care about the order
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(kThreads) void merge_decode_kernel(
     // the same selection as stage 1, from the sign bit down (candidates of a map with fewer than K positive scores are
     // zero or, outside the reference's use, negative)
     {
-        __shared__ int hist[kBins];
+        __shared__ int hist[kBins2];
         __shared__ int wave_tot[kThreads / 64];
         if (!merge_select<kThreads>(key2, n, K, hist, wave_tot, s)) block_topk<kThreads>(key2, n, K, KP, s);
     }
@@ -725,16 +732,16 @@ extern "C" int cnuda_decode_detection(const float* heat, const float* wh, const 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(plane_topk_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_decode_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL(plane_topk_kernel, dim3(B * C), dim3(kPlaneThreads), lds_plane ? bits_bytes : 0, st, heat, cand,
                        H, W, K, KP, pad, lds_plane);
     int rc = check_launch("cnuda_decode_detection(stage 1)");
     if (rc) return rc;
-    // stage 2 keeps an image's C*K candidates in LDS when they fit beside its 30 KB of static arrays
+    // stage 2 keeps an image's C*K candidates in LDS when they fit beside its 42 KB of static arrays
     const size_t cand_bytes = (size_t)C * K * sizeof(uint64_t);
-    const int lds_cand = cand_bytes <= 120 * 1024 ? 1 : 0;
+    const int lds_cand = cand_bytes <= 112 * 1024 ? 1 : 0;
     hipLaunchKernelGGL(merge_decode_kernel, dim3(B), dim3(kThreads), lds_cand ? cand_bytes : 0, st,
                        cand, wh, reg, dets, inds, C, H, W, K, KP, wh_ch, rotated ? 1 : 0, lds_cand);
     return check_launch("cnuda_decode_detection(stage 2)");

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 --kernel-trace --stats directly on a decode-only run (120 calls per map shape)
+# rocprofv3 --kernel-trace --stats directly on a decode-only run (140 calls per map shape)
 #   gpurun -- 'bash profiles/collect_decode_stats.sh r3'  ->  gpurun_out/<tag>_decode_kernel_stats.csv
 TAG=${1:-rX}
 cd /tmp && export TMPDIR=/tmp

@@ -19,10 +19,14 @@ for C, H in cases:
     for _ in range(20):
         decode_detection(heat, wh, reg, K=K)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(100):
-        decode_detection(heat, wh, reg, K=K)
-    e1.record()
-    torch.cuda.synchronize()
-    print('C=%d %dx%d: %.1f us per call' % (C, H, H, e0.elapsed_time(e1) * 10))
+    groups = []
+    for _ in range(5):                 # median of five groups (host hiccups land in one group, not in the figure)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(24):
+            decode_detection(heat, wh, reg, K=K)
+        e1.record()
+        torch.cuda.synchronize()
+        groups.append(e0.elapsed_time(e1) * 1e3 / 24)
+    print('C=%d %dx%d: %.1f us per call' % (C, H, H, sorted(groups)[2]))

@@ -93,7 +93,7 @@ if cfgs:
 dk = path('%s_decode_kernel_stats.csv' % TAG)
 if dk:
     out.append('Decode-only kernel stats (`profiles/collect_decode_stats.sh`: rocprofv3 --kernel-trace --stats on '
-               '`profiles/decode_only.py`, 120 calls per map shape: C=6 / C=80 at 128x128 and 160x160 mixed):\n')
+               '`profiles/decode_only.py`, 140 calls per map shape: C=6 / C=80 at 128x128 and 160x160 mixed):\n')
     out.append('| kernel | calls | avg us | min us | max us |\n|---|---|---|---|---|')
     for r in csv.DictReader(open(dk)):
         out.append('| `%s` | %s | %.1f | %.1f | %.1f |' % (short(r['Name'])[:60], r['Calls'], float(r['AverageNs']) / 1e3,
