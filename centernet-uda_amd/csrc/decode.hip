@@ -223,6 +223,28 @@ __device__ __forceinline__ void nms_quad(const float* __restrict__ plane, int H,
     }
 }
 
+// The same from a plane in LDS, addressed by the quad's pixel index i (x0 = i % W): the rows above and below are i -/+ W
+// unless the quad sits in the first / last row, the edge columns i - 1 and i + 4 unless it starts / ends its row.
+__device__ __forceinline__ void nms_quad_lds(const float* __restrict__ p, int i, int x0, int W, int HW, float (&out)[4]) {
+    const int rows[3] = {i >= W ? i - W : i, i, i < HW - W ? i + W : i};
+    const int lo = x0 == 0 ? 0 : -1, hi = x0 + 4 == W ? 3 : 4;
+    float col[6];
+    float mid[4];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float4 c = *reinterpret_cast<const float4*>(p + rows[d]);
+        const float v[6] = {p[rows[d] + lo], c.x, c.y, c.z, c.w, p[rows[d] + hi]};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) col[j] = d == 0 ? v[j] : fmaxf(col[j], v[j]);
+        if (d == 1) { mid[0] = c.x; mid[1] = c.y; mid[2] = c.z; mid[3] = c.w; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float m = fmaxf(fmaxf(col[j], col[j + 1]), col[j + 2]);
+        out[j] = mid[j] * (1.0f - ceilf(m - mid[j]));          // decode.py:12, see nms_value
+    }
+}
+
 __global__ void nms_kernel(const float* __restrict__ heat, float* __restrict__ out,
                            long long planes, int H, int W, int pad) {
     const long long total = planes * H * W;
@@ -385,12 +407,15 @@ __device__ __forceinline__ void hist_threshold(const int* __restrict__ hist, int
     int local = 0;
 #pragma unroll
     for (int j = 0; j < BPT; ++j) local += c[j];
+    // inclusive scan over the wave in the data-parallel-primitive network: shifts inside the rows of 16, then the last
+    // lane of row 0 / 2 into row 1 / 3 and lane 31 into rows 2 and 3
     int incl = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);      // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);      // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);      // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);      // row_shr:8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
     if (lane == 63) wave_tot[wid] = incl;
     __syncthreads();
     int acc = incl - local;
@@ -518,13 +543,17 @@ __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* 
     // pixel of v[u]: quads -- thread owns quads of consecutive pixels, v[4*q + j] <-> (q * NT + tid) * 4 + j
     auto pixel = [&](int u) { return quads ? ((u >> 2) * kPlaneThreads + tid) * 4 + (u & 3) : u * kPlaneThreads + tid; };
     const int rounds = (HW + 4 * kPlaneThreads - 1) / (4 * kPlaneThreads);   // groups of 4 registers in use (uniform)
+    int x0 = (tid * 4) % W;                           // column of the thread's quad; the next one is 4 * NT pixels on
+    const int x_step = (4 * kPlaneThreads) % W;
 #pragma unroll
     for (int q = 0; q < kPlanePer / 4; ++q) {
         float o[4] = {0.f, 0.f, 0.f, 0.f};
         if (q < rounds) {
             if (quads) {
                 const int i = (q * kPlaneThreads + tid) * 4;
-                if (i < HW) { const int y = i / W; nms_quad(plane_lds, H, W, y, i - y * W, o); }
+                if (i < HW) nms_quad_lds(plane_lds, i, x0, W, HW, o);
+                x0 += x_step;
+                x0 -= x0 >= W ? W : 0;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
