@@ -166,8 +166,11 @@ class BasicBlock(nn.Module):
     _fold = None
 
     def fold_batchnorm_(self):
+        import hip_runtime as hr
         self._fold = _folded(self.conv1.weight, None, self.bn1) + _folded(self.conv2.weight, None, self.bn2)
         _fold_stamp(self)
+        if not hasattr(self, '_fold_token2'):          # one identity per folded weight: two of one shape under one
+            self._fold_token2 = hr.new_pack_token()    # token would keep taking over each other's packed image
 
     def forward(self, x, residual=None):
         if _use_folded(self):
@@ -175,7 +178,7 @@ class BasicBlock(nn.Module):
             y = ops.conv2d_infer(x, w1, b1, self.conv1.stride, self.conv1.padding, 0.0, None, self._fold_token,
                                  self._fold_gen)
             # conv2 + BatchNorm + skip connection + ReLU in one launch (dla.py:48-62)
-            return ops.conv2d_infer(y, w2, b2, 1, 1, 0.0, x if residual is None else residual, self._fold_token,
+            return ops.conv2d_infer(y, w2, b2, 1, 1, 0.0, x if residual is None else residual, self._fold_token2,
                                     self._fold_gen)
         y = self.bn1(self.conv1(x), relu=True)
         return self.bn2(self.conv2(y), residual=x if residual is None else residual, relu=True)

@@ -2,6 +2,7 @@
 // slab reduction, per-channel sums.
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -158,6 +159,7 @@ std::unordered_map<PackKey, PackSlot, PackKeyHash> g_pack_slots;
 char* g_pack_arena = nullptr;
 size_t g_pack_arena_bytes = 0, g_pack_arena_used = 0;
 uint64_t g_pack_generation = 0;               // bumped when a slot is added (the refresh table is rebuilt then)
+std::atomic<unsigned long long> g_pack_fills{0};   // cached images (re)written on a convolution's own call
 thread_local uint64_t g_pack_token = 0, g_pack_version = 0;
 
 // -> cached slot to use (fill == true: pack into it first), or nullptr: use the workspace
@@ -193,6 +195,7 @@ float* pack_slot(const PackKey& key, size_t bytes, bool& fill, int cpad = 0, con
     it->second.cpad = cpad;
     if (taps) { it->second.ntaps = taps->n; for (int i = 0; i < 9; ++i) it->second.taps[i] = taps->tap[i]; }
     fill = it->second.version != g_pack_version;
+    if (fill) ++g_pack_fills;
     it->second.version = g_pack_version;
     return reinterpret_cast<float*>(g_pack_arena + it->second.offset);
 }
@@ -363,3 +366,4 @@ extern "C" int cnuda_pack_stamp(unsigned long long token, unsigned long long ver
     return 0;
 }
 extern "C" size_t cnuda_pack_cache_used(void) { return cnuda::g_pack_arena_used; }
+extern "C" unsigned long long cnuda_pack_cache_fills(void) { return cnuda::g_pack_fills.load(); }

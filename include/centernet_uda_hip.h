@@ -55,10 +55,12 @@ int cnuda_get_matrix_mode(void);
  * names the weights that call will pack: `token` identifies their owner (0 = anonymous: never cached), `version`
  * changes whenever their values may have changed.  A slot is reused iff the same token packed the same source
  * buffer to the same image before and the version is unchanged; the stamp stays in force until the next
- * cnuda_pack_stamp on that thread (callers reset it to (0, 0) after the call).  cnuda_pack_cache_used: bytes taken. */
+ * cnuda_pack_stamp on that thread (callers reset it to (0, 0) after the call).  cnuda_pack_cache_used: bytes taken;
+ * cnuda_pack_cache_fills: how often a cached image was (re)written on a convolution's own call (steady state: 0 per call). */
 int cnuda_pack_cache_attach(void* arena, size_t bytes);
 int cnuda_pack_stamp(unsigned long long token, unsigned long long version);
 size_t cnuda_pack_cache_used(void);
+unsigned long long cnuda_pack_cache_fills(void);
 /* After an optimizer step that rewrote [params, params + params_bytes) behind the callers' version counters: every
  * cached image whose source lies in that range and that was current in epoch `old_epoch` (the high 32 bits of the
  * version it was stamped with) is rebuilt by ONE launch on `stream` and re-stamped with `new_epoch` (low 32 bits

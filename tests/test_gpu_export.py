@@ -170,3 +170,26 @@ def test_folded_weights_follow_running_statistics_re_estimated_without_an_optimi
             got = backend(x)
     for k in want:
         assert (got[k] - want[k]).abs().max().item() <= 1e-4 * want[k].abs().max().item(), k
+
+
+def test_steady_state_inference_packs_no_weight(golden):
+    """Every folded weight has its own identity in the library's pack cache: after the first call of the wrapper no
+    cached weight image is written again (the two 3x3 convolutions of a BasicBlock have one shape; under one token they
+    took over each other's slot on every call: 20 pack launches per forward)."""
+    import hip_runtime as hr
+    from backends import dla
+    from export import CenterNet
+    g = golden('dla_axis')
+    shapes = dict(ast.literal_eval(str(g['shapes_json'])))
+    backend = dla.build(num_classes=6)
+    backend.load_state_dict({k: T(v) for k, v in gin.fill_state(shapes, 0.3).items()})
+    backend = backend.to(DEV).eval()
+    x = T(gin.image_batch(2, 128, 128, 96)).to(DEV)
+    model = CenterNet(backend, 30).eval()
+    first = model(x)
+    model(x)
+    fills, used = hr.lib().cnuda_pack_cache_fills(), hr.lib().cnuda_pack_cache_used()
+    again = model(x)
+    torch.cuda.synchronize()
+    assert hr.lib().cnuda_pack_cache_fills() == fills and hr.lib().cnuda_pack_cache_used() == used
+    assert all(torch.equal(a, b) for a, b in zip(first, again))
