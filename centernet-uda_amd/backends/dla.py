@@ -411,7 +411,7 @@ class DLASeg(nn.Module):
         self.heads = dict(heads)
         for head, classes in self.heads.items():
             if head_conv > 0:
-                fc = nn.Sequential(
+                fc = hnn.Head(
                     hnn.Conv2d(channels[self.first_level], head_conv, 3, padding=1, bias=True, act_slope=0.0),
                     hnn.Slot(),     # index of the reference's nn.ReLU (fused into conv '0')
                     hnn.Conv2d(head_conv, classes, final_kernel, padding=final_kernel // 2, bias=True))

@@ -125,7 +125,7 @@ class CenterMobileNetV2(nn.Module):
                 setattr(self, "skip_%d" % deconv_id, hnn.Conv2d(in_channels, out_channels, 1, padding=0))
         self.heads = heads
         for head in sorted(self.heads):
-            fc = nn.Sequential(
+            fc = hnn.Head(
                 hnn.Conv2d(256, head_conv, 3, padding=1, bias=True, act_slope=0.0),
                 hnn.Slot(),      # index of the reference's nn.ReLU (fused into conv '0')
                 hnn.Conv2d(head_conv, self.heads[head], 1, bias=True))

@@ -138,7 +138,7 @@ class CenterResNet(nn.Module):
         self.deconv_layers = self._make_deconv_layer(3, [256, 256, 256], [4, 4, 4])
         self.heads = heads
         for head in sorted(self.heads):
-            fc = nn.Sequential(
+            fc = hnn.Head(
                 hnn.Conv2d(256, head_conv, 3, padding=1, bias=True, act_slope=0.0),
                 hnn.Slot(),      # index of the reference's nn.ReLU (fused into conv '0')
                 hnn.Conv2d(head_conv, self.heads[head], 1, bias=True))

@@ -321,6 +321,35 @@ __global__ void act_bwd_kernel(const float* __restrict__ gy, const float* __rest
          i += (long long)gridDim.x * blockDim.x)
         gx[i] = y[i] > 0.0f ? gy[i] : gy[i] * slope;
 }
+// The input gradient of a 1x1 convolution with a handful of output channels (a detection head's last layer,
+// dla.py:474-483: 256 -> classes / 2 / 2) fused with the backward of the activation in front of it:
+//   gh[b][m][p] = (hid[b][m][p] > 0 ? 1 : slope) * sum_c w[c][m] * go[b][c][p]            (c in increasing order)
+// K = CO <= 8 is no GEMM: the kernel is one read of the hidden map (for the gate) and one write of its gradient, the
+// CO gradient planes of a pixel quad stay in registers across the channel loop and the weights are scalar loads.
+// grid (quads of pixels / kT, channel chunks, B)
+template <int CO>
+__global__ __launch_bounds__(kT) void conv1x1_dgrad_act_kernel(const float* __restrict__ go, const float* __restrict__ w,
+                                                               const float* __restrict__ hid, float* __restrict__ gh,
+                                                               int Ch, int ch_chunk, long long HW, float slope) {
+    const long long q = (long long)blockIdx.x * kT + threadIdx.x;
+    if (q * 4 >= HW) return;
+    const int b = blockIdx.z, m0 = blockIdx.y * ch_chunk, m1 = min(m0 + ch_chunk, Ch);
+    float4 g[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) g[c] = *reinterpret_cast<const float4*>(go + ((size_t)b * CO + c) * HW + q * 4);
+    for (int m = m0; m < m1; ++m) {
+        const size_t at = ((size_t)b * Ch + m) * HW + q * 4;
+        const float4 h = *reinterpret_cast<const float4*>(hid + at);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            const float wc = w[(size_t)c * Ch + m];
+            o.x += wc * g[c].x; o.y += wc * g[c].y; o.z += wc * g[c].z; o.w += wc * g[c].w;
+        }
+        *reinterpret_cast<float4*>(gh + at) = make_float4(h.x > 0.0f ? o.x : o.x * slope, h.y > 0.0f ? o.y : o.y * slope,
+                                                          h.z > 0.0f ? o.z : o.z * slope, h.w > 0.0f ? o.w : o.w * slope);
+    }
+}
 // Row-wise kernels: grid (chunks of a row, rows); a row is one (image, channel) plane of HW floats, so the
 // channel bookkeeping is per workgroup and the inner loop is 16-byte copies when HW % 4 == 0.
 // copy a [B, Cn, HW] block between tensors with Csrc / Cdst channels at channel offsets
@@ -653,6 +682,29 @@ extern "C" int cnuda_act_backward(const float* grad_y, const float* y, float* gr
     hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(n, kT)), dim3(kT), 0, (hipStream_t)stream, grad_y, y, grad_x, n,
                        slope);
     return check_launch("cnuda_act_backward");
+}
+extern "C" int cnuda_conv1x1_backward_data_act(const float* grad_y, const float* weight, const float* hidden,
+                                               float* grad_hidden, int B, int Co, int Ch, long long HW, float slope,
+                                               cnuda_stream_t stream) {
+    CNUDA_REQUIRE(grad_y && weight && hidden && grad_hidden && B > 0 && Ch > 0 && HW > 0,
+                  "cnuda_conv1x1_backward_data_act: bad arguments");
+    CNUDA_REQUIRE(Co >= 1 && Co <= 8, "cnuda_conv1x1_backward_data_act: %d output channels (1..8 are built)", Co);
+    CNUDA_REQUIRE((HW & 3) == 0 && B <= 65535, "cnuda_conv1x1_backward_data_act: plane size %lld not a multiple of 4",
+                  HW);
+    // enough workgroups for the chip: channel chunks of >= 32 until there are ~2048
+    const long long quads = ceil_div(HW / 4, kT);
+    int chunks = 1;
+    while (chunks * 2 * 32 <= Ch && quads * B * chunks < 2048) chunks *= 2;
+    const int ch_chunk = (int)ceil_div(Ch, chunks);
+    const dim3 grid((unsigned)quads, (unsigned)ceil_div(Ch, ch_chunk), (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+#define CNUDA_C1(CO) case CO: hipLaunchKernelGGL(conv1x1_dgrad_act_kernel<CO>, grid, dim3(kT), 0, st, grad_y, weight, \
+                                                  hidden, grad_hidden, Ch, ch_chunk, HW, slope); break
+    switch (Co) {
+        CNUDA_C1(1); CNUDA_C1(2); CNUDA_C1(3); CNUDA_C1(4); CNUDA_C1(5); CNUDA_C1(6); CNUDA_C1(7); CNUDA_C1(8);
+    }
+#undef CNUDA_C1
+    return check_launch("cnuda_conv1x1_backward_data_act");
 }
 extern "C" int cnuda_copy_channels(const float* src, float* dst, int B, int Cn, long long HW, int Csrc, int src_off,
                                    int Cdst, int dst_off, cnuda_stream_t stream) {

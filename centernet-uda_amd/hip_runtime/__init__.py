@@ -90,6 +90,7 @@ class _Sig:
     cnuda_dwconv2d_backward = (_I, [_P] * 5 + [_I] * 7 + _WS)
     cnuda_add = (_I, [_P] * 3 + [_LL, _P])
     cnuda_act_backward = (_I, [_P] * 3 + [_LL, _F, _P])
+    cnuda_conv1x1_backward_data_act = (_I, [_P] * 4 + [_I] * 3 + [_LL, _F, _P])
     cnuda_copy_channels = (_I, [_P, _P, _I, _I, _LL, _I, _I, _I, _I, _P])
     cnuda_split_offset_mask = (_I, [_P] * 3 + [_I, _I, _LL, _P])
     cnuda_split_offset_mask_backward = (_I, [_P] * 4 + [_I, _I, _LL, _P])

@@ -95,6 +95,19 @@ class ConvTranspose2d(nn.Module):
         return ops.conv_transpose2d(x, self.weight, self.stride, self.padding, self.output_padding)
 
 
+class Head(nn.Sequential):
+    """A detection head: Conv2d(+ReLU), Slot (the index of the reference's nn.ReLU), Conv2d -- the reference's
+    `nn.Sequential(nn.Conv2d(C, head_conv, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(head_conv, classes, 1))`
+    (dla.py:474-483) with the same state_dict keys ('0.weight', '2.weight', ...).  While a tape is recorded the pair
+    is one node (ops.conv_act_conv1x1: the hidden map's gradient in one pass); otherwise the layers run in turn."""
+
+    def forward(self, x):
+        if len(self) == 3 and isinstance(self[0], Conv2d) and isinstance(self[2], Conv2d) \
+                and ops.conv_act_conv1x1_supported(x, self[0], self[2]):
+            return ops.conv_act_conv1x1(x, self[0], self[2])
+        return super().forward(x)
+
+
 class DepthwiseConvTranspose2d(nn.Module):
     """nn.ConvTranspose2d(C, C, k, stride, padding, groups=C, bias=False); weight [C,1,k,k]."""
 

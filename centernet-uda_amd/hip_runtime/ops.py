@@ -101,6 +101,94 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0, pack_token
     return _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope), pack_token)
 
 
+class _ConvActConv1x1(Function):
+    """A detection head, `nn.Sequential(Conv2d(C, Ch, k, padding) + ReLU, Conv2d(Ch, Co, 1))` (dla.py:474-483), as one
+    tape node: the two forward launches are the ones two `_Conv2d` nodes make; backward computes the hidden map's
+    gradient -- the 1x1 layer's input gradient times the ReLU's -- in one pass over the hidden map
+    (cnuda_conv1x1_backward_data_act) instead of a K <= 8 GEMM launch followed by cnuda_act_backward's own pass."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, padding, act_slope, token1, token2):
+        require_gpu(x, w1, b1, w2, b2)
+        x, w1, w2 = f32c(x), f32c(w1), f32c(w2)
+        b1 = None if b1 is None else f32c(b1)
+        b2 = None if b2 is None else f32c(b2)
+        g1 = _conv_geom(x, w1, 1, padding)
+        B, C, H, W, Ch, kh, kw, sh, sw, ph, pw = g1
+        Ho, Wo = H + 2 * ph - kh + 1, W + 2 * pw - kw + 1
+        hidden = torch.empty((B, Ch, Ho, Wo), dtype=torch.float32, device=x.device)
+        L = lib()
+        wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g1), x)
+        prof_arm('conv_fwd', B, C, H, W, Ch, kh, kw, Ho, Wo)
+        with pack_stamp(token1, w1):
+            check(L.cnuda_conv2d_forward(ptr(x), ptr(w1), ptr(b1), ptr(hidden), *g1, float(act_slope), wp, wn, stream()),
+                  'conv2d_forward')
+        g2 = _conv_geom(hidden, w2, 1, 0)
+        Co = g2[4]
+        y = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+        wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g2), x)
+        prof_arm('conv_fwd', B, Ch, Ho, Wo, Co, 1, 1, Ho, Wo)
+        with pack_stamp(token2, w2):
+            check(L.cnuda_conv2d_forward(ptr(hidden), ptr(w2), ptr(b2), ptr(y), *g2, -1.0, wp, wn, stream()),
+                  'conv2d_forward')
+        ctx.g1, ctx.g2, ctx.act_slope, ctx.token1 = g1, g2, float(act_slope), token1
+        ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+        ctx.save_for_backward(x, w1, b1, w2, b2, hidden)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w1, b1, w2, b2, hidden = ctx.saved_tensors
+        g1, g2 = ctx.g1, ctx.g2
+        L = lib()
+        gy = f32c(gy)
+        B, C, H, W, Ch, kh, kw = g1[:7]
+        Co, Ho, Wo = g2[4], hidden.shape[2], hidden.shape[3]
+        gx = gw1 = gb1 = gw2 = gb2 = None
+        if ctx.needs_input_grad[3] or (ctx.has_b2 and ctx.needs_input_grad[4]):
+            gw2_buf, gw2 = _param_grad(w2)
+            gb2_buf, gb2 = _param_grad(b2, ctx.has_b2)
+            wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g2), x)
+            prof_arm('conv_wgrad', B, Ch, Ho, Wo, Co, 1, 1, Ho, Wo)
+            check(L.cnuda_conv2d_backward_weight(ptr(hidden), ptr(gy), ptr(gw2_buf), ptr(gb2_buf), *g2, wp, wn, stream()),
+                  'conv2d_backward_weight')
+        gh = torch.empty_like(hidden)
+        check(L.cnuda_conv1x1_backward_data_act(ptr(gy), ptr(w2), ptr(hidden), ptr(gh), B, Co, Ch, Ho * Wo,
+                                                ctx.act_slope, stream()), 'conv1x1_backward_data_act')
+        wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g1), x)
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            prof_arm('conv_dgrad', B, C, H, W, Ch, kh, kw, Ho, Wo)
+            with pack_stamp(ctx.token1, w1):
+                check(L.cnuda_conv2d_backward_data(ptr(gh), ptr(w1), ptr(gx), *g1, wp, wn, stream()),
+                      'conv2d_backward_data')
+        if ctx.needs_input_grad[1] or (ctx.has_b1 and ctx.needs_input_grad[2]):
+            gw1_buf, gw1 = _param_grad(w1)
+            gb1_buf, gb1 = _param_grad(b1, ctx.has_b1)
+            prof_arm('conv_wgrad', B, C, H, W, Ch, kh, kw, Ho, Wo)
+            check(L.cnuda_conv2d_backward_weight(ptr(x), ptr(gh), ptr(gw1_buf), ptr(gb1_buf), *g1, wp, wn, stream()),
+                  'conv2d_backward_weight')
+        return gx, gw1, gb1, gw2, gb2, None, None, None, None
+
+
+def conv_act_conv1x1_supported(x, conv, last):
+    """The fused head node applies: stride-1 `conv` with an activation, a 1x1 `last` with 1..8 outputs, planes of a
+    multiple of 4 pixels, and a tape being recorded."""
+    if not (torch.is_grad_enabled() and x.is_cuda and x.dim() == 4):
+        return False
+    (kh, kw), (ph, pw) = conv.kernel_size, conv.padding
+    hw = (x.shape[2] + 2 * ph - kh + 1) * (x.shape[3] + 2 * pw - kw + 1)
+    return (conv.act_slope >= 0 and conv.stride == (1, 1) and last.kernel_size == (1, 1) and last.stride == (1, 1)
+            and last.padding == (0, 0) and last.act_slope < 0 and 1 <= last.out_channels <= 8 and hw > 0 and hw % 4 == 0)
+
+
+def conv_act_conv1x1(x, conv, last):
+    """last(conv(x)) for the two `hip_runtime.nn.Conv2d` layers of a detection head, recorded as one tape node."""
+    return _ConvActConv1x1.apply(x, conv.weight, conv.bias, last.weight, last.bias, conv.padding, conv.act_slope,
+                                 conv._pack_token, last._pack_token)
+
+
 def conv2d_infer(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0, residual=None, pack_token=0,
                  pack_version=None):
     """Tape-free y = act(conv2d(x, weight) + bias + residual): the forward kernel with the skip connection in its

@@ -285,6 +285,12 @@ int cnuda_dwconv2d_backward(const float* x, const float* w, const float* grad_y,
 int cnuda_add(const float* a, const float* b, float* out, long long n, cnuda_stream_t stream);
 int cnuda_act_backward(const float* grad_y, const float* y, float* grad_x, long long n, float slope,
                        cnuda_stream_t stream);
+/* grad_hidden = act'(hidden) * conv1x1_input_gradient(grad_y, weight): the last layer of a detection head
+ * (nn.Conv2d(head_conv, classes, 1), dla.py:474-483) has 1..8 output channels, so its input gradient is one pass over
+ * the hidden map fused with the backward of the ReLU in front of it.  weight [Co, Ch] (the 1x1 kernel), hidden /
+ * grad_hidden [B, Ch, HW] (HW % 4 == 0), grad_y [B, Co, HW]; channels summed in increasing order. */
+int cnuda_conv1x1_backward_data_act(const float* grad_y, const float* weight, const float* hidden, float* grad_hidden,
+                                    int B, int Co, int Ch, long long HW, float slope, cnuda_stream_t stream);
 int cnuda_copy_channels(const float* src, float* dst, int B, int Cn, long long HW,
                         int Csrc, int src_off, int Cdst, int dst_off, cnuda_stream_t stream);
 int cnuda_split_offset_mask(const float* om, float* offset, float* mask, int B, int taps, long long HW,

@@ -170,6 +170,46 @@ def test_depthwise_conv_transpose_with_summand_is_the_separate_add(C, H, W, f):
         ops.depthwise_conv_transpose2d(x, w, f, f // 2, skip[:, :, 1:])
 
 
+@pytest.mark.parametrize('B,C,Ch,Co,H,W,k', [(2, 16, 32, 6, 8, 12, 3), (3, 64, 256, 2, 16, 16, 3), (1, 16, 48, 8, 6, 10, 1),
+                                            (2, 32, 64, 1, 4, 8, 3)])
+def test_head_pair_is_one_tape_node_with_the_two_layers_values(B, C, Ch, Co, H, W, k):
+    """hnn.Head = Conv2d + ReLU + Conv2d(.., 1): forward bit-identical to the two layers run in turn; the hidden
+    map's gradient (1x1 input gradient x ReLU gradient in one pass, channels summed in order) and everything behind
+    it within 1e-5 of the unfused tape and of torch's own conv2d."""
+    import hip_runtime.nn as hnn
+    torch.manual_seed(40 + Co)
+    head = hnn.Head(hnn.Conv2d(C, Ch, k, padding=k // 2, bias=True, act_slope=0.0), hnn.Slot(),
+                    hnn.Conv2d(Ch, Co, 1, bias=True)).to(DEV)
+    x = torch.randn(B, C, H, W, device=DEV)
+    gy = torch.randn(B, Co, H, W, device=DEV)
+    xa = x.clone().requires_grad_(True)
+    ya = head(xa)
+    assert type(ya.grad_fn).__name__.startswith('_ConvActConv1x1')
+    ya.backward(gy)
+    fused = [xa.grad.clone()] + [p.grad.clone() for p in head.parameters()]
+    for p in head.parameters():
+        p.grad = None
+    xb = x.clone().requires_grad_(True)
+    yb = head[2](head[0](xb))                                  # the two _Conv2d nodes
+    assert torch.equal(ya, yb)
+    yb.backward(gy)
+    unfused = [xb.grad] + [p.grad for p in head.parameters()]
+    xr = x.detach().cpu().requires_grad_(True)
+    ps = [p.detach().cpu().requires_grad_(True) for p in head.parameters()]
+    yr = F.conv2d(F.relu(F.conv2d(xr, ps[0], ps[1], padding=k // 2)), ps[2], ps[3])
+    yr.backward(gy.cpu())
+    for a, b, r in zip(fused, unfused, [xr.grad] + [p.grad for p in ps]):
+        _close(a, b, 1e-5)
+        _close(a, r, 1e-4)
+    with torch.no_grad():                                      # no tape: the layers run in turn
+        assert torch.equal(head(x), ya)
+    # 9 outputs, odd planes: the fused node does not apply and the module still works
+    wide = hnn.Head(hnn.Conv2d(C, Ch, k, padding=k // 2, act_slope=0.0), hnn.Slot(), hnn.Conv2d(Ch, 9, 1)).to(DEV)
+    assert not type(wide(x.clone().requires_grad_(True)).grad_fn).__name__.startswith('_ConvActConv1x1')
+    odd = torch.randn(1, C, 3, 5, device=DEV, requires_grad=True)
+    assert not type(head(odd).grad_fn).__name__.startswith('_ConvActConv1x1')
+
+
 def test_cat_add_split():
     from hip_runtime import ops
     g = torch.Generator().manual_seed(7)
