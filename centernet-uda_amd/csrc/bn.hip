@@ -47,10 +47,14 @@ __device__ __forceinline__ bool bn_pass(float y, int relu) { return y > 0.0f && 
 // partial[(c*S + s)*2 + {0,1}] = sum(v), sum(v*w) over one chunk of one (b, c) plane
 // MODE 0: v = x, w = x                       (forward statistics)
 // MODE 1: v = dy', w = xhat                   (backward), dy' = dy * (y > 0) when relu
+// The activation's gate: when no residual entered the forward (`beta` given), y = act(x * sc + sh) and the gate is
+// RECOMPUTED from x with the forward's own two operations (bn_apply_kernel: sc = invstd * gamma, sh = beta - mean * sc,
+// one multiply, one add) instead of read from y -- one tensor less per backward pass.
 template <int MODE>
 __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
-    const float* __restrict__ mean, const float* __restrict__ invstd, double* __restrict__ partial,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, double* __restrict__ partial,
     int C, long long HW, long long chunk, int per_plane, int S, int relu, int imgs_per_group) {
     __shared__ double red[16];
     const int c = blockIdx.x, s = blockIdx.y;
@@ -61,8 +65,10 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
     long long e1 = e0 + chunk;
     if (e1 > HW) e1 = HW;
     double a0 = 0.0, a1 = 0.0;
-    float mu = 0.f, is = 0.f;
+    float mu = 0.f, is = 0.f, sc = 0.f, sh = 0.f;
     if (MODE == 1) { mu = mean[grp * C + c]; is = invstd[grp * C + c]; }
+    const bool regate = MODE == 1 && relu && beta != nullptr;
+    if (regate) { sc = is * gamma[c]; sh = beta[c] - mu * sc; }
     auto acc = [&](float xv, float gv, float yv) {
         if (MODE == 0) {
             const double v = (double)xv;
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
             a1 += v * v;
         } else {
             float g = gv;
-            if (relu && !bn_pass(yv, relu)) g = 0.0f;
+            if (relu && !bn_pass(regate ? xv * sc + sh : yv, relu)) g = 0.0f;
             const float xh = (xv - mu) * is;
             a0 += (double)g;
             a1 += (double)g * (double)xh;
@@ -82,13 +88,13 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
             float4 gv = make_float4(0, 0, 0, 0), yv = make_float4(1, 1, 1, 1);
             if (MODE == 1) {
                 gv = *reinterpret_cast<const float4*>(dy + base + e);
-                if (relu) yv = *reinterpret_cast<const float4*>(y + base + e);
+                if (relu && !regate) yv = *reinterpret_cast<const float4*>(y + base + e);
             }
             acc(xv.x, gv.x, yv.x); acc(xv.y, gv.y, yv.y); acc(xv.z, gv.z, yv.z); acc(xv.w, gv.w, yv.w);
         }
     } else {
         for (long long e = e0 + threadIdx.x; e < e1; e += kBnThreads)
-            acc(x[base + e], MODE == 1 ? dy[base + e] : 0.f, (MODE == 1 && relu) ? y[base + e] : 1.f);
+            acc(x[base + e], MODE == 1 ? dy[base + e] : 0.f, (MODE == 1 && relu && !regate) ? y[base + e] : 1.f);
     }
     a0 = block_sum(a0, red);
     a1 = block_sum(a1, red);
@@ -198,6 +204,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta /* nullable: see bn_reduce_kernel */,
     const double* __restrict__ partial, int S, float* __restrict__ ggamma, float* __restrict__ gbeta,
     float* __restrict__ gx, float* __restrict__ gres, int C, long long HW, long long count, int relu, int groups,
     int imgs_per_group, int per_plane) {
@@ -227,6 +234,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
     __syncthreads();
     const float mu = mean[grp * C + c], is = invstd[grp * C + c];
     const float k = gamma[c] * is;
+    const bool regate = relu && beta != nullptr;
+    const float sc = is * gamma[c], sh = regate ? beta[c] - mu * sc : 0.0f;
     const float inv_n = 1.0f / (float)count;
     const float m0 = stat[0] * inv_n, m1 = stat[1] * inv_n;
     const size_t base = (size_t)plane * HW;
@@ -235,14 +244,16 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
         const long long stride = (long long)gridDim.y * kBnThreads * 4;
         for (long long i = start; i < HW; i += stride) {
             float4 g = *reinterpret_cast<const float4*>(dy + base + i);
+            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
             if (relu) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
+                float4 yv;
+                if (regate) yv = make_float4(xv.x * sc + sh, xv.y * sc + sh, xv.z * sc + sh, xv.w * sc + sh);
+                else yv = *reinterpret_cast<const float4*>(y + base + i);
                 if (!bn_pass(yv.x, relu)) g.x = 0.0f;
                 if (!bn_pass(yv.y, relu)) g.y = 0.0f;
                 if (!bn_pass(yv.z, relu)) g.z = 0.0f;
                 if (!bn_pass(yv.w, relu)) g.w = 0.0f;
             }
-            const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
             float4 o;
             o.x = k * (g.x - m0 - (xv.x - mu) * is * m1);
             o.y = k * (g.y - m0 - (xv.y - mu) * is * m1);
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
     }
     for (long long i = (long long)blockIdx.y * kBnThreads + threadIdx.x; i < HW; i += (long long)gridDim.y * kBnThreads) {
         float g = dy[base + i];
-        if (relu && !bn_pass(y[base + i], relu)) g = 0.0f;
+        if (relu && !bn_pass(regate ? x[base + i] * sc + sh : y[base + i], relu)) g = 0.0f;
         const float xh = (x[base + i] - mu) * is;
         gx[base + i] = k * (g - m0 - xh * m1);
         if (gres) gres[base + i] = g;
@@ -317,7 +328,8 @@ extern "C" int cnuda_bn_train_forward(const float* x, const float* gamma, const 
     const Split sp = pick_split(B, C, HW);
     double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, C, HW,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, partial, C, HW,
                        sp.chunk, sp.per_plane, sp.S, 0, Bg);
     const long long planes = (long long)B * C;
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
@@ -339,12 +351,14 @@ extern "C" int cnuda_bn_eval_forward(const float* x, const float* gamma, const f
 }
 
 extern "C" int cnuda_bn_backward(const float* grad_y, const float* x, const float* y, const float* gamma,
-                                 const float* save_mean, const float* save_invstd, float* grad_x, float* grad_residual,
+                                 const float* beta, const float* save_mean, const float* save_invstd, float* grad_x,
+                                 float* grad_residual,
                                  float* grad_gamma, float* grad_beta, int relu, int B, int C, long long HW, int groups,
                                  void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
     CNUDA_REQUIRE(grad_y && x && gamma && save_mean && save_invstd && grad_x && grad_gamma && grad_beta,
                   "cnuda_bn_backward: null pointer");
-    CNUDA_REQUIRE(!relu || y, "cnuda_bn_backward: relu backward needs the forward output");
+    CNUDA_REQUIRE(!relu || y || beta, "cnuda_bn_backward: relu backward needs the forward output (or beta)");
+    CNUDA_REQUIRE(!(beta && grad_residual), "cnuda_bn_backward: the gate is recomputed from x only without a residual");
     CNUDA_REQUIRE(B > 0 && C > 0 && HW > 0, "cnuda_bn_backward: empty tensor");
     CNUDA_REQUIRE(groups >= 1 && B % groups == 0, "cnuda_bn_backward: batch %d not divisible into %d groups", B, groups);
     CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_bn_workspace_bytes(B, C, HW),
@@ -356,10 +370,10 @@ extern "C" int cnuda_bn_backward(const float* grad_y, const float* x, const floa
     uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
     double* partial = reinterpret_cast<double*>(base);
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, grad_y, y, save_mean,
-                       save_invstd, partial, C, HW, sp.chunk, sp.per_plane, sp.S, relu, Bg);
+                       save_invstd, gamma, beta, partial, C, HW, sp.chunk, sp.per_plane, sp.S, relu, Bg);
     const long long planes = (long long)B * C;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
-                       dim3(kBnThreads), 0, st, grad_y, x, y, save_mean, save_invstd, gamma, partial, sp.S, grad_gamma,
+                       dim3(kBnThreads), 0, st, grad_y, x, y, save_mean, save_invstd, gamma, beta, partial, sp.S, grad_gamma,
                        grad_beta, grad_x, grad_residual, C, HW, count, relu, groups, Bg, sp.per_plane);
     return check_launch("cnuda_bn_backward");
 }

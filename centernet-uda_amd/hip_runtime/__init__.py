@@ -76,7 +76,7 @@ class _Sig:
     cnuda_bn_workspace_bytes = (c_size_t, [_I, _I, _LL])
     cnuda_bn_train_forward = (_I, [_P] * 10 + [_F, _F, _I, _I, _I, _LL, _I] + _WS)
     cnuda_bn_eval_forward = (_I, [_P] * 7 + [_F, _I, _I, _I, _LL, _P])
-    cnuda_bn_backward = (_I, [_P] * 10 + [_I, _I, _I, _LL, _I] + _WS)
+    cnuda_bn_backward = (_I, [_P] * 11 + [_I, _I, _I, _LL, _I] + _WS)
     cnuda_maxpool2d_forward = (_I, [_P] * 2 + [_I] * 5 + [_P])
     cnuda_maxpool2d_backward = (_I, [_P] * 3 + [_I] * 5 + [_P])
     cnuda_maxpool2d_window_forward = (_I, [_P] * 2 + [_I] * 7 + [_P])

@@ -321,9 +321,11 @@ class _BatchNormAct(Function):
         gb_buf, gb = _param_grad(beta)
         L = lib()
         wp, wn = _ws(L.cnuda_bn_workspace_bytes(B, C, HW), x)
-        check(L.cnuda_bn_backward(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(mean), ptr(invstd), ptr(gx), ptr(gres),
-                                  ptr(gg_buf), ptr(gb_buf), _act_code(ctx.relu), B, C, HW, ctx.groups, wp, wn, stream()),
-              'bn_backward')
+        # without a residual the activation's gate is recomputed from x (y is not read): beta goes along for that
+        regate = beta if (ctx.relu and not ctx.has_res) else None
+        check(L.cnuda_bn_backward(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(regate), ptr(mean), ptr(invstd), ptr(gx),
+                                  ptr(gres), ptr(gg_buf), ptr(gb_buf), _act_code(ctx.relu), B, C, HW, ctx.groups, wp, wn,
+                                  stream()), 'bn_backward')
         return gx, gg, gb, gres, None, None, None, None, None, None, None
 
 

@@ -241,6 +241,9 @@ int cnuda_bn_eval_forward(const float* x, const float* gamma, const float* beta,
                           const float* running_mean, const float* running_var, const float* residual,
                           float* y, float eps, int relu, int B, int C, long long HW, cnuda_stream_t stream);
 int cnuda_bn_backward(const float* grad_y, const float* x, const float* y, const float* gamma,
+                      const float* beta /* nullable.  Given (only without a residual): the activation's gate is
+                                           recomputed from x with the forward's own multiply and add instead of read
+                                           from y -- one tensor less per pass; y may then be NULL */,
                       const float* save_mean, const float* save_invstd,
                       float* grad_x, float* grad_residual, float* grad_gamma, float* grad_beta,
                       int relu, int B, int C, long long HW, int groups,

@@ -99,6 +99,44 @@ def test_batch_norm_train_fwd_bwd_and_running_stats(shape, relu, res):
     _close(rv_d, rv, 1e-6)
 
 
+@pytest.mark.parametrize('shape,relu', [((4, 16, 8, 12), True), ((2, 5, 7, 9), True), ((3, 8, 16, 16), 'relu6'),
+                                        ((2, 32, 64, 64), True)])
+def test_batch_norm_backward_gate_recomputed_from_x_is_the_gate_read_from_y(shape, relu):
+    """Without a residual the backward passes recompute the activation's gate from x (the forward's own multiply and
+    add) instead of reading y: every output must be bit-identical to the y-reading form of the same entry point."""
+    import hip_runtime as hr
+    L = hr.lib()
+    g = torch.Generator().manual_seed(21)
+    B, C, H, W = shape
+    HW = H * W
+    x = (torch.randn(shape, generator=g) * 2 + 0.3).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.5).to(DEV)
+    gy = torch.randn(shape, generator=g).to(DEV)
+    code = 2 if relu == 'relu6' else 1
+    for groups in (1, 2) if B % 2 == 0 else (1,):
+        y = torch.empty_like(x)
+        mean, invstd = torch.empty(groups * C, device=DEV), torch.empty(groups * C, device=DEV)
+        ws = hr.workspace(L.cnuda_bn_workspace_bytes(B, C, HW), x.device)
+        hr.check(L.cnuda_bn_train_forward(hr.ptr(x), hr.ptr(gamma), hr.ptr(beta), None, hr.ptr(y), hr.ptr(mean),
+                                          hr.ptr(invstd), None, None, None, 0.1, 1e-5, code, B, C, HW, groups, hr.ptr(ws),
+                                          ws.numel(), hr.stream()), 'bn_train_forward')
+        assert (y == 0).float().mean().item() > 0.1            # the gate matters
+        outs = []
+        for regate in (False, True):
+            gx, gg, gb = torch.empty_like(x), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+            hr.check(L.cnuda_bn_backward(hr.ptr(gy), hr.ptr(x), None if regate else hr.ptr(y), hr.ptr(gamma),
+                                         hr.ptr(beta) if regate else None, hr.ptr(mean), hr.ptr(invstd), hr.ptr(gx), None,
+                                         hr.ptr(gg), hr.ptr(gb), code, B, C, HW, groups, hr.ptr(ws), ws.numel(),
+                                         hr.stream()), 'bn_backward')
+            outs.append((gx, gg, gb))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match='residual'):
+        hr.check(L.cnuda_bn_backward(hr.ptr(gy), hr.ptr(x), hr.ptr(y), hr.ptr(gamma), hr.ptr(beta), hr.ptr(mean),
+                                     hr.ptr(invstd), hr.ptr(gx), hr.ptr(torch.empty_like(x)), hr.ptr(gg), hr.ptr(gb), code,
+                                     B, C, HW, 1, hr.ptr(ws), ws.numel(), hr.stream()), 'bn_backward')
+
+
 def test_batch_norm_eval_and_single_value_error():
     from hip_runtime import ops
     g = torch.Generator().manual_seed(4)
