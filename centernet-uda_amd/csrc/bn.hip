@@ -20,10 +20,12 @@ constexpr int kBnThreads = 256;
 
 struct Split {
     int per_plane;     // splits of one (b, c) plane
-    int S;             // partials per channel = B * per_plane
+    int ips;           // images per split / per apply workgroup (> 1 only with per_plane == 1: small planes)
+    int S;             // partials per channel = B / ips * per_plane
     long long chunk;   // elements of a plane per split (multiple of 4)
 };
-Split pick_split(int B, int C, long long HW) {
+// Bg = images per statistics group (a split never straddles two groups)
+Split pick_split(int B, int C, long long HW, int Bg) {
     // aim for ~2048 workgroups in total, at least 4096 elements each
     long long s = 2048 / ((long long)B * C > 0 ? (long long)B * C : 1);
     const long long max_s = (HW + 4095) / 4096;
@@ -32,7 +34,14 @@ Split pick_split(int B, int C, long long HW) {
     Split r;
     r.chunk = ((HW + s - 1) / s + 3) / 4 * 4;
     r.per_plane = (int)((HW + r.chunk - 1) / r.chunk);
-    r.S = B * r.per_plane;
+    // many small planes (the 256- and 512-channel levels: 8,192 / 16,384 planes of 1,024 / 256 values): a workgroup per
+    // plane is bound by the workgroup launch rate (16,384 workgroups: 38 us for 17 MB), so one workgroup takes several
+    // images of its channel -- at least 1,024 values per workgroup while more than 2,048 workgroups per statistics
+    // group remain (a function of the GROUP's size only: a batch of two domains sums like the two batches alone)
+    r.ips = 1;
+    if (r.per_plane == 1)
+        while (r.ips * 2 <= Bg && Bg % (r.ips * 2) == 0 && (long long)Bg * C / r.ips > 2048 && HW * r.ips < 4096) r.ips *= 2;
+    r.S = B / r.ips * r.per_plane;
     return r;
 }
 
@@ -55,12 +64,11 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
     const float* __restrict__ beta, double* __restrict__ partial,
-    int C, long long HW, long long chunk, int per_plane, int S, int relu, int imgs_per_group) {
+    int C, long long HW, long long chunk, int per_plane, int ips, int S, int relu, int imgs_per_group) {
     __shared__ double red[16];
     const int c = blockIdx.x, s = blockIdx.y;
-    const int b = s / per_plane, part = s - b * per_plane;
-    const int grp = b / imgs_per_group;
-    const size_t base = ((size_t)b * C + c) * HW;
+    const int b0 = s / per_plane * ips, part = s - s / per_plane * per_plane;
+    const int grp = b0 / imgs_per_group;
     const long long e0 = (long long)part * chunk;
     long long e1 = e0 + chunk;
     if (e1 > HW) e1 = HW;
@@ -82,19 +90,22 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
             a1 += (double)g * (double)xh;
         }
     };
-    if ((HW & 3) == 0) {
-        for (long long e = e0 + threadIdx.x * 4; e < e1; e += kBnThreads * 4) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + base + e);
-            float4 gv = make_float4(0, 0, 0, 0), yv = make_float4(1, 1, 1, 1);
-            if (MODE == 1) {
-                gv = *reinterpret_cast<const float4*>(dy + base + e);
-                if (relu && !regate) yv = *reinterpret_cast<const float4*>(y + base + e);
+    for (int b = b0; b < b0 + ips; ++b) {
+        const size_t base = ((size_t)b * C + c) * HW;
+        if ((HW & 3) == 0) {
+            for (long long e = e0 + threadIdx.x * 4; e < e1; e += kBnThreads * 4) {
+                const float4 xv = *reinterpret_cast<const float4*>(x + base + e);
+                float4 gv = make_float4(0, 0, 0, 0), yv = make_float4(1, 1, 1, 1);
+                if (MODE == 1) {
+                    gv = *reinterpret_cast<const float4*>(dy + base + e);
+                    if (relu && !regate) yv = *reinterpret_cast<const float4*>(y + base + e);
+                }
+                acc(xv.x, gv.x, yv.x); acc(xv.y, gv.y, yv.y); acc(xv.z, gv.z, yv.z); acc(xv.w, gv.w, yv.w);
             }
-            acc(xv.x, gv.x, yv.x); acc(xv.y, gv.y, yv.y); acc(xv.z, gv.z, yv.z); acc(xv.w, gv.w, yv.w);
+        } else {
+            for (long long e = e0 + threadIdx.x; e < e1; e += kBnThreads)
+                acc(x[base + e], MODE == 1 ? dy[base + e] : 0.f, (MODE == 1 && relu && !regate) ? y[base + e] : 1.f);
         }
-    } else {
-        for (long long e = e0 + threadIdx.x; e < e1; e += kBnThreads)
-            acc(x[base + e], MODE == 1 ? dy[base + e] : 0.f, (MODE == 1 && relu && !regate) ? y[base + e] : 1.f);
     }
     a0 = block_sum(a0, red);
     a1 = block_sum(a1, red);
@@ -127,13 +138,13 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ running_mean,
     float* __restrict__ running_var, long long* __restrict__ num_batches_tracked,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ residual,
-    float* __restrict__ y, int C, long long HW, int relu, int groups, int imgs_per_group, int per_plane) {
+    float* __restrict__ y, int C, long long HW, int relu, int groups, int imgs_per_group, int per_plane, int ips) {
     __shared__ double red[16];
     __shared__ float stat[2];
-    const long long plane = blockIdx.x;
+    const long long plane = blockIdx.x;               // (block of ips images, channel)
     const int c = (int)(plane % C);
-    const int b = (int)(plane / C), grp = b / imgs_per_group;
-    const int s_per_group = imgs_per_group * per_plane;
+    const int b = (int)(plane / C) * ips, grp = b / imgs_per_group;
+    const int s_per_group = imgs_per_group / ips * per_plane;
     const double n = (double)count;                        // values per channel and GROUP
     double s0, s1;
     bn_sum_partials(partial, c, S, grp * s_per_group, (grp + 1) * s_per_group, s0, s1, red);
@@ -175,9 +186,10 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
     __syncthreads();
     const float sc = stat[1] * gamma[c];
     const float sh = beta[c] - stat[0] * sc;
-    const size_t base = (size_t)plane * HW;
     const long long start = (long long)blockIdx.y * kBnThreads * 4 + threadIdx.x * 4;
     const long long stride = (long long)gridDim.y * kBnThreads * 4;
+    for (int img = b; img < b + ips; ++img) {
+    const size_t base = ((size_t)img * C + c) * HW;
     if ((HW & 3) == 0) {
         for (long long i = start; i < HW; i += stride) {
             float4 v = *reinterpret_cast<const float4*>(x + base + i);
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
                 if (relu) v = bn_act(v, relu);
                 y[base + i] = v;
             }
-    }
+    }    }
 }
 
 // gx = gamma*invstd*(dy' - sum_dy/n - xhat*sum_dy_xhat/n);  gres = dy'
@@ -207,13 +219,13 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
     const float* __restrict__ beta /* nullable: see bn_reduce_kernel */,
     const double* __restrict__ partial, int S, float* __restrict__ ggamma, float* __restrict__ gbeta,
     float* __restrict__ gx, float* __restrict__ gres, int C, long long HW, long long count, int relu, int groups,
-    int imgs_per_group, int per_plane) {
+    int imgs_per_group, int per_plane, int ips) {
     __shared__ double red[16];
     __shared__ float stat[2];
-    const long long plane = blockIdx.x;
+    const long long plane = blockIdx.x;               // (block of ips images, channel)
     const int c = (int)(plane % C);
-    const int b = (int)(plane / C), grp = b / imgs_per_group;
-    const int s_per_group = imgs_per_group * per_plane;
+    const int b = (int)(plane / C) * ips, grp = b / imgs_per_group;
+    const int s_per_group = imgs_per_group / ips * per_plane;
     double s0, s1;
     bn_sum_partials(partial, c, S, grp * s_per_group, (grp + 1) * s_per_group, s0, s1, red);
     if (threadIdx.x == 0) {
@@ -238,7 +250,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
     const float sc = is * gamma[c], sh = regate ? beta[c] - mu * sc : 0.0f;
     const float inv_n = 1.0f / (float)count;
     const float m0 = stat[0] * inv_n, m1 = stat[1] * inv_n;
-    const size_t base = (size_t)plane * HW;
+    for (int img = b; img < b + ips; ++img) {
+    const size_t base = ((size_t)img * C + c) * HW;
     if ((HW & 3) == 0) {
         const long long start = (long long)blockIdx.y * kBnThreads * 4 + threadIdx.x * 4;
         const long long stride = (long long)gridDim.y * kBnThreads * 4;
@@ -262,7 +275,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
             *reinterpret_cast<float4*>(gx + base + i) = o;
             if (gres) *reinterpret_cast<float4*>(gres + base + i) = g;
         }
-        return;
+        continue;
     }
     for (long long i = (long long)blockIdx.y * kBnThreads + threadIdx.x; i < HW; i += (long long)gridDim.y * kBnThreads) {
         float g = dy[base + i];
@@ -270,6 +283,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
         const float xh = (x[base + i] - mu) * is;
         gx[base + i] = k * (g - m0 - xh * m1);
         if (gres) gres[base + i] = g;
+    }
     }
 }
 
@@ -304,7 +318,7 @@ int plane_splits(long long planes, long long HW, int per_block) {
 using namespace cnuda;
 
 extern "C" size_t cnuda_bn_workspace_bytes(int B, int C, long long HW) {
-    const Split sp = pick_split(B, C, HW);
+    const Split sp = pick_split(B, C, HW, 1);          // (ips = 1: the most partials any grouping needs)
     return (size_t)C * sp.S * 2 * sizeof(double) + (size_t)C * 2 * sizeof(float) + 512;
 }
 
@@ -325,17 +339,17 @@ extern "C" int cnuda_bn_train_forward(const float* x, const float* gamma, const 
     CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_bn_workspace_bytes(B, C, HW),
                   "cnuda_bn_train_forward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    const Split sp = pick_split(B, C, HW);
+    const Split sp = pick_split(B, C, HW, Bg);
     double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, partial, C, HW,
-                       sp.chunk, sp.per_plane, sp.S, 0, Bg);
-    const long long planes = (long long)B * C;
+                       sp.chunk, sp.per_plane, sp.ips, sp.S, 0, Bg);
+    const long long planes = (long long)B * C / sp.ips;        // workgroups of the apply pass (x its plane splits)
     hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
                        dim3(kBnThreads), 0, st, x, partial, sp.S, count, momentum, eps, save_mean, save_invstd,
                        running_mean, running_var, num_batches_tracked, gamma, beta, residual, y, C, HW, relu, groups, Bg,
-                       sp.per_plane);
+                       sp.per_plane, sp.ips);
     return check_launch("cnuda_bn_train_forward");
 }
 
@@ -366,14 +380,14 @@ extern "C" int cnuda_bn_backward(const float* grad_y, const float* x, const floa
     hipStream_t st = (hipStream_t)stream;
     const int Bg = B / groups;
     const long long count = (long long)Bg * HW;
-    const Split sp = pick_split(B, C, HW);
+    const Split sp = pick_split(B, C, HW, Bg);
     uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
     double* partial = reinterpret_cast<double*>(base);
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, grad_y, y, save_mean,
-                       save_invstd, gamma, beta, partial, C, HW, sp.chunk, sp.per_plane, sp.S, relu, Bg);
-    const long long planes = (long long)B * C;
+                       save_invstd, gamma, beta, partial, C, HW, sp.chunk, sp.per_plane, sp.ips, sp.S, relu, Bg);
+    const long long planes = (long long)B * C / sp.ips;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
                        dim3(kBnThreads), 0, st, grad_y, x, y, save_mean, save_invstd, gamma, beta, partial, sp.S, grad_gamma,
-                       grad_beta, grad_x, grad_residual, C, HW, count, relu, groups, Bg, sp.per_plane);
+                       grad_beta, grad_x, grad_residual, C, HW, count, relu, groups, Bg, sp.per_plane, sp.ips);
     return check_launch("cnuda_bn_backward");
 }
