@@ -45,6 +45,24 @@ __global__ void pack_taps_kernel(const float* __restrict__ W, float* __restrict_
     }
 }
 
+// The same sum for Z <= 4 slabs, one thread per output: ((s0 + s1) + s2) + s3 is the four-wave kernel's own order
+// (each wave holds one slab), and a large weight (2.4 M outputs) needs 9,216 workgroups instead of 36,864 -- that many
+// 64-output workgroups were bound by the workgroup launch rate, not by the 4 slabs' 38 MB.
+__global__ __launch_bounds__(256) void slab_reduce_few_kernel(const float* __restrict__ slabs, float* __restrict__ gw,
+                                                              int Z, int Mp, int Jp, int Co, int C, int T) {
+    const long long total = (long long)Co * C * T;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int K = T * C;
+    const int j = (int)(i % K), o = (int)(i / K);
+    const size_t off = (size_t)o * Jp + j, zs = (size_t)Mp * Jp;
+    float v[4];
+#pragma unroll
+    for (int z = 0; z < 4; ++z) v[z] = z < Z ? 0.0f + slabs[(size_t)z * zs + off] : 0.0f;   // (0 + x: the wave's start)
+    const int tap = j / C, c = j - tap * C;
+    gw[((size_t)o * C + c) * T + tap] = ((v[0] + v[1]) + v[2]) + v[3];
+}
+
 // gw[o][c][tap] = sum_z slabs[z][o][tap*C + c].  Workgroup = 64 consecutive outputs x 4 waves; wave w sums
 // slabs w, w+4, w+8, ... (coalesced 256-B rows), the four partial sums are added in wave order through LDS:
 // a fixed summation order (bit-reproducible) with 4x the parallelism of one thread per output.
@@ -233,8 +251,12 @@ const float* launch_pack_taps(const float* W, float* dst, size_t room, int Co, i
 
 void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp, int Co, int C, int T, hipStream_t st) {
     const long long total = (long long)Co * C * T;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, slabs, gw, Z, Mp, Jp,
-                       Co, C, T);
+    if (Z <= 4 && total >= (1 << 18))       // (the large weights are the ones with few slabs)
+        hipLaunchKernelGGL(slab_reduce_few_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabs, gw, Z,
+                           Mp, Jp, Co, C, T);
+    else
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, slabs, gw, Z, Mp,
+                           Jp, Co, C, T);
 }
 
 void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st, float* scratch) {

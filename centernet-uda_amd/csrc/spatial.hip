@@ -149,7 +149,9 @@ __global__ __launch_bounds__(kT) void dwconvt_fwd_kernel(const float* __restrict
 // all index arithmetic is shifts; one thread produces four consecutive outputs of a row (Wo % 4 == 0).  `skip` (may be
 // null) is IDAUp's other summand (dla.py:400-401 node(up(project(x)) + layers[i-1])): added after the taps, in the
 // rounding order of the separate add, so the upsampled tensor is written once and never re-read
-template <int F>
+// ROWS consecutive output rows per thread (Ho % ROWS == 0): 8 KB of traffic per workgroup and row is little enough for
+// the workgroup launch rate to bound the kernel (32,768 workgroups for a 134 MB map: 2.7 TB/s)
+template <int F, int ROWS>
 __global__ __launch_bounds__(kT) void dwconvt_fwd_f_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ skip, float* __restrict__ y, int C,
                                                            int H, int W) {
@@ -159,36 +161,42 @@ __global__ __launch_bounds__(kT) void dwconvt_fwd_f_kernel(const float* __restri
     for (int i = threadIdx.x; i < K * K; i += kT) ws[i] = w[(size_t)c * K * K + i];
     __syncthreads();
     const int Ho = H * F, Wo = W * F;                       // (H-1)*F - 2*(F/2) + 2F
-    const int q = blockIdx.x * kT + threadIdx.x;           // quad of outputs
-    if (q * 4 >= Ho * Wo) return;
-    const int oy = (q * 4) / Wo, ox0 = q * 4 - oy * Wo;
+    const int q = blockIdx.x * kT + threadIdx.x;           // quad of outputs in a band of ROWS rows
+    const int qw = Wo >> 2;
+    if (q >= qw * (Ho / ROWS)) return;
+    const int band = q / qw, ox0 = (q - band * qw) * 4;
     const float* xp = x + (size_t)pl * H * W;
-    // rows: ky = (oy + P) % F + {0, F}  ->  iy = (oy + P) / F - {0, 1}
-    const int ky0 = (oy + P) % F, iy0 = (oy + P) / F;
-    float o[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int ox = ox0 + j;
-        const int kx0 = (ox + P) % F, ix0 = (ox + P) / F;
-        float acc = 0.0f;
+    for (int r = 0; r < ROWS; ++r) {
+        const int oy = band * ROWS + r;
+        // rows: ky = (oy + P) % F + {0, F}  ->  iy = (oy + P) / F - {0, 1}
+        const int ky0 = (oy + P) % F, iy0 = (oy + P) / F;
+        float o[4];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int iy = iy0 - a;
-            if (iy < 0 || iy >= H) continue;
+        for (int j = 0; j < 4; ++j) {
+            const int ox = ox0 + j;
+            const int kx0 = (ox + P) % F, ix0 = (ox + P) / F;
+            float acc = 0.0f;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int ix = ix0 - b;
-                if (ix < 0 || ix >= W) continue;
-                acc += xp[iy * W + ix] * ws[(ky0 + a * F) * K + kx0 + b * F];
+            for (int a = 0; a < 2; ++a) {
+                const int iy = iy0 - a;
+                if (iy < 0 || iy >= H) continue;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int ix = ix0 - b;
+                    if (ix < 0 || ix >= W) continue;
+                    acc += xp[iy * W + ix] * ws[(ky0 + a * F) * K + kx0 + b * F];
+                }
             }
+            o[j] = acc;
         }
-        o[j] = acc;
+        const size_t at = (size_t)pl * Ho * Wo + (size_t)oy * Wo + ox0;
+        if (skip) {
+            const float4 k4 = *reinterpret_cast<const float4*>(skip + at);
+            o[0] += k4.x; o[1] += k4.y; o[2] += k4.z; o[3] += k4.w;
+        }
+        *reinterpret_cast<float4*>(y + at) = make_float4(o[0], o[1], o[2], o[3]);
     }
-    if (skip) {
-        const float4 k4 = *reinterpret_cast<const float4*>(skip + (size_t)pl * Ho * Wo + (size_t)q * 4);
-        o[0] += k4.x; o[1] += k4.y; o[2] += k4.z; o[3] += k4.w;
-    }
-    *reinterpret_cast<float4*>(y + (size_t)pl * Ho * Wo + (size_t)q * 4) = make_float4(o[0], o[1], o[2], o[3]);
 }
 // Both gradients read the same K x K window of gy around an input pixel:
 //   gx[b,c,iy,ix]  = sum_{ky,kx} gy[b,c,iy*s-p+ky, ix*s-p+kx] * w[c,ky,kx]
@@ -572,12 +580,16 @@ extern "C" int cnuda_dwconvt2d_add_forward(const float* x, const float* w, const
     CNUDA_REQUIRE(Ho > 0 && Wo > 0, "cnuda_dwconvt2d_forward: empty output");
     CNUDA_REQUIRE((long long)B * C <= 65535, "cnuda_dwconvt2d_forward: more than 65535 planes");
     const bool upsample = k == 2 * s && p == s / 2 && (s == 2 || s == 4) && Wo % 4 == 0;   // IDAUp's bilinear-style layers
-    if (upsample && s == 2)
-        hipLaunchKernelGGL(dwconvt_fwd_f_kernel<2>, dim3(ceil_div((long long)Ho * Wo / 4, kT), B * C), dim3(kT), 0,
-                           (hipStream_t)stream, x, w, skip, y, C, H, W);
+    const int rows = (upsample && Ho % 4 == 0 && (long long)Ho * Wo >= 4096) ? 4 : 1;
+    const dim3 fgrid(ceil_div((long long)Ho * Wo / 4 / rows, kT), B * C);
+    if (upsample && s == 2 && rows == 4)
+        hipLaunchKernelGGL((dwconvt_fwd_f_kernel<2, 4>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
+    else if (upsample && s == 2)
+        hipLaunchKernelGGL((dwconvt_fwd_f_kernel<2, 1>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
+    else if (upsample && rows == 4)
+        hipLaunchKernelGGL((dwconvt_fwd_f_kernel<4, 4>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
     else if (upsample)
-        hipLaunchKernelGGL(dwconvt_fwd_f_kernel<4>, dim3(ceil_div((long long)Ho * Wo / 4, kT), B * C), dim3(kT), 0,
-                           (hipStream_t)stream, x, w, skip, y, C, H, W);
+        hipLaunchKernelGGL((dwconvt_fwd_f_kernel<4, 1>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
     else
         hipLaunchKernelGGL(dwconvt_fwd_kernel, dim3(ceil_div((long long)Ho * Wo, kT), B * C), dim3(kT), 0,
                            (hipStream_t)stream, x, w, skip, y, C, H, W, Ho, Wo, k, s, p);
