@@ -192,6 +192,43 @@ def test_isolated_peaks_sharing_score_bits_threshold_path(levels):
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-5)
 
 
+@pytest.mark.parametrize('case', ['dominant', 'many_classes', 'constant80', 'seeds_overflow', 'survivors_overflow'])
+def test_stage_two_seed_threshold_cases(case):
+    """Stage 2 bounds the K-th largest candidate by the K-th largest of every class's ceil(K / C) best, then rank-sorts
+    the classes' heads above that bound.  Shapes of the candidate set that stress it: one class holding every high
+    score, more classes than K (one seed per class), tied scores across 80 classes, more seeds than the sorting buffer
+    (falls back to the histogram selection), more survivors than the buffer (ditto)."""
+    from backends.decode import decode_detection
+    rs = np.random.RandomState({'dominant': 1, 'many_classes': 2, 'constant80': 3, 'seeds_overflow': 4,
+                                'survivors_overflow': 5}[case])
+    if case == 'dominant':
+        B, C, H, W, K = 2, 40, 64, 64, 150
+        heat = (rs.uniform(1e-4, 0.05, (B, C, H, W))).astype(np.float32)
+        heat[:, 5] = rs.uniform(0.3, 0.99, (B, H, W)).astype(np.float32)
+    elif case == 'many_classes':
+        B, C, H, W, K = 1, 200, 32, 32, 50
+        heat = rs.uniform(1e-4, 0.99, (B, C, H, W)).astype(np.float32)
+    elif case == 'constant80':
+        B, C, H, W, K = 1, 80, 32, 32, 100
+        heat = np.full((B, C, H, W), 0.25, np.float32)
+        heat[0, 7, 3, 4] = heat[0, 60, 9, 9] = 0.9
+    elif case == 'seeds_overflow':
+        B, C, H, W, K = 1, 600, 32, 32, 700                # ceil(700 / 600) * 600 = 1,200 seeds > 1,024
+        heat = rs.uniform(1e-4, 0.99, (B, C, H, W)).astype(np.float32)
+    else:
+        # 50 weak classes (scores <= 0.2) pull the seed bound down; 10 strong ones then have all their 100 entries
+        # above it: more than 1,024 survivors
+        B, C, H, W, K = 1, 60, 32, 32, 100
+        heat = rs.uniform(1e-4, 0.2, (B, C, H, W)).astype(np.float32)
+        heat[:, ::6] = rs.uniform(0.5, 0.9, (B, 10, H, W)).astype(np.float32)
+    wh = rs.uniform(2, 40, (B, 2, H, W)).astype(np.float32)
+    reg = rs.uniform(0, 1, (B, 2, H, W)).astype(np.float32)
+    got = decode_detection(T(heat), T(wh), reg=T(reg), K=K).cpu().numpy()
+    want = od.decode_detection(heat, wh, reg, K=K)
+    assert np.array_equal(got[..., 4:], want[..., 4:])
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-5)
+
+
 def test_negative_and_zero_scores_general_path():
     # not the reference's call path (scores are probabilities there), but the kernel defines it: Q9's literal formula
     from backends.decode import _topk
