@@ -198,6 +198,59 @@ __global__ __launch_bounds__(kT) void dwconvt_fwd_f_kernel(const float* __restri
         *reinterpret_cast<float4*>(y + at) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
+// k = 4, stride 2, padding 1 (every IDAUp layer of DLA-34 but one), H and W even: a thread produces a 4 x 4 block of
+// outputs from the 4 x 4 block of inputs around it -- twelve loads (per input row one aligned 8-byte load and two edge
+// scalars) instead of sixty-four bounds-checked ones; the taps of an output are added in the generic kernels' order
+// (a = 0, 1 over rows, b = 0, 1 over columns), so the result is theirs bit for bit.
+__global__ __launch_bounds__(kT) void dwconvt_fwd_k4s2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ skip, float* __restrict__ y, int C,
+                                                              int H, int W) {
+    __shared__ float ws[16];
+    const int pl = blockIdx.y, c = pl % C;
+    if (threadIdx.x < 16) ws[threadIdx.x] = w[(size_t)c * 16 + threadIdx.x];
+    __syncthreads();
+    const int Wo = 2 * W, qw = W >> 1;                     // blocks of 4 x 4 outputs: (H / 2) x (W / 2)
+    const int q = blockIdx.x * kT + threadIdx.x;
+    if (q >= qw * (H >> 1)) return;
+    const int br = q / qw, bc = q - br * qw;
+    const float* xp = x + (size_t)pl * H * W;
+    float xin[4][4];                                        // input rows 2 br - 1 .. + 2, columns 2 bc - 1 .. + 2
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int iy = 2 * br - 1 + a;
+        xin[a][0] = xin[a][1] = xin[a][2] = xin[a][3] = 0.0f;
+        if (iy >= 0 && iy < H) {
+            const float* row = xp + (size_t)iy * W + 2 * bc;
+            const float2 m = *reinterpret_cast<const float2*>(row);
+            xin[a][1] = m.x; xin[a][2] = m.y;
+            if (bc > 0) xin[a][0] = row[-1];
+            if (2 * bc + 2 < W) xin[a][3] = row[2];
+        }
+    }
+    // output j of the block (row or column alike): first tap input index r0[j] with kernel index k0[j], second tap
+    // input index r0[j] - 1 with kernel index k0[j] + 2
+    constexpr int r0[4] = {1, 2, 2, 3}, k0[4] = {1, 0, 1, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc += xin[r0[j] - a][r0[i] - b] * ws[(k0[j] + 2 * a) * 4 + k0[i] + 2 * b];
+            o[i] = acc;
+        }
+        const size_t at = (size_t)pl * (2 * H) * Wo + (size_t)(4 * br + j) * Wo + 4 * bc;
+        if (skip) {
+            const float4 k4 = *reinterpret_cast<const float4*>(skip + at);
+            o[0] += k4.x; o[1] += k4.y; o[2] += k4.z; o[3] += k4.w;
+        }
+        *reinterpret_cast<float4*>(y + at) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
 // Both gradients read the same K x K window of gy around an input pixel:
 //   gx[b,c,iy,ix]  = sum_{ky,kx} gy[b,c,iy*s-p+ky, ix*s-p+kx] * w[c,ky,kx]
 //   gw[c,ky,kx]    = sum_{b,iy,ix} x[b,c,iy,ix] * gy[b,c,iy*s-p+ky, ix*s-p+kx]
@@ -640,7 +693,10 @@ extern "C" int cnuda_dwconvt2d_add_forward(const float* x, const float* w, const
     const bool upsample = k == 2 * s && p == s / 2 && (s == 2 || s == 4) && Wo % 4 == 0;   // IDAUp's bilinear-style layers
     const int rows = (upsample && Ho % 4 == 0 && (long long)Ho * Wo >= 4096) ? 4 : 1;
     const dim3 fgrid(ceil_div((long long)Ho * Wo / 4 / rows, kT), B * C);
-    if (upsample && s == 2 && rows == 4)
+    if (upsample && s == 2 && rows == 4 && (H & 1) == 0 && (W & 1) == 0)
+        hipLaunchKernelGGL(dwconvt_fwd_k4s2_kernel, dim3(ceil_div((long long)(H / 2) * (W / 2), kT), B * C), dim3(kT), 0,
+                           (hipStream_t)stream, x, w, skip, y, C, H, W);
+    else if (upsample && s == 2 && rows == 4)
         hipLaunchKernelGGL((dwconvt_fwd_f_kernel<2, 4>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
     else if (upsample && s == 2)
         hipLaunchKernelGGL((dwconvt_fwd_f_kernel<2, 1>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
