@@ -693,7 +693,8 @@ extern "C" int cnuda_dwconvt2d_add_forward(const float* x, const float* w, const
     const bool upsample = k == 2 * s && p == s / 2 && (s == 2 || s == 4) && Wo % 4 == 0;   // IDAUp's bilinear-style layers
     const int rows = (upsample && Ho % 4 == 0 && (long long)Ho * Wo >= 4096) ? 4 : 1;
     const dim3 fgrid(ceil_div((long long)Ho * Wo / 4 / rows, kT), B * C);
-    if (upsample && s == 2 && rows == 4 && (H & 1) == 0 && (W & 1) == 0)
+    const bool aligned16 = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)skip) & 15) == 0;      // (8-byte loads of x, 16 of y)
+    if (upsample && s == 2 && rows == 4 && (H & 1) == 0 && (W & 1) == 0 && aligned16)
         hipLaunchKernelGGL(dwconvt_fwd_k4s2_kernel, dim3(ceil_div((long long)(H / 2) * (W / 2), kT), B * C), dim3(kT), 0,
                            (hipStream_t)stream, x, w, skip, y, C, H, W);
     else if (upsample && s == 2 && rows == 4)
@@ -774,7 +775,8 @@ extern "C" int cnuda_dwconvt2d_backward(const float* x, const float* w, const fl
                           "cnuda_dwconvt2d_backward: workspace too small");
             part = (float*)workspace;
         }
-        if (k == 4 && s == 2 && p == 1 && (W & 1) == 0)
+        if (k == 4 && s == 2 && p == 1 && (W & 1) == 0 &&
+            (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x) & 15) == 0)
             hipLaunchKernelGGL(dwconvt_bwd_k4s2_kernel, dim3(C, B), dim3(kT), 0, st, x, w, grad_y, grad_x, part, B, C, H, W);
         else if (k == 4)
             hipLaunchKernelGGL(dwconvt_bwd_kernel<4>, dim3(C, B), dim3(kT), 0, st, x, w, grad_y, grad_x, part, B, C, H, W,
@@ -819,6 +821,8 @@ extern "C" int cnuda_conv1x1_backward_data_act(const float* grad_y, const float*
     CNUDA_REQUIRE(Co >= 1 && Co <= 8, "cnuda_conv1x1_backward_data_act: %d output channels (1..8 are built)", Co);
     CNUDA_REQUIRE((HW & 3) == 0 && B <= 65535, "cnuda_conv1x1_backward_data_act: plane size %lld not a multiple of 4",
                   HW);
+    CNUDA_REQUIRE((((uintptr_t)grad_y | (uintptr_t)hidden | (uintptr_t)grad_hidden) & 15) == 0,
+                  "cnuda_conv1x1_backward_data_act: tensors must be 16-byte aligned");
     // enough workgroups for the chip: channel chunks of >= 32 until there are ~2048
     const long long quads = ceil_div(HW / 4, kT);
     int chunks = 1;

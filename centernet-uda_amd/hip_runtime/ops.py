@@ -143,6 +143,8 @@ class _ConvActConv1x1(Function):
         g1, g2 = ctx.g1, ctx.g2
         L = lib()
         gy = f32c(gy)
+        if gy.data_ptr() % 16:                 # (a view at an odd offset: the fused pass reads 16 bytes at a time)
+            gy = gy.clone()
         B, C, H, W, Ch, kh, kw = g1[:7]
         Co, Ho, Wo = g2[4], hidden.shape[2], hidden.shape[3]
         gx = gw1 = gb1 = gw2 = gb2 = None
