@@ -570,11 +570,13 @@ bool wgrad_buffer_ok(const ConvGeom& g) {
            (long long)g.Ho * g.Wo < (1 << 23);
 }
 
-// largest tile that still gives the chip >= ~2 workgroups per CU (small feature maps: 16x16 / 32x32)
+// largest tile that still gives every CU a workgroup (small feature maps: 16x16 / 32x32).  (Round 3: two per CU --
+// 512 -- measured 0.2 ms per step and 1.5 % per inference batch slower: the 32-row tile it forces on the 512-channel
+// level at batch 16 runs at 80 TFLOP/s, one 64-row workgroup per CU at more.)
 int pick_bm(int M, long long N) {
     int bm = M > 64 ? 128 : (M > 32 ? 64 : 32);
     const long long n_tiles = (N + IG_BN - 1) / IG_BN;
-    while (bm > 32 && n_tiles * ((M + bm - 1) / bm) < 512) bm >>= 1;
+    while (bm > 32 && n_tiles * ((M + bm - 1) / bm) < 256) bm >>= 1;
     return bm;
 }
 
