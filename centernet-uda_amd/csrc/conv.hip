@@ -570,13 +570,13 @@ bool wgrad_buffer_ok(const ConvGeom& g) {
            (long long)g.Ho * g.Wo < (1 << 23);
 }
 
-// largest tile that still gives every CU a workgroup (small feature maps: 16x16 / 32x32).  (Round 3: two per CU --
-// 512 -- measured 0.2 ms per step and 1.5 % per inference batch slower: the 32-row tile it forces on the 512-channel
-// level at batch 16 runs at 80 TFLOP/s, one 64-row workgroup per CU at more.)
+// largest tile that still fills the chip (small feature maps: 16x16 / 32x32): the 128-row tile wants two workgroups
+// per CU, the 64-row tile is still the better choice with one (round 3: the 32-row tile this used to force on the
+// 512-channel level at batch 16 runs at 80 TFLOP/s; -1.5 % per inference batch)
 int pick_bm(int M, long long N) {
     int bm = M > 64 ? 128 : (M > 32 ? 64 : 32);
     const long long n_tiles = (N + IG_BN - 1) / IG_BN;
-    while (bm > 32 && n_tiles * ((M + bm - 1) / bm) < 256) bm >>= 1;
+    while (bm > 32 && n_tiles * ((M + bm - 1) / bm) < (bm == 128 ? 512 : 256)) bm >>= 1;
     return bm;
 }
 
