@@ -167,7 +167,8 @@ def test_maxpool(shape, k):
     assert torch.equal(dx.grad.cpu(), x.grad)
 
 
-@pytest.mark.parametrize('C,H,W,f', [(8, 5, 6, 2), (64, 4, 4, 4), (3, 3, 5, 8), (4, 3, 5, 2), (16, 32, 32, 2), (16, 16, 16, 4)])
+@pytest.mark.parametrize('C,H,W,f', [(8, 5, 6, 2), (64, 4, 4, 4), (3, 3, 5, 8), (4, 3, 5, 2), (16, 32, 32, 2), (16, 16, 16, 4),
+                                     (4, 34, 36, 2), (4, 33, 36, 2), (5, 64, 32, 2), (3, 32, 34, 2)])
 def test_depthwise_conv_transpose(C, H, W, f):
     from hip_runtime import ops
     g = torch.Generator().manual_seed(6)
