@@ -20,7 +20,8 @@ def _rel(a, b):
     return (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), 1e-30)
 
 
-@pytest.mark.parametrize('shape', [(4, 16, 10, 12), (6, 5, 7, 7), (2, 64, 2, 2), (8, 32, 33, 31)])
+@pytest.mark.parametrize('shape', [(4, 16, 10, 12), (6, 5, 7, 7), (2, 64, 2, 2), (8, 32, 33, 31),
+                                   (16, 512, 4, 4)])             # (last: several images per workgroup, 2 groups of 8)
 @pytest.mark.parametrize('relu,res', [(False, False), (True, True)])
 def test_grouped_batch_norm_equals_two_calls(shape, relu, res):
     from hip_runtime import ops

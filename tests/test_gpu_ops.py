@@ -67,7 +67,7 @@ def test_conv2d_fwd_bwd(name):
 
 
 @pytest.mark.parametrize('relu,res', [(False, False), (True, False), (True, True), (False, True)])
-@pytest.mark.parametrize('shape', [(2, 16, 10, 12), (3, 5, 7, 7), (1, 64, 2, 2)])
+@pytest.mark.parametrize('shape', [(2, 16, 10, 12), (3, 5, 7, 7), (1, 64, 2, 2), (16, 512, 4, 4)])   # (last: 4 images per workgroup)
 def test_batch_norm_train_fwd_bwd_and_running_stats(shape, relu, res):
     from hip_runtime import ops
     g = torch.Generator().manual_seed(3)
@@ -100,7 +100,7 @@ def test_batch_norm_train_fwd_bwd_and_running_stats(shape, relu, res):
 
 
 @pytest.mark.parametrize('shape,relu', [((4, 16, 8, 12), True), ((2, 5, 7, 9), True), ((3, 8, 16, 16), 'relu6'),
-                                        ((2, 32, 64, 64), True)])
+                                        ((2, 32, 64, 64), True), ((16, 512, 4, 4), True)])
 def test_batch_norm_backward_gate_recomputed_from_x_is_the_gate_read_from_y(shape, relu):
     """Without a residual the backward passes recompute the activation's gate from x (the forward's own multiply and
     add) instead of reading y: every output must be bit-identical to the y-reading form of the same entry point."""
