@@ -249,6 +249,20 @@ def test_head_pair_is_one_tape_node_with_the_two_layers_values(B, C, Ch, Co, H, 
     assert not type(head(odd).grad_fn).__name__.startswith('_ConvActConv1x1')
 
 
+def test_launch_stream_is_torchs_current_stream():
+    """hip_runtime.stream() (the raw handle from torch's C layer) follows torch's current stream, also inside a
+    `torch.cuda.stream(...)` context and on the workspace key."""
+    import hip_runtime as hr
+    assert (hr.stream().value or 0) == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert (hr.stream().value or 0) == side.cuda_stream
+        a = hr.workspace(1024, torch.device(DEV))
+    b = hr.workspace(1024, torch.device(DEV))
+    assert a.data_ptr() != b.data_ptr()                  # one scratch buffer per stream
+    assert (hr.stream().value or 0) == torch.cuda.current_stream().cuda_stream
+
+
 def test_cat_add_split():
     from hip_runtime import ops
     g = torch.Generator().manual_seed(7)
