@@ -263,7 +263,7 @@ __global__ void nms_kernel(const float* __restrict__ heat, float* __restrict__ o
 // value above the threshold is taken, and of the values EQUAL to it the ones with the lowest pixel indices (the
 // order the 64-bit keys define).  Nothing is re-read from global memory and the NMS is not recomputed: plateaus
 // (a trained model's background is clamped to exactly 1e-4, so whole regions survive the NMS) and maps with fewer
-// than K or more than kPool survivors cost the same as any other map.  Result: s.sel[0..K) sorted descending.
+// than K positive scores cost the same as any other map.  Result: s.sel[0..K) sorted descending (rank sort).
 template <int NT>
 __device__ void lds_plane_topk(const uint32_t* __restrict__ bits, int n, int K, int KP, SelectScratch& s,
                                int* __restrict__ whist /* [NT/64][256] */, int* __restrict__ wcnt /* [2][NT/64] */) {
