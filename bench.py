@@ -274,24 +274,24 @@ def other_configs(device, skip):
     return res
 
 
-def csrc_fingerprint():
-    """sha256 (16 hex digits) over the kernel sources: says whether a committed counter profile was collected
-    from the kernels this run executes."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, 'centernet-uda_amd', 'csrc', '*.hip')) +
-                    glob.glob(os.path.join(ROOT, 'centernet-uda_amd', 'csrc', '*.cuh')) +
-                    glob.glob(os.path.join(ROOT, 'centernet-uda_amd', 'csrc', '*.h'))):
-        h.update(open(f, 'rb').read())
-    return h.hexdigest()[:16]
+def code_fingerprint():
+    """sha256 (16 hex digits) over the gfx950 code objects inside libcenternet_uda_hip.so (profiles/fingerprint.py):
+    says whether a committed counter profile was collected from the kernels this run EXECUTES.  Comment or
+    whitespace edits of the sources do not change it (round 3 hashed the source text and a comment-only commit
+    disowned the profile)."""
+    sys.path.insert(0, os.path.join(ROOT, 'profiles'))
+    try:
+        import fingerprint
+        return fingerprint.code_fingerprint()
+    finally:
+        sys.path.pop(0)
 
 
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 counter profile (separate
     `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command, profiles/collect_pmc_traffic.sh).  PMC
     passes cannot run inside the timed process, so the note says whether that profile was collected from the
-    kernel sources this run executes."""
+    kernel code this run executes (code_fingerprint)."""
     import glob
     import re
     files = glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json'))
@@ -307,13 +307,14 @@ def pmc_traffic(kernel_name):
     t = {norm(k): v for k, v in data.items() if k != '_meta'}.get(norm(kernel_name.split(' (')[0].split(' [')[0]))
     if not t:
         return None, '%s has no entry for this kernel' % os.path.basename(path)
-    same = meta.get('csrc_sha16') == csrc_fingerprint()
+    mine = code_fingerprint()
+    same = meta.get('code_sha16') == mine
     fetch = t['fetch_kb_per_launch'] * (2.0 if meta.get('fetch_doubled_for_wide_reads') else 1.0)
     note = ('bytes/launch = FETCH_SIZE + WRITE_SIZE from profiles/%s, %s'
             % (os.path.basename(path),
-               'collected from the kernel sources of this run' if same else
-               'COLLECTED FROM DIFFERENT KERNEL SOURCES (profile %s, this run %s): indicative only'
-               % (meta.get('csrc_sha16', 'unknown: pre-round-2 profile'), csrc_fingerprint())))
+               'collected from the kernel code this run executes (code object %s)' % mine if same else
+               'COLLECTED FROM DIFFERENT KERNEL CODE (profile %s, this run %s): indicative only'
+               % (meta.get('code_sha16', 'unknown: pre-round-4 profile'), mine)))
     return round((fetch + t['write_kb_per_launch']) * 1024), note
 
 

@@ -66,7 +66,7 @@ def _fold_stamp(module):
     the folded copy's own, and the generation of the fold (a re-fold may land on a recycled address)."""
     import hip_runtime as hr
     if not hasattr(module, '_fold_token'):
-        module._fold_token = hr.new_pack_token()
+        module._fold_token = hr.PackToken()
     _FOLD_GEN[0] += 1
     module._fold_gen = _FOLD_GEN[0]
 
@@ -170,7 +170,7 @@ class BasicBlock(nn.Module):
         self._fold = _folded(self.conv1.weight, None, self.bn1) + _folded(self.conv2.weight, None, self.bn2)
         _fold_stamp(self)
         if not hasattr(self, '_fold_token2'):          # one identity per folded weight: two of one shape under one
-            self._fold_token2 = hr.new_pack_token()    # token would keep taking over each other's packed image
+            self._fold_token2 = hr.PackToken()         # token would keep taking over each other's packed image
 
     def forward(self, x, residual=None):
         if _use_folded(self):

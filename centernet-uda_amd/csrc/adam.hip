@@ -35,7 +35,7 @@ extern "C" int cnuda_adam_step(float* param, const float* grad, float* exp_avg, 
     CNUDA_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "cnuda_adam_step: bad arguments");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+    CNUDA_LAUNCH(adam_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n, (float)((double)lr / bc1), beta1, beta2, (float)sqrt(bc2), eps, weight_decay);
     return check_launch("cnuda_adam_step");
 }

@@ -53,6 +53,13 @@ __device__ __forceinline__ float bn_act(float v, int relu) {
 }
 __device__ __forceinline__ bool bn_pass(float y, int relu) { return y > 0.0f && (relu != 2 || y < 6.0f); }
 
+// The normalisation as the forward applies it, y = x * sc + sh with sc = invstd * gamma and sh = beta - mean * sc: ONE
+// rounded multiply and ONE rounded add, spelled with the explicit-rounding intrinsics so that no compiler flag or
+// optimisation level can contract them into an fma in one kernel and not in another.  The backward kernels recompute
+// the activation's gate from x with these same two functions: the sign they see is the forward's, bit for bit.
+__device__ __forceinline__ float bn_shift(float beta, float mean, float sc) { return __fsub_rn(beta, __fmul_rn(mean, sc)); }
+__device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return __fadd_rn(__fmul_rn(x, sc), sh); }
+
 // partial[(c*S + s)*2 + {0,1}] = sum(v), sum(v*w) over one chunk of one (b, c) plane
 // MODE 0: v = x, w = x                       (forward statistics)
 // MODE 1: v = dy', w = xhat                   (backward), dy' = dy * (y > 0) when relu
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
     float mu = 0.f, is = 0.f, sc = 0.f, sh = 0.f;
     if (MODE == 1) { mu = mean[grp * C + c]; is = invstd[grp * C + c]; }
     const bool regate = MODE == 1 && relu && beta != nullptr;
-    if (regate) { sc = is * gamma[c]; sh = beta[c] - mu * sc; }
+    if (regate) { sc = __fmul_rn(is, gamma[c]); sh = bn_shift(beta[c], mu, sc); }
     auto acc = [&](float xv, float gv, float yv) {
         if (MODE == 0) {
             const double v = (double)xv;
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(
             a1 += v * v;
         } else {
             float g = gv;
-            if (relu && !bn_pass(regate ? xv * sc + sh : yv, relu)) g = 0.0f;
+            if (relu && !bn_pass(regate ? bn_affine(xv, sc, sh) : yv, relu)) g = 0.0f;
             const float xh = (xv - mu) * is;
             a0 += (double)g;
             a1 += (double)g * (double)xh;
@@ -184,8 +191,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
         }
     }
     __syncthreads();
-    const float sc = stat[1] * gamma[c];
-    const float sh = beta[c] - stat[0] * sc;
+    const float sc = __fmul_rn(stat[1], gamma[c]);
+    const float sh = bn_shift(beta[c], stat[0], sc);
     const long long start = (long long)blockIdx.y * kBnThreads * 4 + threadIdx.x * 4;
     const long long stride = (long long)gridDim.y * kBnThreads * 4;
     for (int img = b; img < b + ips; ++img) {
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
     if ((HW & 3) == 0) {
         for (long long i = start; i < HW; i += stride) {
             float4 v = *reinterpret_cast<const float4*>(x + base + i);
-            v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+            v.x = bn_affine(v.x, sc, sh); v.y = bn_affine(v.y, sc, sh); v.z = bn_affine(v.z, sc, sh); v.w = bn_affine(v.w, sc, sh);
             if (residual) {
                 const float4 r = *reinterpret_cast<const float4*>(residual + base + i);
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
     } else {
         for (long long i0 = start; i0 < HW; i0 += stride)
             for (long long i = i0; i < i0 + 4 && i < HW; ++i) {
-                float v = x[base + i] * sc + sh;
+                float v = bn_affine(x[base + i], sc, sh);
                 if (residual) v += residual[base + i];
                 if (relu) v = bn_act(v, relu);
                 y[base + i] = v;
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
     const float mu = mean[grp * C + c], is = invstd[grp * C + c];
     const float k = gamma[c] * is;
     const bool regate = relu && beta != nullptr;
-    const float sc = is * gamma[c], sh = regate ? beta[c] - mu * sc : 0.0f;
+    const float sc = __fmul_rn(is, gamma[c]), sh = regate ? bn_shift(beta[c], mu, sc) : 0.0f;
     const float inv_n = 1.0f / (float)count;
     const float m0 = stat[0] * inv_n, m1 = stat[1] * inv_n;
     for (int img = b; img < b + ips; ++img) {
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
             const float4 xv = *reinterpret_cast<const float4*>(x + base + i);
             if (relu) {
                 float4 yv;
-                if (regate) yv = make_float4(xv.x * sc + sh, xv.y * sc + sh, xv.z * sc + sh, xv.w * sc + sh);
+                if (regate) yv = make_float4(bn_affine(xv.x, sc, sh), bn_affine(xv.y, sc, sh), bn_affine(xv.z, sc, sh), bn_affine(xv.w, sc, sh));
                 else yv = *reinterpret_cast<const float4*>(y + base + i);
                 if (!bn_pass(yv.x, relu)) g.x = 0.0f;
                 if (!bn_pass(yv.y, relu)) g.y = 0.0f;
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_apply_kernel(
     }
     for (long long i = (long long)blockIdx.y * kBnThreads + threadIdx.x; i < HW; i += (long long)gridDim.y * kBnThreads) {
         float g = dy[base + i];
-        if (relu && !bn_pass(regate ? x[base + i] * sc + sh : y[base + i], relu)) g = 0.0f;
+        if (relu && !bn_pass(regate ? bn_affine(x[base + i], sc, sh) : y[base + i], relu)) g = 0.0f;
         const float xh = (x[base + i] - mu) * is;
         gx[base + i] = k * (g - m0 - xh * m1);
         if (gres) gres[base + i] = g;
@@ -341,12 +348,12 @@ extern "C" int cnuda_bn_train_forward(const float* x, const float* gamma, const 
     hipStream_t st = (hipStream_t)stream;
     const Split sp = pick_split(B, C, HW, Bg);
     double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, (const float*)nullptr,
+    CNUDA_LAUNCH(bn_reduce_kernel<0>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, partial, C, HW,
                        sp.chunk, sp.per_plane, sp.ips, sp.S, 0, Bg);
     const long long planes = (long long)B * C / sp.ips;        // workgroups of the apply pass (x its plane splits)
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
+    CNUDA_LAUNCH(bn_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
                        dim3(kBnThreads), 0, st, x, partial, sp.S, count, momentum, eps, save_mean, save_invstd,
                        running_mean, running_var, num_batches_tracked, gamma, beta, residual, y, C, HW, relu, groups, Bg,
                        sp.per_plane, sp.ips);
@@ -359,7 +366,7 @@ extern "C" int cnuda_bn_eval_forward(const float* x, const float* gamma, const f
     CNUDA_REQUIRE(x && gamma && beta && running_mean && running_var && y, "cnuda_bn_eval_forward: null pointer");
     CNUDA_REQUIRE(B > 0 && C > 0 && HW > 0, "cnuda_bn_eval_forward: empty tensor");
     const long long planes = (long long)B * C;
-    hipLaunchKernelGGL(bn_eval_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads)), dim3(kBnThreads), 0,
+    CNUDA_LAUNCH(bn_eval_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads)), dim3(kBnThreads), 0,
                        (hipStream_t)stream, x, running_mean, running_var, gamma, beta, residual, y, C, HW, eps, relu);
     return check_launch("cnuda_bn_eval_forward");
 }
@@ -383,10 +390,10 @@ extern "C" int cnuda_bn_backward(const float* grad_y, const float* x, const floa
     const Split sp = pick_split(B, C, HW, Bg);
     uintptr_t base = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
     double* partial = reinterpret_cast<double*>(base);
-    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, grad_y, y, save_mean,
+    CNUDA_LAUNCH(bn_reduce_kernel<1>, dim3(C, sp.S), dim3(kBnThreads), 0, st, x, grad_y, y, save_mean,
                        save_invstd, gamma, beta, partial, C, HW, sp.chunk, sp.per_plane, sp.ips, sp.S, relu, Bg);
     const long long planes = (long long)B * C / sp.ips;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
+    CNUDA_LAUNCH(bn_bwd_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
                        dim3(kBnThreads), 0, st, grad_y, x, y, save_mean, save_invstd, gamma, beta, partial, sp.S, grad_gamma,
                        grad_beta, grad_x, grad_residual, C, HW, count, relu, groups, Bg, sp.per_plane, sp.ips);
     return check_launch("cnuda_bn_backward");

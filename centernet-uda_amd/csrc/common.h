@@ -50,6 +50,18 @@ public:
     ~ProfGroup();
 };
 
+// Launch log (tests/test_zz_kernel_coverage.py): while enabled through cnuda_launch_log_enable(1), every kernel
+// launch of the library records its host function pointer; cnuda_launch_log_collect resolves the distinct pointers to
+// the kernels' own symbol names (hipKernelNameRefByPtr, demangled) -- the names a rocprofv3 kernel trace shows.  One
+// predictable branch per launch otherwise.
+extern bool g_launch_log_on;
+void launch_log(const void* host_function);
+#define CNUDA_LAUNCH(kernel, grid, block, lds, st, ...)                                               \
+    do {                                                                                              \
+        if (::cnuda::g_launch_log_on) ::cnuda::launch_log(reinterpret_cast<const void*>(&kernel));    \
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                \
+    } while (0)
+
 #define CNUDA_REQUIRE(cond, ...)                 \
     do {                                         \
         if (!(cond)) {                           \

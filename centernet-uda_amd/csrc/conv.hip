@@ -628,7 +628,7 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
         static const bool shortk = !(getenv("CNUDA_SHORTK") && getenv("CNUDA_SHORTK")[0] == '0');
         if (shortk && matrix_mode() == 0 && bm == 128 && Kp <= 64 && m_tiles >= 2) {
             prof.name("igemm_fwd_shortk_kernel<128, %s, 64>", Loader::name());
-            hipLaunchKernelGGL((igemm_fwd_shortk_kernel<128, Loader, 64>), dim3(n_tiles), block, 0, st, p, A, Mp, Kp, M, N,
+            CNUDA_LAUNCH((igemm_fwd_shortk_kernel<128, Loader, 64>), dim3(n_tiles), block, 0, st, p, A, Mp, Kp, M, N,
                                n_tiles, m_tiles);
             return check_launch(who);
         }
@@ -639,15 +639,15 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     if (matrix_mode() == 1) {
         // the caller's A buffer has ig_a_bytes() of room: split image behind the f32 matrix
         float* A3 = const_cast<float*>(A) + (size_t)Kp * Mp;
-        hipLaunchKernelGGL(split_a_kernel, dim3(stream_grid((long long)(Kp / 16) * 2 * Mp, 256)), dim3(256), 0, st, A,
+        CNUDA_LAUNCH(split_a_kernel, dim3(stream_grid((long long)(Kp / 16) * 2 * Mp, 256)), dim3(256), 0, st, A,
                            reinterpret_cast<u32x4*>(A3), Kp, Mp);
         A = A3;
         if (bm == 128)
-            hipLaunchKernelGGL((igemm_fwd_kernel<128, Loader, true>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+            CNUDA_LAUNCH((igemm_fwd_kernel<128, Loader, true>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         else if (bm == 64)
-            hipLaunchKernelGGL((igemm_fwd_kernel<64, Loader, true>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+            CNUDA_LAUNCH((igemm_fwd_kernel<64, Loader, true>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         else
-            hipLaunchKernelGGL((igemm_fwd_kernel<32, Loader, true>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+            CNUDA_LAUNCH((igemm_fwd_kernel<32, Loader, true>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         return check_launch(who);
     }
     // wave-specialised variant (igemm.cuh): +4-8 % on the 64- and 128-row tiles of the 128..512-channel layers,
@@ -655,17 +655,17 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     if (wave_specialised() && bm >= 64) {
         const dim3 block2(2 * IG_THREADS);
         if (bm == 128)
-            hipLaunchKernelGGL((igemm_fwd_ws_kernel<128, Loader>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+            CNUDA_LAUNCH((igemm_fwd_ws_kernel<128, Loader>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         else
-            hipLaunchKernelGGL((igemm_fwd_ws_kernel<64, Loader>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+            CNUDA_LAUNCH((igemm_fwd_ws_kernel<64, Loader>), grid, block2, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
         return check_launch(who);
     }
     if (bm == 128)
-        hipLaunchKernelGGL((igemm_fwd_kernel<128, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        CNUDA_LAUNCH((igemm_fwd_kernel<128, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
     else if (bm == 64)
-        hipLaunchKernelGGL((igemm_fwd_kernel<64, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        CNUDA_LAUNCH((igemm_fwd_kernel<64, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
     else
-        hipLaunchKernelGGL((igemm_fwd_kernel<32, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+        CNUDA_LAUNCH((igemm_fwd_kernel<32, Loader>), grid, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles);
     return check_launch(who);
 }
 
@@ -808,56 +808,56 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
         if (buf) {
             const dim3 blk2(2 * IG_THREADS);
             if (q.wbm == 128 && q.wbj == 128 && wave_specialised())
-                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
             else if (q.wbm == 128 && q.wbj == 128)
-                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWBufLoader, 128, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 128, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
             else if (q.wbm == 128 && wave_specialised())
-                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
             else if (q.wbm == 128)
-                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWBufLoader, 128, 64>), grid, blk, 0, st, p, slabs, q.Mpw,
+                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 128, 64>), grid, blk, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
             else if (wave_specialised() && q.wbm == 64 && q.wbj == 128)
-                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
             else if (wave_specialised() && q.wbm == 64)
-                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
             else if (q.wbm == 64 && q.wbj == 128)
-                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWBufLoader, 64, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 64, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
             else if (q.wbm == 64)
-                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWBufLoader, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
+                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
                                    q.Nf, q.pix_per_split);
             else
-                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWBufLoader, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
         } else if (wave_specialised() && fast && q.wbm == 64) {
             const dim3 blk2(2 * IG_THREADS);
             if (q.wbj == 128)
-                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWLoader<2>, 64, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWLoader<2>, 64, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
             else
-                hipLaunchKernelGGL((igemm_wgrad_ws_kernel<ConvWLoader<2>, 64, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWLoader<2>, 64, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
         } else if (q.wbm == 64) {
             if (fast && q.wbj == 128)
-                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<2>, 64, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWLoader<2>, 64, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
             else if (fast)
-                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<2>, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
+                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWLoader<2>, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
                                    q.Nf, q.pix_per_split);
             else
-                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<0>, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
+                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWLoader<0>, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
                                    q.Nf, q.pix_per_split);
         } else {
             if (fast)
-                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<2>, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWLoader<2>, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
             else
-                hipLaunchKernelGGL((igemm_wgrad_kernel<ConvWLoader<0>, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWLoader<0>, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
                                    q.Jp, q.Nf, q.pix_per_split);
         }
     }

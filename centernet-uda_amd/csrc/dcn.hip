@@ -1166,6 +1166,9 @@ int pick_bm(int M, long long N) {
     return bm;
 }
 
+constexpr int kFusedMinTilesDefault = 512;
+int g_fused_min_tiles = kFusedMinTilesDefault;      // cnuda_dcn_set_fused_min_tiles (tests)
+
 struct DcnPlan {
     int T, K, Kp, bm, Mp;           // forward pack [Kp][Mp]
     int Mpw, Jp, Z;                 // wgrad slabs [Z][Mpw][Jp]
@@ -1220,7 +1223,7 @@ DcnPlan make_plan(const DcnGeom& g) {
     if ((size_t)CI_CG * q.WSZmax * 4 + 4096 + 4 * (size_t)q.claim_sz > 53 * 1024) { q.WSZmax = 0; q.claim_sz = 16; }
     q.col2im_lds = ((size_t)CI_CG * q.WSZmax + 4 * 256) * sizeof(float) + 4 * (size_t)q.claim_sz;
     // one workgroup per (image, tile) must still fill the chip (three resident per CU): the 128 x 128 and 64 x 64 maps
-    q.fused_consumers = q.WSZmax > 0 && g.W >= 2 && (long long)g.B * q.tiles_y * q.tiles_x >= 512;
+    q.fused_consumers = q.WSZmax > 0 && g.W >= 2 && (long long)g.B * q.tiles_y * q.tiles_x >= g_fused_min_tiles;
     q.fused_split = 4;     // measured 1..4 on the 128 x 128 / 64 x 64 layers: 1116/1077/1093/1064 and 716/645/611/584 us
     if (q.fused_split > q.ncg) q.fused_split = q.ncg;
     return q;
@@ -1230,6 +1233,12 @@ DcnPlan make_plan(const DcnGeom& g) {
 }  // namespace cnuda
 
 using namespace cnuda;
+
+extern "C" int cnuda_dcn_set_fused_min_tiles(int min_tiles) {
+    const int prev = g_fused_min_tiles;
+    g_fused_min_tiles = min_tiles < 1 ? kFusedMinTilesDefault : min_tiles;
+    return prev;
+}
 
 extern "C" size_t cnuda_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw,
                                                int ph, int pw, int dh, int dw, int dg) {
@@ -1270,7 +1279,7 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
     CNUDA_REQUIRE(act_slope < 0.0f || (dg == 1 && W >= 2), "cnuda_dcn_v2_forward_act: fused activation needs deformable_group == 1 and width >= 2");
     if (dg != 1 || W < 2) {   // the MFMA path samples horizontally adjacent pairs
         DcnNaiveParams p{g, input, weight, bias, offset, mask, nullptr, output, nullptr, nullptr, nullptr, nullptr};
-        hipLaunchKernelGGL(dcn_naive_fwd_kernel, dim3(stream_grid((long long)B * Cout * g.Ho * g.Wo, 256)), dim3(256),
+        CNUDA_LAUNCH(dcn_naive_fwd_kernel, dim3(stream_grid((long long)B * Cout * g.Ho * g.Wo, 256)), dim3(256),
                            0, st, p);
         return check_launch("cnuda_dcn_v2_forward(dg>1)");
     }
@@ -1292,26 +1301,26 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
         {
             DcnSampleParams sp{g, input, offset, mask, cols};
             const int tiles = ceil_div(g.Ho * g.Wo, 64), tw = q.T < 16 ? q.T : 16;
-            hipLaunchKernelGGL(dcn_sample_kernel, dim3(B * tiles), dim3(64, tw), 0, st, sp, tiles);
+            CNUDA_LAUNCH(dcn_sample_kernel, dim3(B * tiles), dim3(64, tw), 0, st, sp, tiles);
         }
         DcnColsParams p{g, cols, bias, act_slope, output};
         if (buf && q.bm == 128)
-            hipLaunchKernelGGL((igemm_fwd_kernel<128, DcnColsBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+            CNUDA_LAUNCH((igemm_fwd_kernel<128, DcnColsBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                                n_tiles, m_tiles);
         else if (buf && q.bm == 64)
-            hipLaunchKernelGGL((igemm_fwd_kernel<64, DcnColsBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+            CNUDA_LAUNCH((igemm_fwd_kernel<64, DcnColsBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                                n_tiles, m_tiles);
         else if (buf)
-            hipLaunchKernelGGL((igemm_fwd_kernel<32, DcnColsBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+            CNUDA_LAUNCH((igemm_fwd_kernel<32, DcnColsBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                                n_tiles, m_tiles);
         else if (q.bm == 128)
-            hipLaunchKernelGGL((igemm_fwd_kernel<128, DcnColsLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+            CNUDA_LAUNCH((igemm_fwd_kernel<128, DcnColsLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                                n_tiles, m_tiles);
         else if (q.bm == 64)
-            hipLaunchKernelGGL((igemm_fwd_kernel<64, DcnColsLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+            CNUDA_LAUNCH((igemm_fwd_kernel<64, DcnColsLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                                n_tiles, m_tiles);
         else
-            hipLaunchKernelGGL((igemm_fwd_kernel<32, DcnColsLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+            CNUDA_LAUNCH((igemm_fwd_kernel<32, DcnColsLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                                n_tiles, m_tiles);
         return check_launch("cnuda_dcn_v2_forward(columns + GEMM)");
     }
@@ -1319,22 +1328,22 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
     ProfScope prof(st);
     prof.name("igemm_fwd_kernel<%d, DcnFwdLoader>%s", q.bm, columns ? " (+ column side output)" : "");
     if (buf && q.bm == 128)
-        hipLaunchKernelGGL((igemm_fwd_kernel<128, DcnFwdBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+        CNUDA_LAUNCH((igemm_fwd_kernel<128, DcnFwdBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                            n_tiles, m_tiles);
     else if (buf && q.bm == 64)
-        hipLaunchKernelGGL((igemm_fwd_kernel<64, DcnFwdBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+        CNUDA_LAUNCH((igemm_fwd_kernel<64, DcnFwdBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                            n_tiles, m_tiles);
     else if (buf)
-        hipLaunchKernelGGL((igemm_fwd_kernel<32, DcnFwdBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+        CNUDA_LAUNCH((igemm_fwd_kernel<32, DcnFwdBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                            n_tiles, m_tiles);
     else if (q.bm == 128)
-        hipLaunchKernelGGL((igemm_fwd_kernel<128, DcnFwdLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+        CNUDA_LAUNCH((igemm_fwd_kernel<128, DcnFwdLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                            n_tiles, m_tiles);
     else if (q.bm == 64)
-        hipLaunchKernelGGL((igemm_fwd_kernel<64, DcnFwdLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+        CNUDA_LAUNCH((igemm_fwd_kernel<64, DcnFwdLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                            n_tiles, m_tiles);
     else
-        hipLaunchKernelGGL((igemm_fwd_kernel<32, DcnFwdLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
+        CNUDA_LAUNCH((igemm_fwd_kernel<32, DcnFwdLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                            n_tiles, m_tiles);
     return check_launch("cnuda_dcn_v2_forward");
 }
@@ -1375,7 +1384,7 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
         (void)hipMemsetAsync(grad_weight, 0, (size_t)Cout * C * T * sizeof(float), st);
         DcnNaiveParams p{g, input, weight, nullptr, offset, mask, grad_output, nullptr,
                          grad_input, grad_offset, grad_mask, grad_weight};
-        hipLaunchKernelGGL(dcn_naive_bwd_kernel, dim3(stream_grid((long long)B * C * T * HoWo, 256)), dim3(256), 0, st,
+        CNUDA_LAUNCH(dcn_naive_bwd_kernel, dim3(stream_grid((long long)B * C * T * HoWo, 256)), dim3(256), 0, st,
                            p);
         return check_launch("cnuda_dcn_v2_backward(dg>1)");
     }
@@ -1406,21 +1415,21 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
                              (size_t)B * Cout * HoWo * sizeof(float) < IG_BUF_OOB && HoWo < (1 << 23);
             wscope.name("igemm_wgrad_kernel<%s, 64, %d>", buf ? "DcnColWBufLoader" : "DcnColWLoader", q.Jp % 128 == 0 ? 128 : 64);
             if (buf && q.Jp % 128 == 0)
-                hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
+                CNUDA_LAUNCH((igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
                                    dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
             else if (buf)
-                hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWBufLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+                CNUDA_LAUNCH((igemm_wgrad_kernel<DcnColWBufLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
                                    dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
             else if (q.Jp % 128 == 0)
-                hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
+                CNUDA_LAUNCH((igemm_wgrad_kernel<DcnColWLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
                                    dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
             else
-                hipLaunchKernelGGL((igemm_wgrad_kernel<DcnColWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+                CNUDA_LAUNCH((igemm_wgrad_kernel<DcnColWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
                                    dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
         } else {
             DcnWParams p{g, input, offset, mask, grad_output};
             wscope.name("igemm_wgrad_kernel<DcnWLoader, 64, 64>");
-            hipLaunchKernelGGL((igemm_wgrad_kernel<DcnWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+            CNUDA_LAUNCH((igemm_wgrad_kernel<DcnWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
                                dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
         }
       }
@@ -1434,7 +1443,7 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
             const int wt_blocks = stream_grid((long long)q.T * C * Cout, 256);
             const int geo_blocks = q.fused_consumers ? stream_grid((long long)B * q.T * HoWo, 256) : 0;
             DcnPrepParams pp{g, weight, offset, mask, wt, q.fused_consumers ? geo : nullptr, wt_blocks};
-            hipLaunchKernelGGL(dcn_prep_kernel, dim3(wt_blocks + geo_blocks), dim3(256), 0, st, pp);
+            CNUDA_LAUNCH(dcn_prep_kernel, dim3(wt_blocks + geo_blocks), dim3(256), 0, st, pp);
         }
         if (int rc = cnuda_conv2d_forward(grad_output, wt, nullptr, dcol, B, Cout, g.Ho, g.Wo, q.T * C, 1, 1, 1, 1, 0,
                                           0, -1.0f, gemm_ws, q.gemm_bytes, stream))
@@ -1445,14 +1454,14 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
             const int n_wg = B * q.tiles_y * q.tiles_x * q.fused_split;
             ProfScope scope(st, 3);
             scope.name("dcn_bwd_data_kernel");
-            hipLaunchKernelGGL(dcn_bwd_data_kernel, dim3(n_wg), dim3(512), q.col2im_lds, st, p, n_wg);
+            CNUDA_LAUNCH(dcn_bwd_data_kernel, dim3(n_wg), dim3(512), q.col2im_lds, st, p, n_wg);
         } else {
             {
                 DcnCoordParams p{g, input, offset, mask, dcol, grad_offset, grad_mask, geo};
                 const int tiles = ceil_div(HoWo, 64), tw = q.T < 16 ? q.T : 16;
                 ProfScope scope(st, 1);
                 scope.name("dcn_coord_grad_kernel");
-                hipLaunchKernelGGL(dcn_coord_grad_kernel, dim3(B * tiles), dim3(64, tw), 0, st, p, tiles);
+                CNUDA_LAUNCH(dcn_coord_grad_kernel, dim3(B * tiles), dim3(64, tw), 0, st, p, tiles);
             }
             {
                 DcnCol2imParams p{g, dcol, geo, grad_input, q.TR, q.TC, q.tc_shift, q.tiles_y, q.tiles_x,
@@ -1460,7 +1469,7 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
                 const int n_wg = B * q.tiles_y * q.tiles_x * q.ncg;
                 ProfScope scope(st, 2);
                 scope.name("dcn_col2im_kernel");
-                hipLaunchKernelGGL(dcn_col2im_kernel, dim3(n_wg), dim3(256), q.col2im_lds, st, p, n_wg);
+                CNUDA_LAUNCH(dcn_col2im_kernel, dim3(n_wg), dim3(256), q.col2im_lds, st, p, n_wg);
             }
         }
         if (int rc = check_launch("cnuda_dcn_v2_backward(data)")) return rc;

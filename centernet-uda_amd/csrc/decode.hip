@@ -794,7 +794,7 @@ extern "C" int cnuda_nms(const float* heat, float* out, int B, int C, int H, int
     CNUDA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "cnuda_nms: empty tensor");
     CNUDA_REQUIRE(nms_size >= 1 && (nms_size & 1), "cnuda_nms: nms_size must be odd, got %d", nms_size);
     const long long total = (long long)B * C * H * W;
-    hipLaunchKernelGGL(nms_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+    CNUDA_LAUNCH(nms_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        heat, out, (long long)B * C, H, W, (nms_size - 1) / 2);
     return check_launch("cnuda_nms");
 }
@@ -829,14 +829,14 @@ extern "C" int cnuda_decode_detection(const float* heat, const float* wh, const 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(plane_topk_kernel, dim3(B * C), dim3(kPlaneThreads), lds_plane ? bits_bytes : 0, st, heat, cand,
+    CNUDA_LAUNCH(plane_topk_kernel, dim3(B * C), dim3(kPlaneThreads), lds_plane ? bits_bytes : 0, st, heat, cand,
                        H, W, K, KP, pad, lds_plane);
     int rc = check_launch("cnuda_decode_detection(stage 1)");
     if (rc) return rc;
     // stage 2 keeps an image's C*K candidates in LDS when they fit beside its 42 KB of static arrays
     const size_t cand_bytes = (size_t)C * K * sizeof(uint64_t);
     const int lds_cand = cand_bytes <= 112 * 1024 ? 1 : 0;
-    hipLaunchKernelGGL(merge_decode_kernel, dim3(B), dim3(kThreads), lds_cand ? cand_bytes : 0, st,
+    CNUDA_LAUNCH(merge_decode_kernel, dim3(B), dim3(kThreads), lds_cand ? cand_bytes : 0, st,
                        cand, wh, reg, dets, inds, C, H, W, K, KP, wh_ch, rotated ? 1 : 0, lds_cand);
     return check_launch("cnuda_decode_detection(stage 2)");
 }

@@ -453,15 +453,15 @@ extern "C" int cnuda_focal_loss_forward(const float* logits, const float* gt, fl
     int blocks = stream_grid(n, kT);
     if (blocks > kLossBlocks) blocks = kLossBlocks;
     double* partial = ws_ptr(workspace);
-    hipLaunchKernelGGL(focal_fwd_kernel, dim3(blocks), dim3(kT), 0, st, logits, gt, prob, partial, n);
-    hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(kT), 0, st, partial, blocks, weight, out2);
+    CNUDA_LAUNCH(focal_fwd_kernel, dim3(blocks), dim3(kT), 0, st, logits, gt, prob, partial, n);
+    CNUDA_LAUNCH(focal_finalize_kernel, dim3(1), dim3(kT), 0, st, partial, blocks, weight, out2);
     return check_launch("cnuda_focal_loss_forward");
 }
 extern "C" int cnuda_focal_loss_backward(const float* logits, const float* gt, const float* out2,
                                          const float* upstream, float* grad_logits, long long n, float weight,
                                          cnuda_stream_t stream) {
     CNUDA_REQUIRE(logits && gt && out2 && upstream && grad_logits && n > 0, "cnuda_focal_loss_backward: bad arguments");
-    hipLaunchKernelGGL(focal_bwd_kernel, dim3(stream_grid(n, kT)), dim3(kT), 0, (hipStream_t)stream, logits, gt, out2,
+    CNUDA_LAUNCH(focal_bwd_kernel, dim3(stream_grid(n, kT)), dim3(kT), 0, (hipStream_t)stream, logits, gt, out2,
                        upstream, weight, grad_logits, n);
     return check_launch("cnuda_focal_loss_backward");
 }
@@ -471,7 +471,7 @@ extern "C" int cnuda_reg_l1_forward(const float* feat, const uint8_t* mask, cons
                                     float angle_weight, cnuda_stream_t stream) {
     CNUDA_REQUIRE(feat && mask && ind && target && out2 && B > 0 && M > 0 && HW > 0, "cnuda_reg_l1_forward: bad arguments");
     CNUDA_REQUIRE(ch >= 1 && (!periodic || ch == 3), "cnuda_reg_l1_forward: periodic loss needs 3 channels, got %d", ch);
-    hipLaunchKernelGGL(regl1_fwd_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, feat, mask,
+    CNUDA_LAUNCH(regl1_fwd_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, feat, mask,
                        (const long long*)ind, target, B, M, ch, (int)HW, periodic ? 1 : 0, weight, angle_weight, out2);
     return check_launch("cnuda_reg_l1_forward");
 }
@@ -484,7 +484,7 @@ extern "C" int cnuda_reg_l1_backward(const float* feat, const uint8_t* mask, con
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(grad_feat, 0, (size_t)B * ch * HW * sizeof(float), st) != hipSuccess)
         return check_launch("cnuda_reg_l1_backward(memset)");
-    hipLaunchKernelGGL(regl1_bwd_kernel, dim3(stream_grid((long long)B * M * ch, kT)), dim3(kT), 0, st, feat, mask,
+    CNUDA_LAUNCH(regl1_bwd_kernel, dim3(stream_grid((long long)B * M * ch, kT)), dim3(kT), 0, st, feat, mask,
                        (const long long*)ind, target, out2, upstream, B, M, ch, (int)HW, periodic ? 1 : 0, weight,
                        angle_weight, grad_feat);
     return check_launch("cnuda_reg_l1_backward");
@@ -495,7 +495,7 @@ extern "C" int cnuda_kps_l1_forward(const float* feat, const uint8_t* mask, cons
                                     int use_l1, float weight, float distance_weight, cnuda_stream_t stream) {
     CNUDA_REQUIRE(feat && mask && ind && target && out2 && B > 0 && M > 0 && J > 0 && HW > 0 && n_pairs >= 0 &&
                       (n_pairs == 0 || pairs), "cnuda_kps_l1_forward: bad arguments");
-    hipLaunchKernelGGL(kpsl1_fwd_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, feat, mask, (const long long*)ind,
+    CNUDA_LAUNCH(kpsl1_fwd_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, feat, mask, (const long long*)ind,
                        target, (const int*)pairs, B, M, J, (int)HW, n_pairs, use_l1 ? 1 : 0, weight, distance_weight, out2);
     return check_launch("cnuda_kps_l1_forward");
 }
@@ -508,7 +508,7 @@ extern "C" int cnuda_kps_l1_backward(const float* feat, const uint8_t* mask, con
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(grad_feat, 0, (size_t)B * 2 * J * HW * sizeof(float), st) != hipSuccess)
         return check_launch("cnuda_kps_l1_backward(memset)");
-    hipLaunchKernelGGL(kpsl1_bwd_kernel, dim3(stream_grid((long long)B * M * (2 * J + n_pairs), kT)), dim3(kT), 0, st, feat,
+    CNUDA_LAUNCH(kpsl1_bwd_kernel, dim3(stream_grid((long long)B * M * (2 * J + n_pairs), kT)), dim3(kT), 0, st, feat,
                        mask, (const long long*)ind, target, (const int*)pairs, out2, upstream, B, M, J, (int)HW, n_pairs,
                        use_l1 ? 1 : 0, weight, distance_weight, grad_feat);
     return check_launch("cnuda_kps_l1_backward");
@@ -516,7 +516,7 @@ extern "C" int cnuda_kps_l1_backward(const float* feat, const uint8_t* mask, con
 extern "C" int cnuda_decode_keypoints(const float* kps, const float* reg, const int64_t* inds, float* out, int B, int J,
                                       int K, int H, int W, cnuda_stream_t stream) {
     CNUDA_REQUIRE(kps && inds && out && B > 0 && J > 0 && K > 0 && H > 0 && W > 0, "cnuda_decode_keypoints: bad arguments");
-    hipLaunchKernelGGL(decode_kps_kernel, dim3(stream_grid((long long)B * K * J, kT)), dim3(kT), 0, (hipStream_t)stream,
+    CNUDA_LAUNCH(decode_kps_kernel, dim3(stream_grid((long long)B * K * J, kT)), dim3(kT), 0, (hipStream_t)stream,
                        kps, reg, (const long long*)inds, out, B, J, K, H, W);
     return check_launch("cnuda_decode_keypoints");
 }
@@ -535,8 +535,8 @@ extern "C" int cnuda_softmax_loss_forward(const float* logits, float* out1, int 
     int blocks = stream_grid((long long)B * HW, kT);
     if (blocks > kLossBlocks) blocks = kLossBlocks;
     double* partial = ws_ptr(workspace);
-    hipLaunchKernelGGL(softmax_loss_fwd_kernel, dim3(blocks), dim3(kT), 0, st, logits, partial, B, C, HW, kind);
-    hipLaunchKernelGGL(scalar_finalize_kernel, dim3(1), dim3(kT), 0, st, partial, blocks,
+    CNUDA_LAUNCH(softmax_loss_fwd_kernel, dim3(blocks), dim3(kT), 0, st, logits, partial, B, C, HW, kind);
+    CNUDA_LAUNCH(scalar_finalize_kernel, dim3(1), dim3(kT), 0, st, partial, blocks,
                        softmax_loss_scale(kind, B, C, HW), out1);
     return check_launch("cnuda_softmax_loss_forward");
 }
@@ -544,7 +544,7 @@ extern "C" int cnuda_softmax_loss_backward(const float* logits, const float* ups
                                            long long HW, int kind, cnuda_stream_t stream) {
     CNUDA_REQUIRE(logits && upstream && grad_logits && B > 0 && C > 0 && HW > 0 && (kind == 0 || kind == 1),
                   "cnuda_softmax_loss_backward: bad arguments");
-    hipLaunchKernelGGL(softmax_loss_bwd_kernel, dim3(stream_grid((long long)B * HW, kT)), dim3(kT), 0,
+    CNUDA_LAUNCH(softmax_loss_bwd_kernel, dim3(stream_grid((long long)B * HW, kT)), dim3(kT), 0,
                        (hipStream_t)stream, logits, upstream, (float)softmax_loss_scale(kind, B, C, HW), grad_logits, B,
                        C, HW, kind);
     return check_launch("cnuda_softmax_loss_backward");
@@ -552,39 +552,39 @@ extern "C" int cnuda_softmax_loss_backward(const float* logits, const float* ups
 extern "C" int cnuda_entropy_map_forward(const float* logits, float* out, int B, int C, long long HW,
                                          cnuda_stream_t stream) {
     CNUDA_REQUIRE(logits && out && B > 0 && C > 0 && HW > 0, "cnuda_entropy_map_forward: bad arguments");
-    hipLaunchKernelGGL(entropy_map_fwd_kernel, dim3(stream_grid((long long)B * HW, kT)), dim3(kT), 0,
+    CNUDA_LAUNCH(entropy_map_fwd_kernel, dim3(stream_grid((long long)B * HW, kT)), dim3(kT), 0,
                        (hipStream_t)stream, logits, out, B, C, HW);
     return check_launch("cnuda_entropy_map_forward");
 }
 extern "C" int cnuda_entropy_map_backward(const float* logits, const float* grad_out, float* grad_logits, int B, int C,
                                           long long HW, cnuda_stream_t stream) {
     CNUDA_REQUIRE(logits && grad_out && grad_logits && B > 0 && C > 0 && HW > 0, "cnuda_entropy_map_backward: bad arguments");
-    hipLaunchKernelGGL(entropy_map_bwd_kernel, dim3(stream_grid((long long)B * HW, kT)), dim3(kT), 0,
+    CNUDA_LAUNCH(entropy_map_bwd_kernel, dim3(stream_grid((long long)B * HW, kT)), dim3(kT), 0,
                        (hipStream_t)stream, logits, grad_out, grad_logits, B, C, HW);
     return check_launch("cnuda_entropy_map_backward");
 }
 extern "C" int cnuda_bce_const_forward(const float* logits, float label, float* out1, long long n,
                                        cnuda_stream_t stream) {
     CNUDA_REQUIRE(logits && out1 && n > 0, "cnuda_bce_const_forward: bad arguments");
-    hipLaunchKernelGGL(bce_const_fwd_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, logits, label, n, out1);
+    CNUDA_LAUNCH(bce_const_fwd_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, logits, label, n, out1);
     return check_launch("cnuda_bce_const_forward");
 }
 extern "C" int cnuda_bce_const_backward(const float* logits, float label, const float* upstream, float* grad_logits,
                                         long long n, cnuda_stream_t stream) {
     CNUDA_REQUIRE(logits && upstream && grad_logits && n > 0, "cnuda_bce_const_backward: bad arguments");
-    hipLaunchKernelGGL(bce_const_bwd_kernel, dim3(stream_grid(n, kT)), dim3(kT), 0, (hipStream_t)stream, logits, label,
+    CNUDA_LAUNCH(bce_const_bwd_kernel, dim3(stream_grid(n, kT)), dim3(kT), 0, (hipStream_t)stream, logits, label,
                        upstream, n, grad_logits);
     return check_launch("cnuda_bce_const_backward");
 }
 extern "C" int cnuda_sigmoid_clamp_(float* x, float* y, long long n, cnuda_stream_t stream) {
     CNUDA_REQUIRE(x && y && n > 0, "cnuda_sigmoid_clamp_: bad arguments");
-    hipLaunchKernelGGL(sigmoid_clamp_kernel, dim3(stream_grid(n, kT)), dim3(kT), 0, (hipStream_t)stream, x, y, n);
+    CNUDA_LAUNCH(sigmoid_clamp_kernel, dim3(stream_grid(n, kT)), dim3(kT), 0, (hipStream_t)stream, x, y, n);
     return check_launch("cnuda_sigmoid_clamp_");
 }
 extern "C" int cnuda_gather_feat(const float* feat, const int64_t* ind, float* out, int B, int M, int ch, long long HW,
                                  cnuda_stream_t stream) {
     CNUDA_REQUIRE(feat && ind && out && B > 0 && M > 0 && ch > 0 && HW > 0, "cnuda_gather_feat: bad arguments");
-    hipLaunchKernelGGL(gather_feat_kernel, dim3(stream_grid((long long)B * M * ch, kT)), dim3(kT), 0,
+    CNUDA_LAUNCH(gather_feat_kernel, dim3(stream_grid((long long)B * M * ch, kT)), dim3(kT), 0,
                        (hipStream_t)stream, feat, (const long long*)ind, out, B, M, ch, HW);
     return check_launch("cnuda_gather_feat");
 }

@@ -227,7 +227,7 @@ const float* launch_pack(const float* W, float* dst, size_t room, int Co, int C,
     if (float* slot = pack_slot(key, room, fill, Cpad)) dst = slot;
     if (fill) {
         const long long total = (long long)Kp * Mp;
-        hipLaunchKernelGGL(pack_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, W, dst, Co, C, T, (int)mode, Kp,
+        CNUDA_LAUNCH(pack_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, W, dst, Co, C, T, (int)mode, Kp,
                            Mp, Cpad);
     }
     return dst;
@@ -244,7 +244,7 @@ const float* launch_pack_taps(const float* W, float* dst, size_t room, int Co, i
     if (float* slot = pack_slot(key, room, fill, 0, &tl)) dst = slot;
     if (fill) {
         const long long total = (long long)Kp * Mp;
-        hipLaunchKernelGGL(pack_taps_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, W, dst, Co, C, T, tl, Kp, Mp);
+        CNUDA_LAUNCH(pack_taps_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, st, W, dst, Co, C, T, tl, Kp, Mp);
     }
     return dst;
 }
@@ -252,19 +252,19 @@ const float* launch_pack_taps(const float* W, float* dst, size_t room, int Co, i
 void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp, int Co, int C, int T, hipStream_t st) {
     const long long total = (long long)Co * C * T;
     if (Z <= 4 && total >= (1 << 18))       // (the large weights are the ones with few slabs)
-        hipLaunchKernelGGL(slab_reduce_few_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabs, gw, Z,
+        CNUDA_LAUNCH(slab_reduce_few_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabs, gw, Z,
                            Mp, Jp, Co, C, T);
     else
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, slabs, gw, Z, Mp,
+        CNUDA_LAUNCH(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, slabs, gw, Z, Mp,
                            Jp, Co, C, T);
 }
 
 void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st, float* scratch) {
     if (scratch && B > 1) {
-        hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(C, B), dim3(256), 0, st, x, scratch, C, HW);
-        hipLaunchKernelGGL(channel_sum_final_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratch, out, C, B);
+        CNUDA_LAUNCH(channel_sum_partial_kernel, dim3(C, B), dim3(256), 0, st, x, scratch, C, HW);
+        CNUDA_LAUNCH(channel_sum_final_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratch, out, C, B);
     } else {
-        hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, st, x, out, B, C, HW);
+        CNUDA_LAUNCH(channel_sum_kernel, dim3(C), dim3(256), 0, st, x, out, B, C, HW);
     }
 }
 
@@ -376,7 +376,7 @@ extern "C" int cnuda_pack_refresh(const void* params, size_t params_bytes, unsig
             return check_launch("cnuda_pack_refresh(table)");
         g_refresh_blocks = blocks;
     }
-    hipLaunchKernelGGL(pack_multi_kernel, dim3(g_refresh_blocks), dim3(256), 0, st, static_cast<const PackJob*>(table),
+    CNUDA_LAUNCH(pack_multi_kernel, dim3(g_refresh_blocks), dim3(256), 0, st, static_cast<const PackJob*>(table),
                        (int)g_refresh_jobs.size());
     for (PackSlot* sl : live) sl->version = ((new_epoch & 0xffffffffull) << 32) | (sl->version & 0xffffffffull);
     return check_launch("cnuda_pack_refresh");

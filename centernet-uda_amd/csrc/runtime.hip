@@ -1,4 +1,5 @@
 // Error reporting and ABI bookkeeping shared by every entry point.
+#include <cxxabi.h>
 #include <stdarg.h>
 #include <string.h>
 
@@ -119,6 +120,53 @@ extern "C" int cnuda_set_matrix_mode(int mode) {
     return 0;
 }
 extern "C" int cnuda_get_matrix_mode(void) { return cnuda::g_matrix_mode; }
+
+namespace cnuda {
+bool g_launch_log_on = false;
+namespace {
+struct LaunchCount { const void* fn; unsigned long long n; };
+std::vector<LaunchCount> g_launch_log;      // one entry per distinct host function, in first-launch order
+}
+void launch_log(const void* fn) {
+    for (auto& e : g_launch_log)
+        if (e.fn == fn) { ++e.n; return; }
+    g_launch_log.push_back({fn, 1});
+}
+}  // namespace cnuda
+extern "C" int cnuda_launch_log_enable(int on) {
+    if (on && !cnuda::g_launch_log_on) cnuda::g_launch_log.clear();
+    cnuda::g_launch_log_on = on != 0;
+    return 0;
+}
+extern "C" int cnuda_launch_log_collect(char* names, size_t cap) {
+    using namespace cnuda;
+    size_t used = 0;
+    int n = 0;
+    for (const auto& e : g_launch_log) {
+        const char* mangled = hipKernelNameRefByPtr(e.fn, nullptr);
+        if (!mangled) mangled = "?";
+        int status = 1;
+        char* plain = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+        const char* nm = (status == 0 && plain) ? plain : mangled;
+        char count[32];
+        const int clen = snprintf(count, sizeof(count), "\t%llu\n", e.n);
+        const size_t len = strlen(nm);
+        const bool fits = used + len + (size_t)clen + 1 <= cap;
+        if (fits) {
+            memcpy(names + used, nm, len);
+            memcpy(names + used + len, count, (size_t)clen);
+            used += len + (size_t)clen;
+            ++n;
+        }
+        free(plain);
+        if (!fits) {
+            set_error("cnuda_launch_log_collect: %zu bytes do not hold the names of %zu kernels", cap, g_launch_log.size());
+            return CNUDA_ERR_INVALID_ARGUMENT;
+        }
+    }
+    if (cap) names[used] = 0;
+    return n;
+}
 
 extern "C" int cnuda_abi_version(void) { return CNUDA_ABI_VERSION; }
 extern "C" const char* cnuda_last_error(void) { return cnuda::g_error; }

@@ -447,12 +447,12 @@ int smallc_forward(const float* x, const float* w, const float* bias, float* y, 
     float* Wp = cv.take<float>((size_t)g.Kp * 16 * mt);
     int* koff = cv.take<int>(SC_MAXK);
     CNUDA_REQUIRE(cv.ok(), "smallc_forward: workspace too small");
-    hipLaunchKernelGGL(smallc_koff_kernel, dim3(1), dim3(SC_MAXK), 0, st, g, koff, SC_MAXK);
+    CNUDA_LAUNCH(smallc_koff_kernel, dim3(1), dim3(SC_MAXK), 0, st, g, koff, SC_MAXK);
     // pack: forward W[Co][C][T]; transposed: original W[C_here... ] see kernel comment
     if (!transposed)
-        hipLaunchKernelGGL(smallc_pack_kernel, dim3(32), dim3(256), 0, st, w, Wp, Co, C, kh * kw, g.Kp, 16 * mt, 0);
+        CNUDA_LAUNCH(smallc_pack_kernel, dim3(32), dim3(256), 0, st, w, Wp, Co, C, kh * kw, g.Kp, 16 * mt, 0);
     else
-        hipLaunchKernelGGL(smallc_pack_kernel, dim3(32), dim3(256), 0, st, w, Wp, /*Co_orig=*/C, /*C_orig=*/Co,
+        CNUDA_LAUNCH(smallc_pack_kernel, dim3(32), dim3(256), 0, st, w, Wp, /*Co_orig=*/C, /*C_orig=*/Co,
                            kh * kw, g.Kp, 16 * mt, 1);
     // halo image + 4 staging tiles + weights [Kp][16 mt] + row offsets [Kp]
     const size_t lds = (size_t)(g.C * g.plane + 16 + 4 * 16 * mt * SC_YLD + g.Kp * 16 * mt + g.Kp) * sizeof(float);
@@ -460,9 +460,9 @@ int smallc_forward(const float* x, const float* w, const float* bias, float* y, 
     ProfScope prof(st);
     prof.name("smallc_fwd_kernel<%d>", mt);
     if (mt == 1)
-        hipLaunchKernelGGL(smallc_fwd_kernel<1>, grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope);
+        CNUDA_LAUNCH(smallc_fwd_kernel<1>, grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope);
     else
-        hipLaunchKernelGGL(smallc_fwd_kernel<2>, grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope);
+        CNUDA_LAUNCH(smallc_fwd_kernel<2>, grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope);
     return check_launch("smallc_forward");
 }
 
@@ -479,7 +479,7 @@ int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, in
     float* slabs = cv.take<float>(tiles * 16 * mt * Kp16);
     float* partial = cv.take<float>((size_t)SC_RED_GROUPS * 16 * mt * Kp16);
     CNUDA_REQUIRE(cv.ok(), "smallc_backward_weight: workspace too small");
-    hipLaunchKernelGGL(smallc_koff_kernel, dim3(1), dim3(SC_MAXK), 0, st, g, koff, SC_MAXK);
+    CNUDA_LAUNCH(smallc_koff_kernel, dim3(1), dim3(SC_MAXK), 0, st, g, koff, SC_MAXK);
     const size_t stage = (size_t)(g.C * g.plane + 16) + (size_t)16 * mt * (SC_TH * SC_TW + 1);
     const size_t red = (size_t)4 * 16 * mt * Kp16;
     const size_t lds = (stage > red ? stage : red) * sizeof(float);
@@ -495,15 +495,15 @@ int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, in
         ProfScope prof(st);
         prof.name("smallc_wgrad_kernel<%d>", mt);
         if (mt == 1)
-            hipLaunchKernelGGL(smallc_wgrad_kernel<1>, grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16);
+            CNUDA_LAUNCH(smallc_wgrad_kernel<1>, grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16);
         else
-            hipLaunchKernelGGL(smallc_wgrad_kernel<2>, grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16);
+            CNUDA_LAUNCH(smallc_wgrad_kernel<2>, grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16);
     }
     if (int rc = check_launch("smallc_backward_weight")) return rc;
     const int slab_elems = 16 * mt * Kp16;
-    hipLaunchKernelGGL(smallc_slab_reduce1_kernel, dim3((slab_elems + 63) / 64, SC_RED_GROUPS), dim3(256), 0, st, slabs,
+    CNUDA_LAUNCH(smallc_slab_reduce1_kernel, dim3((slab_elems + 63) / 64, SC_RED_GROUPS), dim3(256), 0, st, slabs,
                        partial, (int)tiles, slab_elems);
-    hipLaunchKernelGGL(smallc_slab_reduce2_kernel, dim3((Co * g.K + 255) / 256), dim3(256), 0, st, partial, gw, slab_elems,
+    CNUDA_LAUNCH(smallc_slab_reduce2_kernel, dim3((Co * g.K + 255) / 256), dim3(256), 0, st, partial, gw, slab_elems,
                        Kp16, Co, C, kh * kw);
     return check_launch("smallc_backward_weight(reduce)");
 }

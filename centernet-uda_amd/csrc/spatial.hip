@@ -642,7 +642,7 @@ extern "C" int cnuda_maxpool2d_forward(const float* x, float* y, int B, int C, i
     CNUDA_REQUIRE(x && y && B > 0 && C > 0 && k > 0 && H >= k && W >= k, "cnuda_maxpool2d_forward: bad arguments");
     const int Ho = H / k, Wo = W / k;
     const long long planes = (long long)B * C;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_grid(planes * Ho * Wo, kT)), dim3(kT), 0, (hipStream_t)stream, x,
+    CNUDA_LAUNCH(maxpool_fwd_kernel, dim3(stream_grid(planes * Ho * Wo, kT)), dim3(kT), 0, (hipStream_t)stream, x,
                        y, planes, H, W, Ho, Wo, k);
     return check_launch("cnuda_maxpool2d_forward");
 }
@@ -654,9 +654,9 @@ extern "C" int cnuda_maxpool2d_backward(const float* x, const float* grad_y, flo
     const long long planes = (long long)B * C;
     hipStream_t st = (hipStream_t)stream;
     if (Ho * k != H || Wo * k != W)
-        hipLaunchKernelGGL(maxpool_bwd_tail_kernel, dim3(stream_grid(planes * H * W, kT)), dim3(kT), 0, st, grad_x,
+        CNUDA_LAUNCH(maxpool_bwd_tail_kernel, dim3(stream_grid(planes * H * W, kT)), dim3(kT), 0, st, grad_x,
                            planes, H, W, Ho * k, Wo * k);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid(planes * Ho * Wo, kT)), dim3(kT), 0, st, x, grad_y, grad_x,
+    CNUDA_LAUNCH(maxpool_bwd_kernel, dim3(stream_grid(planes * Ho * Wo, kT)), dim3(kT), 0, st, x, grad_y, grad_x,
                        planes, H, W, Ho, Wo, k);
     return check_launch("cnuda_maxpool2d_backward");
 }
@@ -667,7 +667,7 @@ extern "C" int cnuda_maxpool2d_window_forward(const float* x, float* y, int B, i
                   "cnuda_maxpool2d_window_forward: bad arguments (need 2*padding <= kernel <= padded size)");
     const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
     const long long planes = (long long)B * C;
-    hipLaunchKernelGGL(maxpool_win_fwd_kernel, dim3(stream_grid(planes * Ho * Wo, kT)), dim3(kT), 0,
+    CNUDA_LAUNCH(maxpool_win_fwd_kernel, dim3(stream_grid(planes * Ho * Wo, kT)), dim3(kT), 0,
                        (hipStream_t)stream, x, y, planes, H, W, Ho, Wo, k, s, p);
     return check_launch("cnuda_maxpool2d_window_forward");
 }
@@ -678,7 +678,7 @@ extern "C" int cnuda_maxpool2d_window_backward(const float* x, const float* grad
                   "cnuda_maxpool2d_window_backward: bad arguments");
     const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
     const long long planes = (long long)B * C;
-    hipLaunchKernelGGL(maxpool_win_bwd_kernel, dim3(stream_grid(planes * H * W, kT)), dim3(kT), 0, (hipStream_t)stream,
+    CNUDA_LAUNCH(maxpool_win_bwd_kernel, dim3(stream_grid(planes * H * W, kT)), dim3(kT), 0, (hipStream_t)stream,
                        x, grad_y, grad_x, planes, H, W, Ho, Wo, k, s, p);
     return check_launch("cnuda_maxpool2d_window_backward");
 }
@@ -690,23 +690,25 @@ extern "C" int cnuda_dwconvt2d_add_forward(const float* x, const float* w, const
     const int Ho = (H - 1) * s - 2 * p + k, Wo = (W - 1) * s - 2 * p + k;
     CNUDA_REQUIRE(Ho > 0 && Wo > 0, "cnuda_dwconvt2d_forward: empty output");
     CNUDA_REQUIRE((long long)B * C <= 65535, "cnuda_dwconvt2d_forward: more than 65535 planes");
-    const bool upsample = k == 2 * s && p == s / 2 && (s == 2 || s == 4) && Wo % 4 == 0;   // IDAUp's bilinear-style layers
+    // the vector kernels read `skip` and write `y` 16 bytes at a time (and read x 8 bytes at a time): a view at an
+    // odd offset takes the scalar kernel
+    const bool aligned16 = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)skip) & 15) == 0;
+    const bool upsample = k == 2 * s && p == s / 2 && (s == 2 || s == 4) && Wo % 4 == 0 && aligned16;   // IDAUp's bilinear-style layers
     const int rows = (upsample && Ho % 4 == 0 && (long long)Ho * Wo >= 4096) ? 4 : 1;
     const dim3 fgrid(ceil_div((long long)Ho * Wo / 4 / rows, kT), B * C);
-    const bool aligned16 = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)skip) & 15) == 0;      // (8-byte loads of x, 16 of y)
-    if (upsample && s == 2 && rows == 4 && (H & 1) == 0 && (W & 1) == 0 && aligned16)
-        hipLaunchKernelGGL(dwconvt_fwd_k4s2_kernel, dim3(ceil_div((long long)(H / 2) * (W / 2), kT), B * C), dim3(kT), 0,
+    if (upsample && s == 2 && rows == 4 && (H & 1) == 0 && (W & 1) == 0)
+        CNUDA_LAUNCH(dwconvt_fwd_k4s2_kernel, dim3(ceil_div((long long)(H / 2) * (W / 2), kT), B * C), dim3(kT), 0,
                            (hipStream_t)stream, x, w, skip, y, C, H, W);
     else if (upsample && s == 2 && rows == 4)
-        hipLaunchKernelGGL((dwconvt_fwd_f_kernel<2, 4>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
+        CNUDA_LAUNCH((dwconvt_fwd_f_kernel<2, 4>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
     else if (upsample && s == 2)
-        hipLaunchKernelGGL((dwconvt_fwd_f_kernel<2, 1>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
+        CNUDA_LAUNCH((dwconvt_fwd_f_kernel<2, 1>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
     else if (upsample && rows == 4)
-        hipLaunchKernelGGL((dwconvt_fwd_f_kernel<4, 4>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
+        CNUDA_LAUNCH((dwconvt_fwd_f_kernel<4, 4>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
     else if (upsample)
-        hipLaunchKernelGGL((dwconvt_fwd_f_kernel<4, 1>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
+        CNUDA_LAUNCH((dwconvt_fwd_f_kernel<4, 1>), fgrid, dim3(kT), 0, (hipStream_t)stream, x, w, skip, y, C, H, W);
     else
-        hipLaunchKernelGGL(dwconvt_fwd_kernel, dim3(ceil_div((long long)Ho * Wo, kT), B * C), dim3(kT), 0,
+        CNUDA_LAUNCH(dwconvt_fwd_kernel, dim3(ceil_div((long long)Ho * Wo, kT), B * C), dim3(kT), 0,
                            (hipStream_t)stream, x, w, skip, y, C, H, W, Ho, Wo, k, s, p);
     return check_launch("cnuda_dwconvt2d_forward");
 }
@@ -732,8 +734,8 @@ extern "C" int cnuda_dwconv2d_forward(const float* x, const float* w, float* y, 
     if (int rc = dwconv_geom(B, C, H, W, k, s, p, Ho, Wo, "cnuda_dwconv2d_forward")) return rc;
     CNUDA_REQUIRE(x && w && y, "cnuda_dwconv2d_forward: null pointer");
     const dim3 grid(B * C, ceil_div(ceil_div(Ho * Wo, kT), 4) > 0 ? ceil_div(ceil_div(Ho * Wo, kT), 4) : 1);
-    if (k == 3) hipLaunchKernelGGL(dwconv_fwd_kernel<3>, grid, dim3(kT), 0, (hipStream_t)stream, x, w, y, C, H, W, Ho, Wo, s, p);
-    else hipLaunchKernelGGL(dwconv_fwd_kernel<5>, grid, dim3(kT), 0, (hipStream_t)stream, x, w, y, C, H, W, Ho, Wo, s, p);
+    if (k == 3) CNUDA_LAUNCH(dwconv_fwd_kernel<3>, grid, dim3(kT), 0, (hipStream_t)stream, x, w, y, C, H, W, Ho, Wo, s, p);
+    else CNUDA_LAUNCH(dwconv_fwd_kernel<5>, grid, dim3(kT), 0, (hipStream_t)stream, x, w, y, C, H, W, Ho, Wo, s, p);
     return check_launch("cnuda_dwconv2d_forward");
 }
 extern "C" int cnuda_dwconv2d_backward(const float* x, const float* w, const float* grad_y, float* grad_x, float* grad_w,
@@ -745,16 +747,16 @@ extern "C" int cnuda_dwconv2d_backward(const float* x, const float* w, const flo
     hipStream_t st = (hipStream_t)stream;
     if (grad_x) {
         const dim3 grid(B * C, ceil_div(ceil_div(H * W, kT), 4) > 0 ? ceil_div(ceil_div(H * W, kT), 4) : 1);
-        if (k == 3) hipLaunchKernelGGL(dwconv_bwd_data_kernel<3>, grid, dim3(kT), 0, st, grad_y, w, grad_x, C, H, W, Ho, Wo, s, p);
-        else hipLaunchKernelGGL(dwconv_bwd_data_kernel<5>, grid, dim3(kT), 0, st, grad_y, w, grad_x, C, H, W, Ho, Wo, s, p);
+        if (k == 3) CNUDA_LAUNCH(dwconv_bwd_data_kernel<3>, grid, dim3(kT), 0, st, grad_y, w, grad_x, C, H, W, Ho, Wo, s, p);
+        else CNUDA_LAUNCH(dwconv_bwd_data_kernel<5>, grid, dim3(kT), 0, st, grad_y, w, grad_x, C, H, W, Ho, Wo, s, p);
     }
     if (grad_w) {
         CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_dwconv2d_workspace_bytes(B, C, k), "cnuda_dwconv2d_backward: workspace too small");
         CNUDA_REQUIRE(C <= 2147483647 && B <= 65535, "cnuda_dwconv2d_backward: batch > 65535");
         float* part = (float*)workspace;
-        if (k == 3) hipLaunchKernelGGL(dwconv_bwd_weight_kernel<3>, dim3(C, B), dim3(kT), 0, st, x, grad_y, part, B, C, H, W, Ho, Wo, s, p);
-        else hipLaunchKernelGGL(dwconv_bwd_weight_kernel<5>, dim3(C, B), dim3(kT), 0, st, x, grad_y, part, B, C, H, W, Ho, Wo, s, p);
-        hipLaunchKernelGGL(dwconvt_wsum_kernel, dim3(ceil_div((long long)C * k * k, 256)), dim3(256), 0, st, part, grad_w, B, C, k * k);
+        if (k == 3) CNUDA_LAUNCH(dwconv_bwd_weight_kernel<3>, dim3(C, B), dim3(kT), 0, st, x, grad_y, part, B, C, H, W, Ho, Wo, s, p);
+        else CNUDA_LAUNCH(dwconv_bwd_weight_kernel<5>, dim3(C, B), dim3(kT), 0, st, x, grad_y, part, B, C, H, W, Ho, Wo, s, p);
+        CNUDA_LAUNCH(dwconvt_wsum_kernel, dim3(ceil_div((long long)C * k * k, 256)), dim3(256), 0, st, part, grad_w, B, C, k * k);
     }
     return check_launch("cnuda_dwconv2d_backward");
 }
@@ -777,23 +779,23 @@ extern "C" int cnuda_dwconvt2d_backward(const float* x, const float* w, const fl
         }
         if (k == 4 && s == 2 && p == 1 && (W & 1) == 0 &&
             (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x) & 15) == 0)
-            hipLaunchKernelGGL(dwconvt_bwd_k4s2_kernel, dim3(C, B), dim3(kT), 0, st, x, w, grad_y, grad_x, part, B, C, H, W);
+            CNUDA_LAUNCH(dwconvt_bwd_k4s2_kernel, dim3(C, B), dim3(kT), 0, st, x, w, grad_y, grad_x, part, B, C, H, W);
         else if (k == 4)
-            hipLaunchKernelGGL(dwconvt_bwd_kernel<4>, dim3(C, B), dim3(kT), 0, st, x, w, grad_y, grad_x, part, B, C, H, W,
+            CNUDA_LAUNCH(dwconvt_bwd_kernel<4>, dim3(C, B), dim3(kT), 0, st, x, w, grad_y, grad_x, part, B, C, H, W,
                                Ho, Wo, s, p);
         else
-            hipLaunchKernelGGL(dwconvt_bwd_kernel<8>, dim3(C, B), dim3(kT), 0, st, x, w, grad_y, grad_x, part, B, C, H, W,
+            CNUDA_LAUNCH(dwconvt_bwd_kernel<8>, dim3(C, B), dim3(kT), 0, st, x, w, grad_y, grad_x, part, B, C, H, W,
                                Ho, Wo, s, p);
         if (grad_w)
-            hipLaunchKernelGGL(dwconvt_wsum_kernel, dim3(ceil_div((long long)C * k * k, 256)), dim3(256), 0, st, part,
+            CNUDA_LAUNCH(dwconvt_wsum_kernel, dim3(ceil_div((long long)C * k * k, 256)), dim3(256), 0, st, part,
                                grad_w, B, C, k * k);
         return check_launch("cnuda_dwconvt2d_backward");
     }
     if (grad_x)
-        hipLaunchKernelGGL(dwconvt_bwd_data_kernel, dim3(stream_grid((long long)B * C * H * W, kT)), dim3(kT), 0, st,
+        CNUDA_LAUNCH(dwconvt_bwd_data_kernel, dim3(stream_grid((long long)B * C * H * W, kT)), dim3(kT), 0, st,
                            grad_y, w, grad_x, B, C, H, W, Ho, Wo, k, s, p);
     if (grad_w)
-        hipLaunchKernelGGL(dwconvt_bwd_weight_kernel, dim3(C, k * k), dim3(kT), 0, st, x, grad_y, grad_w, B, C, H, W, Ho,
+        CNUDA_LAUNCH(dwconvt_bwd_weight_kernel, dim3(C, k * k), dim3(kT), 0, st, x, grad_y, grad_w, B, C, H, W, Ho,
                            Wo, k, s, p);
     return check_launch("cnuda_dwconvt2d_backward");
 }
@@ -802,14 +804,14 @@ extern "C" int cnuda_add(const float* a, const float* b, float* out, long long n
     CNUDA_REQUIRE(a && b && out && n > 0, "cnuda_add: bad arguments");
     const bool aligned = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0;
     const long long n4 = aligned ? n / 4 : 0;
-    hipLaunchKernelGGL(add_kernel, dim3(stream_grid(n4 > 0 ? n4 : n, kT)), dim3(kT), 0, (hipStream_t)stream, a, b, out,
+    CNUDA_LAUNCH(add_kernel, dim3(stream_grid(n4 > 0 ? n4 : n, kT)), dim3(kT), 0, (hipStream_t)stream, a, b, out,
                        n4, n);
     return check_launch("cnuda_add");
 }
 extern "C" int cnuda_act_backward(const float* grad_y, const float* y, float* grad_x, long long n, float slope,
                                   cnuda_stream_t stream) {
     CNUDA_REQUIRE(grad_y && y && grad_x && n > 0, "cnuda_act_backward: bad arguments");
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(n, kT)), dim3(kT), 0, (hipStream_t)stream, grad_y, y, grad_x, n,
+    CNUDA_LAUNCH(act_bwd_kernel, dim3(stream_grid(n, kT)), dim3(kT), 0, (hipStream_t)stream, grad_y, y, grad_x, n,
                        slope);
     return check_launch("cnuda_act_backward");
 }
@@ -830,7 +832,7 @@ extern "C" int cnuda_conv1x1_backward_data_act(const float* grad_y, const float*
     const int ch_chunk = (int)ceil_div(Ch, chunks);
     const dim3 grid((unsigned)quads, (unsigned)ceil_div(Ch, ch_chunk), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-#define CNUDA_C1(CO) case CO: hipLaunchKernelGGL(conv1x1_dgrad_act_kernel<CO>, grid, dim3(kT), 0, st, grad_y, weight, \
+#define CNUDA_C1(CO) case CO: CNUDA_LAUNCH(conv1x1_dgrad_act_kernel<CO>, grid, dim3(kT), 0, st, grad_y, weight, \
                                                   hidden, grad_hidden, Ch, ch_chunk, HW, slope); break
     switch (Co) {
         CNUDA_C1(1); CNUDA_C1(2); CNUDA_C1(3); CNUDA_C1(4); CNUDA_C1(5); CNUDA_C1(6); CNUDA_C1(7); CNUDA_C1(8);
@@ -846,7 +848,7 @@ extern "C" int cnuda_copy_channels(const float* src, float* dst, int B, int Cn, 
     const int chunks = (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) > 0 ? (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) : 1;
     const long long rows = (long long)B * Cn;
     CNUDA_REQUIRE(rows < (1ll << 31), "cnuda_copy_channels: too many planes");
-    hipLaunchKernelGGL(copy_channels_kernel, dim3(chunks, (unsigned)(rows < 65535 ? rows : 65535)), dim3(kT), 0,
+    CNUDA_LAUNCH(copy_channels_kernel, dim3(chunks, (unsigned)(rows < 65535 ? rows : 65535)), dim3(kT), 0,
                        (hipStream_t)stream, src, dst, (int)rows, Cn, HW, Csrc, src_off, Cdst, dst_off);
     return check_launch("cnuda_copy_channels");
 }
@@ -856,7 +858,7 @@ extern "C" int cnuda_split_offset_mask(const float* om, float* offset, float* ma
     const int chunks = (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) > 0 ? (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) : 1;
     const long long rows = (long long)B * 3 * taps;
     CNUDA_REQUIRE(rows < (1ll << 31), "cnuda_split_offset_mask: too many planes");
-    hipLaunchKernelGGL(split_offset_mask_kernel, dim3(chunks, (unsigned)(rows < 65535 ? rows : 65535)), dim3(kT), 0,
+    CNUDA_LAUNCH(split_offset_mask_kernel, dim3(chunks, (unsigned)(rows < 65535 ? rows : 65535)), dim3(kT), 0,
                        (hipStream_t)stream, om, offset, mask, (int)rows, taps, HW);
     return check_launch("cnuda_split_offset_mask");
 }
@@ -867,7 +869,7 @@ extern "C" int cnuda_split_offset_mask_backward(const float* grad_offset, const 
     const int chunks = (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) > 0 ? (int)((HW / 4 + kT * 4 - 1) / (kT * 4)) : 1;
     const long long rows = (long long)B * 3 * taps;
     CNUDA_REQUIRE(rows < (1ll << 31), "cnuda_split_offset_mask_backward: too many planes");
-    hipLaunchKernelGGL(split_offset_mask_bwd_kernel, dim3(chunks, (unsigned)(rows < 65535 ? rows : 65535)), dim3(kT), 0,
+    CNUDA_LAUNCH(split_offset_mask_bwd_kernel, dim3(chunks, (unsigned)(rows < 65535 ? rows : 65535)), dim3(kT), 0,
                        (hipStream_t)stream, grad_offset, grad_mask, mask, grad_om, (int)rows, taps, HW);
     return check_launch("cnuda_split_offset_mask_backward");
 }

@@ -93,7 +93,7 @@ extern "C" int cnuda_encode_targets(const double* boxes, const int* classes, con
     (void)hipMemsetAsync(reg, 0, (size_t)B * M * 2 * sizeof(float), st);
     (void)hipMemsetAsync(gt_dets, 0, (size_t)B * M * 6 * sizeof(float), st);
     (void)hipMemsetAsync(gt_areas, 0, (size_t)B * M * sizeof(float), st);
-    hipLaunchKernelGGL(encode_targets_kernel, dim3(M, B), dim3(256), 0, st, boxes, classes, counts, hm, reg_mask, ind,
+    CNUDA_LAUNCH(encode_targets_kernel, dim3(M, B), dim3(256), 0, st, boxes, classes, counts, hm, reg_mask, ind,
                        wh, reg, gt_dets, gt_areas, C, H, W, M);
     return check_launch("cnuda_encode_targets");
 }

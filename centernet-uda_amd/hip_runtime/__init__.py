@@ -123,6 +123,9 @@ class _Sig:
     cnuda_prof_arm = (_I, [_I])
     cnuda_prof_collect = (_I, [_P, _P, _P, _I])
     cnuda_prof_name_len = (_I, [])
+    cnuda_launch_log_enable = (_I, [_I])
+    cnuda_launch_log_collect = (_I, [ctypes.c_char_p, c_size_t])
+    cnuda_dcn_set_fused_min_tiles = (_I, [_I])
 
 
 # ---------------------------------------------------------------------------
@@ -183,6 +186,32 @@ def new_pack_token():
     t = _PACK['next_token']
     _PACK['next_token'] += 1
     return t
+
+
+class PackToken:
+    """A module's identity in the pack cache, as a module attribute.  A DEEP copy of the module (an EMA / mean-teacher
+    copy, swa_utils.AveragedModel, copy.deepcopy(model)) or an unpickled module owns different weight buffers, so it
+    takes a fresh identity: with a shared token two live models would take over each other's cached image on every
+    call (each call re-packs; results stay right, the cache is defeated).  A shallow copy shares the weights and keeps
+    the token."""
+    __slots__ = ('id',)
+
+    def __init__(self):
+        self.id = new_pack_token()
+
+    def __int__(self):
+        return self.id
+
+    __index__ = __int__
+
+    def __deepcopy__(self, memo):
+        return PackToken()
+
+    def __reduce__(self):
+        return (PackToken, ())
+
+    def __repr__(self):
+        return 'PackToken(%d)' % self.id
 
 
 class pack_stamp:
@@ -366,3 +395,52 @@ def prof_end(by_shape=False):
     _Prof.enabled, _Prof.table, _Prof.shapes = False, [], []
     lib().cnuda_prof_enable(0)
     return out
+
+
+# ---------------------------------------------------------------------------
+# test aids (include/centernet_uda_hip.h, "Test aids")
+# ---------------------------------------------------------------------------
+def launch_counts():
+    """-> {kernel symbol name: launches since the log was enabled}; enables the log on first use (it stays on: one
+    predictable branch per launch)."""
+    L = lib()
+    L.cnuda_launch_log_enable(1)
+    buf = ctypes.create_string_buffer(1 << 18)
+    n = L.cnuda_launch_log_collect(buf, len(buf))
+    if n < 0:
+        check(n, 'launch_log_collect')
+    out = {}
+    for line in buf.value.decode().split('\n'):
+        if line:
+            name, _, count = line.rpartition('\t')
+            out[name] = int(count)
+    return out
+
+
+class launch_log:
+    """with launch_log() as log: ...   ->  log.names: the library's kernels launched inside the block, by their own
+    symbol names (what a rocprofv3 kernel trace shows); log.counts: launches of each.  Blocks may nest."""
+
+    def __enter__(self):
+        self.before = launch_counts()
+        self.names, self.counts = [], {}
+        return self
+
+    def __exit__(self, *exc):
+        after = launch_counts()
+        self.counts = {k: v - self.before.get(k, 0) for k, v in after.items() if v > self.before.get(k, 0)}
+        self.names = list(self.counts)
+
+
+class dcn_fused_min_tiles:
+    """with dcn_fused_min_tiles(1): every DCN backward inside the block that CAN take the one-launch data-gradient
+    walk (dcn_bwd_data_kernel) takes it, whatever its size; with dcn_fused_min_tiles(2 ** 31 - 1): none does."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.prev = lib().cnuda_dcn_set_fused_min_tiles(self.n)
+
+    def __exit__(self, *exc):
+        lib().cnuda_dcn_set_fused_min_tiles(self.prev)

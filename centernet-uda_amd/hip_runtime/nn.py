@@ -24,8 +24,8 @@ class Conv2d(nn.Module):
         self.act_slope = float(act_slope)
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
-        from . import new_pack_token
-        self._pack_token = new_pack_token()         # identity of these weights for the library's pack cache
+        from . import PackToken
+        self._pack_token = PackToken()              # identity of these weights for the library's pack cache
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -102,7 +102,12 @@ class Head(nn.Sequential):
     is one node (ops.conv_act_conv1x1: the hidden map's gradient in one pass); otherwise the layers run in turn."""
 
     def forward(self, x):
+        # The fused node calls the kernels on the children's parameters directly, i.e. it REPLACES the children's
+        # forward: it is taken only when that is unobservable and useful -- no forward (pre-)hooks on any child
+        # (feature extraction, activation statistics, profilers) and something in the head or its input needs a gradient.
         if len(self) == 3 and isinstance(self[0], Conv2d) and isinstance(self[2], Conv2d) \
+                and not any(m._forward_hooks or m._forward_pre_hooks for m in self) \
+                and (x.requires_grad or any(p.requires_grad for p in self.parameters())) \
                 and ops.conv_act_conv1x1_supported(x, self[0], self[2]):
             return ops.conv_act_conv1x1(x, self[0], self[2])
         return super().forward(x)

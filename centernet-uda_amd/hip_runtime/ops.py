@@ -308,7 +308,9 @@ class _BatchNormAct(Function):
                                        float(eps),
                                        _act_code(relu), B, C, HW, groups, wp, wn, stream()), 'bn_train_forward')
         ctx.relu, ctx.dims, ctx.has_res, ctx.groups = relu, (B, C, HW), residual is not None, groups
-        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd, beta)
+        # y is read by the backward only where a residual entered the activation; without one the gate is recomputed
+        # from x (cnuda_bn_backward, `beta` given) and y is not kept
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, mean, invstd, beta)
         return y
 
     @staticmethod

@@ -14,9 +14,10 @@ is the gradient of that global loss.
 BatchNorm buffers: nn.DataParallel re-broadcasts device 0's buffers to the replicas on every forward and only
 replica 0's in-place updates persist, so the running statistics the reference evaluates and checkpoints with are
 those of replica 0's shard.  Here every rank updates its own statistics while training (they are not read in train
-mode) and rank 0's are broadcast to all ranks whenever the wrapper switches to eval (`train(False)` / `eval()`,
-i.e. `uda.set_phase(False)`): evaluation on any rank then sees exactly replica 0's statistics, and rank 0 -- the
-rank that writes checkpoints -- holds them by construction.
+mode) and rank 0's are broadcast to all ranks by an EXPLICIT collective, `sync_buffers()`, which
+`uda.base.Model.set_phase(False)` calls on the switch from training to evaluation: evaluation on any rank then sees
+exactly replica 0's statistics, and rank 0 -- the rank that writes checkpoints -- holds them by construction.
+`train()` / `eval()` themselves are plain nn.Module calls and communicate nothing.
 
 Two (or more) backward() calls per step accumulate locally under `no_sync()`;
 buckets fire during the last backward; `finish_gradient_sync()` launches any
@@ -105,14 +106,11 @@ class DataParallel(nn.Module):
                     off += b.numel()
 
     def train(self, mode=True):
-        """COLLECTIVE when it switches from training to evaluation (sync_buffers broadcasts rank 0's BatchNorm
-        statistics): every rank must make the same train()/eval() transitions -- a driver that validates on rank 0
-        only must still call set_phase(False) on all ranks (or evaluate the unwrapped `.module`)."""
-        was_training = self.training
-        super().train(mode)
-        if was_training and not mode:
-            self.sync_buffers()                 # evaluate (on every rank) with replica 0's statistics
-        return self
+        """Plain nn.Module.train(): NO collective.  (Round 3 broadcast the buffers from inside this method; a rank that
+        validated alone then hung its peers in a call that does not look like communication.)  The switch to
+        evaluation with replica 0's statistics is explicit: `sync_buffers()`, which uda.base.Model.set_phase(False)
+        calls on every rank."""
+        return super().train(mode)
 
     @contextlib.contextmanager
     def no_sync(self):

@@ -61,7 +61,7 @@ class DCNv2(nn.Module):
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels))
         import hip_runtime as hr
-        self._pack_token = hr.new_pack_token()      # identity of these weights for the library's pack cache
+        self._pack_token = hr.PackToken()           # identity of these weights for the library's pack cache
         self.reset_parameters()
 
     def reset_parameters(self):

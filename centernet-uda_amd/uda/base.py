@@ -47,7 +47,13 @@ class Model:
             self.scheduler.step()
 
     def set_phase(self, is_training=True):
+        """train.py:150,171.  With a data-parallel backend the switch from training to evaluation is a COLLECTIVE
+        (every rank's BatchNorm statistics := rank 0's, hip_runtime.parallel.DataParallel.sync_buffers: what the
+        reference's nn.DataParallel does on every forward): all ranks must make it, also when only rank 0 validates."""
+        was_training = self.backend.training
         self.backend.train(is_training)
+        if was_training and not is_training and hasattr(self.backend, 'sync_buffers'):
+            self.backend.sync_buffers()
 
     def to(self, device, parallel=False, global_normalizers=True):
         """parallel: one process per GPU.  global_normalizers (default): the detection loss divides by the

@@ -83,6 +83,21 @@ int cnuda_prof_arm(int tag);
 int cnuda_prof_collect(int* tags, float* ms, char* names, int cap);
 int cnuda_prof_name_len(void);
 
+/* Test aids (tests/test_zz_kernel_coverage.py, tests/test_gpu_dcn.py), not part of the reference's surface.
+ * Launch log: while enabled, every kernel launch of the library is counted per kernel; cnuda_launch_log_collect
+ * writes one line "<kernel symbol name, demangled, as a rocprofv3 kernel trace shows it>\t<launches so far>" per
+ * distinct kernel, in first-launch order, into names[cap] and returns their count (callers diff two snapshots to
+ * learn what ran in between).  enable(1) from the disabled state clears the counts.
+ * cnuda_dcn_set_fused_min_tiles: cnuda_dcn_v2_backward runs its two data-gradient walks as ONE launch
+ * (dcn_bwd_data_kernel + geometry records from dcn_prep_kernel) when the call has at least this many
+ * (image, 256-pixel tile) pairs -- 512 by default: the 128 x 128 / 64 x 64 maps of the benched step -- and as two
+ * kernels below it.  Tests set 1 to run small geometries (borders, odd widths, out-of-bounds samples) through the
+ * one-launch form, and INT_MAX to force the two-kernel form; values < 1 restore the default.  Returns the previous
+ * threshold.  Process-wide; results do not depend on it beyond the summation order inside grad_input. */
+int cnuda_launch_log_enable(int on);
+int cnuda_launch_log_collect(char* names, size_t cap);
+int cnuda_dcn_set_fused_min_tiles(int min_tiles);
+
 /* ------------------------------------------------------------------------
  * Detection decode -- replaces backends/decode.py:35-76 (decode_detection),
  * :6-13 (_nms), :16-32 (_topk) and the gathers of utils/tensor.py:10-25.

@@ -1,0 +1,332 @@
+"""Kernel -> the oracle-value tests that select it.
+
+Every kernel of libcenternet_uda_hip.so that one benched training step launches (tests/test_zz_kernel_coverage.py runs
+that step under the library's launch log) must have an entry here naming tests that compare ITS results with the
+oracle / the reference's golden vectors / an fp64 or CPU-torch restatement -- and the coverage test checks, from the
+launch log recorded while those very tests ran (tests/conftest.py), that they did launch it.  A new kernel on the hot
+path without a value test fails the suite; so does a size rule that moves an existing test off the kernel it claims
+(round 3: the one-launch DCN data-gradient walk ran 11 of the 16 DCN backwards of the bench and no oracle test).
+
+Keys: the kernel's symbol name with the namespace prefix and the argument list dropped (what
+`tests/test_zz_kernel_coverage.py::short` makes of the demangled name).  Values: pytest node-id prefixes.
+"""
+
+MANIFEST = {
+    'adam_kernel': [
+        'tests/test_gpu_ops.py::test_adam_matches_torch_and_skips_untouched_params',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+    ],
+    'bn_apply_kernel': [
+        'tests/test_gpu_ops.py::test_batch_norm_backward_gate_recomputed_from_x_is_the_gate_read_from_y',
+        'tests/test_gpu_ops.py::test_batch_norm_train_fwd_bwd_and_running_stats',
+        'tests/test_gpu_fuzz.py::test_batch_norm_random_geometry',
+    ],
+    'bn_bwd_apply_kernel': [
+        'tests/test_gpu_ops.py::test_batch_norm_backward_gate_recomputed_from_x_is_the_gate_read_from_y',
+        'tests/test_gpu_ops.py::test_batch_norm_train_fwd_bwd_and_running_stats',
+        'tests/test_gpu_fuzz.py::test_batch_norm_random_geometry',
+    ],
+    'bn_reduce_kernel<0>': [
+        'tests/test_gpu_ops.py::test_batch_norm_backward_gate_recomputed_from_x_is_the_gate_read_from_y',
+        'tests/test_gpu_ops.py::test_batch_norm_train_fwd_bwd_and_running_stats',
+        'tests/test_gpu_fuzz.py::test_batch_norm_random_geometry',
+    ],
+    'bn_reduce_kernel<1>': [
+        'tests/test_gpu_ops.py::test_batch_norm_backward_gate_recomputed_from_x_is_the_gate_read_from_y',
+        'tests/test_gpu_ops.py::test_batch_norm_train_fwd_bwd_and_running_stats',
+        'tests/test_gpu_fuzz.py::test_batch_norm_random_geometry',
+    ],
+    'channel_sum_final_kernel': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+    ],
+    'channel_sum_partial_kernel': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+    ],
+    'conv1x1_dgrad_act_kernel<2>': [
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+    ],
+    'conv1x1_dgrad_act_kernel<6>': [
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+    ],
+    'copy_channels_kernel': [
+        'tests/test_gpu_ops.py::test_cat_add_split',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+    ],
+    'dcn_bwd_data_kernel': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[64to64_128sq_one_launch',
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[128to64_64sq_one_launch',
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+        'tests/test_gpu_dcn.py::test_known_answer_validity_window_open_at_minus_one_and_H',
+        'tests/test_gpu_fuzz.py::test_dcn_random_geometry_vs_oracle',
+    ],
+    'dcn_col2im_kernel': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+        'tests/test_gpu_dcn.py::test_autograd_module_path_and_argument_order',
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+    ],
+    'dcn_coord_grad_kernel': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+        'tests/test_gpu_dcn.py::test_autograd_module_path_and_argument_order',
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+    ],
+    'dcn_prep_kernel': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+        'tests/test_gpu_dcn.py::test_autograd_module_path_and_argument_order',
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+    ],
+    'dcn_sample_kernel': [
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+        'tests/test_gpu_dcn.py::test_known_answer_half_pixel_offsets_are_box_blurs',
+        'tests/test_gpu_dcn.py::test_known_answer_linear_ramp_gradients',
+    ],
+    'dwconvt_bwd_k4s2_kernel': [
+        'tests/test_gpu_ops.py::test_depthwise_conv_transpose',
+        'tests/test_gpu_ops.py::test_depthwise_conv_transpose_with_summand_is_the_separate_add',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'dwconvt_bwd_kernel<8>': [
+        'tests/test_gpu_ops.py::test_depthwise_conv_transpose',
+        'tests/test_gpu_ops.py::test_depthwise_conv_transpose_with_summand_is_the_separate_add',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'dwconvt_fwd_f_kernel<2, 1>': [
+        'tests/test_gpu_ops.py::test_depthwise_conv_transpose',
+        'tests/test_gpu_ops.py::test_depthwise_conv_transpose_with_summand_is_the_separate_add',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'dwconvt_fwd_f_kernel<4, 4>': [
+        'tests/test_gpu_ops.py::test_depthwise_conv_transpose',
+        'tests/test_gpu_ops.py::test_depthwise_conv_transpose_with_summand_is_the_separate_add',
+    ],
+    'dwconvt_fwd_k4s2_kernel': [
+        'tests/test_gpu_ops.py::test_depthwise_conv_transpose',
+        'tests/test_gpu_ops.py::test_depthwise_conv_transpose_with_summand_is_the_separate_add',
+    ],
+    'dwconvt_wsum_kernel': [
+        'tests/test_gpu_ops.py::test_depthwise_conv_transpose',
+        'tests/test_gpu_ops.py::test_depthwise_conv_transpose_with_summand_is_the_separate_add',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'focal_bwd_kernel': [
+        'tests/test_gpu_losses.py::test_detection_loss_golden',
+        'tests/test_gpu_losses.py::test_full_size_losses_vs_oracle_cfg3',
+        'tests/test_gpu_losses.py::test_keypoint_detection_loss_golden',
+    ],
+    'focal_finalize_kernel': [
+        'tests/test_gpu_losses.py::test_detection_loss_golden',
+        'tests/test_gpu_losses.py::test_full_size_losses_vs_oracle_cfg3',
+        'tests/test_gpu_losses.py::test_keypoint_detection_loss_golden',
+    ],
+    'focal_fwd_kernel': [
+        'tests/test_gpu_losses.py::test_detection_loss_golden',
+        'tests/test_gpu_losses.py::test_full_size_losses_vs_oracle_cfg3',
+        'tests/test_gpu_losses.py::test_keypoint_detection_loss_golden',
+    ],
+    'igemm_fwd_kernel<128, DcnColsBufLoader, false>': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[256to256_32sq',
+    ],
+    'igemm_fwd_kernel<128, DcnFwdLoaderT<true>, false>': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[128to128_64sq',
+    ],
+    'igemm_fwd_kernel<32, ConvDgradBufLoader, false>': [
+        'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+    ],
+    'igemm_fwd_kernel<32, ConvDgradClassBufLoader, false>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
+        'tests/test_gpu_fuzz.py::test_conv_transpose2d_random_geometry',
+    ],
+    'igemm_fwd_kernel<32, ConvFwdBufLoader, false>': [
+        'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+    ],
+    'igemm_fwd_kernel<32, DcnColsBufLoader, false>': [
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+        'tests/test_gpu_dcn.py::test_known_answer_half_pixel_offsets_are_box_blurs',
+        'tests/test_gpu_dcn.py::test_known_answer_linear_ramp_gradients',
+    ],
+    'igemm_fwd_kernel<64, DcnColsBufLoader, false>': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[256to128_32sq',
+    ],
+    'igemm_fwd_kernel<64, DcnFwdLoaderT<true>, false>': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+    ],
+    'igemm_fwd_shortk_kernel<128, ConvFwdBufLoader, 64>': [
+        'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+    ],
+    'igemm_fwd_ws_kernel<128, ConvDgradBufLoader, 16>': [
+        'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+    ],
+    'igemm_fwd_ws_kernel<128, ConvFwdBufLoader, 16>': [
+        'tests/test_gpu_fullsize.py::test_full_size_3x3_convolution_matches_fp64',
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+    ],
+    'igemm_fwd_ws_kernel<64, ConvDgradBufLoader, 16>': [
+        'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
+        'tests/test_gpu_fullsize.py::test_full_size_3x3_convolution_matches_fp64',
+        'tests/test_gpu_resnet.py::test_model_step_resnet18_config0',
+    ],
+    'igemm_fwd_ws_kernel<64, ConvDgradClassBufLoader, 16>': [
+        'tests/test_gpu_fullsize.py::test_full_size_strided_convolution_matches_fp64',
+    ],
+    'igemm_fwd_ws_kernel<64, ConvFwdBufLoader, 16>': [
+        'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+    ],
+    'igemm_wgrad_kernel<ConvWBufLoader, 32, 128>': [
+        'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+    ],
+    'igemm_wgrad_kernel<ConvWLoader<0>, 32, 128>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
+    ],
+    'igemm_wgrad_kernel<ConvWLoader<0>, 64, 64>': [
+        'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+    ],
+    'igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+    ],
+    'igemm_wgrad_kernel<DcnColWBufLoader, 64, 64>': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+        'tests/test_gpu_dcn.py::test_autograd_module_path_and_argument_order',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 128>': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 64>': [
+        'tests/test_gpu_fullsize.py::test_full_size_3x3_convolution_matches_fp64',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+    ],
+    'igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 128>': [
+        'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
+        'tests/test_gpu_fuzz.py::test_conv_transpose2d_random_geometry',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 64>': [
+        'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
+    ],
+    'maxpool_bwd_kernel': [
+        'tests/test_gpu_ops.py::test_maxpool',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+    ],
+    'maxpool_fwd_kernel': [
+        'tests/test_gpu_ops.py::test_maxpool',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+    ],
+    'pack_kernel': [
+        'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
+        'tests/test_gpu_fullsize.py::test_full_size_3x3_convolution_matches_fp64',
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+    ],
+    'pack_taps_kernel': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
+        'tests/test_gpu_fuzz.py::test_conv_transpose2d_random_geometry',
+    ],
+    'regl1_bwd_kernel': [
+        'tests/test_gpu_losses.py::test_detection_loss_golden',
+        'tests/test_gpu_losses.py::test_full_size_losses_vs_oracle_cfg3',
+        'tests/test_gpu_losses.py::test_keypoint_detection_loss_golden',
+    ],
+    'regl1_fwd_kernel': [
+        'tests/test_gpu_losses.py::test_detection_loss_golden',
+        'tests/test_gpu_losses.py::test_full_size_losses_vs_oracle_cfg3',
+        'tests/test_gpu_losses.py::test_keypoint_detection_loss_golden',
+    ],
+    'scalar_finalize_kernel': [
+        'tests/test_gpu_losses.py::test_full_size_losses_vs_oracle_cfg3',
+        'tests/test_gpu_losses.py::test_uda_losses_golden',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'slab_reduce_few_kernel': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'slab_reduce_kernel': [
+        'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
+        'tests/test_gpu_fullsize.py::test_full_size_3x3_convolution_matches_fp64',
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+    ],
+    'smallc_fwd_kernel<1>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+        'tests/test_gpu_dcn.py::test_known_answer_col2im_four_weights',
+    ],
+    'smallc_koff_kernel': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+    ],
+    'smallc_pack_kernel': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+    ],
+    'smallc_slab_reduce1_kernel': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
+    ],
+    'smallc_slab_reduce2_kernel': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
+        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
+    ],
+    'smallc_wgrad_kernel<1>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
+        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
+        'tests/test_gpu_fuzz.py::test_conv_transpose2d_random_geometry',
+    ],
+    'softmax_loss_bwd_kernel': [
+        'tests/test_gpu_losses.py::test_full_size_losses_vs_oracle_cfg3',
+        'tests/test_gpu_losses.py::test_uda_losses_golden',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'softmax_loss_fwd_kernel': [
+        'tests/test_gpu_losses.py::test_full_size_losses_vs_oracle_cfg3',
+        'tests/test_gpu_losses.py::test_uda_losses_golden',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'split_offset_mask_bwd_kernel': [
+        'tests/test_gpu_ops.py::test_cat_add_split',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+    ],
+    'split_offset_mask_kernel': [
+        'tests/test_gpu_ops.py::test_cat_add_split',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+    ],
+}

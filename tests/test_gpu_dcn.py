@@ -53,8 +53,49 @@ CASES = {
 }
 
 
+# The data-gradient walk of the backward has two forms (csrc/dcn.hip): coord_grad + col2im as two kernels, and both
+# roles as ONE launch (`dcn_bwd_data_kernel` on `dcn_prep_kernel`'s packed geometry records) -- the form the benched
+# step runs on its 128 x 128 / 64 x 64 maps, selected by size.  Every value test below runs both: 'one_launch' lowers
+# the size rule to one tile (cnuda_dcn_set_fused_min_tiles), so borders, odd widths, tiles narrower than 64 pixels and
+# out-of-bounds samples (`cell = 0x80000000` records) go through that kernel too; the launch log says which ran.
+WALKS = {'two_kernels': 2 ** 31 - 1, 'one_launch': 1}
+
+
+class _walk:
+    """forces one form of the data-gradient walk and checks, from the library's launch log, that it ran"""
+
+    def __init__(self, walk, geoms):
+        self.walk, self.geoms = walk, geoms          # geoms: [(H, W, k, s, p, d, dg)] of the DCN calls inside the block
+
+    def __enter__(self):
+        import hip_runtime as hr
+        self.ctx = hr.dcn_fused_min_tiles(WALKS[self.walk])
+        self.ctx.__enter__()
+        self.log = hr.launch_log()
+        self.log.__enter__()
+
+    def __exit__(self, et, ev, tb):
+        import dcn_plan
+        import hip_runtime as hr
+        self.log.__exit__(et, ev, tb)
+        names = self.log.names
+        self.ctx.__exit__(et, ev, tb)
+        if et is None:
+            ran = dcn_plan.backward_walk_kernels(names)
+            can = [dcn_plan.one_launch_possible(*g) for g in self.geoms]
+            if self.walk == 'one_launch' and all(can):
+                assert ran == 'one_launch', (ran, names)
+            elif self.walk == 'two_kernels' and all(g[6] == 1 and g[1] >= 2 for g in self.geoms):
+                assert ran == 'two_kernels', (ran, names)
+
+
+def _geom_of(x, geom):
+    return (x.shape[2], x.shape[3], geom[0], geom[2], geom[4], geom[6], geom[8])
+
+
+@pytest.mark.parametrize('walk', sorted(WALKS))
 @pytest.mark.parametrize('name', sorted(CASES))
-def test_forward_backward_vs_oracle(name):
+def test_forward_backward_vs_oracle(name, walk):
     import _ext
     (x, w, b, off, m, go), geom = _case(zlib.crc32(name.encode()) % 1000, **CASES[name])
     want = od.dcn_v2_forward(x, w, b, off, m, *geom)
@@ -62,10 +103,21 @@ def test_forward_backward_vs_oracle(name):
     dx, dw_, db, doff, dm, dgo = [t.to(DEV) for t in (x, w, b, off, m, go)]
     out = _ext.dcn_v2_forward(dx, dw_, db, doff, dm, *geom)
     _close(out, want)
-    grads = _ext.dcn_v2_backward(dx, dw_, db, doff, dm, dgo, *geom)
+    with _walk(walk, [_geom_of(x, geom)]):
+        grads = _ext.dcn_v2_backward(dx, dw_, db, doff, dm, dgo, *geom)
     for got, ref, nm in zip(grads, wg, ['input', 'offset', 'mask', 'weight', 'bias']):
         assert got.shape == ref.shape, nm
         _close(got, ref)
+
+
+def test_the_one_launch_walk_is_reachable_for_the_expected_cases():
+    """the cases above that cannot take the one-launch walk are exactly: deformable groups, width 1, and the two
+    strided layers whose LDS window exceeds the budget (they run windowless two-kernel / generic paths)"""
+    import dcn_plan
+    cannot = sorted(n for n, c in CASES.items()
+                    if not dcn_plan.one_launch_possible(c['H'], c['W'], c.get('k', 3), c.get('s', 1), c.get('p', 1),
+                                                        c.get('d', 1), c.get('dg', 1)))
+    assert cannot == ['dg2', 'stride2', 'stride2_wide', 'width1'], cannot
 
 
 def test_zero_offset_identity_testcpu_32_67():
@@ -116,6 +168,13 @@ def _gpu_bwd(x, w, b, off, m, go, *geom):
     return [t.cpu() for t in _ext.dcn_v2_backward(*[t.to(DEV) for t in (x, w, b, off, m, go)], *geom)]
 
 
+def _gpu_bwd_walk(walk):
+    def run(x, w, b, off, m, go, *geom):
+        with _walk(walk, [_geom_of(x, geom)]):
+            return _gpu_bwd(x, w, b, off, m, go, *geom)
+    return run
+
+
 @pytest.mark.parametrize('dh,dw', [(0.5, 0.0), (0.0, 0.5), (0.5, 0.5), (-0.5, 0.5), (0.25, -0.75)])
 @pytest.mark.parametrize('size', [(2, 3, 7, 9, 4), (2, 64, 32, 40, 64), (1, 128, 16, 16, 128)])
 def test_known_answer_half_pixel_offsets_are_box_blurs(dh, dw, size):
@@ -123,20 +182,23 @@ def test_known_answer_half_pixel_offsets_are_box_blurs(dh, dw, size):
     ka.check_uniform_fractional_offset_is_box_blur_then_conv(_gpu_fwd, dh, dw, torch.float32, 2e-5, size=size)
 
 
-def test_known_answer_validity_window_open_at_minus_one_and_H():
+@pytest.mark.parametrize('walk', sorted(WALKS))
+def test_known_answer_validity_window_open_at_minus_one_and_H(walk):
     import dcn_known_answers as ka
-    ka.check_validity_window_is_open(_gpu_fwd, _gpu_bwd, torch.float32, 1e-6)
+    ka.check_validity_window_is_open(_gpu_fwd, _gpu_bwd_walk(walk), torch.float32, 1e-6)
 
 
+@pytest.mark.parametrize('walk', sorted(WALKS))
 @pytest.mark.parametrize('size', [(2, 3, 12, 11, 2), (2, 64, 40, 36, 64), (1, 16, 20, 70, 32)])
-def test_known_answer_linear_ramp_gradients(size):
+def test_known_answer_linear_ramp_gradients(size, walk):
     import dcn_known_answers as ka
-    ka.check_linear_ramp_has_constant_coordinate_gradient(_gpu_fwd, _gpu_bwd, torch.float32, 5e-5, size=size)
+    ka.check_linear_ramp_has_constant_coordinate_gradient(_gpu_fwd, _gpu_bwd_walk(walk), torch.float32, 5e-5, size=size)
 
 
-def test_known_answer_col2im_four_weights():
+@pytest.mark.parametrize('walk', sorted(WALKS))
+def test_known_answer_col2im_four_weights(walk):
     import dcn_known_answers as ka
-    ka.check_col2im_scatters_the_four_bilinear_weights(_gpu_bwd, torch.float32, 1e-6)
+    ka.check_col2im_scatters_the_four_bilinear_weights(_gpu_bwd_walk(walk), torch.float32, 1e-6)
 
 
 def test_errors():

@@ -118,6 +118,35 @@ def test_full_size_1x1_convolutions_match_fp64_and_repeat(B, C, S, Co):
         assert (got.double() - want).abs().max().item() <= 1e-4 * scale, name
 
 
+def test_full_size_strided_convolution_matches_fp64():
+    """3x3 stride 2, 64 -> 128 from 128 x 128 to 64 x 64, B = 32 (level3.tree1.tree1.conv1 of the benched step): the
+    input gradient runs one launch per input-pixel parity class on the wave-specialised 64-row tile
+    (`igemm_fwd_ws_kernel<64, ConvDgradClassBufLoader>`, 36 launches per benched step and no value test before round 4's
+    kernel-coverage manifest), against the CPU's fp64 convolution; forward and weight gradient ride along."""
+    import torch.nn.functional as F
+    import hip_runtime as hr
+    from hip_runtime import ops
+    from test_zz_kernel_coverage import short
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(32, 64, 128, 128, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) * 0.05
+    gy = torch.randn(32, 128, 64, 64, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    want_y = F.conv2d(xr, wr, None, 2, 1)
+    want_y.backward(gy.double())
+    xx, ww = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    with hr.launch_log() as log:
+        y = ops.conv2d(xx, ww, None, 2, 1)
+        y.backward(gy.to(DEV))
+    names = sorted(short(n) for n in log.names)
+    import os
+    if not any(os.environ.get(v) == '0' for v in ('CNUDA_BUF', 'CNUDA_WS')):
+        assert any(n.startswith('igemm_fwd_ws_kernel<64, ConvDgradClassBufLoader') for n in names), names
+    for name, got, want in (('y', y.detach(), want_y.detach()), ('gx', xx.grad, xr.grad), ('gw', ww.grad, wr.grad)):
+        scale = want.abs().max().item()
+        assert (got.double().cpu() - want).abs().max().item() <= 1e-4 * scale, name
+
+
 def test_full_size_3x3_convolution_matches_fp64():
     """3x3, 64 -> 256 at 64 x 64, B = 8: the 128-row forward tile (2 row tiles x 256 pixel tiles), the 64-row input
     gradient and the 128 x 64 weight-gradient tile, against the CPU's fp64 convolution."""
@@ -195,12 +224,29 @@ def _dcn_full_case(B, C, Co, S, off_scale, seed):
     return x, w, b, off, m, go
 
 
-# B is the smallest batch at which the launch plan picks the kernels the 32-image bench batch runs: the fused 64-row
-# `DcnFwdLoader` tile (one M tile: >= 512 pixel tiles), its column side output, the weight gradient from the saved
-# columns, the short-K column-gradient GEMM, the LDS-window col2im on 4 x 64 tiles
-@pytest.mark.parametrize('off_scale', [0.3, 1.0, 6.0], ids=['pm03px', 'pm1px', 'pm6px'])   # 0.3: col2im's DPP ranking path
-@pytest.mark.parametrize('B,C,Co,S', [(4, 64, 64, 128), (16, 128, 64, 64)], ids=['64to64_128sq', '128to64_64sq'])
-def test_full_size_dcn_layer_matches_the_oracle(B, C, Co, S, off_scale):
+# The DCN layer shapes of the benched step (32 images), each at the smallest batch at which the launch plan
+# (csrc/dcn.hip make_plan / pick_bm) picks the kernels the bench batch runs -- asserted from the library's launch log:
+#   64 -> 64 at 128 x 128 and 128 -> 64 at 64 x 64, each on either side of the 512-tile rule of the data-gradient walk:
+#     the smaller batch takes coord_grad + col2im (what the 32 x 32 / 16 x 16 maps of the bench run), the larger one
+#     (B * tiles = 512) the ONE-launch walk `dcn_bwd_data_kernel` on `dcn_prep_kernel`'s geometry records (what its
+#     128 x 128 / 64 x 64 maps run); forward: the 64-row `DcnFwdLoader` tile with its column side output;
+#   128 -> 128 at 64 x 64: the 128-row `DcnFwdLoader` tile;
+#   256 -> 256 and 256 -> 128 at 32 x 32: the two-kernel forward (dcn_sample_kernel + a 128- / 64-row GEMM over the columns).
+DCN_LAYERS = {
+    '64to64_128sq': dict(B=4, C=64, Co=64, S=128, kernels=['igemm_fwd_kernel<64, DcnFwdLoaderT<true>', 'dcn_col2im_kernel', 'dcn_coord_grad_kernel', 'igemm_fwd_shortk_kernel', 'igemm_wgrad_kernel<DcnColWBufLoader, 64, 64>']),
+    '64to64_128sq_one_launch': dict(B=8, C=64, Co=64, S=128, kernels=['igemm_fwd_kernel<64, DcnFwdLoaderT<true>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel', 'igemm_fwd_shortk_kernel']),
+    '128to64_64sq': dict(B=16, C=128, Co=64, S=64, kernels=['igemm_fwd_kernel<64, DcnFwdLoaderT<true>', 'dcn_col2im_kernel', 'dcn_coord_grad_kernel', 'igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>']),
+    '128to64_64sq_one_launch': dict(B=32, C=128, Co=64, S=64, kernels=['igemm_fwd_kernel<64, DcnFwdLoaderT<true>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel']),
+    '128to128_64sq': dict(B=16, C=128, Co=128, S=64, kernels=['igemm_fwd_kernel<128, DcnFwdLoaderT<true>']),
+    '256to256_32sq': dict(B=32, C=256, Co=256, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_kernel<128, DcnColsBufLoader']),
+    '256to128_32sq': dict(B=32, C=256, Co=128, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_kernel<64, DcnColsBufLoader']),
+}
+_DCN_CASES = [(n, o) for n in DCN_LAYERS for o in ((0.3, 1.0, 6.0) if DCN_LAYERS[n]['S'] >= 64 and DCN_LAYERS[n]['Co'] == 64 else (1.0,))]
+
+
+@pytest.mark.parametrize('layer,off_scale', _DCN_CASES,      # 0.3 px: col2im's DPP ranking path; 6 px: strays beyond the LDS window
+                         ids=['%s-pm%gpx' % (n, o) for n, o in _DCN_CASES])
+def test_full_size_dcn_layer_matches_the_oracle(layer, off_scale):
     """`dcn_v2_cuda.cu:42-341` at the layer shapes the bench runs, VALUES against the CPU oracle (forward, the saved
     columns, all five gradients, 1e-4 of each tensor's magnitude), through the product's autograd path (which keeps
     the columns) and through the literal `_ext` entry points (which do not) -- and again while a second stream runs
@@ -210,6 +256,8 @@ def test_full_size_dcn_layer_matches_the_oracle(B, C, Co, S, off_scale):
     from hip_runtime import ops
     from libs.DCNv2.dcn_v2 import dcn_v2_conv
     from oracle import dcn as od
+    from test_zz_kernel_coverage import short
+    B, C, Co, S = (DCN_LAYERS[layer][k] for k in ('B', 'C', 'Co', 'S'))
     x, w, b, off, m, go = _dcn_full_case(B, C, Co, S, off_scale, 1000 * C + S + int(10 * off_scale))
     geom = (3, 3, 1, 1, 1, 1, 1, 1, 1)
     want_y = od.dcn_v2_forward(x, w, b, off, m, *geom)
@@ -235,12 +283,15 @@ def test_full_size_dcn_layer_matches_the_oracle(B, C, Co, S, off_scale):
         y.backward(dev[5])
         return [y.detach()] + [l.grad for l in leaves] + [cols.clone()]
 
-    hr.prof_begin()
-    res = autograd_path()
-    names = ' | '.join(hr.prof_end())
+    with hr.launch_log() as log:
+        res = autograd_path()
+    names = sorted(short(n) for n in log.names)
     print(names)
-    assert '(+ column side output)' in names, names
-    assert 'dcn_col2im_kernel' in names and 'dcn_coord_grad_kernel' in names, names
+    import os
+    if not any(os.environ.get(v) == '0' for v in ('CNUDA_BUF', 'CNUDA_WS', 'CNUDA_SHORTK')):     # (tests/test_gpu_kernel_switches.py)
+        for want_kernel in DCN_LAYERS[layer]['kernels']:
+            assert any(n.startswith(want_kernel) for n in names), (want_kernel, names)
+    assert ('dcn_bwd_data_kernel' in names) != ('dcn_col2im_kernel' in names), names
     y, gx, goff, gm, gw, gb, cols = res
     close(y, want_y, 'forward')
     for bi, wc in want_cols.items():

@@ -109,9 +109,11 @@ def _dcn_cases(n, seed):
     return out
 
 
+@pytest.mark.parametrize('walk', ['two_kernels', 'one_launch'])      # the two forms of the data-gradient walk (test_gpu_dcn.py)
 @pytest.mark.parametrize('case', _dcn_cases(20, 4321), ids=lambda c: 'B%dC%dCo%dH%dW%ds%ddg%dsig%g' % c)
-def test_dcn_random_geometry_vs_oracle(case):
+def test_dcn_random_geometry_vs_oracle(case, walk):
     import _ext
+    from test_gpu_dcn import _walk
     from oracle import dcn as od
     od.build()
     B, C, Co, H, W, s, dg, sigma = case
@@ -130,7 +132,8 @@ def test_dcn_random_geometry_vs_oracle(case):
     want = od.dcn_v2_backward(x, w, b, off, m, gy, *geom)
     d = [t.to(DEV) for t in (x, w, b, off, m)]
     got_y = _ext.dcn_v2_forward(*d, *geom)
-    got = _ext.dcn_v2_backward(*d, gy.to(DEV), *geom)
+    with _walk(walk, [(H, W, 3, s, 1, 1, dg)]):
+        got = _ext.dcn_v2_backward(*d, gy.to(DEV), *geom)
     _close(got_y, want_y, what='y')
     for name, a, r in zip(('gx', 'goff', 'gmask', 'gw', 'gb'), got, want):
         _close(a, r, what=name)

@@ -249,6 +249,33 @@ def test_head_pair_is_one_tape_node_with_the_two_layers_values(B, C, Ch, Co, H, 
     assert not type(head(odd).grad_fn).__name__.startswith('_ConvActConv1x1')
 
 
+def test_head_fused_node_leaves_hooks_and_gradient_free_calls_to_the_children():
+    """The fused head node replaces the children's forward (hip_runtime/nn.py Head.forward): with a forward hook on a
+    child -- feature extraction, activation statistics -- or with nothing that needs a gradient, the layers run in turn
+    (same values: the same two kernels)."""
+    import hip_runtime.nn as hnn
+    torch.manual_seed(3)
+    head = hnn.Head(hnn.Conv2d(16, 32, 3, padding=1, act_slope=0.0), hnn.Slot(), hnn.Conv2d(32, 2, 1)).to(DEV)
+    x = torch.randn(2, 16, 8, 12, device=DEV)
+    fused = head(x)
+    assert type(fused.grad_fn).__name__.startswith('_ConvActConv1x1')
+    seen = []
+    handle = head[0].register_forward_hook(lambda m, i, o: seen.append(tuple(o.shape)))
+    hooked = head(x)
+    handle.remove()
+    assert seen == [(2, 32, 8, 12)] and not type(hooked.grad_fn).__name__.startswith('_ConvActConv1x1')
+    assert torch.equal(hooked, fused)
+    pre = head[2].register_forward_pre_hook(lambda m, i: seen.append('pre'))
+    head(x)
+    pre.remove()
+    assert seen[-1] == 'pre'
+    for p in head.parameters():
+        p.requires_grad_(False)
+    frozen = head(x)                       # tape enabled, but nothing requires a gradient: no hidden map is kept
+    assert frozen.grad_fn is None and torch.equal(frozen, fused)
+    assert type(head(x.clone().requires_grad_(True)).grad_fn).__name__.startswith('_ConvActConv1x1')
+
+
 def test_launch_stream_is_torchs_current_stream():
     """hip_runtime.stream() (the raw handle from torch's C layer) follows torch's current stream, also inside a
     `torch.cuda.stream(...)` context and on the workspace key."""

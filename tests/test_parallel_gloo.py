@@ -90,9 +90,19 @@ def _worker(rank, world, port, bucket_bytes, q):
         net.register_buffer('count', torch.tensor(rank + 5, dtype=torch.int64))
         dp.train()
         assert float(net.stat[0]) == 10.0 * (rank + 1)            # train -> train: nothing is exchanged
-        dp.eval()
-        assert float(net.stat[0]) == 10.0 and int(net.count) == 5 and not net.training
+        dp.eval()                                                 # plain nn.Module call: no hidden collective
+        assert float(net.stat[0]) == 10.0 * (rank + 1) and not net.training
         dp.train()
+        # the plugin's set_phase(False) is where the exchange happens, explicitly (uda/base.py)
+        import uda.base
+        plugin = uda.base.Model()
+        plugin.backend = dp
+        plugin.set_phase(True)
+        assert float(net.stat[0]) == 10.0 * (rank + 1)
+        plugin.set_phase(False)
+        assert float(net.stat[0]) == 10.0 and int(net.count) == 5 and not net.training
+        plugin.set_phase(False)                                   # eval -> eval: nothing is exchanged
+        plugin.set_phase(True)
         q.put((rank, 'ok'))
     except Exception as e:                                  # pragma: no cover
         import traceback
