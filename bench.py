@@ -165,6 +165,9 @@ def cpu_baseline(budget_s=150.0):
         'value': round(1.0 / med, 5), 'unit': 'images/sec (512x512 source images)', 'cores': torch.get_num_threads(),
         'kind': 'port',
         's_per_step_512': {'median': round(med, 3), 'min': round(ts[0], 3), 'max': round(ts[-1], 3), 'repeats': len(ts)},
+        # the same leg on other boxes of this pool (128-thread hosts): 0.074 (round-3 collection box), 0.089 (round-3
+        # driver box) -- quote the CPU figure as 0.07-0.09 img/s, not to three digits
+        'box_to_box_range': [0.074, 0.089],
         'sample': ('EntropyMinimization step of the CPU oracle on 1 source + 1 target 512x512 image: 1 untimed warm-up '
                    'at 256x256, %d timed step(s) (median %.2f s, spread %.2f-%.2f s, budget %.0f s); torch CPU conv/BN '
                    '(%d threads) + single-thread C DCN loops like the reference CPU extension; `value` = 1 / median'
@@ -243,6 +246,49 @@ def inference_throughput(device, backend, size, batch):
             'mfma_fraction': round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
             'what': 'export.CenterNet: eval forward + decode (K=%d), fp32, BatchNorm folded into the conv / DCN '
                     'weights (bias + skip connection + ReLU in the GEMM epilogues), no tape' % MAX_OBJS}
+
+
+def dp1_rccl_leg(device, args):
+    """The headline step through the data-parallel wrapper with a ONE-rank RCCL group -- the N = 1 point of the
+    multi-GPU code path: gradient arena flushed per bucket, 4 bucketed all-reduces launched from the gradient-ready
+    hooks, finish_gradient_sync, the global-normaliser all-reduces of the detection loss -- timed beside the plain
+    step of the same process, so the wrapper's fixed overhead is a number (SCALE runs then start from it)."""
+    import socket
+    created = False
+    if not dist.is_initialized():
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=device)
+        created = True
+    try:
+        plugin = build_plugin(device, parallel=True, uda_name=args.uda, backend_name=args.backend)
+        batch = synthetic_batch(args.batch, args.size, 42, device, rotated=UDA_WORKLOADS[args.uda][2])
+        for _ in range(3):
+            plugin.step(fresh(batch))
+        torch.cuda.synchronize()
+        dp = plugin.backend
+        dp.reset_exchange_stats(measure=True)
+        n = max(5, args.steps)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            plugin.step(fresh(batch))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        xs = dp.exchange_stats()
+        dp.reset_exchange_stats(measure=False)
+        del plugin, batch
+        torch.cuda.empty_cache()
+        return {'ms_per_step': round(dt * 1e3, 3), 'value': round(args.batch / dt, 3), 'unit': 'images/sec',
+                'steps': n, 'collective': xs,
+                'what': 'same workload, uda.Model.to(device, parallel=True): hip_runtime.parallel.DataParallel over a '
+                        'one-rank RCCL process group (all-reduce = identity, every launch and wait of the N > 1 path)'}
+    finally:
+        if created:
+            dist.destroy_process_group()
 
 
 def other_configs(device, skip):
@@ -493,6 +539,12 @@ def main():
                          'value': round(args.batch * args.steps / e1, 3), 'unit': 'images/sec',
                          'note': 'cnuda_set_matrix_mode(1) for conv forward / input-gradient / DCN column-gradient '
                                  'GEMMs; weight-gradient and DCN forward GEMMs stay on the f32 MFMA'}
+    dp1 = None
+    if world == 1 and not args.no_extras:
+        try:
+            dp1 = dp1_rccl_leg(device, args)
+        except Exception as e:                       # (a box without a usable RCCL: report, do not lose the line)
+            dp1 = {'error': '%s: %s' % (type(e).__name__, e)}
     if world > 1:
         dist.barrier()
 
@@ -532,6 +584,7 @@ def main():
             if args.backend == 'dla34' else None,
             'step_mfma_fraction_executed': round(roofline['executed_tflop_per_step'] / (ms * 1e-3) / PEAK_FP32_MFMA_TFLOPS, 4)
             if roofline else None,
+            'gc_frozen': True,      # gc.freeze() after the warm-up (see above): gen-2 passes over warm-up objects are not in `value`
             'ms_per_step_sd': round(float(np.std(per_step)), 3), 'ms_per_step_min': round(min(per_step), 3),
             'ms_per_step_max': round(max(per_step), 3),
             'collective': collective,
@@ -542,6 +595,7 @@ def main():
             'inference': inference_throughput(device, getattr(plugin.backend, 'module', plugin.backend), args.size,
                                               args.batch) if world == 1 and not args.no_extras else None,
             'matrix_mode_split': split_leg,
+            'dp1_rccl': dp1,
             'other_configs': other_configs(device, args.config if args.config is not None else 2)
             if world == 1 and not args.no_extras and args.config in (None, 2) and args.uda == 'entropy'
             and args.size == 512 and args.batch == 16 else None,

@@ -178,6 +178,14 @@ char* g_pack_arena = nullptr;
 size_t g_pack_arena_bytes = 0, g_pack_arena_used = 0;
 uint64_t g_pack_generation = 0;               // bumped when a slot is added (the refresh table is rebuilt then)
 std::atomic<unsigned long long> g_pack_fills{0};   // cached images (re)written on a convolution's own call
+// Eviction.  The arena is a bump allocator and a module that is gone (a model deleted, a plugin rebuilt: bench.py's
+// other_configs legs, a test session) never returns its slots, so a long-lived process would fill the arena and then
+// silently stop caching.  When a slot does not fit, the request is served from the caller's workspace and a RESET is
+// scheduled; it happens at the next cnuda_pack_stamp of a cached call -- never in the middle of an entry point, whose
+// earlier packs may still be in flight in slots a reset would hand out again -- and forgets every slot: the live
+// modules re-pack once, on the launch stream, in stream order behind everything that still reads the old images.
+std::atomic<bool> g_pack_reset_wanted{false};
+std::atomic<unsigned long long> g_pack_resets{0};
 thread_local uint64_t g_pack_token = 0, g_pack_version = 0;
 
 // -> cached slot to use (fill == true: pack into it first), or nullptr: use the workspace
@@ -204,7 +212,10 @@ float* pack_slot(const PackKey& key, size_t bytes, bool& fill, int cpad = 0, con
     }
     if (it == g_pack_slots.end()) {
         const size_t need = (bytes + 255) / 256 * 256;
-        if (g_pack_arena_used + need > g_pack_arena_bytes) return nullptr;        // arena full: no caching
+        if (g_pack_arena_used + need > g_pack_arena_bytes) {                      // arena full: this request goes to the
+            g_pack_reset_wanted = need <= g_pack_arena_bytes;                     // workspace, the cache starts over at
+            return nullptr;                                                       // the next stamped call
+        }
         it = g_pack_slots.emplace(key, PackSlot{g_pack_arena_used, bytes, ~0ull, 0, 0, {0}}).first;
         g_pack_arena_used += need;
         ++g_pack_generation;
@@ -276,6 +287,8 @@ extern "C" int cnuda_pack_cache_attach(void* arena, size_t bytes) {
     cnuda::g_pack_arena = reinterpret_cast<char*>(((uintptr_t)arena + 255) & ~(uintptr_t)255);
     cnuda::g_pack_arena_bytes = arena ? bytes - (size_t)(cnuda::g_pack_arena - (char*)arena) : 0;
     cnuda::g_pack_arena_used = 0;
+    cnuda::g_pack_reset_wanted = false;
+    ++cnuda::g_pack_generation;
     if (!arena) cnuda::g_pack_arena = nullptr;
     return 0;
 }
@@ -383,9 +396,22 @@ extern "C" int cnuda_pack_refresh(const void* params, size_t params_bytes, unsig
 }
 
 extern "C" int cnuda_pack_stamp(unsigned long long token, unsigned long long version) {
-    cnuda::g_pack_token = token;
-    cnuda::g_pack_version = version;
+    using namespace cnuda;
+    if (token != 0 && g_pack_reset_wanted) {
+        std::lock_guard<std::mutex> lock(g_pack_mutex);
+        if (g_pack_reset_wanted) {
+            g_pack_slots.clear();
+            g_pack_arena_used = 0;
+            ++g_pack_generation;
+            g_refresh_table = nullptr;       // (the next refresh uploads its job list afresh)
+            g_pack_reset_wanted = false;
+            ++g_pack_resets;
+        }
+    }
+    g_pack_token = token;
+    g_pack_version = version;
     return 0;
 }
+extern "C" unsigned long long cnuda_pack_cache_resets(void) { return cnuda::g_pack_resets.load(); }
 extern "C" size_t cnuda_pack_cache_used(void) { return cnuda::g_pack_arena_used; }
 extern "C" unsigned long long cnuda_pack_cache_fills(void) { return cnuda::g_pack_fills.load(); }

@@ -119,6 +119,7 @@ class _Sig:
     cnuda_pack_refresh = (_I, [_P, ctypes.c_size_t, ctypes.c_ulonglong, ctypes.c_ulonglong, _P, ctypes.c_size_t, _P])
     cnuda_pack_cache_used = (c_size_t, [])
     cnuda_pack_cache_fills = (ctypes.c_ulonglong, [])
+    cnuda_pack_cache_resets = (ctypes.c_ulonglong, [])
     cnuda_prof_enable = (_I, [_I])
     cnuda_prof_arm = (_I, [_I])
     cnuda_prof_collect = (_I, [_P, _P, _P, _I])

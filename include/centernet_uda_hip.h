@@ -61,6 +61,10 @@ int cnuda_pack_cache_attach(void* arena, size_t bytes);
 int cnuda_pack_stamp(unsigned long long token, unsigned long long version);
 size_t cnuda_pack_cache_used(void);
 unsigned long long cnuda_pack_cache_fills(void);
+/* Eviction: slots of modules that no longer exist are never returned one by one; when an image does not fit any more
+ * the cache forgets EVERY slot at the start of the next stamped call (the live modules re-pack once) instead of
+ * silently not caching for the rest of the process.  cnuda_pack_cache_resets: how often that happened. */
+unsigned long long cnuda_pack_cache_resets(void);
 /* After an optimizer step that rewrote [params, params + params_bytes) behind the callers' version counters: every
  * cached image whose source lies in that range and that was current in epoch `old_epoch` (the high 32 bits of the
  * version it was stamped with) is rebuilt by ONE launch on `stream` and re-stamped with `new_epoch` (low 32 bits

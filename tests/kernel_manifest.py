@@ -249,6 +249,9 @@ MANIFEST = {
         'tests/test_gpu_fullsize.py::test_full_size_3x3_convolution_matches_fp64',
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
     ],
+    'pack_multi_kernel': [
+        'tests/test_gpu_ops.py::test_pack_refresh_after_the_fused_adam_step',
+    ],
     'pack_taps_kernel': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
         'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',

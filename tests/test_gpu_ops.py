@@ -392,6 +392,41 @@ def test_pack_cache_follows_the_weights():
     _close(xg.grad, xr.grad)
 
 
+def test_pack_cache_starts_over_when_the_arena_is_full():
+    """Slots of modules that are gone are never returned one by one; once an image does not fit, the cache forgets
+    every slot at the next stamped call (csrc/pack.hip, "Eviction") instead of silently not caching for the rest of the
+    process -- the state the 768 MB arena reached half-way through a test session or bench.py's other_configs legs."""
+    import hip_runtime as hr
+    from hip_runtime import nn as hnn
+    L = hr.lib()
+    x = torch.randn(2, 64, 9, 11, device=DEV)
+    hnn.Conv2d(64, 64, 3, padding=1).to(DEV)(x)                   # (the process-wide arena exists from here on)
+    big = hr._PACK['arena']
+    small = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)    # room for two 64 -> 64 3x3 images (368 KB each)
+    hr.check(L.cnuda_pack_cache_attach(hr.ptr(small), small.numel()), 'attach')
+    try:
+        r0 = L.cnuda_pack_cache_resets()
+        convs = [hnn.Conv2d(64, 64, 3, padding=1, bias=True).to(DEV) for _ in range(5)]
+        with torch.no_grad():
+            for rounds in range(2):
+                for c in convs:
+                    _close(c(x), F.conv2d(x.cpu(), c.weight.detach().cpu(), c.bias.detach().cpu(), 1, 1), 1e-4)
+                    assert L.cnuda_pack_cache_used() <= small.numel()
+        assert L.cnuda_pack_cache_resets() > r0
+        # steady state of a working set that fits: two modules, no further fills, no further resets
+        pair = convs[:2]
+        for c in pair:
+            c(x)
+        f0, r1 = L.cnuda_pack_cache_fills(), L.cnuda_pack_cache_resets()
+        with torch.no_grad():
+            for _ in range(3):
+                for c in pair:
+                    c(x)
+        assert L.cnuda_pack_cache_fills() == f0 and L.cnuda_pack_cache_resets() == r1
+    finally:
+        hr.check(L.cnuda_pack_cache_attach(hr.ptr(big), big.numel()), 'attach')
+
+
 def test_pack_refresh_after_the_fused_adam_step():
     """After optim.Adam.step() every cached packed image built from the parameter arena is rebuilt by one launch and
     carried into the new parameter epoch (cnuda_pack_refresh): a few training steps of a small stack (3x3, strided,
