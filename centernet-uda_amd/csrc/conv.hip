@@ -13,6 +13,7 @@
 
 #include <type_traits>
 #include "igemm.cuh"
+#include "hconv.cuh"
 #include "igemm_host.h"
 
 namespace cnuda {
@@ -616,6 +617,57 @@ ConvPlan make_plan(const ConvGeom& g) {
     return q;
 }
 
+// ---------------------------------------------------------------------------
+// Halo-tile kernels (hconv.cuh) for 3x3 / stride 1 / padding 1: the forward and -- over grad_y, with flipped taps --
+// the input gradient.  CNUDA_HCONV=0 keeps the im2col-style kernels (A/B measurements).
+// ---------------------------------------------------------------------------
+struct HconvFwd {
+    using Params = ConvFwdParams;
+    using Out = ConvFwdLoader<true>::Out;
+    static const char* name() { return "fwd"; }
+};
+struct HconvDgrad {
+    using Params = ConvDgradParams;
+    using Out = ConvDgradLoader::Out;
+    static const char* name() { return "dgrad"; }
+};
+bool hconv_enabled() {
+    static const bool on = !(getenv("CNUDA_HCONV") && getenv("CNUDA_HCONV")[0] == '0');
+    return on;
+}
+// kc: channels of the gathered tensor (x for the forward, grad_y for the input gradient)
+bool hconv_ok(const ConvGeom& g, int kc) {
+    return hconv_enabled() && matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 &&
+           g.pw == 1 && kc % 16 == 0 && (g.W == 16 || g.W == 32 || g.W == 64 || g.W == 128) &&
+           ((long long)g.H * g.W) % IG_BN == 0 && (size_t)g.B * kc * g.H * g.W * sizeof(float) < IG_BUF_OOB;
+}
+template <int BM, class Ad>
+void hconv_launch_one(const typename Ad::Params& p, const float* src, const float* A, int Mp, int Kp, int M, long long N,
+                      int n_tiles, int m_tiles, const HaloGeom& hg, hipStream_t st) {
+    const size_t lds = hconv_lds_bytes(hg, BM);
+    static size_t allowed = 64 * 1024;                  // dynamic LDS beyond 64 KiB is opt-in per kernel
+    if (lds > allowed) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hconv_kernel<BM, Ad>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        allowed = 160 * 1024;
+    }
+    CNUDA_LAUNCH((hconv_kernel<BM, Ad>), dim3(n_tiles * m_tiles), dim3(IG_THREADS), lds, st, p, src, A, Mp, Kp, M, N,
+                 n_tiles, m_tiles, hg);
+}
+template <class Ad>
+int launch_hconv(int bm, const typename Ad::Params& p, const float* src, int kc, const ConvGeom& g, const float* A, int Mp,
+                 int Kp, int M, long long N, hipStream_t st, const char* who) {
+    CNUDA_REQUIRE(N < (1ll << 31) - IG_BN, "%s: more than 2^31 pixels per call", who);
+    const int n_tiles = ceil_div(N, IG_BN), m_tiles = Mp / bm;
+    const HaloGeom hg = make_halo_geom(kc, g.H, g.W);
+    ProfScope prof(st);
+    prof.name("hconv_kernel<%d, %s>", bm, Ad::name());
+    if (bm == 128) hconv_launch_one<128, Ad>(p, src, A, Mp, Kp, M, N, n_tiles, m_tiles, hg, st);
+    else if (bm == 64) hconv_launch_one<64, Ad>(p, src, A, Mp, Kp, M, N, n_tiles, m_tiles, hg, st);
+    else hconv_launch_one<32, Ad>(p, src, A, Mp, Kp, M, N, n_tiles, m_tiles, hg, st);
+    return check_launch(who);
+}
+
 template <class Loader>
 int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp, int Kp, int M, long long N,
                hipStream_t st, const char* who) {
@@ -711,9 +763,14 @@ extern "C" int cnuda_conv2d_forward_res(const float* x, const float* weight, con
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_conv2d_forward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
+    ConvFwdParams p{g, x, bias, y, act_slope, residual};
+    if (hconv_ok(g, C)) {      // (K = 9 C is already a multiple of the chunk: the same packed size, another K order)
+        const float* Ah = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),
+                                      ig_a_bytes(q.Kpf, q.Mpf), Cout, C, q.T, PACK_HALO_FWD, q.Kpf, q.Mpf, 0, st);
+        return launch_hconv<HconvFwd>(q.bmf, p, x, C, g, Ah, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
+    }
     const float* A = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),
                                  ig_a_bytes(q.Kpf, q.Mpf), Cout, C, q.T, PACK_FWD, q.Kpf, q.Mpf, 0, st);
-    ConvFwdParams p{g, x, bias, y, act_slope, residual};
     if (C % IG_BK == 0 && buffer_addressing() && q.T <= 32 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB)
         return launch_fwd<ConvFwdBufLoader>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
     if (C % IG_BK == 0)
@@ -767,6 +824,11 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
                     return rc;
             }
         return 0;
+    }
+    if (hconv_ok(g, Cout)) {   // (Co % 16 == 0: Kpd = 9 Co, no padded rows)
+        const float* Ah = launch_pack(weight, Aws, ig_a_bytes(q.Kpd, q.Mpd), Cout, C, q.T, PACK_HALO_DGRAD, q.Kpd, q.Mpd, 0, st);
+        ConvDgradParams ph{g, grad_y, grad_x, Cout};
+        return launch_hconv<HconvDgrad>(q.bmd, ph, grad_y, Cout, g, Ah, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
     }
     const float* A = launch_pack(weight, Aws, ig_a_bytes(q.Kpd, q.Mpd), Cout, C, q.T, PACK_DGRAD, q.Kpd, q.Mpd,
                                  round_up(Cout, IG_BK), st);

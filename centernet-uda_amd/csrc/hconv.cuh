@@ -1,0 +1,204 @@
+// Halo-tile implicit GEMM for 3x3 / stride 1 / padding 1 convolutions (forward, and the input gradient, which is the
+// same convolution over grad_y with flipped taps) on the fp32 MFMA.
+//
+// The im2col-style kernels of igemm.cuh gather every tap's B tile from global memory: nine loads of (nearly) the same
+// input element per channel, nine LDS stores, and -- for the narrow GEMMs (27 output rows: the DCN offset
+// convolutions) -- a texture-address unit that is as busy as the matrix pipe.  Here the K axis is ordered
+// (16-channel group, tap, channel in group): a workgroup stages the INPUT tile of a channel group once -- its 128
+// consecutive pixels (TR full rows of an image row width W <= 128) plus a one-pixel halo, 16-byte loads and LDS
+// stores -- and the nine chunks of that group read their B fragments straight from that halo tile at (row + r,
+// column + s): lane-consecutive ds_read_b32 like the im2col tile's, one wave-uniform address term per chunk.
+// Per channel group a thread issues 2..6 16-byte loads instead of 72 4-byte ones.  The A (weight) tile is staged per
+// chunk exactly as in igemm_fwd_kernel; the packed weights use the same K order (PACK_HALO_FWD / PACK_HALO_DGRAD).
+//
+// Tile = 128 consecutive pixels n of the flattened (b, y, x) axis, so the epilogues of igemm.cuh apply unchanged.
+// Host-side conditions (conv.hip hconv_ok): 3x3, stride 1, padding 1, gathered channels % 16 == 0, W in {16, 32, 64,
+// 128}, H * W % 128 == 0, tensor below 2 GiB, f32 matrix mode.
+#pragma once
+#include "igemm.cuh"
+
+namespace cnuda {
+
+struct HaloGeom {
+    int Kc, H, W, w_shift;     // gathered channels, plane size, log2(W)
+    int TR;                    // image rows per pixel tile (128 / W)
+    int RS, PL;                // LDS row stride and plane size of the halo tile, floats
+    int cpr, cpp, cells;       // 16-byte cells per row (W / 4), per plane ((TR + 2) * cpr), per channel group (16 * cpp)
+};
+constexpr int HC_MAXCELLS = 6;      // per thread: W = 128 -> 16 * 3 * 32 / 256
+
+inline HaloGeom make_halo_geom(int Kc, int H, int W) {
+    HaloGeom h;
+    h.Kc = Kc; h.H = H; h.W = W;
+    h.w_shift = W == 128 ? 7 : (W == 64 ? 6 : (W == 32 ? 5 : 4));
+    h.TR = 128 / W;
+    // column index of image column x is x + 4 (16-byte aligned interior), the halo columns are 3 and W + 4.  W = 16:
+    // a 32-pixel MFMA column block spans two rows, a stride of 48 puts the second row 16 banks away from the first
+    h.RS = W == 16 ? 48 : W + 8;
+    h.PL = (h.TR + 2) * h.RS;
+    h.cpr = W / 4;
+    h.cpp = (h.TR + 2) * h.cpr;
+    h.cells = 16 * h.cpp;
+    return h;
+}
+inline size_t hconv_lds_bytes(const HaloGeom& h, int bm) { return (size_t)(2 * 16 * h.PL + 2 * IG_KC * bm) * sizeof(float); }
+
+// One 16-deep chunk = one tap (r, s) of one channel group: A fragments from the staged weight tile, B fragments from
+// the halo tile.  Same two-deep register pipeline as ig_mma_chunk.
+template <int BM>
+__device__ __forceinline__ void hc_mma_chunk(const float* __restrict__ As, const float* __restrict__ Hb,
+                                             f32x16 (&acc)[IgTile<BM>::TM][IgTile<BM>::TN], int wm_off,
+                                             const int (&boff)[IgTile<BM>::TN], int PL, int lane) {
+    using T = IgTile<BM>;
+    const int kl = lane >> 5, il = lane & 31;
+    const float* ap = As + kl * BM + wm_off + il;
+    const float* bp[T::TN];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) bp[j] = Hb + kl * PL + boff[j];
+    float a[2][T::TM], b[2][T::TN];
+    auto frag = [&](int kk, float (&fa)[T::TM], float (&fb)[T::TN]) {
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i) fa[i] = ap[kk * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j) fb[j] = bp[j][kk * PL];
+    };
+    auto mma = [&](const float (&fa)[T::TM], const float (&fb)[T::TN]) {
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    frag(0, a[0], b[0]);
+#pragma unroll
+    for (int kk = 0; kk < IG_KC; kk += 4) {
+        frag(kk + 2, a[1], b[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a[0], b[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 4 < IG_KC) frag(kk + 4, a[0], b[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a[1], b[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Ad: { using Params; using Out; static const char* name(); }  -- the epilogue contract of igemm.cuh's loaders.
+template <int BM, class Ad>
+__global__ __launch_bounds__(IG_THREADS, 2) void hconv_kernel(
+    typename Ad::Params p, const float* __restrict__ src, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
+    int n_tiles, int m_tiles, HaloGeom hg) {
+    using T = IgTile<BM>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // Hs[2][16 * PL] | As[2][16 * BM]; reused by the epilogue
+    const int PL = hg.PL, RS = hg.RS;
+    float* const Hs = smem;
+    float* const Asb = smem + 2 * 16 * PL;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wg = xcd_remap(blockIdx.x, n_tiles * m_tiles);
+    const int m0 = (wg % m_tiles) * BM;
+    const long long n0 = (long long)(wg / m_tiles) * IG_BN;
+    const int wm_off = (wid / T::WN) * (T::TM * 32), wn_off = (wid % T::WN) * (T::TN * 32);
+    const int HW = hg.H * hg.W;
+    // the tile lies inside one image (H * W % 128 == 0) and starts at column 0 (W <= 128)
+    const int b = (int)(n0 / HW), y0 = (int)(n0 - (long long)b * HW) >> hg.w_shift;
+
+    // halo cells of this thread: global byte offset (channel 0 of the group; sentinel for rows outside the image) and LDS slot
+    const buf_rsrc rs = ig_make_rsrc(src, (unsigned)((size_t)N * hg.Kc * sizeof(float)));
+    unsigned voff[HC_MAXCELLS];
+    int loff[HC_MAXCELLS];
+    const int ncell = (hg.cells + IG_THREADS - 1) / IG_THREADS;           // uniform: 2..6
+#pragma unroll
+    for (int i = 0; i < HC_MAXCELLS; ++i) {
+        const int e = tid + i * IG_THREADS;
+        voff[i] = IG_BUF_OOB;
+        loff[i] = -1;
+        if (i < ncell && e < hg.cells) {
+            const int c = e / hg.cpp, rem = e - c * hg.cpp;
+            const int row = rem / hg.cpr, q = rem - row * hg.cpr;
+            const int iy = y0 - 1 + row;
+            loff[i] = c * PL + row * RS + 4 + 4 * q;
+            if (iy >= 0 && iy < hg.H)
+                voff[i] = (unsigned)(((b * hg.Kc + c) * HW + iy * hg.W + 4 * q) * (int)sizeof(float));
+        }
+    }
+    // the halo columns left and right of the image are zero for every group: written once, never overwritten
+    for (int e = tid; e < 2 * 16 * (hg.TR + 2) * 2; e += IG_THREADS) {
+        const int side = e & 1, rowi = e >> 1;                           // rowi over (buffer, channel, row)
+        const int buf = rowi / (16 * (hg.TR + 2)), cr = rowi - buf * 16 * (hg.TR + 2);
+        const int c = cr / (hg.TR + 2), row = cr - c * (hg.TR + 2);
+        Hs[buf * 16 * PL + c * PL + row * RS + (side ? hg.W + 4 : 3)] = 0.0f;
+    }
+    // B fragment offsets of this lane inside a plane: pixel -> (row, column + 3); the tap adds r * RS + s
+    int boff[T::TN];
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const int px = wn_off + j * 32 + (lane & 31);
+        boff[j] = (px >> hg.w_shift) * RS + (px & (hg.W - 1)) + 3;
+    }
+
+    f32x16 acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 hreg[HC_MAXCELLS];
+    auto halo_load = [&](int g) {
+        const unsigned soff = (unsigned)(g * 16 * HW) * (unsigned)sizeof(float);
+#pragma unroll
+        for (int i = 0; i < HC_MAXCELLS; ++i)
+            if (i < ncell) hreg[i] = ig_buf_load4(rs, voff[i], soff);
+    };
+    auto halo_store = [&](int buf) {
+        float* hb = Hs + buf * 16 * PL;
+#pragma unroll
+        for (int i = 0; i < HC_MAXCELLS; ++i)
+            if (i < ncell && loff[i] >= 0) *reinterpret_cast<f32x4*>(hb + loff[i]) = hreg[i];
+    };
+    f32x4 ra[ig_a_per<BM>()];
+    const IgABuf<BM> abuf(A, Mp, Kp, m0, tid);
+    const int nchunk = Kp / IG_KC, G = hg.Kc >> 4;
+
+    halo_load(0);
+    abuf.load(0, ra);
+    halo_store(0);
+    ig_store_a<BM>(Asb, tid, ra);
+    if (1 < nchunk) abuf.load(IG_KC, ra);
+    __syncthreads();
+    int g = 0, tap = 0, tr = 0, ts = 0;                                  // chunk c = 9 g + tap, tap = 3 tr + ts
+    for (int c = 0; c < nchunk; ++c) {
+        const bool more = g + 1 < G;
+        if (tap == 0 && more) halo_load(g + 1);
+        hc_mma_chunk<BM>(Asb + (c & 1) * IG_KC * BM, Hs + (g & 1) * 16 * PL + tr * RS + ts, acc, wm_off, boff, PL, lane);
+        if (c + 1 < nchunk) {
+            ig_store_a<BM>(Asb + ((c + 1) & 1) * IG_KC * BM, tid, ra);
+            if (c + 2 < nchunk) abuf.load((c + 2) * IG_KC, ra);
+        }
+        // the other halo buffer was last read in group g - 1: every wave has passed a barrier since
+        if (tap == 5 && more) halo_store((g + 1) & 1);
+        __syncthreads();
+        if (++ts == 3) { ts = 0; if (++tr == 3) { tr = 0; } }
+        if (++tap == 9) { tap = 0; ++g; }
+    }
+    if (Ad::Out::vec4_ok(p)) {
+        ig_epilogue_vec4<BM, Ad>(p, smem + wid * IG_EPI_WAVE, acc, m0, n0, wm_off, wn_off, lane, M, N);
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const long long n = n0 + wn_off + j * 32 + (lane & 31);
+        if (n >= N) continue;
+        typename Ad::Out out(p, n);
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm_off + i * 32 + mfma_row(r, lane);
+                if (m < M) out.store(p, m, acc[i][j][r]);
+            }
+    }
+}
+
+}  // namespace cnuda

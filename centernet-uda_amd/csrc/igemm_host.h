@@ -10,6 +10,12 @@ namespace cnuda {
 enum PackMode {
     PACK_FWD = 0,    // dst[k = tap*C + c][m = o]        (forward / wgrad column order)
     PACK_DGRAD = 1,  // dst[k = tap*Cpad + o][m = c]     (transposed conv; Cpad = Co rounded up to 16)
+    // (2: tap subsets, launch_pack_taps)
+    // halo-tile kernels (hconv.cuh; 3x3, stride 1, padding 1): K ordered (16-channel group, tap, channel in group), so that
+    // the nine taps of a channel group -- which all read the same LDS halo tile -- are consecutive chunks
+    PACK_HALO_FWD = 3,    // dst[k = (g*9 + tap)*16 + ci][m = o] = W[o][16g + ci][tap]                     (C % 16 == 0)
+    PACK_HALO_DGRAD = 4,  // dst[k = (g*9 + tap)*16 + oi][m = c] = W[16g + oi][c][8 - tap]: the input gradient of a
+                          // 3x3 / stride 1 / padding 1 convolution is that convolution over grad_y with flipped taps (Co % 16 == 0)
 };
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }

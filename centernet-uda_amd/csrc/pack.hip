@@ -21,6 +21,10 @@ __global__ void pack_kernel(const float* __restrict__ W, float* __restrict__ dst
         int o = -1, c = -1, tap = -1;
         if (mode == PACK_FWD) {
             if (k < T * C && m < Co) { tap = k / C; c = k % C; o = m; }
+        } else if (mode == PACK_HALO_FWD) {
+            if (k < T * C && m < Co) { const int g = k / (16 * T), r = k - g * 16 * T; tap = r >> 4; c = 16 * g + (r & 15); o = m; }
+        } else if (mode == PACK_HALO_DGRAD) {
+            if (k < T * Co && m < C) { const int g = k / (16 * T), r = k - g * 16 * T; tap = T - 1 - (r >> 4); o = 16 * g + (r & 15); c = m; }
         } else {   // PACK_DGRAD: Cpad = Co rounded up to the K chunk, rows o >= Co stay zero
             if (k < T * Cpad && m < C) { tap = k / Cpad; o = k % Cpad; c = m; if (o >= Co) o = -1; }
         }
@@ -325,6 +329,16 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
         float v = 0.0f;
         if (j.mode == PACK_FWD) {
             if (k < j.T * j.C && m < j.Co) v = j.src[((size_t)m * j.C + k % j.C) * j.T + k / j.C];
+        } else if (j.mode == PACK_HALO_FWD) {
+            if (k < j.T * j.C && m < j.Co) {
+                const int g = k / (16 * j.T), r = k - g * 16 * j.T;
+                v = j.src[((size_t)m * j.C + 16 * g + (r & 15)) * j.T + (r >> 4)];
+            }
+        } else if (j.mode == PACK_HALO_DGRAD) {
+            if (k < j.T * j.Co && m < j.C) {
+                const int g = k / (16 * j.T), r = k - g * 16 * j.T;
+                v = j.src[((size_t)(16 * g + (r & 15)) * j.C + m) * j.T + (j.T - 1 - (r >> 4))];
+            }
         } else if (j.mode == PACK_DGRAD) {
             if (k < j.T * j.cpad && m < j.C) {
                 const int tap = k / j.cpad, o = k % j.cpad;

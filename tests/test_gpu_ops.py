@@ -2,6 +2,7 @@
 pooling, depthwise transposed conv, concat/add, Adam) against the CPU torch
 primitives the oracle (oracle/dla.py) is made of.  fp32 tolerance 1e-4 of the
 tensor's scale (north_star)."""
+import os
 import zlib
 
 import numpy as np
@@ -247,6 +248,40 @@ def test_head_pair_is_one_tape_node_with_the_two_layers_values(B, C, Ch, Co, H, 
     assert not type(wide(x.clone().requires_grad_(True)).grad_fn).__name__.startswith('_ConvActConv1x1')
     odd = torch.randn(1, C, 3, 5, device=DEV, requires_grad=True)
     assert not type(head(odd).grad_fn).__name__.startswith('_ConvActConv1x1')
+
+
+@pytest.mark.parametrize('B,C,Co,H,W', [(2, 16, 27, 8, 16), (1, 32, 64, 16, 16), (3, 64, 100, 4, 32), (2, 48, 27, 8, 32),
+                                        (2, 64, 64, 8, 64), (1, 128, 256, 6, 64), (2, 16, 16, 2, 128), (1, 64, 27, 3, 128),
+                                        (2, 256, 144, 16, 16)])
+def test_halo_tile_convolution_3x3(B, C, Co, H, W):
+    """3x3 / stride 1 / padding 1 with channels % 16 == 0 on maps 16 / 32 / 64 / 128 wide takes the halo-tile kernels
+    (csrc/hconv.cuh: the input tile of a 16-channel group staged once with its halo, K ordered (group, tap, channel)):
+    forward (bias + ReLU epilogue) and input gradient (the same kernel over grad_y, flipped taps, when Co % 16 == 0)
+    against torch's CPU convolution; 1, 2, 4 or 8 image rows per 128-pixel tile, tiles at the image's top and bottom
+    edge, several tiles per image, several channel groups, row counts that leave padded output rows."""
+    import hip_runtime as hr
+    from hip_runtime import ops
+    from test_zz_kernel_coverage import short
+    g = torch.Generator().manual_seed(B * 1000 + C + Co + W)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) / (3 * C ** 0.5)
+    bias = torch.randn(Co, generator=g)
+    gy = torch.randn(B, Co, H, W, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yr = F.relu(F.conv2d(xr, wr, br, 1, 1))
+    yr.backward(gy)
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, bias))
+    with hr.launch_log() as log:
+        yd = ops.conv2d(xd, wd, bd, 1, 1, act_slope=0.0)
+        yd.backward(gy.to(DEV))
+    names = [short(n) for n in log.names]
+    if os.environ.get('CNUDA_HCONV') != '0' and hr.get_matrix_mode() == 0:
+        assert any(n.startswith('hconv_kernel') and 'HconvFwd' in n for n in names), names
+        assert any('HconvDgrad' in n for n in names) == (Co % 16 == 0), names
+    _close(yd, yr.detach(), 1e-4)
+    _close(xd.grad, xr.grad, 1e-4)
+    _close(wd.grad, wr.grad, 1e-4)
+    _close(bd.grad, br.grad, 1e-4)
 
 
 def test_head_fused_node_leaves_hooks_and_gradient_free_calls_to_the_children():
