@@ -641,30 +641,35 @@ bool hconv_ok(const ConvGeom& g, int kc) {
            g.pw == 1 && kc % 16 == 0 && (g.W == 16 || g.W == 32 || g.W == 64 || g.W == 128) &&
            ((long long)g.H * g.W) % IG_BN == 0 && (size_t)g.B * kc * g.H * g.W * sizeof(float) < IG_BUF_OOB;
 }
-template <int BM, class Ad>
+template <int BM, int BN, class Ad>
 void hconv_launch_one(const typename Ad::Params& p, const float* src, const float* A, int Mp, int Kp, int M, long long N,
-                      int n_tiles, int m_tiles, const HaloGeom& hg, hipStream_t st) {
+                      int m_tiles, const HaloGeom& hg, hipStream_t st) {
     const size_t lds = hconv_lds_bytes(hg, BM);
     static size_t allowed = 64 * 1024;                  // dynamic LDS beyond 64 KiB is opt-in per kernel
     if (lds > allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hconv_kernel<BM, Ad>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hconv_kernel<BM, BN, Ad>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         allowed = 160 * 1024;
     }
-    CNUDA_LAUNCH((hconv_kernel<BM, Ad>), dim3(n_tiles * m_tiles), dim3(IG_THREADS), lds, st, p, src, A, Mp, Kp, M, N,
+    const int n_tiles = (int)(N / BN);
+    CNUDA_LAUNCH((hconv_kernel<BM, BN, Ad>), dim3(n_tiles * m_tiles), dim3(IG_THREADS), lds, st, p, src, A, Mp, Kp, M, N,
                  n_tiles, m_tiles, hg);
 }
 template <class Ad>
 int launch_hconv(int bm, const typename Ad::Params& p, const float* src, int kc, const ConvGeom& g, const float* A, int Mp,
                  int Kp, int M, long long N, hipStream_t st, const char* who) {
-    CNUDA_REQUIRE(N < (1ll << 31) - IG_BN, "%s: more than 2^31 pixels per call", who);
-    const int n_tiles = ceil_div(N, IG_BN), m_tiles = Mp / bm;
-    const HaloGeom hg = make_halo_geom(kc, g.H, g.W);
+    CNUDA_REQUIRE(N < (1ll << 31) - 256, "%s: more than 2^31 pixels per call", who);
+    const int m_tiles = Mp / bm;
+    // 256-pixel tiles for the narrow GEMMs when that still leaves two rounds of workgroups (and the halo fits: W >= 32)
+    const bool wide = bm <= 64 && g.W >= 32 && ((long long)g.H * g.W) % 256 == 0 && (N / 256) * m_tiles >= 1024;
+    const HaloGeom hg = make_halo_geom(kc, g.H, g.W, wide ? 256 : 128);
     ProfScope prof(st);
-    prof.name("hconv_kernel<%d, %s>", bm, Ad::name());
-    if (bm == 128) hconv_launch_one<128, Ad>(p, src, A, Mp, Kp, M, N, n_tiles, m_tiles, hg, st);
-    else if (bm == 64) hconv_launch_one<64, Ad>(p, src, A, Mp, Kp, M, N, n_tiles, m_tiles, hg, st);
-    else hconv_launch_one<32, Ad>(p, src, A, Mp, Kp, M, N, n_tiles, m_tiles, hg, st);
+    prof.name("hconv_kernel<%d, %d, %s>", bm, wide ? 256 : 128, Ad::name());
+    if (bm == 128) hconv_launch_one<128, 128, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
+    else if (bm == 64 && wide) hconv_launch_one<64, 256, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
+    else if (bm == 64) hconv_launch_one<64, 128, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
+    else if (wide) hconv_launch_one<32, 256, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
+    else hconv_launch_one<32, 128, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
     return check_launch(who);
 }
 

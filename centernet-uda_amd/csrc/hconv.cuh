@@ -11,27 +11,37 @@
 // Per channel group a thread issues 2..6 16-byte loads instead of 72 4-byte ones.  The A (weight) tile is staged per
 // chunk exactly as in igemm_fwd_kernel; the packed weights use the same K order (PACK_HALO_FWD / PACK_HALO_DGRAD).
 //
-// Tile = 128 consecutive pixels n of the flattened (b, y, x) axis, so the epilogues of igemm.cuh apply unchanged.
-// Host-side conditions (conv.hip hconv_ok): 3x3, stride 1, padding 1, gathered channels % 16 == 0, W in {16, 32, 64,
-// 128}, H * W % 128 == 0, tensor below 2 GiB, f32 matrix mode.
+// Pixel tile = BN (128 or 256) consecutive pixels n of the flattened (b, y, x) axis, i.e. BN / W full image rows, so the
+// 16-byte epilogue of igemm.cuh applies as it stands.  Host-side conditions (conv.hip hconv_ok): 3x3, stride 1,
+// padding 1, gathered channels % 16 == 0, W in {16, 32, 64, 128}, H * W % BN == 0, tensor below 2 GiB, f32 matrix mode.
 #pragma once
 #include "igemm.cuh"
 
 namespace cnuda {
 
+// Block tiles BM x BN (four waves; each wave TM x TN accumulator tiles of 32 x 32).  With the B staging nearly free the
+// pixel tile can be 256 wide for the narrow GEMMs: twice the MFMAs per barrier and per A-tile load, half the tiles
+// (prologue and store tail per tile) -- a 64 x 256 tile runs the 64 -> 64 layers like the 128 x 128 tile runs the wide ones.
+template <int BM, int BN> struct HcTile;
+template <> struct HcTile<128, 128> { static constexpr int WM = 2, WN = 2, TM = 2, TN = 2; };
+template <> struct HcTile<64, 128>  { static constexpr int WM = 2, WN = 2, TM = 1, TN = 2; };
+template <> struct HcTile<32, 128>  { static constexpr int WM = 1, WN = 4, TM = 1, TN = 1; };
+template <> struct HcTile<64, 256>  { static constexpr int WM = 2, WN = 2, TM = 1, TN = 4; };
+template <> struct HcTile<32, 256>  { static constexpr int WM = 1, WN = 4, TM = 1, TN = 2; };
+
 struct HaloGeom {
     int Kc, H, W, w_shift;     // gathered channels, plane size, log2(W)
-    int TR;                    // image rows per pixel tile (128 / W)
+    int TR;                    // image rows per pixel tile (BN / W)
     int RS, PL;                // LDS row stride and plane size of the halo tile, floats
     int cpr, cpp, cells;       // 16-byte cells per row (W / 4), per plane ((TR + 2) * cpr), per channel group (16 * cpp)
 };
-constexpr int HC_MAXCELLS = 6;      // per thread: W = 128 -> 16 * 3 * 32 / 256
+constexpr int HC_MAXCELLS = 8;      // per thread: W = 128, 256-pixel tile -> 16 * 4 * 32 / 256
 
-inline HaloGeom make_halo_geom(int Kc, int H, int W) {
+inline HaloGeom make_halo_geom(int Kc, int H, int W, int bn) {
     HaloGeom h;
     h.Kc = Kc; h.H = H; h.W = W;
     h.w_shift = W == 128 ? 7 : (W == 64 ? 6 : (W == 32 ? 5 : 4));
-    h.TR = 128 / W;
+    h.TR = bn / W;
     // column index of image column x is x + 4 (16-byte aligned interior), the halo columns are 3 and W + 4.  W = 16:
     // a 32-pixel MFMA column block spans two rows, a stride of 48 puts the second row 16 banks away from the first
     h.RS = W == 16 ? 48 : W + 8;
@@ -41,15 +51,21 @@ inline HaloGeom make_halo_geom(int Kc, int H, int W) {
     h.cells = 16 * h.cpp;
     return h;
 }
-inline size_t hconv_lds_bytes(const HaloGeom& h, int bm) { return (size_t)(2 * 16 * h.PL + 2 * IG_KC * bm) * sizeof(float); }
+// ONE halo buffer (occupancy: the MFMA loop wants three to four waves per SIMD; a second buffer for W = 128 costs two
+// of four resident workgroups) + two A stages; the epilogue's staging tiles must fit as well
+inline size_t hconv_lds_bytes(const HaloGeom& h, int bm) {
+    size_t fl = (size_t)16 * h.PL + 2 * IG_KC * bm;
+    if (fl < (size_t)4 * IG_EPI_WAVE) fl = 4 * IG_EPI_WAVE;
+    return fl * sizeof(float);
+}
 
 // One 16-deep chunk = one tap (r, s) of one channel group: A fragments from the staged weight tile, B fragments from
 // the halo tile.  Same two-deep register pipeline as ig_mma_chunk.
-template <int BM>
+template <int BM, int BN>
 __device__ __forceinline__ void hc_mma_chunk(const float* __restrict__ As, const float* __restrict__ Hb,
-                                             f32x16 (&acc)[IgTile<BM>::TM][IgTile<BM>::TN], int wm_off,
-                                             const int (&boff)[IgTile<BM>::TN], int PL, int lane) {
-    using T = IgTile<BM>;
+                                             f32x16 (&acc)[HcTile<BM, BN>::TM][HcTile<BM, BN>::TN], int wm_off,
+                                             const int (&boff)[HcTile<BM, BN>::TN], int PL, int lane) {
+    using T = HcTile<BM, BN>;
     const int kl = lane >> 5, il = lane & 31;
     const float* ap = As + kl * BM + wm_off + il;
     const float* bp[T::TN];
@@ -83,30 +99,58 @@ __device__ __forceinline__ void hc_mma_chunk(const float* __restrict__ As, const
     }
 }
 
+// ig_epilogue_vec4 for these tiles: every wave stages its 32 x 32 tiles through LDS and stores 16 bytes per lane
+template <int BM, int BN, class Ad>
+__device__ __forceinline__ void hc_epilogue_vec4(const typename Ad::Params& p, float* __restrict__ stage,
+                                                 const f32x16 (&acc)[HcTile<BM, BN>::TM][HcTile<BM, BN>::TN], int m0,
+                                                 long long n0, int wm_off, int wn_off, int lane, int M, long long N) {
+    using T = HcTile<BM, BN>;
+    const int col = lane & 31, cg = lane & 7, rsub = lane >> 3;
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const long long n = n0 + wn_off + j * 32 + 4 * cg;
+        typename Ad::Out out(p, n < N ? n : 0);
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stage[mfma_row(r, lane) * IG_EPI_LD + col] = acc[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + rsub;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * IG_EPI_LD + 4 * cg);
+                const int m = m0 + wm_off + i * 32 + row;
+                if (m < M && n < N) out.store4(p, m, v);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+}
+
 // Ad: { using Params; using Out; static const char* name(); }  -- the epilogue contract of igemm.cuh's loaders.
-template <int BM, class Ad>
+template <int BM, int BN, class Ad>
 __global__ __launch_bounds__(IG_THREADS, 2) void hconv_kernel(
     typename Ad::Params p, const float* __restrict__ src, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
     int n_tiles, int m_tiles, HaloGeom hg) {
-    using T = IgTile<BM>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // Hs[2][16 * PL] | As[2][16 * BM]; reused by the epilogue
+    using T = HcTile<BM, BN>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // Hs[16 * PL] | As[2][16 * BM]; reused by the epilogue
     const int PL = hg.PL, RS = hg.RS;
     float* const Hs = smem;
-    float* const Asb = smem + 2 * 16 * PL;
+    float* const Asb = smem + 16 * PL;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wg = xcd_remap(blockIdx.x, n_tiles * m_tiles);
     const int m0 = (wg % m_tiles) * BM;
-    const long long n0 = (long long)(wg / m_tiles) * IG_BN;
+    const long long n0 = (long long)(wg / m_tiles) * BN;
     const int wm_off = (wid / T::WN) * (T::TM * 32), wn_off = (wid % T::WN) * (T::TN * 32);
     const int HW = hg.H * hg.W;
-    // the tile lies inside one image (H * W % 128 == 0) and starts at column 0 (W <= 128)
+    // the tile lies inside one image (H * W % BN == 0) and starts at column 0 (W <= 128)
     const int b = (int)(n0 / HW), y0 = (int)(n0 - (long long)b * HW) >> hg.w_shift;
 
     // halo cells of this thread: global byte offset (channel 0 of the group; sentinel for rows outside the image) and LDS slot
     const buf_rsrc rs = ig_make_rsrc(src, (unsigned)((size_t)N * hg.Kc * sizeof(float)));
     unsigned voff[HC_MAXCELLS];
     int loff[HC_MAXCELLS];
-    const int ncell = (hg.cells + IG_THREADS - 1) / IG_THREADS;           // uniform: 2..6
+    const int ncell = (hg.cells + IG_THREADS - 1) / IG_THREADS;           // uniform: 3..8
 #pragma unroll
     for (int i = 0; i < HC_MAXCELLS; ++i) {
         const int e = tid + i * IG_THREADS;
@@ -122,11 +166,10 @@ __global__ __launch_bounds__(IG_THREADS, 2) void hconv_kernel(
         }
     }
     // the halo columns left and right of the image are zero for every group: written once, never overwritten
-    for (int e = tid; e < 2 * 16 * (hg.TR + 2) * 2; e += IG_THREADS) {
-        const int side = e & 1, rowi = e >> 1;                           // rowi over (buffer, channel, row)
-        const int buf = rowi / (16 * (hg.TR + 2)), cr = rowi - buf * 16 * (hg.TR + 2);
+    for (int e = tid; e < 16 * (hg.TR + 2) * 2; e += IG_THREADS) {
+        const int side = e & 1, cr = e >> 1;                             // cr over (channel, row)
         const int c = cr / (hg.TR + 2), row = cr - c * (hg.TR + 2);
-        Hs[buf * 16 * PL + c * PL + row * RS + (side ? hg.W + 4 : 3)] = 0.0f;
+        Hs[c * PL + row * RS + (side ? hg.W + 4 : 3)] = 0.0f;
     }
     // B fragment offsets of this lane inside a plane: pixel -> (row, column + 3); the tap adds r * RS + s
     int boff[T::TN];
@@ -151,11 +194,10 @@ __global__ __launch_bounds__(IG_THREADS, 2) void hconv_kernel(
         for (int i = 0; i < HC_MAXCELLS; ++i)
             if (i < ncell) hreg[i] = ig_buf_load4(rs, voff[i], soff);
     };
-    auto halo_store = [&](int buf) {
-        float* hb = Hs + buf * 16 * PL;
+    auto halo_store = [&]() {
 #pragma unroll
         for (int i = 0; i < HC_MAXCELLS; ++i)
-            if (i < ncell && loff[i] >= 0) *reinterpret_cast<f32x4*>(hb + loff[i]) = hreg[i];
+            if (i < ncell && loff[i] >= 0) *reinterpret_cast<f32x4*>(Hs + loff[i]) = hreg[i];
     };
     f32x4 ra[ig_a_per<BM>()];
     const IgABuf<BM> abuf(A, Mp, Kp, m0, tid);
@@ -163,7 +205,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void hconv_kernel(
 
     halo_load(0);
     abuf.load(0, ra);
-    halo_store(0);
+    halo_store();
     ig_store_a<BM>(Asb, tid, ra);
     if (1 < nchunk) abuf.load(IG_KC, ra);
     __syncthreads();
@@ -171,19 +213,21 @@ __global__ __launch_bounds__(IG_THREADS, 2) void hconv_kernel(
     for (int c = 0; c < nchunk; ++c) {
         const bool more = g + 1 < G;
         if (tap == 0 && more) halo_load(g + 1);
-        hc_mma_chunk<BM>(Asb + (c & 1) * IG_KC * BM, Hs + (g & 1) * 16 * PL + tr * RS + ts, acc, wm_off, boff, PL, lane);
+        hc_mma_chunk<BM, BN>(Asb + (c & 1) * IG_KC * BM, Hs + tr * RS + ts, acc, wm_off, boff, PL, lane);
         if (c + 1 < nchunk) {
             ig_store_a<BM>(Asb + ((c + 1) & 1) * IG_KC * BM, tid, ra);
             if (c + 2 < nchunk) abuf.load((c + 2) * IG_KC, ra);
         }
-        // the other halo buffer was last read in group g - 1: every wave has passed a barrier since
-        if (tap == 5 && more) halo_store((g + 1) & 1);
         __syncthreads();
+        if (tap == 8 && more) {          // every wave has read the group's last fragments: the next group's tile moves in
+            halo_store();                // (its loads went out nine chunks ago; the other resident workgroups fill the gap)
+            __syncthreads();
+        }
         if (++ts == 3) { ts = 0; if (++tr == 3) { tr = 0; } }
         if (++tap == 9) { tap = 0; ++g; }
     }
     if (Ad::Out::vec4_ok(p)) {
-        ig_epilogue_vec4<BM, Ad>(p, smem + wid * IG_EPI_WAVE, acc, m0, n0, wm_off, wn_off, lane, M, N);
+        hc_epilogue_vec4<BM, BN, Ad>(p, smem + wid * IG_EPI_WAVE, acc, m0, n0, wm_off, wn_off, lane, M, N);
         return;
     }
 #pragma unroll

@@ -147,6 +147,39 @@ def test_full_size_strided_convolution_matches_fp64():
         assert (got.double().cpu() - want).abs().max().item() <= 1e-4 * scale, name
 
 
+@pytest.mark.parametrize('B,C,Co,S', [(16, 64, 64, 128), (16, 64, 27, 128), (64, 128, 27, 64), (32, 64, 256, 128)],
+                         ids=['64to64_128sq', '64to27_128sq', '128to27_64sq', '64to256_128sq'])
+def test_full_size_halo_tile_convolutions_match_fp64(B, C, Co, S):
+    """3x3 / stride 1 layers of the benched step on the halo-tile kernels (csrc/hconv.cuh) at sizes where the launch
+    plan picks the 256-pixel tiles (64 x 256 and 32 x 256: two or four image rows per tile, >= 1024 tiles) and the
+    128 x 128 tile: forward and input gradient against the CPU's fp64 convolution."""
+    import os
+    import torch.nn.functional as F
+    import hip_runtime as hr
+    from hip_runtime import ops
+    from test_zz_kernel_coverage import short
+    g = torch.Generator().manual_seed(79 + Co)
+    x = torch.randn(B, C, S, S, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) * 0.05
+    gy = torch.randn(B, Co, S, S, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    want_y = F.conv2d(xr, wr, None, 1, 1)
+    want_y.backward(gy.double())
+    xx, ww = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    with hr.launch_log() as log:
+        y = ops.conv2d(xx, ww, None, 1, 1)
+        y.backward(gy.to(DEV))
+    names = sorted(short(n) for n in log.names)
+    if os.environ.get('CNUDA_HCONV') != '0' and hr.get_matrix_mode() == 0:
+        want_fwd = 'hconv_kernel<%s, HconvFwd>' % {64: '64, 256', 27: '32, 256', 256: '128, 128'}[Co]
+        assert want_fwd in names, (want_fwd, names)
+        if Co % 16 == 0:
+            assert 'hconv_kernel<64, 256, HconvDgrad>' in names, names
+    for name, got, want in (('y', y.detach(), want_y.detach()), ('gx', xx.grad, xr.grad), ('gw', ww.grad, wr.grad)):
+        scale = want.abs().max().item()
+        assert (got.double().cpu() - want).abs().max().item() <= 1e-4 * scale, name
+
+
 def test_full_size_3x3_convolution_matches_fp64():
     """3x3, 64 -> 256 at 64 x 64, B = 8: the 128-row forward tile (2 row tiles x 256 pixel tiles), the 64-row input
     gradient and the 128 x 64 weight-gradient tile, against the CPU's fp64 convolution."""
