@@ -255,6 +255,11 @@ def dp1_rccl_leg(device, args):
     step of the same process, so the wrapper's fixed overhead is a number (SCALE runs then start from it)."""
     import socket
     created = False
+    # RCCL prints a version banner on STDOUT when its first communicator comes up; the bench line must stay the only
+    # thing on stdout, so file descriptor 1 points at stderr for the duration of this leg
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
     if not dist.is_initialized():
         s = socket.socket()
         s.bind(('127.0.0.1', 0))
@@ -289,6 +294,9 @@ def dp1_rccl_leg(device, args):
     finally:
         if created:
             dist.destroy_process_group()
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
 
 
 def other_configs(device, skip):

@@ -619,7 +619,7 @@ ConvPlan make_plan(const ConvGeom& g) {
 
 // ---------------------------------------------------------------------------
 // Halo-tile kernels (hconv.cuh) for 3x3 / stride 1 / padding 1: the forward and -- over grad_y, with flipped taps --
-// the input gradient.  CNUDA_HCONV=0 keeps the im2col-style kernels (A/B measurements).
+// the input gradient.
 // ---------------------------------------------------------------------------
 struct HconvFwd {
     using Params = ConvFwdParams;
@@ -631,15 +631,23 @@ struct HconvDgrad {
     using Out = ConvDgradLoader::Out;
     static const char* name() { return "dgrad"; }
 };
-bool hconv_enabled() {
-    static const bool on = !(getenv("CNUDA_HCONV") && getenv("CNUDA_HCONV")[0] == '0');
-    return on;
-}
-// kc: channels of the gathered tensor (x for the forward, grad_y for the input gradient)
-bool hconv_ok(const ConvGeom& g, int kc) {
-    return hconv_enabled() && matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 &&
-           g.pw == 1 && kc % 16 == 0 && (g.W == 16 || g.W == 32 || g.W == 64 || g.W == 128) &&
-           ((long long)g.H * g.W) % IG_BN == 0 && (size_t)g.B * kc * g.H * g.W * sizeof(float) < IG_BUF_OOB;
+// Which layers take them (CNUDA_HCONV: 0 none, 1 every eligible layer, 2 = default: the 32-row GEMMs).  Measured in
+// round 4, A/B on one box, whole benched step: 32-row GEMMs only 84.0-84.3 ms, none 84.5-84.7, every eligible layer
+// 85.0-85.3 -- the 64- and 128-row tiles are matrix-pipe-bound either way (PMC: 0.72-0.81 of the cycles the chip
+// clocks under them, profiles/r4_pmc_conv.md) and the wave-specialised im2col kernels keep the edge there; the 27-row
+// DCN offset convolutions were bound by the texture-address unit and gain 9-14 % per launch.
+int g_hconv_level = getenv("CNUDA_HCONV") ? atoi(getenv("CNUDA_HCONV")) : 2;
+int g_hconv_min_tiles = 128;         // cnuda_conv_set_halo_policy (tests)
+int hconv_level() { return g_hconv_level; }
+// kc: channels of the gathered tensor (x for the forward, grad_y for the input gradient); bm: the GEMM's row tile.
+// Small problems (under 128 pixel tiles) keep the im2col kernels: nothing to gain, and their results stay bit for bit
+// what the golden step fixtures were calibrated on.
+bool hconv_ok(const ConvGeom& g, int kc, int bm) {
+    const int lv = hconv_level();
+    return lv != 0 && (lv == 1 || bm == 32) && matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 &&
+           g.ph == 1 && g.pw == 1 && kc % 16 == 0 && (g.W == 16 || g.W == 32 || g.W == 64 || g.W == 128) &&
+           ((long long)g.H * g.W) % IG_BN == 0 && (long long)g.B * g.H * g.W >= (long long)g_hconv_min_tiles * IG_BN &&
+           (size_t)g.B * kc * g.H * g.W * sizeof(float) < IG_BUF_OOB;
 }
 template <int BM, int BN, class Ad>
 void hconv_launch_one(const typename Ad::Params& p, const float* src, const float* A, int Mp, int Kp, int M, long long N,
@@ -732,6 +740,12 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
 using namespace cnuda;
 
 
+extern "C" int cnuda_conv_set_halo_policy(int level, int min_tiles) {
+    if (level >= 0) g_hconv_level = level;
+    if (min_tiles >= 1) g_hconv_min_tiles = min_tiles;
+    return g_hconv_level | (g_hconv_min_tiles << 8);
+}
+
 extern "C" size_t cnuda_conv2d_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw,
                                                int ph, int pw) {
     ConvGeom g;
@@ -769,7 +783,7 @@ extern "C" int cnuda_conv2d_forward_res(const float* x, const float* weight, con
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
     ConvFwdParams p{g, x, bias, y, act_slope, residual};
-    if (hconv_ok(g, C)) {      // (K = 9 C is already a multiple of the chunk: the same packed size, another K order)
+    if (hconv_ok(g, C, q.bmf)) {      // (K = 9 C is already a multiple of the chunk: the same packed size, another K order)
         const float* Ah = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),
                                       ig_a_bytes(q.Kpf, q.Mpf), Cout, C, q.T, PACK_HALO_FWD, q.Kpf, q.Mpf, 0, st);
         return launch_hconv<HconvFwd>(q.bmf, p, x, C, g, Ah, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
@@ -830,7 +844,7 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
             }
         return 0;
     }
-    if (hconv_ok(g, Cout)) {   // (Co % 16 == 0: Kpd = 9 Co, no padded rows)
+    if (hconv_ok(g, Cout, q.bmd)) {   // (Co % 16 == 0: Kpd = 9 Co, no padded rows)
         const float* Ah = launch_pack(weight, Aws, ig_a_bytes(q.Kpd, q.Mpd), Cout, C, q.T, PACK_HALO_DGRAD, q.Kpd, q.Mpd, 0, st);
         ConvDgradParams ph{g, grad_y, grad_x, Cout};
         return launch_hconv<HconvDgrad>(q.bmd, ph, grad_y, Cout, g, Ah, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");

@@ -127,6 +127,7 @@ class _Sig:
     cnuda_launch_log_enable = (_I, [_I])
     cnuda_launch_log_collect = (_I, [ctypes.c_char_p, c_size_t])
     cnuda_dcn_set_fused_min_tiles = (_I, [_I])
+    cnuda_conv_set_halo_policy = (_I, [_I, _I])
 
 
 # ---------------------------------------------------------------------------
@@ -445,3 +446,20 @@ class dcn_fused_min_tiles:
 
     def __exit__(self, *exc):
         lib().cnuda_dcn_set_fused_min_tiles(self.prev)
+
+
+class halo_conv:
+    """with halo_conv(level, min_tiles): which 3x3 / stride-1 convolutions inside the block take the halo-tile kernels
+    (cnuda_conv_set_halo_policy: level 0 none, 1 every eligible layer, 2 the 32-row GEMMs; calls with at least
+    `min_tiles` pixel tiles).  Tests use halo_conv(1, 1)."""
+
+    def __init__(self, level, min_tiles):
+        self.level, self.min_tiles = int(level), int(min_tiles)
+
+    def __enter__(self):
+        prev = lib().cnuda_conv_set_halo_policy(-1, 0)
+        self.prev = (prev & 0xff, prev >> 8)
+        lib().cnuda_conv_set_halo_policy(self.level, self.min_tiles)
+
+    def __exit__(self, *exc):
+        lib().cnuda_conv_set_halo_policy(*self.prev)

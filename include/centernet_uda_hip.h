@@ -97,10 +97,15 @@ int cnuda_prof_name_len(void);
  * (image, 256-pixel tile) pairs -- 512 by default: the 128 x 128 / 64 x 64 maps of the benched step -- and as two
  * kernels below it.  Tests set 1 to run small geometries (borders, odd widths, out-of-bounds samples) through the
  * one-launch form, and INT_MAX to force the two-kernel form; values < 1 restore the default.  Returns the previous
- * threshold.  Process-wide; results do not depend on it beyond the summation order inside grad_input. */
+ * threshold.  Process-wide; results do not depend on it beyond the summation order inside grad_input.
+ * cnuda_conv_set_halo_policy: which 3x3 / stride-1 / padding-1 convolutions take the halo-tile kernels (csrc/hconv.cuh):
+ * level 0 none, 1 every eligible layer, 2 the 32-row GEMMs (default; initial value from CNUDA_HCONV), and only calls
+ * with at least min_tiles 128-pixel tiles (default 128).  Negative level / min_tiles < 1 leave that setting unchanged.
+ * Returns level | min_tiles << 8 after the change.  Tests use (1, 1) to run small shapes through every tile variant. */
 int cnuda_launch_log_enable(int on);
 int cnuda_launch_log_collect(char* names, size_t cap);
 int cnuda_dcn_set_fused_min_tiles(int min_tiles);
+int cnuda_conv_set_halo_policy(int level, int min_tiles);
 
 /* ------------------------------------------------------------------------
  * Detection decode -- replaces backends/decode.py:35-76 (decode_detection),

@@ -1,7 +1,7 @@
 """The kernel-selection switches that remain (`CNUDA_BUF=0`: pointer-addressed loaders -- also what tensors of 2 GiB
 and more take; `CNUDA_WS=0`: the 4-wave kernels on the 64- / 128-row tiles -- also what matrix mode 1 takes;
 `CNUDA_SHORTK=0`: the pipelined kernel for the K = 64 column-gradient GEMM; `CNUDA_HCONV=0`: the im2col-style kernels
-for the 3x3 / stride-1 layers that otherwise take the halo-tile kernels) are read once per process, so each
+for the 27-row DCN offset convolutions that otherwise take the halo-tile kernels) are read once per process, so each
 alternate runs the operator-level parity tests in a child process: per-operator values against the oracle at small
 sizes, the full-size convolution and DCN value checks.  (The switches whose alternate lost in round 2 are gone.)"""
 import os
@@ -15,9 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SUBSET = ['tests/test_gpu_ops.py::test_conv2d_fwd_bwd', 'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
           'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
           'tests/test_gpu_fullsize.py::test_full_size_3x3_convolution_matches_fp64',
-          'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
-          'tests/test_gpu_ops.py::test_halo_tile_convolution_3x3',
-          'tests/test_gpu_fullsize.py::test_full_size_halo_tile_convolutions_match_fp64']
+          'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle']
 
 
 @pytest.mark.parametrize('switch', ['CNUDA_BUF', 'CNUDA_WS', 'CNUDA_SHORTK', 'CNUDA_HCONV'])
