@@ -315,6 +315,231 @@ using DcnFwdLoader = DcnFwdLoaderT<false>;
 using DcnFwdBufLoader = DcnFwdLoaderT<true>;
 
 // ---------------------------------------------------------------------------
+// forward from an LDS input window (round 4): 3x3, stride 1, padding 1, dilation 1, deformable_group 1, C % 16 == 0,
+// row width 16 / 32 / 64 / 128, one M tile (Co <= 128).
+//
+// The loader above gathers two unaligned 8-byte corner pairs per (pixel, tap, channel) from global memory: the
+// texture-address unit is busy 0.77 of the kernel's cycles and the matrix pipe 0.38 (profiles/r3_pmc_dcn.md).  Here --
+// as in hconv.cuh -- the K axis is ordered (16-channel group, tap, channel) and a workgroup stages the INPUT window of
+// a channel group once per nine chunks: the 128 pixels' rows plus (1 + DW_MARGIN) rows above and below and the whole
+// row width plus 4 zero columns left and right, zero wherever the image ends, with 16-byte loads.  Every wave owns 32
+// pixels and ALL output rows: lane l of k-step s samples channel 2s + (l >> 5) of its pixel -- two ds_read2_b32 of the
+// corner pairs at the pixel's window address, one multiply and three fused multiply-adds with the tap's four corner
+// weights (mask folded in), which live in registers for all nine taps of the tile -- and the sample IS the MFMA's B
+// fragment: it never goes through LDS.  Out-of-image corners read the window's zeros, which reproduces the reference's
+// validity rule (dcn_v2_im2col_cuda.cu:37-48,180) without a predicate.  A sample whose corners leave the window
+// (|offset| >= 1 + DW_MARGIN rows, or >= 3 columns) is a STRAY: its lane takes the four corners from global memory
+// (exec-masked, the slow path; correct for any offset).  The column side output for the weight gradient is one
+// 4-byte store per sample, rows in (tap, channel) order as before.
+// ---------------------------------------------------------------------------
+constexpr int DW_MARGIN = 2;         // window rows beyond the undeformed 3x3 footprint, above and below
+constexpr int DW_MAXCELLS = 16;      // 16-byte window cells per thread and channel group (W = 128: one per channel)
+struct DcnWinGeom {
+    int w_shift, TR, NR, RS, PL, cpr, pos, nrep;
+};
+DcnWinGeom make_win_geom(int W) {
+    DcnWinGeom q;
+    q.w_shift = W == 128 ? 7 : (W == 64 ? 6 : (W == 32 ? 5 : 4));
+    q.TR = IG_BN / W;
+    q.NR = q.TR + 2 + 2 * DW_MARGIN;
+    q.RS = W + 8;                    // image column x sits at index x + 4; indices 0..3 and W+4..W+7 stay zero
+    q.PL = q.NR * q.RS;
+    q.cpr = W / 4;
+    q.pos = q.NR * q.cpr;            // 16-byte cells of one channel plane (<= 224): a thread keeps ONE of them ...
+    q.nrep = IG_THREADS / q.pos;     // ... for the channels rep, rep + nrep, ... of a group (rep = tid / pos)
+    return q;
+}
+size_t dcnw_lds_bytes(const DcnWinGeom& q, int bm) {
+    size_t fl = (size_t)16 * q.PL + 2 * IG_KC * bm;
+    if (fl < (size_t)4 * IG_EPI_WAVE) fl = 4 * IG_EPI_WAVE;
+    return fl * sizeof(float);
+}
+
+template <int BM>
+__global__ __launch_bounds__(IG_THREADS, 2) void dcnw_fwd_kernel(DcnFwdParams p, const float* __restrict__ A, int Mp, int Kp,
+                                                                 long long N, int n_tiles, DcnWinGeom wq) {
+    constexpr int TM = BM / 32;                                        // every wave: all BM rows x 32 pixels
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // Hs[16 * PL] | As[2][16 * BM]; reused by the epilogue
+    const DcnGeom& g = p.g;
+    const int PL = wq.PL, RS = wq.RS, W = g.W, H = g.H, HW = g.H * g.W;
+    float* const Hs = smem;
+    float* const Asb = smem + 16 * PL;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const long long n0 = (long long)xcd_remap(blockIdx.x, n_tiles) * IG_BN;
+    const int b = (int)(n0 / HW), pp0 = (int)(n0 - (long long)b * HW), y0 = pp0 >> wq.w_shift;
+    const int yw0 = y0 - 1 - DW_MARGIN;                                // image row of window row 0
+    const int pxl = wid * 32 + (lane & 31), kl = lane >> 5;
+    const int py = y0 + (pxl >> wq.w_shift), px = pxl & (W - 1), pp = pp0 + pxl;
+
+    // window staging: this thread's cell position inside a channel plane and its first channel
+    const buf_rsrc rs = ig_make_rsrc(p.in, (unsigned)((size_t)g.B * g.C * HW * sizeof(float)));
+    const int rep = tid / wq.pos, pos = tid - rep * wq.pos;
+    const bool stager = rep < wq.nrep;
+    const int srow = pos / wq.cpr, sq4 = pos - srow * wq.cpr;
+    const int siy = yw0 + srow;
+    const unsigned voff0 = (stager && siy >= 0 && siy < H)
+                               ? (unsigned)(((b * g.C + rep) * HW + siy * W + 4 * sq4) * (int)sizeof(float)) : IG_BUF_OOB;
+    float* const hdst = Hs + rep * PL + srow * RS + 4 + 4 * sq4;
+    const int ncell = stager ? (16 - rep + wq.nrep - 1) / wq.nrep : 0;   // channels rep, rep + nrep, ... < 16
+    const int ncell_max = (16 + wq.nrep - 1) / wq.nrep;                  // (uniform bound of the unrolled loops)
+    for (int e = tid; e < 16 * wq.NR * 8; e += IG_THREADS) {             // the zero columns left and right of the image
+        const int k8 = e & 7, cr = e >> 3;
+        const int c = cr / wq.NR, row = cr - c * wq.NR;
+        Hs[c * PL + row * RS + (k8 < 4 ? k8 : W + k8)] = 0.0f;
+    }
+
+    // per-tap sampling state of this lane's pixel: window address of the top-left corner, the two fractions and the
+    // mask (zero for a stray or an invalid sample); `stray`: bit t set -> tap t takes its corners from global memory
+    int addr[9];
+    float flh[9], flw[9], fmk[9];
+    unsigned stray = 0;
+    {
+        const float* off_b = p.off + (size_t)b * 18 * HW + pp;
+        const float* mask_b = p.mask + (size_t)b * 9 * HW + pp;
+        float dy[9], dx[9], mk[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            dy[t] = off_b[(size_t)(2 * t) * HW];
+            dx[t] = off_b[(size_t)(2 * t + 1) * HW];
+            mk[t] = mask_b[(size_t)t * HW];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float h = (float)(py - 1 + t / 3) + dy[t], w = (float)(px - 1 + t % 3) + dx[t];
+            const float hf = floorf(h), wf = floorf(w);
+            const bool valid = h > -1.0f && w > -1.0f && h < (float)H && w < (float)W;    // (false for NaN)
+            const int h0 = valid ? (int)hf : 0, w0i = valid ? (int)wf : 0;
+            const int wr = h0 - yw0;
+            const bool inwin = valid && wr >= 0 && wr + 1 <= wq.NR - 1 && w0i >= -4 && w0i <= W + 2;
+            addr[t] = inwin ? wr * RS + w0i + 4 : 0;
+            flh[t] = h - hf;
+            flw[t] = w - wf;
+            fmk[t] = inwin ? mk[t] : 0.0f;
+            if (valid && !inwin) stray |= 1u << t;
+        }
+    }
+    const bool any_stray = __any(stray != 0);
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    f32x4 hreg[DW_MAXCELLS];
+    auto win_load = [&](int grp) {
+        const int step = wq.nrep * HW * (int)sizeof(float);
+        unsigned soff = (unsigned)(grp * 16 * HW) * (unsigned)sizeof(float);
+#pragma unroll
+        for (int i = 0; i < DW_MAXCELLS; ++i)
+            if (i < ncell_max) { hreg[i] = ig_buf_load4(rs, i < ncell ? voff0 : IG_BUF_OOB, soff); soff += (unsigned)step; }
+    };
+    auto win_store = [&]() {
+        const int step = wq.nrep * PL;
+#pragma unroll
+        for (int i = 0; i < DW_MAXCELLS; ++i)
+            if (i < ncell_max && i < ncell) *reinterpret_cast<f32x4*>(hdst + i * step) = hreg[i];
+    };
+    f32x4 ra[ig_a_per<BM>()];
+    const IgABuf<BM> abuf(A, Mp, Kp, 0, tid);
+    const int nchunk = Kp / IG_KC, G = g.C >> 4;
+    // column side output: rows (tap, channel), this lane's part of the address is fixed (k parity row + pixel)
+    const bool col_on = p.col != nullptr;
+    float* const col_l = col_on ? p.col + (size_t)b * 9 * g.C * HW + (size_t)kl * HW + pp : nullptr;
+
+    win_load(0);
+    abuf.load(0, ra);
+    win_store();
+    ig_store_a<BM>(Asb, tid, ra);
+    if (1 < nchunk) abuf.load(IG_KC, ra);
+    __syncthreads();
+    int grp = 0;
+    for (int c0 = 0; c0 < nchunk; c0 += 9, ++grp) {
+        const bool more = grp + 1 < G;
+        if (more) win_load(grp + 1);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {                                  // (unrolled: the tap's registers are addressed statically)
+            const int c = c0 + t;
+            const float* As = Asb + (c & 1) * IG_KC * BM;
+            const float* ap = As + kl * BM + (lane & 31);
+            // (opaque copies: without them the compiler hoists the 72 per-(tap, k-step) window addresses and the 72
+            // column row bases out of the group loop as loop invariants and spills ~300 registers)
+            int a_t = addr[t];
+            asm volatile("" : "+v"(a_t));
+            const float* hb = Hs + kl * PL + a_t;
+            const bool tstray = any_stray && __any((stray >> t) & 1u);
+            const float lh = flh[t], lw = flw[t], hh = 1.0f - lh, hw = 1.0f - lw, mk = fmk[t];
+            const float w00 = hh * hw * mk, w01 = hh * lw * mk, w10 = lh * hw * mk, w11 = lh * lw * mk;
+            float v[IG_KC / 2];
+            // the eight samples of this chunk (channels kl, kl + 2, ..): corner pairs from the window
+#pragma unroll
+            for (int s = 0; s < IG_KC / 2; ++s) {
+                const float* q = hb + 2 * s * PL;
+                float x = w00 * q[0];
+                x = fmaf(w01, q[1], x);
+                x = fmaf(w10, q[RS], x);
+                v[s] = fmaf(w11, q[RS + 1], x);
+            }
+            if (tstray) {                                              // rare: corners beyond the window, from global memory
+                if ((stray >> t) & 1u) {
+                    const Tap tp = make_tap(g, p.off + (size_t)b * 18 * HW, p.mask + (size_t)b * 9 * HW, 0, t, py, px);
+                    const float* in_c = p.in + ((size_t)b * g.C + grp * 16 + kl) * HW;
+#pragma unroll
+                    for (int s = 0; s < IG_KC / 2; ++s) {
+                        float v00, v01, v10, v11;
+                        tap_corners(tp, in_c + (size_t)(2 * s) * HW, v00, v01, v10, v11);
+                        v[s] = tap_sample(tp, v00, v01, v10, v11) * tp.mask;
+                    }
+                }
+            }
+            if (col_on) {
+                unsigned long long rowoff = (unsigned long long)(unsigned)((t * g.C + grp * 16) * HW) * sizeof(float);
+                asm volatile("" : "+s"(rowoff));
+                float* cp = reinterpret_cast<float*>(reinterpret_cast<char*>(col_l) + rowoff);
+#pragma unroll
+                for (int s = 0; s < IG_KC / 2; ++s) cp[(size_t)(2 * s) * HW] = v[s];
+            }
+#pragma unroll
+            for (int s = 0; s < IG_KC / 2; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * BM + i * 32], v[s], acc[i], 0, 0, 0);
+            }
+            if (c + 1 < nchunk) {
+                ig_store_a<BM>(Asb + ((c + 1) & 1) * IG_KC * BM, tid, ra);
+                if (c + 2 < nchunk) abuf.load((c + 2) * IG_KC, ra);
+            }
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);                         // (nothing moves across taps: register pressure)
+        }
+        if (more) {          // every wave has read the group's last corners: the next group's window moves in
+            win_store();
+            __syncthreads();
+        }
+    }
+    // epilogue: bias (+ activation), 16 bytes per lane through LDS (every wave: TM tiles of 32 rows x its 32 pixels)
+    using Out = DcnFwdLoaderT<true>::Out;
+    float* stage = smem + wid * IG_EPI_WAVE;
+    const int col = lane & 31, cg = lane & 7, rsub = lane >> 3;
+    const long long n = n0 + wid * 32 + 4 * cg;
+    Out out(p, n < N ? n : 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[mfma_row(r, lane) * IG_EPI_LD + col] = acc[i][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + rsub;
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(stage + row * IG_EPI_LD + 4 * cg);
+            const int m = i * 32 + row;
+            if (m < g.Co && n < N) out.store4(p, m, v4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// ---------------------------------------------------------------------------
 // forward, two-kernel form for layers whose output channels span several M tiles (small feature maps run
 // 32- or 64-row tiles to fill the chip): the fused loader would re-sample the columns once per M tile, so the
 // columns are sampled ONCE by a streaming kernel (they are the weight gradient's side output anyway) and a
@@ -1202,6 +1427,10 @@ DcnPlan make_plan(const DcnGeom& g) {
     q.fwd_two_kernels = q.Mp / q.bm > 1;
     q.fwd_bytes = carve_bytes((size_t)q.Kp * q.Mp, 4) + 256 +
                   (q.fwd_two_kernels ? carve_bytes((size_t)g.B * q.K * g.Ho * g.Wo, 4) : 0);
+    if (g.Co <= 128) {      // the window kernel (dcnw_fwd_kernel) packs [K][64 or 128]
+        const size_t wb = carve_bytes((size_t)q.Kp * (g.Co <= 64 ? 64 : 128), 4) + 256;
+        if (wb > q.fwd_bytes) q.fwd_bytes = wb;
+    }
     q.gemm_bytes = cnuda_conv2d_workspace_bytes(g.B, g.Co, g.Ho, g.Wo, q.T * g.C, 1, 1, 1, 1, 0, 0);
     q.bwd_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) +
                   carve_bytes((size_t)g.Co * g.B, 4) + carve_bytes((size_t)q.T * g.C * g.Co, 4) +
@@ -1287,6 +1516,39 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
     CNUDA_REQUIRE(q.N < (1ll << 31) - IG_BN, "cnuda_dcn_v2_forward: more than 2^31 pixels per call");
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_dcn_v2_forward: workspace too small");
     Carver cv(workspace, workspace_bytes);
+    // the LDS-window kernel: 3x3 / stride 1 / padding 1 / dilation 1 on maps 16..128 wide, one M tile.  CNUDA_DCNW=0
+    // keeps the gathering loader (A/B measurements; tests/test_gpu_kernel_switches.py).
+    static const bool dcnw_on = !(getenv("CNUDA_DCNW") && getenv("CNUDA_DCNW")[0] == '0');
+    if (dcnw_on && matrix_mode() == 0 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 &&
+        dw == 1 && C % 16 == 0 && Cout <= 128 && (W == 16 || W == 32 || W == 64 || W == 128) &&
+        ((long long)H * W) % IG_BN == 0 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB) {
+        const int bm = Cout <= 64 ? 64 : 128;
+        const float* Aw = launch_pack(weight, cv.take<float>((size_t)q.Kp * bm), (size_t)q.Kp * bm * sizeof(float), Cout, C,
+                                      q.T, PACK_HALO_FWD, q.Kp, bm, 0, st);
+        const DcnWinGeom wq = make_win_geom(W);
+        const size_t lds = dcnw_lds_bytes(wq, bm);
+        DcnFwdParams p{g, input, offset, mask, bias, act_slope, output, columns};
+        const int n_tiles = (int)(q.N / IG_BN);
+        ProfScope prof(st);
+        prof.name("dcnw_fwd_kernel<%d>%s", bm, columns ? " (+ column side output)" : "");
+        static size_t allowed64 = 64 * 1024, allowed128 = 64 * 1024;
+        if (bm == 64) {
+            if (lds > allowed64) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnw_fwd_kernel<64>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                allowed64 = 160 * 1024;
+            }
+            CNUDA_LAUNCH(dcnw_fwd_kernel<64>, dim3(n_tiles), dim3(IG_THREADS), lds, st, p, Aw, bm, q.Kp, q.N, n_tiles, wq);
+        } else {
+            if (lds > allowed128) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnw_fwd_kernel<128>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                allowed128 = 160 * 1024;
+            }
+            CNUDA_LAUNCH(dcnw_fwd_kernel<128>, dim3(n_tiles), dim3(IG_THREADS), lds, st, p, Aw, bm, q.Kp, q.N, n_tiles, wq);
+        }
+        return check_launch("cnuda_dcn_v2_forward(window)");
+    }
     const float* A = launch_pack(weight, cv.take<float>((size_t)q.Kp * q.Mp), (size_t)q.Kp * q.Mp * sizeof(float), Cout,
                                  C, q.T, PACK_FWD, q.Kp, q.Mp, 0, st);
     const int n_tiles = ceil_div(q.N, IG_BN), m_tiles = q.Mp / q.bm;
