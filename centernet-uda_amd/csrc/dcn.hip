@@ -333,60 +333,51 @@ using DcnFwdBufLoader = DcnFwdLoaderT<true>;
 // 4-byte store per sample, rows in (tap, channel) order as before.
 // ---------------------------------------------------------------------------
 constexpr int DW_MARGIN = 2;         // window rows beyond the undeformed 3x3 footprint, above and below
-constexpr int DW_MAXCELLS = 16;      // 16-byte window cells per thread and channel group (W = 128: one per channel)
-struct DcnWinGeom {
-    int w_shift, TR, NR, RS, PL, cpr, pos, nrep;
+// Pixel tile = TR rows x TC columns = 128 pixels, TC = min(W, 64): two rows of 64 (W = 64, 128), four of 32, eight of
+// 16.  Window of a 16-channel group: NR = TR + 2 + 2 * DW_MARGIN rows x (TC + 8) columns -- tile column x sits at index
+// x - x0 + 4, four real or zero columns on either side -- staged as 16-byte cells: TC / 4 + 2 per row, (W = 128: the
+// side cells hold the neighbouring tile's pixels), zero by the buffer range check wherever the image ends.
+template <int TC> struct DwTile {
+    static constexpr int TR = IG_BN / TC, NR = TR + 2 + 2 * DW_MARGIN, RS = TC + 8, PL = NR * RS;
+    static constexpr int CPR = TC / 4 + 2, CPP = NR * CPR, CELLS = 16 * CPP;
+    static constexpr int NCELL = (CELLS + IG_THREADS - 1) / IG_THREADS;       // per thread: 9 (TC 64), 7 (32), 6 (16)
+    static constexpr int SHIFT = TC == 64 ? 6 : (TC == 32 ? 5 : 4);
 };
-DcnWinGeom make_win_geom(int W) {
-    DcnWinGeom q;
-    q.w_shift = W == 128 ? 7 : (W == 64 ? 6 : (W == 32 ? 5 : 4));
-    q.TR = IG_BN / W;
-    q.NR = q.TR + 2 + 2 * DW_MARGIN;
-    q.RS = W + 8;                    // image column x sits at index x + 4; indices 0..3 and W+4..W+7 stay zero
-    q.PL = q.NR * q.RS;
-    q.cpr = W / 4;
-    q.pos = q.NR * q.cpr;            // 16-byte cells of one channel plane (<= 224): a thread keeps ONE of them ...
-    q.nrep = IG_THREADS / q.pos;     // ... for the channels rep, rep + nrep, ... of a group (rep = tid / pos)
-    return q;
-}
-size_t dcnw_lds_bytes(const DcnWinGeom& q, int bm) {
-    size_t fl = (size_t)16 * q.PL + 2 * IG_KC * bm;
-    if (fl < (size_t)4 * IG_EPI_WAVE) fl = 4 * IG_EPI_WAVE;
-    return fl * sizeof(float);
-}
+template <int TC> constexpr size_t dcnw_lds_floats(int bm) { return (size_t)16 * DwTile<TC>::PL + 2 * IG_KC * bm; }
 
-template <int BM>
-__global__ __launch_bounds__(IG_THREADS, 2) void dcnw_fwd_kernel(DcnFwdParams p, const float* __restrict__ A, int Mp, int Kp,
-                                                                 long long N, int n_tiles, DcnWinGeom wq) {
-    constexpr int TM = BM / 32;                                        // every wave: all BM rows x 32 pixels
+template <int BM, int TC>
+__global__ __launch_bounds__(IG_THREADS, 3) void dcnw_fwd_kernel(DcnFwdParams p, const float* __restrict__ A, int Mp, int Kp,
+                                                                 int n_tiles, int tiles_x) {
+    using Q = DwTile<TC>;
+    constexpr int TM = BM / 32, PL = Q::PL, RS = Q::RS;                // every wave: all BM rows x 32 pixels
     extern __shared__ __attribute__((aligned(16))) float smem[];      // Hs[16 * PL] | As[2][16 * BM]; reused by the epilogue
     const DcnGeom& g = p.g;
-    const int PL = wq.PL, RS = wq.RS, W = g.W, H = g.H, HW = g.H * g.W;
+    const int W = g.W, H = g.H, HW = g.H * g.W;
     float* const Hs = smem;
     float* const Asb = smem + 16 * PL;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const long long n0 = (long long)xcd_remap(blockIdx.x, n_tiles) * IG_BN;
-    const int b = (int)(n0 / HW), pp0 = (int)(n0 - (long long)b * HW), y0 = pp0 >> wq.w_shift;
+    // tile -> (image, tile row, tile column)
+    int tile = xcd_remap(blockIdx.x, n_tiles);
+    const int tx = tile % tiles_x; tile /= tiles_x;
+    const int tiles_y = H / Q::TR;
+    const int ty = tile % tiles_y, b = tile / tiles_y;
+    const int y0 = ty * Q::TR, x0 = tx * TC;
     const int yw0 = y0 - 1 - DW_MARGIN;                                // image row of window row 0
     const int pxl = wid * 32 + (lane & 31), kl = lane >> 5;
-    const int py = y0 + (pxl >> wq.w_shift), px = pxl & (W - 1), pp = pp0 + pxl;
+    const int py = y0 + (pxl >> Q::SHIFT), px = x0 + (pxl & (TC - 1)), pp = py * W + px;
 
-    // window staging: this thread's cell position inside a channel plane and its first channel
     const buf_rsrc rs = ig_make_rsrc(p.in, (unsigned)((size_t)g.B * g.C * HW * sizeof(float)));
-    const int rep = tid / wq.pos, pos = tid - rep * wq.pos;
-    const bool stager = rep < wq.nrep;
-    const int srow = pos / wq.cpr, sq4 = pos - srow * wq.cpr;
-    const int siy = yw0 + srow;
-    const unsigned voff0 = (stager && siy >= 0 && siy < H)
-                               ? (unsigned)(((b * g.C + rep) * HW + siy * W + 4 * sq4) * (int)sizeof(float)) : IG_BUF_OOB;
-    float* const hdst = Hs + rep * PL + srow * RS + 4 + 4 * sq4;
-    const int ncell = stager ? (16 - rep + wq.nrep - 1) / wq.nrep : 0;   // channels rep, rep + nrep, ... < 16
-    const int ncell_max = (16 + wq.nrep - 1) / wq.nrep;                  // (uniform bound of the unrolled loops)
-    for (int e = tid; e < 16 * wq.NR * 8; e += IG_THREADS) {             // the zero columns left and right of the image
-        const int k8 = e & 7, cr = e >> 3;
-        const int c = cr / wq.NR, row = cr - c * wq.NR;
-        Hs[c * PL + row * RS + (k8 < 4 ? k8 : W + k8)] = 0.0f;
-    }
+    // window cell e = tid + 256 i of a channel group -> (channel, row, 16-byte column cell); offsets recomputed per use
+    // (constant divisors: a few multiply-shifts) instead of kept in 2 x NCELL registers
+    auto cell = [&](int i, unsigned& voff, int& loff) {
+        const int e = tid + i * IG_THREADS;
+        const int c = e / Q::CPP, rem = e - c * Q::CPP;
+        const int row = rem / Q::CPR, q4 = rem - row * Q::CPR;
+        const int iy = yw0 + row, ix = x0 - 4 + 4 * q4;
+        loff = e < Q::CELLS ? c * PL + row * RS + 4 * q4 : -1;
+        voff = (e < Q::CELLS && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                   ? (unsigned)(((b * g.C + c) * HW + iy * W + ix) * (int)sizeof(float)) : IG_BUF_OOB;
+    };
 
     // per-tap sampling state of this lane's pixel: window address of the top-left corner, the two fractions and the
     // mask (zero for a stray or an invalid sample); `stray`: bit t set -> tap t takes its corners from global memory
@@ -409,9 +400,9 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnw_fwd_kernel(DcnFwdParams p,
             const float hf = floorf(h), wf = floorf(w);
             const bool valid = h > -1.0f && w > -1.0f && h < (float)H && w < (float)W;    // (false for NaN)
             const int h0 = valid ? (int)hf : 0, w0i = valid ? (int)wf : 0;
-            const int wr = h0 - yw0;
-            const bool inwin = valid && wr >= 0 && wr + 1 <= wq.NR - 1 && w0i >= -4 && w0i <= W + 2;
-            addr[t] = inwin ? wr * RS + w0i + 4 : 0;
+            const int wr = h0 - yw0, wc = w0i - x0 + 4;
+            const bool inwin = valid && wr >= 0 && wr + 1 <= Q::NR - 1 && wc >= 0 && wc + 1 <= RS - 1;
+            addr[t] = inwin ? wr * RS + wc : 0;
             flh[t] = h - hf;
             flw[t] = w - wf;
             fmk[t] = inwin ? mk[t] : 0.0f;
@@ -426,19 +417,23 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnw_fwd_kernel(DcnFwdParams p,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    f32x4 hreg[DW_MAXCELLS];
+    f32x4 hreg[Q::NCELL];
     auto win_load = [&](int grp) {
-        const int step = wq.nrep * HW * (int)sizeof(float);
-        unsigned soff = (unsigned)(grp * 16 * HW) * (unsigned)sizeof(float);
+        const unsigned soff = (unsigned)(grp * 16 * HW) * (unsigned)sizeof(float);
 #pragma unroll
-        for (int i = 0; i < DW_MAXCELLS; ++i)
-            if (i < ncell_max) { hreg[i] = ig_buf_load4(rs, i < ncell ? voff0 : IG_BUF_OOB, soff); soff += (unsigned)step; }
+        for (int i = 0; i < Q::NCELL; ++i) {
+            unsigned voff; int loff;
+            cell(i, voff, loff);
+            hreg[i] = ig_buf_load4(rs, voff, soff);
+        }
     };
     auto win_store = [&]() {
-        const int step = wq.nrep * PL;
 #pragma unroll
-        for (int i = 0; i < DW_MAXCELLS; ++i)
-            if (i < ncell_max && i < ncell) *reinterpret_cast<f32x4*>(hdst + i * step) = hreg[i];
+        for (int i = 0; i < Q::NCELL; ++i) {
+            unsigned voff; int loff;
+            cell(i, voff, loff);
+            if (loff >= 0) *reinterpret_cast<f32x4*>(Hs + loff) = hreg[i];
+        }
     };
     f32x4 ra[ig_a_per<BM>()];
     const IgABuf<BM> abuf(A, Mp, Kp, 0, tid);
@@ -467,7 +462,6 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnw_fwd_kernel(DcnFwdParams p,
             int a_t = addr[t];
             asm volatile("" : "+v"(a_t));
             const float* hb = Hs + kl * PL + a_t;
-            const bool tstray = any_stray && __any((stray >> t) & 1u);
             const float lh = flh[t], lw = flw[t], hh = 1.0f - lh, hw = 1.0f - lw, mk = fmk[t];
             const float w00 = hh * hw * mk, w01 = hh * lw * mk, w10 = lh * hw * mk, w11 = lh * lw * mk;
             float v[IG_KC / 2];
@@ -479,18 +473,6 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnw_fwd_kernel(DcnFwdParams p,
                 x = fmaf(w01, q[1], x);
                 x = fmaf(w10, q[RS], x);
                 v[s] = fmaf(w11, q[RS + 1], x);
-            }
-            if (tstray) {                                              // rare: corners beyond the window, from global memory
-                if ((stray >> t) & 1u) {
-                    const Tap tp = make_tap(g, p.off + (size_t)b * 18 * HW, p.mask + (size_t)b * 9 * HW, 0, t, py, px);
-                    const float* in_c = p.in + ((size_t)b * g.C + grp * 16 + kl) * HW;
-#pragma unroll
-                    for (int s = 0; s < IG_KC / 2; ++s) {
-                        float v00, v01, v10, v11;
-                        tap_corners(tp, in_c + (size_t)(2 * s) * HW, v00, v01, v10, v11);
-                        v[s] = tap_sample(tp, v00, v01, v10, v11) * tp.mask;
-                    }
-                }
             }
             if (col_on) {
                 unsigned long long rowoff = (unsigned long long)(unsigned)((t * g.C + grp * 16) * HW) * sizeof(float);
@@ -512,17 +494,70 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnw_fwd_kernel(DcnFwdParams p,
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);                         // (nothing moves across taps: register pressure)
         }
+        if (any_stray) {
+            // Strays of this wave (rare): their window weights were zero above; here the tap's eight channels come from
+            // global memory for the stray lanes (zero for the others), the chunk's A fragments from the packed matrix in
+            // L2, and the same 16 MFMAs add the missing products.  A runtime loop over the taps, apart from the unrolled
+            // hot path: inlined there, its address arithmetic was hoisted out of the group loop for all nine taps and
+            // spilled ~200 registers.  The tap index goes through an opaque copy for the same reason.
+#pragma unroll 1
+            for (int t0 = 0; t0 < 9; ++t0) {
+                int t = t0;
+                asm volatile("" : "+s"(t));
+                if (!__any((stray >> t) & 1u)) continue;
+                float sv[IG_KC / 2];
+#pragma unroll
+                for (int s = 0; s < IG_KC / 2; ++s) sv[s] = 0.0f;
+                if ((stray >> t) & 1u) {
+                    // the tap's state again from the raw offsets, corner addresses clamped into the plane, weights zeroed
+                    // where a corner lies outside it (dcn_v2_im2col_cuda.cu:37-48)
+                    const float* off_b = p.off + (size_t)b * 18 * HW + pp;
+                    const int tr = t / 3;
+                    const float sh_ = (float)(py - 1 + tr) + off_b[(size_t)(2 * t) * HW];
+                    const float sw_ = (float)(px - 1 + t - 3 * tr) + off_b[(size_t)(2 * t + 1) * HW];
+                    const float smk = p.mask[((size_t)b * 9 + t) * HW + pp];
+                    const float shf = floorf(sh_), swf = floorf(sw_);
+                    const int sh0 = (int)shf, sw0 = (int)swf;
+                    const float slh = sh_ - shf, slw = sw_ - swf, shh = 1.0f - slh, shw = 1.0f - slw;
+                    const bool top = sh0 >= 0, bot = sh0 + 1 <= H - 1, lef = sw0 >= 0, rig = sw0 + 1 <= W - 1;
+                    const float g00 = (top && lef) ? shh * shw * smk : 0.0f, g01 = (top && rig) ? shh * slw * smk : 0.0f;
+                    const float g10 = (bot && lef) ? slh * shw * smk : 0.0f, g11 = (bot && rig) ? slh * slw * smk : 0.0f;
+                    const int cy0 = top ? sh0 : 0, cy1 = bot ? sh0 + 1 : H - 1, cx0 = lef ? sw0 : 0, cx1 = rig ? sw0 + 1 : W - 1;
+                    const float* in_c = p.in + ((size_t)b * g.C + grp * 16 + kl) * HW;
+                    const int o00 = cy0 * W + cx0, o01 = cy0 * W + cx1, o10 = cy1 * W + cx0, o11 = cy1 * W + cx1;
+#pragma unroll
+                    for (int s = 0; s < IG_KC / 2; ++s) {
+                        const float* pl = in_c + (size_t)(2 * s) * HW;
+                        float x = g00 * pl[o00];
+                        x = fmaf(g01, pl[o01], x);
+                        x = fmaf(g10, pl[o10], x);
+                        sv[s] = fmaf(g11, pl[o11], x);
+                    }
+                    if (col_on) {
+                        float* cp = col_l + (size_t)(t * g.C + grp * 16) * HW;
+#pragma unroll
+                        for (int s = 0; s < IG_KC / 2; ++s) cp[(size_t)(2 * s) * HW] = sv[s];
+                    }
+                }
+                const float* ag = A + (size_t)((c0 + t) * IG_KC + kl) * Mp + (lane & 31);
+#pragma unroll
+                for (int s = 0; s < IG_KC / 2; ++s) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ag[(size_t)(2 * s) * Mp + i * 32], sv[s], acc[i], 0, 0, 0);
+                }
+            }
+        }
         if (more) {          // every wave has read the group's last corners: the next group's window moves in
             win_store();
             __syncthreads();
         }
     }
     // epilogue: bias (+ activation), 16 bytes per lane through LDS (every wave: TM tiles of 32 rows x its 32 pixels)
-    using Out = DcnFwdLoaderT<true>::Out;
     float* stage = smem + wid * IG_EPI_WAVE;
     const int col = lane & 31, cg = lane & 7, rsub = lane >> 3;
-    const long long n = n0 + wid * 32 + 4 * cg;
-    Out out(p, n < N ? n : 0);
+    const int epl = wid * 32 + 4 * cg;                                  // four consecutive pixels of one tile row
+    float* const obase = p.out + (size_t)b * g.Co * HW + (size_t)(y0 + (epl >> Q::SHIFT)) * W + x0 + (epl & (TC - 1));
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -531,9 +566,16 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnw_fwd_kernel(DcnFwdParams p,
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 8 + rsub;
-            const f32x4 v4 = *reinterpret_cast<const f32x4*>(stage + row * IG_EPI_LD + 4 * cg);
+            f32x4 v4 = *reinterpret_cast<const f32x4*>(stage + row * IG_EPI_LD + 4 * cg);
             const int m = i * 32 + row;
-            if (m < g.Co && n < N) out.store4(p, m, v4);
+            if (m < g.Co) {
+                v4 += p.bias[m];
+                if (p.act_slope >= 0.0f) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (v4[e] < 0.0f) v4[e] *= p.act_slope;
+                }
+                *reinterpret_cast<f32x4*>(obase + (size_t)m * HW) = v4;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -1427,8 +1469,8 @@ DcnPlan make_plan(const DcnGeom& g) {
     q.fwd_two_kernels = q.Mp / q.bm > 1;
     q.fwd_bytes = carve_bytes((size_t)q.Kp * q.Mp, 4) + 256 +
                   (q.fwd_two_kernels ? carve_bytes((size_t)g.B * q.K * g.Ho * g.Wo, 4) : 0);
-    if (g.Co <= 128) {      // the window kernel (dcnw_fwd_kernel) packs [K][64 or 128]
-        const size_t wb = carve_bytes((size_t)q.Kp * (g.Co <= 64 ? 64 : 128), 4) + 256;
+    if (g.Co <= 64) {       // the window kernel (dcnw_fwd_kernel) packs [K][64]
+        const size_t wb = carve_bytes((size_t)q.Kp * 64, 4) + 256;
         if (wb > q.fwd_bytes) q.fwd_bytes = wb;
     }
     q.gemm_bytes = cnuda_conv2d_workspace_bytes(g.B, g.Co, g.Ho, g.Wo, q.T * g.C, 1, 1, 1, 1, 0, 0);
@@ -1520,33 +1562,32 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
     // keeps the gathering loader (A/B measurements; tests/test_gpu_kernel_switches.py).
     static const bool dcnw_on = !(getenv("CNUDA_DCNW") && getenv("CNUDA_DCNW")[0] == '0');
     if (dcnw_on && matrix_mode() == 0 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 &&
-        dw == 1 && C % 16 == 0 && Cout <= 128 && (W == 16 || W == 32 || W == 64 || W == 128) &&
+        dw == 1 && C % 16 == 0 && Cout <= 64 && (W == 16 || W == 32 || W == 64 || W == 128) &&
         ((long long)H * W) % IG_BN == 0 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB) {
-        const int bm = Cout <= 64 ? 64 : 128;
+        const int bm = 64;
         const float* Aw = launch_pack(weight, cv.take<float>((size_t)q.Kp * bm), (size_t)q.Kp * bm * sizeof(float), Cout, C,
                                       q.T, PACK_HALO_FWD, q.Kp, bm, 0, st);
-        const DcnWinGeom wq = make_win_geom(W);
-        const size_t lds = dcnw_lds_bytes(wq, bm);
         DcnFwdParams p{g, input, offset, mask, bias, act_slope, output, columns};
-        const int n_tiles = (int)(q.N / IG_BN);
         ProfScope prof(st);
         prof.name("dcnw_fwd_kernel<%d>%s", bm, columns ? " (+ column side output)" : "");
-        static size_t allowed64 = 64 * 1024, allowed128 = 64 * 1024;
-        if (bm == 64) {
-            if (lds > allowed64) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnw_fwd_kernel<64>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                allowed64 = 160 * 1024;
-            }
-            CNUDA_LAUNCH(dcnw_fwd_kernel<64>, dim3(n_tiles), dim3(IG_THREADS), lds, st, p, Aw, bm, q.Kp, q.N, n_tiles, wq);
-        } else {
-            if (lds > allowed128) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnw_fwd_kernel<128>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                allowed128 = 160 * 1024;
-            }
-            CNUDA_LAUNCH(dcnw_fwd_kernel<128>, dim3(n_tiles), dim3(IG_THREADS), lds, st, p, Aw, bm, q.Kp, q.N, n_tiles, wq);
-        }
+        const int tc = W >= 64 ? 64 : W, tiles_x = W / tc, n_tiles = (int)(q.N / IG_BN);
+#define CNUDA_DCNW_LAUNCH(BMV, TCV)                                                                                    \
+    do {                                                                                                               \
+        const size_t fl = dcnw_lds_floats<TCV>(BMV);                                                                   \
+        const size_t lds = (fl < (size_t)4 * IG_EPI_WAVE ? (size_t)4 * IG_EPI_WAVE : fl) * sizeof(float);             \
+        static bool raised = false;                                                                                    \
+        if (lds > 64 * 1024 && !raised) {                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnw_fwd_kernel<BMV, TCV>),                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+            raised = true;                                                                                             \
+        }                                                                                                              \
+        CNUDA_LAUNCH((dcnw_fwd_kernel<BMV, TCV>), dim3(n_tiles), dim3(IG_THREADS), lds, st, p, Aw, bm, q.Kp, n_tiles,  \
+                     tiles_x);                                                                                         \
+    } while (0)
+        // (a 128-row variant -- four accumulator tiles per wave -- spills and measured slower than the gathering
+        // loader's 128-row tile, 571 vs 452 us at 128 -> 128, 64 x 64, B = 32: layers with more than 64 outputs stay there)
+        if (tc == 64) CNUDA_DCNW_LAUNCH(64, 64); else if (tc == 32) CNUDA_DCNW_LAUNCH(64, 32); else CNUDA_DCNW_LAUNCH(64, 16);
+#undef CNUDA_DCNW_LAUNCH
         return check_launch("cnuda_dcn_v2_forward(window)");
     }
     const float* A = launch_pack(weight, cv.take<float>((size_t)q.Kp * q.Mp), (size_t)q.Kp * q.Mp * sizeof(float), Cout,
