@@ -328,20 +328,22 @@ using DcnFwdBufLoader = DcnFwdLoaderT<true>;
 // weights (mask folded in), which live in registers for all nine taps of the tile -- and the sample IS the MFMA's B
 // fragment: it never goes through LDS.  Out-of-image corners read the window's zeros, which reproduces the reference's
 // validity rule (dcn_v2_im2col_cuda.cu:37-48,180) without a predicate.  A sample whose corners leave the window
-// (|offset| >= 1 + DW_MARGIN rows, or >= 3 columns) is a STRAY: its lane takes the four corners from global memory
+// (|offset| >= DW_MARGIN = 3 pixels) is a STRAY: its lane takes the four corners from global memory
 // (exec-masked, the slow path; correct for any offset).  The column side output for the weight gradient is one
 // 4-byte store per sample, rows in (tap, channel) order as before.
 // ---------------------------------------------------------------------------
-constexpr int DW_MARGIN = 2;         // window rows beyond the undeformed 3x3 footprint, above and below
-// Pixel tile = TR rows x TC columns = 128 pixels, TC = min(W, 64): two rows of 64 (W = 64, 128), four of 32, eight of
-// 16.  Window of a 16-channel group: NR = TR + 2 + 2 * DW_MARGIN rows x (TC + 8) columns -- tile column x sits at index
-// x - x0 + 4, four real or zero columns on either side -- staged as 16-byte cells: TC / 4 + 2 per row, (W = 128: the
-// side cells hold the neighbouring tile's pixels), zero by the buffer range check wherever the image ends.
+constexpr int DW_MARGIN = 3;         // window rows beyond the undeformed 3x3 footprint, above and below
+// Pixel tile = TR rows x TC columns = 128 pixels, TC = min(W, 32): four rows of 32 (eight of 16 on the 16-wide maps).
+// Window of a 16-channel group: NR = TR + 2 + 2 * DW_MARGIN rows x (TC + 8) columns -- tile column x sits at index
+// x - x0 + 4, four real (the neighbouring tile's) or zero columns on either side -- staged as 16-byte cells, TC / 4 + 2
+// per row, zero by the buffer range check wherever the image ends.  The squarer the tile, the smaller the window per
+// pixel: 12 x 40 cells for 4 x 32 pixels (31 KB per group, offsets up to +-3 pixels stay inside) against 10 x 72 for
+// 2 x 64; a wave's 32 pixels are still one row segment (128-byte stores).
 template <int TC> struct DwTile {
     static constexpr int TR = IG_BN / TC, NR = TR + 2 + 2 * DW_MARGIN, RS = TC + 8, PL = NR * RS;
     static constexpr int CPR = TC / 4 + 2, CPP = NR * CPR, CELLS = 16 * CPP;
-    static constexpr int NCELL = (CELLS + IG_THREADS - 1) / IG_THREADS;       // per thread: 9 (TC 64), 7 (32), 6 (16)
-    static constexpr int SHIFT = TC == 64 ? 6 : (TC == 32 ? 5 : 4);
+    static constexpr int NCELL = (CELLS + IG_THREADS - 1) / IG_THREADS;       // per thread: 8 (TC 32), 6 (16)
+    static constexpr int SHIFT = TC == 32 ? 5 : 4;
 };
 template <int TC> constexpr size_t dcnw_lds_floats(int bm) { return (size_t)16 * DwTile<TC>::PL + 2 * IG_KC * bm; }
 
@@ -370,7 +372,11 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcnw_fwd_kernel(DcnFwdParams p,
     // window cell e = tid + 256 i of a channel group -> (channel, row, 16-byte column cell); offsets recomputed per use
     // (constant divisors: a few multiply-shifts) instead of kept in 2 x NCELL registers
     auto cell = [&](int i, unsigned& voff, int& loff) {
-        const int e = tid + i * IG_THREADS;
+        // (an opaque zero: the compiler would otherwise compute every cell's offsets once per group, keep them across
+        // the nine taps for win_store and spill them -- and a scratch reload sits behind the window loads in vmcnt order)
+        int salt = 0;
+        asm volatile("" : "+v"(salt));
+        const int e = tid + i * IG_THREADS + salt;
         const int c = e / Q::CPP, rem = e - c * Q::CPP;
         const int row = rem / Q::CPR, q4 = rem - row * Q::CPR;
         const int iy = yw0 + row, ix = x0 - 4 + 4 * q4;
@@ -1563,14 +1569,14 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
     static const bool dcnw_on = !(getenv("CNUDA_DCNW") && getenv("CNUDA_DCNW")[0] == '0');
     if (dcnw_on && matrix_mode() == 0 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 &&
         dw == 1 && C % 16 == 0 && Cout <= 64 && (W == 16 || W == 32 || W == 64 || W == 128) &&
-        ((long long)H * W) % IG_BN == 0 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB) {
+        H % (IG_BN / (W >= 32 ? 32 : W)) == 0 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB) {
         const int bm = 64;
         const float* Aw = launch_pack(weight, cv.take<float>((size_t)q.Kp * bm), (size_t)q.Kp * bm * sizeof(float), Cout, C,
                                       q.T, PACK_HALO_FWD, q.Kp, bm, 0, st);
         DcnFwdParams p{g, input, offset, mask, bias, act_slope, output, columns};
         ProfScope prof(st);
         prof.name("dcnw_fwd_kernel<%d>%s", bm, columns ? " (+ column side output)" : "");
-        const int tc = W >= 64 ? 64 : W, tiles_x = W / tc, n_tiles = (int)(q.N / IG_BN);
+        const int tc = W >= 32 ? 32 : W, tiles_x = W / tc, n_tiles = (int)(q.N / IG_BN);
 #define CNUDA_DCNW_LAUNCH(BMV, TCV)                                                                                    \
     do {                                                                                                               \
         const size_t fl = dcnw_lds_floats<TCV>(BMV);                                                                   \
@@ -1586,7 +1592,7 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
     } while (0)
         // (a 128-row variant -- four accumulator tiles per wave -- spills and measured slower than the gathering
         // loader's 128-row tile, 571 vs 452 us at 128 -> 128, 64 x 64, B = 32: layers with more than 64 outputs stay there)
-        if (tc == 64) CNUDA_DCNW_LAUNCH(64, 64); else if (tc == 32) CNUDA_DCNW_LAUNCH(64, 32); else CNUDA_DCNW_LAUNCH(64, 16);
+        if (tc == 32) CNUDA_DCNW_LAUNCH(64, 32); else CNUDA_DCNW_LAUNCH(64, 16);
 #undef CNUDA_DCNW_LAUNCH
         return check_launch("cnuda_dcn_v2_forward(window)");
     }
