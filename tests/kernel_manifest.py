@@ -12,6 +12,19 @@ Keys: the kernel's symbol name with the namespace prefix and the argument list d
 """
 
 MANIFEST = {
+    'dcnw_fwd_kernel<64, 32>': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+        'tests/test_gpu_dcn.py::test_known_answer_half_pixel_offsets_are_box_blurs',
+    ],
+    'hconv_kernel<32, 256, HconvFwd>': [
+        'tests/test_gpu_fullsize.py::test_full_size_halo_tile_convolutions_match_fp64[64to27_128sq',
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+    ],
+    'hconv_kernel<32, 128, HconvFwd>': [
+        'tests/test_gpu_fullsize.py::test_full_size_halo_tile_convolutions_match_fp64[128to27_64sq',
+        'tests/test_gpu_ops.py::test_halo_tile_convolution_3x3',
+    ],
     'adam_kernel': [
         'tests/test_gpu_ops.py::test_adam_matches_torch_and_skips_untouched_params',
         'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
