@@ -19,7 +19,6 @@ MANIFEST = {
     ],
     'hconv_kernel<32, 256, HconvFwd>': [
         'tests/test_gpu_fullsize.py::test_full_size_halo_tile_convolutions_match_fp64[64to27_128sq',
-        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
     ],
     'hconv_kernel<32, 128, HconvFwd>': [
         'tests/test_gpu_fullsize.py::test_full_size_halo_tile_convolutions_match_fp64[128to27_64sq',
