@@ -461,6 +461,10 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcnw_fwd_kernel(DcnFwdParams p,
 #pragma unroll
         for (int t = 0; t < 9; ++t) {                                  // (unrolled: the tap's registers are addressed statically)
             const int c = c0 + t;
+            // chunk c + 2's A tile goes out FIRST: vmcnt retires in issue order, so behind this tap's eight column stores
+            // the load's data would arrive only after every one of them has drained
+            f32x4 ra2[ig_a_per<BM>()];
+            if (c + 2 < nchunk) abuf.load((c + 2) * IG_KC, ra2);
             const float* As = Asb + (c & 1) * IG_KC * BM;
             const float* ap = As + kl * BM + (lane & 31);
             // (opaque copies: without them the compiler hoists the 72 per-(tap, k-step) window addresses and the 72
@@ -470,33 +474,55 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcnw_fwd_kernel(DcnFwdParams p,
             const float* hb = Hs + kl * PL + a_t;
             const float lh = flh[t], lw = flw[t], hh = 1.0f - lh, hw = 1.0f - lw, mk = fmk[t];
             const float w00 = hh * hw * mk, w01 = hh * lw * mk, w10 = lh * hw * mk, w11 = lh * lw * mk;
-            float v[IG_KC / 2];
-            // the eight samples of this chunk (channels kl, kl + 2, ..): corner pairs from the window
-#pragma unroll
-            for (int s = 0; s < IG_KC / 2; ++s) {
-                const float* q = hb + 2 * s * PL;
-                float x = w00 * q[0];
-                x = fmaf(w01, q[1], x);
-                x = fmaf(w10, q[RS], x);
-                v[s] = fmaf(w11, q[RS + 1], x);
-            }
+            // The eight samples of this chunk (channels kl, kl + 2, ..) in two halves: the corner pairs of the second half
+            // are read from the window while the first half's MFMAs run (sched_barrier pins the order; left alone the
+            // compiler reads all sixteen pairs, waits, then issues sixteen MFMAs: PMC showed 38 % of the wave cycles waiting)
+            float v[IG_KC / 2], cr[IG_KC / 4][4];
+            float* cp = nullptr;
             if (col_on) {
                 unsigned long long rowoff = (unsigned long long)(unsigned)((t * g.C + grp * 16) * HW) * sizeof(float);
                 asm volatile("" : "+s"(rowoff));
-                float* cp = reinterpret_cast<float*>(reinterpret_cast<char*>(col_l) + rowoff);
-#pragma unroll
-                for (int s = 0; s < IG_KC / 2; ++s) cp[(size_t)(2 * s) * HW] = v[s];
+                cp = reinterpret_cast<float*>(reinterpret_cast<char*>(col_l) + rowoff);
             }
+            auto read_half = [&](int h) {
 #pragma unroll
-            for (int s = 0; s < IG_KC / 2; ++s) {
+                for (int s = 0; s < IG_KC / 4; ++s) {
+                    const float* q = hb + 2 * (h * (IG_KC / 4) + s) * PL;
+                    cr[s][0] = q[0]; cr[s][1] = q[1]; cr[s][2] = q[RS]; cr[s][3] = q[RS + 1];
+                }
+            };
+            auto blend_half = [&](int h) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * BM + i * 32], v[s], acc[i], 0, 0, 0);
-            }
-            if (c + 1 < nchunk) {
-                ig_store_a<BM>(Asb + ((c + 1) & 1) * IG_KC * BM, tid, ra);
-                if (c + 2 < nchunk) abuf.load((c + 2) * IG_KC, ra);
-            }
+                for (int s = 0; s < IG_KC / 4; ++s) {
+                    float x = w00 * cr[s][0];
+                    x = fmaf(w01, cr[s][1], x);
+                    x = fmaf(w10, cr[s][2], x);
+                    v[h * (IG_KC / 4) + s] = fmaf(w11, cr[s][3], x);
+                }
+                if (col_on) {
+#pragma unroll
+                    for (int s = 0; s < IG_KC / 4; ++s) cp[(size_t)(2 * (h * (IG_KC / 4) + s)) * HW] = v[h * (IG_KC / 4) + s];
+                }
+            };
+            auto mma_half = [&](int h) {
+#pragma unroll
+                for (int s = h * (IG_KC / 4); s < (h + 1) * (IG_KC / 4); ++s) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * BM + i * 32], v[s], acc[i], 0, 0, 0);
+                }
+            };
+            read_half(0);
+            blend_half(0);
+            read_half(1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(0);
+            __builtin_amdgcn_sched_barrier(0);
+            blend_half(1);
+            mma_half(1);
+            if (c + 1 < nchunk) ig_store_a<BM>(Asb + ((c + 1) & 1) * IG_KC * BM, tid, ra);
+#pragma unroll
+            for (int i = 0; i < ig_a_per<BM>(); ++i) ra[i] = ra2[i];
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);                         // (nothing moves across taps: register pressure)
         }
