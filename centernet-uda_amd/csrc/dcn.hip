@@ -614,6 +614,247 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcnw_fwd_kernel(DcnFwdParams p,
 }
 
 // ---------------------------------------------------------------------------
+// backward data path with the column gradient ON-CHIP (round 4): same layers as dcnw_fwd_kernel.
+//
+// dcol[(tap, c), p] = sum_o W[o, c, tap] * gout[o, p] used to be a 1x1 implicit GEMM that wrote 9*C*Ho*Wo floats per
+// image to workspace (864 MB per 128 x 128 layer of the benched step) for two consumers to stream back.  Here a
+// workgroup owns 128 pixels (the forward's 4 x 32 tile); every wave holds grad_output of its 32 pixels as MFMA B
+// fragments (Co <= 64: 32 registers) for the whole tile and, per channel group and PAIR of taps, computes the 32 x 32
+// tile of dcol -- rows (2 taps x 16 channels), columns its pixels -- with 32 f32 MFMAs whose A fragments come straight
+// from the packed weights (PACK_DCN_DCOL, L2-resident).  The accumulator layout puts a pixel on a lane and eight
+// channels of each tap in its registers, which is what the coordinate / mask gradients want: four running sums
+// u_kl = sum_c dcol_c * corner_kl(c) per (pixel, tap) from the INPUT window in LDS (dcnw_fwd_kernel's window: two
+// ds_read2_b32 per channel instead of two unaligned 8-byte gathers through the texture-address unit), kept in
+// registers across the channel groups and turned into grad_offset / grad_mask at the end of the tile.
+// SCATTER == false (validation build, and layers the in-kernel scatter does not take): dcol is also written out in the
+// layout dcn_col2im_kernel reads.
+// ---------------------------------------------------------------------------
+struct DcnBwdWinParams {
+    DcnGeom g;
+    const float *in, *off, *mask, *gout;
+    float *goff, *gmask;
+    float* dcol;                  // [B][9 * C][HW], plain column gradient (SCATTER == false)
+};
+
+template <int TC, bool SCATTER>
+__global__ __launch_bounds__(IG_THREADS, 2) void dcnb_kernel(DcnBwdWinParams p, const float* __restrict__ A, int Mp, int n_tiles,
+                                                             int tiles_x) {
+    using Q = DwTile<TC>;
+    constexpr int PL = Q::PL, RS = Q::RS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // Win[16 * PL]
+    const DcnGeom& g = p.g;
+    const int W = g.W, H = g.H, HW = g.H * g.W;
+    float* const Win = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int tile = xcd_remap(blockIdx.x, n_tiles);
+    const int tx = tile % tiles_x; tile /= tiles_x;
+    const int tiles_y = H / Q::TR;
+    const int ty = tile % tiles_y, b = tile / tiles_y;
+    const int y0 = ty * Q::TR, x0 = tx * TC;
+    const int yw0 = y0 - 1 - DW_MARGIN;
+    const int pxl = wid * 32 + (lane & 31), kl = lane >> 5;
+    const int py = y0 + (pxl >> Q::SHIFT), px = x0 + (pxl & (TC - 1)), pp = py * W + px;
+
+    const buf_rsrc rs = ig_make_rsrc(p.in, (unsigned)((size_t)g.B * g.C * HW * sizeof(float)));
+    const buf_rsrc ra = ig_make_rsrc(A, (unsigned)((size_t)64 * Mp * sizeof(float)));
+    auto cell = [&](int i, unsigned& voff, int& loff) {
+        int salt = 0;
+        asm volatile("" : "+v"(salt));                                 // (see dcnw_fwd_kernel)
+        const int e = tid + i * IG_THREADS + salt;
+        const int c = e / Q::CPP, rem = e - c * Q::CPP;
+        const int row = rem / Q::CPR, q4 = rem - row * Q::CPR;
+        const int iy = yw0 + row, ix = x0 - 4 + 4 * q4;
+        loff = e < Q::CELLS ? c * PL + row * RS + 4 * q4 : -1;
+        voff = (e < Q::CELLS && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                   ? (unsigned)(((b * g.C + c) * HW + iy * W + ix) * (int)sizeof(float)) : IG_BUF_OOB;
+    };
+
+    // grad_output of this lane's pixel: B fragments of the column-gradient GEMM, k-step s holds output channel 2s + kl
+    float gf[32];
+    {
+        const float* go = p.gout + (size_t)b * g.Co * HW + pp;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) gf[s] = 2 * s + kl < g.Co ? go[(size_t)(2 * s + kl) * HW] : 0.0f;
+    }
+    // per-tap sampling state (as dcnw_fwd_kernel) and the four running sums of every tap
+    int addr[9];
+    float u00[9], u01[9], u10[9], u11[9];
+    unsigned stray = 0, inwin_bits = 0;
+    {
+        const float* off_b = p.off + (size_t)b * 18 * HW + pp;
+        float dy[9], dx[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            dy[t] = off_b[(size_t)(2 * t) * HW];
+            dx[t] = off_b[(size_t)(2 * t + 1) * HW];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float h = (float)(py - 1 + t / 3) + dy[t], w = (float)(px - 1 + t % 3) + dx[t];
+            const float hf = floorf(h), wf = floorf(w);
+            const bool valid = h > -1.0f && w > -1.0f && h < (float)H && w < (float)W;
+            const int h0 = valid ? (int)hf : 0, w0i = valid ? (int)wf : 0;
+            const int wr = h0 - yw0, wc = w0i - x0 + 4;
+            const bool inwin = valid && wr >= 0 && wr + 1 <= Q::NR - 1 && wc >= 0 && wc + 1 <= RS - 1;
+            addr[t] = inwin ? wr * RS + wc : 0;
+            if (inwin) inwin_bits |= 1u << t;
+            if (valid && !inwin) stray |= 1u << t;
+            u00[t] = u01[t] = u10[t] = u11[t] = 0.0f;
+        }
+    }
+    const bool any_stray = __any(stray != 0);
+
+    f32x4 hreg[Q::NCELL];
+    auto win_load = [&](int grp) {
+        const unsigned soff = (unsigned)(grp * 16 * HW) * (unsigned)sizeof(float);
+#pragma unroll
+        for (int i = 0; i < Q::NCELL; ++i) {
+            unsigned voff; int loff;
+            cell(i, voff, loff);
+            hreg[i] = ig_buf_load4(rs, voff, soff);
+        }
+    };
+    auto win_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < Q::NCELL; ++i) {
+            unsigned voff; int loff;
+            cell(i, voff, loff);
+            if (loff >= 0) *reinterpret_cast<f32x4*>(Win + loff) = hreg[i];
+        }
+    };
+    const int G = g.C >> 4;
+    win_load(0);
+    win_store();
+    __syncthreads();
+    for (int grp = 0; grp < G; ++grp) {
+        const bool more = grp + 1 < G;
+        if (more) win_load(grp + 1);
+#pragma unroll
+        for (int pr = 0; pr < 5; ++pr) {                               // pairs of taps: rows (2 taps x 16 channels) of the GEMM
+            // --- the 32 x 32 tile of dcol: 32 MFMAs, A fragments straight from the packed weights
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            {
+                // (scalar row offsets 2 s Mp through the buffer form: the 32 rows cost SGPRs, not hoisted VGPR addresses)
+                const unsigned mvoff = (unsigned)((kl * Mp + (lane & 31)) * (int)sizeof(float));
+                const unsigned gbase = (unsigned)((grp * 10 + 2 * pr) * 16) * (unsigned)sizeof(float);
+#pragma unroll
+                for (int s0 = 0; s0 < 32; s0 += 8) {                   // eight A loads in flight, then their MFMAs
+                    float af[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) af[s] = ig_buf_load(ra, mvoff, gbase + (unsigned)(2 * (s0 + s) * Mp) * (unsigned)sizeof(float));
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], gf[s0 + s], acc, 0, 0, 0);
+                }
+            }
+            // --- gather role for the two taps: this lane's eight channels of each, corners from the input window
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 2 * pr + tt;
+                if (t >= 9) continue;                                  // (the tenth slot of a group is padding)
+                int a_t = addr[t];
+                asm volatile("" : "+v"(a_t));
+                const float* wb = Win + a_t;
+                const float live = ((inwin_bits >> t) & 1u) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int jh = 0; jh < 8; jh += 4) {                    // four channels' corners in registers at a time
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = jh; j < jh + 4; ++j) {
+                        const int c = 4 * kl + (j & 3) + 8 * (j >> 2); // channel of register 8 * tt + j inside the group
+                        const float d = acc[8 * tt + j] * live;
+                        const float* q = wb + c * PL;
+                        u00[t] = fmaf(d, q[0], u00[t]);
+                        u01[t] = fmaf(d, q[1], u01[t]);
+                        u10[t] = fmaf(d, q[RS], u10[t]);
+                        u11[t] = fmaf(d, q[RS + 1], u11[t]);
+                    }
+                    // (the sums are only read at the end of the tile: without an anchor the compiler sinks the whole FMA
+                    // chain below the loop body and keeps every corner it read alive -- in scratch -- until then)
+                    asm volatile("" : "+v"(u00[t]), "+v"(u01[t]), "+v"(u10[t]), "+v"(u11[t]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!SCATTER) {
+                    unsigned lo = (unsigned)(4 * kl * HW + pp) * 4u;
+                    asm volatile("" : "+v"(lo));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned long long db = reinterpret_cast<unsigned long long>(
+                            p.dcol + ((size_t)(b * 9 + t) * g.C + grp * 16 + (j & 3) + 8 * (j >> 2)) * HW);
+                        *reinterpret_cast<__attribute__((address_space(1))) float*>(db + (unsigned long long)lo) = acc[8 * tt + j];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {
+            __syncthreads();                                           // every wave has read this group's window
+            win_store();
+            __syncthreads();
+        }
+    }
+    // --- strays (rare): a (pixel, tap) whose corners left the window.  The lane with kl == 0 redoes the tap's sums
+    // from global memory, channel by channel: dcol_c as a plain dot product over the output channels
+    if (any_stray) {
+#pragma unroll 1
+        for (int t0 = 0; t0 < 9; ++t0) {
+            int t = t0;
+            asm volatile("" : "+s"(t));
+            if (!__any((stray >> t) & 1u)) continue;
+            float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
+            if (((stray >> t) & 1u) && kl == 0) {
+                const float* off_b = p.off + (size_t)b * 18 * HW + pp;
+                const int tr = t / 3;
+                const float sh_ = (float)(py - 1 + tr) + off_b[(size_t)(2 * t) * HW];
+                const float sw_ = (float)(px - 1 + t - 3 * tr) + off_b[(size_t)(2 * t + 1) * HW];
+                const float shf = floorf(sh_), swf = floorf(sw_);
+                const int sh0 = (int)shf, sw0 = (int)swf;
+                const bool top = sh0 >= 0, bot = sh0 + 1 <= H - 1, lef = sw0 >= 0, rig = sw0 + 1 <= W - 1;
+                const float f00 = (top && lef) ? 1.f : 0.f, f01 = (top && rig) ? 1.f : 0.f, f10 = (bot && lef) ? 1.f : 0.f,
+                            f11 = (bot && rig) ? 1.f : 0.f;
+                const int cy0 = top ? sh0 : 0, cy1 = bot ? sh0 + 1 : H - 1, cx0 = lef ? sw0 : 0, cx1 = rig ? sw0 + 1 : W - 1;
+                const int o00 = cy0 * W + cx0, o01 = cy0 * W + cx1, o10 = cy1 * W + cx0, o11 = cy1 * W + cx1;
+                const float* go = p.gout + (size_t)b * g.Co * HW + pp;
+                for (int c = 0; c < g.C; ++c) {
+                    const float* wrow = A + ((c >> 4) * 10 + t) * 16 + (c & 15);          // A[o][m(c, t)]
+                    float d = 0.0f;
+                    for (int o = 0; o < g.Co; ++o) d = fmaf(wrow[(size_t)o * Mp], go[(size_t)o * HW], d);
+                    const float* pl = p.in + ((size_t)b * g.C + c) * HW;
+                    s00 = fmaf(d, pl[o00] * f00, s00);
+                    s01 = fmaf(d, pl[o01] * f01, s01);
+                    s10 = fmaf(d, pl[o10] * f10, s10);
+                    s11 = fmaf(d, pl[o11] * f11, s11);
+                }
+            }
+            // into the tap's sums (static register arrays: select the tap)
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (k == t) { u00[k] += s00; u01[k] += s01; u10[k] += s10; u11[k] += s11; }
+        }
+    }
+    // --- the two lane halves hold disjoint channel subsets of the same pixel: add them, then lanes 0..31 write (the
+    // fractions and the mask are read again here rather than held across the channel loop)
+    const float* off_e = p.off + (size_t)b * 18 * HW + pp;
+    const float* mask_e = p.mask + (size_t)b * 9 * HW + pp;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float a00 = u00[t] + __shfl_xor(u00[t], 32, 64), a01 = u01[t] + __shfl_xor(u01[t], 32, 64);
+        const float a10 = u10[t] + __shfl_xor(u10[t], 32, 64), a11 = u11[t] + __shfl_xor(u11[t], 32, 64);
+        if (kl == 0) {
+            const float h = (float)(py - 1 + t / 3) + off_e[(size_t)(2 * t) * HW], w = (float)(px - 1 + t % 3) + off_e[(size_t)(2 * t + 1) * HW];
+            const float lh = h - floorf(h), lw = w - floorf(w), hh = 1.0f - lh, hw = 1.0f - lw, mk = mask_e[(size_t)t * HW];
+            const float sm = hh * hw * a00 + hh * lw * a01 + lh * hw * a10 + lh * lw * a11;
+            const float sh_ = (-hw * a00 - lw * a01 + hw * a10 + lw * a11) * mk;
+            const float sw_ = (-hh * a00 + hh * a01 - lh * a10 + lh * a11) * mk;
+            p.gmask[((size_t)b * 9 + t) * HW + pp] = sm;
+            p.goff[((size_t)b * 18 + 2 * t) * HW + pp] = sh_;
+            p.goff[((size_t)b * 18 + 2 * t + 1) * HW + pp] = sw_;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // forward, two-kernel form for layers whose output channels span several M tiles (small feature maps run
 // 32- or 64-row tiles to fill the chip): the fused loader would re-sample the columns once per M tile, so the
 // columns are sampled ONCE by a streaming kernel (they are the weight gradient's side output anyway) and a
@@ -1507,7 +1748,7 @@ DcnPlan make_plan(const DcnGeom& g) {
     }
     q.gemm_bytes = cnuda_conv2d_workspace_bytes(g.B, g.Co, g.Ho, g.Wo, q.T * g.C, 1, 1, 1, 1, 0, 0);
     q.bwd_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) +
-                  carve_bytes((size_t)g.Co * g.B, 4) + carve_bytes((size_t)q.T * g.C * g.Co, 4) +
+                  carve_bytes((size_t)g.Co * g.B, 4) + carve_bytes((size_t)(q.T + 1) * g.C * (g.Co < 64 ? 64 : g.Co), 4) +
                   carve_bytes((size_t)g.B * q.T * g.C * g.Ho * g.Wo, 4) +
                   carve_bytes((size_t)g.B * q.T * g.Ho * g.Wo, sizeof(DcnGeo)) + carve_bytes(q.gemm_bytes, 1) + 256;
     // col2im tile: 256 output pixels, lanes along x
@@ -1728,7 +1969,7 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
     Carver cv(workspace, workspace_bytes);
     float* slabs = cv.take<float>((size_t)q.Z * q.Mpw * q.Jp);
     float* bsum = cv.take<float>((size_t)Cout * B);
-    float* wt = cv.take<float>((size_t)q.T * C * Cout);
+    float* wt = cv.take<float>((size_t)(q.T + 1) * C * (Cout < 64 ? 64 : Cout));   // (or dcnb_kernel's [64][10 C] pack)
     float* dcol = cv.take<float>((size_t)B * q.T * C * HoWo);
     DcnGeo* geo = cv.take<DcnGeo>((size_t)B * q.T * HoWo);
     void* gemm_ws = cv.take<char>(q.gemm_bytes);
@@ -1770,6 +2011,46 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
       }
         if (int rc = check_launch("cnuda_dcn_v2_backward(weight)")) return rc;
         launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, wst);
+    }
+    // the on-chip form (dcnb_kernel): the layers dcnw_fwd_kernel takes.  CNUDA_DCNB=0: the three-kernel form below
+    static const int dcnb_mode = getenv("CNUDA_DCNB") ? atoi(getenv("CNUDA_DCNB")) : 0;
+    if (dcnb_mode && matrix_mode() == 0 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 &&
+        dw == 1 && C % 16 == 0 && Cout <= 64 && (W == 16 || W == 32 || W == 64 || W == 128) &&
+        H % (IG_BN / (W >= 32 ? 32 : W)) == 0 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB) {
+        const int Mp = 10 * C;
+        const float* Ad = launch_pack(weight, wt, (size_t)64 * Mp * sizeof(float), Cout, C, q.T, PACK_DCN_DCOL, 64, Mp, 0, st);
+        {
+            DcnPrepParams pp{g, weight, offset, mask, wt, geo, 0};
+            CNUDA_LAUNCH(dcn_prep_kernel, dim3(stream_grid((long long)B * q.T * HoWo, 256)), dim3(256), 0, st, pp);
+        }
+        const int tc = W >= 32 ? 32 : W, tiles_x = W / tc, n_tiles = (int)(q.N / IG_BN);
+        DcnBwdWinParams p{g, input, offset, mask, grad_output, grad_offset, grad_mask, dcol};
+        {
+            ProfScope scope(st, 3);
+            scope.name("dcnb_kernel<%d, false>", tc);
+#define CNUDA_DCNB_LAUNCH(TCV, SC)                                                                                     \
+    do {                                                                                                               \
+        const size_t lds = (size_t)16 * DwTile<TCV>::PL * sizeof(float);                                               \
+        static bool raised = false;                                                                                    \
+        if (lds > 64 * 1024 && !raised) {                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnb_kernel<TCV, SC>),                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+            raised = true;                                                                                             \
+        }                                                                                                              \
+        CNUDA_LAUNCH((dcnb_kernel<TCV, SC>), dim3(n_tiles), dim3(IG_THREADS), lds, st, p, Ad, Mp, n_tiles, tiles_x);   \
+    } while (0)
+            if (tc == 32) CNUDA_DCNB_LAUNCH(32, false); else CNUDA_DCNB_LAUNCH(16, false);
+#undef CNUDA_DCNB_LAUNCH
+        }
+        {
+            DcnCol2imParams pc{g, dcol, geo, grad_input, q.TR, q.TC, q.tc_shift, q.tiles_y, q.tiles_x, q.ncg, q.WSZmax,
+                               q.claim_sz};
+            const int n_wg = B * q.tiles_y * q.tiles_x * q.ncg;
+            ProfScope scope(st, 2);
+            scope.name("dcn_col2im_kernel");
+            CNUDA_LAUNCH(dcn_col2im_kernel, dim3(n_wg), dim3(256), q.col2im_lds, st, pc, n_wg);
+        }
+        return check_launch("cnuda_dcn_v2_backward(window)");
     }
     {
         // (1) dcol = W^T x grad_output as a 1x1 implicit GEMM, then the two streaming consumers

@@ -16,6 +16,9 @@ enum PackMode {
     PACK_HALO_FWD = 3,    // dst[k = (g*9 + tap)*16 + ci][m = o] = W[o][16g + ci][tap]                     (C % 16 == 0)
     PACK_HALO_DGRAD = 4,  // dst[k = (g*9 + tap)*16 + oi][m = c] = W[16g + oi][c][8 - tap]: the input gradient of a
                           // 3x3 / stride 1 / padding 1 convolution is that convolution over grad_y with flipped taps (Co % 16 == 0)
+    // DCN column gradient on-chip (dcn.hip dcnb_kernel): dst[k = o][m = (g*10 + tap)*16 + ci] = W[o][16g + ci][tap] for
+    // tap < 9, zero for the tenth slot of a group (taps come in pairs: 32 GEMM rows = 2 taps x 16 channels); Mp = 10 C / 16 * 16
+    PACK_DCN_DCOL = 5,
 };
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }

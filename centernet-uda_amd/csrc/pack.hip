@@ -25,6 +25,8 @@ __global__ void pack_kernel(const float* __restrict__ W, float* __restrict__ dst
             if (k < T * C && m < Co) { const int g = k / (16 * T), r = k - g * 16 * T; tap = r >> 4; c = 16 * g + (r & 15); o = m; }
         } else if (mode == PACK_HALO_DGRAD) {
             if (k < T * Co && m < C) { const int g = k / (16 * T), r = k - g * 16 * T; tap = T - 1 - (r >> 4); o = 16 * g + (r & 15); c = m; }
+        } else if (mode == PACK_DCN_DCOL) {
+            if (k < Co && m < (T + 1) * C) { const int g = m / (16 * (T + 1)), r = m - g * 16 * (T + 1); tap = r >> 4; c = 16 * g + (r & 15); o = tap < T ? k : -1; }
         } else {   // PACK_DGRAD: Cpad = Co rounded up to the K chunk, rows o >= Co stay zero
             if (k < T * Cpad && m < C) { tap = k / Cpad; o = k % Cpad; c = m; if (o >= Co) o = -1; }
         }
@@ -338,6 +340,11 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
             if (k < j.T * j.Co && m < j.C) {
                 const int g = k / (16 * j.T), r = k - g * 16 * j.T;
                 v = j.src[((size_t)(16 * g + (r & 15)) * j.C + m) * j.T + (j.T - 1 - (r >> 4))];
+            }
+        } else if (j.mode == PACK_DCN_DCOL) {
+            if (k < j.Co && m < (j.T + 1) * j.C) {
+                const int g = m / (16 * (j.T + 1)), r = m - g * 16 * (j.T + 1);
+                if ((r >> 4) < j.T) v = j.src[((size_t)k * j.C + 16 * g + (r & 15)) * j.T + (r >> 4)];
             }
         } else if (j.mode == PACK_DGRAD) {
             if (k < j.T * j.cpad && m < j.C) {
