@@ -634,17 +634,23 @@ struct DcnBwdWinParams {
     const float *in, *off, *mask, *gout;
     float *goff, *gmask;
     float* dcol;                  // [B][9 * C][HW], plain column gradient (SCATTER == false)
+    float* gin;                   // grad_input, zeroed by the caller (SCATTER == true)
 };
+// LDS float add without a return value (ds_add_f32): collisions between lanes are the hardware's business
+__device__ __forceinline__ void lds_add(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 template <int TC, bool SCATTER>
 __global__ __launch_bounds__(IG_THREADS, 2) void dcnb_kernel(DcnBwdWinParams p, const float* __restrict__ A, int Mp, int n_tiles,
                                                              int tiles_x) {
     using Q = DwTile<TC>;
     constexpr int PL = Q::PL, RS = Q::RS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // Win[16 * PL]
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // Win[16 * PL] | Gwin[16 * PL] (SCATTER)
     const DcnGeom& g = p.g;
     const int W = g.W, H = g.H, HW = g.H * g.W;
     float* const Win = smem;
+    float* const Gwin = smem + 16 * PL;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     int tile = xcd_remap(blockIdx.x, n_tiles);
     const int tx = tile % tiles_x; tile /= tiles_x;
@@ -676,17 +682,22 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnb_kernel(DcnBwdWinParams p, 
 #pragma unroll
         for (int s = 0; s < 32; ++s) gf[s] = 2 * s + kl < g.Co ? go[(size_t)(2 * s + kl) * HW] : 0.0f;
     }
-    // per-tap sampling state (as dcnw_fwd_kernel) and the four running sums of every tap
+    // per-tap sampling state (as dcnw_fwd_kernel) and the four running sums of every tap; the scattering build also
+    // keeps the fractions and the mask (the weights of the four corner adds)
+    constexpr int NG = SCATTER ? 9 : 1;
     int addr[9];
     float u00[9], u01[9], u10[9], u11[9];
+    float flh[NG], flw[NG], fmk[NG];
     unsigned stray = 0, inwin_bits = 0;
     {
         const float* off_b = p.off + (size_t)b * 18 * HW + pp;
+        const float* mask_b = p.mask + (size_t)b * 9 * HW + pp;
         float dy[9], dx[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             dy[t] = off_b[(size_t)(2 * t) * HW];
             dx[t] = off_b[(size_t)(2 * t + 1) * HW];
+            if (SCATTER) fmk[t % NG] = mask_b[(size_t)t * HW];
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -697,6 +708,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnb_kernel(DcnBwdWinParams p, 
             const int wr = h0 - yw0, wc = w0i - x0 + 4;
             const bool inwin = valid && wr >= 0 && wr + 1 <= Q::NR - 1 && wc >= 0 && wc + 1 <= RS - 1;
             addr[t] = inwin ? wr * RS + wc : 0;
+            if (SCATTER) { flh[t % NG] = h - hf; flw[t % NG] = w - wf; }
             if (inwin) inwin_bits |= 1u << t;
             if (valid && !inwin) stray |= 1u << t;
             u00[t] = u01[t] = u10[t] = u11[t] = 0.0f;
@@ -722,8 +734,28 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnb_kernel(DcnBwdWinParams p, 
             if (loff >= 0) *reinterpret_cast<f32x4*>(Win + loff) = hreg[i];
         }
     };
+    // the grad_input window of one channel group: every in-image cell the group's samples touched goes out with one
+    // atomic (neighbouring tiles share their halo cells), and the window is zero again afterwards
+    auto gwin_flush = [&](int grp) {
+        static_assert(16 * PL % IG_THREADS == 0, "window cells per thread");
+        float* gin_g = p.gin + ((size_t)b * g.C + grp * 16) * HW;
+#pragma unroll 2
+        for (int i = 0; i < 16 * PL / IG_THREADS; ++i) {
+            const int e = tid + i * IG_THREADS;
+            const float v = Gwin[e];
+            const int c = e / PL, rem = e - c * PL;
+            const int row = rem / RS, col = rem - row * RS;
+            const int iy = yw0 + row, ix = x0 - 4 + col;
+            if (v != 0.0f) {
+                Gwin[e] = 0.0f;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) atomicAdd(gin_g + (size_t)c * HW + iy * W + ix, v);
+            }
+        }
+    };
     const int G = g.C >> 4;
     win_load(0);
+    if (SCATTER)
+        for (int e = tid; e < 4 * PL; e += IG_THREADS) reinterpret_cast<f32x4*>(Gwin)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
     win_store();
     __syncthreads();
     for (int grp = 0; grp < G; ++grp) {
@@ -748,7 +780,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnb_kernel(DcnBwdWinParams p, 
                     for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], gf[s0 + s], acc, 0, 0, 0);
                 }
             }
-            // --- gather role for the two taps: this lane's eight channels of each, corners from the input window
+            // --- gather (and scatter) role for the two taps: this lane's eight channels of each
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int t = 2 * pr + tt;
@@ -757,6 +789,11 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnb_kernel(DcnBwdWinParams p, 
                 asm volatile("" : "+v"(a_t));
                 const float* wb = Win + a_t;
                 const float live = ((inwin_bits >> t) & 1u) ? 1.0f : 0.0f;
+                float k00 = 0.f, k01 = 0.f, k10 = 0.f, k11 = 0.f;
+                if (SCATTER) {
+                    const float lh = flh[t % NG], lw = flw[t % NG], hh = 1.0f - lh, hw = 1.0f - lw, mk = fmk[t % NG] * live;
+                    k00 = hh * hw * mk; k01 = hh * lw * mk; k10 = lh * hw * mk; k11 = lh * lw * mk;
+                }
 #pragma unroll
                 for (int jh = 0; jh < 8; jh += 4) {                    // four channels' corners in registers at a time
                     __builtin_amdgcn_sched_barrier(0);
@@ -769,6 +806,14 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnb_kernel(DcnBwdWinParams p, 
                         u01[t] = fmaf(d, q[1], u01[t]);
                         u10[t] = fmaf(d, q[RS], u10[t]);
                         u11[t] = fmaf(d, q[RS + 1], u11[t]);
+                        if (SCATTER) {
+                            float* r = Gwin + a_t + c * PL;
+                            const float dd = acc[8 * tt + j];
+                            lds_add(r, dd * k00);
+                            lds_add(r + 1, dd * k01);
+                            lds_add(r + RS, dd * k10);
+                            lds_add(r + RS + 1, dd * k11);
+                        }
                     }
                     // (the sums are only read at the end of the tile: without an anchor the compiler sinks the whole FMA
                     // chain below the loop body and keeps every corner it read alive -- in scratch -- until then)
@@ -788,43 +833,70 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnb_kernel(DcnBwdWinParams p, 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) {
-            __syncthreads();                                           // every wave has read this group's window
-            win_store();
+        if (more || SCATTER) {
+            __syncthreads();                                           // every wave has read (and added into) this group's windows
+            if (SCATTER) gwin_flush(grp);
+            if (more) win_store();
             __syncthreads();
         }
     }
-    // --- strays (rare): a (pixel, tap) whose corners left the window.  The lane with kl == 0 redoes the tap's sums
-    // from global memory, channel by channel: dcol_c as a plain dot product over the output channels
+    // --- strays (rare): a (pixel, tap) whose corners left the window.  For every tap some lane of the wave strayed on,
+    // the wave computes the tap's tile of dcol once more per channel group; the lanes concerned read their corners
+    // from global memory (clamped rows / columns, zero weights outside the image) and, in the scattering build, add
+    // into grad_input with global atomics.
     if (any_stray) {
 #pragma unroll 1
         for (int t0 = 0; t0 < 9; ++t0) {
             int t = t0;
             asm volatile("" : "+s"(t));
-            if (!__any((stray >> t) & 1u)) continue;
+            const bool mine = (stray >> t) & 1u;
+            if (!__any(mine)) continue;
             float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
-            if (((stray >> t) & 1u) && kl == 0) {
-                const float* off_b = p.off + (size_t)b * 18 * HW + pp;
-                const int tr = t / 3;
-                const float sh_ = (float)(py - 1 + tr) + off_b[(size_t)(2 * t) * HW];
-                const float sw_ = (float)(px - 1 + t - 3 * tr) + off_b[(size_t)(2 * t + 1) * HW];
-                const float shf = floorf(sh_), swf = floorf(sw_);
-                const int sh0 = (int)shf, sw0 = (int)swf;
-                const bool top = sh0 >= 0, bot = sh0 + 1 <= H - 1, lef = sw0 >= 0, rig = sw0 + 1 <= W - 1;
-                const float f00 = (top && lef) ? 1.f : 0.f, f01 = (top && rig) ? 1.f : 0.f, f10 = (bot && lef) ? 1.f : 0.f,
-                            f11 = (bot && rig) ? 1.f : 0.f;
-                const int cy0 = top ? sh0 : 0, cy1 = bot ? sh0 + 1 : H - 1, cx0 = lef ? sw0 : 0, cx1 = rig ? sw0 + 1 : W - 1;
-                const int o00 = cy0 * W + cx0, o01 = cy0 * W + cx1, o10 = cy1 * W + cx0, o11 = cy1 * W + cx1;
-                const float* go = p.gout + (size_t)b * g.Co * HW + pp;
-                for (int c = 0; c < g.C; ++c) {
-                    const float* wrow = A + ((c >> 4) * 10 + t) * 16 + (c & 15);          // A[o][m(c, t)]
-                    float d = 0.0f;
-                    for (int o = 0; o < g.Co; ++o) d = fmaf(wrow[(size_t)o * Mp], go[(size_t)o * HW], d);
-                    const float* pl = p.in + ((size_t)b * g.C + c) * HW;
-                    s00 = fmaf(d, pl[o00] * f00, s00);
-                    s01 = fmaf(d, pl[o01] * f01, s01);
-                    s10 = fmaf(d, pl[o10] * f10, s10);
-                    s11 = fmaf(d, pl[o11] * f11, s11);
+            const int tr = t / 3;
+            const float* off_b = p.off + (size_t)b * 18 * HW + pp;
+            const float sh_ = (float)(py - 1 + tr) + off_b[(size_t)(2 * t) * HW];
+            const float sw_ = (float)(px - 1 + t - 3 * tr) + off_b[(size_t)(2 * t + 1) * HW];
+            const float shf = floorf(sh_), swf = floorf(sw_);
+            const int sh0 = mine ? (int)shf : 0, sw0 = mine ? (int)swf : 0;
+            const bool top = sh0 >= 0, bot = sh0 + 1 <= H - 1, lef = sw0 >= 0, rig = sw0 + 1 <= W - 1;
+            const float f00 = (mine && top && lef) ? 1.f : 0.f, f01 = (mine && top && rig) ? 1.f : 0.f,
+                        f10 = (mine && bot && lef) ? 1.f : 0.f, f11 = (mine && bot && rig) ? 1.f : 0.f;
+            const int cy0 = top ? sh0 : 0, cy1 = bot ? sh0 + 1 : H - 1, cx0 = lef ? sw0 : 0, cx1 = rig ? sw0 + 1 : W - 1;
+            const int o00 = cy0 * W + cx0, o01 = cy0 * W + cx1, o10 = cy1 * W + cx0, o11 = cy1 * W + cx1;
+            const float slh = sh_ - shf, slw = sw_ - swf, shh = 1.0f - slh, shw = 1.0f - slw;
+            const float smk = p.mask[((size_t)b * 9 + t) * HW + pp];
+            const float a00 = shh * shw * smk * f00, a01 = shh * slw * smk * f01, a10 = slh * shw * smk * f10, a11 = slh * slw * smk * f11;
+            const int pr = t >> 1;
+            const bool second = t & 1;
+#pragma unroll 1
+            for (int grp = 0; grp < G; ++grp) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                const unsigned mvoff = (unsigned)((kl * Mp + (lane & 31)) * (int)sizeof(float));
+                const unsigned gbase = (unsigned)((grp * 10 + 2 * pr) * 16) * (unsigned)sizeof(float);
+#pragma unroll
+                for (int s = 0; s < 32; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ig_buf_load(ra, mvoff, gbase + (unsigned)(2 * s * Mp) * (unsigned)sizeof(float)),
+                                                               gf[s], acc, 0, 0, 0);
+                if (mine) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float d = second ? acc[8 + j] : acc[j];
+                        const int c = grp * 16 + 4 * kl + (j & 3) + 8 * (j >> 2);
+                        const float* pl = p.in + ((size_t)b * g.C + c) * HW;
+                        s00 = fmaf(d, pl[o00] * f00, s00);
+                        s01 = fmaf(d, pl[o01] * f01, s01);
+                        s10 = fmaf(d, pl[o10] * f10, s10);
+                        s11 = fmaf(d, pl[o11] * f11, s11);
+                        if (SCATTER) {
+                            float* gp = p.gin + ((size_t)b * g.C + c) * HW;
+                            if (a00 != 0.0f) atomicAdd(gp + o00, d * a00);
+                            if (a01 != 0.0f) atomicAdd(gp + o01, d * a01);
+                            if (a10 != 0.0f) atomicAdd(gp + o10, d * a10);
+                            if (a11 != 0.0f) atomicAdd(gp + o11, d * a11);
+                        }
+                    }
                 }
             }
             // into the tap's sums (static register arrays: select the tap)
@@ -851,6 +923,311 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnb_kernel(DcnBwdWinParams p, 
             p.goff[((size_t)b * 18 + 2 * t) * HW + pp] = sh_;
             p.goff[((size_t)b * 18 + 2 * t + 1) * HW + pp] = sw_;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward data path on CHANNEL-QUAD PLANES (round 4): the column gradient never leaves the chip and every gradient
+// of the data path (grad_input, grad_offset, grad_mask) comes out of ONE kernel.
+//
+// What the two earlier forms could not combine: the scatter into grad_input wants every wave to own its channel
+// planes of the LDS window (plain read-add-write, no atomics -- profiles/microbench/lds_atomic_bench.hip: a
+// ds_add_f32 costs 193 cycles per wave instruction on gfx950, a b128 read + write pair 22), while an MFMA tile with
+// pixels on lanes gives every wave ALL channels of ITS pixels.  Here the GEMM is laid out the other way round:
+//   * workgroup = 64 pixels (TR x TC) x one 16-channel group at a time, wave w = channel quad w of the group;
+//   * per (16-pixel column tile, row tile of 3 taps) the wave issues 16 v_mfma_f32_16x16x4_f32 -- rows (tap slot,
+//     channel of the quad), columns pixels, k = the <= 64 output channels -- whose accumulator layout hands lane
+//     (pixel, tap slot) the four channels of its quad: one (pixel, tap) record of dcol, in registers, as the
+//     16-byte quad the window planes are made of;
+//   * gather role: four ds_read_b128 (the corners, [cell][4 channels] planes of the input window) and 16 FMAs into
+//     the four running sums of the (pixel, tap); scatter role: four b128 read-add-write into the wave's own
+//     grad_input planes, lanes that share an anchor cell taking turns through a claim map;
+//   * both windows, the flush of grad_input (one atomic per touched in-image cell and channel) and the staging of
+//     the next group's input window are wave-private: the four waves never synchronise between tile setup and the
+//     final reduction of the running sums.
+// The taps of a row tile are {rt, rt + 3, rt + 6} (one kernel column): lanes of one instruction then differ in pixel
+// column or kernel row, so undeformed samples never share an anchor.  The fourth tap slot is padding (zero rows of
+// the packed weights: 25% of the MFMA work).
+// ---------------------------------------------------------------------------
+template <int TC> struct DqTile {
+    static constexpr int NPX = 64, TR = NPX / TC, NR = TR + 2 + 2 * DW_MARGIN, RS = TC + 8, CELLS = NR * RS;
+    static constexpr int CPR = RS / 4, ITEMS = NR * CPR, NIT = (ITEMS + 63) / 64;   // staging: (row, 4 columns) per lane
+    static constexpr int SHIFT = TC == 32 ? 5 : 4;
+    static constexpr int CLAIM = (CELLS + 15) / 16 * 16;                            // bytes per wave
+    // LDS, in floats: input window | grad_input window | geometry records | grad_output tile | claim maps | stray list
+    static constexpr int WIN = 0, GWIN = 16 * CELLS, GEO = 32 * CELLS, GO = GEO + 9 * NPX * 4, CLM = GO + 64 * NPX;
+    static constexpr int STRAY = CLM + CLAIM, END = STRAY + 4 + 9 * NPX / 2;
+    static_assert(4 * 9 * NPX * 4 <= 32 * CELLS, "the running sums of the four waves reuse the windows");
+};
+struct DcnBwdQuadParams {
+    DcnGeom g;
+    const float *in, *w, *off, *mask, *gout;
+    float *gin, *goff, *gmask;
+};
+
+template <int TC>
+__global__ __launch_bounds__(IG_THREADS, 2) void dcnq_kernel(DcnBwdQuadParams p, const float* __restrict__ A, int n_tiles,
+                                                             int tiles_x) {
+    using Q = DqTile<TC>;
+    constexpr int RS = Q::RS, CELLS = Q::CELLS, NPX = Q::NPX;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DcnGeom& g = p.g;
+    const int W = g.W, H = g.H, HW = g.H * g.W, C = g.C;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = xcd_remap(blockIdx.x, n_tiles);
+    const int tx = tile % tiles_x; tile /= tiles_x;
+    const int tiles_y = H / Q::TR;
+    const int ty = tile % tiles_y, b = tile / tiles_y;
+    const int y0 = ty * Q::TR, x0 = tx * TC, yw0 = y0 - 1 - DW_MARGIN, xw0 = x0 - 4;
+    f32x4* const Wq = reinterpret_cast<f32x4*>(smem + Q::WIN) + wid * CELLS;     // [cell][4 channels] of this wave's quad
+    f32x4* const Gq = reinterpret_cast<f32x4*>(smem + Q::GWIN) + wid * CELLS;
+    f32x4* const Geo = reinterpret_cast<f32x4*>(smem + Q::GEO);                  // [tap][pixel]: window cell (int bits; -1: none), lh, lw, mask
+    float* const Go = smem + Q::GO;                                              // [o / 4][pixel][o % 4]
+    volatile unsigned char* const claim = reinterpret_cast<unsigned char*>(smem + Q::CLM) + wid * Q::CLAIM;
+    int* const nstray = reinterpret_cast<int*>(smem + Q::STRAY);
+    unsigned short* const strays = reinterpret_cast<unsigned short*>(smem + Q::STRAY + 4);
+    auto pixel = [&](int px) { return (y0 + (px >> Q::SHIFT)) * W + x0 + (px & (TC - 1)); };
+
+    // ---- tile setup (all four waves) ----
+    if (tid == 0) *nstray = 0;
+    __syncthreads();
+    for (int e = tid; e < 9 * NPX; e += IG_THREADS) {
+        const int t = e >> 6, px = e & 63, py = y0 + (px >> Q::SHIFT), pxx = x0 + (px & (TC - 1)), pp = py * W + pxx;
+        const float dy = p.off[((size_t)b * 18 + 2 * t) * HW + pp], dx = p.off[((size_t)b * 18 + 2 * t + 1) * HW + pp];
+        const float h = (float)(py - 1 + t / 3) + dy, w = (float)(pxx - 1 + t % 3) + dx;
+        const float hf = floorf(h), wf = floorf(w);
+        const bool valid = h > -1.0f && w > -1.0f && h < (float)H && w < (float)W;
+        const int h0 = valid ? (int)hf : 0, w0 = valid ? (int)wf : 0;
+        const int wr = h0 - yw0, wc = w0 - xw0;
+        const bool inwin = valid && wr >= 0 && wr + 1 <= Q::NR - 1 && wc >= 0 && wc + 1 <= RS - 1;
+        if (valid && !inwin) strays[atomicAdd(nstray, 1)] = (unsigned short)e;
+        f32x4 rec;
+        rec.x = __int_as_float(inwin ? wr * RS + wc : -1);
+        rec.y = h - hf; rec.z = w - wf; rec.w = p.mask[((size_t)b * 9 + t) * HW + pp];
+        Geo[e] = rec;
+    }
+    for (int e = tid; e < 64 * NPX; e += IG_THREADS) {
+        const int o = e >> 6, px = e & 63;
+        Go[(o >> 2) * (4 * NPX) + px * 4 + (o & 3)] = o < g.Co ? p.gout[((size_t)b * g.Co + o) * HW + pixel(px)] : 0.0f;
+    }
+    for (int i = lane; i < CELLS; i += 64) Gq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- the input window of this wave's quad: four planes loaded as rows of float4, stored transposed ----
+    const buf_rsrc rs = ig_make_rsrc(p.in, (unsigned)((size_t)g.B * C * HW * sizeof(float)));
+    const buf_rsrc ra = ig_make_rsrc(A, (unsigned)((size_t)12 * C * 64 * sizeof(float)));
+    f32x4 hreg[Q::NIT][4];
+    auto stage_item = [&](int i, unsigned& voff, int& cell) {
+        int salt = 0;
+        asm volatile("" : "+v"(salt));                                 // (the addresses are recomputed where they are used)
+        const int it = lane + 64 * i + salt;
+        const int row = it / Q::CPR, q4 = it - row * Q::CPR;
+        const int iy = yw0 + row, ix = xw0 + 4 * q4;
+        cell = it < Q::ITEMS ? row * RS + 4 * q4 : -1;
+        voff = (it < Q::ITEMS && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                   ? (unsigned)(((b * C + 4 * wid) * HW + iy * W + ix) * (int)sizeof(float)) : IG_BUF_OOB;
+    };
+    auto win_load = [&](int grp) {
+#pragma unroll
+        for (int i = 0; i < Q::NIT; ++i) {
+            unsigned voff; int cell;
+            stage_item(i, voff, cell);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hreg[i][r] = ig_buf_load4(rs, voff, (unsigned)((grp * 16 + r) * HW) * (unsigned)sizeof(float));
+        }
+    };
+    auto win_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < Q::NIT; ++i) {
+            unsigned voff; int cell;
+            stage_item(i, voff, cell);
+            if (cell >= 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Wq[cell + k] = f32x4{hreg[i][0][k], hreg[i][1][k], hreg[i][2][k], hreg[i][3][k]};
+            }
+        }
+    };
+    win_load(0);
+    win_store();
+    __syncthreads();
+
+    // ---- channel groups ----
+    const int pxl = lane & 15, slot = lane >> 4;
+    float u[4][3][4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[ct][rt][k] = 0.0f;
+    const int G = C >> 4;
+    for (int grp = 0; grp < G; ++grp) {
+        const bool more = grp + 1 < G;
+        if (more) win_load(grp + 1);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            int pbase = (ct * 16 + pxl) * 4 + slot;
+            asm volatile("" : "+v"(pbase));                            // (the tile does not change with the group: keep the reads here)
+            float bf[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) bf[s] = Go[s * (4 * NPX) + pbase];
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) {
+                // --- the (pixel, tap) records of dcol: 16 k-steps over the output channels
+                const unsigned abase = (unsigned)((((grp * 4 + wid) * 3 + rt) * 16) * 64) * (unsigned)sizeof(float);
+                float af[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) af[s] = ig_buf_load(ra, (unsigned)lane * 4u, abase + (unsigned)(s * 64 * 4));
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], acc, 0, 0, 0);
+                // --- this lane's (pixel, tap): geometry record, corners of the input window, claim on the anchor cell
+                int gi = (slot < 3 ? rt + 3 * slot : rt) * NPX + ct * 16 + pxl;
+                asm volatile("" : "+v"(gi));
+                const f32x4 rec = Geo[gi];
+                const int addr = __float_as_int(rec.x);
+                const bool live = slot < 3 && addr >= 0;
+                const int a = live ? addr : 0;
+                const f32x4 v00 = Wq[a], v01 = Wq[a + 1], v10 = Wq[a + RS], v11 = Wq[a + RS + 1];
+                f32x4 d;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = live ? acc[k] : 0.0f;
+                u[ct][rt][0] += (d[0] * v00[0] + d[1] * v00[1]) + (d[2] * v00[2] + d[3] * v00[3]);
+                u[ct][rt][1] += (d[0] * v01[0] + d[1] * v01[1]) + (d[2] * v01[2] + d[3] * v01[3]);
+                u[ct][rt][2] += (d[0] * v10[0] + d[1] * v10[1]) + (d[2] * v10[2] + d[3] * v10[3]);
+                u[ct][rt][3] += (d[0] * v11[0] + d[1] * v11[1]) + (d[2] * v11[2] + d[3] * v11[3]);
+                asm volatile("" : "+v"(u[ct][rt][0]), "+v"(u[ct][rt][1]), "+v"(u[ct][rt][2]), "+v"(u[ct][rt][3]));   // (see dcnb_kernel)
+                // --- scatter: grad_input window planes of this wave, one corner at a time (neighbouring lanes' footprints
+                // overlap: a corner is one wave-wide read and one wave-wide write, LDS executes them in order)
+                const float lh = rec.y, lw = rec.z, hh = 1.0f - lh, hw = 1.0f - lw, mk = rec.w;
+                const float k00 = hh * hw * mk, k01 = hh * lw * mk, k10 = lh * hw * mk, k11 = lh * lw * mk;
+                bool pending = live;
+#pragma unroll 1
+                for (int round = 0; round < 3 && __any(pending); ++round) {
+                    bool won = false;
+                    if (pending) {
+                        claim[a] = (unsigned char)lane;
+                        won = claim[a] == (unsigned char)lane;          // same wave: LDS executes in order
+                    }
+                    asm volatile("" ::: "memory");
+                    if (won) {
+                        f32x4 c0 = Gq[a];
+                        c0 += k00 * d;
+                        Gq[a] = c0;
+                        asm volatile("" ::: "memory");
+                        f32x4 c1 = Gq[a + 1];
+                        c1 += k01 * d;
+                        Gq[a + 1] = c1;
+                        asm volatile("" ::: "memory");
+                        f32x4 c2 = Gq[a + RS];
+                        c2 += k10 * d;
+                        Gq[a + RS] = c2;
+                        asm volatile("" ::: "memory");
+                        f32x4 c3 = Gq[a + RS + 1];
+                        c3 += k11 * d;
+                        Gq[a + RS + 1] = c3;
+                    }
+                    asm volatile("" ::: "memory");
+                    pending = pending && !won;
+                }
+                if (__any(pending)) {                                  // more than three lanes on one anchor: global atomics
+                    if (pending) {
+                        const int wr = a / RS, wc = a - wr * RS, iy = yw0 + wr, ix = xw0 + wc;
+                        const bool top = iy >= 0, bot = iy + 1 <= H - 1, lef = ix >= 0, rig = ix + 1 <= W - 1;
+                        float* gp = p.gin + ((size_t)b * C + grp * 16 + 4 * wid) * HW + iy * W + ix;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (top && lef) atomicAdd(gp + (size_t)k * HW, k00 * d[k]);
+                            if (top && rig) atomicAdd(gp + (size_t)k * HW + 1, k01 * d[k]);
+                            if (bot && lef) atomicAdd(gp + (size_t)k * HW + W, k10 * d[k]);
+                            if (bot && rig) atomicAdd(gp + (size_t)k * HW + W + 1, k11 * d[k]);
+                        }
+                    }
+                }
+            }
+        }
+        // --- flush this group's grad_input planes (touched in-image cells: one atomic per cell and channel), next window
+        asm volatile("" ::: "memory");
+        for (int i = lane; i < CELLS; i += 64) {
+            const f32x4 v = Gq[i];
+            if (v[0] != 0.0f || v[1] != 0.0f || v[2] != 0.0f || v[3] != 0.0f) {
+                Gq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int row = i / RS, col = i - row * RS, iy = yw0 + row, ix = xw0 + col;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    float* gp = p.gin + ((size_t)b * C + grp * 16 + 4 * wid) * HW + iy * W + ix;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (v[k] != 0.0f) atomicAdd(gp + (size_t)k * HW, v[k]);
+                }
+            }
+        }
+        if (more) win_store();
+    }
+
+    // ---- the running sums: per wave into LDS (the windows are done), strays, then one sum over the waves per (pixel, tap) ----
+    __syncthreads();
+    f32x4* const U = reinterpret_cast<f32x4*>(smem) + wid * (9 * NPX);
+    if (slot < 3) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+                U[(rt + 3 * slot) * NPX + ct * 16 + pxl] = f32x4{u[ct][rt][0], u[ct][rt][1], u[ct][rt][2], u[ct][rt][3]};
+    }
+    // strays (rare): a (pixel, tap) whose corners left the window.  Every wave redoes the tap for ITS channels of all
+    // groups, a channel per lane: dcol as a dot product over the output channels, corners from global memory
+    // (clamped, zero weight outside the image), grad_input through global atomics.
+    const int ns = *nstray;
+    for (int k = 0; k < ns; ++k) {
+        const int e = strays[k], t = e >> 6, px = e & 63;
+        const int py = y0 + (px >> Q::SHIFT), pxx = x0 + (px & (TC - 1)), pp = py * W + pxx;
+        const f32x4 rec = Geo[e];
+        const float h = (float)(py - 1 + t / 3) + p.off[((size_t)b * 18 + 2 * t) * HW + pp];
+        const float w = (float)(pxx - 1 + t % 3) + p.off[((size_t)b * 18 + 2 * t + 1) * HW + pp];
+        const int h0 = (int)floorf(h), w0 = (int)floorf(w);
+        const bool top = h0 >= 0, bot = h0 + 1 <= H - 1, lef = w0 >= 0, rig = w0 + 1 <= W - 1;
+        const float f00 = (top && lef) ? 1.f : 0.f, f01 = (top && rig) ? 1.f : 0.f, f10 = (bot && lef) ? 1.f : 0.f,
+                    f11 = (bot && rig) ? 1.f : 0.f;
+        const int cy0 = top ? h0 : 0, cy1 = bot ? h0 + 1 : H - 1, cx0 = lef ? w0 : 0, cx1 = rig ? w0 + 1 : W - 1;
+        const int o00 = cy0 * W + cx0, o01 = cy0 * W + cx1, o10 = cy1 * W + cx0, o11 = cy1 * W + cx1;
+        const float lh = rec.y, lw = rec.z, hh = 1.0f - lh, hw = 1.0f - lw, mk = rec.w;
+        float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
+        for (int cb = 0; cb < 4 * G; cb += 64) {
+            const int ci = cb + lane;                                  // (group, channel of the quad)
+            if (ci < 4 * G) {
+                const int c = (ci >> 2) * 16 + 4 * wid + (ci & 3);
+                float d = 0.0f;
+                for (int o = 0; o < g.Co; ++o)
+                    d = fmaf(p.w[((size_t)o * C + c) * 9 + t], Go[(o >> 2) * (4 * NPX) + px * 4 + (o & 3)], d);
+                const float* pl = p.in + ((size_t)b * C + c) * HW;
+                s00 = fmaf(d, pl[o00] * f00, s00);
+                s01 = fmaf(d, pl[o01] * f01, s01);
+                s10 = fmaf(d, pl[o10] * f10, s10);
+                s11 = fmaf(d, pl[o11] * f11, s11);
+                float* gp = p.gin + ((size_t)b * C + c) * HW;
+                const float dm = d * mk;
+                if (f00 != 0.0f) atomicAdd(gp + o00, hh * hw * dm);
+                if (f01 != 0.0f) atomicAdd(gp + o01, hh * lw * dm);
+                if (f10 != 0.0f) atomicAdd(gp + o10, lh * hw * dm);
+                if (f11 != 0.0f) atomicAdd(gp + o11, lh * lw * dm);
+            }
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            s00 += __shfl_xor(s00, sft, 64); s01 += __shfl_xor(s01, sft, 64);
+            s10 += __shfl_xor(s10, sft, 64); s11 += __shfl_xor(s11, sft, 64);
+        }
+        if (lane == 0) U[e] = f32x4{s00, s01, s10, s11};               // (the window part of a stray is zero)
+    }
+    __syncthreads();
+    const f32x4* const U0 = reinterpret_cast<const f32x4*>(smem);
+    for (int e = tid; e < 9 * NPX; e += IG_THREADS) {
+        const int t = e >> 6, px = e & 63, pp = pixel(px);
+        const f32x4 rec = Geo[e];
+        const f32x4 a = ((U0[e] + U0[9 * NPX + e]) + U0[2 * 9 * NPX + e]) + U0[3 * 9 * NPX + e];
+        const float lh = rec.y, lw = rec.z, hh = 1.0f - lh, hw = 1.0f - lw, mk = rec.w;
+        p.gmask[((size_t)b * 9 + t) * HW + pp] = hh * hw * a[0] + hh * lw * a[1] + lh * hw * a[2] + lh * lw * a[3];
+        p.goff[((size_t)b * 18 + 2 * t) * HW + pp] = (-hw * a[0] - lw * a[1] + hw * a[2] + lw * a[3]) * mk;
+        p.goff[((size_t)b * 18 + 2 * t + 1) * HW + pp] = (-hh * a[0] + hh * a[1] - lh * a[2] + lh * a[3]) * mk;
     }
 }
 
@@ -1748,7 +2125,7 @@ DcnPlan make_plan(const DcnGeom& g) {
     }
     q.gemm_bytes = cnuda_conv2d_workspace_bytes(g.B, g.Co, g.Ho, g.Wo, q.T * g.C, 1, 1, 1, 1, 0, 0);
     q.bwd_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) +
-                  carve_bytes((size_t)g.Co * g.B, 4) + carve_bytes((size_t)(q.T + 1) * g.C * (g.Co < 64 ? 64 : g.Co), 4) +
+                  carve_bytes((size_t)g.Co * g.B, 4) + carve_bytes((size_t)12 * g.C * (g.Co < 64 ? 64 : g.Co), 4) +
                   carve_bytes((size_t)g.B * q.T * g.C * g.Ho * g.Wo, 4) +
                   carve_bytes((size_t)g.B * q.T * g.Ho * g.Wo, sizeof(DcnGeo)) + carve_bytes(q.gemm_bytes, 1) + 256;
     // col2im tile: 256 output pixels, lanes along x
@@ -1969,7 +2346,7 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
     Carver cv(workspace, workspace_bytes);
     float* slabs = cv.take<float>((size_t)q.Z * q.Mpw * q.Jp);
     float* bsum = cv.take<float>((size_t)Cout * B);
-    float* wt = cv.take<float>((size_t)(q.T + 1) * C * (Cout < 64 ? 64 : Cout));   // (or dcnb_kernel's [64][10 C] pack)
+    float* wt = cv.take<float>((size_t)12 * C * (Cout < 64 ? 64 : Cout));   // (or the window kernels' packs: [64][10 C], [12 C][64])
     float* dcol = cv.take<float>((size_t)B * q.T * C * HoWo);
     DcnGeo* geo = cv.take<DcnGeo>((size_t)B * q.T * HoWo);
     void* gemm_ws = cv.take<char>(q.gemm_bytes);
@@ -2017,20 +2394,42 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
     if (dcnb_mode && matrix_mode() == 0 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 &&
         dw == 1 && C % 16 == 0 && Cout <= 64 && (W == 16 || W == 32 || W == 64 || W == 128) &&
         H % (IG_BN / (W >= 32 ? 32 : W)) == 0 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB) {
+        if (dcnb_mode == 3) {
+            const int tc = W >= 32 ? 32 : 16, tiles_x = W / tc, n_tiles = (int)(q.N / 64);
+            const float* Aq = launch_pack(weight, wt, (size_t)12 * C * 64 * sizeof(float), Cout, C, q.T, PACK_DCN_QUAD, 12 * C, 64, 0, st);
+            DcnBwdQuadParams pq{g, input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask};
+            ProfScope scope(st, 3);
+            scope.name("dcnq_kernel<%d>", tc);
+#define CNUDA_DCNQ_LAUNCH(TCV)                                                                                         \
+    do {                                                                                                               \
+        const size_t lds = (size_t)DqTile<TCV>::END * sizeof(float);                                                   \
+        static bool raised = false;                                                                                    \
+        if (lds > 64 * 1024 && !raised) {                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnq_kernel<TCV>),                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
+            raised = true;                                                                                             \
+        }                                                                                                              \
+        CNUDA_LAUNCH((dcnq_kernel<TCV>), dim3(n_tiles), dim3(IG_THREADS), lds, st, pq, Aq, n_tiles, tiles_x);          \
+    } while (0)
+            if (tc == 32) CNUDA_DCNQ_LAUNCH(32); else CNUDA_DCNQ_LAUNCH(16);
+#undef CNUDA_DCNQ_LAUNCH
+            return check_launch("cnuda_dcn_v2_backward(quad planes)");
+        }
         const int Mp = 10 * C;
         const float* Ad = launch_pack(weight, wt, (size_t)64 * Mp * sizeof(float), Cout, C, q.T, PACK_DCN_DCOL, 64, Mp, 0, st);
-        {
+        if (dcnb_mode < 2) {
             DcnPrepParams pp{g, weight, offset, mask, wt, geo, 0};
             CNUDA_LAUNCH(dcn_prep_kernel, dim3(stream_grid((long long)B * q.T * HoWo, 256)), dim3(256), 0, st, pp);
         }
         const int tc = W >= 32 ? 32 : W, tiles_x = W / tc, n_tiles = (int)(q.N / IG_BN);
-        DcnBwdWinParams p{g, input, offset, mask, grad_output, grad_offset, grad_mask, dcol};
+        DcnBwdWinParams p{g, input, offset, mask, grad_output, grad_offset, grad_mask, dcol, grad_input};
+        const bool scatter = dcnb_mode >= 2;
         {
             ProfScope scope(st, 3);
-            scope.name("dcnb_kernel<%d, false>", tc);
+            scope.name("dcnb_kernel<%d, %s>", tc, scatter ? "true" : "false");
 #define CNUDA_DCNB_LAUNCH(TCV, SC)                                                                                     \
     do {                                                                                                               \
-        const size_t lds = (size_t)16 * DwTile<TCV>::PL * sizeof(float);                                               \
+        const size_t lds = (size_t)(SC ? 32 : 16) * DwTile<TCV>::PL * sizeof(float);                                   \
         static bool raised = false;                                                                                    \
         if (lds > 64 * 1024 && !raised) {                                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnb_kernel<TCV, SC>),                            \
@@ -2039,10 +2438,11 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
         }                                                                                                              \
         CNUDA_LAUNCH((dcnb_kernel<TCV, SC>), dim3(n_tiles), dim3(IG_THREADS), lds, st, p, Ad, Mp, n_tiles, tiles_x);   \
     } while (0)
-            if (tc == 32) CNUDA_DCNB_LAUNCH(32, false); else CNUDA_DCNB_LAUNCH(16, false);
+            if (scatter) { if (tc == 32) CNUDA_DCNB_LAUNCH(32, true); else CNUDA_DCNB_LAUNCH(16, true); }
+            else { if (tc == 32) CNUDA_DCNB_LAUNCH(32, false); else CNUDA_DCNB_LAUNCH(16, false); }
 #undef CNUDA_DCNB_LAUNCH
         }
-        {
+        if (!scatter) {
             DcnCol2imParams pc{g, dcol, geo, grad_input, q.TR, q.TC, q.tc_shift, q.tiles_y, q.tiles_x, q.ncg, q.WSZmax,
                                q.claim_sz};
             const int n_wg = B * q.tiles_y * q.tiles_x * q.ncg;

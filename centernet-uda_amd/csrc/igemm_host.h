@@ -19,6 +19,10 @@ enum PackMode {
     // DCN column gradient on-chip (dcn.hip dcnb_kernel): dst[k = o][m = (g*10 + tap)*16 + ci] = W[o][16g + ci][tap] for
     // tap < 9, zero for the tenth slot of a group (taps come in pairs: 32 GEMM rows = 2 taps x 16 channels); Mp = 10 C / 16 * 16
     PACK_DCN_DCOL = 5,
+    // DCN backward on channel-quad planes (dcn.hip dcnq_kernel): A fragments of v_mfma_f32_16x16x4_f32 in issue order,
+    // dst[k = ((g*4 + quad)*3 + rt)*16 + s][m = lane] = W[o = 4s + (lane >> 4)][c = 16g + 4 quad + (lane & 3)][tap = rt + 3*((lane & 15) >> 2)]
+    // (the fourth tap slot of a row tile and o >= Co are zero); Kp = 12 * C / 16 * 16 = 12 C... rows, Mp = 64
+    PACK_DCN_QUAD = 6,
 };
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
