@@ -339,6 +339,7 @@ constexpr int DW_MARGIN = 3;         // window rows beyond the undeformed 3x3 fo
 // per row, zero by the buffer range check wherever the image ends.  The squarer the tile, the smaller the window per
 // pixel: 12 x 40 cells for 4 x 32 pixels (31 KB per group, offsets up to +-3 pixels stay inside) against 10 x 72 for
 // 2 x 64; a wave's 32 pixels are still one row segment (128-byte stores).
+typedef __attribute__((address_space(3))) volatile unsigned char lds_vu8;   // volatile through a GENERIC pointer compiles to flat_load / flat_store
 template <int TC> struct DwTile {
     static constexpr int TR = IG_BN / TC, NR = TR + 2 + 2 * DW_MARGIN, RS = TC + 8, PL = NR * RS;
     static constexpr int CPR = TC / 4 + 2, CPP = NR * CPR, CELLS = 16 * CPP;
@@ -614,319 +615,6 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcnw_fwd_kernel(DcnFwdParams p,
 }
 
 // ---------------------------------------------------------------------------
-// backward data path with the column gradient ON-CHIP (round 4): same layers as dcnw_fwd_kernel.
-//
-// dcol[(tap, c), p] = sum_o W[o, c, tap] * gout[o, p] used to be a 1x1 implicit GEMM that wrote 9*C*Ho*Wo floats per
-// image to workspace (864 MB per 128 x 128 layer of the benched step) for two consumers to stream back.  Here a
-// workgroup owns 128 pixels (the forward's 4 x 32 tile); every wave holds grad_output of its 32 pixels as MFMA B
-// fragments (Co <= 64: 32 registers) for the whole tile and, per channel group and PAIR of taps, computes the 32 x 32
-// tile of dcol -- rows (2 taps x 16 channels), columns its pixels -- with 32 f32 MFMAs whose A fragments come straight
-// from the packed weights (PACK_DCN_DCOL, L2-resident).  The accumulator layout puts a pixel on a lane and eight
-// channels of each tap in its registers, which is what the coordinate / mask gradients want: four running sums
-// u_kl = sum_c dcol_c * corner_kl(c) per (pixel, tap) from the INPUT window in LDS (dcnw_fwd_kernel's window: two
-// ds_read2_b32 per channel instead of two unaligned 8-byte gathers through the texture-address unit), kept in
-// registers across the channel groups and turned into grad_offset / grad_mask at the end of the tile.
-// SCATTER == false (validation build, and layers the in-kernel scatter does not take): dcol is also written out in the
-// layout dcn_col2im_kernel reads.
-// ---------------------------------------------------------------------------
-struct DcnBwdWinParams {
-    DcnGeom g;
-    const float *in, *off, *mask, *gout;
-    float *goff, *gmask;
-    float* dcol;                  // [B][9 * C][HW], plain column gradient (SCATTER == false)
-    float* gin;                   // grad_input, zeroed by the caller (SCATTER == true)
-};
-// LDS float add without a return value (ds_add_f32): collisions between lanes are the hardware's business
-__device__ __forceinline__ void lds_add(float* p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-template <int TC, bool SCATTER>
-__global__ __launch_bounds__(IG_THREADS, 2) void dcnb_kernel(DcnBwdWinParams p, const float* __restrict__ A, int Mp, int n_tiles,
-                                                             int tiles_x) {
-    using Q = DwTile<TC>;
-    constexpr int PL = Q::PL, RS = Q::RS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // Win[16 * PL] | Gwin[16 * PL] (SCATTER)
-    const DcnGeom& g = p.g;
-    const int W = g.W, H = g.H, HW = g.H * g.W;
-    float* const Win = smem;
-    float* const Gwin = smem + 16 * PL;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    int tile = xcd_remap(blockIdx.x, n_tiles);
-    const int tx = tile % tiles_x; tile /= tiles_x;
-    const int tiles_y = H / Q::TR;
-    const int ty = tile % tiles_y, b = tile / tiles_y;
-    const int y0 = ty * Q::TR, x0 = tx * TC;
-    const int yw0 = y0 - 1 - DW_MARGIN;
-    const int pxl = wid * 32 + (lane & 31), kl = lane >> 5;
-    const int py = y0 + (pxl >> Q::SHIFT), px = x0 + (pxl & (TC - 1)), pp = py * W + px;
-
-    const buf_rsrc rs = ig_make_rsrc(p.in, (unsigned)((size_t)g.B * g.C * HW * sizeof(float)));
-    const buf_rsrc ra = ig_make_rsrc(A, (unsigned)((size_t)64 * Mp * sizeof(float)));
-    auto cell = [&](int i, unsigned& voff, int& loff) {
-        int salt = 0;
-        asm volatile("" : "+v"(salt));                                 // (see dcnw_fwd_kernel)
-        const int e = tid + i * IG_THREADS + salt;
-        const int c = e / Q::CPP, rem = e - c * Q::CPP;
-        const int row = rem / Q::CPR, q4 = rem - row * Q::CPR;
-        const int iy = yw0 + row, ix = x0 - 4 + 4 * q4;
-        loff = e < Q::CELLS ? c * PL + row * RS + 4 * q4 : -1;
-        voff = (e < Q::CELLS && iy >= 0 && iy < H && ix >= 0 && ix < W)
-                   ? (unsigned)(((b * g.C + c) * HW + iy * W + ix) * (int)sizeof(float)) : IG_BUF_OOB;
-    };
-
-    // grad_output of this lane's pixel: B fragments of the column-gradient GEMM, k-step s holds output channel 2s + kl
-    float gf[32];
-    {
-        const float* go = p.gout + (size_t)b * g.Co * HW + pp;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) gf[s] = 2 * s + kl < g.Co ? go[(size_t)(2 * s + kl) * HW] : 0.0f;
-    }
-    // per-tap sampling state (as dcnw_fwd_kernel) and the four running sums of every tap; the scattering build also
-    // keeps the fractions and the mask (the weights of the four corner adds)
-    constexpr int NG = SCATTER ? 9 : 1;
-    int addr[9];
-    float u00[9], u01[9], u10[9], u11[9];
-    float flh[NG], flw[NG], fmk[NG];
-    unsigned stray = 0, inwin_bits = 0;
-    {
-        const float* off_b = p.off + (size_t)b * 18 * HW + pp;
-        const float* mask_b = p.mask + (size_t)b * 9 * HW + pp;
-        float dy[9], dx[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            dy[t] = off_b[(size_t)(2 * t) * HW];
-            dx[t] = off_b[(size_t)(2 * t + 1) * HW];
-            if (SCATTER) fmk[t % NG] = mask_b[(size_t)t * HW];
-        }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const float h = (float)(py - 1 + t / 3) + dy[t], w = (float)(px - 1 + t % 3) + dx[t];
-            const float hf = floorf(h), wf = floorf(w);
-            const bool valid = h > -1.0f && w > -1.0f && h < (float)H && w < (float)W;
-            const int h0 = valid ? (int)hf : 0, w0i = valid ? (int)wf : 0;
-            const int wr = h0 - yw0, wc = w0i - x0 + 4;
-            const bool inwin = valid && wr >= 0 && wr + 1 <= Q::NR - 1 && wc >= 0 && wc + 1 <= RS - 1;
-            addr[t] = inwin ? wr * RS + wc : 0;
-            if (SCATTER) { flh[t % NG] = h - hf; flw[t % NG] = w - wf; }
-            if (inwin) inwin_bits |= 1u << t;
-            if (valid && !inwin) stray |= 1u << t;
-            u00[t] = u01[t] = u10[t] = u11[t] = 0.0f;
-        }
-    }
-    const bool any_stray = __any(stray != 0);
-
-    f32x4 hreg[Q::NCELL];
-    auto win_load = [&](int grp) {
-        const unsigned soff = (unsigned)(grp * 16 * HW) * (unsigned)sizeof(float);
-#pragma unroll
-        for (int i = 0; i < Q::NCELL; ++i) {
-            unsigned voff; int loff;
-            cell(i, voff, loff);
-            hreg[i] = ig_buf_load4(rs, voff, soff);
-        }
-    };
-    auto win_store = [&]() {
-#pragma unroll
-        for (int i = 0; i < Q::NCELL; ++i) {
-            unsigned voff; int loff;
-            cell(i, voff, loff);
-            if (loff >= 0) *reinterpret_cast<f32x4*>(Win + loff) = hreg[i];
-        }
-    };
-    // the grad_input window of one channel group: every in-image cell the group's samples touched goes out with one
-    // atomic (neighbouring tiles share their halo cells), and the window is zero again afterwards
-    auto gwin_flush = [&](int grp) {
-        static_assert(16 * PL % IG_THREADS == 0, "window cells per thread");
-        float* gin_g = p.gin + ((size_t)b * g.C + grp * 16) * HW;
-#pragma unroll 2
-        for (int i = 0; i < 16 * PL / IG_THREADS; ++i) {
-            const int e = tid + i * IG_THREADS;
-            const float v = Gwin[e];
-            const int c = e / PL, rem = e - c * PL;
-            const int row = rem / RS, col = rem - row * RS;
-            const int iy = yw0 + row, ix = x0 - 4 + col;
-            if (v != 0.0f) {
-                Gwin[e] = 0.0f;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) atomicAdd(gin_g + (size_t)c * HW + iy * W + ix, v);
-            }
-        }
-    };
-    const int G = g.C >> 4;
-    win_load(0);
-    if (SCATTER)
-        for (int e = tid; e < 4 * PL; e += IG_THREADS) reinterpret_cast<f32x4*>(Gwin)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-    win_store();
-    __syncthreads();
-    for (int grp = 0; grp < G; ++grp) {
-        const bool more = grp + 1 < G;
-        if (more) win_load(grp + 1);
-#pragma unroll
-        for (int pr = 0; pr < 5; ++pr) {                               // pairs of taps: rows (2 taps x 16 channels) of the GEMM
-            // --- the 32 x 32 tile of dcol: 32 MFMAs, A fragments straight from the packed weights
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            {
-                // (scalar row offsets 2 s Mp through the buffer form: the 32 rows cost SGPRs, not hoisted VGPR addresses)
-                const unsigned mvoff = (unsigned)((kl * Mp + (lane & 31)) * (int)sizeof(float));
-                const unsigned gbase = (unsigned)((grp * 10 + 2 * pr) * 16) * (unsigned)sizeof(float);
-#pragma unroll
-                for (int s0 = 0; s0 < 32; s0 += 8) {                   // eight A loads in flight, then their MFMAs
-                    float af[8];
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) af[s] = ig_buf_load(ra, mvoff, gbase + (unsigned)(2 * (s0 + s) * Mp) * (unsigned)sizeof(float));
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], gf[s0 + s], acc, 0, 0, 0);
-                }
-            }
-            // --- gather (and scatter) role for the two taps: this lane's eight channels of each
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int t = 2 * pr + tt;
-                if (t >= 9) continue;                                  // (the tenth slot of a group is padding)
-                int a_t = addr[t];
-                asm volatile("" : "+v"(a_t));
-                const float* wb = Win + a_t;
-                const float live = ((inwin_bits >> t) & 1u) ? 1.0f : 0.0f;
-                float k00 = 0.f, k01 = 0.f, k10 = 0.f, k11 = 0.f;
-                if (SCATTER) {
-                    const float lh = flh[t % NG], lw = flw[t % NG], hh = 1.0f - lh, hw = 1.0f - lw, mk = fmk[t % NG] * live;
-                    k00 = hh * hw * mk; k01 = hh * lw * mk; k10 = lh * hw * mk; k11 = lh * lw * mk;
-                }
-#pragma unroll
-                for (int jh = 0; jh < 8; jh += 4) {                    // four channels' corners in registers at a time
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = jh; j < jh + 4; ++j) {
-                        const int c = 4 * kl + (j & 3) + 8 * (j >> 2); // channel of register 8 * tt + j inside the group
-                        const float d = acc[8 * tt + j] * live;
-                        const float* q = wb + c * PL;
-                        u00[t] = fmaf(d, q[0], u00[t]);
-                        u01[t] = fmaf(d, q[1], u01[t]);
-                        u10[t] = fmaf(d, q[RS], u10[t]);
-                        u11[t] = fmaf(d, q[RS + 1], u11[t]);
-                        if (SCATTER) {
-                            float* r = Gwin + a_t + c * PL;
-                            const float dd = acc[8 * tt + j];
-                            lds_add(r, dd * k00);
-                            lds_add(r + 1, dd * k01);
-                            lds_add(r + RS, dd * k10);
-                            lds_add(r + RS + 1, dd * k11);
-                        }
-                    }
-                    // (the sums are only read at the end of the tile: without an anchor the compiler sinks the whole FMA
-                    // chain below the loop body and keeps every corner it read alive -- in scratch -- until then)
-                    asm volatile("" : "+v"(u00[t]), "+v"(u01[t]), "+v"(u10[t]), "+v"(u11[t]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (!SCATTER) {
-                    unsigned lo = (unsigned)(4 * kl * HW + pp) * 4u;
-                    asm volatile("" : "+v"(lo));
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const unsigned long long db = reinterpret_cast<unsigned long long>(
-                            p.dcol + ((size_t)(b * 9 + t) * g.C + grp * 16 + (j & 3) + 8 * (j >> 2)) * HW);
-                        *reinterpret_cast<__attribute__((address_space(1))) float*>(db + (unsigned long long)lo) = acc[8 * tt + j];
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more || SCATTER) {
-            __syncthreads();                                           // every wave has read (and added into) this group's windows
-            if (SCATTER) gwin_flush(grp);
-            if (more) win_store();
-            __syncthreads();
-        }
-    }
-    // --- strays (rare): a (pixel, tap) whose corners left the window.  For every tap some lane of the wave strayed on,
-    // the wave computes the tap's tile of dcol once more per channel group; the lanes concerned read their corners
-    // from global memory (clamped rows / columns, zero weights outside the image) and, in the scattering build, add
-    // into grad_input with global atomics.
-    if (any_stray) {
-#pragma unroll 1
-        for (int t0 = 0; t0 < 9; ++t0) {
-            int t = t0;
-            asm volatile("" : "+s"(t));
-            const bool mine = (stray >> t) & 1u;
-            if (!__any(mine)) continue;
-            float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
-            const int tr = t / 3;
-            const float* off_b = p.off + (size_t)b * 18 * HW + pp;
-            const float sh_ = (float)(py - 1 + tr) + off_b[(size_t)(2 * t) * HW];
-            const float sw_ = (float)(px - 1 + t - 3 * tr) + off_b[(size_t)(2 * t + 1) * HW];
-            const float shf = floorf(sh_), swf = floorf(sw_);
-            const int sh0 = mine ? (int)shf : 0, sw0 = mine ? (int)swf : 0;
-            const bool top = sh0 >= 0, bot = sh0 + 1 <= H - 1, lef = sw0 >= 0, rig = sw0 + 1 <= W - 1;
-            const float f00 = (mine && top && lef) ? 1.f : 0.f, f01 = (mine && top && rig) ? 1.f : 0.f,
-                        f10 = (mine && bot && lef) ? 1.f : 0.f, f11 = (mine && bot && rig) ? 1.f : 0.f;
-            const int cy0 = top ? sh0 : 0, cy1 = bot ? sh0 + 1 : H - 1, cx0 = lef ? sw0 : 0, cx1 = rig ? sw0 + 1 : W - 1;
-            const int o00 = cy0 * W + cx0, o01 = cy0 * W + cx1, o10 = cy1 * W + cx0, o11 = cy1 * W + cx1;
-            const float slh = sh_ - shf, slw = sw_ - swf, shh = 1.0f - slh, shw = 1.0f - slw;
-            const float smk = p.mask[((size_t)b * 9 + t) * HW + pp];
-            const float a00 = shh * shw * smk * f00, a01 = shh * slw * smk * f01, a10 = slh * shw * smk * f10, a11 = slh * slw * smk * f11;
-            const int pr = t >> 1;
-            const bool second = t & 1;
-#pragma unroll 1
-            for (int grp = 0; grp < G; ++grp) {
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                const unsigned mvoff = (unsigned)((kl * Mp + (lane & 31)) * (int)sizeof(float));
-                const unsigned gbase = (unsigned)((grp * 10 + 2 * pr) * 16) * (unsigned)sizeof(float);
-#pragma unroll
-                for (int s = 0; s < 32; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ig_buf_load(ra, mvoff, gbase + (unsigned)(2 * s * Mp) * (unsigned)sizeof(float)),
-                                                               gf[s], acc, 0, 0, 0);
-                if (mine) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float d = second ? acc[8 + j] : acc[j];
-                        const int c = grp * 16 + 4 * kl + (j & 3) + 8 * (j >> 2);
-                        const float* pl = p.in + ((size_t)b * g.C + c) * HW;
-                        s00 = fmaf(d, pl[o00] * f00, s00);
-                        s01 = fmaf(d, pl[o01] * f01, s01);
-                        s10 = fmaf(d, pl[o10] * f10, s10);
-                        s11 = fmaf(d, pl[o11] * f11, s11);
-                        if (SCATTER) {
-                            float* gp = p.gin + ((size_t)b * g.C + c) * HW;
-                            if (a00 != 0.0f) atomicAdd(gp + o00, d * a00);
-                            if (a01 != 0.0f) atomicAdd(gp + o01, d * a01);
-                            if (a10 != 0.0f) atomicAdd(gp + o10, d * a10);
-                            if (a11 != 0.0f) atomicAdd(gp + o11, d * a11);
-                        }
-                    }
-                }
-            }
-            // into the tap's sums (static register arrays: select the tap)
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-                if (k == t) { u00[k] += s00; u01[k] += s01; u10[k] += s10; u11[k] += s11; }
-        }
-    }
-    // --- the two lane halves hold disjoint channel subsets of the same pixel: add them, then lanes 0..31 write (the
-    // fractions and the mask are read again here rather than held across the channel loop)
-    const float* off_e = p.off + (size_t)b * 18 * HW + pp;
-    const float* mask_e = p.mask + (size_t)b * 9 * HW + pp;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const float a00 = u00[t] + __shfl_xor(u00[t], 32, 64), a01 = u01[t] + __shfl_xor(u01[t], 32, 64);
-        const float a10 = u10[t] + __shfl_xor(u10[t], 32, 64), a11 = u11[t] + __shfl_xor(u11[t], 32, 64);
-        if (kl == 0) {
-            const float h = (float)(py - 1 + t / 3) + off_e[(size_t)(2 * t) * HW], w = (float)(px - 1 + t % 3) + off_e[(size_t)(2 * t + 1) * HW];
-            const float lh = h - floorf(h), lw = w - floorf(w), hh = 1.0f - lh, hw = 1.0f - lw, mk = mask_e[(size_t)t * HW];
-            const float sm = hh * hw * a00 + hh * lw * a01 + lh * hw * a10 + lh * lw * a11;
-            const float sh_ = (-hw * a00 - lw * a01 + hw * a10 + lw * a11) * mk;
-            const float sw_ = (-hh * a00 + hh * a01 - lh * a10 + lh * a11) * mk;
-            p.gmask[((size_t)b * 9 + t) * HW + pp] = sm;
-            p.goff[((size_t)b * 18 + 2 * t) * HW + pp] = sh_;
-            p.goff[((size_t)b * 18 + 2 * t + 1) * HW + pp] = sw_;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // backward data path on CHANNEL-QUAD PLANES (round 4): the column gradient never leaves the chip and every gradient
 // of the data path (grad_input, grad_offset, grad_mask) comes out of ONE kernel.
 //
@@ -953,10 +641,12 @@ template <int TC> struct DqTile {
     static constexpr int NPX = 64, TR = NPX / TC, NR = TR + 2 + 2 * DW_MARGIN, RS = TC + 8, CELLS = NR * RS;
     static constexpr int CPR = RS / 4, ITEMS = NR * CPR, NIT = (ITEMS + 63) / 64;   // staging: (row, 4 columns) per lane
     static constexpr int SHIFT = TC == 32 ? 5 : 4;
-    static constexpr int CLAIM = (CELLS + 15) / 16 * 16;                            // bytes per wave
+    static constexpr int CLAIM = (CELLS + 16 + 15) / 16 * 16;                       // bytes per wave (+ a spare cell for lanes without a sample)
     // LDS, in floats: input window | grad_input window | geometry records | grad_output tile | claim maps | stray list
     static constexpr int WIN = 0, GWIN = 16 * CELLS, GEO = 32 * CELLS, GO = GEO + 9 * NPX * 4, CLM = GO + 64 * NPX;
-    static constexpr int STRAY = CLM + CLAIM, END = STRAY + 4 + 9 * NPX / 2;
+    // stray bitmap (one bit per (tap, pixel)) | dump area: lanes without a turn add into cell `lane` (+ 1, + RS, + RS + 1) of it
+    static constexpr int STRAY = CLM + CLAIM, DUMP = STRAY + 20, END = DUMP + (64 + RS + 2) * 4;
+    static_assert(DUMP % 4 == 0, "dump cells are float4");
     static_assert(4 * 9 * NPX * 4 <= 32 * CELLS, "the running sums of the four waves reuse the windows");
 };
 struct DcnBwdQuadParams {
@@ -982,14 +672,14 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnq_kernel(DcnBwdQuadParams p,
     f32x4* const Wq = reinterpret_cast<f32x4*>(smem + Q::WIN) + wid * CELLS;     // [cell][4 channels] of this wave's quad
     f32x4* const Gq = reinterpret_cast<f32x4*>(smem + Q::GWIN) + wid * CELLS;
     f32x4* const Geo = reinterpret_cast<f32x4*>(smem + Q::GEO);                  // [tap][pixel]: window cell (int bits; -1: none), lh, lw, mask
-    float* const Go = smem + Q::GO;                                              // [o / 4][pixel][o % 4]
-    volatile unsigned char* const claim = reinterpret_cast<unsigned char*>(smem + Q::CLM) + wid * Q::CLAIM;
-    int* const nstray = reinterpret_cast<int*>(smem + Q::STRAY);
-    unsigned short* const strays = reinterpret_cast<unsigned short*>(smem + Q::STRAY + 4);
+    float* const Go = smem + Q::GO;                                              // [o / 16][o % 4][pixel][(o / 4) % 4]: a lane's four k-steps are one 16-byte read
+    lds_vu8* const claim = (lds_vu8*)(reinterpret_cast<unsigned char*>(smem + Q::CLM) + wid * Q::CLAIM);   // (LDS pointer type: a volatile generic access is a FLAT instruction)
+    unsigned* const stray_bits = reinterpret_cast<unsigned*>(smem + Q::STRAY);  // [18] words + any-flag
+    f32x4* const Dump = reinterpret_cast<f32x4*>(smem + Q::DUMP) + lane;        // (shared by the waves: its content means nothing)
     auto pixel = [&](int px) { return (y0 + (px >> Q::SHIFT)) * W + x0 + (px & (TC - 1)); };
 
     // ---- tile setup (all four waves) ----
-    if (tid == 0) *nstray = 0;
+    if (tid < 20) stray_bits[tid] = 0;
     __syncthreads();
     for (int e = tid; e < 9 * NPX; e += IG_THREADS) {
         const int t = e >> 6, px = e & 63, py = y0 + (px >> Q::SHIFT), pxx = x0 + (px & (TC - 1)), pp = py * W + pxx;
@@ -1000,15 +690,25 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnq_kernel(DcnBwdQuadParams p,
         const int h0 = valid ? (int)hf : 0, w0 = valid ? (int)wf : 0;
         const int wr = h0 - yw0, wc = w0 - xw0;
         const bool inwin = valid && wr >= 0 && wr + 1 <= Q::NR - 1 && wc >= 0 && wc + 1 <= RS - 1;
-        if (valid && !inwin) strays[atomicAdd(nstray, 1)] = (unsigned short)e;
+        if (valid && !inwin) { atomicOr(stray_bits + (e >> 5), 1u << (e & 31)); stray_bits[18] = 1; }
+        // record: window cell (-1: none), (1 - lh) mask, lh mask, lw -- the four corner weights are two packed products away
+        const float lh = h - hf, mk = p.mask[((size_t)b * 9 + t) * HW + pp];
         f32x4 rec;
         rec.x = __int_as_float(inwin ? wr * RS + wc : -1);
-        rec.y = h - hf; rec.z = w - wf; rec.w = p.mask[((size_t)b * 9 + t) * HW + pp];
+        rec.y = (1.0f - lh) * mk; rec.z = lh * mk; rec.w = w - wf;
         Geo[e] = rec;
     }
-    for (int e = tid; e < 64 * NPX; e += IG_THREADS) {
-        const int o = e >> 6, px = e & 63;
-        Go[(o >> 2) * (4 * NPX) + px * 4 + (o & 3)] = o < g.Co ? p.gout[((size_t)b * g.Co + o) * HW + pixel(px)] : 0.0f;
+    {   // grad_output tile: thread = (pixel, output channels wid, wid + 4, ...), sixteen loads in flight
+        const int px = tid & 63;
+        const float* gp = p.gout + (size_t)b * g.Co * HW + pixel(px);
+        float gv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gv[i] = wid + 4 * i < g.Co ? gp[(size_t)(wid + 4 * i) * HW] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = wid + 4 * i;
+            Go[(((o >> 4) * 4 + (o & 3)) * NPX + px) * 4 + ((o >> 2) & 3)] = gv[i];
+        }
     }
     for (int i = lane; i < CELLS; i += 64) Gq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -1016,41 +716,45 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnq_kernel(DcnBwdQuadParams p,
     const buf_rsrc rs = ig_make_rsrc(p.in, (unsigned)((size_t)g.B * C * HW * sizeof(float)));
     const buf_rsrc ra = ig_make_rsrc(A, (unsigned)((size_t)12 * C * 64 * sizeof(float)));
     f32x4 hreg[Q::NIT][4];
-    auto stage_item = [&](int i, unsigned& voff, int& cell) {
-        int salt = 0;
-        asm volatile("" : "+v"(salt));                                 // (the addresses are recomputed where they are used)
-        const int it = lane + 64 * i + salt;
+    unsigned st_voff[Q::NIT];
+    int st_cell[Q::NIT];
+#pragma unroll
+    for (int i = 0; i < Q::NIT; ++i) {
+        const int it = lane + 64 * i;
         const int row = it / Q::CPR, q4 = it - row * Q::CPR;
         const int iy = yw0 + row, ix = xw0 + 4 * q4;
-        cell = it < Q::ITEMS ? row * RS + 4 * q4 : -1;
-        voff = (it < Q::ITEMS && iy >= 0 && iy < H && ix >= 0 && ix < W)
-                   ? (unsigned)(((b * C + 4 * wid) * HW + iy * W + ix) * (int)sizeof(float)) : IG_BUF_OOB;
-    };
+        st_cell[i] = it < Q::ITEMS ? row * RS + 4 * q4 : -1;
+        const bool ok = (it < Q::ITEMS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
+        st_voff[i] = ok ? (unsigned)(((b * C + 4 * wid) * HW + iy * W + ix) * (int)sizeof(float)) : IG_BUF_OOB;
+    }
     auto win_load = [&](int grp) {
 #pragma unroll
-        for (int i = 0; i < Q::NIT; ++i) {
-            unsigned voff; int cell;
-            stage_item(i, voff, cell);
+        for (int i = 0; i < Q::NIT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hreg[i][r] = ig_buf_load4(rs, voff, (unsigned)((grp * 16 + r) * HW) * (unsigned)sizeof(float));
-        }
+            for (int r = 0; r < 4; ++r) hreg[i][r] = ig_buf_load4(rs, st_voff[i], (unsigned)((grp * 16 + r) * HW) * (unsigned)sizeof(float));
     };
     auto win_store = [&]() {
 #pragma unroll
-        for (int i = 0; i < Q::NIT; ++i) {
-            unsigned voff; int cell;
-            stage_item(i, voff, cell);
-            if (cell >= 0) {
+        for (int i = 0; i < Q::NIT; ++i)
+            if (st_cell[i] >= 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) Wq[cell + k] = f32x4{hreg[i][0][k], hreg[i][1][k], hreg[i][2][k], hreg[i][3][k]};
+                for (int k = 0; k < 4; ++k) Wq[st_cell[i] + k] = f32x4{hreg[i][0][k], hreg[i][1][k], hreg[i][2][k], hreg[i][3][k]};
             }
-        }
     };
     win_load(0);
     win_store();
     __syncthreads();
 
     // ---- channel groups ----
+    // Software pipeline over the items (column tile ct, row tile rt) of a group and across groups.  A step holds item
+    // n's gather / scatter roles (VALU + LDS: six dependent LDS round trips) and the 16-link MFMA chain of item
+    // n + 1, interleaved BY HAND -- a link leaves the issue port free for about seven other instructions -- and
+    // pinned with scheduling barriers (left alone the compiler issues the chain first and the round trips after
+    // it).  The A fragments of item n + 2 replace those of n + 1 a quarter at a time as the chain releases them;
+    // likewise the B fragments when the column tile changes.
+    // (Measured and dropped, round 4: the record and the claim / corner reads of the next item issued a step ahead
+    // -- +6%; two items per step through the corner phases in lockstep, halving the round trips per item -- +29%,
+    // with spills: the step is bound by what the LDS pipe moves, not by the length of the dependent chain.)
     const int pxl = lane & 15, slot = lane >> 4;
     float u[4][3][4];
 #pragma unroll
@@ -1060,91 +764,150 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnq_kernel(DcnBwdQuadParams p,
 #pragma unroll
             for (int k = 0; k < 4; ++k) u[ct][rt][k] = 0.0f;
     const int G = C >> 4;
+    float af[16], bf[16];
+    f32x4 acc[2];
+    auto load_a4 = [&](int grp_, int rt, int s4) {                     // k-steps 4 s4 .. 4 s4 + 3 (past the last group: zeros)
+        const unsigned abase = (unsigned)((((grp_ * 4 + wid) * 3 + rt) * 16) * 64) * (unsigned)sizeof(float);
+        const f32x4 v = ig_buf_load4(ra, (unsigned)lane * 16u, abase + (unsigned)(s4 * 256 * 4));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) af[4 * s4 + k] = v[k];
+    };
+    auto load_b4 = [&](int ct, int s4) {
+        int pbase = (slot * NPX + ct * 16 + pxl) * 4;
+        asm volatile("" : "+v"(pbase));                                // (the tile does not change with the group: keep the reads here)
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Go + s4 * (16 * NPX) + pbase);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bf[4 * s4 + k] = v[k];
+    };
+#define CNUDA_SB() __builtin_amdgcn_sched_barrier(0)
+    {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { load_a4(0, 0, s4); load_b4(0, s4); }
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], c, 0, 0, 0);
+        acc[0] = c;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) load_a4(0, 1, s4);
+    }
     for (int grp = 0; grp < G; ++grp) {
         const bool more = grp + 1 < G;
-        if (more) win_load(grp + 1);
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            int pbase = (ct * 16 + pxl) * 4 + slot;
-            asm volatile("" : "+v"(pbase));                            // (the tile does not change with the group: keep the reads here)
-            float bf[16];
+        for (int n = 0; n < 12; ++n) {
+            const int ct = n / 3, rt = n % 3, cur = n & 1;
+            const int n2 = (n + 2) % 12;
+            const int grp2 = grp + (n + 2 >= 12 ? 1 : 0);
+            const bool new_b = n2 % 3 == 0;                            // item n + 2 starts a column tile: its B fragments follow the chain too
+            f32x4 cn = {0.f, 0.f, 0.f, 0.f};                           // item n + 1
+#define CNUDA_MM(S) cn = __builtin_amdgcn_mfma_f32_16x16x4f32(af[S], bf[S], cn, 0, 0, 0)
+#define CNUDA_REFILL(Q4) do { load_a4(grp2, n2 % 3, Q4); if (new_b) load_b4(n2 / 3, Q4); } while (0)
+            // --- links 0-3 | the (pixel, tap) record
+            int gi = (slot < 3 ? rt + 3 * slot : rt) * NPX + ct * 16 + pxl;
+            asm volatile("" : "+v"(gi));
+            const f32x4 rec = Geo[gi];
+            CNUDA_SB(); CNUDA_MM(0); CNUDA_SB(); CNUDA_MM(1); CNUDA_SB(); CNUDA_MM(2); CNUDA_SB(); CNUDA_MM(3); CNUDA_SB();
+            CNUDA_REFILL(0);
+            // --- links 4-7 | claim on the anchor cell, corners of the input window
+            const int addr = __float_as_int(rec.x);
+            const bool live = slot < 3 && addr >= 0;
+            const int a = live ? addr : 0;
+            const int ca = live ? addr : CELLS;                        // (dead lanes: one spare byte behind the map)
+            claim[ca] = (unsigned char)lane;
+            const unsigned char holder = claim[ca];                    // same wave: LDS executes in order
+            const f32x4 v00 = Wq[a], v01 = Wq[a + 1], v10 = Wq[a + RS], v11 = Wq[a + RS + 1];
+            f32x4 d;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) bf[s] = Go[s * (4 * NPX) + pbase];
-#pragma unroll
-            for (int rt = 0; rt < 3; ++rt) {
-                // --- the (pixel, tap) records of dcol: 16 k-steps over the output channels
-                const unsigned abase = (unsigned)((((grp * 4 + wid) * 3 + rt) * 16) * 64) * (unsigned)sizeof(float);
-                float af[16];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) af[s] = ig_buf_load(ra, (unsigned)lane * 4u, abase + (unsigned)(s * 64 * 4));
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], acc, 0, 0, 0);
-                // --- this lane's (pixel, tap): geometry record, corners of the input window, claim on the anchor cell
-                int gi = (slot < 3 ? rt + 3 * slot : rt) * NPX + ct * 16 + pxl;
-                asm volatile("" : "+v"(gi));
-                const f32x4 rec = Geo[gi];
-                const int addr = __float_as_int(rec.x);
-                const bool live = slot < 3 && addr >= 0;
-                const int a = live ? addr : 0;
-                const f32x4 v00 = Wq[a], v01 = Wq[a + 1], v10 = Wq[a + RS], v11 = Wq[a + RS + 1];
-                f32x4 d;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) d[k] = live ? acc[k] : 0.0f;
-                u[ct][rt][0] += (d[0] * v00[0] + d[1] * v00[1]) + (d[2] * v00[2] + d[3] * v00[3]);
-                u[ct][rt][1] += (d[0] * v01[0] + d[1] * v01[1]) + (d[2] * v01[2] + d[3] * v01[3]);
-                u[ct][rt][2] += (d[0] * v10[0] + d[1] * v10[1]) + (d[2] * v10[2] + d[3] * v10[3]);
-                u[ct][rt][3] += (d[0] * v11[0] + d[1] * v11[1]) + (d[2] * v11[2] + d[3] * v11[3]);
-                asm volatile("" : "+v"(u[ct][rt][0]), "+v"(u[ct][rt][1]), "+v"(u[ct][rt][2]), "+v"(u[ct][rt][3]));   // (see dcnb_kernel)
-                // --- scatter: grad_input window planes of this wave, one corner at a time (neighbouring lanes' footprints
-                // overlap: a corner is one wave-wide read and one wave-wide write, LDS executes them in order)
-                const float lh = rec.y, lw = rec.z, hh = 1.0f - lh, hw = 1.0f - lw, mk = rec.w;
-                const float k00 = hh * hw * mk, k01 = hh * lw * mk, k10 = lh * hw * mk, k11 = lh * lw * mk;
-                bool pending = live;
+            for (int k = 0; k < 4; ++k) d[k] = live ? acc[cur][k] : 0.0f;
+            const float hw = 1.0f - rec.w;
+            const float k00 = rec.y * hw, k01 = rec.y * rec.w, k10 = rec.z * hw, k11 = rec.z * rec.w;
+            CNUDA_SB(); CNUDA_MM(4); CNUDA_SB(); CNUDA_MM(5); CNUDA_SB(); CNUDA_MM(6); CNUDA_SB(); CNUDA_MM(7); CNUDA_SB();
+            CNUDA_REFILL(1);
+            // --- links 8-15 | the four running sums (gather role) between the four corner read-add-writes (scatter role:
+            // neighbouring lanes' footprints overlap, so a corner is one wave-wide read and one wave-wide write, and
+            // LDS executes them in order).  Lanes without a turn -- padding slot, no sample, anchor claimed by another
+            // lane -- add into the dump area, whose content means nothing: no branch in the step.
+            const bool won = live & (holder == (unsigned char)lane);
+            f32x4* const q = won ? Gq + a : Dump;
+            asm volatile("" ::: "memory");
+            f32x4 c0 = q[0];
+            u[ct][rt][0] = fmaf(d[3], v00[3], fmaf(d[2], v00[2], fmaf(d[1], v00[1], fmaf(d[0], v00[0], u[ct][rt][0]))));
+            CNUDA_SB(); CNUDA_MM(8); CNUDA_SB();
+            u[ct][rt][1] = fmaf(d[3], v01[3], fmaf(d[2], v01[2], fmaf(d[1], v01[1], fmaf(d[0], v01[0], u[ct][rt][1]))));
+            CNUDA_SB(); CNUDA_MM(9); CNUDA_SB();
+            c0 = __builtin_elementwise_fma(f32x4{k00, k00, k00, k00}, d, c0);
+            q[0] = c0;
+            asm volatile("" ::: "memory");
+            f32x4 c1 = q[1];
+            u[ct][rt][2] = fmaf(d[3], v10[3], fmaf(d[2], v10[2], fmaf(d[1], v10[1], fmaf(d[0], v10[0], u[ct][rt][2]))));
+            CNUDA_SB(); CNUDA_MM(10); CNUDA_SB();
+            u[ct][rt][3] = fmaf(d[3], v11[3], fmaf(d[2], v11[2], fmaf(d[1], v11[1], fmaf(d[0], v11[0], u[ct][rt][3]))));
+            // (the sums are only read at the end of the tile: without an anchor the compiler sinks the FMA chains below the
+            // loop and keeps every corner it read alive -- in scratch -- until then)
+            asm volatile("" : "+v"(u[ct][rt][0]), "+v"(u[ct][rt][1]), "+v"(u[ct][rt][2]), "+v"(u[ct][rt][3]));
+            CNUDA_SB(); CNUDA_MM(11); CNUDA_SB();
+            CNUDA_REFILL(2);
+            c1 = __builtin_elementwise_fma(f32x4{k01, k01, k01, k01}, d, c1);
+            q[1] = c1;
+            asm volatile("" ::: "memory");
+            f32x4 c2 = q[RS];
+            CNUDA_SB(); CNUDA_MM(12); CNUDA_SB(); CNUDA_MM(13); CNUDA_SB();
+            c2 = __builtin_elementwise_fma(f32x4{k10, k10, k10, k10}, d, c2);
+            q[RS] = c2;
+            asm volatile("" ::: "memory");
+            f32x4 c3 = q[RS + 1];
+            CNUDA_SB(); CNUDA_MM(14); CNUDA_SB(); CNUDA_MM(15); CNUDA_SB();
+            CNUDA_REFILL(3);
+            c3 = __builtin_elementwise_fma(f32x4{k11, k11, k11, k11}, d, c3);
+            q[RS + 1] = c3;
+            asm volatile("" ::: "memory");
+            acc[cur ^ 1] = cn;
+#undef CNUDA_MM
+#undef CNUDA_REFILL
+            bool pending = live && !won;
+            if (__any(pending)) {                                      // lanes that share an anchor cell take turns; leftovers: global atomics
 #pragma unroll 1
-                for (int round = 0; round < 3 && __any(pending); ++round) {
-                    bool won = false;
+                for (int round = 0; round < 2 && __any(pending); ++round) {
+                    bool w2 = false;
                     if (pending) {
                         claim[a] = (unsigned char)lane;
-                        won = claim[a] == (unsigned char)lane;          // same wave: LDS executes in order
+                        w2 = claim[a] == (unsigned char)lane;
                     }
                     asm volatile("" ::: "memory");
-                    if (won) {
-                        f32x4 c0 = Gq[a];
-                        c0 += k00 * d;
-                        Gq[a] = c0;
-                        asm volatile("" ::: "memory");
-                        f32x4 c1 = Gq[a + 1];
-                        c1 += k01 * d;
-                        Gq[a + 1] = c1;
-                        asm volatile("" ::: "memory");
-                        f32x4 c2 = Gq[a + RS];
-                        c2 += k10 * d;
-                        Gq[a + RS] = c2;
-                        asm volatile("" ::: "memory");
-                        f32x4 c3 = Gq[a + RS + 1];
-                        c3 += k11 * d;
-                        Gq[a + RS + 1] = c3;
-                    }
+                    f32x4* const q2 = w2 ? Gq + a : Dump;
+                    f32x4 e0 = q2[0];
+                    e0 = __builtin_elementwise_fma(f32x4{k00, k00, k00, k00}, d, e0);
+                    q2[0] = e0;
                     asm volatile("" ::: "memory");
-                    pending = pending && !won;
+                    f32x4 e1 = q2[1];
+                    e1 = __builtin_elementwise_fma(f32x4{k01, k01, k01, k01}, d, e1);
+                    q2[1] = e1;
+                    asm volatile("" ::: "memory");
+                    f32x4 e2 = q2[RS];
+                    e2 = __builtin_elementwise_fma(f32x4{k10, k10, k10, k10}, d, e2);
+                    q2[RS] = e2;
+                    asm volatile("" ::: "memory");
+                    f32x4 e3 = q2[RS + 1];
+                    e3 = __builtin_elementwise_fma(f32x4{k11, k11, k11, k11}, d, e3);
+                    q2[RS + 1] = e3;
+                    asm volatile("" ::: "memory");
+                    pending = pending && !w2;
                 }
-                if (__any(pending)) {                                  // more than three lanes on one anchor: global atomics
-                    if (pending) {
-                        const int wr = a / RS, wc = a - wr * RS, iy = yw0 + wr, ix = xw0 + wc;
-                        const bool top = iy >= 0, bot = iy + 1 <= H - 1, lef = ix >= 0, rig = ix + 1 <= W - 1;
-                        float* gp = p.gin + ((size_t)b * C + grp * 16 + 4 * wid) * HW + iy * W + ix;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            if (top && lef) atomicAdd(gp + (size_t)k * HW, k00 * d[k]);
-                            if (top && rig) atomicAdd(gp + (size_t)k * HW + 1, k01 * d[k]);
-                            if (bot && lef) atomicAdd(gp + (size_t)k * HW + W, k10 * d[k]);
-                            if (bot && rig) atomicAdd(gp + (size_t)k * HW + W + 1, k11 * d[k]);
-                        }
+                if (pending) {
+                    const int wr = a / RS, wc = a - wr * RS, iy = yw0 + wr, ix = xw0 + wc;
+                    const bool top = iy >= 0, bot = iy + 1 <= H - 1, lef = ix >= 0, rig = ix + 1 <= W - 1;
+                    float* gp = p.gin + ((size_t)b * C + grp * 16 + 4 * wid) * HW + iy * W + ix;
+#pragma unroll 1
+                    for (int k = 0; k < 4; ++k) {
+                        const float dk = k == 0 ? d[0] : (k == 1 ? d[1] : (k == 2 ? d[2] : d[3]));
+                        if (top && lef) atomicAdd(gp + (size_t)k * HW, k00 * dk);
+                        if (top && rig) atomicAdd(gp + (size_t)k * HW + 1, k01 * dk);
+                        if (bot && lef) atomicAdd(gp + (size_t)k * HW + W, k10 * dk);
+                        if (bot && rig) atomicAdd(gp + (size_t)k * HW + W + 1, k11 * dk);
                     }
                 }
             }
         }
+        if (more) win_load(grp + 1);                                   // (in flight under the flush; between steps the registers are free)
         // --- flush this group's grad_input planes (touched in-image cells: one atomic per cell and channel), next window
         asm volatile("" ::: "memory");
         for (int i = lane; i < CELLS; i += 64) {
@@ -1176,55 +939,63 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnq_kernel(DcnBwdQuadParams p,
     // strays (rare): a (pixel, tap) whose corners left the window.  Every wave redoes the tap for ITS channels of all
     // groups, a channel per lane: dcol as a dot product over the output channels, corners from global memory
     // (clamped, zero weight outside the image), grad_input through global atomics.
-    const int ns = *nstray;
-    for (int k = 0; k < ns; ++k) {
-        const int e = strays[k], t = e >> 6, px = e & 63;
-        const int py = y0 + (px >> Q::SHIFT), pxx = x0 + (px & (TC - 1)), pp = py * W + pxx;
-        const f32x4 rec = Geo[e];
-        const float h = (float)(py - 1 + t / 3) + p.off[((size_t)b * 18 + 2 * t) * HW + pp];
-        const float w = (float)(pxx - 1 + t % 3) + p.off[((size_t)b * 18 + 2 * t + 1) * HW + pp];
-        const int h0 = (int)floorf(h), w0 = (int)floorf(w);
-        const bool top = h0 >= 0, bot = h0 + 1 <= H - 1, lef = w0 >= 0, rig = w0 + 1 <= W - 1;
-        const float f00 = (top && lef) ? 1.f : 0.f, f01 = (top && rig) ? 1.f : 0.f, f10 = (bot && lef) ? 1.f : 0.f,
-                    f11 = (bot && rig) ? 1.f : 0.f;
-        const int cy0 = top ? h0 : 0, cy1 = bot ? h0 + 1 : H - 1, cx0 = lef ? w0 : 0, cx1 = rig ? w0 + 1 : W - 1;
-        const int o00 = cy0 * W + cx0, o01 = cy0 * W + cx1, o10 = cy1 * W + cx0, o11 = cy1 * W + cx1;
-        const float lh = rec.y, lw = rec.z, hh = 1.0f - lh, hw = 1.0f - lw, mk = rec.w;
-        float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
-        for (int cb = 0; cb < 4 * G; cb += 64) {
-            const int ci = cb + lane;                                  // (group, channel of the quad)
-            if (ci < 4 * G) {
-                const int c = (ci >> 2) * 16 + 4 * wid + (ci & 3);
-                float d = 0.0f;
-                for (int o = 0; o < g.Co; ++o)
-                    d = fmaf(p.w[((size_t)o * C + c) * 9 + t], Go[(o >> 2) * (4 * NPX) + px * 4 + (o & 3)], d);
-                const float* pl = p.in + ((size_t)b * C + c) * HW;
-                s00 = fmaf(d, pl[o00] * f00, s00);
-                s01 = fmaf(d, pl[o01] * f01, s01);
-                s10 = fmaf(d, pl[o10] * f10, s10);
-                s11 = fmaf(d, pl[o11] * f11, s11);
-                float* gp = p.gin + ((size_t)b * C + c) * HW;
-                const float dm = d * mk;
-                if (f00 != 0.0f) atomicAdd(gp + o00, hh * hw * dm);
-                if (f01 != 0.0f) atomicAdd(gp + o01, hh * lw * dm);
-                if (f10 != 0.0f) atomicAdd(gp + o10, lh * hw * dm);
-                if (f11 != 0.0f) atomicAdd(gp + o11, lh * lw * dm);
+    if (stray_bits[18]) {
+      for (int wi = 0; wi < 18; ++wi) {
+        unsigned bits = stray_bits[wi];
+        while (bits) {
+            const int e = wi * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const int t = e >> 6, px = e & 63;
+            const int py = y0 + (px >> Q::SHIFT), pxx = x0 + (px & (TC - 1)), pp = py * W + pxx;
+            const float h = (float)(py - 1 + t / 3) + p.off[((size_t)b * 18 + 2 * t) * HW + pp];
+            const float w = (float)(pxx - 1 + t % 3) + p.off[((size_t)b * 18 + 2 * t + 1) * HW + pp];
+            const float hf = floorf(h), wf = floorf(w);
+            const int h0 = (int)hf, w0 = (int)wf;
+            const bool top = h0 >= 0, bot = h0 + 1 <= H - 1, lef = w0 >= 0, rig = w0 + 1 <= W - 1;
+            const float f00 = (top && lef) ? 1.f : 0.f, f01 = (top && rig) ? 1.f : 0.f, f10 = (bot && lef) ? 1.f : 0.f,
+                        f11 = (bot && rig) ? 1.f : 0.f;
+            const int cy0 = top ? h0 : 0, cy1 = bot ? h0 + 1 : H - 1, cx0 = lef ? w0 : 0, cx1 = rig ? w0 + 1 : W - 1;
+            const int o00 = cy0 * W + cx0, o01 = cy0 * W + cx1, o10 = cy1 * W + cx0, o11 = cy1 * W + cx1;
+            const float lh = h - hf, lw = w - wf, hh = 1.0f - lh, hw = 1.0f - lw, mk = p.mask[((size_t)b * 9 + t) * HW + pp];
+            float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
+            for (int cb = 0; cb < 4 * G; cb += 64) {
+                const int ci = cb + lane;                              // (group, channel of the quad)
+                if (ci < 4 * G) {
+                    const int c = (ci >> 2) * 16 + 4 * wid + (ci & 3);
+                    float d = 0.0f;
+                    for (int o = 0; o < g.Co; ++o)
+                        d = fmaf(p.w[((size_t)o * C + c) * 9 + t], Go[(((o >> 4) * 4 + (o & 3)) * NPX + px) * 4 + ((o >> 2) & 3)], d);
+                    const float* pl = p.in + ((size_t)b * C + c) * HW;
+                    s00 = fmaf(d, pl[o00] * f00, s00);
+                    s01 = fmaf(d, pl[o01] * f01, s01);
+                    s10 = fmaf(d, pl[o10] * f10, s10);
+                    s11 = fmaf(d, pl[o11] * f11, s11);
+                    float* gp = p.gin + ((size_t)b * C + c) * HW;
+                    const float dm = d * mk;
+                    if (f00 != 0.0f) atomicAdd(gp + o00, hh * hw * dm);
+                    if (f01 != 0.0f) atomicAdd(gp + o01, hh * lw * dm);
+                    if (f10 != 0.0f) atomicAdd(gp + o10, lh * hw * dm);
+                    if (f11 != 0.0f) atomicAdd(gp + o11, lh * lw * dm);
+                }
             }
-        }
 #pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) {
-            s00 += __shfl_xor(s00, sft, 64); s01 += __shfl_xor(s01, sft, 64);
-            s10 += __shfl_xor(s10, sft, 64); s11 += __shfl_xor(s11, sft, 64);
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                s00 += __shfl_xor(s00, sft, 64); s01 += __shfl_xor(s01, sft, 64);
+                s10 += __shfl_xor(s10, sft, 64); s11 += __shfl_xor(s11, sft, 64);
+            }
+            if (lane == 0) U[e] = f32x4{s00, s01, s10, s11};           // (the window part of a stray is zero)
         }
-        if (lane == 0) U[e] = f32x4{s00, s01, s10, s11};               // (the window part of a stray is zero)
+      }
     }
     __syncthreads();
     const f32x4* const U0 = reinterpret_cast<const f32x4*>(smem);
     for (int e = tid; e < 9 * NPX; e += IG_THREADS) {
         const int t = e >> 6, px = e & 63, pp = pixel(px);
-        const f32x4 rec = Geo[e];
         const f32x4 a = ((U0[e] + U0[9 * NPX + e]) + U0[2 * 9 * NPX + e]) + U0[3 * 9 * NPX + e];
-        const float lh = rec.y, lw = rec.z, hh = 1.0f - lh, hw = 1.0f - lw, mk = rec.w;
+        const int py = y0 + (px >> Q::SHIFT), pxx = x0 + (px & (TC - 1));
+        const float h = (float)(py - 1 + t / 3) + p.off[((size_t)b * 18 + 2 * t) * HW + pp];
+        const float w = (float)(pxx - 1 + t % 3) + p.off[((size_t)b * 18 + 2 * t + 1) * HW + pp];
+        const float lh = h - floorf(h), lw = w - floorf(w), hh = 1.0f - lh, hw = 1.0f - lw, mk = p.mask[((size_t)b * 9 + t) * HW + pp];
         p.gmask[((size_t)b * 9 + t) * HW + pp] = hh * hw * a[0] + hh * lw * a[1] + lh * hw * a[2] + lh * lw * a[3];
         p.goff[((size_t)b * 18 + 2 * t) * HW + pp] = (-hw * a[0] - lw * a[1] + hw * a[2] + lw * a[3]) * mk;
         p.goff[((size_t)b * 18 + 2 * t + 1) * HW + pp] = (-hh * a[0] + hh * a[1] - lh * a[2] + lh * a[3]) * mk;
@@ -1491,7 +1262,7 @@ struct DcnScatterCtx {
     int wy0, wx0, WR, WC, WSZ;                // window (unclipped; WR = WC = 0: no window, global atomics only)
     float4* wp;                               // this wave's window planes
     float4* dump;                             // a private cell for inactive lanes
-    volatile unsigned char* claim;            // this wave's claim map [WSZ]
+    lds_vu8* claim;                           // this wave's claim map [WSZ]
 };
 __device__ __forceinline__ void dcn_scatter_window(DcnScatterCtx& x, const DcnGeom& g, int TR, int WSZmax) {
     x.wy0 = x.y0 * g.sh - g.ph - CI_MARGIN;
@@ -1665,7 +1436,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int 
     dcn_scatter_window(x, g, p.TR, p.WSZmax);
     x.wp = reinterpret_cast<float4*>(win) + (size_t)wid * x.WSZ;
     x.dump = reinterpret_cast<float4*>(win + CI_CG * p.WSZmax) + tid;
-    x.claim = reinterpret_cast<unsigned char*>(win + CI_CG * p.WSZmax + 4 * 256) + wid * p.claim_sz;
+    x.claim = (lds_vu8*)(reinterpret_cast<unsigned char*>(win + CI_CG * p.WSZmax + 4 * 256) + wid * p.claim_sz);
     *x.dump = make_float4(0.f, 0.f, 0.f, 0.f);
     dcn_scatter_group(x, g, p.geo + (size_t)b * T * HoWo, p.dcol + (size_t)b * T * g.C * HoWo,
                       p.gin + (size_t)b * g.C * HW, cg * CI_CG + wid * 4, lane);
@@ -1814,7 +1585,7 @@ __global__ __launch_bounds__(512, 6) void dcn_bwd_data_kernel(DcnBwdDataParams p
     dcn_scatter_window(x, g, p.TR, p.WSZmax);
     x.wp = reinterpret_cast<float4*>(win) + (size_t)wid * x.WSZ;
     x.dump = reinterpret_cast<float4*>(win + CI_CG * p.WSZmax) + tid;
-    x.claim = reinterpret_cast<unsigned char*>(win + CI_CG * p.WSZmax + 4 * 256) + wid * p.claim_sz;
+    x.claim = (lds_vu8*)(reinterpret_cast<unsigned char*>(win + CI_CG * p.WSZmax + 4 * 256) + wid * p.claim_sz);
     *x.dump = make_float4(0.f, 0.f, 0.f, 0.f);
     float* gin_b = p.gin + (size_t)b * g.C * HW;
     const int cg_end = (part + 1) * p.ncg / p.nsplit;
@@ -2085,6 +1856,8 @@ int pick_bm(int M, long long N) {
 
 constexpr int kFusedMinTilesDefault = 512;
 int g_fused_min_tiles = kFusedMinTilesDefault;      // cnuda_dcn_set_fused_min_tiles (tests)
+inline int kQuadBackwardDefault() { const char* e = getenv("CNUDA_DCNQ"); return e && e[0] == '1'; }
+int g_quad_backward = kQuadBackwardDefault();       // cnuda_dcn_set_quad_backward (tests, A/B)
 
 struct DcnPlan {
     int T, K, Kp, bm, Mp;           // forward pack [Kp][Mp]
@@ -2155,6 +1928,11 @@ DcnPlan make_plan(const DcnGeom& g) {
 
 using namespace cnuda;
 
+extern "C" int cnuda_dcn_set_quad_backward(int on) {
+    const int prev = g_quad_backward;
+    g_quad_backward = on < 0 ? kQuadBackwardDefault() : (on != 0);
+    return prev;
+}
 extern "C" int cnuda_dcn_set_fused_min_tiles(int min_tiles) {
     const int prev = g_fused_min_tiles;
     g_fused_min_tiles = min_tiles < 1 ? kFusedMinTilesDefault : min_tiles;
@@ -2389,17 +2167,18 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
         if (int rc = check_launch("cnuda_dcn_v2_backward(weight)")) return rc;
         launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, wst);
     }
-    // the on-chip form (dcnb_kernel): the layers dcnw_fwd_kernel takes.  CNUDA_DCNB=0: the three-kernel form below
-    static const int dcnb_mode = getenv("CNUDA_DCNB") ? atoi(getenv("CNUDA_DCNB")) : 0;
-    if (dcnb_mode && matrix_mode() == 0 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 &&
+    // the one-kernel form on channel-quad planes (dcnq_kernel; the layers dcnw_fwd_kernel takes).  OFF by default: per layer
+    // it beats the three kernels below when neighbouring pixels sample neighbouring cells (1058 vs 1298 us at 64 -> 64,
+    // 128 x 128, B = 32) and loses when offsets are independent noise (1840 vs 1573 us); inside the benched step it
+    // measured 82.7 / 83.2 vs 82.2 / 82.7 ms.  CNUDA_DCNQ=1 or cnuda_dcn_set_quad_backward(1).
+    if (g_quad_backward && matrix_mode() == 0 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 &&
         dw == 1 && C % 16 == 0 && Cout <= 64 && (W == 16 || W == 32 || W == 64 || W == 128) &&
-        H % (IG_BN / (W >= 32 ? 32 : W)) == 0 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB) {
-        if (dcnb_mode == 3) {
-            const int tc = W >= 32 ? 32 : 16, tiles_x = W / tc, n_tiles = (int)(q.N / 64);
-            const float* Aq = launch_pack(weight, wt, (size_t)12 * C * 64 * sizeof(float), Cout, C, q.T, PACK_DCN_QUAD, 12 * C, 64, 0, st);
-            DcnBwdQuadParams pq{g, input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask};
-            ProfScope scope(st, 3);
-            scope.name("dcnq_kernel<%d>", tc);
+        H % (64 / (W >= 32 ? 32 : 16)) == 0 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB) {
+        const int tc = W >= 32 ? 32 : 16, tiles_x = W / tc, n_tiles = (int)(q.N / 64);
+        const float* Aq = launch_pack(weight, wt, (size_t)12 * C * 64 * sizeof(float), Cout, C, q.T, PACK_DCN_QUAD, 12 * C, 64, 0, st);
+        DcnBwdQuadParams pq{g, input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask};
+        ProfScope scope(st, 3);
+        scope.name("dcnq_kernel<%d>", tc);
 #define CNUDA_DCNQ_LAUNCH(TCV)                                                                                         \
     do {                                                                                                               \
         const size_t lds = (size_t)DqTile<TCV>::END * sizeof(float);                                                   \
@@ -2411,46 +2190,9 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
         }                                                                                                              \
         CNUDA_LAUNCH((dcnq_kernel<TCV>), dim3(n_tiles), dim3(IG_THREADS), lds, st, pq, Aq, n_tiles, tiles_x);          \
     } while (0)
-            if (tc == 32) CNUDA_DCNQ_LAUNCH(32); else CNUDA_DCNQ_LAUNCH(16);
+        if (tc == 32) CNUDA_DCNQ_LAUNCH(32); else CNUDA_DCNQ_LAUNCH(16);
 #undef CNUDA_DCNQ_LAUNCH
-            return check_launch("cnuda_dcn_v2_backward(quad planes)");
-        }
-        const int Mp = 10 * C;
-        const float* Ad = launch_pack(weight, wt, (size_t)64 * Mp * sizeof(float), Cout, C, q.T, PACK_DCN_DCOL, 64, Mp, 0, st);
-        if (dcnb_mode < 2) {
-            DcnPrepParams pp{g, weight, offset, mask, wt, geo, 0};
-            CNUDA_LAUNCH(dcn_prep_kernel, dim3(stream_grid((long long)B * q.T * HoWo, 256)), dim3(256), 0, st, pp);
-        }
-        const int tc = W >= 32 ? 32 : W, tiles_x = W / tc, n_tiles = (int)(q.N / IG_BN);
-        DcnBwdWinParams p{g, input, offset, mask, grad_output, grad_offset, grad_mask, dcol, grad_input};
-        const bool scatter = dcnb_mode >= 2;
-        {
-            ProfScope scope(st, 3);
-            scope.name("dcnb_kernel<%d, %s>", tc, scatter ? "true" : "false");
-#define CNUDA_DCNB_LAUNCH(TCV, SC)                                                                                     \
-    do {                                                                                                               \
-        const size_t lds = (size_t)(SC ? 32 : 16) * DwTile<TCV>::PL * sizeof(float);                                   \
-        static bool raised = false;                                                                                    \
-        if (lds > 64 * 1024 && !raised) {                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnb_kernel<TCV, SC>),                            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
-            raised = true;                                                                                             \
-        }                                                                                                              \
-        CNUDA_LAUNCH((dcnb_kernel<TCV, SC>), dim3(n_tiles), dim3(IG_THREADS), lds, st, p, Ad, Mp, n_tiles, tiles_x);   \
-    } while (0)
-            if (scatter) { if (tc == 32) CNUDA_DCNB_LAUNCH(32, true); else CNUDA_DCNB_LAUNCH(16, true); }
-            else { if (tc == 32) CNUDA_DCNB_LAUNCH(32, false); else CNUDA_DCNB_LAUNCH(16, false); }
-#undef CNUDA_DCNB_LAUNCH
-        }
-        if (!scatter) {
-            DcnCol2imParams pc{g, dcol, geo, grad_input, q.TR, q.TC, q.tc_shift, q.tiles_y, q.tiles_x, q.ncg, q.WSZmax,
-                               q.claim_sz};
-            const int n_wg = B * q.tiles_y * q.tiles_x * q.ncg;
-            ProfScope scope(st, 2);
-            scope.name("dcn_col2im_kernel");
-            CNUDA_LAUNCH(dcn_col2im_kernel, dim3(n_wg), dim3(256), q.col2im_lds, st, pc, n_wg);
-        }
-        return check_launch("cnuda_dcn_v2_backward(window)");
+        return check_launch("cnuda_dcn_v2_backward(quad planes)");
     }
     {
         // (1) dcol = W^T x grad_output as a 1x1 implicit GEMM, then the two streaming consumers

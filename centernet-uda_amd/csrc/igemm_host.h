@@ -16,13 +16,11 @@ enum PackMode {
     PACK_HALO_FWD = 3,    // dst[k = (g*9 + tap)*16 + ci][m = o] = W[o][16g + ci][tap]                     (C % 16 == 0)
     PACK_HALO_DGRAD = 4,  // dst[k = (g*9 + tap)*16 + oi][m = c] = W[16g + oi][c][8 - tap]: the input gradient of a
                           // 3x3 / stride 1 / padding 1 convolution is that convolution over grad_y with flipped taps (Co % 16 == 0)
-    // DCN column gradient on-chip (dcn.hip dcnb_kernel): dst[k = o][m = (g*10 + tap)*16 + ci] = W[o][16g + ci][tap] for
-    // tap < 9, zero for the tenth slot of a group (taps come in pairs: 32 GEMM rows = 2 taps x 16 channels); Mp = 10 C / 16 * 16
-    PACK_DCN_DCOL = 5,
-    // DCN backward on channel-quad planes (dcn.hip dcnq_kernel): A fragments of v_mfma_f32_16x16x4_f32 in issue order,
-    // dst[k = ((g*4 + quad)*3 + rt)*16 + s][m = lane] = W[o = 4s + (lane >> 4)][c = 16g + 4 quad + (lane & 3)][tap = rt + 3*((lane & 15) >> 2)]
-    // (the fourth tap slot of a row tile and o >= Co are zero); Kp = 12 * C / 16 * 16 = 12 C... rows, Mp = 64
-    PACK_DCN_QUAD = 6,
+    // DCN backward on channel-quad planes (dcn.hip dcnq_kernel): A fragments of v_mfma_f32_16x16x4_f32 in issue order.  Block
+    // ((g*4 + quad)*3 + rt) holds 1024 floats, index s4*256 + lane*4 + (s & 3) (a lane's four k-steps 4 s4 .. 4 s4 + 3 are one
+    // 16-byte load) = W[o = 4s + (lane >> 4)][c = 16g + 4 quad + (lane & 3)][tap = rt + 3*((lane & 15) >> 2)]; the fourth tap slot
+    // of a row tile and o >= Co are zero.  As a [Kp][Mp] image: Kp = 12 C rows of Mp = 64
+    PACK_DCN_QUAD = 5,
 };
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }

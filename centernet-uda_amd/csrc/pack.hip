@@ -25,13 +25,13 @@ __global__ void pack_kernel(const float* __restrict__ W, float* __restrict__ dst
             if (k < T * C && m < Co) { const int g = k / (16 * T), r = k - g * 16 * T; tap = r >> 4; c = 16 * g + (r & 15); o = m; }
         } else if (mode == PACK_HALO_DGRAD) {
             if (k < T * Co && m < C) { const int g = k / (16 * T), r = k - g * 16 * T; tap = T - 1 - (r >> 4); o = 16 * g + (r & 15); c = m; }
-        } else if (mode == PACK_DCN_DCOL) {
-            if (k < Co && m < (T + 1) * C) { const int g = m / (16 * (T + 1)), r = m - g * 16 * (T + 1); tap = r >> 4; c = 16 * g + (r & 15); o = tap < T ? k : -1; }
         } else if (mode == PACK_DCN_QUAD) {
             // k = ((g*4 + quad)*3 + rt)*16 + s, m = lane: row i = lane & 15 = (tap slot, channel of the quad), k-step column lane >> 4
-            const int s_ = k & 15, rt = (k >> 4) % 3, gq = (k >> 4) / 3, slot = (m & 15) >> 2;
-            tap = rt + 3 * slot; c = 4 * gq + (m & 3);
-            o = (slot < 3 && 4 * s_ + (m >> 4) < Co && c < C) ? 4 * s_ + (m >> 4) : -1;
+            // (a lane's four k-steps 4 s4 .. 4 s4 + 3 are one 16-byte load: flat index in the block = s4*256 + lane*4 + (s & 3))
+            const int f = (k & 15) * 64 + m, ln = (f >> 2) & 63, s_ = 4 * (f >> 8) + (f & 3);
+            const int rt = (k >> 4) % 3, gq = (k >> 4) / 3, slot = (ln & 15) >> 2;
+            tap = rt + 3 * slot; c = 4 * gq + (ln & 3);
+            o = (slot < 3 && 4 * s_ + (ln >> 4) < Co && c < C) ? 4 * s_ + (ln >> 4) : -1;
             if (o < 0) { tap = 0; c = 0; }
         } else {   // PACK_DGRAD: Cpad = Co rounded up to the K chunk, rows o >= Co stay zero
             if (k < T * Cpad && m < C) { tap = k / Cpad; o = k % Cpad; c = m; if (o >= Co) o = -1; }
@@ -347,14 +347,10 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
                 const int g = k / (16 * j.T), r = k - g * 16 * j.T;
                 v = j.src[((size_t)(16 * g + (r & 15)) * j.C + m) * j.T + (j.T - 1 - (r >> 4))];
             }
-        } else if (j.mode == PACK_DCN_DCOL) {
-            if (k < j.Co && m < (j.T + 1) * j.C) {
-                const int g = m / (16 * (j.T + 1)), r = m - g * 16 * (j.T + 1);
-                if ((r >> 4) < j.T) v = j.src[((size_t)k * j.C + 16 * g + (r & 15)) * j.T + (r >> 4)];
-            }
         } else if (j.mode == PACK_DCN_QUAD) {
-            const int s_ = k & 15, rt = (k >> 4) % 3, gq = (k >> 4) / 3, slot = (m & 15) >> 2;
-            const int o = 4 * s_ + (m >> 4), c = 4 * gq + (m & 3);
+            const int f = (k & 15) * 64 + m, ln = (f >> 2) & 63, s_ = 4 * (f >> 8) + (f & 3);
+            const int rt = (k >> 4) % 3, gq = (k >> 4) / 3, slot = (ln & 15) >> 2;
+            const int o = 4 * s_ + (ln >> 4), c = 4 * gq + (ln & 3);
             if (slot < 3 && o < j.Co && c < j.C) v = j.src[((size_t)o * j.C + c) * j.T + rt + 3 * slot];
         } else if (j.mode == PACK_DGRAD) {
             if (k < j.T * j.cpad && m < j.C) {

@@ -13,15 +13,18 @@ Keys: the kernel's symbol name with the namespace prefix and the argument list d
 
 MANIFEST = {
     'dcnw_fwd_kernel<64, 32>': [
-        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
-        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
-        'tests/test_gpu_dcn.py::test_known_answer_half_pixel_offsets_are_box_blurs',
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[64to64_128sq',
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[128to64_64sq',
+        'tests/test_gpu_dcn.py::test_quad_plane_backward_known_answers',
+    ],
+    'dcnw_fwd_kernel<64, 16>': [
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle[dla_64',
     ],
     'hconv_kernel<32, 256, HconvFwd>': [
         'tests/test_gpu_fullsize.py::test_full_size_halo_tile_convolutions_match_fp64[64to27_128sq',
+        'tests/test_gpu_fullsize.py::test_full_size_halo_tile_convolutions_match_fp64[128to27_64sq',
     ],
     'hconv_kernel<32, 128, HconvFwd>': [
-        'tests/test_gpu_fullsize.py::test_full_size_halo_tile_convolutions_match_fp64[128to27_64sq',
         'tests/test_gpu_ops.py::test_halo_tile_convolution_3x3',
     ],
     'adam_kernel': [
@@ -73,6 +76,16 @@ MANIFEST = {
         'tests/test_gpu_ops.py::test_cat_add_split',
         'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
         'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+    ],
+    # (opt-in: hr.dcn_quad_backward / CNUDA_DCNQ=1; not launched by the default benched step)
+    'dcnq_kernel<32>': [
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[64to64_128sq_quad',
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[128to64_64sq_quad',
+        'tests/test_gpu_dcn.py::test_quad_plane_backward_vs_oracle[w32',
+        'tests/test_gpu_dcn.py::test_quad_plane_backward_known_answers',
+    ],
+    'dcnq_kernel<16>': [
+        'tests/test_gpu_dcn.py::test_quad_plane_backward_vs_oracle[w16',
     ],
     'dcn_bwd_data_kernel': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[64to64_128sq_one_launch',
@@ -173,8 +186,8 @@ MANIFEST = {
     'igemm_fwd_kernel<64, DcnColsBufLoader, false>': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[256to128_32sq',
     ],
-    'igemm_fwd_kernel<64, DcnFwdLoaderT<true>, false>': [
-        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+    'igemm_fwd_kernel<64, DcnFwdLoaderT<true>, false>': [      # (since round 4: only layers the window kernel does not take)
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[32to64_96sq',
     ],
     'igemm_fwd_shortk_kernel<128, ConvFwdBufLoader, 64>': [
         'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',

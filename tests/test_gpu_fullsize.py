@@ -273,6 +273,10 @@ DCN_LAYERS = {
     '64to64_128sq_one_launch': dict(B=8, C=64, Co=64, S=128, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel', 'igemm_fwd_shortk_kernel']),
     '128to64_64sq': dict(B=16, C=128, Co=64, S=64, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_col2im_kernel', 'dcn_coord_grad_kernel', 'igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>']),
     '128to64_64sq_one_launch': dict(B=32, C=128, Co=64, S=64, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel']),
+    # the one-kernel backward on channel-quad planes (opt-in: hr.dcn_quad_backward / CNUDA_DCNQ=1)
+    '64to64_128sq_quad': dict(B=4, C=64, Co=64, S=128, quad=True, kernels=['dcnw_fwd_kernel<64, 32>', 'dcnq_kernel<32>', 'igemm_wgrad_kernel<DcnColWBufLoader, 64, 64>']),
+    '128to64_64sq_quad': dict(B=16, C=128, Co=64, S=64, quad=True, kernels=['dcnw_fwd_kernel<64, 32>', 'dcnq_kernel<32>']),
+    '32to64_96sq': dict(B=8, C=32, Co=64, S=96, kernels=['igemm_fwd_kernel<64, DcnFwdLoaderT<true>']),      # a map the window kernels do not take
     '128to128_64sq': dict(B=16, C=128, Co=128, S=64, kernels=['igemm_fwd_kernel<128, DcnFwdLoaderT<true>']),
     '256to256_32sq': dict(B=32, C=256, Co=256, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_kernel<128, DcnColsBufLoader']),
     '256to128_32sq': dict(B=32, C=256, Co=128, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_kernel<64, DcnColsBufLoader']),
@@ -283,6 +287,12 @@ _DCN_CASES = [(n, o) for n in DCN_LAYERS for o in ((0.3, 1.0, 6.0) if DCN_LAYERS
 @pytest.mark.parametrize('layer,off_scale', _DCN_CASES,      # 0.3 px: col2im's DPP ranking path; 6 px: strays beyond the LDS window
                          ids=['%s-pm%gpx' % (n, o) for n, o in _DCN_CASES])
 def test_full_size_dcn_layer_matches_the_oracle(layer, off_scale):
+    import hip_runtime as hr
+    with hr.dcn_quad_backward(bool(DCN_LAYERS[layer].get('quad'))):
+        _full_size_dcn_layer(layer, off_scale)
+
+
+def _full_size_dcn_layer(layer, off_scale):
     """`dcn_v2_cuda.cu:42-341` at the layer shapes the bench runs, VALUES against the CPU oracle (forward, the saved
     columns, all five gradients, 1e-4 of each tensor's magnitude), through the product's autograd path (which keeps
     the columns) and through the literal `_ext` entry points (which do not) -- and again while a second stream runs
@@ -324,7 +334,7 @@ def test_full_size_dcn_layer_matches_the_oracle(layer, off_scale):
     names = sorted(short(n) for n in log.names)
     print(names)
     import os
-    if not any(os.environ.get(v) == '0' for v in ('CNUDA_BUF', 'CNUDA_WS', 'CNUDA_SHORTK', 'CNUDA_NAMES')):     # (tests/test_gpu_kernel_switches.py)
+    if not any(os.environ.get(v) == '0' for v in ('CNUDA_BUF', 'CNUDA_WS', 'CNUDA_SHORTK')):     # (tests/test_gpu_kernel_switches.py)
         for want_kernel in DCN_LAYERS[layer]['kernels']:
             assert any(n.startswith(want_kernel) for n in names), (want_kernel, names)
     y, gx, goff, gm, gw, gb, cols = res

@@ -65,7 +65,7 @@ def test_manifest_tests_really_launch_their_kernels(request):
     import conftest
     from kernel_manifest import MANIFEST
     ran = {nodeid: {short(k) for k in ks} for nodeid, ks in conftest.KERNELS_BY_TEST.items()}
-    filtered = bool(request.config.option.keyword) or any('::' in a for a in request.config.args)
+    filtered = bool(request.config.option.keyword) or any('::' in a or a.endswith('.py') for a in request.config.args)
     collected = [it.nodeid for it in request.session.items]
     wrong, unverified = [], []
     for kernel, prefixes in sorted(MANIFEST.items()):
