@@ -61,14 +61,17 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
 
 def dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h, stride_w,
                     pad_h, pad_w, dilation_h, dilation_w, deformable_group, _columns=None, _grad_weight=None,
-                    _grad_bias=None):
+                    _grad_bias=None, _grad_input=None):
+    """_grad_input: a buffer that already holds another consumer's share of the input's gradient (hip_runtime.fanout):
+    the data-gradient walks add into it instead of into a cleared tensor."""
     hr.require_gpu(input, weight, bias, offset, mask, grad_output)
     input, weight, bias, offset, mask, grad_output = [
         hr.f32c(t) for t in (input, weight, bias, offset, mask, grad_output)]
     B, C, H, W, Co = _shapes(input, weight, offset, mask, kernel_h, kernel_w, deformable_group)
     geom = (B, C, H, W, Co, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
             dilation_h, dilation_w, deformable_group)
-    grads = [torch.empty_like(t) for t in (input, offset, mask)]
+    grads = [_grad_input if _grad_input is not None else torch.empty_like(input), torch.empty_like(offset),
+             torch.empty_like(mask)]
     # the parameter gradients may be written straight into caller-owned buffers (the arena's gradient sink)
     grads += [_grad_weight if _grad_weight is not None else torch.empty_like(weight),
               _grad_bias if _grad_bias is not None else torch.empty_like(bias)]
@@ -77,8 +80,9 @@ def dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kernel_h, ke
     ws = hr.workspace(nbytes, input.device)
     if deformable_group == 1:
         hr.prof_arm('dcn_bwd', B, C, H, W, Co, kernel_h, kernel_w, grad_output.shape[2], grad_output.shape[3])
-    hr.check(L.cnuda_dcn_v2_backward_cols(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
-                                     hr.ptr(grad_output), hr.ptr(_columns), *[hr.ptr(g) for g in grads], *geom,
-                                     hr.ptr(ws), ws.numel(), hr.stream()),
+    hr.check(L.cnuda_dcn_v2_backward_acc(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
+                                         hr.ptr(grad_output), hr.ptr(_columns), hr.ptr(grads[0]),
+                                         1 if _grad_input is not None else 0, *[hr.ptr(g) for g in grads[1:]], *geom,
+                                         hr.ptr(ws), ws.numel(), hr.stream()),
              'dcn_v2_backward')
     return grads        # [grad_input, grad_offset, grad_mask, grad_weight, grad_bias]

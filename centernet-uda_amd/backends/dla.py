@@ -37,6 +37,7 @@ from torch import nn
 
 from hip_runtime import nn as hnn
 from hip_runtime import ops
+from hip_runtime.fanout import fork
 from libs.DCNv2.dcn_v2 import DCN
 
 log = logging.getLogger(__name__)
@@ -180,8 +181,12 @@ class BasicBlock(nn.Module):
             # conv2 + BatchNorm + skip connection + ReLU in one launch (dla.py:48-62)
             return ops.conv2d_infer(y, w2, b2, 1, 1, 0.0, x if residual is None else residual, self._fold_token2,
                                     self._fold_gen)
+        if residual is None or residual is x:
+            # the block's input also is its skip connection: two aliases, one gradient slot (hip_runtime.fanout) -- bn2's
+            # backward leaves the skip's share there, conv1's input-gradient GEMM adds it in its epilogue
+            x, residual = fork(x, 2)
         y = self.bn1(self.conv1(x), relu=True)
-        return self.bn2(self.conv2(y), residual=x if residual is None else residual, relu=True)
+        return self.bn2(self.conv2(y), residual=residual, relu=True)
 
 
 class Root(nn.Module):
@@ -222,19 +227,35 @@ class Tree(nn.Module):
 
     def forward(self, x, children=None):
         children = [] if children is None else children
-        bottom = self.downsample(x) if self.downsample is not None else x
-        residual = self.project(bottom) if self.project is not None else bottom
-        if self.level_root:
-            children.append(bottom)
+        # Every tensor with several consumers is handed out as one alias per consumer (hip_runtime.fanout.fork): the
+        # consumers' gradients then meet in a slot that a convolution's input-gradient epilogue sums, not in passes of
+        # the autograd engine.  A consumer whose output never reaches a loss simply leaves its alias without a gradient.
+        if self.downsample is not None:
+            x_pool, x = fork(x, 2)
+            bottom = self.downsample(x_pool)
+            takers = int(self.project is not None or self.levels == 1) + int(self.level_root)
+            bs = list(fork(bottom, takers)) if takers > 1 else [bottom]
+            residual = self.project(bs.pop()) if self.project is not None else (bs.pop() if self.levels == 1 else None)
+            if self.level_root:
+                children.append(bs.pop())
+        else:                       # bottom is x itself
+            takers = 1 + int(self.project is not None) + int(self.level_root)
+            xs = list(fork(x, takers)) if takers > 1 else [x]
+            x = xs.pop()
+            residual = self.project(xs.pop()) if self.project is not None else x   # identity: forked inside the block
+            if self.level_root:
+                children.append(xs.pop())
         if self.levels == 1:
             x1 = self.tree1(x, residual)
-            x2 = self.tree2(x1)
-            return self.root(x2, x1, *children)
+            x1_next, x1_root = fork(x1, 2)
+            x2 = self.tree2(x1_next)
+            return self.root(x2, x1_root, *children)
         # an inner Tree recomputes its own residual; `residual` above is only
         # evaluated for its BatchNorm side effect (see module docstring)
         x1 = self.tree1(x)
-        children.append(x1)
-        return self.tree2(x1, children=children)
+        x1_next, x1_root = fork(x1, 2)
+        children.append(x1_root)
+        return self.tree2(x1_next, children=children)
 
 
 class DLA(nn.Module):
@@ -260,9 +281,10 @@ class DLA(nn.Module):
     def forward(self, x):
         x = self.base_layer(x)
         feats = []
-        for name in ('level0', 'level1', 'level2', 'level3', 'level4', 'level5'):
-            x = getattr(self, name)(x)
-            feats.append(x)
+        for name in ('level0', 'level1', 'level2', 'level3', 'level4'):
+            x, keep = fork(getattr(self, name)(x), 2)       # the next level's input | the aggregation's
+            feats.append(keep)
+        feats.append(self.level5(x))
         return feats
 
 
@@ -342,11 +364,22 @@ class IDAUp(nn.Module):
             setattr(self, 'up_%d' % i, up)
             setattr(self, 'node_%d' % i, DeformConv(o, o))
 
-    def forward(self, layers, startp, endp):
+    def forward(self, layers, startp, endp, fan=None):
+        """fan: the aggregation's alias plan (_FanPlan) -- `layers` then holds _Aliases and every read takes its own alias."""
         for i in range(startp + 1, endp):
             k = i - startp
-            t = getattr(self, 'up_%d' % k)(getattr(self, 'proj_%d' % k)(layers[i]), layers[i - 1])   # up(..) + skip
-            layers[i] = getattr(self, 'node_%d' % k)(t)
+            src, skip = (layers[i], layers[i - 1]) if fan is None else (layers[i].take(), layers[i - 1].take())
+            t = getattr(self, 'up_%d' % k)(getattr(self, 'proj_%d' % k)(src), skip)   # up(..) + skip
+            t = getattr(self, 'node_%d' % k)(t)
+            layers[i] = t if fan is None else fan.wrap(t)
+
+    @staticmethod
+    def plan(ids, startp, endp, reads, fresh):
+        """the reads of forward() on tensor ids"""
+        for i in range(startp + 1, endp):
+            reads[ids[i]] += 1
+            reads[ids[i - 1]] += 1
+            ids[i] = fresh()
 
 
 class DLAUp(nn.Module):
@@ -362,13 +395,58 @@ class DLAUp(nn.Module):
                 scales[q] = scales[j]
                 in_channels[q] = channels[j]
 
-    def forward(self, layers):
-        layers = list(layers)
+    def forward(self, layers, fan=None):
+        layers = list(layers) if fan is None else [fan.wrap(t) for t in layers]
         out = [layers[-1]]
         for i in range(len(layers) - self.startp - 1):
-            getattr(self, 'ida_%d' % i)(layers, len(layers) - i - 2, len(layers))
+            getattr(self, 'ida_%d' % i)(layers, len(layers) - i - 2, len(layers), fan)
             out.insert(0, layers[-1])
         return out
+
+    def plan(self, ids, reads, fresh):
+        out = [ids[-1]]
+        for i in range(len(ids) - self.startp - 1):
+            IDAUp.plan(ids, len(ids) - i - 2, len(ids), reads, fresh)
+            out.insert(0, ids[-1])
+        return out
+
+
+class _Aliases:
+    """A tensor of the aggregation with one alias per reader (hip_runtime.fanout.fork)."""
+
+    def __init__(self, t, n):
+        self.t, self.pool = t, (list(fork(t, n)) if n > 1 else None)
+
+    def take(self):
+        return self.pool.pop() if self.pool else self.t      # (more readers than planned: the tensor itself -- still correct)
+
+
+class _FanPlan:
+    """How often every tensor of DLAUp + IDAUp is read (layers are re-used as skip connections and as inputs of later
+    aggregation steps): found once by walking the same loops over tensor ids, then every tensor is forked into that many
+    aliases when it is produced."""
+
+    def __init__(self, seg, n_feats):
+        import collections
+        reads = collections.Counter()
+        counter = [n_feats]
+
+        def fresh():
+            counter[0] += 1
+            return counter[0] - 1
+        out = seg.dla_up.plan(list(range(n_feats)), reads, fresh)
+        y = out[:seg.last_level - seg.first_level]
+        IDAUp.plan(y, 0, len(y), reads, fresh)
+        reads[y[-1]] += 1                      # the map the heads read
+        self.reads, self.n = reads, 0
+
+    def start(self):
+        self.n = 0
+        return self
+
+    def wrap(self, t):
+        self.n += 1
+        return _Aliases(t, self.reads[self.n - 1])
 
 
 class _TapeFreeTargetHead(torch.autograd.Function):
@@ -430,14 +508,22 @@ class DLASeg(nn.Module):
 
     def features(self, x):
         """The [B, 64, H/4, W/4] map every head reads (dla.py:500-505)."""
-        feats = self.dla_up(self.base(x))
+        feats = self.base(x)
+        if not (torch.is_grad_enabled() and feats[-1].requires_grad):
+            feats = self.dla_up(feats)
+            y = list(feats[:self.last_level - self.first_level])
+            self.ida_up(y, 0, len(y))
+            return y[-1]
+        # recording a tape: every tensor of the aggregation is handed out as one alias per reader (hip_runtime.fanout)
+        fan = _FanPlan(self, len(feats)).start()
+        feats = self.dla_up(feats, fan)
         y = list(feats[:self.last_level - self.first_level])
-        self.ida_up(y, 0, len(y))
-        return y[-1]
+        self.ida_up(y, 0, len(y), fan)
+        return y[-1].take()
 
     def forward(self, x):
         feat = self.features(x)
-        return {head: getattr(self, head)(feat) for head in self.heads}
+        return {head: getattr(self, head)(f) for head, f in zip(self.heads, fork(feat, len(self.heads)))}
 
     def forward_domains(self, source, target, target_grad_heads=('hm',)):
         """Both domains' forward passes of a UDA step (uda/entropy_minimization.py:18-19) as ONE pass over the
@@ -457,20 +543,25 @@ class DLASeg(nn.Module):
         with hr.domain_groups(2 if self.training else 1):
             feat = self.features(torch.cat([source, target], 0))
         out_s, out_t = {}, {}
-        f_s, f_t = feat[:B], feat[B:]
-        for head in self.heads:
+        f_t = feat[B:]
+        # one alias of the feature map per head (hip_runtime.fanout).  The heads that only see the source half come first:
+        # the backward pass then runs the whole-batch heads first, their gradient takes the map's slot with a plain write
+        # and the source-half heads add theirs on top of its leading images
+        order = sorted(self.heads, key=lambda h: h in target_grad_heads)
+        for head, f in zip(order, fork(feat, len(order))):
             fc = getattr(self, head)
             if head in target_grad_heads or not torch.is_grad_enabled():
-                y = fc(feat)
+                y = fc(f)
                 out_s[head], out_t[head] = y[:B], y[B:]
             else:
-                out_s[head] = fc(f_s)
+                out_s[head] = fc(f, lead=B) if isinstance(fc, hnn.Head) else fc(f[:B])
                 with torch.no_grad():
                     y_t = fc(f_t)
                 # requires_grad like the reference's (uda/entropy_minimization.py:18-19) -- and a loss that does reach
                 # it fails loudly in backward() instead of silently training nothing
                 out_t[head] = _TapeFreeTargetHead.apply(y_t, f_t, head) if f_t.requires_grad else y_t
-        return out_s, out_t
+        # (the dictionaries keep the heads' own order, like two forward() calls)
+        return {h: out_s[h] for h in self.heads}, {h: out_t[h] for h in self.heads}
 
 
 def build(num_classes, num_keypoints=0, head_conv=256, down_ratio=4, freeze_base=False, rotated_boxes=False):

@@ -175,6 +175,8 @@ struct ConvDgradParams {
     float* gx;
     int cop;   // output channels per tap on the K axis: Co rounded up to the 16-deep chunk, so that a chunk
                // never straddles two taps (padded rows carry zero weights; their loads are clamped to Co-1)
+    const float* add = nullptr;   // nullable, shaped like gx (may BE gx): gx = input gradient + add (+ add2) -- the other
+    const float* add2 = nullptr;  // consumers' shares of a tensor's gradient, summed in this epilogue (hip_runtime.fanout)
 };
 struct ConvDgradLoader {
     using Params = ConvDgradParams;
@@ -228,16 +230,25 @@ struct ConvDgradLoader {
     }
     struct Out {
         float* base;
+        const float *addb, *addc;
         int HW;
         __device__ Out(const Params& p, long long n) {
             HW = p.g.H * p.g.W;
             const int ni = (int)n, b = ni / HW, pp = ni - b * HW;
             base = p.gx + (size_t)b * p.g.C * HW + pp;
+            addb = p.add ? p.add + (size_t)b * p.g.C * HW + pp : nullptr;
+            addc = p.add2 ? p.add2 + (size_t)b * p.g.C * HW + pp : nullptr;
         }
-        __device__ __forceinline__ void store(const Params&, int m, float v) { base[(size_t)m * HW] = v; }
+        __device__ __forceinline__ void store(const Params&, int m, float v) {
+            if (addb) v += addb[(size_t)m * HW];
+            if (addc) v += addc[(size_t)m * HW];
+            base[(size_t)m * HW] = v;
+        }
         static constexpr bool kVec4 = true;
         __device__ static bool vec4_ok(const Params& p) { return ((p.g.H * p.g.W) & 3) == 0; }
         __device__ __forceinline__ void store4(const Params&, int m, f32x4 v) {
+            if (addb) v += *reinterpret_cast<const f32x4*>(addb + (size_t)m * HW);
+            if (addc) v += *reinterpret_cast<const f32x4*>(addc + (size_t)m * HW);
             *reinterpret_cast<f32x4*>(base + (size_t)m * HW) = v;
         }
     };
@@ -305,6 +316,7 @@ struct ConvDgradClassParams {
     int py, px, Hc, Wc, ntaps;
     int tap_r[9], tap_s[9];     // kernel coordinates of the class's taps, in packed-K order
     int tap_dy[9], tap_dx[9];   // (py + ph - r) / sh, (px + pw - s) / sw: output pixel of tap t = (qy + dy, qx + dx)
+    const float *add = nullptr, *add2 = nullptr;   // as ConvDgradParams::add, add2
 };
 struct ConvDgradClassLoader {
     using Params = ConvDgradClassParams;
@@ -342,15 +354,23 @@ struct ConvDgradClassLoader {
     }
     struct Out {
         float* base;
+        const float *addb, *addc;
         int HW;
         __device__ Out(const Params& p, long long n) {
             HW = p.g.H * p.g.W;
             const int HcWc = p.Hc * p.Wc;
             const int ni = (int)n, b = ni / HcWc, q = ni - b * HcWc;
             const int qy = q / p.Wc, qx = q - qy * p.Wc;
-            base = p.gx + (size_t)b * p.g.C * HW + (size_t)(p.py + qy * p.g.sh) * p.g.W + p.px + qx * p.g.sw;
+            const size_t o = (size_t)b * p.g.C * HW + (size_t)(p.py + qy * p.g.sh) * p.g.W + p.px + qx * p.g.sw;
+            base = p.gx + o;
+            addb = p.add ? p.add + o : nullptr;
+            addc = p.add2 ? p.add2 + o : nullptr;
         }
-        __device__ __forceinline__ void store(const Params&, int m, float v) { base[(size_t)m * HW] = v; }
+        __device__ __forceinline__ void store(const Params&, int m, float v) {
+            if (addb) v += addb[(size_t)m * HW];
+            if (addc) v += addc[(size_t)m * HW];
+            base[(size_t)m * HW] = v;
+        }
         static constexpr bool kVec4 = false;      // a parity class's pixels are `stride` apart in memory
         __device__ static bool vec4_ok(const Params&) { return false; }
         __device__ __forceinline__ void store4(const Params&, int, f32x4) {}
@@ -800,12 +820,26 @@ extern "C" int cnuda_conv2d_forward_res(const float* x, const float* weight, con
 extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weight, float* grad_x, int B, int C, int H,
                                           int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                                           void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+    return cnuda_conv2d_backward_data_add(grad_y, weight, nullptr, nullptr, grad_x, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, workspace,
+                                          workspace_bytes, stream);
+}
+
+extern "C" int cnuda_conv2d_backward_data_add(const float* grad_y, const float* weight, const float* addend,
+                                              const float* addend2, float* grad_x, int B, int C, int H, int W, int Cout,
+                                              int kh, int kw, int sh, int sw, int ph, int pw, void* workspace,
+                                              size_t workspace_bytes, cnuda_stream_t stream) {
+    if (!addend && addend2) { addend = addend2; addend2 = nullptr; }
     CNUDA_REQUIRE(grad_y && weight && grad_x, "cnuda_conv2d_backward_data: null pointer");
     ConvGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_backward_data")) return rc;
-    if (sh == 1 && sw == 1 && smallc_supported(Cout, C, kh, kw, 1, 1) && kh - 1 - ph >= 0 && kw - 1 - pw >= 0)
-        return smallc_forward(grad_y, weight, nullptr, grad_x, B, Cout, g.Ho, g.Wo, C, kh, kw, 1, kh - 1 - ph,
-                              kw - 1 - pw, -1.0f, 1, workspace, workspace_bytes, (hipStream_t)stream);
+    if (sh == 1 && sw == 1 && smallc_supported(Cout, C, kh, kw, 1, 1) && kh - 1 - ph >= 0 && kw - 1 - pw >= 0) {
+        // (the LDS-tile kernels of the 3- / 16-channel layers have no addend: one elementwise pass behind them)
+        if (int rc = smallc_forward(grad_y, weight, nullptr, grad_x, B, Cout, g.Ho, g.Wo, C, kh, kw, 1, kh - 1 - ph,
+                                    kw - 1 - pw, -1.0f, 1, workspace, workspace_bytes, (hipStream_t)stream))
+            return rc;
+        if (addend) if (int rc = cnuda_add(grad_x, addend, grad_x, (long long)B * C * H * W, stream)) return rc;
+        return addend2 ? cnuda_add(grad_x, addend2, grad_x, (long long)B * C * H * W, stream) : 0;
+    }
     const ConvPlan q = make_plan(g);
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.dgrad_bytes, "cnuda_conv2d_backward_data: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -821,6 +855,7 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
             for (int px = 0; px < sw; ++px) {
                 ConvDgradClassParams cp;
                 cp.g = g; cp.gy = grad_y; cp.gx = grad_x; cp.py = py; cp.px = px; cp.Hc = H / sh; cp.Wc = W / sw;
+                cp.add = addend; cp.add2 = addend2;
                 cp.ntaps = 0;
                 int taps[9];   // at most ceil(kh/sh)*ceil(kw/sw) entries
                 for (int r = 0; r < kh; ++r)
@@ -846,12 +881,12 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
     }
     if (hconv_ok(g, Cout, q.bmd)) {   // (Co % 16 == 0: Kpd = 9 Co, no padded rows)
         const float* Ah = launch_pack(weight, Aws, ig_a_bytes(q.Kpd, q.Mpd), Cout, C, q.T, PACK_HALO_DGRAD, q.Kpd, q.Mpd, 0, st);
-        ConvDgradParams ph{g, grad_y, grad_x, Cout};
+        ConvDgradParams ph{g, grad_y, grad_x, Cout, addend, addend2};
         return launch_hconv<HconvDgrad>(q.bmd, ph, grad_y, Cout, g, Ah, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
     }
     const float* A = launch_pack(weight, Aws, ig_a_bytes(q.Kpd, q.Mpd), Cout, C, q.T, PACK_DGRAD, q.Kpd, q.Mpd,
                                  round_up(Cout, IG_BK), st);
-    ConvDgradParams p{g, grad_y, grad_x, round_up(Cout, IG_BK)};
+    ConvDgradParams p{g, grad_y, grad_x, round_up(Cout, IG_BK), addend, addend2};
     if (buf_ok && sh == 1 && sw == 1)
         return launch_fwd<ConvDgradBufLoader>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
     return launch_fwd<ConvDgradLoader>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");

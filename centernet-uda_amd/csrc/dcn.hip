@@ -2097,6 +2097,18 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
                                           int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
                                           int dw, int dg, void* workspace, size_t workspace_bytes,
                                           cnuda_stream_t stream) {
+    return cnuda_dcn_v2_backward_acc(input, weight, bias, offset, mask, grad_output, columns, grad_input, 0, grad_offset,
+                                     grad_mask, grad_weight, grad_bias, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg,
+                                     workspace, workspace_bytes, stream);
+}
+
+extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight, const float* bias,
+                                         const float* offset, const float* mask, const float* grad_output,
+                                         const float* columns, float* grad_input, int accumulate_input,
+                                         float* grad_offset, float* grad_mask, float* grad_weight, float* grad_bias, int B,
+                                         int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                                         int dh, int dw, int dg, void* workspace, size_t workspace_bytes,
+                                         cnuda_stream_t stream) {
     CNUDA_REQUIRE(!columns || dg == 1, "cnuda_dcn_v2_backward_cols: columns input needs deformable_group == 1");
     CNUDA_REQUIRE(input && weight && offset && mask && grad_output && grad_input && grad_offset && grad_mask &&
                       grad_weight && grad_bias,
@@ -2106,7 +2118,9 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, "cnuda_dcn_v2_backward")) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int T = kh * kw, HoWo = g.Ho * g.Wo;
-    if (hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), st) != hipSuccess)
+    // (every data-gradient walk below ADDS into grad_input -- window flushes and strays are atomics -- so a caller that
+    // already holds another consumer's share of the input's gradient there passes accumulate_input and saves the sum)
+    if (!accumulate_input && hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), st) != hipSuccess)
         return check_launch("cnuda_dcn_v2_backward(memset)");
     if (dg != 1) {
         launch_channel_sum(grad_output, grad_bias, B, Cout, HoWo, st);

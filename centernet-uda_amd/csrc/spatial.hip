@@ -417,8 +417,8 @@ __global__ __launch_bounds__(kT) void dwconvt_bwd_weight_kernel(const float* __r
 }
 
 // ---- elementwise ------------------------------------------------------------
-__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                           long long n4, long long n) {
+// (no __restrict__: out may be a or b -- hip_runtime.fork sums gradients in place)
+__global__ void add_kernel(const float* a, const float* b, float* out, long long n4, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
         reinterpret_cast<float4*>(out)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);

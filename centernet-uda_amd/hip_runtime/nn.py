@@ -101,7 +101,10 @@ class Head(nn.Sequential):
     (dla.py:474-483) with the same state_dict keys ('0.weight', '2.weight', ...).  While a tape is recorded the pair
     is one node (ops.conv_act_conv1x1: the hidden map's gradient in one pass); otherwise the layers run in turn."""
 
-    def forward(self, x):
+    def forward(self, x, lead=None):
+        """lead: run the head on the first `lead` images of x only (backends.dla.DLASeg.forward_domains: the source half of
+        a batched UDA step).  The fused node then takes all of x and leaves the leading images' share of its gradient
+        where the other heads' shares are (hip_runtime.fanout) -- no slice, no zero-filled gradient, no sum."""
         # The fused node calls the kernels on the children's parameters directly, i.e. it REPLACES the children's
         # forward: it is taken only when that is unobservable and useful -- no forward (pre-)hooks on any child
         # (feature extraction, activation statistics, profilers) and something in the head or its input needs a gradient.
@@ -109,8 +112,8 @@ class Head(nn.Sequential):
                 and not any(m._forward_hooks or m._forward_pre_hooks for m in self) \
                 and (x.requires_grad or any(p.requires_grad for p in self.parameters())) \
                 and ops.conv_act_conv1x1_supported(x, self[0], self[2]):
-            return ops.conv_act_conv1x1(x, self[0], self[2])
-        return super().forward(x)
+            return ops.conv_act_conv1x1(x, self[0], self[2], lead)
+        return super().forward(x if lead is None else x[:lead])
 
 
 class DepthwiseConvTranspose2d(nn.Module):

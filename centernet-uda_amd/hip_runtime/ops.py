@@ -8,6 +8,7 @@ from torch.autograd.function import once_differentiable
 
 from . import check, f32c, lib, pack_stamp, prof_arm, ptr, require_gpu, stream, workspace
 from .arena import grad_sink
+from .fanout import accumulate_target, claim, first_writer, slot_of
 
 
 def _pair(v):
@@ -48,6 +49,7 @@ class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, act_slope, pack_token=0):
         require_gpu(x, weight, bias)
+        ctx.slot = slot_of(x)          # (hip_runtime.fanout: where the other consumers of x leave their share of its gradient)
         x, weight = f32c(x), f32c(weight)
         bias = None if bias is None else f32c(bias)
         g = _conv_geom(x, weight, stride, padding)
@@ -80,11 +82,11 @@ class _Conv2d(Function):
         B, C, H, W, Co, kh, kw = g[:7]
         Ho, Wo = gy.shape[2], gy.shape[3]
         if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
+            gx, addend, addend2 = accumulate_target(ctx.slot, x)     # the slots' content is summed in the GEMM's epilogue
             prof_arm('conv_dgrad', B, C, H, W, Co, kh, kw, Ho, Wo)
             with pack_stamp(ctx.pack_token, weight):
-                check(L.cnuda_conv2d_backward_data(ptr(gy), ptr(weight), ptr(gx), *g, wp, wn, stream()),
-                      'conv2d_backward_data')
+                check(L.cnuda_conv2d_backward_data_add(ptr(gy), ptr(weight), ptr(addend), ptr(addend2), ptr(gx), *g, wp, wn,
+                                                       stream()), 'conv2d_backward_data')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw_buf, gw = _param_grad(weight)
             gb_buf, gb = _param_grad(bias, ctx.has_bias)
@@ -108,8 +110,14 @@ class _ConvActConv1x1(Function):
     (cnuda_conv1x1_backward_data_act) instead of a K <= 8 GEMM launch followed by cnuda_act_backward's own pass."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, padding, act_slope, token1, token2):
+    def forward(ctx, x, w1, b1, w2, b2, padding, act_slope, token1, token2, lead=None):
         require_gpu(x, w1, b1, w2, b2)
+        # lead: only the first `lead` images of x go through the head (a UDA step's source half: forward_domains) -- the
+        # gradient still covers all of x, zero beyond them, or simply added into what x's gradient slot already holds
+        ctx.slot, ctx.full = slot_of(x), None
+        if lead is not None and lead < x.shape[0]:
+            ctx.full = x.shape
+            x = f32c(x)[:lead]
         x, w1, w2 = f32c(x), f32c(w1), f32c(w2)
         b1 = None if b1 is None else f32c(b1)
         b2 = None if b2 is None else f32c(b2)
@@ -160,18 +168,30 @@ class _ConvActConv1x1(Function):
                                                 ctx.act_slope, stream()), 'conv1x1_backward_data_act')
         wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g1), x)
         if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
             prof_arm('conv_dgrad', B, C, H, W, Ch, kh, kw, Ho, Wo)
+            slot = ctx.slot
+            if ctx.full is None:
+                gx, addend, addend2 = accumulate_target(slot, x)
+                part = gx
+            elif slot is not None and slot.buf is not None and slot.owned:
+                gx = slot.buf                                   # the leading images' share lands on top of the slot's total
+                part = addend = gx[:B]
+                addend2 = None
+                slot.included.append(gx)
+            else:
+                gx = claim(slot, torch.empty(ctx.full, dtype=torch.float32, device=x.device))
+                gx[B:].zero_()
+                part, addend, addend2 = gx[:B], None, None
             with pack_stamp(ctx.token1, w1):
-                check(L.cnuda_conv2d_backward_data(ptr(gh), ptr(w1), ptr(gx), *g1, wp, wn, stream()),
-                      'conv2d_backward_data')
+                check(L.cnuda_conv2d_backward_data_add(ptr(gh), ptr(w1), ptr(addend), ptr(addend2), ptr(part), *g1, wp, wn,
+                                                       stream()), 'conv2d_backward_data')
         if ctx.needs_input_grad[1] or (ctx.has_b1 and ctx.needs_input_grad[2]):
             gw1_buf, gw1 = _param_grad(w1)
             gb1_buf, gb1 = _param_grad(b1, ctx.has_b1)
             prof_arm('conv_wgrad', B, C, H, W, Ch, kh, kw, Ho, Wo)
             check(L.cnuda_conv2d_backward_weight(ptr(x), ptr(gh), ptr(gw1_buf), ptr(gb1_buf), *g1, wp, wn, stream()),
                   'conv2d_backward_weight')
-        return gx, gw1, gb1, gw2, gb2, None, None, None, None
+        return gx, gw1, gb1, gw2, gb2, None, None, None, None, None
 
 
 def conv_act_conv1x1_supported(x, conv, last):
@@ -185,10 +205,11 @@ def conv_act_conv1x1_supported(x, conv, last):
             and last.padding == (0, 0) and last.act_slope < 0 and 1 <= last.out_channels <= 8 and hw > 0 and hw % 4 == 0)
 
 
-def conv_act_conv1x1(x, conv, last):
-    """last(conv(x)) for the two `hip_runtime.nn.Conv2d` layers of a detection head, recorded as one tape node."""
+def conv_act_conv1x1(x, conv, last, lead=None):
+    """last(conv(x)) for the two `hip_runtime.nn.Conv2d` layers of a detection head, recorded as one tape node.
+    lead: evaluate the first `lead` images of x only (the result has `lead` images; x's gradient is whole)."""
     return _ConvActConv1x1.apply(x, conv.weight, conv.bias, last.weight, last.bias, conv.padding, conv.act_slope,
-                                 conv._pack_token, last._pack_token)
+                                 conv._pack_token, last._pack_token, lead)
 
 
 def conv2d_infer(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0, residual=None, pack_token=0,
@@ -292,6 +313,7 @@ class _BatchNormAct(Function):
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, num_batches_tracked,
                 groups):
         require_gpu(x, gamma, beta, residual)
+        ctx.res_slot = None if residual is None else slot_of(residual)
         x = f32c(x)
         residual = None if residual is None else f32c(residual)
         B, C = x.shape[0], x.shape[1]
@@ -320,7 +342,7 @@ class _BatchNormAct(Function):
         B, C, HW = ctx.dims
         gy = f32c(gy)
         gx = torch.empty_like(x)
-        gres = torch.empty_like(x) if ctx.has_res else None
+        gres = first_writer(ctx.res_slot, x) if ctx.has_res else None
         gg_buf, gg = _param_grad(gamma)
         gb_buf, gb = _param_grad(beta)
         L = lib()
@@ -371,6 +393,7 @@ class _MaxPool(Function):
     @staticmethod
     def forward(ctx, x, k):
         require_gpu(x)
+        ctx.slot = slot_of(x)
         x = f32c(x)
         B, C, H, W = x.shape
         y = torch.empty((B, C, H // k, W // k), dtype=torch.float32, device=x.device)
@@ -384,7 +407,7 @@ class _MaxPool(Function):
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
         B, C, H, W = x.shape
-        gx = torch.empty_like(x)
+        gx = first_writer(ctx.slot, x)
         check(lib().cnuda_maxpool2d_backward(ptr(x), ptr(f32c(gy)), ptr(gx), B, C, H, W, ctx.k, stream()),
               'maxpool2d_backward')
         return gx, None
@@ -529,6 +552,7 @@ class _Cat(Function):
     @staticmethod
     def forward(ctx, *xs):
         require_gpu(*xs)
+        slots = [slot_of(t) for t in xs]
         xs = [f32c(t) for t in xs]
         B, _, H, W = xs[0].shape
         chans = [t.shape[1] for t in xs]
@@ -540,6 +564,7 @@ class _Cat(Function):
             check(L.cnuda_copy_channels(ptr(t), ptr(out), B, c, H * W, c, 0, sum(chans), off, stream()), 'cat')
             off += c
         ctx.chans = chans
+        ctx.slots = slots
         return out
 
     @staticmethod
@@ -550,7 +575,7 @@ class _Cat(Function):
         outs, off, L = [], 0, lib()
         for i, c in enumerate(ctx.chans):
             if ctx.needs_input_grad[i]:
-                t = torch.empty((B, c, H, W), dtype=torch.float32, device=g.device)
+                t = claim(ctx.slots[i], torch.empty((B, c, H, W), dtype=torch.float32, device=g.device))
                 check(L.cnuda_copy_channels(ptr(g), ptr(t), B, c, H * W, Ct, off, c, 0, stream()), 'cat_backward')
                 outs.append(t)
             else:

@@ -22,6 +22,8 @@ class _DeformConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token=0):
         kh, kw = weight.shape[2], weight.shape[3]
+        from hip_runtime.fanout import slot_of
+        ctx.slot = slot_of(input)      # where the offset convolution (the input's other consumer) meets this gradient
         ctx.geom = (kh, kw) + _pair(stride) + _pair(padding) + _pair(dilation) + (deformable_groups,)
         # keep the sampled columns (a side output of the forward kernel) for the weight gradient:
         # on a 288 GB part re-reading ~0.3 GB per layer beats re-sampling the input
@@ -41,8 +43,18 @@ class _DeformConvFn(torch.autograd.Function):
         input, offset, mask, weight, bias, cols = ctx.saved_tensors
         from hip_runtime.arena import grad_sink
         sw, sb = grad_sink(weight), grad_sink(bias)       # arena slots: written by the kernels, not returned
+        # the data-gradient walks ADD into grad_input: on top of what the slot already holds when it is the slot's own
+        # buffer, else into a cleared tensor -- which an empty slot takes over
+        slot = ctx.slot
+        acc = slot.buf if (slot is not None and slot.buf is not None and slot.owned) else None
         g_in, g_off, g_mask, g_w, g_b = _backend.dcn_v2_backward(
-            input, weight, bias, offset, mask, grad_output, *ctx.geom, _columns=cols, _grad_weight=sw, _grad_bias=sb)
+            input, weight, bias, offset, mask, grad_output, *ctx.geom, _columns=cols, _grad_weight=sw, _grad_bias=sb,
+            _grad_input=acc)
+        if acc is None:
+            from hip_runtime.fanout import claim
+            claim(slot, g_in)
+        else:
+            slot.included.append(acc)
         return g_in, g_off, g_mask, (None if sw is not None else g_w), (None if sb is not None else g_b), \
             None, None, None, None, None
 
@@ -94,7 +106,10 @@ class DCN(DCNv2):
 
     def forward(self, input):
         from hip_runtime import ops
-        om = self.conv_offset_mask(input)
+        from hip_runtime.fanout import fork
+        # the input feeds the offset / mask convolution AND the sampling: their gradients meet in a slot, not in the engine
+        input_om, input = fork(input, 2)
+        om = self.conv_offset_mask(input_om)
         # channels [0, 2*taps) are offsets (chunks o1|o2 re-concatenated, dcn_v2.py:120-121),
         # [2*taps, 3*taps) the mask logits
         offset, mask = ops.split_offset_mask(om)

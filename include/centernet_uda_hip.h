@@ -212,6 +212,19 @@ int cnuda_dcn_v2_backward_cols(const float* input, const float* weight, const fl
                                int sh, int sw, int ph, int pw, int dh, int dw, int dg,
                                void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 
+/* backward_cols with accumulate_input != 0: grad_input is NOT cleared first -- the data-gradient walks add into it (window
+ * flushes and strays are atomics either way), so a caller that already holds another consumer's share of the input's
+ * gradient there (the offset / mask convolution's input gradient: backends/dla.py:263-270, x feeds both) saves the clear and
+ * autograd's sum.  accumulate_input == 0: exactly backward_cols. */
+int cnuda_dcn_v2_backward_acc(const float* input, const float* weight, const float* bias,
+                              const float* offset, const float* mask, const float* grad_output,
+                              const float* columns,
+                              float* grad_input, int accumulate_input, float* grad_offset, float* grad_mask,
+                              float* grad_weight, float* grad_bias,
+                              int B, int C, int H, int W, int Cout, int kh, int kw,
+                              int sh, int sw, int ph, int pw, int dh, int dw, int dg,
+                              void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Dense convolution (groups 1, dilation 1) -- replaces torch.nn.Conv2d -> cuDNN
  * on the hot path: backends/dla.py:37-44,153-155,234-235,281-283,478-483 (DLA
@@ -239,6 +252,15 @@ int cnuda_conv2d_backward_data(const float* grad_y, const float* weight, float* 
                                int B, int C, int H, int W, int Cout, int kh, int kw,
                                int sh, int sw, int ph, int pw,
                                void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+/* grad_x = input gradient + addend + addend2 (both nullable, shaped like grad_x, either may BE grad_x): where a tensor
+ * feeds a convolution and something else (a skip connection, a concatenation, a DCN's sampling), the other consumers'
+ * shares of its gradient are summed in the epilogue of this one instead of by passes of their own (what autograd's
+ * accumulation does in the reference: torch's engine, one at::add per extra consumer; hip_runtime.fanout). */
+int cnuda_conv2d_backward_data_add(const float* grad_y, const float* weight, const float* addend, const float* addend2,
+                                   float* grad_x,
+                                   int B, int C, int H, int W, int Cout, int kh, int kw,
+                                   int sh, int sw, int ph, int pw,
+                                   void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 int cnuda_conv2d_backward_weight(const float* x, const float* grad_y, float* grad_weight, float* grad_bias,
                                  int B, int C, int H, int W, int Cout, int kh, int kw,
                                  int sh, int sw, int ph, int pw,
