@@ -8,7 +8,7 @@ import os
 import sys
 
 root, out_dir = sys.argv[1], sys.argv[2]
-KEEP = ('dcn_', 'igemm_fwd_kernel<64, DcnFwd', 'igemm_fwd_kernel<128, DcnFwd', 'shortk', 'DcnColW')
+KEEP = ('dcn_', 'dcnq', 'dcnw', 'igemm_fwd_kernel<64, DcnFwd', 'igemm_fwd_kernel<128, DcnFwd', 'shortk', 'DcnColW')
 
 
 def short(n):
@@ -50,11 +50,11 @@ def g(m, n):
 
 md = ['| kernel | mean µs | wave-cycles waiting (any / LDS issue) | VALU / LDS / VMEM-read / VMEM-write instructions per wave-kilocycle | '
       'LDS bank-conflict cycles ÷ LDS active cycles | TA busy ÷ (256 TAs × active cycles) | TA stalled by TC (addr / data) ÷ TA busy | '
-      'L1 accesses per TA wavefront | L1→L2 read requests ÷ L1 accesses | HBM fetch + write MB |', '|' + '---|' * 10]
+      'L1 accesses per TA wavefront | L1→L2 read requests ÷ L1 accesses | HBM fetch + write MB | MFMA busy ÷ (1024 SIMDs × active cycles) |', '|' + '---|' * 11]
 for k, m in sorted(res.items(), key=lambda kv: -kv[1].get('mean_us', 0)):
     wc = g(m, 'SQ_WAVE_CYCLES')
     act = g(m, 'GRBM_GUI_ACTIVE') / 8.0
-    md.append('| `%s` | %.0f | %.2f / %.2f | %.1f / %.1f / %.1f / %.1f | %.2f | %.2f | %.2f / %.2f | %.1f | %.2f | %.0f + %.0f |' % (
+    md.append('| `%s` | %.0f | %.2f / %.2f | %.1f / %.1f / %.1f / %.1f | %.2f | %.2f | %.2f / %.2f | %.1f | %.2f | %.0f + %.0f | %.2f |' % (
         k[:70], m['mean_us'], g(m, 'SQ_WAIT_ANY') / wc, g(m, 'SQ_WAIT_INST_LDS') / wc,
         1e3 * g(m, 'SQ_INSTS_VALU') / wc, 1e3 * g(m, 'SQ_INSTS_LDS') / wc, 1e3 * g(m, 'SQ_INSTS_VMEM_RD') / wc,
         1e3 * g(m, 'SQ_INSTS_VMEM_WR') / wc,
@@ -64,7 +64,8 @@ for k, m in sorted(res.items(), key=lambda kv: -kv[1].get('mean_us', 0)):
         g(m, 'TA_DATA_STALLED_BY_TC_CYCLES_sum') / max(g(m, 'TA_TA_BUSY_sum'), 1.0),
         g(m, 'TCP_TOTAL_CACHE_ACCESSES_sum') / max(g(m, 'TA_TOTAL_WAVEFRONTS_sum'), 1.0),
         g(m, 'TCP_TCC_READ_REQ_sum') / max(g(m, 'TCP_TOTAL_CACHE_ACCESSES_sum'), 1.0),
-        g(m, 'FETCH_SIZE') / 1024.0, g(m, 'WRITE_SIZE') / 1024.0))
+        g(m, 'FETCH_SIZE') / 1024.0, g(m, 'WRITE_SIZE') / 1024.0,
+        g(m, 'SQ_VALU_MFMA_BUSY_CYCLES') / (1024.0 * act)))
 open(os.path.join(out_dir, 'pmc_dcn.md'), 'w').write('\n'.join(md) + '\n')
 print('\n'.join(md))
 if os.path.exists(root + '/failed.txt'):
