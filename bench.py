@@ -613,6 +613,11 @@ def main():
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)
+    # The bench line is the only thing this process may leave on stdout.  RCCL (this build) prints a version banner on
+    # STDOUT when the process that initialised it exits -- after the line, from every rank: from here on file
+    # descriptor 1 is stderr.
+    sys.stdout.flush()
+    os.dup2(2, 1)
     if world > 1:
         dist.destroy_process_group()
 

@@ -30,15 +30,17 @@ rf = line['roofline']
 def bucket(name):
     n = name
     if 'DcnColW' in n or 'DcnWLoader' in n: return 'DCN wgrad'
-    if 'DcnFwdLoader' in n or 'DcnCols' in n or 'dcn_sample' in n: return 'DCN forward'
+    if 'DcnFwdLoader' in n or 'DcnCols' in n or 'dcn_sample' in n or 'dcnw_fwd' in n: return 'DCN forward'
+    if 'dcnq_kernel' in n: return 'DCN backward, one kernel (opt-in)'
+    if 'add_kernel' in n: return 'gradient fan-in sums no epilogue takes (cnuda_add)'
     if 'dcn_bwd_data' in n or 'dcn_prep' in n: return 'DCN coord-grad + col2im (one launch)'
     if 'dcn_coord' in n: return 'DCN coord-grad'
     if 'dcn_col2im' in n: return 'DCN col2im'
     if 'igemm_wgrad' in n or 'smallc_wgrad' in n or 'slab_reduce' in n: return 'conv wgrad'
     if 'Dgrad' in n: return 'conv dgrad'
-    if 'igemm_fwd' in n or 'smallc_fwd' in n: return 'conv fwd (incl. DCN column-gradient GEMMs, stride-1 smallc dgrad)'
+    if 'igemm_fwd' in n or 'smallc_fwd' in n or 'hconv_kernel' in n: return 'conv fwd (incl. DCN column-gradient GEMMs, stride-1 smallc dgrad)'
     if n.startswith('bn_') or 'bn_' in n.split('<')[0]: return 'BatchNorm'
-    if 'at::native' in n: return 'ATen (autograd fan-in sums, loss scalars)'
+    if 'at::native' in n: return 'ATen (loss scalars, arena flush)' if N >= 4 else 'ATen (autograd fan-in sums, loss scalars)'
     return 'rest'
 
 

@@ -56,3 +56,15 @@ def test_plain_two_rank_start_prints_one_json_line():
     assert c['bytes_per_step'] >= 4 * 18e6 and c['buckets_per_step'] >= 2          # ~18.5 M parameters, 24 MB buckets
     assert c['host_wait_ms_per_step'] >= 0 and 'exposed_allreduce_ms_per_step' in c
     assert line['ms_per_step_sd'] >= 0 and line['ms_per_step_min'] <= line['ms_per_step'] * 1.05
+
+
+@pytest.mark.gpu
+def test_single_gpu_run_with_the_rccl_leg_leaves_exactly_one_line_on_stdout():
+    # the one-rank RCCL leg brings a communicator up; this RCCL build prints a version banner on STDOUT when such a
+    # process exits -- after the bench line.  The driver reads stdout: nothing but the line may be there.
+    r = _run(['--steps', '1', '--warmup', '1', '--batch', '2', '--size', '128', '--no-cpu-baseline'])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out) == 1 and out[0].startswith('{'), out
+    line = json.loads(out[0])
+    assert line['n_gpus'] == 1 and line.get('dp1_rccl'), sorted(line)

@@ -334,7 +334,7 @@ def _full_size_dcn_layer(layer, off_scale):
     names = sorted(short(n) for n in log.names)
     print(names)
     import os
-    if not any(os.environ.get(v) == '0' for v in ('CNUDA_BUF', 'CNUDA_WS', 'CNUDA_SHORTK')):     # (tests/test_gpu_kernel_switches.py)
+    if not any(os.environ.get(v) == '0' for v in ('CNUDA_BUF', 'CNUDA_WS', 'CNUDA_SHORTK', 'CNUDA_DCNW')):     # (tests/test_gpu_kernel_switches.py)
         for want_kernel in DCN_LAYERS[layer]['kernels']:
             assert any(n.startswith(want_kernel) for n in names), (want_kernel, names)
     y, gx, goff, gm, gw, gb, cols = res
