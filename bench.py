@@ -166,8 +166,9 @@ def cpu_baseline(budget_s=150.0):
         'kind': 'port',
         's_per_step_512': {'median': round(med, 3), 'min': round(ts[0], 3), 'max': round(ts[-1], 3), 'repeats': len(ts)},
         # the same leg on other boxes of this pool (128-thread hosts): 0.074 (round-3 collection box), 0.089 (round-3
-        # driver box) -- quote the CPU figure as 0.07-0.09 img/s, not to three digits
-        'box_to_box_range': [0.074, 0.089],
+        # driver box), 0.081 and 0.044 (two round-4 boxes: the host side varies 2x with what else the machine runs) --
+        # quote the CPU figure as 0.04-0.09 img/s, not to three digits
+        'box_to_box_range': [0.044, 0.089],
         'sample': ('EntropyMinimization step of the CPU oracle on 1 source + 1 target 512x512 image: 1 untimed warm-up '
                    'at 256x256, %d timed step(s) (median %.2f s, spread %.2f-%.2f s, budget %.0f s); torch CPU conv/BN '
                    '(%d threads) + single-thread C DCN loops like the reference CPU extension; `value` = 1 / median'
