@@ -13,6 +13,13 @@ from torch import nn
 import _ext as _backend
 
 
+# CNUDA_DCN_KEEP_COLS=0: the forward does not store the sampled columns and the weight gradient samples the input again
+# (the reference's scheme, dcn_v2_cuda.cu:302-319) -- an A/B switch for the measurement in DESIGN.md section 12; the
+# default keeps them (one 1 GB side output per 128 x 128 layer, read once by a plain-GEMM weight gradient)
+import os as _os
+_KEEP_COLUMNS = _os.environ.get('CNUDA_DCN_KEEP_COLS', '1') != '0'
+
+
 def _pair(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
@@ -27,7 +34,7 @@ class _DeformConvFn(torch.autograd.Function):
         ctx.geom = (kh, kw) + _pair(stride) + _pair(padding) + _pair(dilation) + (deformable_groups,)
         # keep the sampled columns (a side output of the forward kernel) for the weight gradient:
         # on a 288 GB part re-reading ~0.3 GB per layer beats re-sampling the input
-        keep = deformable_groups == 1 and input.shape[3] >= 2 and any(ctx.needs_input_grad[:5])
+        keep = deformable_groups == 1 and input.shape[3] >= 2 and any(ctx.needs_input_grad[:5]) and _KEEP_COLUMNS
         if keep:
             out, cols = _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geom, _want_columns=True,
                                                 _pack_token=pack_token)
