@@ -638,7 +638,12 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcnw_fwd_kernel(DcnFwdParams p,
 // the packed weights: 25% of the MFMA work).
 // ---------------------------------------------------------------------------
 template <int TC> struct DqTile {
-    static constexpr int NPX = 64, TR = NPX / TC, NR = TR + 2 + 2 * DW_MARGIN, RS = TC + 8, CELLS = NR * RS;
+    // Window: the tile's rows plus (1 + MARGIN) above and below; RS = TC + 16 columns, tile column x at index x + 8.  The
+    // row stride is a multiple of 16 cells (256 bytes = the bank period of ds_read_b128): the lane groups of a b128 read
+    // mix pixels 0-3 / 12-15 of one tap row with pixels 4-11 of the next, and with a stride of 40 cells (TC + 8) those
+    // two sets fell on the same banks -- every corner read of undeformed samples a 2-way conflict.
+    static constexpr int MARGIN = 2, XPAD = 8;
+    static constexpr int NPX = 64, TR = NPX / TC, NR = TR + 2 + 2 * MARGIN, RS = TC + 2 * XPAD, CELLS = NR * RS;
     static constexpr int CPR = RS / 4, ITEMS = NR * CPR, NIT = (ITEMS + 63) / 64;   // staging: (row, 4 columns) per lane
     static constexpr int SHIFT = TC == 32 ? 5 : 4;
     static constexpr int CLAIM = (CELLS + 16 + 15) / 16 * 16;                       // bytes per wave (+ a spare cell for lanes without a sample)
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void dcnq_kernel(DcnBwdQuadParams p,
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int tiles_y = H / Q::TR;
     const int ty = tile % tiles_y, b = tile / tiles_y;
-    const int y0 = ty * Q::TR, x0 = tx * TC, yw0 = y0 - 1 - DW_MARGIN, xw0 = x0 - 4;
+    const int y0 = ty * Q::TR, x0 = tx * TC, yw0 = y0 - 1 - Q::MARGIN, xw0 = x0 - Q::XPAD;
     f32x4* const Wq = reinterpret_cast<f32x4*>(smem + Q::WIN) + wid * CELLS;     // [cell][4 channels] of this wave's quad
     f32x4* const Gq = reinterpret_cast<f32x4*>(smem + Q::GWIN) + wid * CELLS;
     f32x4* const Geo = reinterpret_cast<f32x4*>(smem + Q::GEO);                  // [tap][pixel]: window cell (int bits; -1: none), lh, lw, mask
@@ -1858,6 +1863,11 @@ constexpr int kFusedMinTilesDefault = 512;
 int g_fused_min_tiles = kFusedMinTilesDefault;      // cnuda_dcn_set_fused_min_tiles (tests)
 inline int kQuadBackwardDefault() { const char* e = getenv("CNUDA_DCNQ"); return e && e[0] == '1'; }
 int g_quad_backward = kQuadBackwardDefault();       // cnuda_dcn_set_quad_backward (tests, A/B)
+// ... and only calls with at least this many 64-pixel tiles: a tile is one workgroup that walks ALL channel groups (49 us
+// for four of them), so the 32 x 32 / 16 x 16 maps -- few tiles, 8-16 groups -- took 1.4 ms where the two-kernel walk takes
+// 0.3 (in-step trace, round 4).  cnuda_dcn_set_quad_backward(2) drops the rule (tests run small geometries)
+constexpr long long kQuadMinTilesDefault = 2048;
+long long g_quad_min_tiles = kQuadMinTilesDefault;
 
 struct DcnPlan {
     int T, K, Kp, bm, Mp;           // forward pack [Kp][Mp]
@@ -1931,6 +1941,7 @@ using namespace cnuda;
 extern "C" int cnuda_dcn_set_quad_backward(int on) {
     const int prev = g_quad_backward;
     g_quad_backward = on < 0 ? kQuadBackwardDefault() : (on != 0);
+    g_quad_min_tiles = on == 2 ? 1 : kQuadMinTilesDefault;
     return prev;
 }
 extern "C" int cnuda_dcn_set_fused_min_tiles(int min_tiles) {
@@ -2187,7 +2198,8 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
     // measured 82.7 / 83.2 vs 82.2 / 82.7 ms.  CNUDA_DCNQ=1 or cnuda_dcn_set_quad_backward(1).
     if (g_quad_backward && matrix_mode() == 0 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 &&
         dw == 1 && C % 16 == 0 && Cout <= 64 && (W == 16 || W == 32 || W == 64 || W == 128) &&
-        H % (64 / (W >= 32 ? 32 : 16)) == 0 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB) {
+        H % (64 / (W >= 32 ? 32 : 16)) == 0 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB &&
+        q.N / 64 >= g_quad_min_tiles) {
         const int tc = W >= 32 ? 32 : 16, tiles_x = W / tc, n_tiles = (int)(q.N / 64);
         const float* Aq = launch_pack(weight, wt, (size_t)12 * C * 64 * sizeof(float), Cout, C, q.T, PACK_DCN_QUAD, 12 * C, 64, 0, st);
         DcnBwdQuadParams pq{g, input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask};

@@ -453,10 +453,11 @@ class dcn_fused_min_tiles:
 
 class dcn_quad_backward:
     """with dcn_quad_backward(True): every DCN backward inside the block that CAN take the one-kernel form on channel-quad
-    planes (dcnq_kernel: 3x3 / stride 1 / padding 1, C % 16 == 0, Cout <= 64, map 16 / 32 / 64 / 128 wide) takes it."""
+    planes (dcnq_kernel: 3x3 / stride 1 / padding 1, C % 16 == 0, Cout <= 64, map 16 / 32 / 64 / 128 wide) and has at
+    least 2,048 64-pixel tiles takes it; dcn_quad_backward(2): whatever its size (tests); False / 0: none."""
 
     def __init__(self, on=True):
-        self.on = 1 if on else 0
+        self.on = (2 if on == 2 else 1) if on else 0      # 2: every eligible call, whatever its size (tests)
 
     def __enter__(self):
         self.prev = lib().cnuda_dcn_set_quad_backward(self.on)

@@ -104,9 +104,10 @@ int cnuda_prof_name_len(void);
  * Returns level | min_tiles << 8 after the change.  Tests use (1, 1) to run small shapes through every tile variant.
  * cnuda_dcn_set_quad_backward: 1 -> cnuda_dcn_v2_backward[_cols] takes its one-kernel form (dcnq_kernel: column
  * gradient, grad_offset / grad_mask sums and the grad_input scatter on channel-quad LDS planes) for 3x3 / stride 1 /
- * padding 1 / dilation 1 layers with C % 16 == 0, Cout <= 64 and a 16 / 32 / 64 / 128 wide map; 0 -> the GEMM +
- * walk kernels; < 0 -> the initial value (CNUDA_DCNQ=1 in the environment, else 0: it measured no faster inside the
- * benched step).  Returns the previous setting.  Same results up to summation order. */
+ * padding 1 / dilation 1 layers with C % 16 == 0, Cout <= 64, a 16 / 32 / 64 / 128 wide map and at least 2,048 tiles of
+ * 64 pixels; 2 -> the same without the size rule (tests); 0 -> the GEMM + walk kernels; < 0 -> the initial value
+ * (CNUDA_DCNQ in the environment).  Returns the previous on/off setting.  Same results up to
+ * summation order. */
 int cnuda_launch_log_enable(int on);
 int cnuda_launch_log_collect(char* names, size_t cap);
 int cnuda_dcn_set_fused_min_tiles(int min_tiles);

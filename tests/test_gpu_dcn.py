@@ -197,7 +197,7 @@ def test_quad_plane_backward_vs_oracle(name):
     (x, w, b, off, m, go), geom = _case(zlib.crc32(name.encode()) % 1000, **QUAD_CASES[name])
     wg = od.dcn_v2_backward(x, w, b, off, m, go, *geom)
     dev = [t.to(DEV) for t in (x, w, b, off, m, go)]
-    with hr.dcn_quad_backward(True), hr.launch_log() as log:
+    with hr.dcn_quad_backward(2), hr.launch_log() as log:
         grads = _ext.dcn_v2_backward(*dev, *geom)
     assert any('dcnq_kernel' in n for n in log.names), log.names
     assert not any(k in n for n in log.names for k in ('dcn_col2im', 'dcn_coord_grad', 'dcn_bwd_data', 'dcn_prep')), log.names
@@ -215,7 +215,7 @@ def test_quad_plane_backward_known_answers():
     import hip_runtime as hr
 
     def bwd(*a):
-        with hr.dcn_quad_backward(True):
+        with hr.dcn_quad_backward(2):
             return _gpu_bwd(*a)
     ka.check_linear_ramp_has_constant_coordinate_gradient(_gpu_fwd, bwd, torch.float32, 5e-5, size=(2, 64, 40, 32, 64))
     ka.check_linear_ramp_has_constant_coordinate_gradient(_gpu_fwd, bwd, torch.float32, 5e-5, size=(1, 16, 8, 16, 32))

@@ -288,7 +288,7 @@ _DCN_CASES = [(n, o) for n in DCN_LAYERS for o in ((0.3, 1.0, 6.0) if DCN_LAYERS
                          ids=['%s-pm%gpx' % (n, o) for n, o in _DCN_CASES])
 def test_full_size_dcn_layer_matches_the_oracle(layer, off_scale):
     import hip_runtime as hr
-    with hr.dcn_quad_backward(bool(DCN_LAYERS[layer].get('quad'))):
+    with hr.dcn_quad_backward(2 if DCN_LAYERS[layer].get('quad') else 0):
         _full_size_dcn_layer(layer, off_scale)
 
 
