@@ -281,7 +281,9 @@ DCN_LAYERS = {
     '256to256_32sq': dict(B=32, C=256, Co=256, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_kernel<128, DcnColsBufLoader']),
     '256to128_32sq': dict(B=32, C=256, Co=128, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_kernel<64, DcnColsBufLoader']),
 }
-_DCN_CASES = [(n, o) for n in DCN_LAYERS for o in ((0.3, 1.0, 6.0) if DCN_LAYERS[n]['S'] >= 64 and DCN_LAYERS[n]['Co'] == 64 else (1.0,))]
+# offset scales: 1e-3 px of either sign is the benched step after its first optimizer step (a sample at y - 1e-4 has its anchor
+# one cell above its neighbour's at y + 1e-4: jittered anchors, all four corner weights non-zero, one of them ~1)
+_DCN_CASES = [(n, o) for n in DCN_LAYERS for o in ((0.001, 0.3, 1.0, 6.0) if DCN_LAYERS[n]['S'] >= 64 and DCN_LAYERS[n]['Co'] == 64 and DCN_LAYERS[n]['C'] >= 64 else (1.0,))]
 
 
 @pytest.mark.parametrize('layer,off_scale', _DCN_CASES,      # 0.3 px: col2im's DPP ranking path; 6 px: strays beyond the LDS window
