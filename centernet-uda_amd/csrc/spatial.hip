@@ -30,8 +30,9 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
     }
 }
 // gx is written completely (zeros where not the arg-max); one thread per output cell
+// accumulate: gx already holds another consumer's share of x's gradient -- only the arg-max cell is touched (+= g)
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
-                                   long long planes, int H, int W, int Ho, int Wo, int k) {
+                                   long long planes, int H, int W, int Ho, int Wo, int k, int accumulate) {
     const long long total = planes * Ho * Wo;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -46,6 +47,10 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
                 if (v > m || v != v) { m = v; arg = dy * W + dx; }
             }
         const float g = gy[i];
+        if (accumulate) {
+            gx[base + arg] += g;
+            continue;
+        }
         for (int dy = 0; dy < k; ++dy)
             for (int dx = 0; dx < k; ++dx) gx[base + dy * W + dx] = (dy * W + dx == arg) ? g : 0.0f;
     }
@@ -648,16 +653,20 @@ extern "C" int cnuda_maxpool2d_forward(const float* x, float* y, int B, int C, i
 }
 extern "C" int cnuda_maxpool2d_backward(const float* x, const float* grad_y, float* grad_x, int B, int C, int H, int W,
                                         int k, cnuda_stream_t stream) {
+    return cnuda_maxpool2d_backward_acc(x, grad_y, grad_x, 0, B, C, H, W, k, stream);
+}
+extern "C" int cnuda_maxpool2d_backward_acc(const float* x, const float* grad_y, float* grad_x, int accumulate, int B, int C,
+                                            int H, int W, int k, cnuda_stream_t stream) {
     CNUDA_REQUIRE(x && grad_y && grad_x && B > 0 && C > 0 && k > 0 && H >= k && W >= k,
                   "cnuda_maxpool2d_backward: bad arguments");
     const int Ho = H / k, Wo = W / k;
     const long long planes = (long long)B * C;
     hipStream_t st = (hipStream_t)stream;
-    if (Ho * k != H || Wo * k != W)
+    if (!accumulate && (Ho * k != H || Wo * k != W))
         CNUDA_LAUNCH(maxpool_bwd_tail_kernel, dim3(stream_grid(planes * H * W, kT)), dim3(kT), 0, st, grad_x,
                            planes, H, W, Ho * k, Wo * k);
     CNUDA_LAUNCH(maxpool_bwd_kernel, dim3(stream_grid(planes * Ho * Wo, kT)), dim3(kT), 0, st, x, grad_y, grad_x,
-                       planes, H, W, Ho, Wo, k);
+                       planes, H, W, Ho, Wo, k, accumulate);
     return check_launch("cnuda_maxpool2d_backward");
 }
 

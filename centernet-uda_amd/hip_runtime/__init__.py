@@ -81,6 +81,7 @@ class _Sig:
     cnuda_bn_backward = (_I, [_P] * 11 + [_I, _I, _I, _LL, _I] + _WS)
     cnuda_maxpool2d_forward = (_I, [_P] * 2 + [_I] * 5 + [_P])
     cnuda_maxpool2d_backward = (_I, [_P] * 3 + [_I] * 5 + [_P])
+    cnuda_maxpool2d_backward_acc = (_I, [_P] * 3 + [_I] * 6 + [_P])
     cnuda_maxpool2d_window_forward = (_I, [_P] * 2 + [_I] * 7 + [_P])
     cnuda_maxpool2d_window_backward = (_I, [_P] * 3 + [_I] * 7 + [_P])
     cnuda_dwconvt2d_forward = (_I, [_P] * 3 + [_I] * 7 + [_P])

@@ -407,8 +407,14 @@ class _MaxPool(Function):
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
         B, C, H, W = x.shape
-        gx = first_writer(ctx.slot, x)
-        check(lib().cnuda_maxpool2d_backward(ptr(x), ptr(f32c(gy)), ptr(gx), B, C, H, W, ctx.k, stream()),
+        slot = ctx.slot
+        if slot is not None and slot.buf is not None and slot.owned:
+            # another consumer's share is already in the slot's own buffer: only the arg-max cells are touched (+=)
+            gx, acc = slot.buf, 1
+            slot.included.append(gx)
+        else:
+            gx, acc = first_writer(slot, x), 0
+        check(lib().cnuda_maxpool2d_backward_acc(ptr(x), ptr(f32c(gy)), ptr(gx), acc, B, C, H, W, ctx.k, stream()),
               'maxpool2d_backward')
         return gx, None
 

@@ -313,6 +313,11 @@ int cnuda_bn_backward(const float* grad_y, const float* x, const float* y, const
 int cnuda_maxpool2d_forward(const float* x, float* y, int B, int C, int H, int W, int k, cnuda_stream_t stream);
 int cnuda_maxpool2d_backward(const float* x, const float* grad_y, float* grad_x,
                              int B, int C, int H, int W, int k, cnuda_stream_t stream);
+/* ... with accumulate != 0: grad_x already holds another consumer's share of x's gradient (hip_runtime.fanout: a level input
+ * that feeds the pooling shortcut and a strided convolution, backends/dla.py:199-203) and only the arg-max cell of every window
+ * is touched (+= grad_y). */
+int cnuda_maxpool2d_backward_acc(const float* x, const float* grad_y, float* grad_x, int accumulate, int B, int C, int H, int W,
+                                 int k, cnuda_stream_t stream);
 /* general window (kernel k, stride s, padding p with -inf, floor mode): torchvision's ResNet stem pool
  * nn.MaxPool2d(3, 2, 1), kept inside `base` by backends/resnet.py:27-30.  Backward is a deterministic gather. */
 int cnuda_maxpool2d_window_forward(const float* x, float* y, int B, int C, int H, int W, int k, int s, int p,

@@ -28,7 +28,7 @@ MANIFEST = {
         'tests/test_gpu_ops.py::test_halo_tile_convolution_3x3',
     ],
     'add_kernel': [           # gradient fan-in sums that no epilogue takes over (hip_runtime.fanout)
-        'tests/test_gpu_fanout.py::test_forked_graph_has_the_gradients_of_the_plain_graph[pool_and_conv',
+        'tests/test_gpu_fanout.py::test_forked_graph_has_the_gradients_of_the_plain_graph[unused_alias',
         'tests/test_gpu_fanout.py::test_forked_graph_has_the_gradients_of_the_plain_graph[foreign_consumer',
     ],
     'adam_kernel': [
