@@ -130,8 +130,8 @@ def _cpu_step_fn():
         state[k] = t
     opt = torch.optim.Adam([v for v in state.values() if v.requires_grad], lr=5e-5, weight_decay=1e-4)
 
-    def step(size, seed):
-        batch = synthetic_batch(1, size, seed, 'cpu')
+    def step(size, seed, images=1):
+        batch = synthetic_batch(images, size, seed, 'cpu')
         t0 = time.perf_counter()
         opt.zero_grad()
         out_s = odla.forward(state, batch['input'], training=True)
@@ -161,8 +161,23 @@ def cpu_baseline(budget_s=150.0):
         times.append(step(512, 11 + i))
     ts = sorted(times)
     med = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
+    # B = 2 beside B = 1, and the linear extrapolation to the metric's B = 16 (time per step
+    # = a + b * B through the two samples); one step, when the budget still has room for it
+    b2 = None
+    if time.perf_counter() - t_begin + 2.2 * med <= budget_s:
+        t2 = step(512, 17, images=2)
+        per_image = max(t2 - med, 1e-9)                     # b of a + b * B
+        t16 = med + 15.0 * per_image
+        b2 = {'s_per_step': round(t2, 3), 'images_per_s': round(2.0 / t2, 5),
+              'extrapolated_b16': {'s_per_step': round(t16, 2), 'images_per_s': round(16.0 / t16, 5),
+                                   'how': 't(B) = a + b*B through the B=1 median and this B=2 step'}}
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count()
     return {
         'value': round(1.0 / med, 5), 'unit': 'images/sec (512x512 source images)', 'cores': torch.get_num_threads(),
+        'nproc': affinity, 'host_cpus': os.cpu_count(), 'b2': b2,
         'kind': 'port',
         's_per_step_512': {'median': round(med, 3), 'min': round(ts[0], 3), 'max': round(ts[-1], 3), 'repeats': len(ts)},
         # the same leg on other boxes of this pool (128-thread hosts): 0.074 (round-3 collection box), 0.089 (round-3
@@ -261,16 +276,16 @@ def dp1_rccl_leg(device, args):
     sys.stdout.flush()
     saved_fd = os.dup(1)
     os.dup2(2, 1)
-    if not dist.is_initialized():
-        s = socket.socket()
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
-        s.close()
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ['MASTER_PORT'] = str(port)
-        dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=device)
-        created = True
-    try:
+    try:                # everything after the redirect sits inside: whatever raises, `finally` hands stdout back
+        if not dist.is_initialized():
+            s = socket.socket()
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+            s.close()
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ['MASTER_PORT'] = str(port)
+            dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=device)
+            created = True
         plugin = build_plugin(device, parallel=True, uda_name=args.uda, backend_name=args.backend)
         batch = synthetic_batch(args.batch, args.size, 42, device, rotated=UDA_WORKLOADS[args.uda][2])
         for _ in range(3):
@@ -293,11 +308,13 @@ def dp1_rccl_leg(device, args):
                 'what': 'same workload, uda.Model.to(device, parallel=True): hip_runtime.parallel.DataParallel over a '
                         'one-rank RCCL process group (all-reduce = identity, every launch and wait of the N > 1 path)'}
     finally:
-        if created:
-            dist.destroy_process_group()
-        sys.stdout.flush()
-        os.dup2(saved_fd, 1)
-        os.close(saved_fd)
+        try:
+            if created:
+                dist.destroy_process_group()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
 
 def other_configs(device, skip):

@@ -418,7 +418,11 @@ class _Aliases:
         self.t, self.pool = t, (list(fork(t, n)) if n > 1 else None)
 
     def take(self):
-        return self.pool.pop() if self.pool else self.t      # (more readers than planned: the tensor itself -- still correct)
+        if self.pool is None:                    # planned for one reader: the tensor itself
+            return self.t
+        if not self.pool:
+            raise RuntimeError("DLAUp / IDAUp read a tensor more often than _FanPlan counted: plan() and forward() drifted apart")
+        return self.pool.pop()
 
 
 class _FanPlan:
@@ -438,13 +442,15 @@ class _FanPlan:
         y = out[:seg.last_level - seg.first_level]
         IDAUp.plan(y, 0, len(y), reads, fresh)
         reads[y[-1]] += 1                      # the map the heads read
-        self.reads, self.n = reads, 0
+        self.reads, self.n, self.n_ids = reads, 0, counter[0]
 
     def start(self):
         self.n = 0
         return self
 
     def wrap(self, t):
+        if self.n >= self.n_ids:
+            raise RuntimeError("DLAUp / IDAUp produced more tensors than _FanPlan walked: plan() and forward() drifted apart")
         self.n += 1
         return _Aliases(t, self.reads[self.n - 1])
 
@@ -475,6 +481,7 @@ class DLASeg(nn.Module):
         if base_name != 'dla34':
             raise ValueError("only 'dla34' is built (dla.py:521 hard-codes it)")
         self.down_ratio, self.rotated_boxes = down_ratio, rotated_boxes
+        self._fan_plan = None       # (n feature maps, _FanPlan): the aggregation's reader counts, walked once
         self.first_level, self.last_level = int(math.log2(down_ratio)), last_level
         self.base = dla34(pretrained=pretrained)
         if freeze_base:
@@ -515,7 +522,9 @@ class DLASeg(nn.Module):
             self.ida_up(y, 0, len(y))
             return y[-1]
         # recording a tape: every tensor of the aggregation is handed out as one alias per reader (hip_runtime.fanout)
-        fan = _FanPlan(self, len(feats)).start()
+        if self._fan_plan is None or self._fan_plan[0] != len(feats):     # built once: the module tree is fixed after __init__
+            self._fan_plan = (len(feats), _FanPlan(self, len(feats)))
+        fan = self._fan_plan[1].start()
         feats = self.dla_up(feats, fan)
         y = list(feats[:self.last_level - self.first_level])
         self.ida_up(y, 0, len(y), fan)

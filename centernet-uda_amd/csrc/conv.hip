@@ -832,7 +832,12 @@ extern "C" int cnuda_conv2d_backward_data_add(const float* grad_y, const float* 
     CNUDA_REQUIRE(grad_y && weight && grad_x, "cnuda_conv2d_backward_data: null pointer");
     ConvGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_backward_data")) return rc;
-    if (sh == 1 && sw == 1 && smallc_supported(Cout, C, kh, kw, 1, 1) && kh - 1 - ph >= 0 && kw - 1 - pw >= 0) {
+    // An addend that IS grad_x (the fan-in slots of hip_runtime.fanout accumulate in place) must be read before the
+    // tile is stored: the implicit-GEMM epilogues below do that per element; the LDS-tile kernels store first and add
+    // in a second pass, which would double the new gradient and lose the old content -> they take the call only when
+    // no addend aliases the output.
+    const bool aliased = (addend && addend == grad_x) || (addend2 && addend2 == grad_x);
+    if (!aliased && sh == 1 && sw == 1 && smallc_supported(Cout, C, kh, kw, 1, 1) && kh - 1 - ph >= 0 && kw - 1 - pw >= 0) {
         // (the LDS-tile kernels of the 3- / 16-channel layers have no addend: one elementwise pass behind them)
         if (int rc = smallc_forward(grad_y, weight, nullptr, grad_x, B, Cout, g.Ho, g.Wo, C, kh, kw, 1, kh - 1 - ph,
                                     kw - 1 - pw, -1.0f, 1, workspace, workspace_bytes, (hipStream_t)stream))

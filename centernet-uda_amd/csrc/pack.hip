@@ -196,8 +196,17 @@ std::atomic<unsigned long long> g_pack_fills{0};   // cached images (re)written 
 // scheduled; it happens at the next cnuda_pack_stamp of a cached call -- never in the middle of an entry point, whose
 // earlier packs may still be in flight in slots a reset would hand out again -- and forgets every slot: the live
 // modules re-pack once, on the launch stream, in stream order behind everything that still reads the old images.
+// A working set LARGER than the arena (teacher + student, a small CNUDA_PACK_CACHE_MB) would fill it again within one
+// step of every reset and re-pack everything every step: a reset is therefore only honoured when at least
+// g_pack_reset_min_stamps stamped calls have gone by since the previous one, and that distance doubles with every reset
+// (1,024 stamps ~ 7 DLA-34 steps at first) -- in between, the slots that fit stay cached and only the overflow is
+// served from the workspace, which is what the cache did before it had a reset.
+// Threading: the stamp / slot state is per process; the library expects ONE thread at a time inside its convolution
+// entry points (torch runs backward() on its device thread while the caller's thread blocks, so a training loop
+// satisfies this by construction).  Two threads driving convolutions concurrently must not share a pack arena.
 std::atomic<bool> g_pack_reset_wanted{false};
 std::atomic<unsigned long long> g_pack_resets{0};
+unsigned long long g_pack_stamps_since_reset = ~0ull >> 1, g_pack_reset_min_stamps = 0;
 thread_local uint64_t g_pack_token = 0, g_pack_version = 0;
 
 // -> cached slot to use (fill == true: pack into it first), or nullptr: use the workspace
@@ -300,6 +309,8 @@ extern "C" int cnuda_pack_cache_attach(void* arena, size_t bytes) {
     cnuda::g_pack_arena_bytes = arena ? bytes - (size_t)(cnuda::g_pack_arena - (char*)arena) : 0;
     cnuda::g_pack_arena_used = 0;
     cnuda::g_pack_reset_wanted = false;
+    cnuda::g_pack_stamps_since_reset = ~0ull >> 1;       // a fresh arena: its first overflow may reset at once
+    cnuda::g_pack_reset_min_stamps = 0;
     ++cnuda::g_pack_generation;
     if (!arena) cnuda::g_pack_arena = nullptr;
     return 0;
@@ -424,9 +435,16 @@ extern "C" int cnuda_pack_refresh(const void* params, size_t params_bytes, unsig
 
 extern "C" int cnuda_pack_stamp(unsigned long long token, unsigned long long version) {
     using namespace cnuda;
+    if (token != 0) ++g_pack_stamps_since_reset;
     if (token != 0 && g_pack_reset_wanted) {
         std::lock_guard<std::mutex> lock(g_pack_mutex);
-        if (g_pack_reset_wanted) {
+        if (g_pack_reset_wanted && g_pack_stamps_since_reset < g_pack_reset_min_stamps) {
+            g_pack_reset_wanted = false;     // too soon after the last one: the live set does not fit, keep what does
+        } else if (g_pack_reset_wanted) {
+            g_pack_stamps_since_reset = 0;
+            g_pack_reset_min_stamps = g_pack_reset_min_stamps ? (g_pack_reset_min_stamps < (1ull << 20) ? 2 * g_pack_reset_min_stamps
+                                                                                                      : g_pack_reset_min_stamps)
+                                                              : 1024;
             g_pack_slots.clear();
             g_pack_arena_used = 0;
             ++g_pack_generation;

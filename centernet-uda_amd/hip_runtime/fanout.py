@@ -13,8 +13,9 @@ alias of `x`; the aliases share a GradSlot, and the consumers' backward passes m
 
 A slot belongs to ONE fork.  An alias forked again gets a fresh slot that remembers its parent: the inner fork's total
 is one contribution to the parent, and a convolution of the inner fork whose parent already holds an owned buffer
-writes `own share + parent's content + inner content` there in one epilogue (two addends) -- the inner slot then IS the
-parent's buffer, its fork hands that buffer up, and the parent recognises its own storage: nothing is counted twice.
+writes `own share + parent's content + inner content` there in one epilogue (two addends) -- the inner slot then is an
+ALIAS of its parent (`GradSlot.up`), its fork hands the parent's buffer up, and the parent recognises its own storage:
+nothing is counted twice, at any nesting depth.
 Outside a grad-enabled graph `fork` returns `x` itself n times.
 """
 import torch
@@ -25,14 +26,44 @@ from . import check, f32c, lib, ptr, stream
 
 
 class GradSlot:
-    __slots__ = ('buf', 'owned', 'parent', 'included')
+    """Running total of one fork's gradient shares.  A slot that has merged into its parent (`up`) is from then on a pure
+    alias of it: `buf`, `owned` and `included` resolve through the chain, so every consumer -- whichever level's alias
+    it holds, and however far the parents have merged upwards since -- sees the ONE buffer the totals live in."""
+    __slots__ = ('_buf', '_owned', '_included', 'parent', 'up')
 
     def __init__(self, parent=None):
-        self.buf = None       # running total of the shares that went through the slot so far
-        self.owned = False    # buf was allocated for this slot (nobody else holds it): adding into it in place is safe
+        self._buf = None      # running total of the shares that went through the slot so far
+        self._owned = False   # buf was allocated for this slot (nobody else holds it): adding into it in place is safe
         self.parent = parent  # the slot of the alias this fork was made from (nested forks)
-        self.included = []    # tensors slot-aware consumers wrote and handed to autograd as their gradient: already in the
+        self.up = None        # the slot this one's total has been folded into (accumulate_target's parent merge)
+        self._included = []   # tensors slot-aware consumers wrote and handed to autograd as their gradient: already in the
                               # total when `_Fork.backward` meets them (held here, so their storage cannot be reused meanwhile)
+
+    def root(self):
+        s = self
+        while s.up is not None:
+            s = s.up
+        return s
+
+    @property
+    def buf(self):
+        return self.root()._buf
+
+    @buf.setter
+    def buf(self, t):
+        self.root()._buf = t
+
+    @property
+    def owned(self):
+        return self.root()._owned
+
+    @owned.setter
+    def owned(self, v):
+        self.root()._owned = v
+
+    @property
+    def included(self):
+        return self.root()._included
 
     def has(self, g):
         p = g.data_ptr()
@@ -75,12 +106,16 @@ def accumulate_target(slot, like):
     -> (out, addend, addend2): write `out = own share + addend + addend2` (None: nothing to add).  The slot then holds `out`."""
     if slot is None:
         return torch.empty_like(like), None, None
-    par = slot.parent
-    if par is not None and par.buf is not None and par.owned and (slot.buf is None or slot.buf.data_ptr() != par.buf.data_ptr()):
-        # merge into the parent's buffer: parent's content + this slot's content + the consumer's share, in place
-        out, addend, addend2 = par.buf, par.buf, slot.buf
-        slot.buf, slot.owned = out, True
-        slot.included.append(out)
+    slot = slot.root()
+    par = None if slot.parent is None else slot.parent.root()
+    if par is not None and par.buf is not None and par.owned:
+        # merge into the parent's buffer: parent's content + this slot's content + the consumer's share, in place.  From
+        # here on the slot is an alias of its parent (`up`): whatever it held is folded exactly once, and a later
+        # consumer -- also one that arrives after the parent itself has merged further up -- adds to the live total.
+        out, addend, addend2 = par.buf, par.buf, slot._buf
+        par._included.extend(slot._included)
+        par._included.append(out)
+        slot._buf, slot._owned, slot._included, slot.up = None, False, [], par
         return out, addend, addend2
     if slot.buf is None:
         out, addend = torch.empty_like(like), None
@@ -107,8 +142,11 @@ class _Fork(Function):
         for g in gs:
             if g is not None:
                 add_into(slot, g)
-        total, slot.buf = slot.buf, None
-        slot.included = []
+        if slot.up is not None:            # folded into an outer fork's total: hand that buffer up, the outer fork knows it
+            total, slot.up = slot.buf, None    # (this fork's last act in the pass: a later pass over the graph starts unmerged)
+            return total, None, None
+        total, slot._buf = slot._buf, None
+        slot._included = []
         return total, None, None
 
 

@@ -6,7 +6,7 @@ Replaces the reference's single-process `CustomDataParallel(nn.DataParallel)`
 (utils/helper.py:75-80; scatter / replicate / gather / ReduceAddCoalesced
 through device 0).  Semantics: each rank owns its own per-GPU batch and its own
 BatchNorm statistics (as DataParallel's replicas do); gradients are averaged
-over ranks (sum / world_size).  The reference's loss sees the gathered global
+over ranks (RCCL's averaging all-reduce; sum then / world_size on gloo).  The reference's loss sees the gathered global
 batch; losses.centernet.DetectionLoss.use_global_normalizers() (the default of
 uda.base.Model.to(parallel=True)) scales every rank's loss so that this average
 is the gradient of that global loss.
@@ -42,6 +42,7 @@ class DataParallel(nn.Module):
         self.process_group = process_group
         self._sync = True
         self._works = []
+        self._avg_in_collective = None      # decided at the first all-reduce: RCCL yes, gloo no
         # what the exchange step did since the last reset_exchange_stats(): bytes / buckets all-reduced, and the time the
         # compute stream spent waiting for collectives that had not finished under the backward pass ("exposed")
         self.measure_exchange = False
@@ -162,7 +163,15 @@ class DataParallel(nn.Module):
             chunk = self.arena.flat_grad[b[0]:b[1]]
             self._xstats['bytes'] += chunk.numel() * chunk.element_size()
             self._xstats['buckets'] += 1
-            self._works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True))
+            self._works.append(dist.all_reduce(chunk, op=self._reduce_op(), group=self.process_group, async_op=True))
+
+    def _reduce_op(self):
+        """RCCL averages inside the collective (ncclAvg: every rank's contribution is scaled by 1 / world as it is
+        read, no pass of its own over the 78.6 MB arena); gloo has no such operator -> SUM, and
+        finish_gradient_sync() scales."""
+        if self._avg_in_collective is None:
+            self._avg_in_collective = dist.get_backend(self.process_group) == 'nccl'
+        return dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
 
     def _param_ready(self, i):
         if not self._sync:
@@ -189,6 +198,6 @@ class DataParallel(nn.Module):
             self._xstats['host_wait_s'] += time.perf_counter() - t0
         self._xstats['steps'] += 1
         self._works = []
-        if self.world_size > 1:
-            self.arena.flat_grad.mul_(1.0 / self.world_size)
+        if self.world_size > 1 and not self._avg_in_collective:
+            self.arena.flat_grad.mul_(1.0 / self.world_size)       # (gloo only: the CPU / shared-GPU test backends)
         self._reset()

@@ -121,3 +121,82 @@ def test_head_on_the_leading_images_leaves_a_whole_gradient():
         (heads[0](h).sum() * 1.5 + heads[1](h[:2]).sum() * 2.5).backward()
         _close(got, x.grad, 1e-5)
         assert got[2:].abs().sum() > 0
+
+
+@pytest.mark.parametrize('ch', [16, 32])
+def test_block_at_sixteen_channels_accumulates_in_place(ch):
+    """A forked BasicBlock whose convolutions have <= 16 channels: the slot's owned buffer is BOTH the addend and the output
+    of conv1's input gradient.  The LDS-tile kernels (smallc) store before they add and must not take that call."""
+    from hip_runtime import ops
+    x, w0, w1, w2, gam, bet = _leaves((2, ch, 24, 24), (ch, ch, 3, 3), (ch, ch, 3, 3), (ch, ch, 3, 3), (ch,), (ch,))
+    rm, rv = torch.zeros(ch, device=DEV), torch.ones(ch, device=DEV)
+
+    def bn(t, res=None):
+        return ops.batch_norm_act(t, gam, bet, rm.clone(), rv.clone(), True, residual=res, relu=True)
+
+    def build(fork, x, w0, w1, w2, gam, bet):
+        h = ops.conv2d(x, w0, None, 1, 1)
+        a, b = fork(h, 2)                        # bn2's residual share is written first, conv1's dgrad adds into it
+        return bn(ops.conv2d(bn(ops.conv2d(a, w1, None, 1, 1)), w2, None, 1, 1), res=b)
+
+    leaves = [x, w0, w1, w2, gam, bet]
+    got = _run(build, leaves, True)
+    want = _run(build, leaves, False)
+    for a, b in zip(got, want):
+        _close(a, b)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 16, 20, 20, 3), (2, 3, 16, 20, 20, 7), (2, 64, 32, 12, 12, 3)])
+def test_backward_data_add_with_the_output_as_addend(shape):
+    """C ABI: `addend == grad_x` (and `addend2 == grad_x`) means grad_x += dgrad, whichever kernel family takes the layer."""
+    import hip_runtime as hr
+    from hip_runtime import ops
+    B, C, Co, H, W, k = shape
+    L = hr.lib()
+    g = torch.Generator().manual_seed(7)
+    gy = torch.randn(B, Co, H, W, generator=g).to(DEV)
+    w = (torch.randn(Co, C, k, k, generator=g) / k).to(DEV)
+    base = torch.randn(B, C, H, W, generator=g).to(DEV)
+    geom = (B, C, H, W, Co, k, k, 1, 1, k // 2, k // 2)
+    wp, wn = ops._ws(L.cnuda_conv2d_workspace_bytes(*geom), gy)
+    plain = torch.empty_like(base)
+    hr.check(L.cnuda_conv2d_backward_data(hr.ptr(gy), hr.ptr(w), hr.ptr(plain), *geom, wp, wn, hr.stream()), 'dgrad')
+    for which in (0, 1):
+        acc = base.clone()
+        add = (hr.ptr(acc), hr.ptr(None)) if which == 0 else (hr.ptr(None), hr.ptr(acc))
+        hr.check(L.cnuda_conv2d_backward_data_add(hr.ptr(gy), hr.ptr(w), add[0], add[1], hr.ptr(acc), *geom, wp, wn,
+                                                  hr.stream()), 'dgrad_add')
+        _close(acc, base + plain, 2e-6)
+    other = torch.randn(B, C, H, W, generator=g).to(DEV)
+    acc = base.clone()
+    hr.check(L.cnuda_conv2d_backward_data_add(hr.ptr(gy), hr.ptr(w), hr.ptr(acc), hr.ptr(other), hr.ptr(acc), *geom, wp, wn,
+                                              hr.stream()), 'dgrad_add2')
+    _close(acc, base + other + plain, 2e-6)
+
+
+def test_three_levels_of_forks_with_several_convolutions_on_the_innermost():
+    """X forked from an alias of Y forked from an alias of Z: X merges into Y, Y into Z, then ANOTHER convolution of X arrives
+    -- its slot must add to the live total (Z's buffer), and what X and Y held is counted exactly once."""
+    from hip_runtime import ops
+    x, w1, w2, w3, w4 = _leaves((2, 32, 12, 12), (32, 32, 3, 3), (32, 32, 3, 3), (32, 32, 3, 3), (32, 32, 1, 1))
+
+    def build(fork, x, w1, w2, w3, w4):
+        h = ops.conv2d(x, w1, None, 1, 1)
+        z1, z2 = fork(h, 2)                      # Z: outermost
+        y1, y2 = fork(z1, 2)                     # Y
+        x1, x2, x3 = fork(y1, 3)                 # X: innermost, three convolutions
+        # backward order = reverse of creation: z2's consumer first (owned buffer in Z), then x3, y2, x2, x1
+        o = ops.conv2d(x1, w2, None, 1, 1)
+        o = o + ops.conv2d(x2, w3, None, 1, 1)
+        o = o + ops.conv2d(y2, w4, None, 1, 0)
+        o = o + ops.conv2d(x3, w2, None, 1, 1)
+        return o + ops.conv2d(z2, w3, None, 1, 1)
+
+    leaves = [x, w1, w2, w3, w4]
+    got = _run(build, leaves, True)
+    want = _run(build, leaves, False)
+    for a, b in zip(got, want):
+        _close(a, b, 5e-6)
+    got2 = _run(build, leaves, True)             # slots are per forward: a second build starts unmerged
+    for a, b in zip(got2, got):
+        assert torch.equal(a, b)

@@ -448,6 +448,15 @@ def test_pack_cache_starts_over_when_the_arena_is_full():
                     _close(c(x), F.conv2d(x.cpu(), c.weight.detach().cpu(), c.bias.detach().cpu(), 1, 1), 1e-4)
                     assert L.cnuda_pack_cache_used() <= small.numel()
         assert L.cnuda_pack_cache_resets() > r0
+        # a live working set LARGER than the arena must not start over on every pass: the slots that fit
+        # stay, the overflow is packed into the caller's workspace, resets are at least 1,024 stamped calls apart
+        r_mid = L.cnuda_pack_cache_resets()
+        with torch.no_grad():
+            for rounds in range(4):
+                for c in convs:
+                    _close(c(x), F.conv2d(x.cpu(), c.weight.detach().cpu(), c.bias.detach().cpu(), 1, 1), 1e-4)
+        assert L.cnuda_pack_cache_resets() == r_mid
+        hr.check(L.cnuda_pack_cache_attach(hr.ptr(small), small.numel()), 'attach')      # (fresh arena for the next part)
         # steady state of a working set that fits: two modules, no further fills, no further resets
         pair = convs[:2]
         with torch.no_grad():
