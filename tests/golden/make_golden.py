@@ -188,6 +188,16 @@ GRAD_PROBES = [
 ]
 
 
+# Whole gradient tensors (small ones) stored by the *128 step fixtures: a sparse defect -- a dropped store, one wrong tile --
+# passes three moments of a tensor; it does not pass an element-wise comparison.  One detection-head output layer, one DCN
+# offset / mask convolution (its gradient flows through the deformable sampling's coordinate path), a strided 3x3 of the
+# base, a depthwise transposed convolution of IDAUp, and a BatchNorm scale deep in the tree.
+FULL_GRADS = [
+    'hm.2.weight', 'wh.2.weight', 'ida_up.node_1.conv.conv_offset_mask.weight', 'base.level2.tree1.conv1.weight',
+    'dla_up.ida_1.up_2.weight', 'base.level4.tree1.tree2.bn2.weight',
+]
+
+
 def _dla_case(dla, rotated, B, S, seed, dtype):
     """Reference DLASeg at `dtype` (float32 = the reference's arithmetic; float64 =
     the same module evaluated exactly, used by the tests to express tolerances
@@ -500,6 +510,8 @@ def _base_step_case(uda, dla, dtype):
         if params[n].grad is not None:
             res['gradsum__' + n] = _checksums(params[n].grad)
             res['param__' + n] = _checksums(params[n])
+    for n in FULL_GRADS:
+        res['grad__' + n] = params[n].grad.detach().numpy().copy()
     sd = model.state_dict()
     for n in ('base.base_layer.1', 'base.level5.tree2.bn2', 'ida_up.node_2.actf.0'):
         res['rm__' + n] = sd[n + '.running_mean'].numpy()
@@ -515,7 +527,7 @@ def make_base_step(dla):
     r64 = _base_step_case(uda, dla, torch.float64)
     out = dict(r32)
     for k, v in r64.items():
-        if k.startswith(('stat_', 'eval_', 'train_', 'gradsum__')) and k != 'stat_keys':
+        if k.startswith(('stat_', 'eval_', 'train_', 'gradsum__', 'grad__')) and k != 'stat_keys':
             out['f64_' + k] = v
     save('step_base128', **out)
 
@@ -586,10 +598,13 @@ def _uda_step128_case(uda, dla, tag, dtype):
         if n in params and params[n].grad is not None:
             res['gradsum__' + n] = _checksums(params[n].grad)
             res['param__' + n] = _checksums(params[n])
+    for n in FULL_GRADS:
+        res['grad__' + n] = params[n].grad.detach().numpy().copy()
     if tag == 'advent':
         for n, p_ in plugin.discriminator.named_parameters():
             res['dgradsum__' + n] = _checksums(p_.grad)
             res['dparam__' + n] = _checksums(p_)
+        res['dgrad__0.weight'] = dict(plugin.discriminator.named_parameters())['0.weight'].grad.detach().numpy().copy()
         res['source_generator'] = out['source_generator'].detach().numpy()
     sd = model.state_dict()
     for n in ('base.base_layer.1', 'base.level5.tree2.bn2', 'ida_up.node_2.actf.0'):
@@ -607,7 +622,8 @@ def make_uda_step128(dla, tags=None):
         r64 = _uda_step128_case(uda, dla, tag, torch.float64)
         out = dict(r32)
         for k, v in r64.items():
-            if k.startswith(('stat_', 'src_', 'tgt_', 'gradsum__', 'dgradsum__', 'source_generator', 'rm__', 'rv__')) \
+            if k.startswith(('stat_', 'src_', 'tgt_', 'gradsum__', 'dgradsum__', 'grad__', 'dgrad__', 'source_generator',
+                             'rm__', 'rv__')) \
                     and k != 'stat_keys':
                 out['f64_' + k] = v
         save('step_%s128' % tag, **out)

@@ -361,4 +361,27 @@ MANIFEST = {
         'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
         'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
     ],
+    # ---- kernels only the other BASELINE configs launch (round 5: the guard runs configs[0], [1], [3], [4] at full size too) ----
+    'act_bwd_kernel': [           # LeakyReLU(0.2) gate of the discriminator's convolutions (configs[4])
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[disc4x4',
+        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
+    ],
+    'bce_const_fwd_kernel': ['tests/test_gpu_losses.py::test_uda_losses_golden'],
+    'bce_const_bwd_kernel': ['tests/test_gpu_losses.py::test_uda_losses_golden'],
+    'entropy_map_fwd_kernel': ['tests/test_gpu_losses.py::test_uda_losses_golden'],
+    'entropy_map_bwd_kernel': ['tests/test_gpu_losses.py::test_uda_losses_golden'],
+    'conv1x1_dgrad_act_kernel<3>': [          # the rotated-box `wh` head (3 outputs)
+        'tests/test_gpu_dla.py::test_dla_forward_backward_golden[rot',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4[advent',
+    ],
+    'igemm_fwd_kernel<32, ConvDgradLoader, false>': [
+        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
+        'tests/test_gpu_fanout.py::test_backward_data_add_with_the_output_as_addend',
+    ],
+    'igemm_fwd_ws_kernel<64, ConvFwdLoader<false>, 16>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[disc4x4_full',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[resnet_stem_full',
+    ],
+    'maxpool_win_fwd_kernel': ['tests/test_gpu_resnet.py::test_max_pool_window_matches_torch'],
+    'maxpool_win_bwd_kernel': ['tests/test_gpu_resnet.py::test_max_pool_window_matches_torch'],
 }

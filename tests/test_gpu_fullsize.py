@@ -8,7 +8,9 @@ checked through size-independent properties -- the CPU oracle needs about a minu
 * a step is a function of (parameters, batch): two runs from the same state agree (the only order-dependent
   arithmetic left is the float atomics of col2im's stragglers);
 * loss values of the full-size batch are finite and equal the loss kernels evaluated on the step's own head
-  outputs by the CPU oracle (the loss is cheap on the CPU even at this size).
+  outputs by the CPU oracle (the loss is cheap on the CPU even at this size);
+* configs[3] (max-squares, 512 x 512) and configs[4] (rotated + periodic + ADVENT, 640 x 640) the same way, the
+  latter with the discriminator, its three adversarial statistics and its whole gradient re-evaluated on the CPU.
 """
 import numpy as np
 import pytest
@@ -18,12 +20,14 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda', 0)
 
 
-def _run(uda_name, weight=None, steps=1, seed=42):
+def _run(uda_name, weight=None, steps=1, seed=42, size=512, before_step=None):
     import bench
     plugin = bench.build_plugin(DEV, parallel=False, uda_name=uda_name)
     if weight is not None:
         plugin.entropy_weight = weight
-    batch = bench.synthetic_batch(16, 512, seed, DEV)
+    batch = bench.synthetic_batch(16, size, seed, DEV, rotated=bench.UDA_WORKLOADS[uda_name][2])
+    if before_step is not None:
+        before_step(plugin)
     outs = [plugin.step(dict(batch)) for _ in range(steps)]
     torch.cuda.synchronize()
     model = plugin.backend
@@ -87,6 +91,143 @@ def test_full_size_uda_step_is_reproducible():
     for n in b1:
         if b1[n].is_floating_point():
             assert torch.equal(b1[n], b2[n]), n
+
+
+def _grads(plugin, module=None):
+    m = plugin.backend if module is None else module
+    return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+
+def _same_step_twice(run):
+    """`run() -> (plugin, outs)`, twice from the same state: statistics and head outputs bit-equal, gradients equal up to
+    the float atomics of col2im's stragglers (1e-4 of the tensor's maximum; DCN biases in front of a BatchNorm are
+    rounding noise only)."""
+    pl1, o1 = run()
+    g1 = _grads(pl1)
+    pl2, o2 = run()
+    g2 = _grads(pl2)
+    for k in o1['stats']:
+        assert float(o1['stats'][k]) == float(o2['stats'][k]), k
+    for dom in ('source_domain', 'target_domain'):
+        for k in o1[dom]:
+            assert torch.equal(o1[dom][k], o2[dom][k]), (dom, k)
+    assert sorted(g1) == sorted(g2)
+    for n in g1:
+        if n.endswith('.conv.bias') and 'ida' in n:
+            continue
+        assert (g1[n] - g2[n]).abs().max().item() <= 1e-4 * max(g2[n].abs().max().item(), 1e-12), n
+    return pl1, o1, pl2, o2
+
+
+def test_full_size_max_squares_step_properties():
+    """configs[3] (uda/max_squares_minimization.py:11-50) at 512 x 512, 16 + 16 images: the detection statistics and the
+    weighted max-squares term re-evaluated by the CPU oracle on the step's OWN head outputs (2e-4), weight 0 = the
+    configs[1] step (same detection gradient -> same parameters after Adam), two runs agree."""
+    from oracle import losses as ol
+    _, batch, out_b, p_base, _ = _run('none')
+
+    def zero_weight(plugin):
+        plugin.max_squares_weight = 0.0
+    _, _, out_0, p_0, b_0 = _run('maxsq', before_step=zero_weight)
+    sb, s0 = out_b[0]['stats'], out_0[0]['stats']
+    for k in ('centernet_loss', 'hm_loss', 'wh_loss', 'off_loss'):
+        assert abs(float(sb[k]) - float(s0[k])) <= 1e-6 * abs(float(sb[k])), k
+    assert float(s0['max_square_loss']) == 0.0
+    lr, moved, total = 5e-5, 0, 0
+    for n in p_base:
+        d = (p_base[n] - p_0[n]).abs()
+        assert d.max().item() <= 2.1 * lr, (n, d.max().item())
+        if not n.endswith('.conv.bias'):
+            moved += int((d > 1e-7).sum())
+            total += d.numel()
+    assert moved <= 1e-3 * total, (moved, total)
+    assert all(int(v) == 2 for n, v in b_0.items() if n.endswith('num_batches_tracked'))           # Q6
+
+    def run():
+        pl, _, outs, _, _ = _run('maxsq')
+        return pl, outs[0]
+    pl, o, _, _ = _same_step_twice(run)
+    st = o['stats']
+    assert list(st) == ['centernet_loss', 'hm_loss', 'wh_loss', 'off_loss', 'max_square_loss', 'total_loss']
+    src = {k: v.detach().float().cpu() for k, v in o['source_domain'].items()}
+    logits = torch.log(src['hm'] / (1 - src['hm']))                                    # the dict holds probabilities (Q1)
+    cb = {k: v.cpu() for k, v in batch.items()}
+    _, want, _ = ol.detection_loss(dict(src, hm=logits), cb, 1.0, 0.1, 1.0, 1.0, False)
+    for k, v in want.items():
+        assert abs(float(v) - float(st[k])) <= 2e-4 * max(abs(float(v)), 1e-3), (k, float(v), float(st[k]))
+    msq = 0.3 * float(ol.max_square_loss(o['target_domain']['hm'].detach().float().cpu()))   # logged WEIGHTED (Q4)
+    assert abs(msq - float(st['max_square_loss'])) <= 2e-4 * abs(msq), (msq, float(st['max_square_loss']))
+    assert abs(float(st['total_loss']) - (float(st['centernet_loss']) + float(st['max_square_loss']))) <= 1e-5 * abs(float(st['total_loss']))
+
+
+def test_full_size_advent_step_properties():
+    """configs[4] (uda/adversarial_entropy_minimization.py:77-152) at 640 x 640, 16 + 16 images, rotated boxes, periodic
+    angle loss, the 5-layer conv4x4-s2 discriminator on 160 x 160 maps.  On the step's OWN head outputs the CPU oracle
+    re-evaluates: the detection statistics (rotated + periodic, 2e-4); entropy_map + discriminator + BCE for the three
+    adversarial statistics and `source_generator` with the discriminator's weights from BEFORE the step; the
+    discriminator's whole gradient (its two backward calls) element by element.  Two runs agree."""
+    import math
+    import torch.nn.functional as F
+    from oracle import losses as ol
+    d_before = {}
+
+    def grab(plugin):
+        d_before.update({k: v.detach().clone().cpu() for k, v in plugin.discriminator.state_dict().items()})
+
+    def run():
+        pl, batch, outs, _, _ = _run('advent', size=640, before_step=grab)
+        run.batch = batch
+        return pl, outs[0]
+    pl, o, _, _ = _same_step_twice(run)
+    st = o['stats']
+    assert list(st) == ['centernet_loss', 'hm_loss', 'wh_loss', 'off_loss', 'total_loss', 'dis_soruce', 'dis_target',
+                        'dis_fool']
+    assert all(math.isfinite(float(v)) for v in st.values()), st
+    assert o['source_domain']['hm'].shape == (16, 6, 160, 160) and o['source_domain']['wh'].shape == (16, 3, 160, 160)
+    src = {k: v.detach().float().cpu() for k, v in o['source_domain'].items()}
+    tgt_logits = o['target_domain']['hm'].detach().float().cpu()
+    logits = torch.log(src['hm'] / (1 - src['hm']))
+    cb = {k: v.cpu() for k, v in run.batch.items()}
+    _, want, _ = ol.detection_loss(dict(src, hm=logits), cb, 1.0, 0.1, 1.0, 1.0, True)
+    for k, v in want.items():
+        assert abs(float(v) - float(st[k])) <= 2e-4 * max(abs(float(v)), 1e-3), (k, float(v), float(st[k]))
+    # the discriminator on the CPU (uda/adversarial_entropy_minimization.py:51-68), weights as they were before the step;
+    # in float64 (the value) and in float32 (how far a float32 evaluation of the SAME graph lands from it: near its
+    # initialisation the discriminator's weight gradients are sums of +- terms that cancel to ~1e-3 of their parts)
+    def cpu_discriminator(dtype):
+        w = {k: v.clone().to(dtype).requires_grad_(True) for k, v in d_before.items()}
+
+        def D(x):
+            for i in (0, 2, 4, 6):
+                x = F.leaky_relu(F.conv2d(x, w['%d.weight' % i], w['%d.bias' % i], 2, 1), 0.2)
+            return F.conv2d(x, w['8.weight'], w['8.bias'], 2, 1)
+        s_logits = D(ol.entropy_map(src['hm'].to(dtype)))        # softmax over PROBABILITIES (Q1)
+        t_logits = D(ol.entropy_map(tgt_logits.to(dtype)))
+        ds, dt = ol.advent_loss(s_logits, 0) / 2, ol.advent_loss(t_logits, 1) / 2
+        fool = 1e-3 * ol.advent_loss(t_logits, 0)
+        (ds + dt).backward()
+        return s_logits.detach(), {'dis_soruce': ds.item(), 'dis_target': dt.item(), 'dis_fool': fool.item()}, \
+            {k: v.grad.double() for k, v in w.items()}
+    s_logits, want_d, g64 = cpu_discriminator(torch.float64)
+    _, _, g32 = cpu_discriminator(torch.float32)
+    assert s_logits.shape == (16, 1, 5, 5)
+    for k, v in want_d.items():
+        assert abs(v - float(st[k])) <= 2e-4 * abs(v), (k, v, float(st[k]))
+    tot = float(st['centernet_loss']) + float(st['dis_soruce']) + float(st['dis_target']) + float(st['dis_fool'])
+    assert abs(tot - float(st['total_loss'])) <= 1e-5 * abs(tot)
+    got_sg = o['source_generator'].detach().double().cpu()
+    assert (got_sg - s_logits).abs().max().item() <= 1e-4 * max(1.0, s_logits.abs().max().item())
+    dg = _grads(pl, pl.discriminator)
+    assert sorted(dg) == sorted(g64)
+    for n, g in dg.items():
+        ref = g64[n]
+        scale, err = ref.abs().max().item(), (g.double().cpu() - ref).abs().max().item()
+        noise = (g32[n] - ref).abs().max().item()
+        print('discriminator %-10s %8d elements  err/max %.2e  float32-on-CPU noise/max %.2e'
+              % (n, ref.numel(), err / max(scale, 1e-30), noise / max(scale, 1e-30)))
+        # element by element: 1e-4 of the tensor's maximum, or 8 x the distance of the CPU's own float32 evaluation
+        assert err <= max(1e-4 * scale, 8 * noise), (n, err, scale, noise)
+    assert all(p.requires_grad for p in pl.discriminator.parameters())
 
 
 @pytest.mark.parametrize('B,C,S,Co', [(32, 256, 128, 6), (16, 256, 128, 2), (32, 64, 128, 576), (32, 16, 128, 256),

@@ -40,6 +40,11 @@ CONV_CASES = {
     's2_even': (2, 32, 16, 12, 64, 3, 2, 1, False, -1.0),       # parity-class input gradient
     's2_k1': (2, 16, 8, 8, 32, 1, 2, 0, False, -1.0),           # 1x1 stride 2: three of four classes get zero
     'c16_wgrad16': (2, 16, 12, 12, 48, 3, 1, 1, False, -1.0),   # C % 16 == 0 wgrad path
+    # C % 16 != 0 at sizes that select the 8-wave 64-row tile with the generic im2col loader -- what configs[4]'s
+    # discriminator (first layer: 6 entropy-map channels, 4x4 stride 2) and configs[0]'s ResNet stem (3 -> 64, 7x7
+    # stride 2) run at full size (tests/kernel_manifest.py: igemm_fwd_ws_kernel<64, ConvFwdLoader<false>, 16>)
+    'disc4x4_full': (2, 6, 256, 256, 64, 4, 2, 1, True, 0.2),
+    'resnet_stem_full': (2, 3, 256, 256, 64, 7, 2, 3, False, -1.0),
 }
 
 

@@ -1,8 +1,9 @@
 """Kernel coverage of the benched step (collected last: the file name sorts after every other test file).
 
-1. One training step of the bench workload (bench.py's own builder: DLA-34 + 16 DCNv2, 512 x 512, 16 source + 16
-   target images, entropy minimisation, Adam) runs under the library's launch log; every kernel it launches must be a
-   key of tests/kernel_manifest.py.
+1. One training step of EVERY BASELINE.json config at its full size (bench.py's own builder and bench.CONFIGS: the
+   headline DLA-34 + 16 DCNv2, 512 x 512, 16 source + 16 target images, entropy minimisation, Adam; ResNet-18 at
+   256 x 256; no UDA; max-squares; rotated + periodic + ADVENT at 640 x 640) runs under the library's launch log; every
+   kernel it launches must be a key of tests/kernel_manifest.py.
 2. Every manifest entry is checked against what its tests really launched in THIS session (tests/conftest.py records
    the launch log around every GPU test): the named tests must exist, and at least one of them must have launched the
    kernel."""
@@ -32,33 +33,42 @@ def short(name):
     return re.sub(r'\s+', ' ', ''.join(out)).strip()
 
 
-def _bench_step_kernels():
+def _bench_step_kernels(idx):
+    """One training step of BASELINE.json configs[idx] at its FULL size, built by bench.py's own builder (bench.CONFIGS:
+    backend, UDA method, input size, per-GPU batch), under the library's launch log -> {kernel: launches}."""
     sys.path.insert(0, ROOT)
     import bench
     import hip_runtime as hr
     import torch
     dev = torch.device('cuda', 0)
-    plugin = bench.build_plugin(dev, parallel=False, uda_name='entropy', backend_name='dla34')
-    batch = bench.synthetic_batch(16, 512, 42, dev)
+    backend_name, uda_name, size, batch_n = bench.CONFIGS[idx]
+    plugin = bench.build_plugin(dev, parallel=False, uda_name=uda_name, backend_name=backend_name)
+    batch = bench.synthetic_batch(batch_n, size, 42, dev, rotated=bench.UDA_WORKLOADS[uda_name][2])
     for _ in range(2):
         plugin.step(batch)
     torch.cuda.synchronize()
     with hr.launch_log() as log:
-        plugin.step(batch)
+        out = plugin.step(batch)
         torch.cuda.synchronize()
-    del plugin, batch
+    stats = {k: float(v) for k, v in out['stats'].items()}
+    del plugin, batch, out
     torch.cuda.empty_cache()
-    return {short(k): v for k, v in log.counts.items()}
+    return {short(k): v for k, v in log.counts.items()}, stats
 
 
-def test_every_kernel_of_the_benched_step_has_an_oracle_value_test():
+@pytest.mark.parametrize('idx', [2, 0, 1, 3, 4], ids=lambda i: 'configs%d' % i)
+def test_every_kernel_of_the_benched_step_has_an_oracle_value_test(idx):
+    """configs[2] is the headline; [0] ResNet-18 256 x 256 B = 2, [1] no UDA, [3] max-squares, [4] rotated boxes +
+    periodic angle loss + ADVENT discriminator at 640 x 640 -- every one at the size and batch BASELINE.json names."""
+    import math
     from kernel_manifest import MANIFEST
-    launched = _bench_step_kernels()
+    launched, stats = _bench_step_kernels(idx)
     print('\n'.join('%5d  %s' % (v, k) for k, v in sorted(launched.items(), key=lambda kv: -kv[1])))
-    assert len(launched) > 30, launched            # the log works and the step is the real one
+    assert len(launched) > (20 if idx == 0 else 30), launched     # the log works and the step is the real one
+    assert stats and all(math.isfinite(v) for v in stats.values()), stats
     missing = sorted(k for k in launched if k not in MANIFEST)
-    assert not missing, ('kernels of the benched step without an entry in tests/kernel_manifest.py '
-                         '(add an oracle-value test that selects each, then name it there): %s' % missing)
+    assert not missing, ('kernels of the configs[%d] step without an entry in tests/kernel_manifest.py '
+                         '(add an oracle-value test that selects each, then name it there): %s' % (idx, missing))
 
 
 def test_manifest_tests_really_launch_their_kernels(request):
