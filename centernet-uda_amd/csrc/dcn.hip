@@ -1525,6 +1525,9 @@ __global__ __launch_bounds__(512, 6) void dcn_bwd_data_kernel(DcnBwdDataParams p
         valid = oy < g.Ho && ox < g.Wo;
         return valid ? oy * g.Wo + ox : 0;
     };
+#ifdef DCN_ABLATE          // A/B builds only (profiles/microbench): 1 = no gather role, 2 = no scatter role
+    if ((DCN_ABLATE == 1) == (threadIdx.x >= 256)) return;
+#endif
     if (threadIdx.x >= 256) {
         // ---- gather role: grad_offset / grad_mask of pixel group `wid` (dcn_coord_grad_kernel's arithmetic) ----
         bool valid;

@@ -32,6 +32,8 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     args = ap.parse_args()
     import hip_runtime as hr
+    if os.environ.get('ABL_LIB'):          # another build of the library (profiles/microbench/build_variant.sh)
+        hr.LIB_PATH = os.environ['ABL_LIB']
     from hip_runtime import ops
     dev = torch.device('cuda', 0)
     print('CNUDA_HCONV=%s' % os.environ.get('CNUDA_HCONV', '(unset)'))

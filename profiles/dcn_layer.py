@@ -12,6 +12,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import hip_runtime as hr  # noqa: E402
+if os.environ.get('ABL_LIB'):          # another build of the library (profiles/microbench/build_variant.sh)
+    hr.LIB_PATH = os.environ['ABL_LIB']
 from libs.DCNv2.dcn_v2 import DCN  # noqa: E402
 
 ap = argparse.ArgumentParser()

@@ -14,6 +14,9 @@ for p in (GOLDEN, ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    if os.environ.get('ABL_LIB'):      # A/B builds of the library (profiles/microbench/build_variant.sh): same tests, other .so
+        import hip_runtime as hr
+        hr.LIB_PATH = os.environ['ABL_LIB']
 
 
 def pytest_collection_modifyitems(config, items):
