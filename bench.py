@@ -512,6 +512,9 @@ def main():
     ap.add_argument('--profile-steps', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the decode-latency and inference legs (profiling runs)')
+    ap.add_argument('--dcn-offset-std', type=float, default=None,
+                    help='profiling runs only: re-initialise every conv_offset_mask for sampling offsets of this standard '
+                         'deviation in pixels before the warm-up (set_dcn_offset_std); the metric name then says so')
     args = ap.parse_args()
 
     apply_config(args)
@@ -541,6 +544,9 @@ def main():
 
     plugin = build_plugin(device, parallel=world > 1, uda_name=args.uda, backend_name=args.backend)
     batch = synthetic_batch(args.batch, args.size, 42 + rank, device, rotated=UDA_WORKLOADS[args.uda][2])
+
+    if args.dcn_offset_std is not None and args.backend == 'dla34':
+        set_dcn_offset_std(plugin, batch, args.dcn_offset_std)
 
     def barrier():
         if world > 1:
@@ -656,8 +662,10 @@ def main():
         arch = 'DLA-34' if args.backend == 'dla34' else 'ResNet-18'
         line = {
             'metric': 'images/sec CenterNet DLA-34 512x512 UDA step (entropy minimisation)'
-            if args.uda == 'entropy' and args.size == 512 and args.backend == 'dla34'
-            else 'images/sec CenterNet %s %dx%d train step (uda=%s)' % (arch, args.size, args.size, args.uda),
+            if args.uda == 'entropy' and args.size == 512 and args.backend == 'dla34' and args.dcn_offset_std is None
+            else 'images/sec CenterNet %s %dx%d train step (uda=%s%s)'
+                 % (arch, args.size, args.size, args.uda,
+                    '' if args.dcn_offset_std is None else ', DCN offsets re-initialised to sigma = %g px' % args.dcn_offset_std),
             'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32' if hr.get_matrix_mode() == 0 else 'f32 (bf16 x3 split operands)',

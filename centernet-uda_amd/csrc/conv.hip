@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <algorithm>
 #include "igemm.cuh"
 #include "hconv.cuh"
 #include "igemm_host.h"
@@ -633,7 +634,9 @@ ConvPlan make_plan(const ConvGeom& g) {
     q.Z = (int)((q.Nf + q.pix_per_split - 1) / q.pix_per_split);
     q.fwd_bytes = carve_bytes(ig_a_bytes(q.Kpf, q.Mpf), 1) + 256;
     q.dgrad_bytes = carve_bytes(ig_a_bytes(q.Kpd, q.Mpd), 1) + 256;
-    q.wgrad_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) + carve_bytes((size_t)g.Co * g.B, 4) + 256;
+    // (slabs, then the bias row sums per split: [Z][Mpw] -- never less than the [Co][B] scratch of the channel-sum kernels)
+    q.wgrad_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) +
+                    carve_bytes(std::max((size_t)g.Co * g.B, (size_t)q.Z * q.Mpw), 4) + 256;
     return q;
 }
 
@@ -917,7 +920,8 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
     float* slabs = cv.take<float>((size_t)q.Z * q.Mpw * q.Jp);
-    float* bsum = cv.take<float>((size_t)Cout * B);
+    // bias gradient: row sums of grad_y per split from the GEMM's own staging registers, summed with the slabs
+    float* bsl = grad_bias ? cv.take<float>((size_t)q.Z * q.Mpw) : nullptr;
     ConvWParams p{g, x, grad_y};
     {
         ProfScope prof(st);
@@ -930,60 +934,59 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
             const dim3 blk2(2 * IG_THREADS);
             if (q.wbm == 128 && q.wbj == 128 && wave_specialised())
                 CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
+                                   q.Jp, q.Nf, q.pix_per_split, bsl);
             else if (q.wbm == 128 && q.wbj == 128)
                 CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 128, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
+                                   q.Jp, q.Nf, q.pix_per_split, bsl);
             else if (q.wbm == 128 && wave_specialised())
                 CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
+                                   q.Jp, q.Nf, q.pix_per_split, bsl);
             else if (q.wbm == 128)
                 CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 128, 64>), grid, blk, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
+                                   q.Jp, q.Nf, q.pix_per_split, bsl);
             else if (wave_specialised() && q.wbm == 64 && q.wbj == 128)
                 CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
+                                   q.Jp, q.Nf, q.pix_per_split, bsl);
             else if (wave_specialised() && q.wbm == 64)
                 CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
+                                   q.Jp, q.Nf, q.pix_per_split, bsl);
             else if (q.wbm == 64 && q.wbj == 128)
                 CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 64, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
+                                   q.Jp, q.Nf, q.pix_per_split, bsl);
             else if (q.wbm == 64)
                 CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
-                                   q.Nf, q.pix_per_split);
+                                   q.Nf, q.pix_per_split, bsl);
             else
                 CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
+                                   q.Jp, q.Nf, q.pix_per_split, bsl);
         } else if (wave_specialised() && fast && q.wbm == 64) {
             const dim3 blk2(2 * IG_THREADS);
             if (q.wbj == 128)
                 CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWLoader<2>, 64, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
+                                   q.Jp, q.Nf, q.pix_per_split, bsl);
             else
                 CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWLoader<2>, 64, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
+                                   q.Jp, q.Nf, q.pix_per_split, bsl);
         } else if (q.wbm == 64) {
             if (fast && q.wbj == 128)
                 CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWLoader<2>, 64, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
+                                   q.Jp, q.Nf, q.pix_per_split, bsl);
             else if (fast)
                 CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWLoader<2>, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
-                                   q.Nf, q.pix_per_split);
+                                   q.Nf, q.pix_per_split, bsl);
             else
                 CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWLoader<0>, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
-                                   q.Nf, q.pix_per_split);
+                                   q.Nf, q.pix_per_split, bsl);
         } else {
             if (fast)
                 CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWLoader<2>, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
+                                   q.Jp, q.Nf, q.pix_per_split, bsl);
             else
                 CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWLoader<0>, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split);
+                                   q.Jp, q.Nf, q.pix_per_split, bsl);
         }
     }
     if (int rc = check_launch("cnuda_conv2d_backward_weight")) return rc;
-    launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, st);
-    if (grad_bias) launch_channel_sum(grad_y, grad_bias, B, Cout, (long long)g.Ho * g.Wo, st, bsum);
+    launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, st, bsl, grad_bias);
     return check_launch("cnuda_conv2d_backward_weight(reduce)");
 }

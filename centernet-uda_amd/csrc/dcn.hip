@@ -18,6 +18,7 @@
 //
 // Sampling rule (dcn_v2_im2col_cuda.cu:25-54,180): a tap contributes iff
 // -1 < y < H and -1 < x < W; corners outside the plane read as 0.
+#include <algorithm>
 #include "igemm.cuh"
 #include "igemm_host.h"
 
@@ -611,399 +612,6 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcnw_fwd_kernel(DcnFwdParams p,
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-}
-
-// ---------------------------------------------------------------------------
-// backward data path on CHANNEL-QUAD PLANES (round 4): the column gradient never leaves the chip and every gradient
-// of the data path (grad_input, grad_offset, grad_mask) comes out of ONE kernel.
-//
-// What the two earlier forms could not combine: the scatter into grad_input wants every wave to own its channel
-// planes of the LDS window (plain read-add-write, no atomics -- profiles/microbench/lds_atomic_bench.hip: a
-// ds_add_f32 costs 193 cycles per wave instruction on gfx950, a b128 read + write pair 22), while an MFMA tile with
-// pixels on lanes gives every wave ALL channels of ITS pixels.  Here the GEMM is laid out the other way round:
-//   * workgroup = 64 pixels (TR x TC) x one 16-channel group at a time, wave w = channel quad w of the group;
-//   * per (16-pixel column tile, row tile of 3 taps) the wave issues 16 v_mfma_f32_16x16x4_f32 -- rows (tap slot,
-//     channel of the quad), columns pixels, k = the <= 64 output channels -- whose accumulator layout hands lane
-//     (pixel, tap slot) the four channels of its quad: one (pixel, tap) record of dcol, in registers, as the
-//     16-byte quad the window planes are made of;
-//   * gather role: four ds_read_b128 (the corners, [cell][4 channels] planes of the input window) and 16 FMAs into
-//     the four running sums of the (pixel, tap); scatter role: four b128 read-add-write into the wave's own
-//     grad_input planes, lanes that share an anchor cell taking turns through a claim map;
-//   * both windows, the flush of grad_input (one atomic per touched in-image cell and channel) and the staging of
-//     the next group's input window are wave-private: the four waves never synchronise between tile setup and the
-//     final reduction of the running sums.
-// The taps of a row tile are {rt, rt + 3, rt + 6} (one kernel column): lanes of one instruction then differ in pixel
-// column or kernel row, so undeformed samples never share an anchor.  The fourth tap slot is padding (zero rows of
-// the packed weights: 25% of the MFMA work).
-// ---------------------------------------------------------------------------
-template <int TC> struct DqTile {
-    // Window: the tile's rows plus (1 + MARGIN) above and below; RS = TC + 16 columns, tile column x at index x + 8.  The
-    // row stride is a multiple of 16 cells (256 bytes = the bank period of ds_read_b128): the lane groups of a b128 read
-    // mix pixels 0-3 / 12-15 of one tap row with pixels 4-11 of the next, and with a stride of 40 cells (TC + 8) those
-    // two sets fell on the same banks -- every corner read of undeformed samples a 2-way conflict.
-    static constexpr int MARGIN = 2, XPAD = 8;
-    static constexpr int NPX = 64, TR = NPX / TC, NR = TR + 2 + 2 * MARGIN, RS = TC + 2 * XPAD, CELLS = NR * RS;
-    static constexpr int CPR = RS / 4, ITEMS = NR * CPR, NIT = (ITEMS + 63) / 64;   // staging: (row, 4 columns) per lane
-    static constexpr int SHIFT = TC == 32 ? 5 : 4;
-    static constexpr int CLAIM = (CELLS + 16 + 15) / 16 * 16;                       // bytes per wave (+ a spare cell for lanes without a sample)
-    // LDS, in floats: input window | grad_input window | geometry records | grad_output tile | claim maps | stray list
-    static constexpr int WIN = 0, GWIN = 16 * CELLS, GEO = 32 * CELLS, GO = GEO + 9 * NPX * 4, CLM = GO + 64 * NPX;
-    // stray bitmap (one bit per (tap, pixel)) | dump area: lanes without a turn add into cell `lane` (+ 1, + RS, + RS + 1) of it
-    static constexpr int STRAY = CLM + CLAIM, DUMP = STRAY + 20, END = DUMP + (64 + RS + 2) * 4;
-    static_assert(DUMP % 4 == 0, "dump cells are float4");
-    static_assert(4 * 9 * NPX * 4 <= 32 * CELLS, "the running sums of the four waves reuse the windows");
-};
-struct DcnBwdQuadParams {
-    DcnGeom g;
-    const float *in, *w, *off, *mask, *gout;
-    float *gin, *goff, *gmask;
-};
-
-template <int TC>
-__global__ __launch_bounds__(IG_THREADS, 2) void dcnq_kernel(DcnBwdQuadParams p, const float* __restrict__ A, int n_tiles,
-                                                             int tiles_x) {
-    using Q = DqTile<TC>;
-    constexpr int RS = Q::RS, CELLS = Q::CELLS, NPX = Q::NPX;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const DcnGeom& g = p.g;
-    const int W = g.W, H = g.H, HW = g.H * g.W, C = g.C;
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int tile = xcd_remap(blockIdx.x, n_tiles);
-    const int tx = tile % tiles_x; tile /= tiles_x;
-    const int tiles_y = H / Q::TR;
-    const int ty = tile % tiles_y, b = tile / tiles_y;
-    const int y0 = ty * Q::TR, x0 = tx * TC, yw0 = y0 - 1 - Q::MARGIN, xw0 = x0 - Q::XPAD;
-    f32x4* const Wq = reinterpret_cast<f32x4*>(smem + Q::WIN) + wid * CELLS;     // [cell][4 channels] of this wave's quad
-    f32x4* const Gq = reinterpret_cast<f32x4*>(smem + Q::GWIN) + wid * CELLS;
-    f32x4* const Geo = reinterpret_cast<f32x4*>(smem + Q::GEO);                  // [tap][pixel]: window cell (int bits; -1: none), lh, lw, mask
-    float* const Go = smem + Q::GO;                                              // [o / 16][o % 4][pixel][(o / 4) % 4]: a lane's four k-steps are one 16-byte read
-    lds_vu8* const claim = (lds_vu8*)(reinterpret_cast<unsigned char*>(smem + Q::CLM) + wid * Q::CLAIM);   // (LDS pointer type: a volatile generic access is a FLAT instruction)
-    unsigned* const stray_bits = reinterpret_cast<unsigned*>(smem + Q::STRAY);  // [18] words + any-flag
-    f32x4* const Dump = reinterpret_cast<f32x4*>(smem + Q::DUMP) + lane;        // (shared by the waves: its content means nothing)
-    auto pixel = [&](int px) { return (y0 + (px >> Q::SHIFT)) * W + x0 + (px & (TC - 1)); };
-
-    // ---- tile setup (all four waves) ----
-    if (tid < 20) stray_bits[tid] = 0;
-    __syncthreads();
-    for (int e = tid; e < 9 * NPX; e += IG_THREADS) {
-        const int t = e >> 6, px = e & 63, py = y0 + (px >> Q::SHIFT), pxx = x0 + (px & (TC - 1)), pp = py * W + pxx;
-        const float dy = p.off[((size_t)b * 18 + 2 * t) * HW + pp], dx = p.off[((size_t)b * 18 + 2 * t + 1) * HW + pp];
-        const float h = (float)(py - 1 + t / 3) + dy, w = (float)(pxx - 1 + t % 3) + dx;
-        const float hf = floorf(h), wf = floorf(w);
-        const bool valid = h > -1.0f && w > -1.0f && h < (float)H && w < (float)W;
-        const int h0 = valid ? (int)hf : 0, w0 = valid ? (int)wf : 0;
-        const int wr = h0 - yw0, wc = w0 - xw0;
-        const bool inwin = valid && wr >= 0 && wr + 1 <= Q::NR - 1 && wc >= 0 && wc + 1 <= RS - 1;
-        if (valid && !inwin) { atomicOr(stray_bits + (e >> 5), 1u << (e & 31)); stray_bits[18] = 1; }
-        // record: window cell (-1: none), (1 - lh) mask, lh mask, lw -- the four corner weights are two packed products away
-        const float lh = h - hf, mk = p.mask[((size_t)b * 9 + t) * HW + pp];
-        f32x4 rec;
-        rec.x = __int_as_float(inwin ? wr * RS + wc : -1);
-        rec.y = (1.0f - lh) * mk; rec.z = lh * mk; rec.w = w - wf;
-        Geo[e] = rec;
-    }
-    {   // grad_output tile: thread = (pixel, output channels wid, wid + 4, ...), sixteen loads in flight
-        const int px = tid & 63;
-        const float* gp = p.gout + (size_t)b * g.Co * HW + pixel(px);
-        float gv[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) gv[i] = wid + 4 * i < g.Co ? gp[(size_t)(wid + 4 * i) * HW] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int o = wid + 4 * i;
-            Go[(((o >> 4) * 4 + (o & 3)) * NPX + px) * 4 + ((o >> 2) & 3)] = gv[i];
-        }
-    }
-    for (int i = lane; i < CELLS; i += 64) Gq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- the input window of this wave's quad: four planes loaded as rows of float4, stored transposed ----
-    const buf_rsrc rs = ig_make_rsrc(p.in, (unsigned)((size_t)g.B * C * HW * sizeof(float)));
-    const buf_rsrc ra = ig_make_rsrc(A, (unsigned)((size_t)12 * C * 64 * sizeof(float)));
-    f32x4 hreg[Q::NIT][4];
-    unsigned st_voff[Q::NIT];
-    int st_cell[Q::NIT];
-#pragma unroll
-    for (int i = 0; i < Q::NIT; ++i) {
-        const int it = lane + 64 * i;
-        const int row = it / Q::CPR, q4 = it - row * Q::CPR;
-        const int iy = yw0 + row, ix = xw0 + 4 * q4;
-        st_cell[i] = it < Q::ITEMS ? row * RS + 4 * q4 : -1;
-        const bool ok = (it < Q::ITEMS) & (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W);
-        st_voff[i] = ok ? (unsigned)(((b * C + 4 * wid) * HW + iy * W + ix) * (int)sizeof(float)) : IG_BUF_OOB;
-    }
-    auto win_load = [&](int grp) {
-#pragma unroll
-        for (int i = 0; i < Q::NIT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hreg[i][r] = ig_buf_load4(rs, st_voff[i], (unsigned)((grp * 16 + r) * HW) * (unsigned)sizeof(float));
-    };
-    auto win_store = [&]() {
-#pragma unroll
-        for (int i = 0; i < Q::NIT; ++i)
-            if (st_cell[i] >= 0) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) Wq[st_cell[i] + k] = f32x4{hreg[i][0][k], hreg[i][1][k], hreg[i][2][k], hreg[i][3][k]};
-            }
-    };
-    win_load(0);
-    win_store();
-    __syncthreads();
-
-    // ---- channel groups ----
-    // Software pipeline over the items (column tile ct, row tile rt) of a group and across groups.  A step holds item
-    // n's gather / scatter roles (VALU + LDS: six dependent LDS round trips) and the 16-link MFMA chain of item
-    // n + 1, interleaved BY HAND -- a link leaves the issue port free for about seven other instructions -- and
-    // pinned with scheduling barriers (left alone the compiler issues the chain first and the round trips after
-    // it).  The A fragments of item n + 2 replace those of n + 1 a quarter at a time as the chain releases them;
-    // likewise the B fragments when the column tile changes.
-    // (Measured and dropped, round 4: the record and the claim / corner reads of the next item issued a step ahead
-    // -- +6%; two items per step through the corner phases in lockstep, halving the round trips per item -- +29%,
-    // with spills: the step is bound by what the LDS pipe moves, not by the length of the dependent chain.)
-    const int pxl = lane & 15, slot = lane >> 4;
-    float u[4][3][4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) u[ct][rt][k] = 0.0f;
-    const int G = C >> 4;
-    float af[16], bf[16];
-    f32x4 acc[2];
-    auto load_a4 = [&](int grp_, int rt, int s4) {                     // k-steps 4 s4 .. 4 s4 + 3 (past the last group: zeros)
-        const unsigned abase = (unsigned)((((grp_ * 4 + wid) * 3 + rt) * 16) * 64) * (unsigned)sizeof(float);
-        const f32x4 v = ig_buf_load4(ra, (unsigned)lane * 16u, abase + (unsigned)(s4 * 256 * 4));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) af[4 * s4 + k] = v[k];
-    };
-    auto load_b4 = [&](int ct, int s4) {
-        int pbase = (slot * NPX + ct * 16 + pxl) * 4;
-        asm volatile("" : "+v"(pbase));                                // (the tile does not change with the group: keep the reads here)
-        const f32x4 v = *reinterpret_cast<const f32x4*>(Go + s4 * (16 * NPX) + pbase);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) bf[4 * s4 + k] = v[k];
-    };
-#define CNUDA_SB() __builtin_amdgcn_sched_barrier(0)
-    {
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { load_a4(0, 0, s4); load_b4(0, s4); }
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 16; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], c, 0, 0, 0);
-        acc[0] = c;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) load_a4(0, 1, s4);
-    }
-    for (int grp = 0; grp < G; ++grp) {
-        const bool more = grp + 1 < G;
-#pragma unroll
-        for (int n = 0; n < 12; ++n) {
-            const int ct = n / 3, rt = n % 3, cur = n & 1;
-            const int n2 = (n + 2) % 12;
-            const int grp2 = grp + (n + 2 >= 12 ? 1 : 0);
-            const bool new_b = n2 % 3 == 0;                            // item n + 2 starts a column tile: its B fragments follow the chain too
-            f32x4 cn = {0.f, 0.f, 0.f, 0.f};                           // item n + 1
-#define CNUDA_MM(S) cn = __builtin_amdgcn_mfma_f32_16x16x4f32(af[S], bf[S], cn, 0, 0, 0)
-#define CNUDA_REFILL(Q4) do { load_a4(grp2, n2 % 3, Q4); if (new_b) load_b4(n2 / 3, Q4); } while (0)
-            // --- links 0-3 | the (pixel, tap) record
-            int gi = (slot < 3 ? rt + 3 * slot : rt) * NPX + ct * 16 + pxl;
-            asm volatile("" : "+v"(gi));
-            const f32x4 rec = Geo[gi];
-            CNUDA_SB(); CNUDA_MM(0); CNUDA_SB(); CNUDA_MM(1); CNUDA_SB(); CNUDA_MM(2); CNUDA_SB(); CNUDA_MM(3); CNUDA_SB();
-            CNUDA_REFILL(0);
-            // --- links 4-7 | claim on the anchor cell, corners of the input window
-            const int addr = __float_as_int(rec.x);
-            const bool live = slot < 3 && addr >= 0;
-            const int a = live ? addr : 0;
-            const int ca = live ? addr : CELLS;                        // (dead lanes: one spare byte behind the map)
-            claim[ca] = (unsigned char)lane;
-            const unsigned char holder = claim[ca];                    // same wave: LDS executes in order
-            const f32x4 v00 = Wq[a], v01 = Wq[a + 1], v10 = Wq[a + RS], v11 = Wq[a + RS + 1];
-            f32x4 d;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) d[k] = live ? acc[cur][k] : 0.0f;
-            const float hw = 1.0f - rec.w;
-            const float k00 = rec.y * hw, k01 = rec.y * rec.w, k10 = rec.z * hw, k11 = rec.z * rec.w;
-            CNUDA_SB(); CNUDA_MM(4); CNUDA_SB(); CNUDA_MM(5); CNUDA_SB(); CNUDA_MM(6); CNUDA_SB(); CNUDA_MM(7); CNUDA_SB();
-            CNUDA_REFILL(1);
-            // --- links 8-15 | the four running sums (gather role) between the four corner read-add-writes (scatter role:
-            // neighbouring lanes' footprints overlap, so a corner is one wave-wide read and one wave-wide write, and
-            // LDS executes them in order).  Lanes without a turn -- padding slot, no sample, anchor claimed by another
-            // lane -- add into the dump area, whose content means nothing: no branch in the step.
-            const bool won = live & (holder == (unsigned char)lane);
-            f32x4* const q = won ? Gq + a : Dump;
-            asm volatile("" ::: "memory");
-            f32x4 c0 = q[0];
-            u[ct][rt][0] = fmaf(d[3], v00[3], fmaf(d[2], v00[2], fmaf(d[1], v00[1], fmaf(d[0], v00[0], u[ct][rt][0]))));
-            CNUDA_SB(); CNUDA_MM(8); CNUDA_SB();
-            u[ct][rt][1] = fmaf(d[3], v01[3], fmaf(d[2], v01[2], fmaf(d[1], v01[1], fmaf(d[0], v01[0], u[ct][rt][1]))));
-            CNUDA_SB(); CNUDA_MM(9); CNUDA_SB();
-            c0 = __builtin_elementwise_fma(f32x4{k00, k00, k00, k00}, d, c0);
-            q[0] = c0;
-            asm volatile("" ::: "memory");
-            f32x4 c1 = q[1];
-            u[ct][rt][2] = fmaf(d[3], v10[3], fmaf(d[2], v10[2], fmaf(d[1], v10[1], fmaf(d[0], v10[0], u[ct][rt][2]))));
-            CNUDA_SB(); CNUDA_MM(10); CNUDA_SB();
-            u[ct][rt][3] = fmaf(d[3], v11[3], fmaf(d[2], v11[2], fmaf(d[1], v11[1], fmaf(d[0], v11[0], u[ct][rt][3]))));
-            // (the sums are only read at the end of the tile: without an anchor the compiler sinks the FMA chains below the
-            // loop and keeps every corner it read alive -- in scratch -- until then)
-            asm volatile("" : "+v"(u[ct][rt][0]), "+v"(u[ct][rt][1]), "+v"(u[ct][rt][2]), "+v"(u[ct][rt][3]));
-            CNUDA_SB(); CNUDA_MM(11); CNUDA_SB();
-            CNUDA_REFILL(2);
-            c1 = __builtin_elementwise_fma(f32x4{k01, k01, k01, k01}, d, c1);
-            q[1] = c1;
-            asm volatile("" ::: "memory");
-            f32x4 c2 = q[RS];
-            CNUDA_SB(); CNUDA_MM(12); CNUDA_SB(); CNUDA_MM(13); CNUDA_SB();
-            c2 = __builtin_elementwise_fma(f32x4{k10, k10, k10, k10}, d, c2);
-            q[RS] = c2;
-            asm volatile("" ::: "memory");
-            f32x4 c3 = q[RS + 1];
-            CNUDA_SB(); CNUDA_MM(14); CNUDA_SB(); CNUDA_MM(15); CNUDA_SB();
-            CNUDA_REFILL(3);
-            c3 = __builtin_elementwise_fma(f32x4{k11, k11, k11, k11}, d, c3);
-            q[RS + 1] = c3;
-            asm volatile("" ::: "memory");
-            acc[cur ^ 1] = cn;
-#undef CNUDA_MM
-#undef CNUDA_REFILL
-            bool pending = live && !won;
-            if (__any(pending)) {                                      // lanes that share an anchor cell take turns; leftovers: global atomics
-#pragma unroll 1
-                for (int round = 0; round < 2 && __any(pending); ++round) {
-                    bool w2 = false;
-                    if (pending) {
-                        claim[a] = (unsigned char)lane;
-                        w2 = claim[a] == (unsigned char)lane;
-                    }
-                    asm volatile("" ::: "memory");
-                    f32x4* const q2 = w2 ? Gq + a : Dump;
-                    f32x4 e0 = q2[0];
-                    e0 = __builtin_elementwise_fma(f32x4{k00, k00, k00, k00}, d, e0);
-                    q2[0] = e0;
-                    asm volatile("" ::: "memory");
-                    f32x4 e1 = q2[1];
-                    e1 = __builtin_elementwise_fma(f32x4{k01, k01, k01, k01}, d, e1);
-                    q2[1] = e1;
-                    asm volatile("" ::: "memory");
-                    f32x4 e2 = q2[RS];
-                    e2 = __builtin_elementwise_fma(f32x4{k10, k10, k10, k10}, d, e2);
-                    q2[RS] = e2;
-                    asm volatile("" ::: "memory");
-                    f32x4 e3 = q2[RS + 1];
-                    e3 = __builtin_elementwise_fma(f32x4{k11, k11, k11, k11}, d, e3);
-                    q2[RS + 1] = e3;
-                    asm volatile("" ::: "memory");
-                    pending = pending && !w2;
-                }
-                if (pending) {
-                    const int wr = a / RS, wc = a - wr * RS, iy = yw0 + wr, ix = xw0 + wc;
-                    const bool top = iy >= 0, bot = iy + 1 <= H - 1, lef = ix >= 0, rig = ix + 1 <= W - 1;
-                    float* gp = p.gin + ((size_t)b * C + grp * 16 + 4 * wid) * HW + iy * W + ix;
-#pragma unroll 1
-                    for (int k = 0; k < 4; ++k) {
-                        const float dk = k == 0 ? d[0] : (k == 1 ? d[1] : (k == 2 ? d[2] : d[3]));
-                        if (top && lef) atomicAdd(gp + (size_t)k * HW, k00 * dk);
-                        if (top && rig) atomicAdd(gp + (size_t)k * HW + 1, k01 * dk);
-                        if (bot && lef) atomicAdd(gp + (size_t)k * HW + W, k10 * dk);
-                        if (bot && rig) atomicAdd(gp + (size_t)k * HW + W + 1, k11 * dk);
-                    }
-                }
-            }
-        }
-        if (more) win_load(grp + 1);                                   // (in flight under the flush; between steps the registers are free)
-        // --- flush this group's grad_input planes (touched in-image cells: one atomic per cell and channel), next window
-        asm volatile("" ::: "memory");
-        for (int i = lane; i < CELLS; i += 64) {
-            const f32x4 v = Gq[i];
-            if (v[0] != 0.0f || v[1] != 0.0f || v[2] != 0.0f || v[3] != 0.0f) {
-                Gq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const int row = i / RS, col = i - row * RS, iy = yw0 + row, ix = xw0 + col;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                    float* gp = p.gin + ((size_t)b * C + grp * 16 + 4 * wid) * HW + iy * W + ix;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (v[k] != 0.0f) atomicAdd(gp + (size_t)k * HW, v[k]);
-                }
-            }
-        }
-        if (more) win_store();
-    }
-
-    // ---- the running sums: per wave into LDS (the windows are done), strays, then one sum over the waves per (pixel, tap) ----
-    __syncthreads();
-    f32x4* const U = reinterpret_cast<f32x4*>(smem) + wid * (9 * NPX);
-    if (slot < 3) {
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int rt = 0; rt < 3; ++rt)
-                U[(rt + 3 * slot) * NPX + ct * 16 + pxl] = f32x4{u[ct][rt][0], u[ct][rt][1], u[ct][rt][2], u[ct][rt][3]};
-    }
-    // strays (rare): a (pixel, tap) whose corners left the window.  Every wave redoes the tap for ITS channels of all
-    // groups, a channel per lane: dcol as a dot product over the output channels, corners from global memory
-    // (clamped, zero weight outside the image), grad_input through global atomics.
-    if (stray_bits[18]) {
-      for (int wi = 0; wi < 18; ++wi) {
-        unsigned bits = stray_bits[wi];
-        while (bits) {
-            const int e = wi * 32 + __builtin_ctz(bits);
-            bits &= bits - 1;
-            const int t = e >> 6, px = e & 63;
-            const int py = y0 + (px >> Q::SHIFT), pxx = x0 + (px & (TC - 1)), pp = py * W + pxx;
-            const float h = (float)(py - 1 + t / 3) + p.off[((size_t)b * 18 + 2 * t) * HW + pp];
-            const float w = (float)(pxx - 1 + t % 3) + p.off[((size_t)b * 18 + 2 * t + 1) * HW + pp];
-            const float hf = floorf(h), wf = floorf(w);
-            const int h0 = (int)hf, w0 = (int)wf;
-            const bool top = h0 >= 0, bot = h0 + 1 <= H - 1, lef = w0 >= 0, rig = w0 + 1 <= W - 1;
-            const float f00 = (top && lef) ? 1.f : 0.f, f01 = (top && rig) ? 1.f : 0.f, f10 = (bot && lef) ? 1.f : 0.f,
-                        f11 = (bot && rig) ? 1.f : 0.f;
-            const int cy0 = top ? h0 : 0, cy1 = bot ? h0 + 1 : H - 1, cx0 = lef ? w0 : 0, cx1 = rig ? w0 + 1 : W - 1;
-            const int o00 = cy0 * W + cx0, o01 = cy0 * W + cx1, o10 = cy1 * W + cx0, o11 = cy1 * W + cx1;
-            const float lh = h - hf, lw = w - wf, hh = 1.0f - lh, hw = 1.0f - lw, mk = p.mask[((size_t)b * 9 + t) * HW + pp];
-            float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
-            for (int cb = 0; cb < 4 * G; cb += 64) {
-                const int ci = cb + lane;                              // (group, channel of the quad)
-                if (ci < 4 * G) {
-                    const int c = (ci >> 2) * 16 + 4 * wid + (ci & 3);
-                    float d = 0.0f;
-                    for (int o = 0; o < g.Co; ++o)
-                        d = fmaf(p.w[((size_t)o * C + c) * 9 + t], Go[(((o >> 4) * 4 + (o & 3)) * NPX + px) * 4 + ((o >> 2) & 3)], d);
-                    const float* pl = p.in + ((size_t)b * C + c) * HW;
-                    s00 = fmaf(d, pl[o00] * f00, s00);
-                    s01 = fmaf(d, pl[o01] * f01, s01);
-                    s10 = fmaf(d, pl[o10] * f10, s10);
-                    s11 = fmaf(d, pl[o11] * f11, s11);
-                    float* gp = p.gin + ((size_t)b * C + c) * HW;
-                    const float dm = d * mk;
-                    if (f00 != 0.0f) atomicAdd(gp + o00, hh * hw * dm);
-                    if (f01 != 0.0f) atomicAdd(gp + o01, hh * lw * dm);
-                    if (f10 != 0.0f) atomicAdd(gp + o10, lh * hw * dm);
-                    if (f11 != 0.0f) atomicAdd(gp + o11, lh * lw * dm);
-                }
-            }
-#pragma unroll
-            for (int sft = 32; sft >= 1; sft >>= 1) {
-                s00 += __shfl_xor(s00, sft, 64); s01 += __shfl_xor(s01, sft, 64);
-                s10 += __shfl_xor(s10, sft, 64); s11 += __shfl_xor(s11, sft, 64);
-            }
-            if (lane == 0) U[e] = f32x4{s00, s01, s10, s11};           // (the window part of a stray is zero)
-        }
-      }
-    }
-    __syncthreads();
-    const f32x4* const U0 = reinterpret_cast<const f32x4*>(smem);
-    for (int e = tid; e < 9 * NPX; e += IG_THREADS) {
-        const int t = e >> 6, px = e & 63, pp = pixel(px);
-        const f32x4 a = ((U0[e] + U0[9 * NPX + e]) + U0[2 * 9 * NPX + e]) + U0[3 * 9 * NPX + e];
-        const int py = y0 + (px >> Q::SHIFT), pxx = x0 + (px & (TC - 1));
-        const float h = (float)(py - 1 + t / 3) + p.off[((size_t)b * 18 + 2 * t) * HW + pp];
-        const float w = (float)(pxx - 1 + t % 3) + p.off[((size_t)b * 18 + 2 * t + 1) * HW + pp];
-        const float lh = h - floorf(h), lw = w - floorf(w), hh = 1.0f - lh, hw = 1.0f - lw, mk = p.mask[((size_t)b * 9 + t) * HW + pp];
-        p.gmask[((size_t)b * 9 + t) * HW + pp] = hh * hw * a[0] + hh * lw * a[1] + lh * hw * a[2] + lh * lw * a[3];
-        p.goff[((size_t)b * 18 + 2 * t) * HW + pp] = (-hw * a[0] - lw * a[1] + hw * a[2] + lw * a[3]) * mk;
-        p.goff[((size_t)b * 18 + 2 * t + 1) * HW + pp] = (-hh * a[0] + hh * a[1] - lh * a[2] + lh * a[3]) * mk;
     }
 }
 
@@ -1864,13 +1472,7 @@ int pick_bm(int M, long long N) {
 
 constexpr int kFusedMinTilesDefault = 512;
 int g_fused_min_tiles = kFusedMinTilesDefault;      // cnuda_dcn_set_fused_min_tiles (tests)
-inline int kQuadBackwardDefault() { const char* e = getenv("CNUDA_DCNQ"); return e && e[0] == '1'; }
-int g_quad_backward = kQuadBackwardDefault();       // cnuda_dcn_set_quad_backward (tests, A/B)
-// ... and only calls with at least this many 64-pixel tiles: a tile is one workgroup that walks ALL channel groups (49 us
-// for four of them), so the 32 x 32 / 16 x 16 maps -- few tiles, 8-16 groups -- took 1.4 ms where the two-kernel walk takes
-// 0.3 (in-step trace, round 4).  cnuda_dcn_set_quad_backward(2) drops the rule (tests run small geometries)
-constexpr long long kQuadMinTilesDefault = 2048;
-long long g_quad_min_tiles = kQuadMinTilesDefault;
+
 
 struct DcnPlan {
     int T, K, Kp, bm, Mp;           // forward pack [Kp][Mp]
@@ -1911,7 +1513,8 @@ DcnPlan make_plan(const DcnGeom& g) {
     }
     q.gemm_bytes = cnuda_conv2d_workspace_bytes(g.B, g.Co, g.Ho, g.Wo, q.T * g.C, 1, 1, 1, 1, 0, 0);
     q.bwd_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) +
-                  carve_bytes((size_t)g.Co * g.B, 4) + carve_bytes((size_t)12 * g.C * (g.Co < 64 ? 64 : g.Co), 4) +
+                  carve_bytes(std::max((size_t)g.Co * g.B, (size_t)q.Z * q.Mpw), 4) +
+                  carve_bytes((size_t)12 * g.C * (g.Co < 64 ? 64 : g.Co), 4) +
                   carve_bytes((size_t)g.B * q.T * g.C * g.Ho * g.Wo, 4) +
                   carve_bytes((size_t)g.B * q.T * g.Ho * g.Wo, sizeof(DcnGeo)) + carve_bytes(q.gemm_bytes, 1) + 256;
     // col2im tile: 256 output pixels, lanes along x
@@ -1941,12 +1544,6 @@ DcnPlan make_plan(const DcnGeom& g) {
 
 using namespace cnuda;
 
-extern "C" int cnuda_dcn_set_quad_backward(int on) {
-    const int prev = g_quad_backward;
-    g_quad_backward = on < 0 ? kQuadBackwardDefault() : (on != 0);
-    g_quad_min_tiles = on == 2 ? 1 : kQuadMinTilesDefault;
-    return prev;
-}
 extern "C" int cnuda_dcn_set_fused_min_tiles(int min_tiles) {
     const int prev = g_fused_min_tiles;
     g_fused_min_tiles = min_tiles < 1 ? kFusedMinTilesDefault : min_tiles;
@@ -2151,7 +1748,7 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.bwd_bytes, "cnuda_dcn_v2_backward: workspace too small");
     Carver cv(workspace, workspace_bytes);
     float* slabs = cv.take<float>((size_t)q.Z * q.Mpw * q.Jp);
-    float* bsum = cv.take<float>((size_t)Cout * B);
+    float* bsl = cv.take<float>(std::max((size_t)Cout * B, (size_t)q.Z * q.Mpw));    // bias row sums per split: [Z][Mpw]
     float* wt = cv.take<float>((size_t)12 * C * (Cout < 64 ? 64 : Cout));   // (or the window kernels' packs: [64][10 C], [12 C][64])
     float* dcol = cv.take<float>((size_t)B * q.T * C * HoWo);
     DcnGeo* geo = cv.take<DcnGeo>((size_t)B * q.T * HoWo);
@@ -2162,8 +1759,7 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
     // every timed scope below is recorded under the call's tag; sub 0: the column-gradient 1x1 GEMM (its own scope
     // inside cnuda_conv2d_forward), 1: coord_grad, 2: col2im, 3: both as one launch, 4: the weight-gradient GEMM
     ProfGroup prof;
-    launch_channel_sum(grad_output, grad_bias, B, Cout, HoWo, wst, bsum);
-    // (2) weight gradient
+    // (2) weight gradient (and, from the same staging registers, the bias gradient: bsl -> slab reduce)
     {
       {
         ProfScope wscope(st, 4);
@@ -2175,53 +1771,25 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
             wscope.name("igemm_wgrad_kernel<%s, 64, %d>", buf ? "DcnColWBufLoader" : "DcnColWLoader", q.Jp % 128 == 0 ? 128 : 64);
             if (buf && q.Jp % 128 == 0)
                 CNUDA_LAUNCH((igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
-                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split, bsl);
             else if (buf)
                 CNUDA_LAUNCH((igemm_wgrad_kernel<DcnColWBufLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
-                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split, bsl);
             else if (q.Jp % 128 == 0)
                 CNUDA_LAUNCH((igemm_wgrad_kernel<DcnColWLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
-                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split, bsl);
             else
                 CNUDA_LAUNCH((igemm_wgrad_kernel<DcnColWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
-                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split, bsl);
         } else {
             DcnWParams p{g, input, offset, mask, grad_output};
             wscope.name("igemm_wgrad_kernel<DcnWLoader, 64, 64>");
             CNUDA_LAUNCH((igemm_wgrad_kernel<DcnWLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
-                               dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split);
+                               dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split, bsl);
         }
       }
         if (int rc = check_launch("cnuda_dcn_v2_backward(weight)")) return rc;
-        launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, wst);
-    }
-    // the one-kernel form on channel-quad planes (dcnq_kernel; the layers dcnw_fwd_kernel takes).  OFF by default: per layer
-    // it beats the three kernels below when neighbouring pixels sample neighbouring cells (1058 vs 1298 us at 64 -> 64,
-    // 128 x 128, B = 32) and loses when offsets are independent noise (1840 vs 1573 us); inside the benched step it
-    // measured 82.7 / 83.2 vs 82.2 / 82.7 ms.  CNUDA_DCNQ=1 or cnuda_dcn_set_quad_backward(1).
-    if (g_quad_backward && matrix_mode() == 0 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 &&
-        dw == 1 && C % 16 == 0 && Cout <= 64 && (W == 16 || W == 32 || W == 64 || W == 128) &&
-        H % (64 / (W >= 32 ? 32 : 16)) == 0 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB &&
-        q.N / 64 >= g_quad_min_tiles) {
-        const int tc = W >= 32 ? 32 : 16, tiles_x = W / tc, n_tiles = (int)(q.N / 64);
-        const float* Aq = launch_pack(weight, wt, (size_t)12 * C * 64 * sizeof(float), Cout, C, q.T, PACK_DCN_QUAD, 12 * C, 64, 0, st);
-        DcnBwdQuadParams pq{g, input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask};
-        ProfScope scope(st, 3);
-        scope.name("dcnq_kernel<%d>", tc);
-#define CNUDA_DCNQ_LAUNCH(TCV)                                                                                         \
-    do {                                                                                                               \
-        const size_t lds = (size_t)DqTile<TCV>::END * sizeof(float);                                                   \
-        static bool raised = false;                                                                                    \
-        if (lds > 64 * 1024 && !raised) {                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnq_kernel<TCV>),                                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
-            raised = true;                                                                                             \
-        }                                                                                                              \
-        CNUDA_LAUNCH((dcnq_kernel<TCV>), dim3(n_tiles), dim3(IG_THREADS), lds, st, pq, Aq, n_tiles, tiles_x);          \
-    } while (0)
-        if (tc == 32) CNUDA_DCNQ_LAUNCH(32); else CNUDA_DCNQ_LAUNCH(16);
-#undef CNUDA_DCNQ_LAUNCH
-        return check_launch("cnuda_dcn_v2_backward(quad planes)");
+        launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, wst, bsl, grad_bias);
     }
     {
         // (1) dcol = W^T x grad_output as a 1x1 implicit GEMM, then the two streaming consumers

@@ -749,12 +749,27 @@ __device__ __forceinline__ void ig_buf_rows(buf_rsrc rs, const IgPixelCursor& c,
     for (int i = 0; i < NV; ++i) v[i] = ig_buf_load(rs, voff, (unsigned)((row0 + STEP * i) * HoWo) * (unsigned)sizeof(float));
 }
 
+// bias row sums of a weight-gradient workgroup: thread (pl, sub) holds the sums of rows sub + STEP * i over its pixel
+// lane's chunks; the 32 pixel lanes of a row group are one half of a wave -> xor butterfly 16..1, lane pl == 0 stores
+template <int NG, int STEP>
+__device__ __forceinline__ void ig_wgrad_store_bias(float (&bs)[NG], float* __restrict__ dst, int pl, int sub) {
+    static_assert(WG_BP == 32, "a row group's pixel lanes are one half of a wave");
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        float v = bs[i];
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (pl == 0) dst[sub + STEP * i] = v;
+    }
+}
+
 // BM x BJ = 64 x 128 (waves 2 x 2, two accumulator tiles each: when the column count is a multiple of 128),
 // 64 x 64 (waves 2 x 2) or 32 x 128 (waves 1 x 4, for layers with <= 32 output channels:
 // the 16-channel stem / level-0 convs and the 27-channel DCN offset convs would waste 2-4x on a 64-row tile)
 template <class WLoader, int BM, int BJ>
 __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
-    typename WLoader::Params p, float* __restrict__ slabs, int Mp, int Jp, long long N, long long pix_per_split) {
+    typename WLoader::Params p, float* __restrict__ slabs, int Mp, int Jp, long long N, long long pix_per_split,
+    float* __restrict__ bslab) {
     constexpr int GLD = BM + 1, BLD = BJ + 1;          // odd row strides: conflict-free pixel-major stores
     constexpr int STEP = IG_THREADS / WG_BP;            // rows (channels / columns) covered per pass
     // 32x32 accumulator tiles per wave: TM x TJ (2 x 2 for the 128 x 128 tile: 4 fragment dwords per 4 MFMAs; else one
@@ -781,11 +796,23 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.0f;
     float rg[NG], rb[NB];
+    // bias gradient (bslab != nullptr): the row sums of G over this split's pixels, taken by the workgroups of the first
+    // column tile from the values they stage anyway -- the G tile passes through these registers once per chunk, so the
+    // separate pass over grad_y (channel_sum_*: 38 launch pairs and 0.7 ms per benched step) is not needed.  Fixed order:
+    // a thread's chunks in sequence, then a butterfly over its 32 pixel lanes; the splits are summed by slab_reduce_*.
+    const bool do_bias = bslab != nullptr && blockIdx.x == 0;
+    float bs[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) bs[i] = 0.0f;
     auto stage_store = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NG; ++i) Gs[buf][pl * GLD + sub + STEP * i] = rg[i];
 #pragma unroll
         for (int i = 0; i < NB; ++i) Bs[buf][pl * BLD + sub + STEP * i] = rb[i];
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < NG; ++i) bs[i] += rg[i];
+        }
     };
     auto stage_load = [&]() {
         ld.template load_g<NG, STEP>(m0, sub, rg);
@@ -848,6 +875,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
                 const int j = j0 + wj_off + t * 32 + (lane & 31);
                 slab[(size_t)m * Jp + j] = acc[i][t][r];
             }
+    if (do_bias) ig_wgrad_store_bias<NG, STEP>(bs, bslab + (size_t)blockIdx.z * Mp + m0, pl, sub);
 }
 
 // Wave-specialised weight-gradient kernel (see igemm_fwd_ws_kernel): threads 256..511 run the two loaders and the
@@ -855,7 +883,8 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_wgrad_kernel(
 // igemm_wgrad_kernel.
 template <class WLoader, int BM, int BJ>
 __global__ __launch_bounds__(2 * IG_THREADS) void igemm_wgrad_ws_kernel(
-    typename WLoader::Params p, float* __restrict__ slabs, int Mp, int Jp, long long N, long long pix_per_split) {
+    typename WLoader::Params p, float* __restrict__ slabs, int Mp, int Jp, long long N, long long pix_per_split,
+    float* __restrict__ bslab) {
     constexpr int GLD = BM + 1, BLD = BJ + 1;
     constexpr int STEP = IG_THREADS / WG_BP;
     constexpr int TM = (BM == 128 && BJ == 128) ? 2 : 1, TJ = (BM / 32) * (BJ / 32) / 4 / TM;     // see igemm_wgrad_kernel
@@ -873,11 +902,19 @@ __global__ __launch_bounds__(2 * IG_THREADS) void igemm_wgrad_ws_kernel(
         const int pl = tid % WG_BP, sub = tid / WG_BP;
         WLoader ld(p, n_begin + pl, n_end);
         struct Regs { float rg[NG], rb[NB]; };
+        const bool do_bias = bslab != nullptr && blockIdx.x == 0;       // (see igemm_wgrad_kernel: bias row sums)
+        float bs[NG];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) bs[i] = 0.0f;
         auto stage_store = [&](int buf, const Regs& r) {
 #pragma unroll
             for (int i = 0; i < NG; ++i) Gs[buf][pl * GLD + sub + STEP * i] = r.rg[i];
 #pragma unroll
             for (int i = 0; i < NB; ++i) Bs[buf][pl * BLD + sub + STEP * i] = r.rb[i];
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < NG; ++i) bs[i] += r.rg[i];
+            }
         };
         auto stage_load = [&](Regs& r) {
             ld.template load_g<NG, STEP>(m0, sub, r.rg);
@@ -898,6 +935,7 @@ __global__ __launch_bounds__(2 * IG_THREADS) void igemm_wgrad_ws_kernel(
             __syncthreads();
             cur ^= 1;
         }
+        if (do_bias) ig_wgrad_store_bias<NG, STEP>(bs, bslab + (size_t)blockIdx.z * Mp + m0, pl, sub);
         return;
     }
     const int wm_off = (wid / WJ) * 32 * TM, wj_off = (wid % WJ) * 32 * TJ;

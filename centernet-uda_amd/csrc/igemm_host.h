@@ -16,11 +16,6 @@ enum PackMode {
     PACK_HALO_FWD = 3,    // dst[k = (g*9 + tap)*16 + ci][m = o] = W[o][16g + ci][tap]                     (C % 16 == 0)
     PACK_HALO_DGRAD = 4,  // dst[k = (g*9 + tap)*16 + oi][m = c] = W[16g + oi][c][8 - tap]: the input gradient of a
                           // 3x3 / stride 1 / padding 1 convolution is that convolution over grad_y with flipped taps (Co % 16 == 0)
-    // DCN backward on channel-quad planes (dcn.hip dcnq_kernel): A fragments of v_mfma_f32_16x16x4_f32 in issue order.  Block
-    // ((g*4 + quad)*3 + rt) holds 1024 floats, index s4*256 + lane*4 + (s & 3) (a lane's four k-steps 4 s4 .. 4 s4 + 3 are one
-    // 16-byte load) = W[o = 4s + (lane >> 4)][c = 16g + 4 quad + (lane & 3)][tap = rt + 3*((lane & 15) >> 2)]; the fourth tap slot
-    // of a row tile and o >= Co are zero.  As a [Kp][Mp] image: Kp = 12 C rows of Mp = 64
-    PACK_DCN_QUAD = 5,
 };
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
@@ -48,14 +43,13 @@ const float* launch_pack(const float* W, float* dst, size_t room, int Co, int C,
 const float* launch_pack_taps(const float* W, float* dst, size_t room, int Co, int C, int T, const int* taps, int ntaps,
                               int Kp, int Mp, hipStream_t st);
 
-// gw[o][c][tap] = sum_z slabs[z][o][tap*C + c]
+// gw[o][c][tap] = sum_z slabs[z][o][tap*C + c]; with bslab ([Z][Mp]: the GEMM's per-split row sums of grad_y, written by
+// igemm_wgrad_*_kernel when it is given the pointer) also gb[o] = sum_z bslab[z][o] -- the bias gradient, same launch
 void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp,
-                        int Co, int C, int T, hipStream_t st);
+                        int Co, int C, int T, hipStream_t st, const float* bslab = nullptr, float* gb = nullptr);
 
-// out[c] = sum over (b, hw) of x[b][c][hw]   (bias gradients)
-// scratch: >= C*B floats of workspace (nullptr -> single-stage kernel)
-void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st,
-                        float* scratch = nullptr);
+// out[c] = sum over (b, hw) of x[b][c][hw]   (bias gradients of the paths without a weight-gradient GEMM)
+void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st);
 
 // small-channel, full-resolution convolutions with LDS halo tiles (smallc.hip)
 bool smallc_supported(int C, int Co, int kh, int kw, int sh, int sw);

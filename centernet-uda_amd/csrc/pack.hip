@@ -25,14 +25,6 @@ __global__ void pack_kernel(const float* __restrict__ W, float* __restrict__ dst
             if (k < T * C && m < Co) { const int g = k / (16 * T), r = k - g * 16 * T; tap = r >> 4; c = 16 * g + (r & 15); o = m; }
         } else if (mode == PACK_HALO_DGRAD) {
             if (k < T * Co && m < C) { const int g = k / (16 * T), r = k - g * 16 * T; tap = T - 1 - (r >> 4); o = 16 * g + (r & 15); c = m; }
-        } else if (mode == PACK_DCN_QUAD) {
-            // k = ((g*4 + quad)*3 + rt)*16 + s, m = lane: row i = lane & 15 = (tap slot, channel of the quad), k-step column lane >> 4
-            // (a lane's four k-steps 4 s4 .. 4 s4 + 3 are one 16-byte load: flat index in the block = s4*256 + lane*4 + (s & 3))
-            const int f = (k & 15) * 64 + m, ln = (f >> 2) & 63, s_ = 4 * (f >> 8) + (f & 3);
-            const int rt = (k >> 4) % 3, gq = (k >> 4) / 3, slot = (ln & 15) >> 2;
-            tap = rt + 3 * slot; c = 4 * gq + (ln & 3);
-            o = (slot < 3 && 4 * s_ + (ln >> 4) < Co && c < C) ? 4 * s_ + (ln >> 4) : -1;
-            if (o < 0) { tap = 0; c = 0; }
         } else {   // PACK_DGRAD: Cpad = Co rounded up to the K chunk, rows o >= Co stay zero
             if (k < T * Cpad && m < C) { tap = k / Cpad; o = k % Cpad; c = m; if (o >= Co) o = -1; }
         }
@@ -61,10 +53,21 @@ __global__ void pack_taps_kernel(const float* __restrict__ W, float* __restrict_
 // (each wave holds one slab), and a large weight (2.4 M outputs) needs 9,216 workgroups instead of 36,864 -- that many
 // 64-output workgroups were bound by the workgroup launch rate, not by the 4 slabs' 38 MB.
 __global__ __launch_bounds__(256) void slab_reduce_few_kernel(const float* __restrict__ slabs, float* __restrict__ gw,
-                                                              int Z, int Mp, int Jp, int Co, int C, int T) {
+                                                              int Z, int Mp, int Jp, int Co, int C, int T,
+                                                              const float* __restrict__ bslab, float* __restrict__ gb) {
     const long long total = (long long)Co * C * T;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
+    if (i >= total) {
+        // bias gradient: the weight-gradient GEMM's row sums per split (bslab[z][Mp]), same fixed order
+        const long long o = i - total;
+        if (bslab && o < Co) {
+            float v[4];
+#pragma unroll
+            for (int z = 0; z < 4; ++z) v[z] = z < Z ? 0.0f + bslab[(size_t)z * Mp + o] : 0.0f;
+            gb[o] = ((v[0] + v[1]) + v[2]) + v[3];
+        }
+        return;
+    }
     const int K = T * C;
     const int j = (int)(i % K), o = (int)(i / K);
     const size_t off = (size_t)o * Jp + j, zs = (size_t)Mp * Jp;
@@ -79,20 +82,25 @@ __global__ __launch_bounds__(256) void slab_reduce_few_kernel(const float* __res
 // slabs w, w+4, w+8, ... (coalesced 256-B rows), the four partial sums are added in wave order through LDS:
 // a fixed summation order (bit-reproducible) with 4x the parallelism of one thread per output.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw,
-                                                          int Z, int Mp, int Jp, int Co, int C, int T) {
+                                                          int Z, int Mp, int Jp, int Co, int C, int T,
+                                                          const float* __restrict__ bslab, float* __restrict__ gb) {
     __shared__ float part[4][64];
     const long long total = (long long)Co * C * T;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + lane;
+    // outputs [total, total + Co): the bias gradient from the GEMM's per-split row sums (bslab[z][Mp]), summed like a
+    // weight element -- wave w takes splits w, w + 4, ..., the four partial sums are added in wave order
+    const bool is_bias = bslab != nullptr && i >= total && i < total + Co;
     float s = 0.0f;
-    if (i < total) {
+    if (i < total || is_bias) {
         // enumerate in slab order (j = tap*C + c contiguous): coalesced reads, strided (small) writes
         const int K = T * C;
         const int j = (int)(i % K), o = (int)(i / K);
-        const size_t off = (size_t)o * Jp + j;
+        if (is_bias) slabs = bslab;
+        const size_t off = is_bias ? (size_t)(i - total) : (size_t)o * Jp + j;
         // same order of additions as a plain loop; the loads of eight slabs are in flight together (the loop is
         // latency-bound: up to ~60 slabs, 14 dependent round trips per wave otherwise)
-        const size_t zs = (size_t)Mp * Jp;
+        const size_t zs = is_bias ? (size_t)Mp : (size_t)Mp * Jp;
         for (int z = w; z < Z; z += 32) {
             float v[8];
 #pragma unroll
@@ -103,6 +111,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
     part[w][lane] = s;
     __syncthreads();
+    if (w == 0 && is_bias) gb[i - total] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
     if (w == 0 && i < total) {
         const int K = T * C;
         const int j = (int)(i % K), o = (int)(i / K);
@@ -111,32 +120,9 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
-// grid (channel, batch image): fixed-order block tree per (c, b) plane, then a second tiny kernel sums
-// the B partials in order -> reproducible, and B times more workgroups than one per channel
-__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const float* __restrict__ x,
-                                                                  float* __restrict__ partial, int C, long long HW) {
-    __shared__ float red[16];
-    const int c = blockIdx.x, b = blockIdx.y;
-    const float* p = x + ((size_t)b * C + c) * HW;
-    float s = 0.0f;
-    if ((HW & 3) == 0) {
-        for (long long i = threadIdx.x * 4; i < HW; i += 1024) {
-            const float4 v = *reinterpret_cast<const float4*>(p + i);
-            s += (v.x + v.y) + (v.z + v.w);
-        }
-    } else {
-        for (long long i = threadIdx.x; i < HW; i += 256) s += p[i];
-    }
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) partial[(size_t)c * gridDim.y + b] = s;
-}
-__global__ void channel_sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int C, int B) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.0f;
-    for (int b = 0; b < B; ++b) s += partial[(size_t)c * B + b];
-    out[c] = s;
-}
+// out[c] = sum over (b, hw) of x[b][c][hw]: the bias gradient of the paths that have no weight-gradient GEMM to take it
+// from (the LDS-tile kernels of the 3- / 16-channel layers, deformable_group > 1).  Everything else gets it from
+// igemm_wgrad_*_kernel's own staging registers (bslab) and slab_reduce_*.
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                           int B, int C, long long HW) {
     __shared__ float red[16];
@@ -281,23 +267,19 @@ const float* launch_pack_taps(const float* W, float* dst, size_t room, int Co, i
     return dst;
 }
 
-void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp, int Co, int C, int T, hipStream_t st) {
-    const long long total = (long long)Co * C * T;
+void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp, int Co, int C, int T, hipStream_t st,
+                        const float* bslab, float* gb) {
+    const long long total = (long long)Co * C * T, outs = total + (bslab ? Co : 0);
     if (Z <= 4 && total >= (1 << 18))       // (the large weights are the ones with few slabs)
-        CNUDA_LAUNCH(slab_reduce_few_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slabs, gw, Z,
-                           Mp, Jp, Co, C, T);
+        CNUDA_LAUNCH(slab_reduce_few_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, st, slabs, gw, Z,
+                           Mp, Jp, Co, C, T, bslab, gb);
     else
-        CNUDA_LAUNCH(slab_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, slabs, gw, Z, Mp,
-                           Jp, Co, C, T);
+        CNUDA_LAUNCH(slab_reduce_kernel, dim3((unsigned)((outs + 63) / 64)), dim3(256), 0, st, slabs, gw, Z, Mp,
+                           Jp, Co, C, T, bslab, gb);
 }
 
-void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st, float* scratch) {
-    if (scratch && B > 1) {
-        CNUDA_LAUNCH(channel_sum_partial_kernel, dim3(C, B), dim3(256), 0, st, x, scratch, C, HW);
-        CNUDA_LAUNCH(channel_sum_final_kernel, dim3((C + 63) / 64), dim3(64), 0, st, scratch, out, C, B);
-    } else {
-        CNUDA_LAUNCH(channel_sum_kernel, dim3(C), dim3(256), 0, st, x, out, B, C, HW);
-    }
+void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st) {
+    CNUDA_LAUNCH(channel_sum_kernel, dim3(C), dim3(256), 0, st, x, out, B, C, HW);
 }
 
 }  // namespace cnuda
@@ -358,11 +340,6 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restri
                 const int g = k / (16 * j.T), r = k - g * 16 * j.T;
                 v = j.src[((size_t)(16 * g + (r & 15)) * j.C + m) * j.T + (j.T - 1 - (r >> 4))];
             }
-        } else if (j.mode == PACK_DCN_QUAD) {
-            const int f = (k & 15) * 64 + m, ln = (f >> 2) & 63, s_ = 4 * (f >> 8) + (f & 3);
-            const int rt = (k >> 4) % 3, gq = (k >> 4) / 3, slot = (ln & 15) >> 2;
-            const int o = 4 * s_ + (ln >> 4), c = 4 * gq + (ln & 3);
-            if (slot < 3 && o < j.Co && c < j.C) v = j.src[((size_t)o * j.C + c) * j.T + rt + 3 * slot];
         } else if (j.mode == PACK_DGRAD) {
             if (k < j.T * j.cpad && m < j.C) {
                 const int tap = k / j.cpad, o = k % j.cpad;

@@ -130,7 +130,6 @@ class _Sig:
     cnuda_launch_log_enable = (_I, [_I])
     cnuda_launch_log_collect = (_I, [ctypes.c_char_p, c_size_t])
     cnuda_dcn_set_fused_min_tiles = (_I, [_I])
-    cnuda_dcn_set_quad_backward = (_I, [_I])
     cnuda_conv_set_halo_policy = (_I, [_I, _I])
 
 
@@ -450,21 +449,6 @@ class dcn_fused_min_tiles:
 
     def __exit__(self, *exc):
         lib().cnuda_dcn_set_fused_min_tiles(self.prev)
-
-
-class dcn_quad_backward:
-    """with dcn_quad_backward(True): every DCN backward inside the block that CAN take the one-kernel form on channel-quad
-    planes (dcnq_kernel: 3x3 / stride 1 / padding 1, C % 16 == 0, Cout <= 64, map 16 / 32 / 64 / 128 wide) and has at
-    least 2,048 64-pixel tiles takes it; dcn_quad_backward(2): whatever its size (tests); False / 0: none."""
-
-    def __init__(self, on=True):
-        self.on = (2 if on == 2 else 1) if on else 0      # 2: every eligible call, whatever its size (tests)
-
-    def __enter__(self):
-        self.prev = lib().cnuda_dcn_set_quad_backward(self.on)
-
-    def __exit__(self, *exc):
-        lib().cnuda_dcn_set_quad_backward(self.prev)
 
 
 class halo_conv:

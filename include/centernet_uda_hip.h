@@ -101,17 +101,10 @@ int cnuda_prof_name_len(void);
  * cnuda_conv_set_halo_policy: which 3x3 / stride-1 / padding-1 convolutions take the halo-tile kernels (csrc/hconv.cuh):
  * level 0 none, 1 every eligible layer, 2 the 32-row GEMMs (default; initial value from CNUDA_HCONV), and only calls
  * with at least min_tiles 128-pixel tiles (default 128).  Negative level / min_tiles < 1 leave that setting unchanged.
- * Returns level | min_tiles << 8 after the change.  Tests use (1, 1) to run small shapes through every tile variant.
- * cnuda_dcn_set_quad_backward: 1 -> cnuda_dcn_v2_backward[_cols] takes its one-kernel form (dcnq_kernel: column
- * gradient, grad_offset / grad_mask sums and the grad_input scatter on channel-quad LDS planes) for 3x3 / stride 1 /
- * padding 1 / dilation 1 layers with C % 16 == 0, Cout <= 64, a 16 / 32 / 64 / 128 wide map and at least 2,048 tiles of
- * 64 pixels; 2 -> the same without the size rule (tests); 0 -> the GEMM + walk kernels; < 0 -> the initial value
- * (CNUDA_DCNQ in the environment).  Returns the previous on/off setting.  Same results up to
- * summation order. */
+ * Returns level | min_tiles << 8 after the change.  Tests use (1, 1) to run small shapes through every tile variant. */
 int cnuda_launch_log_enable(int on);
 int cnuda_launch_log_collect(char* names, size_t cap);
 int cnuda_dcn_set_fused_min_tiles(int min_tiles);
-int cnuda_dcn_set_quad_backward(int on);
 int cnuda_conv_set_halo_policy(int level, int min_tiles);
 
 /* ------------------------------------------------------------------------

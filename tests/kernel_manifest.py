@@ -15,7 +15,6 @@ MANIFEST = {
     'dcnw_fwd_kernel<64, 32>': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[64to64_128sq',
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[128to64_64sq',
-        'tests/test_gpu_dcn.py::test_quad_plane_backward_known_answers',
     ],
     'dcnw_fwd_kernel<64, 16>': [
         'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle[dla_64',
@@ -56,16 +55,6 @@ MANIFEST = {
         'tests/test_gpu_ops.py::test_batch_norm_train_fwd_bwd_and_running_stats',
         'tests/test_gpu_fuzz.py::test_batch_norm_random_geometry',
     ],
-    'channel_sum_final_kernel': [
-        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
-        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
-        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
-    ],
-    'channel_sum_partial_kernel': [
-        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
-        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
-        'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
-    ],
     'conv1x1_dgrad_act_kernel<2>': [
         'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
         'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
@@ -80,16 +69,6 @@ MANIFEST = {
         'tests/test_gpu_ops.py::test_cat_add_split',
         'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
         'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
-    ],
-    # (opt-in: hr.dcn_quad_backward / CNUDA_DCNQ=1; not launched by the default benched step)
-    'dcnq_kernel<32>': [
-        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[64to64_128sq_quad',
-        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[128to64_64sq_quad',
-        'tests/test_gpu_dcn.py::test_quad_plane_backward_vs_oracle[w32',
-        'tests/test_gpu_dcn.py::test_quad_plane_backward_known_answers',
-    ],
-    'dcnq_kernel<16>': [
-        'tests/test_gpu_dcn.py::test_quad_plane_backward_vs_oracle[w16',
     ],
     'dcn_bwd_data_kernel': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[64to64_128sq_one_launch',

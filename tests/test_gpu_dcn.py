@@ -175,52 +175,6 @@ def _gpu_bwd_walk(walk):
     return run
 
 
-# The opt-in one-kernel backward on channel-quad planes (dcnq_kernel; csrc/dcn.hip, hr.dcn_quad_backward): 3x3 / stride 1
-# / padding 1 layers with C % 16 == 0, Cout <= 64 on 16 / 32 / 64 / 128 wide maps.  Cases: both tile shapes (16- and
-# 32-pixel rows), output channels that do not fill the k-steps, samples far outside the 3-cell window margin and the
-# image (the stray path: global atomics), offsets of a few pixels (many lanes of one instruction on one anchor cell:
-# the claim rounds and their leftovers), several channel groups, a batch.
-QUAD_CASES = {
-    'w16': dict(B=2, C=32, Co=37, H=8, W=16, off_scale=1.0),
-    'w16_dla': dict(B=1, C=64, Co=64, H=16, W=16),
-    'w32_far_offsets': dict(B=2, C=16, Co=16, H=6, W=32, off_scale=6.0),
-    'w32_shared_anchors': dict(B=1, C=48, Co=20, H=4, W=32, off_scale=2.5),
-    'w64_smooth': dict(B=1, C=48, Co=64, H=4, W=64, off_scale=0.05),
-    'w128': dict(B=1, C=16, Co=8, H=2, W=128, off_scale=0.7),
-}
-
-
-@pytest.mark.parametrize('name', sorted(QUAD_CASES))
-def test_quad_plane_backward_vs_oracle(name):
-    import _ext
-    import hip_runtime as hr
-    (x, w, b, off, m, go), geom = _case(zlib.crc32(name.encode()) % 1000, **QUAD_CASES[name])
-    wg = od.dcn_v2_backward(x, w, b, off, m, go, *geom)
-    dev = [t.to(DEV) for t in (x, w, b, off, m, go)]
-    with hr.dcn_quad_backward(2), hr.launch_log() as log:
-        grads = _ext.dcn_v2_backward(*dev, *geom)
-    assert any('dcnq_kernel' in n for n in log.names), log.names
-    assert not any(k in n for n in log.names for k in ('dcn_col2im', 'dcn_coord_grad', 'dcn_bwd_data', 'dcn_prep')), log.names
-    for got, ref, nm in zip(grads, wg, ['input', 'offset', 'mask', 'weight', 'bias']):
-        _close(got, ref)
-    # ... and the same values as the default path on the same inputs, to the summation order of grad_input
-    with hr.dcn_quad_backward(False):
-        base = _ext.dcn_v2_backward(*dev, *geom)
-    for got, ref in zip(grads, base):
-        _close(got, ref.cpu(), 2e-5)
-
-
-def test_quad_plane_backward_known_answers():
-    import dcn_known_answers as ka
-    import hip_runtime as hr
-
-    def bwd(*a):
-        with hr.dcn_quad_backward(2):
-            return _gpu_bwd(*a)
-    ka.check_linear_ramp_has_constant_coordinate_gradient(_gpu_fwd, bwd, torch.float32, 5e-5, size=(2, 64, 40, 32, 64))
-    ka.check_linear_ramp_has_constant_coordinate_gradient(_gpu_fwd, bwd, torch.float32, 5e-5, size=(1, 16, 8, 16, 32))
-
-
 @pytest.mark.parametrize('dh,dw', [(0.5, 0.0), (0.0, 0.5), (0.5, 0.5), (-0.5, 0.5), (0.25, -0.75)])
 @pytest.mark.parametrize('size', [(2, 3, 7, 9, 4), (2, 64, 32, 40, 64), (1, 128, 16, 16, 128)])
 def test_known_answer_half_pixel_offsets_are_box_blurs(dh, dw, size):

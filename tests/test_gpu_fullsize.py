@@ -414,9 +414,6 @@ DCN_LAYERS = {
     '64to64_128sq_one_launch': dict(B=8, C=64, Co=64, S=128, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel', 'igemm_fwd_shortk_kernel']),
     '128to64_64sq': dict(B=16, C=128, Co=64, S=64, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_col2im_kernel', 'dcn_coord_grad_kernel', 'igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>']),
     '128to64_64sq_one_launch': dict(B=32, C=128, Co=64, S=64, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel']),
-    # the one-kernel backward on channel-quad planes (opt-in: hr.dcn_quad_backward / CNUDA_DCNQ=1)
-    '64to64_128sq_quad': dict(B=4, C=64, Co=64, S=128, quad=True, kernels=['dcnw_fwd_kernel<64, 32>', 'dcnq_kernel<32>', 'igemm_wgrad_kernel<DcnColWBufLoader, 64, 64>']),
-    '128to64_64sq_quad': dict(B=16, C=128, Co=64, S=64, quad=True, kernels=['dcnw_fwd_kernel<64, 32>', 'dcnq_kernel<32>']),
     '32to64_96sq': dict(B=8, C=32, Co=64, S=96, kernels=['igemm_fwd_kernel<64, DcnFwdLoaderT<true>']),      # a map the window kernels do not take
     '128to128_64sq': dict(B=16, C=128, Co=128, S=64, kernels=['igemm_fwd_kernel<128, DcnFwdLoaderT<true>']),
     '256to256_32sq': dict(B=32, C=256, Co=256, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_kernel<128, DcnColsBufLoader']),
@@ -430,9 +427,7 @@ _DCN_CASES = [(n, o) for n in DCN_LAYERS for o in ((0.001, 0.3, 1.0, 6.0) if DCN
 @pytest.mark.parametrize('layer,off_scale', _DCN_CASES,      # 0.3 px: col2im's DPP ranking path; 6 px: strays beyond the LDS window
                          ids=['%s-pm%gpx' % (n, o) for n, o in _DCN_CASES])
 def test_full_size_dcn_layer_matches_the_oracle(layer, off_scale):
-    import hip_runtime as hr
-    with hr.dcn_quad_backward(2 if DCN_LAYERS[layer].get('quad') else 0):
-        _full_size_dcn_layer(layer, off_scale)
+    _full_size_dcn_layer(layer, off_scale)
 
 
 def _full_size_dcn_layer(layer, off_scale):

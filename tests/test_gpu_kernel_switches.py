@@ -25,7 +25,7 @@ def test_alternate_kernel_paths_hold_the_same_parity(switch):
     # (the full-size DCN layers at one offset scale and without the opt-in backward: the alternates differ in loaders and
     # tiles, not in what the offsets or that kernel exercise)
     r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
-                        '-k', '(not dcn_layer) or (pm1px and not quad)'] + SUBSET,
+                        '-k', '(not dcn_layer) or pm1px'] + SUBSET,
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=3000)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
     assert ' passed' in r.stdout and 'skipped' not in r.stdout.splitlines()[-1], r.stdout[-500:]
