@@ -119,7 +119,7 @@ def unfold_batchnorm(model):
 
 
 def _conv(cin, cout, k, stride=1):
-    return hnn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
+    return hnn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False, emit_stats=True)    # (every caller: conv -> BatchNorm)
 
 
 class ConvBnRelu(nn.Sequential):

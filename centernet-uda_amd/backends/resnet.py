@@ -43,7 +43,7 @@ _PRETRAINED = {18: 'resnet18-5c106cde.pth', 34: 'resnet34-333f7ec4.pth', 50: 're
 
 
 def _conv(cin, cout, k, stride=1):
-    return hnn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
+    return hnn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False, emit_stats=True)    # (every caller: conv -> BatchNorm)
 
 
 class _Downsample(nn.Sequential):

@@ -145,13 +145,14 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ running_mean,
     float* __restrict__ running_var, long long* __restrict__ num_batches_tracked,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ residual,
-    float* __restrict__ y, int C, long long HW, int relu, int groups, int imgs_per_group, int per_plane, int ips) {
+    float* __restrict__ y, int C, long long HW, int relu, int groups, int imgs_per_group, int per_plane, int ips,
+    int spg /* partials per group when they do not come from bn_reduce_kernel<0> (bn_fold_stats_kernel), else 0 */) {
     __shared__ double red[16];
     __shared__ float stat[2];
     const long long plane = blockIdx.x;               // (block of ips images, channel)
     const int c = (int)(plane % C);
     const int b = (int)(plane / C) * ips, grp = b / imgs_per_group;
-    const int s_per_group = imgs_per_group / ips * per_plane;
+    const int s_per_group = spg ? spg : imgs_per_group / ips * per_plane;
     const double n = (double)count;                        // values per channel and GROUP
     double s0, s1;
     bn_sum_partials(partial, c, S, grp * s_per_group, (grp + 1) * s_per_group, s0, s1, red);
@@ -311,6 +312,43 @@ __global__ __launch_bounds__(kBnThreads) void bn_eval_kernel(
     }
 }
 
+// Statistics that arrive from the producing GEMM's epilogue (igemm.cuh, "BatchNorm statistics"): stats[block][rows][2]
+// floats, one block per `blk_px` consecutive pixels of the flattened (image, pixel) axis.  One workgroup adds the blocks
+// of ONE (group, split) range for 16 channels -- thread (channel, lane of 16) walks its blocks in order in double
+// precision, the 16 lanes are added in lane order -- and leaves partial[(c * S + s) * 2 + {0, 1}] exactly where
+// bn_reduce_kernel<0> would: bn_apply_kernel does not know the difference.  Fixed order: bit-reproducible.
+__global__ __launch_bounds__(256) void bn_fold_stats_kernel(const float* __restrict__ stats, int rows, long long blocks_per_group,
+                                                           int spl, double* __restrict__ partial, int C, int S) {
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const int grp = blockIdx.y / spl, sp = blockIdx.y - grp * spl;
+    const long long per = (blocks_per_group + spl - 1) / spl;
+    const long long b0 = grp * blocks_per_group + sp * per;
+    long long b1 = b0 + per;
+    if (b1 > (grp + 1) * blocks_per_group) b1 = (grp + 1) * blocks_per_group;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C) {
+        const float2* src = reinterpret_cast<const float2*>(stats) + c;
+        for (long long b = b0 + bl; b < b1; b += 64) {
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = b + 16 * u < b1 ? src[(size_t)(b + 16 * u) * rows] : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a0 += (double)v[u].x; a1 += (double)v[u].y; }
+        }
+    }
+    red[0][bl][cl] = a0;
+    red[1][bl][cl] = a1;
+    __syncthreads();
+    if (bl == 0 && c < C) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int i = 0; i < 16; ++i) { t0 += red[0][i][cl]; t1 += red[1][i][cl]; }
+        partial[((size_t)c * S + blockIdx.y) * 2 + 0] = t0;
+        partial[((size_t)c * S + blockIdx.y) * 2 + 1] = t1;
+    }
+}
+
 int plane_splits(long long planes, long long HW, int per_block) {
     long long want = 2048 / (planes > 0 ? planes : 1);
     if (want < 1) want = 1;
@@ -326,7 +364,8 @@ using namespace cnuda;
 
 extern "C" size_t cnuda_bn_workspace_bytes(int B, int C, long long HW) {
     const Split sp = pick_split(B, C, HW, 1);          // (ips = 1: the most partials any grouping needs)
-    return (size_t)C * sp.S * 2 * sizeof(double) + (size_t)C * 2 * sizeof(float) + 512;
+    const size_t s_max = sp.S > 64 * 8 ? (size_t)sp.S : (size_t)64 * 8;   // (or 64 folded partials for each of up to 8 groups)
+    return (size_t)C * s_max * 2 * sizeof(double) + (size_t)C * 2 * sizeof(float) + 512;
 }
 
 extern "C" int cnuda_bn_train_forward(const float* x, const float* gamma, const float* beta, const float* residual,
@@ -356,8 +395,47 @@ extern "C" int cnuda_bn_train_forward(const float* x, const float* gamma, const 
     CNUDA_LAUNCH(bn_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
                        dim3(kBnThreads), 0, st, x, partial, sp.S, count, momentum, eps, save_mean, save_invstd,
                        running_mean, running_var, num_batches_tracked, gamma, beta, residual, y, C, HW, relu, groups, Bg,
-                       sp.per_plane, sp.ips);
+                       sp.per_plane, sp.ips, 0);
     return check_launch("cnuda_bn_train_forward");
+}
+
+// The same layer with sum(x) / sum(x^2) already taken by the kernel that produced x (cnuda_conv2d_forward_stats,
+// cnuda_dcn_v2_forward_stats): `stats` = [blocks][rows][2] floats, a block = `blk_px` consecutive pixels of the flattened
+// (image, pixel) axis, channel c in row c.  The pass over x that bn_reduce_kernel<0> makes is replaced by a fold of
+// blocks * C pairs.  Every statistics group must be a whole number of blocks (returns -1 otherwise: the caller then
+// uses cnuda_bn_train_forward).
+extern "C" int cnuda_bn_train_forward_stats(const float* x, const float* stats, int blk_px, int rows, const float* gamma,
+                                            const float* beta, const float* residual, float* y, float* save_mean,
+                                            float* save_invstd, float* running_mean, float* running_var,
+                                            long long* num_batches_tracked, float momentum, float eps, int relu, int B,
+                                            int C, long long HW, int groups, void* workspace, size_t workspace_bytes,
+                                            cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && stats && gamma && beta && y && save_mean && save_invstd, "cnuda_bn_train_forward_stats: null pointer");
+    CNUDA_REQUIRE(B > 0 && C > 0 && HW > 0 && blk_px > 0 && rows >= C, "cnuda_bn_train_forward_stats: bad geometry");
+    CNUDA_REQUIRE(groups >= 1 && B % groups == 0, "cnuda_bn_train_forward_stats: batch %d not divisible into %d groups", B, groups);
+    CNUDA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "cnuda_bn_train_forward_stats: running stats");
+    const int Bg = B / groups;
+    const long long count = (long long)Bg * HW;
+    CNUDA_REQUIRE(count > 1, "Expected more than 1 value per channel when training, got input size [%d, %d, %lld]", Bg, C, HW);
+    CNUDA_REQUIRE(count % blk_px == 0, "cnuda_bn_train_forward_stats: a statistics group (%lld values per channel) is not a "
+                  "whole number of %d-pixel blocks", count, blk_px);
+    CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_bn_workspace_bytes(B, C, HW),
+                  "cnuda_bn_train_forward_stats: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const long long bpg = count / blk_px;                     // blocks per group
+    int spl = (int)((bpg + 255) / 256);                       // <= 256 blocks (16 per thread) per workgroup ...
+    if (spl > 64) spl = 64;                                   // ... and at most 64 partials per group for the apply pass
+    const int S = groups * spl;
+    CNUDA_REQUIRE((size_t)C * S * 2 * sizeof(double) + 512 <= workspace_bytes, "cnuda_bn_train_forward_stats: workspace");
+    double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    CNUDA_LAUNCH(bn_fold_stats_kernel, dim3((C + 15) / 16, S), dim3(256), 0, st, stats, rows, bpg, spl, partial, C, S);
+    const Split sp = pick_split(B, C, HW, Bg);                // (the apply pass's own grid: unchanged)
+    const long long planes = (long long)B * C / sp.ips;
+    CNUDA_LAUNCH(bn_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
+                       dim3(kBnThreads), 0, st, x, partial, S, count, momentum, eps, save_mean, save_invstd,
+                       running_mean, running_var, num_batches_tracked, gamma, beta, residual, y, C, HW, relu, groups, Bg,
+                       sp.per_plane, sp.ips, spl);
+    return check_launch("cnuda_bn_train_forward_stats");
 }
 
 extern "C" int cnuda_bn_eval_forward(const float* x, const float* gamma, const float* beta, const float* running_mean,

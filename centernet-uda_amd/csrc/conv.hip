@@ -30,6 +30,8 @@ struct ConvFwdParams {
     float* y;
     float act_slope;   // < 0: none, 0: ReLU, 0.2: LeakyReLU(0.2)
     const float* residual;   // nullable, shaped like y: y = act(conv + bias + residual) (BatchNorm-folded inference)
+    float* stats;            // nullable: per (pixel block, output channel) sum / sum of squares of y (igemm.cuh, "BatchNorm statistics")
+    int stats_mp;            // rows per pixel block of `stats` (>= the padded row count of the launch)
 };
 
 // B[k = tap*C + c][n] = x[b][c][oy*sh - ph + r][ox*sw - pw + s]   (0 outside)
@@ -791,13 +793,41 @@ extern "C" int cnuda_conv2d_forward(const float* x, const float* weight, const f
                                     workspace, workspace_bytes, stream);
 }
 
+// Which pixel blocks a forward call of this geometry can leave BatchNorm statistics for: 0 (none: the LDS-tile and
+// halo-tile kernels, the scalar epilogue of planes that are no multiple of four pixels), else the pixels per block
+// (64 for the 64- / 128-row tiles, 32 for the 32-row tile); *rows = rows per block of the stats array.
+extern "C" int cnuda_conv2d_stats_block(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph,
+                                        int pw, int* rows) {
+    ConvGeom g;
+    if (fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_stats_block")) return 0;
+    if (smallc_supported(C, Cout, kh, kw, sh, sw) || ((g.Ho * g.Wo) & 3) != 0) return 0;
+    const ConvPlan q = make_plan(g);
+    if (hconv_ok(g, C, q.bmf)) return 0;
+    if (rows) *rows = q.Mpf;
+    return q.bmf == 32 ? 32 : 64;
+}
+
 extern "C" int cnuda_conv2d_forward_res(const float* x, const float* weight, const float* bias, const float* residual,
                                         float* y, int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw,
                                         int ph, int pw, float act_slope, void* workspace, size_t workspace_bytes,
                                         cnuda_stream_t stream) {
+    return cnuda_conv2d_forward_stats(x, weight, bias, residual, y, nullptr, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, act_slope,
+                                      workspace, workspace_bytes, stream);
+}
+
+extern "C" int cnuda_conv2d_forward_stats(const float* x, const float* weight, const float* bias, const float* residual,
+                                          float* y, float* stats, int B, int C, int H, int W, int Cout, int kh, int kw,
+                                          int sh, int sw, int ph, int pw, float act_slope, void* workspace,
+                                          size_t workspace_bytes, cnuda_stream_t stream) {
     CNUDA_REQUIRE(x && weight && y, "cnuda_conv2d_forward: null pointer");
     ConvGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_forward")) return rc;
+    if (stats) {
+        int rows = 0;
+        CNUDA_REQUIRE(!residual && act_slope < 0.0f &&
+                          cnuda_conv2d_stats_block(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, &rows) != 0,
+                      "cnuda_conv2d_forward_stats: no statistics for this call (cnuda_conv2d_stats_block says which)");
+    }
     if (!residual && smallc_supported(C, Cout, kh, kw, sh, sw))
         return smallc_forward(x, weight, bias, y, B, C, H, W, Cout, kh, kw, sh, ph, pw, act_slope, 0, workspace,
                               workspace_bytes, (hipStream_t)stream);
@@ -805,7 +835,7 @@ extern "C" int cnuda_conv2d_forward_res(const float* x, const float* weight, con
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_conv2d_forward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
-    ConvFwdParams p{g, x, bias, y, act_slope, residual};
+    ConvFwdParams p{g, x, bias, y, act_slope, residual, stats, q.Mpf};
     if (hconv_ok(g, C, q.bmf)) {      // (K = 9 C is already a multiple of the chunk: the same packed size, another K order)
         const float* Ah = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),
                                       ig_a_bytes(q.Kpf, q.Mpf), Cout, C, q.T, PACK_HALO_FWD, q.Kpf, q.Mpf, 0, st);

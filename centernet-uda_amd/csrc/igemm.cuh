@@ -17,6 +17,8 @@
 //   A operand: lane l holds A[k = l>>5][i = l&31]; B: B[k = l>>5][j = l&31]
 //   D: col j = l&31, row i = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "common.h"
 
 namespace cnuda {
@@ -278,12 +280,33 @@ struct IgABuf {
 // ---------------------------------------------------------------------------
 constexpr int IG_EPI_LD = 36;                                  // floats per staged row (32 + pad, 16-byte aligned)
 constexpr int IG_EPI_WAVE = 32 * IG_EPI_LD;                    // floats per wave
+// BatchNorm statistics from the epilogue (Params with a `stats` member: the forward loaders).  The layer that follows a
+// convolution in DLA-34 is a train-mode BatchNorm whose first pass re-reads the whole output for sum(x) / sum(x^2) per
+// channel (bn_reduce_kernel<0>: 1.2 ms of a benched step).  Here the tile is in registers anyway -- after the LDS
+// transpose a lane holds four consecutive pixels of one channel row and eight lanes share the row -- so each wave
+// leaves, per channel row of its tile, the two sums over ITS pixels (TN x 32 = IG_STAT_PX<BM> of them) at
+//   stats[(pixel block)][row m][2],   pixel block = first pixel / IG_STAT_PX<BM>, rows padded to Mp,
+// one 8-byte store per row from the lane with cg == 0 (consecutive rows: 64 contiguous bytes per instruction).  The
+// sums are taken over the values that are STORED (bias included); lanes past N contribute nothing.  Fixed order (a lane's
+// four pixels, its TN tiles in sequence, then the row's eight lanes by quad permutes and a half-row mirror):
+// bit-reproducible; bn_fold_stats_kernel adds the blocks of a statistics group in double precision, in order.
+template <class P, class = void> struct IgHasStats : std::false_type {};
+template <class P> struct IgHasStats<P, std::void_t<decltype(std::declval<P>().stats)>> : std::true_type {};
+template <int BM> constexpr int ig_stat_px() { return IgTile<BM>::TN * 32; }
 template <int BM, class Loader>
 __device__ __forceinline__ void ig_epilogue_vec4(const typename Loader::Params& p, float* __restrict__ stage,
                                                  const f32x16 (&acc)[IgTile<BM>::TM][IgTile<BM>::TN], int m0, long long n0,
                                                  int wm_off, int wn_off, int lane, int M, long long N) {
     using T = IgTile<BM>;
     const int col = lane & 31, cg = lane & 7, rsub = lane >> 3;
+    constexpr bool kStats = IgHasStats<typename Loader::Params>::value;
+    bool stats_on = false;
+    if constexpr (kStats) stats_on = p.stats != nullptr;
+    float ssum[T::TM][4], ssq[T::TM][4];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { ssum[i][it] = 0.0f; ssq[i][it] = 0.0f; }
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
         const long long n = n0 + wn_off + j * 32 + 4 * cg;
@@ -299,8 +322,39 @@ __device__ __forceinline__ void ig_epilogue_vec4(const typename Loader::Params& 
                 const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * IG_EPI_LD + 4 * cg);
                 const int m = m0 + wm_off + i * 32 + row;
                 if (m < M && n < N) out.store4(p, m, v);
+                if constexpr (kStats) {
+                    if (stats_on) {
+                        f32x4 w = v;
+                        if (p.bias && m < M) w += p.bias[m];
+                        if (!(n < N)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+                        // (per lane: its four pixels of this tile; the eight lanes of a row meet once, after the last tile)
+                        ssum[i][it] += (w[0] + w[1]) + (w[2] + w[3]);
+                        ssq[i][it] += (w[0] * w[0] + w[1] * w[1]) + (w[2] * w[2] + w[3] * w[3]);
+                    }
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // reads done before the next tile overwrites
+        }
+    }
+    if constexpr (kStats) {
+        if (stats_on) {
+            // the eight lanes (cg = 0..7) of a row: two quad permutes and a half-row mirror on the vector ALU (an LDS-crossbar
+            // shuffle per step measured +4 % on the 128-row tile: three dependent ~60-cycle round trips per row and tile)
+            auto row8 = [](float v) {
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+                return v;
+            };
+            const long long blk = (n0 + wn_off) / ig_stat_px<BM>();
+            float2* dst = reinterpret_cast<float2*>(p.stats) + blk * p.stats_mp + m0 + wm_off;
+#pragma unroll
+            for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const float a = row8(ssum[i][it]), b = row8(ssq[i][it]);
+                    if (cg == 0) dst[i * 32 + it * 8 + rsub] = make_float2(a, b);
+                }
         }
     }
 }

@@ -17,11 +17,15 @@ class Conv2d(nn.Module):
     """Dense convolution on the implicit-GEMM MFMA kernels; optional fused
     bias + ReLU / LeakyReLU epilogue (`act_slope`: <0 none, 0 ReLU, 0.2 leaky)."""
 
-    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, act_slope=-1.0):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, act_slope=-1.0,
+                 emit_stats=False):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size, self.stride, self.padding = _pair(kernel_size), _pair(stride), _pair(padding)
         self.act_slope = float(act_slope)
+        # the layer's only consumer is a BatchNorm2d: in training mode the GEMM's epilogue leaves per-channel sum / sum of
+        # squares with the output (ops.conv2d, emit_stats) and the BatchNorm skips its own pass over it
+        self.emit_stats = bool(emit_stats)
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         from . import PackToken
@@ -38,7 +42,8 @@ class Conv2d(nn.Module):
                 self.bias.uniform_(-bound, bound)
 
     def forward(self, x):
-        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.act_slope, self._pack_token)
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.act_slope, self._pack_token,
+                          emit_stats=self.emit_stats and self.training)
 
     def extra_repr(self):
         return '%d, %d, kernel_size=%s, stride=%s, padding=%s, bias=%s, act_slope=%g' % (

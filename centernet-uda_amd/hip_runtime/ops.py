@@ -47,7 +47,7 @@ def _conv_geom(x, weight, stride, padding):
 
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, act_slope, pack_token=0):
+    def forward(ctx, x, weight, bias, stride, padding, act_slope, pack_token=0, stats_box=None):
         require_gpu(x, weight, bias)
         ctx.slot = slot_of(x)          # (hip_runtime.fanout: where the other consumers of x leave their share of its gradient)
         x, weight = f32c(x), f32c(weight)
@@ -58,10 +58,24 @@ class _Conv2d(Function):
         y = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=x.device)
         L = lib()
         wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g), x)
+        stats = None
+        if stats_box is not None and act_slope < 0:
+            # BatchNorm statistics of y from the GEMM's epilogue, where this geometry's kernel can give them
+            import ctypes
+            rows = ctypes.c_int(0)
+            blk = L.cnuda_conv2d_stats_block(*g, ctypes.byref(rows))
+            if blk:
+                nblk = (B * Ho * Wo + 127) // 128 * (128 // blk)
+                stats = torch.empty((nblk, rows.value, 2), dtype=torch.float32, device=x.device)
+                stats_box.append((stats, blk, rows.value))
         prof_arm('conv_fwd', B, C, H, W, Co, kh, kw, Ho, Wo)
         with pack_stamp(pack_token, weight):
-            check(L.cnuda_conv2d_forward(ptr(x), ptr(weight), ptr(bias), ptr(y), *g, float(act_slope),
-                                         wp, wn, stream()), 'conv2d_forward')
+            if stats is None:
+                check(L.cnuda_conv2d_forward(ptr(x), ptr(weight), ptr(bias), ptr(y), *g, float(act_slope),
+                                             wp, wn, stream()), 'conv2d_forward')
+            else:
+                check(L.cnuda_conv2d_forward_stats(ptr(x), ptr(weight), ptr(bias), ptr(None), ptr(y), ptr(stats), *g,
+                                                   float(act_slope), wp, wn, stream()), 'conv2d_forward_stats')
         ctx.geom, ctx.act_slope, ctx.has_bias, ctx.pack_token = g, act_slope, bias is not None, pack_token
         ctx.save_for_backward(x, weight, y if act_slope >= 0 else None, bias)
         return y
@@ -93,14 +107,25 @@ class _Conv2d(Function):
             prof_arm('conv_wgrad', B, C, H, W, Co, kh, kw, Ho, Wo)
             check(L.cnuda_conv2d_backward_weight(ptr(x), ptr(gy), ptr(gw_buf), ptr(gb_buf), *g, wp, wn, stream()),
                   'conv2d_backward_weight')
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0, pack_token=0):
+EPILOGUE_STATS = True      # (A/B measurements flip it: profiles/microbench/ab_bn_stats.py)
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0, pack_token=0, emit_stats=False):
     """y = act(conv2d(x, weight) + bias); act_slope < 0 none, 0 ReLU, 0.2 LeakyReLU(0.2).  pack_token: identity of
     the module that owns `weight` (hip_runtime.new_pack_token) -- lets the library keep the packed weight image
     until the weights change; 0 = re-pack on every call."""
-    return _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope), pack_token)
+    if not (emit_stats and EPILOGUE_STATS):
+        return _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope), pack_token)
+    # emit_stats: the caller's next layer is a train-mode BatchNorm over y.  Where the kernel can, it leaves
+    # sum / sum of squares per (pixel block, channel) beside y; batch_norm_act finds them on the tensor.
+    box = []
+    y = _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope), pack_token, box)
+    if box:
+        y._cnuda_bn_stats = box[0]
+    return y
 
 
 class _ConvActConv1x1(Function):
@@ -311,7 +336,7 @@ def _act_code(relu):
 class _BatchNormAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, num_batches_tracked,
-                groups):
+                groups, pre=None):
         require_gpu(x, gamma, beta, residual)
         ctx.res_slot = None if residual is None else slot_of(residual)
         x = f32c(x)
@@ -325,10 +350,17 @@ class _BatchNormAct(Function):
         invstd = torch.empty(groups * C, dtype=torch.float32, device=x.device)
         L = lib()
         wp, wn = _ws(L.cnuda_bn_workspace_bytes(B, C, HW), x)
-        check(L.cnuda_bn_train_forward(ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(mean), ptr(invstd),
-                                       ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), float(momentum),
-                                       float(eps),
-                                       _act_code(relu), B, C, HW, groups, wp, wn, stream()), 'bn_train_forward')
+        if pre is not None and (B // groups * HW) % pre[1] == 0 and pre[2] >= C:
+            # sum(x) / sum(x^2) came with x from the producing GEMM's epilogue: no statistics pass over x
+            check(L.cnuda_bn_train_forward_stats(ptr(x), ptr(pre[0]), pre[1], pre[2], ptr(gamma), ptr(beta), ptr(residual),
+                                                 ptr(y), ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var),
+                                                 ptr(num_batches_tracked), float(momentum), float(eps), _act_code(relu),
+                                                 B, C, HW, groups, wp, wn, stream()), 'bn_train_forward_stats')
+        else:
+            check(L.cnuda_bn_train_forward(ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(y), ptr(mean), ptr(invstd),
+                                           ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), float(momentum),
+                                           float(eps),
+                                           _act_code(relu), B, C, HW, groups, wp, wn, stream()), 'bn_train_forward')
         ctx.relu, ctx.dims, ctx.has_res, ctx.groups = relu, (B, C, HW), residual is not None, groups
         # y is read by the backward only where a residual entered the activation; without one the gate is recomputed
         # from x (cnuda_bn_backward, `beta` given) and y is not kept
@@ -352,7 +384,7 @@ class _BatchNormAct(Function):
         check(L.cnuda_bn_backward(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(regate), ptr(mean), ptr(invstd), ptr(gx),
                                   ptr(gres), ptr(gg_buf), ptr(gb_buf), _act_code(ctx.relu), B, C, HW, ctx.groups, wp, wn,
                                   stream()), 'bn_backward')
-        return gx, gg, gb, gres, None, None, None, None, None, None, None
+        return gx, gg, gb, gres, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
@@ -370,7 +402,7 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum
         from . import bump_buffer_epoch
         bump_buffer_epoch()         # the kernel rewrites the running statistics behind torch's version counters
         return _BatchNormAct.apply(x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu,
-                                   num_batches_tracked, int(groups))
+                                   num_batches_tracked, int(groups), getattr(x, '_cnuda_bn_stats', None))
     if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad):
         raise RuntimeError("batch_norm_act: eval-mode BN has no backward in this build "
                            "(the reference evaluates under torch.no_grad(), train.py:172)")

@@ -242,6 +242,18 @@ int cnuda_conv2d_forward_res(const float* x, const float* weight, const float* b
                              int B, int C, int H, int W, int Cout, int kh, int kw,
                              int sh, int sw, int ph, int pw, float act_slope,
                              void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+/* forward that also leaves the statistics a train-mode BatchNorm of y needs (the layer behind almost every convolution of
+ * DLA-34, backends/dla.py:37-62,150-168: the reference's cuDNN BatchNorm re-reads y for them; here the GEMM's epilogue sums
+ * what it stores).  stats: [blocks][rows][2] floats = (sum, sum of squares) of y over one block of `cnuda_conv2d_stats_block`
+ * consecutive pixels of the flattened (image, pixel) axis, per output channel (row); blocks = ceil(B*Ho*Wo / 128) * (128 /
+ * block pixels).  cnuda_conv2d_stats_block returns 0 where this geometry's kernel cannot give them (then pass stats =
+ * NULL and use cnuda_bn_train_forward), else the block size, and *rows.  Needs residual == NULL and act_slope < 0.
+ * cnuda_bn_train_forward_stats (below) consumes them. */
+int cnuda_conv2d_stats_block(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int* rows);
+int cnuda_conv2d_forward_stats(const float* x, const float* weight, const float* bias, const float* residual, float* y,
+                               float* stats, int B, int C, int H, int W, int Cout, int kh, int kw,
+                               int sh, int sw, int ph, int pw, float act_slope,
+                               void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 int cnuda_conv2d_backward_data(const float* grad_y, const float* weight, float* grad_x,
                                int B, int C, int H, int W, int Cout, int kh, int kw,
                                int sh, int sw, int ph, int pw,
@@ -283,6 +295,13 @@ int cnuda_bn_train_forward(const float* x, const float* gamma, const float* beta
                                          the concatenated source | target batch equals the reference's two forward
                                          calls (uda/entropy_minimization.py:18-19) */,
                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+/* train_forward with sum(x) / sum(x^2) supplied by the kernel that produced x (cnuda_conv2d_forward_stats): no statistics
+ * pass over x.  stats [blocks][rows][2], block = blk_px pixels; every statistics group must be whole blocks (-1 otherwise). */
+int cnuda_bn_train_forward_stats(const float* x, const float* stats, int blk_px, int rows, const float* gamma,
+                                 const float* beta, const float* residual, float* y, float* save_mean, float* save_invstd,
+                                 float* running_mean, float* running_var, long long* num_batches_tracked,
+                                 float momentum, float eps, int relu, int B, int C, long long HW, int groups,
+                                 void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 int cnuda_bn_eval_forward(const float* x, const float* gamma, const float* beta,
                           const float* running_mean, const float* running_var, const float* residual,
                           float* y, float eps, int relu, int B, int C, long long HW, cnuda_stream_t stream);

@@ -587,3 +587,59 @@ def test_tensors_of_2gib_take_the_pointer_loaders():
     assert (y_big.detach()[:, :, :63, :63] - y0[:, :, :63, :63]).abs().max().item() <= 1e-5 * y0.abs().max().item()
     del y_big, y_crop, x, gx_big
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('shape', [
+    # B, C, H, W, Co, k, stride, groups      (Co picks the row tile: 128 / 64 / 32 rows -> 64- / 64- / 32-pixel blocks)
+    (4, 32, 32, 32, 160, 3, 1, 2), (4, 32, 32, 32, 64, 3, 1, 2), (2, 16, 64, 64, 32, 3, 2, 1), (2, 64, 16, 16, 128, 1, 1, 2),
+    (1, 16, 12, 12, 48, 3, 1, 1),          # 144 pixels: a partial last tile; no whole blocks per group -> BatchNorm's own pass
+], ids=lambda s: 'B%dC%dH%dW%dCo%dk%ds%dg%d' % s)
+def test_convolution_epilogue_leaves_batchnorm_statistics(shape):
+    """conv -> train-mode BatchNorm (backends/dla.py:37-62): the GEMM's epilogue leaves sum / sum of squares per
+    (pixel block, channel) with its output (cnuda_conv2d_forward_stats) and the BatchNorm uses them instead of its own pass
+    over x (cnuda_bn_train_forward_stats).  The block sums against fp64 sums of the stored output; the normalised
+    output, saved / running statistics and every gradient against the plain path (bn_reduce_kernel<0>)."""
+    import hip_runtime as hr
+    from hip_runtime import ops
+    B, C, H, W, Co, k, st, groups = shape
+    g = torch.Generator().manual_seed(B * 131 + Co)
+    x = torch.randn(B, C, H, W, generator=g).to(DEV)
+    w = (torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5).to(DEV)
+    gamma, beta = (1 + 0.2 * torch.randn(Co, generator=g)).to(DEV), (0.1 * torch.randn(Co, generator=g)).to(DEV)
+
+    def run(emit):
+        xs, ws, ga, be = [t.clone().requires_grad_(True) for t in (x, w, gamma, beta)]
+        rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+        nbt = torch.zeros((), dtype=torch.long, device=DEV)
+        with hr.domain_groups(groups), hr.launch_log() as log:
+            y = ops.conv2d(xs, ws, None, st, k // 2, emit_stats=emit)
+            pre = getattr(y, '_cnuda_bn_stats', None)
+            out = ops.batch_norm_act(y, ga, be, rm, rv, True, relu=True, num_batches_tracked=nbt)
+        torch.manual_seed(3)
+        out.backward(torch.randn_like(out))
+        return y.detach(), pre, out.detach(), (rm, rv, nbt), [t.grad for t in (xs, ws, ga, be)], set(log.names)
+
+    y0, pre0, out0, run0, grads0, k0 = run(False)
+    y1, pre1, out1, run1, grads1, k1 = run(True)
+    assert pre0 is None and pre1 is not None
+    assert torch.equal(y0, y1)
+    stats, blk, rows = pre1
+    Ho = y1.shape[2]
+    N = B * Ho * Ho
+    flat = y1.double().permute(1, 0, 2, 3).reshape(Co, N)
+    nblk = N // blk
+    want = flat[:, :nblk * blk].reshape(Co, nblk, blk)
+    got = stats[:nblk, :Co].double()
+    scale = max(1.0, (want ** 2).sum(-1).max().item())
+    assert (got[..., 0].t() - want.sum(-1)).abs().max().item() <= 2e-6 * scale
+    assert (got[..., 1].t() - (want ** 2).sum(-1)).abs().max().item() <= 2e-6 * scale
+    whole_blocks = (N // groups) % blk == 0
+    assert any('bn_fold_stats_kernel' in n for n in k1) == whole_blocks, k1
+    assert any('bn_reduce_kernel<0>' in n for n in k1) == (not whole_blocks), k1
+    assert any('bn_reduce_kernel<0>' in n for n in k0)
+    _close(out1, out0, 2e-6)
+    for a, b in zip(run1[:2], run0[:2]):
+        _close(a, b, 2e-6)
+    assert int(run1[2]) == int(run0[2]) == groups
+    for a, b in zip(grads1, grads0):
+        _close(a, b, 1e-5)
