@@ -28,7 +28,7 @@ def _out_hw(H, W, kh, kw, sh, sw, ph, pw, dh, dw):
 
 def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w,
                    pad_h, pad_w, dilation_h, dilation_w, deformable_group, _want_columns=False, _act_slope=-1.0,
-                   _pack_token=0, _pack_version=None):
+                   _pack_token=0, _pack_version=None, _stats_box=None):
     hr.require_gpu(input, weight, bias, offset, mask)
     input, weight, bias, offset, mask = [hr.f32c(t) for t in (input, weight, bias, offset, mask)]
     B, C, H, W, Co = _shapes(input, weight, offset, mask, kernel_h, kernel_w, deformable_group)
@@ -49,13 +49,29 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
     ws = hr.workspace(nbytes, input.device)
     if deformable_group == 1 and W >= 2:
         hr.prof_arm('dcn_fwd', B, C, H, W, Co, kernel_h, kernel_w, Ho, Wo)
+    # _stats_box (private): the caller's next layer is a train-mode BatchNorm (DeformConv, backends/dla.py:351-372) -- where
+    # the kernel can, its epilogue leaves the per-channel sum / sum of squares of `out` per pixel block (appended to the box)
+    stats = None
+    if _stats_box is not None and _act_slope < 0:
+        import ctypes
+        rows = ctypes.c_int(0)
+        blk = L.cnuda_dcn_v2_stats_block(*geom, ctypes.byref(rows))
+        if blk:
+            stats = torch.empty(((B * Ho * Wo + 127) // 128 * (128 // blk), rows.value, 2), dtype=torch.float32,
+                                device=input.device)
+            _stats_box.append((stats, blk, rows.value, 0))
     # _act_slope (not part of the reference's signature): fused epilogue activation of the BatchNorm-folded
     # inference path; -1 = none = the reference's operation
     with hr.pack_stamp(_pack_token, weight, _pack_version):     # (private) identity of the weights: pack cache
-        hr.check(L.cnuda_dcn_v2_forward_act(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
-                                            hr.ptr(out), hr.ptr(cols), float(_act_slope), *geom, hr.ptr(ws),
-                                            ws.numel(), hr.stream()),
-                 'dcn_v2_forward')
+        if stats is not None:
+            hr.check(L.cnuda_dcn_v2_forward_stats(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
+                                                  hr.ptr(out), hr.ptr(cols), hr.ptr(stats), *geom, hr.ptr(ws), ws.numel(),
+                                                  hr.stream()), 'dcn_v2_forward_stats')
+        else:
+            hr.check(L.cnuda_dcn_v2_forward_act(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
+                                                hr.ptr(out), hr.ptr(cols), float(_act_slope), *geom, hr.ptr(ws),
+                                                ws.numel(), hr.stream()),
+                     'dcn_v2_forward')
     return (out, cols) if _want_columns else out
 
 

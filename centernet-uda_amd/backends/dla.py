@@ -323,6 +323,7 @@ class DeformConv(nn.Module):
         super().__init__()
         self.actf = nn.Sequential(_bn(cho))
         self.conv = DCN(chi, cho, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1)
+        self.conv.emit_stats = True       # (its only consumer is the BatchNorm above: statistics from the DCN's epilogue)
 
     _fold = None
 

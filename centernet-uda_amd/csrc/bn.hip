@@ -400,29 +400,27 @@ extern "C" int cnuda_bn_train_forward(const float* x, const float* gamma, const 
 }
 
 // The same layer with sum(x) / sum(x^2) already taken by the kernel that produced x (cnuda_conv2d_forward_stats,
-// cnuda_dcn_v2_forward_stats): `stats` = [blocks][rows][2] floats, a block = `blk_px` consecutive pixels of the flattened
-// (image, pixel) axis, channel c in row c.  The pass over x that bn_reduce_kernel<0> makes is replaced by a fold of
-// blocks * C pairs.  Every statistics group must be a whole number of blocks (returns -1 otherwise: the caller then
-// uses cnuda_bn_train_forward).
-extern "C" int cnuda_bn_train_forward_stats(const float* x, const float* stats, int blk_px, int rows, const float* gamma,
+// cnuda_dcn_v2_forward_stats): `stats` = [blocks][rows][2] floats, channel c in row c, the blocks numbered image-major;
+// statistics group g is the blocks [g, g + 1) * blocks_per_group -- the caller has checked that a group is whole blocks
+// (cnuda_conv2d_stats_block / cnuda_dcn_v2_stats_block say how a geometry is cut).  The pass over x that
+// bn_reduce_kernel<0> makes is replaced by a fold of blocks * C pairs.
+extern "C" int cnuda_bn_train_forward_stats(const float* x, const float* stats, long long blocks_per_group, int rows, const float* gamma,
                                             const float* beta, const float* residual, float* y, float* save_mean,
                                             float* save_invstd, float* running_mean, float* running_var,
                                             long long* num_batches_tracked, float momentum, float eps, int relu, int B,
                                             int C, long long HW, int groups, void* workspace, size_t workspace_bytes,
                                             cnuda_stream_t stream) {
     CNUDA_REQUIRE(x && stats && gamma && beta && y && save_mean && save_invstd, "cnuda_bn_train_forward_stats: null pointer");
-    CNUDA_REQUIRE(B > 0 && C > 0 && HW > 0 && blk_px > 0 && rows >= C, "cnuda_bn_train_forward_stats: bad geometry");
+    CNUDA_REQUIRE(B > 0 && C > 0 && HW > 0 && blocks_per_group > 0 && rows >= C, "cnuda_bn_train_forward_stats: bad geometry");
     CNUDA_REQUIRE(groups >= 1 && B % groups == 0, "cnuda_bn_train_forward_stats: batch %d not divisible into %d groups", B, groups);
     CNUDA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "cnuda_bn_train_forward_stats: running stats");
     const int Bg = B / groups;
     const long long count = (long long)Bg * HW;
     CNUDA_REQUIRE(count > 1, "Expected more than 1 value per channel when training, got input size [%d, %d, %lld]", Bg, C, HW);
-    CNUDA_REQUIRE(count % blk_px == 0, "cnuda_bn_train_forward_stats: a statistics group (%lld values per channel) is not a "
-                  "whole number of %d-pixel blocks", count, blk_px);
     CNUDA_REQUIRE(workspace && workspace_bytes >= cnuda_bn_workspace_bytes(B, C, HW),
                   "cnuda_bn_train_forward_stats: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    const long long bpg = count / blk_px;                     // blocks per group
+    const long long bpg = blocks_per_group;                   // (the caller: every group is exactly this many whole blocks)
     int spl = (int)((bpg + 255) / 256);                       // <= 256 blocks (16 per thread) per workgroup ...
     if (spl > 64) spl = 64;                                   // ... and at most 64 partials per group for the apply pass
     const int S = groups * spl;

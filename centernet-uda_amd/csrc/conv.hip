@@ -793,14 +793,18 @@ extern "C" int cnuda_conv2d_forward(const float* x, const float* weight, const f
                                     workspace, workspace_bytes, stream);
 }
 
-// Which pixel blocks a forward call of this geometry can leave BatchNorm statistics for: 0 (none: the LDS-tile and
-// halo-tile kernels, the scalar epilogue of planes that are no multiple of four pixels), else the pixels per block
-// (64 for the 64- / 128-row tiles, 32 for the 32-row tile); *rows = rows per block of the stats array.
+// Which pixel blocks a forward call of this geometry can leave BatchNorm statistics for: 0 (none: the halo-tile kernels,
+// the scalar epilogues of planes / rows that are no multiple of four pixels), else the pixels per block (64 for the 64- /
+// 128-row tiles, 32 for the 32-row tile) of the flattened (image, pixel) axis and *blocks_per_image = 0 -- or, for the
+// LDS-tile kernels of the 3- / 16-channel layers, 64 and *blocks_per_image > 0: a block is one 64-column piece of an
+// output row and never straddles images.  *rows = rows per block of the stats array.
 extern "C" int cnuda_conv2d_stats_block(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph,
-                                        int pw, int* rows) {
+                                        int pw, int* rows, int* blocks_per_image) {
     ConvGeom g;
     if (fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_stats_block")) return 0;
-    if (smallc_supported(C, Cout, kh, kw, sh, sw) || ((g.Ho * g.Wo) & 3) != 0) return 0;
+    if (blocks_per_image) *blocks_per_image = 0;
+    if (smallc_supported(C, Cout, kh, kw, sh, sw)) return smallc_stats_blocks(B, C, H, W, Cout, kh, kw, sh, ph, pw, blocks_per_image, rows);
+    if (((g.Ho * g.Wo) & 3) != 0) return 0;
     const ConvPlan q = make_plan(g);
     if (hconv_ok(g, C, q.bmf)) return 0;
     if (rows) *rows = q.Mpf;
@@ -825,12 +829,12 @@ extern "C" int cnuda_conv2d_forward_stats(const float* x, const float* weight, c
     if (stats) {
         int rows = 0;
         CNUDA_REQUIRE(!residual && act_slope < 0.0f &&
-                          cnuda_conv2d_stats_block(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, &rows) != 0,
+                          cnuda_conv2d_stats_block(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, &rows, nullptr) != 0,
                       "cnuda_conv2d_forward_stats: no statistics for this call (cnuda_conv2d_stats_block says which)");
     }
     if (!residual && smallc_supported(C, Cout, kh, kw, sh, sw))
         return smallc_forward(x, weight, bias, y, B, C, H, W, Cout, kh, kw, sh, ph, pw, act_slope, 0, workspace,
-                              workspace_bytes, (hipStream_t)stream);
+                              workspace_bytes, (hipStream_t)stream, stats);
     const ConvPlan q = make_plan(g);
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_conv2d_forward: workspace too small");
     hipStream_t st = (hipStream_t)stream;

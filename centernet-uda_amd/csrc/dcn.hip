@@ -105,6 +105,8 @@ struct DcnFwdParams {
     float act_slope;   // < 0: none; 0: ReLU fused into the epilogue (BatchNorm-folded inference, DeformConv dla.py:369-372)
     float* out;
     float* col;   // optional [B][T*C][Ho*Wo] side output (rows in (tap, channel) order) for the weight gradient
+    float* stats; // optional BatchNorm statistics of `out` per (pixel block, output channel): igemm.cuh, "BatchNorm statistics"
+    int stats_mp; // rows per pixel block of `stats`
 };
 
 // BUF: the corner loads and the column stores go through buffer descriptors (igemm.cuh, "Buffer addressing"): the
@@ -362,6 +364,7 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcnw_fwd_kernel(DcnFwdParams p,
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // tile -> (image, tile row, tile column)
     int tile = xcd_remap(blockIdx.x, n_tiles);
+    const int tile_id = tile;                                          // (image-major: the statistics blocks' order)
     const int tx = tile % tiles_x; tile /= tiles_x;
     const int tiles_y = H / Q::TR;
     const int ty = tile % tiles_y, b = tile / tiles_y;
@@ -610,6 +613,22 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcnw_fwd_kernel(DcnFwdParams p,
                 }
                 *reinterpret_cast<f32x4*>(obase + (size_t)m * HW) = v4;
             }
+            if (p.stats) {
+                // BatchNorm statistics of what was stored (igemm.cuh, "BatchNorm statistics"): this wave's 32 pixels are one
+                // block; the row's eight lanes meet through two quad permutes and a half-row mirror
+                float s1 = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+                float s2 = (v4[0] * v4[0] + v4[1] * v4[1]) + (v4[2] * v4[2] + v4[3] * v4[3]);
+                auto row8 = [](float v) {
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+                    return v;
+                };
+                s1 = row8(s1);
+                s2 = row8(s2);
+                if (cg == 0)
+                    reinterpret_cast<float2*>(p.stats)[((size_t)tile_id * 4 + wid) * p.stats_mp + m] = make_float2(s1, s2);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -661,6 +680,8 @@ struct DcnColsParams {
     const float *col, *bias;
     float act_slope;
     float* out;
+    float* stats;  // (as DcnFwdParams)
+    int stats_mp;
 };
 struct DcnColsLoader {
     using Params = DcnColsParams;
@@ -1575,11 +1596,62 @@ extern "C" int cnuda_dcn_v2_forward_cols(const float* input, const float* weight
                                     sh, sw, ph, pw, dh, dw, dg, workspace, workspace_bytes, stream);
 }
 
+namespace {
+// the LDS-window kernel's layers: 3x3 / stride 1 / padding 1 / dilation 1 on maps 16..128 wide, one M tile.  CNUDA_DCNW=0
+// keeps the gathering loader (A/B measurements; tests/test_gpu_kernel_switches.py).
+bool dcnw_takes(const DcnGeom& g) {
+    static const bool dcnw_on = !(getenv("CNUDA_DCNW") && getenv("CNUDA_DCNW")[0] == '0');
+    return dcnw_on && matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
+           g.dh == 1 && g.dw == 1 && g.dg == 1 && g.C % 16 == 0 && g.Co <= 64 &&
+           (g.W == 16 || g.W == 32 || g.W == 64 || g.W == 128) && g.H % (IG_BN / (g.W >= 32 ? 32 : g.W)) == 0 &&
+           (size_t)g.B * g.C * g.H * g.W * sizeof(float) < IG_BUF_OOB;
+}
+}  // namespace
+
+// Pixel blocks of the BatchNorm statistics a forward call of this geometry can leave (cnuda_dcn_v2_forward_stats): 0 none
+// (deformable_group > 1, width 1, planes that are no multiple of four pixels), else pixels per block; *rows = rows per block.
+extern "C" int cnuda_dcn_v2_stats_block(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                                        int dh, int dw, int dg, int* rows) {
+    DcnGeom g;
+    if (fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, "cnuda_dcn_v2_stats_block")) return 0;
+    if (dg != 1 || W < 2 || ((g.Ho * g.Wo) & 3) != 0) return 0;
+    if (dcnw_takes(g)) { if (rows) *rows = 64; return 32; }
+    const DcnPlan q = make_plan(g);
+    if (rows) *rows = q.Mp;
+    return q.bm == 32 ? 32 : 64;
+}
+
+static int dcn_forward_impl(const float* input, const float* weight, const float* bias, const float* offset,
+                            const float* mask, float* output, float* columns, float* stats, float act_slope, int B, int C,
+                            int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg,
+                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+
 extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight, const float* bias,
                                         const float* offset, const float* mask, float* output, float* columns,
                                         float act_slope, int B, int C, int H, int W, int Cout, int kh, int kw, int sh,
                                         int sw, int ph, int pw, int dh, int dw, int dg, void* workspace,
                                         size_t workspace_bytes, cnuda_stream_t stream) {
+    return dcn_forward_impl(input, weight, bias, offset, mask, output, columns, nullptr, act_slope, B, C, H, W, Cout, kh, kw,
+                            sh, sw, ph, pw, dh, dw, dg, workspace, workspace_bytes, stream);
+}
+
+// forward (+ saved columns) that also leaves the BatchNorm statistics of the output: DeformConv = DCN + BatchNorm + ReLU
+// (backends/dla.py:351-372).  stats as cnuda_conv2d_forward_stats; cnuda_dcn_v2_stats_block says block size and rows.
+extern "C" int cnuda_dcn_v2_forward_stats(const float* input, const float* weight, const float* bias,
+                                          const float* offset, const float* mask, float* output, float* columns,
+                                          float* stats, int B, int C, int H, int W, int Cout, int kh, int kw, int sh,
+                                          int sw, int ph, int pw, int dh, int dw, int dg, void* workspace,
+                                          size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(!stats || cnuda_dcn_v2_stats_block(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, nullptr) != 0,
+                  "cnuda_dcn_v2_forward_stats: no statistics for this call (cnuda_dcn_v2_stats_block says which)");
+    return dcn_forward_impl(input, weight, bias, offset, mask, output, columns, stats, -1.0f, B, C, H, W, Cout, kh, kw, sh,
+                            sw, ph, pw, dh, dw, dg, workspace, workspace_bytes, stream);
+}
+
+static int dcn_forward_impl(const float* input, const float* weight, const float* bias, const float* offset,
+                            const float* mask, float* output, float* columns, float* stats, float act_slope, int B, int C,
+                            int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg,
+                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
     CNUDA_REQUIRE(input && weight && bias && offset && mask && output, "cnuda_dcn_v2_forward: null pointer");
     CNUDA_REQUIRE(!columns || (dg == 1 && W >= 2),
                   "cnuda_dcn_v2_forward_cols: columns output needs deformable_group == 1 and width >= 2");
@@ -1597,16 +1669,11 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
     CNUDA_REQUIRE(q.N < (1ll << 31) - IG_BN, "cnuda_dcn_v2_forward: more than 2^31 pixels per call");
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_dcn_v2_forward: workspace too small");
     Carver cv(workspace, workspace_bytes);
-    // the LDS-window kernel: 3x3 / stride 1 / padding 1 / dilation 1 on maps 16..128 wide, one M tile.  CNUDA_DCNW=0
-    // keeps the gathering loader (A/B measurements; tests/test_gpu_kernel_switches.py).
-    static const bool dcnw_on = !(getenv("CNUDA_DCNW") && getenv("CNUDA_DCNW")[0] == '0');
-    if (dcnw_on && matrix_mode() == 0 && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 &&
-        dw == 1 && C % 16 == 0 && Cout <= 64 && (W == 16 || W == 32 || W == 64 || W == 128) &&
-        H % (IG_BN / (W >= 32 ? 32 : W)) == 0 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB) {
+    if (dcnw_takes(g)) {
         const int bm = 64;
         const float* Aw = launch_pack(weight, cv.take<float>((size_t)q.Kp * bm), (size_t)q.Kp * bm * sizeof(float), Cout, C,
                                       q.T, PACK_HALO_FWD, q.Kp, bm, 0, st);
-        DcnFwdParams p{g, input, offset, mask, bias, act_slope, output, columns};
+        DcnFwdParams p{g, input, offset, mask, bias, act_slope, output, columns, stats, 64};
         ProfScope prof(st);
         prof.name("dcnw_fwd_kernel<%d>%s", bm, columns ? " (+ column side output)" : "");
         const int tc = W >= 32 ? 32 : W, tiles_x = W / tc, n_tiles = (int)(q.N / IG_BN);
@@ -1645,7 +1712,7 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
             const int tiles = ceil_div(g.Ho * g.Wo, 64), tw = q.T < 16 ? q.T : 16;
             CNUDA_LAUNCH(dcn_sample_kernel, dim3(B * tiles), dim3(64, tw), 0, st, sp, tiles);
         }
-        DcnColsParams p{g, cols, bias, act_slope, output};
+        DcnColsParams p{g, cols, bias, act_slope, output, stats, q.Mp};
         if (buf && q.bm == 128)
             CNUDA_LAUNCH((igemm_fwd_kernel<128, DcnColsBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                                n_tiles, m_tiles);
@@ -1666,7 +1733,7 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
                                n_tiles, m_tiles);
         return check_launch("cnuda_dcn_v2_forward(columns + GEMM)");
     }
-    DcnFwdParams p{g, input, offset, mask, bias, act_slope, output, columns};
+    DcnFwdParams p{g, input, offset, mask, bias, act_slope, output, columns, stats, q.Mp};
     ProfScope prof(st);
     prof.name("igemm_fwd_kernel<%d, DcnFwdLoader>%s", q.bm, columns ? " (+ column side output)" : "");
     if (buf && q.bm == 128)

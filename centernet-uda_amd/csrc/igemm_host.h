@@ -56,7 +56,9 @@ bool smallc_supported(int C, int Co, int kh, int kw, int sh, int sw);
 size_t smallc_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int s, int ph, int pw);
 int smallc_forward(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W, int Co,
                    int kh, int kw, int s, int ph, int pw, float act_slope, int transposed, void* ws, size_t ws_bytes,
-                   hipStream_t st);
+                   hipStream_t st, float* stats = nullptr);
+int smallc_stats_blocks(int B, int C, int H, int W, int Co, int kh, int kw, int s, int ph, int pw, int* blocks_per_image,
+                        int* rows);
 int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, int C, int H, int W, int Co, int kh,
                            int kw, int s, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t st);
 

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void smallc_fwd_kernel(SmallGeom g, 
                                                                const float* __restrict__ Wp,
                                                                const int* __restrict__ koff_tab,
                                                                const float* __restrict__ bias, float* __restrict__ y,
-                                                               float act_slope) {
+                                                               float act_slope, float* __restrict__ stats) {
     extern __shared__ __align__(16) float smem[];
     float* Xh = smem;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -229,6 +229,26 @@ __global__ __launch_bounds__(IG_THREADS, 2) void smallc_fwd_kernel(SmallGeom g, 
                         for (int e = 0; e < 4; ++e) if (v[e] < 0.0f) v[e] *= act_slope;
                     }
                     *reinterpret_cast<f32x4*>(yb + (size_t)o * HoWo + ox) = v;
+                }
+                if (stats) {
+                    // BatchNorm statistics of what was stored (igemm.cuh, "BatchNorm statistics"): the wave's row segment
+                    // (<= 64 pixels of output row oy) is one block, numbered (image, row, column tile); the 16 lanes of an
+                    // output channel meet through two quad permutes, a half-row and a row mirror
+                    if (!(o < g.Co && ox < g.Wo)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                    float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    auto row16 = [](float t) {
+                        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xf, 0xf, false));
+                        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xf, 0xf, false));
+                        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xf, 0xf, false));
+                        t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x140, 0xf, 0xf, false));
+                        return t;
+                    };
+                    s1 = row16(s1);
+                    s2 = row16(s2);
+                    if (c4 == 0)
+                        reinterpret_cast<float2*>(stats)[(((size_t)b * g.Ho + oy) * gridDim.x + blockIdx.x) * (16 * MT) + o] =
+                            make_float2(s1, s2);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // reads done before the next tile's staging
@@ -435,9 +455,21 @@ size_t smallc_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw
            carve_bytes((size_t)SC_RED_GROUPS * 16 * mt * Kp16, 4) + 512;
 }
 
+// BatchNorm statistics of a forward call (stats argument of smallc_forward): one block per (image, output row, 64-column
+// tile) -- *blocks_per_image of them, *rows channels each; 0 when the scalar epilogue would run (Wo % 4 != 0)
+int smallc_stats_blocks(int B, int C, int H, int W, int Co, int kh, int kw, int s, int ph, int pw, int* blocks_per_image,
+                        int* rows) {
+    SmallGeom g;
+    fill_small(g, B, C, H, W, Co, kh, kw, s, ph, pw);
+    if ((g.Wo & 3) != 0) return 0;
+    if (blocks_per_image) *blocks_per_image = g.Ho * ceil_div(g.Wo, SC_TW);
+    if (rows) *rows = 16 * ((Co + 15) / 16);
+    return SC_TW;
+}
+
 int smallc_forward(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W, int Co,
                    int kh, int kw, int s, int ph, int pw, float act_slope, int transposed, void* ws, size_t ws_bytes,
-                   hipStream_t st) {
+                   hipStream_t st, float* stats) {
     // transposed: computes the stride-1 input gradient: x := grad_y [B, Co_orig, H, W], w is the ORIGINAL
     // weight [Co_orig = C here][C_orig = Co here][kh][kw]; the caller passes C/Co already swapped.
     SmallGeom g;
@@ -460,9 +492,9 @@ int smallc_forward(const float* x, const float* w, const float* bias, float* y, 
     ProfScope prof(st);
     prof.name("smallc_fwd_kernel<%d>", mt);
     if (mt == 1)
-        CNUDA_LAUNCH(smallc_fwd_kernel<1>, grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope);
+        CNUDA_LAUNCH(smallc_fwd_kernel<1>, grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope, stats);
     else
-        CNUDA_LAUNCH(smallc_fwd_kernel<2>, grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope);
+        CNUDA_LAUNCH(smallc_fwd_kernel<2>, grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope, stats);
     return check_launch("smallc_forward");
 }
 

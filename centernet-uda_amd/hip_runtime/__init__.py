@@ -67,6 +67,8 @@ class _Sig:
     cnuda_dcn_v2_backward = (_I, [_P] * 11 + [_I] * 14 + _WS)
     cnuda_dcn_v2_forward_cols = (_I, [_P] * 7 + [_I] * 14 + _WS)
     cnuda_dcn_v2_forward_act = (_I, [_P] * 7 + [_F] + [_I] * 14 + _WS)
+    cnuda_dcn_v2_forward_stats = (_I, [_P] * 8 + [_I] * 14 + _WS)
+    cnuda_dcn_v2_stats_block = (_I, [_I] * 14 + [_P])
     cnuda_dcn_v2_backward_cols = (_I, [_P] * 12 + [_I] * 14 + _WS)
     cnuda_dcn_v2_backward_acc = (_I, [_P] * 8 + [_I] + [_P] * 4 + [_I] * 14 + _WS)
     cnuda_conv2d_workspace_bytes = (c_size_t, [_I] * 11)
@@ -74,9 +76,9 @@ class _Sig:
     cnuda_conv2d_forward_res = (_I, [_P] * 5 + [_I] * 11 + [_F] + _WS)
     cnuda_conv2d_backward_data = (_I, [_P] * 3 + [_I] * 11 + _WS)
     cnuda_conv2d_backward_data_add = (_I, [_P] * 5 + [_I] * 11 + _WS)
-    cnuda_conv2d_stats_block = (_I, [_I] * 11 + [_P])
+    cnuda_conv2d_stats_block = (_I, [_I] * 11 + [_P, _P])
     cnuda_conv2d_forward_stats = (_I, [_P] * 6 + [_I] * 11 + [_F] + _WS)
-    cnuda_bn_train_forward_stats = (_I, [_P, _P, _I, _I] + [_P] * 9 + [_F, _F, _I, _I, _I, _LL, _I] + _WS)
+    cnuda_bn_train_forward_stats = (_I, [_P, _P, _LL, _I] + [_P] * 9 + [_F, _F, _I, _I, _I, _LL, _I] + _WS)
     cnuda_conv2d_backward_weight = (_I, [_P] * 4 + [_I] * 11 + _WS)
     cnuda_bn_workspace_bytes = (c_size_t, [_I, _I, _LL])
     cnuda_bn_train_forward = (_I, [_P] * 10 + [_F, _F, _I, _I, _I, _LL, _I] + _WS)

@@ -62,12 +62,13 @@ class _Conv2d(Function):
         if stats_box is not None and act_slope < 0:
             # BatchNorm statistics of y from the GEMM's epilogue, where this geometry's kernel can give them
             import ctypes
-            rows = ctypes.c_int(0)
-            blk = L.cnuda_conv2d_stats_block(*g, ctypes.byref(rows))
+            rows, bpi = ctypes.c_int(0), ctypes.c_int(0)
+            blk = L.cnuda_conv2d_stats_block(*g, ctypes.byref(rows), ctypes.byref(bpi))
             if blk:
-                nblk = (B * Ho * Wo + 127) // 128 * (128 // blk)
+                # (stats, pixels per block on the flattened (image, pixel) axis -- or 0 --, rows, blocks per image -- or 0)
+                nblk = B * bpi.value if bpi.value else (B * Ho * Wo + 127) // 128 * (128 // blk)
                 stats = torch.empty((nblk, rows.value, 2), dtype=torch.float32, device=x.device)
-                stats_box.append((stats, blk, rows.value))
+                stats_box.append((stats, 0 if bpi.value else blk, rows.value, bpi.value))
         prof_arm('conv_fwd', B, C, H, W, Co, kh, kw, Ho, Wo)
         with pack_stamp(pack_token, weight):
             if stats is None:
@@ -350,9 +351,16 @@ class _BatchNormAct(Function):
         invstd = torch.empty(groups * C, dtype=torch.float32, device=x.device)
         L = lib()
         wp, wn = _ws(L.cnuda_bn_workspace_bytes(B, C, HW), x)
-        if pre is not None and (B // groups * HW) % pre[1] == 0 and pre[2] >= C:
+        bpg = 0
+        if pre is not None and pre[2] >= C:
+            # blocks per statistics group: whole images' worth of row pieces, or whole blocks of the flattened pixel axis
+            if pre[3]:
+                bpg = B // groups * pre[3]
+            elif (B // groups * HW) % pre[1] == 0:
+                bpg = B // groups * HW // pre[1]
+        if bpg:
             # sum(x) / sum(x^2) came with x from the producing GEMM's epilogue: no statistics pass over x
-            check(L.cnuda_bn_train_forward_stats(ptr(x), ptr(pre[0]), pre[1], pre[2], ptr(gamma), ptr(beta), ptr(residual),
+            check(L.cnuda_bn_train_forward_stats(ptr(x), ptr(pre[0]), bpg, pre[2], ptr(gamma), ptr(beta), ptr(residual),
                                                  ptr(y), ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var),
                                                  ptr(num_batches_tracked), float(momentum), float(eps), _act_code(relu),
                                                  B, C, HW, groups, wp, wn, stream()), 'bn_train_forward_stats')

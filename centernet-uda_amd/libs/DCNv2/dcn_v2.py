@@ -27,7 +27,8 @@ def _pair(v):
 class _DeformConvFn(torch.autograd.Function):
     # autograd-visible argument order (dcn_v2.py:18-19): input, offset, mask, weight, bias, ...
     @staticmethod
-    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token=0):
+    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token=0,
+                stats_box=None):
         kh, kw = weight.shape[2], weight.shape[3]
         from hip_runtime.fanout import slot_of
         ctx.slot = slot_of(input)      # where the offset convolution (the input's other consumer) meets this gradient
@@ -37,10 +38,10 @@ class _DeformConvFn(torch.autograd.Function):
         keep = deformable_groups == 1 and input.shape[3] >= 2 and any(ctx.needs_input_grad[:5]) and _KEEP_COLUMNS
         if keep:
             out, cols = _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geom, _want_columns=True,
-                                                _pack_token=pack_token)
+                                                _pack_token=pack_token, _stats_box=stats_box)
         else:
             out, cols = _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geom,
-                                                _pack_token=pack_token), None
+                                                _pack_token=pack_token, _stats_box=stats_box), None
         ctx.save_for_backward(input, offset, mask, weight, bias, cols)
         return out
 
@@ -63,10 +64,21 @@ class _DeformConvFn(torch.autograd.Function):
         else:
             slot.included.append(acc)
         return g_in, g_off, g_mask, (None if sw is not None else g_w), (None if sb is not None else g_b), \
-            None, None, None, None, None
+            None, None, None, None, None, None
 
 
-dcn_v2_conv = _DeformConvFn.apply
+def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token=0,
+                emit_stats=False):
+    """emit_stats (not part of the reference's signature): the output goes straight into a train-mode BatchNorm -- the
+    kernel's epilogue then leaves the statistics with it (hip_runtime.ops.batch_norm_act finds them on the tensor)."""
+    from hip_runtime import ops
+    if not (emit_stats and ops.EPILOGUE_STATS):
+        return _DeformConvFn.apply(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token)
+    box = []
+    out = _DeformConvFn.apply(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token, box)
+    if box:
+        out._cnuda_bn_stats = box[0]
+    return out
 
 
 class DCNv2(nn.Module):
@@ -107,6 +119,7 @@ class DCN(DCNv2):
         taps = self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]
         self.conv_offset_mask = hnn.Conv2d(in_channels, 3 * taps, self.kernel_size, self.stride,
                                            self.padding, bias=True)
+        self.emit_stats = False      # set by a caller whose next layer is a BatchNorm2d (backends.dla.DeformConv)
         with torch.no_grad():        # zero init: offsets 0, mask sigmoid(0)=0.5 (dcn_v2.py:114-116, Q7)
             self.conv_offset_mask.weight.zero_()
             self.conv_offset_mask.bias.zero_()
@@ -121,4 +134,5 @@ class DCN(DCNv2):
         # [2*taps, 3*taps) the mask logits
         offset, mask = ops.split_offset_mask(om)
         return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding,
-                           self.dilation, self.deformable_groups, self._pack_token)
+                           self.dilation, self.deformable_groups, self._pack_token,
+                           emit_stats=self.emit_stats and self.training)

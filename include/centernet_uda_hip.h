@@ -183,6 +183,15 @@ int cnuda_dcn_v2_forward_act(const float* input, const float* weight, const floa
                              int B, int C, int H, int W, int Cout, int kh, int kw,
                              int sh, int sw, int ph, int pw, int dh, int dw, int dg,
                              void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+/* forward (+ saved columns) that also leaves the BatchNorm statistics of the output, as cnuda_conv2d_forward_stats does:
+ * DeformConv = DCN + BatchNorm + ReLU (backends/dla.py:351-372).  cnuda_dcn_v2_stats_block: 0 = none for this geometry,
+ * else pixels per block (blocks are numbered image-major and never straddle images), *rows = rows per block. */
+int cnuda_dcn_v2_stats_block(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                             int dh, int dw, int dg, int* rows);
+int cnuda_dcn_v2_forward_stats(const float* input, const float* weight, const float* bias, const float* offset,
+                               const float* mask, float* output, float* columns, float* stats,
+                               int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                               int dh, int dw, int dg, void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 
 /* Same two operations with the sampled column buffer kept between them (the
  * product's autograd path; deformable_group == 1 only): forward_cols stores
@@ -249,7 +258,9 @@ int cnuda_conv2d_forward_res(const float* x, const float* weight, const float* b
  * block pixels).  cnuda_conv2d_stats_block returns 0 where this geometry's kernel cannot give them (then pass stats =
  * NULL and use cnuda_bn_train_forward), else the block size, and *rows.  Needs residual == NULL and act_slope < 0.
  * cnuda_bn_train_forward_stats (below) consumes them. */
-int cnuda_conv2d_stats_block(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int* rows);
+int cnuda_conv2d_stats_block(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int* rows,
+                             int* blocks_per_image /* > 0: blocks are pieces of output rows, this many per image (the 3- / 16-
+                                                      channel layers' kernels) and `stats` holds B * blocks_per_image of them */);
 int cnuda_conv2d_forward_stats(const float* x, const float* weight, const float* bias, const float* residual, float* y,
                                float* stats, int B, int C, int H, int W, int Cout, int kh, int kw,
                                int sh, int sw, int ph, int pw, float act_slope,
@@ -295,9 +306,10 @@ int cnuda_bn_train_forward(const float* x, const float* gamma, const float* beta
                                          the concatenated source | target batch equals the reference's two forward
                                          calls (uda/entropy_minimization.py:18-19) */,
                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
-/* train_forward with sum(x) / sum(x^2) supplied by the kernel that produced x (cnuda_conv2d_forward_stats): no statistics
- * pass over x.  stats [blocks][rows][2], block = blk_px pixels; every statistics group must be whole blocks (-1 otherwise). */
-int cnuda_bn_train_forward_stats(const float* x, const float* stats, int blk_px, int rows, const float* gamma,
+/* train_forward with sum(x) / sum(x^2) supplied by the kernel that produced x (cnuda_conv2d_forward_stats,
+ * cnuda_dcn_v2_forward_stats): no statistics pass over x.  stats [blocks][rows][2], blocks numbered image-major; group g =
+ * blocks [g, g + 1) * blocks_per_group (the caller checks that a statistics group is whole blocks). */
+int cnuda_bn_train_forward_stats(const float* x, const float* stats, long long blocks_per_group, int rows, const float* gamma,
                                  const float* beta, const float* residual, float* y, float* save_mean, float* save_invstd,
                                  float* running_mean, float* running_var, long long* num_batches_tracked,
                                  float momentum, float eps, int relu, int B, int C, long long HW, int groups,

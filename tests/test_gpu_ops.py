@@ -593,6 +593,8 @@ def test_tensors_of_2gib_take_the_pointer_loaders():
     # B, C, H, W, Co, k, stride, groups      (Co picks the row tile: 128 / 64 / 32 rows -> 64- / 64- / 32-pixel blocks)
     (4, 32, 32, 32, 160, 3, 1, 2), (4, 32, 32, 32, 64, 3, 1, 2), (2, 16, 64, 64, 32, 3, 2, 1), (2, 64, 16, 16, 128, 1, 1, 2),
     (1, 16, 12, 12, 48, 3, 1, 1),          # 144 pixels: a partial last tile; no whole blocks per group -> BatchNorm's own pass
+    # the LDS-tile kernels of the 3- / 16-channel full-resolution layers: a block = a 64-column piece of an output row
+    (2, 3, 24, 72, 16, 7, 1, 2), (2, 16, 20, 64, 16, 3, 1, 1),
 ], ids=lambda s: 'B%dC%dH%dW%dCo%dk%ds%dg%d' % s)
 def test_convolution_epilogue_leaves_batchnorm_statistics(shape):
     """conv -> train-mode BatchNorm (backends/dla.py:37-62): the GEMM's epilogue leaves sum / sum of squares per
@@ -602,7 +604,7 @@ def test_convolution_epilogue_leaves_batchnorm_statistics(shape):
     import hip_runtime as hr
     from hip_runtime import ops
     B, C, H, W, Co, k, st, groups = shape
-    g = torch.Generator().manual_seed(B * 131 + Co)
+    g = torch.Generator().manual_seed(B * 131 + Co + C)
     x = torch.randn(B, C, H, W, generator=g).to(DEV)
     w = (torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5).to(DEV)
     gamma, beta = (1 + 0.2 * torch.randn(Co, generator=g)).to(DEV), (0.1 * torch.randn(Co, generator=g)).to(DEV)
@@ -623,17 +625,28 @@ def test_convolution_epilogue_leaves_batchnorm_statistics(shape):
     y1, pre1, out1, run1, grads1, k1 = run(True)
     assert pre0 is None and pre1 is not None
     assert torch.equal(y0, y1)
-    stats, blk, rows = pre1
-    Ho = y1.shape[2]
-    N = B * Ho * Ho
+    stats, blk, rows, bpi = pre1
+    Ho, Wo = y1.shape[2], y1.shape[3]
+    N = B * Ho * Wo
     flat = y1.double().permute(1, 0, 2, 3).reshape(Co, N)
-    nblk = N // blk
-    want = flat[:, :nblk * blk].reshape(Co, nblk, blk)
-    got = stats[:nblk, :Co].double()
-    scale = max(1.0, (want ** 2).sum(-1).max().item())
-    assert (got[..., 0].t() - want.sum(-1)).abs().max().item() <= 2e-6 * scale
-    assert (got[..., 1].t() - (want ** 2).sum(-1)).abs().max().item() <= 2e-6 * scale
-    whole_blocks = (N // groups) % blk == 0
+    if bpi:                                 # row pieces (image, row, 64-column tile): per block against the tensor's rows
+        tiles_x = (Wo + 63) // 64
+        assert bpi == Ho * tiles_x and stats.shape[0] == B * bpi
+        got = stats[:, :Co].double().reshape(B, Ho, tiles_x, Co, 2)
+        for tx in range(tiles_x):
+            piece = y1.double()[:, :, :, tx * 64:(tx + 1) * 64]                       # [B, Co, Ho, <= 64]
+            scale = max(1.0, (piece ** 2).sum(-1).max().item())
+            assert (got[:, :, tx, :, 0] - piece.sum(-1).permute(0, 2, 1)).abs().max().item() <= 2e-6 * scale
+            assert (got[:, :, tx, :, 1] - (piece ** 2).sum(-1).permute(0, 2, 1)).abs().max().item() <= 2e-6 * scale
+        whole_blocks = True
+    else:
+        nblk = N // blk
+        want = flat[:, :nblk * blk].reshape(Co, nblk, blk)
+        got = stats[:nblk, :Co].double()
+        scale = max(1.0, (want ** 2).sum(-1).max().item())
+        assert (got[..., 0].t() - want.sum(-1)).abs().max().item() <= 2e-6 * scale
+        assert (got[..., 1].t() - (want ** 2).sum(-1)).abs().max().item() <= 2e-6 * scale
+        whole_blocks = (N // groups) % blk == 0
     assert any('bn_fold_stats_kernel' in n for n in k1) == whole_blocks, k1
     assert any('bn_reduce_kernel<0>' in n for n in k1) == (not whole_blocks), k1
     assert any('bn_reduce_kernel<0>' in n for n in k0)
@@ -641,5 +654,55 @@ def test_convolution_epilogue_leaves_batchnorm_statistics(shape):
     for a, b in zip(run1[:2], run0[:2]):
         _close(a, b, 2e-6)
     assert int(run1[2]) == int(run0[2]) == groups
+    for a, b in zip(grads1, grads0):
+        _close(a, b, 1e-5)
+
+
+@pytest.mark.parametrize('shape', [(4, 32, 32, 32, 32, 2), (2, 64, 16, 16, 128, 2), (4, 16, 24, 24, 160, 1)],
+                         ids=lambda s: 'B%dC%dH%dW%dCo%dg%d' % s)
+def test_deformable_convolution_epilogue_leaves_batchnorm_statistics(shape):
+    """DeformConv = DCN + BatchNorm + ReLU (backends/dla.py:351-372): the DCN forward's epilogue -- the LDS-window kernel's
+    (<= 64 outputs on a 16..128 wide map: one block per wave's 32 pixels, tiles numbered image-major) and the implicit
+    GEMM's -- leaves the statistics; outputs, statistics buffers and gradients against the plain path."""
+    import hip_runtime as hr
+    from hip_runtime import ops
+    from libs.DCNv2.dcn_v2 import DCN
+    B, C, H, W, Co, groups = shape
+    torch.manual_seed(B * 17 + Co)
+    m = DCN(C, Co, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(DEV)
+    with torch.no_grad():
+        m.conv_offset_mask.weight.normal_(0, 0.05)
+        m.bias.normal_(0, 0.1)
+    gamma, beta = (1 + 0.2 * torch.randn(Co)).to(DEV), (0.1 * torch.randn(Co)).to(DEV)
+    x = torch.randn(B, C, H, W).to(DEV)
+
+    def run(emit):
+        m.emit_stats = emit
+        m.zero_grad()
+        xs, ga, be = [t.clone().requires_grad_(True) for t in (x, gamma, beta)]
+        rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+        with hr.domain_groups(groups), hr.launch_log() as log:
+            y = m(xs)
+            pre = getattr(y, '_cnuda_bn_stats', None)
+            out = ops.batch_norm_act(y, ga, be, rm, rv, True, relu=True)
+        torch.manual_seed(3)
+        out.backward(torch.randn_like(out))
+        return y.detach(), pre, out.detach(), (rm, rv), [xs.grad, ga.grad, be.grad, m.weight.grad.clone()], set(log.names)
+
+    y0, pre0, out0, run0, grads0, k0 = run(False)
+    y1, pre1, out1, run1, grads1, k1 = run(True)
+    assert pre0 is None and pre1 is not None and torch.equal(y0, y1)
+    stats, blk, rows, _ = pre1
+    assert stats.shape[0] * blk == B * H * W and rows >= Co
+    tot = stats[:, :Co].double().sum(0)                       # whole-batch sums: independent of the blocks' pixel order
+    flat = y1.double().permute(1, 0, 2, 3).reshape(Co, -1)
+    scale = max(1.0, (flat ** 2).sum(-1).max().item())
+    assert (tot[:, 0] - flat.sum(-1)).abs().max().item() <= 2e-6 * scale
+    assert (tot[:, 1] - (flat ** 2).sum(-1)).abs().max().item() <= 2e-6 * scale
+    assert any('bn_fold_stats_kernel' in n for n in k1) and not any('bn_reduce_kernel<0>' in n for n in k1), k1
+    assert any('bn_reduce_kernel<0>' in n for n in k0)
+    _close(out1, out0, 2e-6)
+    for a, b in zip(run1, run0):
+        _close(a, b, 2e-6)
     for a, b in zip(grads1, grads0):
         _close(a, b, 1e-5)
