@@ -381,6 +381,9 @@ def set_dcn_offset_std(plugin, batch, std_px, passes=3):
                 m.bias[:18].zero_()
     import hip_runtime as hr
     hr.bump_param_epoch()               # (parameters written behind the library's back: cached packed weights follow)
+    for m in getattr(plugin.backend, 'module', plugin.backend).modules():
+        if hasattr(m, '_census_calls'):
+            m._census_calls = 0         # the layers re-measure their offset regime at their next training forward
     return measure_dcn_offsets(plugin, batch)
 
 

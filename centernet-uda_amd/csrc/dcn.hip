@@ -864,13 +864,13 @@ __global__ __launch_bounds__(1024) void dcn_coord_grad_kernel(DcnCoordParams p, 
 }
 
 constexpr int CI_CG = 16;        // channels per workgroup (4 per wave)
-constexpr int CI_MARGIN = 2;     // window rows / columns beyond the undeformed footprint
+constexpr int CI_MARGIN = 2;     // window rows / columns beyond the undeformed footprint (default; DcnPlan::margin is what runs)
 struct DcnCol2imParams {
     DcnGeom g;
     const float* dcol;
     const DcnGeo* geo;
     float* gin;
-    int TR, TC, tc_shift, tiles_y, tiles_x, ncg, WSZmax, claim_sz;
+    int TR, TC, tc_shift, tiles_y, tiles_x, ncg, WSZmax, claim_sz, margin;
 };
 // The col2im walk of ONE wave over ONE 16-channel group of a TR x TC pixel tile (256 pixels): the wave owns
 // channel planes c_w..c_w+3 of the LDS window ([cell][4 channels]: the four channels of a cell are ONE 16-byte
@@ -898,11 +898,11 @@ struct DcnScatterCtx {
     float4* dump;                             // a private cell for inactive lanes
     lds_vu8* claim;                           // this wave's claim map [WSZ]
 };
-__device__ __forceinline__ void dcn_scatter_window(DcnScatterCtx& x, const DcnGeom& g, int TR, int WSZmax) {
-    x.wy0 = x.y0 * g.sh - g.ph - CI_MARGIN;
-    x.wx0 = x.x0 * g.sw - g.pw - CI_MARGIN;
-    x.WR = WSZmax ? (TR - 1) * g.sh + (g.kh - 1) * g.dh + 2 * CI_MARGIN + 1 : 0;
-    x.WC = WSZmax ? (x.TC - 1) * g.sw + (g.kw - 1) * g.dw + 2 * CI_MARGIN + 1 : 0;
+__device__ __forceinline__ void dcn_scatter_window(DcnScatterCtx& x, const DcnGeom& g, int TR, int WSZmax, int margin) {
+    x.wy0 = x.y0 * g.sh - g.ph - margin;
+    x.wx0 = x.x0 * g.sw - g.pw - margin;
+    x.WR = WSZmax ? (TR - 1) * g.sh + (g.kh - 1) * g.dh + 2 * margin + 1 : 0;
+    x.WC = WSZmax ? (x.TC - 1) * g.sw + (g.kw - 1) * g.dw + 2 * margin + 1 : 0;
     x.WSZ = x.WR * x.WC;                       // == WSZmax (or 0: the window does not fit the LDS)
 }
 __device__ __forceinline__ void dcn_scatter_group(const DcnScatterCtx& x, const DcnGeom& g, const DcnGeo* __restrict__ geo_b,
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int 
     const int b = id / p.tiles_y;
     DcnScatterCtx x;
     x.y0 = ty * p.TR; x.x0 = tx * p.TC; x.TC = p.TC; x.tc_shift = p.tc_shift;
-    dcn_scatter_window(x, g, p.TR, p.WSZmax);
+    dcn_scatter_window(x, g, p.TR, p.WSZmax, p.margin);
     x.wp = reinterpret_cast<float4*>(win) + (size_t)wid * x.WSZ;
     x.dump = reinterpret_cast<float4*>(win + CI_CG * p.WSZmax) + tid;
     x.claim = (lds_vu8*)(reinterpret_cast<unsigned char*>(win + CI_CG * p.WSZmax + 4 * 256) + wid * p.claim_sz);
@@ -1132,7 +1132,7 @@ struct DcnBwdDataParams {
     const float *in, *dcol;
     const DcnGeo* geo;
     float *gin, *goff, *gmask;
-    int TR, TC, tc_shift, tiles_y, tiles_x, ncg, WSZmax, claim_sz;
+    int TR, TC, tc_shift, tiles_y, tiles_x, ncg, WSZmax, claim_sz, margin;
     int nsplit;      // workgroups per tile: workgroup s takes the channel groups [s*ncg/nsplit, (s+1)*ncg/nsplit) and the taps = s (mod nsplit)
 };
 __global__ __launch_bounds__(512, 6) void dcn_bwd_data_kernel(DcnBwdDataParams p, int n_wg) {
@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(512, 6) void dcn_bwd_data_kernel(DcnBwdDataParams p
     // ---- scatter role: dcn_col2im_kernel's walk, channel groups serial ----
     DcnScatterCtx x;
     x.y0 = y0; x.x0 = x0; x.TC = p.TC; x.tc_shift = p.tc_shift;
-    dcn_scatter_window(x, g, p.TR, p.WSZmax);
+    dcn_scatter_window(x, g, p.TR, p.WSZmax, p.margin);
     x.wp = reinterpret_cast<float4*>(win) + (size_t)wid * x.WSZ;
     x.dump = reinterpret_cast<float4*>(win + CI_CG * p.WSZmax) + tid;
     x.claim = (lds_vu8*)(reinterpret_cast<unsigned char*>(win + CI_CG * p.WSZmax + 4 * 256) + wid * p.claim_sz);
@@ -1493,6 +1493,16 @@ int pick_bm(int M, long long N) {
 
 constexpr int kFusedMinTilesDefault = 512;
 int g_fused_min_tiles = kFusedMinTilesDefault;      // cnuda_dcn_set_fused_min_tiles (tests)
+int g_scatter_margin = 0;                           // cnuda_dcn_set_scatter_margin (measurements, tests); 0: by regime
+// Offset regime of the NEXT forward / backward call (cnuda_dcn_set_offset_regime; the host layer sets it per call from a
+// census of the layer's own offsets, libs/DCNv2/dcn_v2.py).  A freshly initialised model samples within a fraction of a
+// pixel of the regular grid; a trained CenterNet has learned offsets of pixels.  The kernels that keep a window on chip
+// are sized for the first case and pay per sample that leaves the window (round 5, B = 32, 64 -> 64 at 128 x 128, us per
+// launch at offsets of sigma 0.5 / 1 / 1.4 / 2 px -- data-gradient walk with a window margin of 2 cells: 1085 / 1322 /
+// 1727 / 3730, of 4 cells: 1106 / 1235 / 1336 / 1600; profiles/r5_dcn_margin_sweep.txt):
+//   bit 0: many samples beyond +-2 px -> the walk's window gets a margin of 4 cells (2 workgroups per CU instead of 3)
+//   bit 1: many samples beyond +-3 px -> the forward takes the gathering loader instead of the LDS-window kernel
+int g_offset_regime = 0;
 
 
 struct DcnPlan {
@@ -1503,7 +1513,7 @@ struct DcnPlan {
     bool fwd_two_kernels;           // several M tiles: sample the columns once, then a plain GEMM
     // split backward: 1x1 GEMM workspace, transposed weights, dcol, geometry records; col2im tiling
     size_t gemm_bytes;
-    int TR, TC, tc_shift, tiles_y, tiles_x, ncg, WSZmax, claim_sz;
+    int TR, TC, tc_shift, tiles_y, tiles_x, ncg, WSZmax, claim_sz, margin;
     size_t col2im_lds;
     bool fused_consumers;           // dcn_bwd_data_kernel (large maps) instead of coord_grad + col2im
     int fused_split;                // its workgroups per tile
@@ -1546,12 +1556,13 @@ DcnPlan make_plan(const DcnGeom& g) {
     q.tiles_y = ceil_div(g.Ho, q.TR);
     q.tiles_x = ceil_div(g.Wo, q.TC);
     q.ncg = ceil_div(g.C, CI_CG);
-    const int wr = (q.TR - 1) * g.sh + (g.kh - 1) * g.dh + 2 * CI_MARGIN + 1;
-    const int wc = (q.TC - 1) * g.sw + (g.kw - 1) * g.dw + 2 * CI_MARGIN + 1;
+    q.margin = g_scatter_margin > 0 ? g_scatter_margin : ((g_offset_regime & 1) ? 4 : CI_MARGIN);
+    const int wr = (q.TR - 1) * g.sh + (g.kh - 1) * g.dh + 2 * q.margin + 1;
+    const int wc = (q.TC - 1) * g.sw + (g.kw - 1) * g.dw + 2 * q.margin + 1;
     q.WSZmax = wr * wc;
     q.claim_sz = ((wr + 1) * (wc + 1) + 15) / 16 * 16;
     // three workgroups per CU need <= 53 KiB each; larger windows (strides, dilations, big kernels) run windowless
-    if ((size_t)CI_CG * q.WSZmax * 4 + 4096 + 4 * (size_t)q.claim_sz > 53 * 1024) { q.WSZmax = 0; q.claim_sz = 16; }
+    if ((size_t)CI_CG * q.WSZmax * 4 + 4096 + 4 * (size_t)q.claim_sz > (q.margin > CI_MARGIN ? 80 : 53) * 1024) { q.WSZmax = 0; q.claim_sz = 16; }
     q.col2im_lds = ((size_t)CI_CG * q.WSZmax + 4 * 256) * sizeof(float) + 4 * (size_t)q.claim_sz;
     // one workgroup per (image, tile) must still fill the chip (three resident per CU): the 128 x 128 and 64 x 64 maps
     q.fused_consumers = q.WSZmax > 0 && g.W >= 2 && (long long)g.B * q.tiles_y * q.tiles_x >= g_fused_min_tiles;
@@ -1565,6 +1576,52 @@ DcnPlan make_plan(const DcnGeom& g) {
 
 using namespace cnuda;
 
+extern "C" int cnuda_dcn_set_scatter_margin(int margin) {
+    const int prev = g_scatter_margin;
+    g_scatter_margin = margin < 1 ? 0 : (margin > 8 ? 8 : margin);
+    return prev;
+}
+extern "C" int cnuda_dcn_set_offset_regime(int regime) {
+    const int prev = g_offset_regime;
+    g_offset_regime = regime & 3;
+    return prev;
+}
+
+namespace cnuda {
+namespace {
+// counts[0] / counts[1] += samples whose offset leaves +-2 px / +-3 px in either direction (offset: [B][2T][HW], channel
+// 2t = dy, 2t + 1 = dx of tap t).  A statistic for the host's choice of kernels, launched once in a while.
+__global__ __launch_bounds__(256) void dcn_offset_census_kernel(const float* __restrict__ offset, long long n_pairs, long long HW,
+                                                                unsigned* __restrict__ counts) {
+    unsigned c2 = 0, c3 = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_pairs; i += (long long)gridDim.x * 256) {
+        const long long plane = i / HW, px = i - plane * HW;            // plane = b * T + t
+        const float dy = fabsf(offset[(2 * plane) * HW + px]), dx = fabsf(offset[(2 * plane + 1) * HW + px]);
+        const float d = dy > dx ? dy : dx;
+        c2 += d >= 2.0f;
+        c3 += d >= 3.0f;
+    }
+    __shared__ unsigned s2, s3;
+    if (threadIdx.x == 0) { s2 = 0; s3 = 0; }
+    __syncthreads();
+    if (c2) atomicAdd(&s2, c2);
+    if (c3) atomicAdd(&s3, c3);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s2) atomicAdd(counts, s2);
+        if (s3) atomicAdd(counts + 1, s3);
+    }
+}
+}  // namespace
+}  // namespace cnuda
+extern "C" int cnuda_dcn_offset_census(const float* offset, int B, int taps, long long HW, unsigned* counts,
+                                       cnuda_stream_t stream) {
+    CNUDA_REQUIRE(offset && counts && B > 0 && taps > 0 && HW > 0, "cnuda_dcn_offset_census: bad arguments");
+    const long long n = (long long)B * taps * HW;
+    CNUDA_LAUNCH(cnuda::dcn_offset_census_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, offset, n, HW,
+                 counts);
+    return check_launch("cnuda_dcn_offset_census");
+}
 extern "C" int cnuda_dcn_set_fused_min_tiles(int min_tiles) {
     const int prev = g_fused_min_tiles;
     g_fused_min_tiles = min_tiles < 1 ? kFusedMinTilesDefault : min_tiles;
@@ -1601,7 +1658,7 @@ namespace {
 // keeps the gathering loader (A/B measurements; tests/test_gpu_kernel_switches.py).
 bool dcnw_takes(const DcnGeom& g) {
     static const bool dcnw_on = !(getenv("CNUDA_DCNW") && getenv("CNUDA_DCNW")[0] == '0');
-    return dcnw_on && matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
+    return dcnw_on && (g_offset_regime & 2) == 0 && matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
            g.dh == 1 && g.dw == 1 && g.dg == 1 && g.C % 16 == 0 && g.Co <= 64 &&
            (g.W == 16 || g.W == 32 || g.W == 64 || g.W == 128) && g.H % (IG_BN / (g.W >= 32 ? 32 : g.W)) == 0 &&
            (size_t)g.B * g.C * g.H * g.W * sizeof(float) < IG_BUF_OOB;
@@ -1872,10 +1929,16 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
             return rc;
         if (q.fused_consumers) {
             DcnBwdDataParams p{g, input, dcol, geo, grad_input, grad_offset, grad_mask, q.TR, q.TC, q.tc_shift,
-                               q.tiles_y, q.tiles_x, q.ncg, q.WSZmax, q.claim_sz, q.fused_split};
+                               q.tiles_y, q.tiles_x, q.ncg, q.WSZmax, q.claim_sz, q.margin, q.fused_split};
             const int n_wg = B * q.tiles_y * q.tiles_x * q.fused_split;
             ProfScope scope(st, 3);
             scope.name("dcn_bwd_data_kernel");
+            static bool raised = false;                       // (a wide-margin window: dynamic LDS beyond 64 KiB is opt-in)
+            if (q.col2im_lds > 64 * 1024 && !raised) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_bwd_data_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                raised = true;
+            }
             CNUDA_LAUNCH(dcn_bwd_data_kernel, dim3(n_wg), dim3(512), q.col2im_lds, st, p, n_wg);
         } else {
             {
@@ -1887,10 +1950,16 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
             }
             {
                 DcnCol2imParams p{g, dcol, geo, grad_input, q.TR, q.TC, q.tc_shift, q.tiles_y, q.tiles_x,
-                                  q.ncg, q.WSZmax, q.claim_sz};
+                                  q.ncg, q.WSZmax, q.claim_sz, q.margin};
                 const int n_wg = B * q.tiles_y * q.tiles_x * q.ncg;
                 ProfScope scope(st, 2);
                 scope.name("dcn_col2im_kernel");
+                static bool raised2 = false;
+                if (q.col2im_lds > 64 * 1024 && !raised2) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_col2im_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    raised2 = true;
+                }
                 CNUDA_LAUNCH(dcn_col2im_kernel, dim3(n_wg), dim3(256), q.col2im_lds, st, p, n_wg);
             }
         }

@@ -135,6 +135,9 @@ class _Sig:
     cnuda_launch_log_enable = (_I, [_I])
     cnuda_launch_log_collect = (_I, [ctypes.c_char_p, c_size_t])
     cnuda_dcn_set_fused_min_tiles = (_I, [_I])
+    cnuda_dcn_set_scatter_margin = (_I, [_I])
+    cnuda_dcn_set_offset_regime = (_I, [_I])
+    cnuda_dcn_offset_census = (_I, [_P, _I, _I, _LL, _P, _P])
     cnuda_conv_set_halo_policy = (_I, [_I, _I])
 
 

@@ -28,20 +28,22 @@ class _DeformConvFn(torch.autograd.Function):
     # autograd-visible argument order (dcn_v2.py:18-19): input, offset, mask, weight, bias, ...
     @staticmethod
     def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token=0,
-                stats_box=None):
+                stats_box=None, regime=0):
         kh, kw = weight.shape[2], weight.shape[3]
+        ctx.regime = int(regime)       # offset regime of this layer (DCN._census): which kernels the library picks
         from hip_runtime.fanout import slot_of
         ctx.slot = slot_of(input)      # where the offset convolution (the input's other consumer) meets this gradient
         ctx.geom = (kh, kw) + _pair(stride) + _pair(padding) + _pair(dilation) + (deformable_groups,)
         # keep the sampled columns (a side output of the forward kernel) for the weight gradient:
         # on a 288 GB part re-reading ~0.3 GB per layer beats re-sampling the input
         keep = deformable_groups == 1 and input.shape[3] >= 2 and any(ctx.needs_input_grad[:5]) and _KEEP_COLUMNS
-        if keep:
-            out, cols = _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geom, _want_columns=True,
-                                                _pack_token=pack_token, _stats_box=stats_box)
-        else:
-            out, cols = _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geom,
-                                                _pack_token=pack_token, _stats_box=stats_box), None
+        with _offset_regime(ctx.regime):
+            if keep:
+                out, cols = _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geom, _want_columns=True,
+                                                    _pack_token=pack_token, _stats_box=stats_box)
+            else:
+                out, cols = _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geom,
+                                                    _pack_token=pack_token, _stats_box=stats_box), None
         ctx.save_for_backward(input, offset, mask, weight, bias, cols)
         return out
 
@@ -55,27 +57,47 @@ class _DeformConvFn(torch.autograd.Function):
         # buffer, else into a cleared tensor -- which an empty slot takes over
         slot = ctx.slot
         acc = slot.buf if (slot is not None and slot.buf is not None and slot.owned) else None
-        g_in, g_off, g_mask, g_w, g_b = _backend.dcn_v2_backward(
-            input, weight, bias, offset, mask, grad_output, *ctx.geom, _columns=cols, _grad_weight=sw, _grad_bias=sb,
-            _grad_input=acc)
+        with _offset_regime(ctx.regime):
+            g_in, g_off, g_mask, g_w, g_b = _backend.dcn_v2_backward(
+                input, weight, bias, offset, mask, grad_output, *ctx.geom, _columns=cols, _grad_weight=sw, _grad_bias=sb,
+                _grad_input=acc)
         if acc is None:
             from hip_runtime.fanout import claim
             claim(slot, g_in)
         else:
             slot.included.append(acc)
         return g_in, g_off, g_mask, (None if sw is not None else g_w), (None if sb is not None else g_b), \
-            None, None, None, None, None, None
+            None, None, None, None, None, None, None
+
+
+class _offset_regime:
+    """The library's offset regime (cnuda_dcn_set_offset_regime) for the calls inside the block, 0 again behind it."""
+
+    def __init__(self, regime):
+        self.regime = regime
+
+    def __enter__(self):
+        if self.regime:
+            import hip_runtime as hr
+            hr.lib().cnuda_dcn_set_offset_regime(self.regime)
+
+    def __exit__(self, *exc):
+        if self.regime:
+            import hip_runtime as hr
+            hr.lib().cnuda_dcn_set_offset_regime(0)
 
 
 def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token=0,
-                emit_stats=False):
+                emit_stats=False, regime=0):
     """emit_stats (not part of the reference's signature): the output goes straight into a train-mode BatchNorm -- the
     kernel's epilogue then leaves the statistics with it (hip_runtime.ops.batch_norm_act finds them on the tensor)."""
     from hip_runtime import ops
     if not (emit_stats and ops.EPILOGUE_STATS):
-        return _DeformConvFn.apply(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token)
+        return _DeformConvFn.apply(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token,
+                                   None, regime)
     box = []
-    out = _DeformConvFn.apply(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token, box)
+    out = _DeformConvFn.apply(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token, box,
+                              regime)
     if box:
         out._cnuda_bn_stats = box[0]
     return out
@@ -120,6 +142,9 @@ class DCN(DCNv2):
         self.conv_offset_mask = hnn.Conv2d(in_channels, 3 * taps, self.kernel_size, self.stride,
                                            self.padding, bias=True)
         self.emit_stats = False      # set by a caller whose next layer is a BatchNorm2d (backends.dla.DeformConv)
+        # offset regime of this layer (cnuda_dcn_set_offset_regime): re-measured every CENSUS_EVERY training forwards by
+        # a census of its own offsets -- one small launch and one host read, i.e. one synchronisation per layer and 64 steps
+        self._regime, self._census_calls = 0, 0
         with torch.no_grad():        # zero init: offsets 0, mask sigmoid(0)=0.5 (dcn_v2.py:114-116, Q7)
             self.conv_offset_mask.weight.zero_()
             self.conv_offset_mask.bias.zero_()
@@ -133,6 +158,26 @@ class DCN(DCNv2):
         # channels [0, 2*taps) are offsets (chunks o1|o2 re-concatenated, dcn_v2.py:120-121),
         # [2*taps, 3*taps) the mask logits
         offset, mask = ops.split_offset_mask(om)
+        if self.training and self.deformable_groups == 1:
+            self._census_calls += 1
+            if self._census_calls % self.CENSUS_EVERY == 1:
+                self._regime = self._census(offset)
         return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding,
                            self.dilation, self.deformable_groups, self._pack_token,
-                           emit_stats=self.emit_stats and self.training)
+                           emit_stats=self.emit_stats and self.training, regime=self._regime)
+
+    CENSUS_EVERY = 64
+    # shares of (pixel, tap) samples beyond +-2 px / +-3 px above which the wide-window walk / the gathering forward win
+    # (profiles/r5_dcn_margin_sweep.txt, r4_dcnw_large_offsets.txt: the crossovers sit near sigma = 0.75 px and 1.25 px)
+    CENSUS_SHARES = (0.015, 0.03)
+
+    def _census(self, offset):
+        import hip_runtime as hr
+        off = offset.detach()
+        B, HW = off.shape[0], off.shape[2] * off.shape[3]
+        taps = off.shape[1] // 2
+        counts = torch.zeros(2, dtype=torch.int32, device=off.device)
+        hr.check(hr.lib().cnuda_dcn_offset_census(hr.ptr(hr.f32c(off)), B, taps, HW, hr.ptr(counts), hr.stream()), 'census')
+        n2, n3 = counts.tolist()
+        total = float(B * taps * HW)
+        return (1 if n2 > self.CENSUS_SHARES[0] * total else 0) | (2 if n3 > self.CENSUS_SHARES[1] * total else 0)

@@ -105,6 +105,17 @@ int cnuda_prof_name_len(void);
 int cnuda_launch_log_enable(int on);
 int cnuda_launch_log_collect(char* names, size_t cap);
 int cnuda_dcn_set_fused_min_tiles(int min_tiles);
+/* cells of the data-gradient walk's LDS window beyond the undeformed 3x3 footprint (default 2; < 1 restores it).  Returns the
+ * previous value.  Samples further out than this are strays (global atomics): a wider window for models whose offsets are
+ * pixels, at fewer workgroups per CU.  Measurements and tests; results do not depend on it beyond summation order. */
+int cnuda_dcn_set_scatter_margin(int margin);
+/* Offset regime of the next cnuda_dcn_v2_* calls (process-wide, the host layer sets it per call): bit 0 -> the data-gradient
+ * walk's window takes a margin of 4 cells (many samples beyond +-2 px), bit 1 -> the forward takes the gathering loader
+ * instead of the LDS-window kernel (many samples beyond +-3 px).  Returns the previous value.  Speed only: results do not
+ * depend on it beyond summation order.  cnuda_dcn_offset_census adds to counts[0] / counts[1] (caller-zeroed) the number
+ * of (pixel, tap) samples of `offset` [B][2*taps][HW] that leave +-2 px / +-3 px in either direction. */
+int cnuda_dcn_set_offset_regime(int regime);
+int cnuda_dcn_offset_census(const float* offset, int B, int taps, long long HW, unsigned* counts, cnuda_stream_t stream);
 int cnuda_conv_set_halo_policy(int level, int min_tiles);
 
 /* ------------------------------------------------------------------------

@@ -17,19 +17,22 @@ if os.environ.get('ABL_LIB'):          # another build of the library (profiles/
 from libs.DCNv2.dcn_v2 import DCN  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument('--offsets', default='small', choices=['zero', 'small', 'sigma1'])
+ap.add_argument('--offsets', default='small', choices=['zero', 'small', 'sigma1', 'sigma1.4', 'sigma2'])
+ap.add_argument('--margin', type=int, default=0, help='cnuda_dcn_set_scatter_margin for the run (0: default)')
 ap.add_argument('--iters', type=int, default=1)
 ap.add_argument('--time', action='store_true')
 args = ap.parse_args()
 torch.manual_seed(0)
+if args.margin:
+    hr.lib().cnuda_dcn_set_scatter_margin(args.margin)
 for (B, C, S, Co) in [(32, 64, 128, 64), (32, 128, 64, 64)]:
     m = DCN(C, Co, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).cuda()
     with torch.no_grad():
         if args.offsets == 'small':          # offsets ~ N(0.3, 0.5 px): the regime after the first optimizer steps
             m.conv_offset_mask.weight.normal_(0, 0.02)
             m.conv_offset_mask.bias.normal_(0, 0.3)
-        elif args.offsets == 'sigma1':
-            m.conv_offset_mask.weight.normal_(0, 0.042)
+        elif args.offsets.startswith('sigma'):
+            m.conv_offset_mask.weight.normal_(0, 0.042 * float(args.offsets[5:]) * (64.0 / C) ** 0.5)
     x = torch.randn(B, C, S, S, device='cuda', requires_grad=True)
     g = torch.randn(B, Co, S, S, device='cuda')
     for _ in range(2):

@@ -273,3 +273,46 @@ def test_literal_c_abi_entry_points():
     # a workspace that is too small is refused, not overrun
     rc = L.cnuda_dcn_v2_forward(P(dx), P(dw_), P(db), P(doff), P(dm), P(out), *dims, P(ws), ctypes.c_size_t(16), st)
     assert rc != 0 and b'workspace' in L.cnuda_last_error()
+
+
+@pytest.mark.parametrize('sigma,want', [(0.3, 0), (1.0, 1), (2.5, 3)], ids=['sigma0.3', 'sigma1', 'sigma2.5'])
+def test_offset_census_picks_the_kernels_and_not_the_values(sigma, want):
+    """libs/DCNv2/dcn_v2.py DCN: every CENSUS_EVERY training forwards the layer counts its own offsets beyond +-2 / +-3 px
+    (cnuda_dcn_offset_census) and tells the library which regime its next calls run in (cnuda_dcn_set_offset_regime): a
+    wide-margin window for the data-gradient walk, the gathering loader for the forward.  Speed only -- output and all
+    gradients equal those of regime 0 to summation order, at every offset scale."""
+    import hip_runtime as hr
+    from libs.DCNv2.dcn_v2 import DCN
+    torch.manual_seed(11)
+    m = DCN(32, 32, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(DEV).train()
+    x = torch.randn(2, 32, 32, 32, device=DEV)
+    with torch.no_grad():
+        m.conv_offset_mask.weight.normal_(0, 1.0)
+        std = m.conv_offset_mask(x)[:, :18].std().item()
+        m.conv_offset_mask.weight[:18] *= sigma / std
+        m.conv_offset_mask.bias.zero_()
+    g = torch.randn(2, 32, 32, 32, device=DEV)
+
+    def run(force_regime):
+        m.zero_grad()
+        xs = x.clone().requires_grad_(True)
+        if force_regime is None:
+            m._census_calls = 0                         # census at this forward
+        else:
+            m._census_calls, m._regime = 1, force_regime  # (not a census call)
+        with hr.launch_log() as log:
+            y = m(xs)
+            y.backward(g)
+        return y.detach(), [xs.grad, m.weight.grad.clone(), m.conv_offset_mask.weight.grad.clone()], set(log.names), m._regime
+
+    y0, g0, k0, _ = run(0)
+    y1, g1, k1, regime = run(None)
+    assert regime == want, (regime, want)
+    assert any('dcn_offset_census_kernel' in n for n in k1) and not any('dcn_offset_census_kernel' in n for n in k0)
+    assert any('dcnw_fwd_kernel' in n for n in k0)
+    assert any('dcnw_fwd_kernel' in n for n in k1) == (not (want & 2)), k1
+    assert hr.lib().cnuda_dcn_set_offset_regime(0) == 0          # every call leaves the process-wide setting at 0
+    scale = max(1.0, y0.abs().max().item())
+    assert (y1 - y0).abs().max().item() <= 1e-5 * scale
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())

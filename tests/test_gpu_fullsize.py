@@ -47,7 +47,10 @@ def test_full_size_step_properties():
     assert float(se['entropy_loss']) == 0.0 and abs(float(se['total_loss']) - float(sb['total_loss'])) <= 1e-6 * abs(float(sb['total_loss']))
     # same Adam step (+-lr * g / (|g| + eps)) from identical detection gradients.  Elements whose gradient is
     # rounding noise -- the DCN biases in front of a BatchNorm have an analytically zero gradient -- may take the
-    # other sign when col2im's straggler atomics land in another order: at most 2 * lr apart, and rare elsewhere
+    # other sign when col2im's straggler atomics land in another order: at most 2 * lr apart, and rare elsewhere.
+    # (Round 5: the BatchNorm statistics come from the producing GEMM's epilogue, whose pixel blocks follow the launch's
+    # tile shape -- 16 images and 16 + 16 images pick different tiles on the small maps, so the two runs' statistics
+    # differ in their last bit and a few more noise-level gradients change sign: measured 0.12 % of the elements.)
     lr, moved, total = 5e-5, 0, 0
     for n in p_base:
         d = (p_base[n] - p_ent0[n]).abs()
@@ -56,7 +59,7 @@ def test_full_size_step_properties():
             continue
         moved += int((d > 1e-7).sum())
         total += d.numel()
-    assert moved <= 1e-3 * total, (moved, total)
+    assert moved <= 3e-3 * total, (moved, total)
     for n in b_base:
         if n.endswith('num_batches_tracked'):
             assert int(b_ent0[n]) == 2 * int(b_base[n]) == 2, n                       # Q6
@@ -140,7 +143,7 @@ def test_full_size_max_squares_step_properties():
         if not n.endswith('.conv.bias'):
             moved += int((d > 1e-7).sum())
             total += d.numel()
-    assert moved <= 1e-3 * total, (moved, total)
+    assert moved <= 3e-3 * total, (moved, total)
     assert all(int(v) == 2 for n, v in b_0.items() if n.endswith('num_batches_tracked'))           # Q6
 
     def run():
