@@ -570,6 +570,33 @@ struct ConvWBufLoader {
     }
 };
 
+// The same loader for channel counts that are multiples of 8 but not of 64 (DLA-34's 16 -> 32 and 32 -> 64 stride-2
+// convolutions): a thread's eight columns j0 + jsub + 8 i of a 64-column group no longer share a tap, but the eight
+// channels [c, c + 8) a lane phase covers never straddle one (8 | C) -- tap, window offset and bounds test per i, all
+// else as above.  Replaces the pointer-arithmetic ConvWLoader<0> there (152 VGPRs, 29-58 TFLOP/s).
+struct ConvWBufLoaderC8 : ConvWBufLoader {
+    static const char* name() { return "ConvWBufLoaderC8"; }
+    __device__ ConvWBufLoaderC8(const Params& pp, long long n, long long n_end) : ConvWBufLoader(pp, n, n_end) {}
+    template <int NV, int STEP>
+    __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[NV]) {
+        static_assert(STEP == 8, "eight row phases: a phase's channels stay inside one tap when 8 | C");
+        const ConvGeom& g = p.g;
+        const int HW = g.H * g.W, K = g.kh * g.kw * g.C;
+        const int iy0 = ig_mad24(c.oy_, g.sh, -g.ph), ix0 = ig_mad24(c.ox_, g.sw, -g.pw);
+        const unsigned corner = ximg + (unsigned)(ig_mad24(jsub, HW, ig_mad24(iy0, g.W, ix0))) * 4u;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int jg = j0 + STEP * i;                     // wave-uniform
+            const int tap = jg / g.C, c0 = jg - tap * g.C;
+            const int r = tap / g.kw, s = tap - r * g.kw;
+            const int iy = iy0 + r, ix = ix0 + s;
+            const bool ok = c.valid_ && jg < K && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            const unsigned voff = ok ? corner + (unsigned)((r * g.W + s) * (int)sizeof(float)) : IG_BUF_OOB;
+            v[i] = ig_buf_load(rx, voff, (unsigned)(c0 * HW) * (unsigned)sizeof(float));
+        }
+    }
+};
+
 int fill_geom(ConvGeom& g, int B, int C, int H, int W, int Co, int kh, int kw, int sh, int sw, int ph, int pw,
               const char* who) {
     CNUDA_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Co > 0, "%s: empty tensor", who);
@@ -962,9 +989,17 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
         const dim3 grid(q.Jp / q.wbj, q.Mpw / q.wbm, q.Z), blk(IG_THREADS);
         const bool fast = C % 64 == 0;
         const bool buf = fast && wgrad_buffer_ok(g);
+        const bool buf8 = !fast && C % 8 == 0 && wgrad_buffer_ok(g) && (q.wbm == 32 || (q.wbm == 64 && q.wbj == 64));
         prof.name((wave_specialised() && fast && q.wbm >= 64) ? "igemm_wgrad_ws_kernel<%s, %d, %d>" : "igemm_wgrad_kernel<%s, %d, %d>",
-                  buf ? "ConvWBufLoader" : (fast ? "ConvWLoader<2>" : "ConvWLoader<0>"), q.wbm, q.wbj);
-        if (buf) {
+                  buf ? "ConvWBufLoader" : (buf8 ? "ConvWBufLoaderC8" : (fast ? "ConvWLoader<2>" : "ConvWLoader<0>")), q.wbm, q.wbj);
+        if (buf8) {
+            if (q.wbm == 32)
+                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoaderC8, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
+                                   q.Nf, q.pix_per_split, bsl);
+            else
+                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoaderC8, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
+                                   q.Nf, q.pix_per_split, bsl);
+        } else if (buf) {
             const dim3 blk2(2 * IG_THREADS);
             if (q.wbm == 128 && q.wbj == 128 && wave_specialised())
                 CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
