@@ -733,6 +733,89 @@ int launch_hconv(int bm, const typename Ad::Params& p, const float* src, int kc,
     return check_launch(who);
 }
 
+// ---------------------------------------------------------------------------
+// Input gradient of a 3x3 / stride 2 / padding 1 convolution with C = 16 input channels (DLA-34's level1, 16 -> 32 at
+// 512 x 512 -> 256 x 256: backends/dla.py:233-241): 8.4 M output pixels per image batch of 32, 16 channels each, K of at
+// most 4 taps x 32.  As four parity-class GEMMs on 32-row MFMA tiles half the rows are padding, a tile has 2..8 K chunks
+// and its stride-2 epilogue stores 4 bytes per lane: 943 us at 20 TFLOP/s (round 5, profiles/r5_early_layers.txt) for
+// 0.8 GB of compulsory traffic.  Here one thread owns one cell (qy, qx) of the grad_y grid and produces the 2 x 2 block of
+// grad_x pixels it feeds into first -- rows 2 qy, 2 qy + 1, columns 2 qx, 2 qx + 1 -- for all 16 channels: every one of the
+// nine taps lands in exactly one of the four pixels (row 2 qy takes kernel row 1 of grad_y row qy; row 2 qy + 1 takes
+// kernel row 0 of grad_y row qy + 1 and kernel row 2 of row qy; columns alike), so the block is 9 x Co x 16 multiply-adds
+// over the four grad_y cells (qy + {0, 1}, qx + {0, 1}), all coalesced along qx.  The weights of one output channel
+// (9 taps x 16 channels, repacked [o][tap][c]) are wave-uniform: scalar loads, one SGPR operand per multiply-add.  The
+// block's two rows are stored as 8-byte pairs.  Vector ALU at the f32 rate the MFMA has, no padding, no K chunks.
+// ---------------------------------------------------------------------------
+struct DgradS2Params {
+    const float *gy, *wt;          // wt: [Co][9][16]
+    float* gx;
+    const float *add, *add2;       // nullable addends shaped like gx (may alias it: read per element before the store)
+    int B, Co, H, W, Ho, Wo, QH, QW;
+};
+__global__ __launch_bounds__(256) void dgrad_s2_c16_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co) {
+    const int i = blockIdx.x * 256 + threadIdx.x;        // wt[(o * 9 + tap) * 16 + c] = w[(o * 16 + c) * 9 + tap]
+    if (i < Co * 144) {
+        const int c = i & 15, t = (i >> 4) % 9, o = i / 144;
+        wt[i] = w[(o * 16 + c) * 9 + t];
+    }
+}
+__global__ __launch_bounds__(256) void dgrad_s2_c16_kernel(DgradS2Params p) {
+    const int qx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int qy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (qy >= p.QH) return;                                  // (wave-uniform)
+    const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
+    const bool x0 = qx < p.Wo, x1 = qx + 1 < p.Wo, y0 = qy < p.Ho, y1 = qy + 1 < p.Ho;
+    const float* g00 = p.gy + (size_t)b * p.Co * HoWo + (size_t)(y0 ? qy : 0) * p.Wo + (x0 ? qx : 0);
+    const int d01 = x1 ? 1 : 0, d10 = y1 ? p.Wo : 0;        // clamped neighbours; their values are zeroed below
+    float acc[4][16];                                        // [2 py + px][c]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[q][c] = 0.0f;
+    for (int o = 0; o < p.Co; ++o) {
+        const float* gp = g00 + (size_t)o * HoWo;
+        float a = gp[0], bb = gp[d01], cc = gp[d10], dd = gp[d10 + d01];     // grad_y (qy, qx), (qy, qx+1), (qy+1, qx), (qy+1, qx+1)
+        if (!(x0 && y0)) a = 0.0f;
+        if (!(x1 && y0)) bb = 0.0f;
+        if (!(x0 && y1)) cc = 0.0f;
+        if (!(x1 && y1)) dd = 0.0f;
+        const float* wo = p.wt + (size_t)o * 144;            // wave-uniform: scalar loads
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            // taps (r, s): pixel (py, px) of the block takes r = 1 | {0, 2}, s = 1 | {0, 2}
+            acc[0][c] = fmaf(wo[4 * 16 + c], a, acc[0][c]);                                   // (1,1) <- (qy, qx)
+            acc[1][c] = fmaf(wo[3 * 16 + c], bb, fmaf(wo[5 * 16 + c], a, acc[1][c]));         // (1,0) <- (qy, qx+1); (1,2) <- (qy, qx)
+            acc[2][c] = fmaf(wo[1 * 16 + c], cc, fmaf(wo[7 * 16 + c], a, acc[2][c]));         // (0,1) <- (qy+1, qx); (2,1) <- (qy, qx)
+            acc[3][c] = fmaf(wo[0 * 16 + c], dd, fmaf(wo[2 * 16 + c], cc,                     // (0,0) <- (qy+1, qx+1); (0,2) <- (qy+1, qx)
+                             fmaf(wo[6 * 16 + c], bb, fmaf(wo[8 * 16 + c], a, acc[3][c]))));  // (2,0) <- (qy, qx+1); (2,2) <- (qy, qx)
+        }
+    }
+    const int iy = 2 * qy, ix = 2 * qx;
+    if (ix >= p.W) return;
+    const bool two = ix + 1 < p.W, pair_ok = two && (p.W & 1) == 0;      // 8-byte stores need even row starts
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+        if (iy + py >= p.H) break;
+        const size_t o0 = (size_t)b * 16 * HW + (size_t)(iy + py) * p.W + ix;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const size_t o = o0 + (size_t)c * HW;
+            float v0 = acc[2 * py][c], v1 = acc[2 * py + 1][c];
+            if (pair_ok) {
+                if (p.add) { const float2 t = *reinterpret_cast<const float2*>(p.add + o); v0 += t.x; v1 += t.y; }
+                if (p.add2) { const float2 t = *reinterpret_cast<const float2*>(p.add2 + o); v0 += t.x; v1 += t.y; }
+                *reinterpret_cast<float2*>(p.gx + o) = make_float2(v0, v1);
+            } else {
+                if (p.add) { v0 += p.add[o]; if (two) v1 += p.add[o + 1]; }
+                if (p.add2) { v0 += p.add2[o]; if (two) v1 += p.add2[o + 1]; }
+                p.gx[o] = v0;
+                if (two) p.gx[o + 1] = v1;
+            }
+        }
+    }
+}
+
 template <class Loader>
 int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp, int Kp, int M, long long N,
                hipStream_t st, const char* who) {
@@ -914,6 +997,16 @@ extern "C" int cnuda_conv2d_backward_data_add(const float* grad_y, const float* 
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
     float* Aws = reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpd, q.Mpd)));
+    if (C == 16 && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1 && Cout <= 256 && matrix_mode() == 0 &&
+        (size_t)Cout * 144 * sizeof(float) <= ig_a_bytes(q.Kpd, q.Mpd)) {
+        // the 16-channel full-resolution level: one thread per 2 x 2 output block (dgrad_s2_c16_kernel)
+        CNUDA_LAUNCH(dgrad_s2_c16_pack_kernel, dim3((Cout * 144 + 255) / 256), dim3(256), 0, st, weight, Aws, Cout);
+        DgradS2Params dp{grad_y, Aws, grad_x, addend, addend2, B, Cout, H, W, g.Ho, g.Wo, (H + 1) / 2, (W + 1) / 2};
+        ProfScope prof(st);
+        prof.name("dgrad_s2_c16_kernel");
+        CNUDA_LAUNCH(dgrad_s2_c16_kernel, dim3((dp.QW + 63) / 64, (dp.QH + 3) / 4, B), dim3(256), 0, st, dp);
+        return check_launch("cnuda_conv2d_backward_data(stride 2, 16 channels)");
+    }
     const bool buf_ok = buffer_addressing() && q.T <= 32 && (size_t)B * Cout * g.Ho * g.Wo * sizeof(float) < IG_BUF_OOB;
     if ((sh > 1 || sw > 1) && H % sh == 0 && W % sw == 0 && Cout % IG_BK == 0 &&
         ceil_div(kh, sh) * ceil_div(kw, sw) <= 9) {   // taps one class can see (tap_r/tap_s hold 9)

@@ -126,8 +126,11 @@ __device__ __forceinline__ int k_offset(const SmallGeom& g, int k) {
 constexpr int SC_NV = 8;   // vertical tiles per workgroup (amortises the per-workgroup weight / offset fetch)
 constexpr int SC_YLD = SC_TW + 4;   // row stride of the per-wave output staging tile (16-byte aligned rows)
 
+#ifndef SC_FWD_OCC
+#define SC_FWD_OCC 2
+#endif
 template <int MT>
-__global__ __launch_bounds__(IG_THREADS, 2) void smallc_fwd_kernel(SmallGeom g, const float* __restrict__ x,
+__global__ __launch_bounds__(IG_THREADS, SC_FWD_OCC) void smallc_fwd_kernel(SmallGeom g, const float* __restrict__ x,
                                                                const float* __restrict__ Wp,
                                                                const int* __restrict__ koff_tab,
                                                                const float* __restrict__ bias, float* __restrict__ y,

@@ -18,6 +18,7 @@ import torch  # noqa: E402
 
 # (C, Co, S, k, stride): the 3x3 / 1x1 layers of DLA-34 + heads + DCN offset convolutions, by map size
 SHAPES = [
+    (3, 16, 512, 7, 1), (16, 16, 512, 3, 1), (16, 32, 512, 3, 2), (32, 64, 256, 3, 2),     # stem, level0, level1, level2's first
     (64, 64, 128, 3, 1), (64, 27, 128, 3, 1), (64, 256, 128, 3, 1),
     (128, 128, 64, 3, 1), (128, 27, 64, 3, 1), (64, 128, 128, 3, 2),
     (256, 256, 32, 3, 1), (256, 27, 32, 3, 1), (128, 256, 64, 3, 2),

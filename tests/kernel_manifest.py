@@ -374,4 +374,13 @@ MANIFEST = {
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[s2_even',
         'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics',
     ],
+    'dgrad_s2_c16_kernel': [          # input gradient of the 16 -> 32 stride-2 convolution (level1), round 5
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[c16_s2',
+        'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics',
+        'tests/test_gpu_ops.py::test_stride2_sixteen_channel_input_gradient',
+    ],
+    'dgrad_s2_c16_pack_kernel': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[c16_s2',
+        'tests/test_gpu_ops.py::test_stride2_sixteen_channel_input_gradient',
+    ],
 }

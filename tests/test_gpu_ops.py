@@ -706,3 +706,33 @@ def test_deformable_convolution_epilogue_leaves_batchnorm_statistics(shape):
         _close(a, b, 2e-6)
     for a, b in zip(grads1, grads0):
         _close(a, b, 1e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 17, 15, 32), (1, 64, 96, 32), (3, 20, 22, 8), (2, 9, 130, 48)],
+                         ids=lambda s: 'B%dH%dW%dCo%d' % s)
+def test_stride2_sixteen_channel_input_gradient(shape):
+    """dgrad_s2_c16_kernel (3x3 / stride 2 / padding 1, 16 input channels: DLA-34's level1): one thread per 2 x 2 block of
+    grad_x.  Odd and even heights / widths (last block rows / columns partly outside), grad_y cells beyond the map, the
+    8-byte and the scalar store paths, and both addends -- also aliasing the output (hip_runtime.fanout)."""
+    import hip_runtime as hr
+    from hip_runtime import ops
+    B, H, W, Co = shape
+    L = hr.lib()
+    g = torch.Generator().manual_seed(H * 7 + W)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    gy = torch.randn(B, Co, Ho, Wo, generator=g)
+    w = torch.randn(Co, 16, 3, 3, generator=g) / 12
+    want = torch.nn.grad.conv2d_input((B, 16, H, W), w.double(), gy.double(), stride=2, padding=1)
+    geom = (B, 16, H, W, Co, 3, 3, 2, 2, 1, 1)
+    gyd, wd = gy.to(DEV), w.to(DEV)
+    wp, wn = ops._ws(L.cnuda_conv2d_workspace_bytes(*geom), gyd)
+    with hr.launch_log() as log:
+        gx = torch.empty(B, 16, H, W, device=DEV)
+        hr.check(L.cnuda_conv2d_backward_data(hr.ptr(gyd), hr.ptr(wd), hr.ptr(gx), *geom, wp, wn, hr.stream()), 'dgrad')
+    assert any('dgrad_s2_c16_kernel' in n for n in log.names), log.names
+    _close(gx, want.float(), 1e-5)
+    a1, a2 = torch.randn(B, 16, H, W, generator=g).to(DEV), torch.randn(B, 16, H, W, generator=g).to(DEV)
+    acc = a1.clone()
+    hr.check(L.cnuda_conv2d_backward_data_add(hr.ptr(gyd), hr.ptr(wd), hr.ptr(acc), hr.ptr(a2), hr.ptr(acc), *geom, wp, wn,
+                                              hr.stream()), 'dgrad_add')
+    _close(acc, (want + a1.double().cpu() + a2.double().cpu()).float(), 1e-5)
