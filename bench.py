@@ -615,8 +615,11 @@ def main():
                 'kernel_ms_per_step': round(d['ms'] / args.profile_steps, 3),
                 # FLOPs the timed GEMM launches of one step actually execute (sum over all_mfma_kernels)
                 'executed_tflop_per_step': round(executed_tflop, 4),
+                # (gb_per_s: the launches' activation tensors once each / time -- a kernel at 4-5 TB/s is bound by HBM whatever its
+                # TFLOP/s: the 2..6-output head convolutions, the 16-channel layers at 512 x 512)
                 'all_mfma_kernels': {k: {'ms_per_step': round(v['ms'] / args.profile_steps, 3),
                                          'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2),
+                                         'gb_per_s': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 0),
                                          'launches': v['launches'] // args.profile_steps}
                                      for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]['ms'])},
                 # the profiled kernels without MFMA work, against the HBM roofline (algorithmic bytes / time)

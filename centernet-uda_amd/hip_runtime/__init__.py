@@ -373,7 +373,13 @@ def prof_arm(kind, B, C, H, W, Co, kh, kw, Ho, Wo):
         fused_bytes = 4.0 * px * T * C + 16.0 * px * T + 12.0 * px * T + 8.0 * B * C * H * W
         _Prof.table.append([(flops, 0.0), (0.0, coord_bytes), (0.0, col2im_bytes), (0.0, fused_bytes), (flops, 0.0)])   # 4: weight gradient
     elif kind in ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'dcn_fwd'):
-        _Prof.table.append([(flops, 0.0)])
+        # algorithmic bytes beside the FLOPs: the two activation tensors once each (the weights are noise) -- the layers with
+        # 2..32 output channels at full resolution are bound by these, not by the matrix pipe; the DCN forward also reads
+        # offsets / mask and, in training, writes its sampled columns
+        nbytes = 4.0 * B * (C * H * W + Co * Ho * Wo)
+        if kind == 'dcn_fwd':
+            nbytes += 4.0 * B * Ho * Wo * (3 * kh * kw + kh * kw * C)
+        _Prof.table.append([(flops, nbytes)])
     else:
         raise ValueError(kind)
     _Prof.shapes.append((kind, B, C, H, W, Co, kh, kw, Ho, Wo))
