@@ -615,6 +615,15 @@ def main():
                 'kernel_ms_per_step': round(d['ms'] / args.profile_steps, 3),
                 # FLOPs the timed GEMM launches of one step actually execute (sum over all_mfma_kernels)
                 'executed_tflop_per_step': round(executed_tflop, 4),
+                # continuity with rounds 1-4, whose dominant kernel was igemm_fwd_ws_kernel<128, ConvFwdBufLoader>: since
+                # round 5 that kernel exists twice -- with and without the BatchNorm-statistics tail in its epilogue
+                # (ConvFwdBufStatsLoader / ConvFwdBufLoader) -- and the two instances together are reported here
+                'forward_ws128_family': (lambda fam: {
+                    'kernels': sorted(fam), 'ms_per_step': round(sum(v['ms'] for v in fam.values()) / args.profile_steps, 3),
+                    'tflops': round(sum(v['flops'] for v in fam.values()) / (sum(v['ms'] for v in fam.values()) * 1e-3) / 1e12, 2),
+                    'frac': round(sum(v['flops'] for v in fam.values()) / (sum(v['ms'] for v in fam.values()) * 1e-3) / 1e12
+                                  / PEAK_FP32_MFMA_TFLOPS, 4)} if fam else None)(
+                    {k: v for k, v in per_kernel.items() if k.startswith('igemm_fwd_ws_kernel<128, ConvFwdBuf')}),
                 # (gb_per_s: the launches' activation tensors once each / time -- a kernel at 4-5 TB/s is bound by HBM whatever its
                 # TFLOP/s: the 2..6-output head convolutions, the 16-channel layers at 512 x 512)
                 'all_mfma_kernels': {k: {'ms_per_step': round(v['ms'] / args.profile_steps, 3),

@@ -30,7 +30,13 @@ struct ConvFwdParams {
     float* y;
     float act_slope;   // < 0: none, 0: ReLU, 0.2: LeakyReLU(0.2)
     const float* residual;   // nullable, shaped like y: y = act(conv + bias + residual) (BatchNorm-folded inference)
-    float* stats;            // nullable: per (pixel block, output channel) sum / sum of squares of y (igemm.cuh, "BatchNorm statistics")
+};
+// ... with the BatchNorm statistics of y as a second output (igemm.cuh, "BatchNorm statistics").  Its own parameter type, and
+// with it its own kernel instances (ConvFwdBufStatsLoader below): compiled into every forward kernel, the statistics tail cost
+// the launches that do not want it -- the detection heads' 64 -> 256 convolutions, 8 of the dominant kernel's 11 ms -- 5 %
+// (12 more registers, 114.7 instead of 120.9 TFLOP/s; round 5).
+struct ConvFwdStatsParams : ConvFwdParams {
+    float* stats;            // per (pixel block, output channel) sum / sum of squares of y
     int stats_mp;            // rows per pixel block of `stats` (>= the padded row count of the launch)
 };
 
@@ -168,6 +174,14 @@ struct ConvFwdBufLoader {
         for (int j = 0; j < 8; ++j) v[j] = ig_buf_load(rs, voff, (unsigned)((c0 + 2 * j) * HW) * (unsigned)sizeof(float));
     }
     using Out = ConvFwdLoader<true>::Out;
+};
+
+// ConvFwdBufLoader for the calls that leave BatchNorm statistics (cnuda_conv2d_forward_stats): same gather, same epilogue
+// stores; the parameter type carries the statistics pointer, which is what turns ig_epilogue_vec4's statistics tail on.
+struct ConvFwdBufStatsLoader : ConvFwdBufLoader {
+    using Params = ConvFwdStatsParams;
+    static const char* name() { return "ConvFwdBufStatsLoader"; }
+    __device__ ConvFwdBufStatsLoader(const Params& p, long long n, bool n_valid) : ConvFwdBufLoader(p, n, n_valid) {}
 };
 
 // Input gradient: gx[b][c][iy][ix] = sum_{tap,o} W[o][c][tap] * gy[b][o][(iy+ph-r)/sh][(ix+pw-s)/sw]
@@ -823,7 +837,8 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     const int n_tiles = ceil_div(N, IG_BN), m_tiles = Mp / bm;
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
     ProfScope prof(st);
-    if constexpr (std::is_same<Loader, ConvFwdBufLoader>::value || std::is_same<Loader, ConvFwdLoader<true>>::value) {
+    if constexpr (std::is_same<Loader, ConvFwdBufLoader>::value || std::is_same<Loader, ConvFwdBufStatsLoader>::value ||
+                  std::is_same<Loader, ConvFwdLoader<true>>::value) {
         // few chunks, several row tiles (the DCN column-gradient GEMM: a 1x1 forward with K = 64 and 9*C rows)
         static const bool shortk = !(getenv("CNUDA_SHORTK") && getenv("CNUDA_SHORTK")[0] == '0');
         if (shortk && matrix_mode() == 0 && bm == 128 && Kp <= 64 && m_tiles >= 2) {
@@ -917,6 +932,9 @@ extern "C" int cnuda_conv2d_stats_block(int B, int C, int H, int W, int Cout, in
     if (((g.Ho * g.Wo) & 3) != 0) return 0;
     const ConvPlan q = make_plan(g);
     if (hconv_ok(g, C, q.bmf)) return 0;
+    // (the statistics kernels exist for the buffer-addressed loader: every DLA-34 / ResNet layer behind the stem)
+    if (!(C % IG_BK == 0 && buffer_addressing() && q.T <= 32 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB) || matrix_mode() != 0)
+        return 0;
     if (rows) *rows = q.Mpf;
     return q.bmf == 32 ? 32 : 64;
 }
@@ -949,7 +967,7 @@ extern "C" int cnuda_conv2d_forward_stats(const float* x, const float* weight, c
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_conv2d_forward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
-    ConvFwdParams p{g, x, bias, y, act_slope, residual, stats, q.Mpf};
+    ConvFwdParams p{g, x, bias, y, act_slope, residual};
     if (hconv_ok(g, C, q.bmf)) {      // (K = 9 C is already a multiple of the chunk: the same packed size, another K order)
         const float* Ah = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),
                                       ig_a_bytes(q.Kpf, q.Mpf), Cout, C, q.T, PACK_HALO_FWD, q.Kpf, q.Mpf, 0, st);
@@ -957,6 +975,13 @@ extern "C" int cnuda_conv2d_forward_stats(const float* x, const float* weight, c
     }
     const float* A = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),
                                  ig_a_bytes(q.Kpf, q.Mpf), Cout, C, q.T, PACK_FWD, q.Kpf, q.Mpf, 0, st);
+    if (stats) {            // (cnuda_conv2d_stats_block vouched for the buffer-addressed loader)
+        ConvFwdStatsParams ps;
+        static_cast<ConvFwdParams&>(ps) = p;
+        ps.stats = stats;
+        ps.stats_mp = q.Mpf;
+        return launch_fwd<ConvFwdBufStatsLoader>(q.bmf, ps, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward_stats");
+    }
     if (C % IG_BK == 0 && buffer_addressing() && q.T <= 32 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB)
         return launch_fwd<ConvFwdBufLoader>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
     if (C % IG_BK == 0)

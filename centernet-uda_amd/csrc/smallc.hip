@@ -44,7 +44,7 @@ constexpr int SC_ROWS_PER_WAVE = 24;   // C * HR <= 96 halo rows per tile (check
 struct HaloRegs { float v0[SC_ROWS_PER_WAVE], v1[SC_ROWS_PER_WAVE]; };
 __device__ __forceinline__ void halo_load(const SmallGeom& g, const float* __restrict__ xb, int iy0, int ix0, int tid,
                                           HaloRegs& h) {
-    const int lane = tid & 63, wid = tid >> 6;
+    const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and the compiler knows it: row bases stay scalar)
     const int rows = g.C * g.HR;
     const int ixa = ix0 + lane, ixb = ix0 + lane + 64;
     const bool oka = ixa >= 0 && ixa < g.W, okb = lane + 64 < g.HC && ixb >= 0 && ixb < g.W;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void halo_load(const SmallGeom& g, const float* __res
     }
 }
 __device__ __forceinline__ void halo_store(const SmallGeom& g, float* __restrict__ Xh, int tid, const HaloRegs& h) {
-    const int lane = tid & 63, wid = tid >> 6;
+    const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and the compiler knows it: row bases stay scalar)
     const int rows = g.C * g.HR;
 #pragma unroll
     for (int i = 0; i < SC_ROWS_PER_WAVE; ++i) {
@@ -80,7 +80,7 @@ __device__ __forceinline__ void halo_store(const SmallGeom& g, float* __restrict
 // one per row, at half the staging registers.
 __device__ __forceinline__ void stage_halo(const SmallGeom& g, const float* __restrict__ xb, int iy0, int ix0,
                                            float* __restrict__ Xh, int tid) {
-    const int lane = tid & 63, wid = tid >> 6;
+    const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and the compiler knows it: row bases stay scalar)
     const int rows = g.C * g.HR;
     constexpr int HB = SC_ROWS_PER_WAVE / 2;
     const int ixa = ix0 + lane, ixb = ix0 + lane + 64;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(IG_THREADS, SC_FWD_OCC) void smallc_fwd_kernel(Smal
                                                                float act_slope, float* __restrict__ stats) {
     extern __shared__ __align__(16) float smem[];
     float* Xh = smem;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and the compiler knows it)
     const int kq = lane >> 4, il = lane & 15;
     const int ox0 = blockIdx.x * SC_TW, b = blockIdx.z;
     const float* xb = x + (size_t)b * g.C * g.H * g.W;
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(IG_THREADS) void smallc_wgrad_kernel(SmallGeom g, c
     float* Xh = smem;                                   // [C][plane]
     float* Gs = Xh + g.C * g.plane + 16;                // [16*MT][SC_TH*SC_TW + 1]  (o, pixel of the tile)
     constexpr int GLD = SC_TH * SC_TW + 1;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and the compiler knows it)
     const int kq = lane >> 4, il = lane & 15;
     const int ox0 = blockIdx.x * SC_TW, b = blockIdx.z;
     const int HoWo = g.Ho * g.Wo;

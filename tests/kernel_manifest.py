@@ -381,4 +381,17 @@ MANIFEST = {
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[c16_s2',
         'tests/test_gpu_ops.py::test_stride2_sixteen_channel_input_gradient',
     ],
+    # the forward GEMMs that leave BatchNorm statistics with their output (their own loader type, round 5)
+    'igemm_fwd_ws_kernel<128, ConvFwdBufStatsLoader, 16>': [
+        'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'igemm_fwd_ws_kernel<64, ConvFwdBufStatsLoader, 16>': [
+        'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'igemm_fwd_kernel<32, ConvFwdBufStatsLoader, false>': [
+        'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
 }
