@@ -38,14 +38,14 @@ def m(n, c):
     return a[0] / a[1] if a and a[1] else float('nan')
 rows = []
 for n in agg:
-    if not any(t in n for t in ('hconv', 'igemm', 'smallc')):
+    if not any(t in n for t in ('hconv', 'igemm', 'smallc_fwd', 'smallc_wgrad', 'dgrad_s2_c16_kernel')):
         continue
-    wc = m(n, 'SQ_WAVE_CYCLES')
+    wc = m(n, 'SQ_WAVE_CYCLES') or float('nan')
     rows.append((dur[n][0], n, dur[n][1], dur[n][0] / max(dur[n][1], 1),
                  m(n, 'SQ_VALU_MFMA_BUSY_CYCLES') / (m(n, 'GRBM_GUI_ACTIVE') / 8 * 1024),
                  m(n, 'SQ_WAIT_ANY') / wc, m(n, 'SQ_WAIT_INST_ANY') / wc, m(n, 'SQ_WAIT_INST_LDS') / wc,
                  m(n, 'SQ_ACTIVE_INST_VALU') / wc, m(n, 'SQ_ACTIVE_INST_LDS') / wc,
-                 m(n, 'SQ_LDS_BANK_CONFLICT') / m(n, 'SQ_LDS_IDX_ACTIVE'),
+                 m(n, 'SQ_LDS_BANK_CONFLICT') / (m(n, 'SQ_LDS_IDX_ACTIVE') or float('nan')),
                  m(n, 'SQ_LDS_IDX_ACTIVE') / (m(n, 'GRBM_GUI_ACTIVE') / 8 * 256),
                  m(n, 'SQ_INSTS_VALU') / max(m(n, 'SQ_INSTS_VALU_MFMA_MOPS_F32'), 1e-9)))
 out = ['| kernel | launches | mean us | MFMA busy | wait any | wait inst | wait inst LDS | active VALU | active LDS | LDS conflict / active | LDS active / CU-cycle | VALU insts / MFMA mops |', '|' + '---|' * 12]
