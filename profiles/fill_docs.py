@@ -52,9 +52,11 @@ for r in rows:
     bk[b] = bk.get(b, 0.0) + float(r['TotalDurationNs']) / 1e6 / STEPS
 launches = sum(int(r['Calls']) for r in rows) // STEPS
 busy = None
-for k, v in mfma.items():
-    if 'igemm_fwd_ws_kernel<128' in k and 'ConvFwd' in k:
+dom = rf['kernel'].split(' (')[0].replace(' ', '')
+for k, v in mfma.items():          # the PMC row of the line's dominant kernel (profiler names carry template defaults)
+    if isinstance(v, dict) and 'mfma_util' in v and k.replace(' ', '').startswith(dom.rstrip('>')):
         busy = v['mfma_util']
+fam = rf.get('forward_ws128_family')
 d, inf, cb, sp = line['decode_latency'], line['inference'], line['cpu_baseline'], line['matrix_mode_split']
 
 prev_launches = sum(int(r['Calls']) for r in prev_rows) // STEPS
@@ -70,6 +72,10 @@ state.append('Measured state at the end of round %d (MI355X, `profiles/%s_*`, wr
 state.append('Dominant kernel `%s`: %.1f ms over %d launches, %.1f TFLOP/s = `roofline.frac` %.3f%s, %.0f MB of HBM traffic per '
              'launch (PMC).' % (rf['kernel'], rf['kernel_ms_per_step'], rf['launches_per_step'], rf['achieved'], rf['frac'],
                                 (', MFMA pipe busy %.0f %% (PMC)' % (100 * busy)) if busy else '', (rf['traffic'] or 0) / 1e6))
+if fam:
+    state.append('The dominant kernel of rounds 1-4, `igemm_fwd_ws_kernel<128, ConvFwdBufLoader>`, now exists as two instances (with / '
+                 'without the BatchNorm-statistics tail, §13): together %.1f ms per step at %.1f TFLOP/s = %.3f of the peak.'
+                 % (fam['ms_per_step'], fam['tflops'], fam['frac']))
 state.append('Per-step kernel time by bucket: ' + ', '.join('%s %.1f ms' % (k, v) for k, v in sorted(bk.items(), key=lambda kv: -kv[1])) + '.')
 state.append('Other BASELINE configs at full size on one GPU (`bench.py --config i`, `profiles/%s_bench_configs.jsonl`; the default '
              'run times them too, `other_configs`): ' % TAG +
@@ -88,8 +94,12 @@ pd, pinf, pcb, psp, prf = prev['decode_latency'], prev['inference'], prev['cpu_b
 tab = ['| | round %d | round %d |' % (N - 1, N), '|---|---|---|',
        '| UDA step, DLA-34 + DCNv2 512², 16 + 16 images (the headline, `bench.py`) | %.1f ms = %.1f img/s | **%.1f ms = %.1f img/s** |'
        % (prev['ms_per_step'], prev['value'], line['ms_per_step'], line['value']),
-       '| `roofline` (dominant kernel, fp32 MFMA, peak 157.3 TFLOP/s) | %.1f TF = %.3f | %.1f TF = %.3f |'
-       % (prf['achieved'], prf['frac'], rf['achieved'], rf['frac']),
+       '| `roofline` (dominant kernel by time, fp32 MFMA, peak 157.3 TFLOP/s) | `%s`: %.1f TF = %.3f | `%s`: %.1f TF = %.3f |'
+       % (prf['kernel'].replace('igemm_', ''), prf['achieved'], prf['frac'], rf['kernel'].replace('igemm_', ''), rf['achieved'], rf['frac'])]
+if fam:
+    tab.append('| the forward kernel `igemm_fwd_ws_kernel<128, ConvFwdBuf*>` (rounds 1-4\'s dominant one; two instances since round 5) | %.1f TF = %.3f | %.1f TF = %.3f |'
+               % (prf['achieved'], prf['frac'], fam['tflops'], fam['frac']))
+tab += [
        '| kernel launches per step | %d | %d |' % (prev_launches, launches)]
 for c in cfgs:
     name = c['config']['workload'].split(':')[0]
