@@ -383,12 +383,12 @@ MANIFEST = {
     ],
     # the forward GEMMs that leave BatchNorm statistics with their output (their own loader type, round 5)
     'igemm_fwd_ws_kernel<128, ConvFwdBufStatsLoader, 16>': [
-        'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics',
-        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+        'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics[B4C16H128W128Co128',
+        'tests/test_gpu_fullsize.py::test_full_size_step_properties',
     ],
     'igemm_fwd_ws_kernel<64, ConvFwdBufStatsLoader, 16>': [
-        'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics',
-        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+        'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics[B4C16H128W128Co64',
+        'tests/test_gpu_fullsize.py::test_full_size_step_properties',
     ],
     'igemm_fwd_kernel<32, ConvFwdBufStatsLoader, false>': [
         'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics',

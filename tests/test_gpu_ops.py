@@ -592,6 +592,8 @@ def test_tensors_of_2gib_take_the_pointer_loaders():
 @pytest.mark.parametrize('shape', [
     # B, C, H, W, Co, k, stride, groups      (Co picks the row tile: 128 / 64 / 32 rows -> 64- / 64- / 32-pixel blocks)
     (4, 32, 32, 32, 160, 3, 1, 2), (4, 32, 32, 32, 64, 3, 1, 2), (2, 16, 64, 64, 32, 3, 2, 1), (2, 64, 16, 16, 128, 1, 1, 2),
+    # enough pixel tiles for the 8-wave 128- and 64-row kernels (igemm_fwd_ws_kernel<128 | 64, ConvFwdBufStatsLoader>)
+    (4, 16, 128, 128, 128, 3, 1, 2), (4, 16, 128, 128, 64, 3, 1, 2),
     (1, 16, 12, 12, 48, 3, 1, 1),          # 144 pixels: a partial last tile; no whole blocks per group -> BatchNorm's own pass
     # the LDS-tile kernels of the 3- / 16-channel full-resolution layers: a block = a 64-column piece of an output row
     (2, 3, 24, 72, 16, 7, 1, 2), (2, 16, 20, 64, 16, 3, 1, 1),
