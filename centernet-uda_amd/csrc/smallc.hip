@@ -32,85 +32,79 @@ struct SmallGeom {
     int HR, HC, plane;      // halo rows / cols and the (odd) channel-plane stride of the LDS image
 };
 
-// halo image: Xh[c][hy][hx], hy in [0, HR), hx in [0, HC); input row = oy0*s - ph + hy.
-// Wave w stages rows w, w+4, ... of the C*HR halo rows; lanes run along the row (coalesced, no per-element
-// index arithmetic).
-constexpr int SC_ROWS_PER_WAVE = 24;   // C * HR <= 96 halo rows per tile (checked in smallc_supported)
+// halo image: Xh[c][hy][hx], hy in [0, HR), hx in [0, HC); input row = oy0 - ph + hy (stride 1).  The kernels are
+// instantiated per (square) filter size KH, so the halo geometry is a set of compile-time constants: the staging code is
+// then a straight line of buffer loads and LDS stores with immediate offsets.  (The first version derived (channel, row)
+// of every halo row by a run-time division and guarded every load with a branch: ~100 scalar instructions per row, 24
+// rows per wave and tile -- measured, with the MFMA loop compiled out the 16 -> 16 layer still took 509 of its 723 us.)
+constexpr int SC_ROWS_PER_WAVE = 24;
+template <int KH> struct ScShape {
+    static constexpr int HR = SC_TH - 1 + KH, HC = SC_TW - 1 + KH;
+    static constexpr int NX = HC - 64;                      // halo columns beyond a wave's 64 lanes
+    static constexpr int plane = (HR * HC) | 1;             // odd plane stride: lanes that differ in c hit different banks
+    // channels a wave stages (wid, wid + 4, ...): at most SC_ROWS_PER_WAVE staging registers, and the extra columns of
+    // all its rows in one load -- 4 channels (C <= 16) for 3x3, 1 (C <= 4) for 7x7
+    static constexpr int CPW = SC_ROWS_PER_WAVE / HR < 64 / (HR * NX) ? SC_ROWS_PER_WAVE / HR : 64 / (HR * NX);
+    static constexpr int ROWS = CPW * HR;
+    static_assert(ROWS * NX <= 64, "the extra columns of a wave's rows fit one load");
+};
 
-// The halo rows a wave stages: rows wid, wid + 4, ... < C * HR, two values per lane (columns lane, lane + 64).
-// halo_load() only ISSUES the global loads (into registers); halo_store() writes them to LDS.  The kernels load the
-// NEXT tile's halo before the MFMA loop of the current one, so the global latency is hidden behind the matrix work
-// instead of being paid (twice) per tile between two barriers.
-struct HaloRegs { float v0[SC_ROWS_PER_WAVE], v1[SC_ROWS_PER_WAVE]; };
-__device__ __forceinline__ void halo_load(const SmallGeom& g, const float* __restrict__ xb, int iy0, int ix0, int tid,
-                                          HaloRegs& h) {
-    const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and the compiler knows it: row bases stay scalar)
-    const int rows = g.C * g.HR;
-    const int ixa = ix0 + lane, ixb = ix0 + lane + 64;
-    const bool oka = ixa >= 0 && ixa < g.W, okb = lane + 64 < g.HC && ixb >= 0 && ixb < g.W;
-#pragma unroll
-    for (int i = 0; i < SC_ROWS_PER_WAVE; ++i) {
-        const int row = wid + 4 * i;
-        if (4 * i >= rows) break;                            // (uniform; rows <= 4 * SC_ROWS_PER_WAVE)
-        const int c = row / g.HR, hy = row - c * g.HR;       // wave-uniform
-        const int iy = iy0 + hy;
-        const bool rok = row < rows && iy >= 0 && iy < g.H;
-        const float* src = xb + ((size_t)(rok ? c : 0) * g.H + (rok ? iy : 0)) * g.W;
-        h.v0[i] = (rok && oka) ? src[ixa] : 0.0f;
-        h.v1[i] = (rok && okb) ? src[ixb] : 0.0f;
+// A wave stages the halo rows of channels wid + 4 * cc (cc < CPW): lane = column (one 256-byte load per row), and the
+// NX columns past the 64th of all its rows in ONE more load (lane -> (row slot, column)).  Rows / columns outside the
+// image read 0.0f through the buffer range check (the padding value), no compare on the data path.
+// load() only ISSUES the global loads (into registers); store() writes them to LDS: the forward kernel loads the NEXT
+// tile's halo before the MFMA loop of the current one.
+template <int KH>
+struct HaloStage {
+    using S = ScShape<KH>;
+    struct Regs { float v[S::ROWS]; float vx; };
+    buf_rsrc rs;
+    unsigned va;                 // byte offset of column ix0 + lane inside an input row, or the sentinel
+    unsigned xcol;               // the extra-column lane: byte offset of ITS column, or the sentinel
+    int x_c, x_hy, x_lds;        // ... its channel, halo row and LDS cell (x_lds < 0: lane unused)
+    int lds0;                    // LDS cell of (channel wid, halo row 0, column lane)
+    int wid;
+    __device__ __forceinline__ HaloStage(const SmallGeom& g, const float* xb, int ix0, int tid) {
+        const int lane = tid & 63;
+        wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // (uniform, and the compiler knows it: row terms stay scalar)
+        rs = ig_make_rsrc(xb, (unsigned)((size_t)g.C * g.H * g.W * sizeof(float)));
+        const int ixa = ix0 + lane;
+        va = (ixa >= 0 && ixa < g.W) ? (unsigned)ixa * 4u : IG_BUF_OOB;
+        lds0 = wid * S::plane + lane;
+        const int slot = lane / S::NX, xc = 64 + lane % S::NX;
+        const int cc = slot / S::HR;
+        x_hy = slot - cc * S::HR;
+        x_c = wid + 4 * cc;
+        const int ixx = ix0 + xc;
+        xcol = (ixx >= 0 && ixx < g.W) ? (unsigned)ixx * 4u : IG_BUF_OOB;
+        x_lds = (slot < S::ROWS && x_c < g.C) ? x_c * S::plane + x_hy * S::HC + xc : -1;
+        if (x_lds < 0) xcol = IG_BUF_OOB;
     }
-}
-__device__ __forceinline__ void halo_store(const SmallGeom& g, float* __restrict__ Xh, int tid, const HaloRegs& h) {
-    const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and the compiler knows it: row bases stay scalar)
-    const int rows = g.C * g.HR;
+    __device__ __forceinline__ void load(const SmallGeom& g, int iy0, Regs& r) const {
 #pragma unroll
-    for (int i = 0; i < SC_ROWS_PER_WAVE; ++i) {
-        const int row = wid + 4 * i;
-        if (4 * i >= rows) break;
-        if (row < rows) {
-            const int c = row / g.HR, hy = row - c * g.HR;
-            float* dst = Xh + c * g.plane + hy * g.HC;
-            dst[lane] = h.v0[i];
-            if (lane + 64 < g.HC) dst[lane + 64] = h.v1[i];
-        }
-    }
-}
-// load + store in one go (the weight-gradient kernel: its accumulators leave no room for a prefetched halo).  Global
-// loads are issued in batches of 12 rows before their LDS stores: two round trips of latency per tile instead of
-// one per row, at half the staging registers.
-__device__ __forceinline__ void stage_halo(const SmallGeom& g, const float* __restrict__ xb, int iy0, int ix0,
-                                           float* __restrict__ Xh, int tid) {
-    const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and the compiler knows it: row bases stay scalar)
-    const int rows = g.C * g.HR;
-    constexpr int HB = SC_ROWS_PER_WAVE / 2;
-    const int ixa = ix0 + lane, ixb = ix0 + lane + 64;
-    const bool oka = ixa >= 0 && ixa < g.W, okb = lane + 64 < g.HC && ixb >= 0 && ixb < g.W;
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        if (half * HB * 4 + wid >= rows) break;
-        float v0[HB], v1[HB];
+        for (int cc = 0; cc < S::CPW; ++cc) {
+            const int c = wid + 4 * cc;                       // wave-uniform
 #pragma unroll
-        for (int i = 0; i < HB; ++i) {
-            const int row = wid + 4 * (half * HB + i);
-            const int c = row / g.HR, hy = row - c * g.HR;       // wave-uniform
-            const int iy = iy0 + hy;
-            const bool rok = row < rows && iy >= 0 && iy < g.H;
-            const float* src = xb + ((size_t)(rok ? c : 0) * g.H + (rok ? iy : 0)) * g.W;
-            v0[i] = (rok && oka) ? src[ixa] : 0.0f;
-            v1[i] = (rok && okb) ? src[ixb] : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < HB; ++i) {
-            const int row = wid + 4 * (half * HB + i);
-            if (row < rows) {
-                const int c = row / g.HR, hy = row - c * g.HR;
-                float* dst = Xh + c * g.plane + hy * g.HC;
-                dst[lane] = v0[i];
-                if (lane + 64 < g.HC) dst[lane + 64] = v1[i];
+            for (int hy = 0; hy < S::HR; ++hy) {
+                const int iy = iy0 + hy;
+                const bool ok = c < g.C && iy >= 0 && iy < g.H;
+                r.v[cc * S::HR + hy] = ig_buf_load(rs, ok ? va : IG_BUF_OOB, ok ? (unsigned)((c * g.H + iy) * g.W) * 4u : 0u);
             }
         }
+        const int iy = iy0 + x_hy;
+        const bool ok = iy >= 0 && iy < g.H;
+        r.vx = ig_buf_load(rs, ok ? xcol + (unsigned)((x_c * g.H + iy) * g.W) * 4u : IG_BUF_OOB, 0u);
     }
-}
+    __device__ __forceinline__ void store(const SmallGeom& g, float* __restrict__ Xh, const Regs& r) const {
+#pragma unroll
+        for (int cc = 0; cc < S::CPW; ++cc) {
+            if (wid + 4 * cc >= g.C) break;                   // (uniform)
+#pragma unroll
+            for (int hy = 0; hy < S::HR; ++hy) Xh[lds0 + 4 * cc * S::plane + hy * S::HC] = r.v[cc * S::HR + hy];
+        }
+        if (x_lds >= 0) Xh[x_lds] = r.vx;
+    }
+};
 
 // offset of GEMM row k = tap*C + c inside the halo image (relative to the pixel's top-left halo cell)
 __device__ __forceinline__ int k_offset(const SmallGeom& g, int k) {
@@ -129,7 +123,7 @@ constexpr int SC_YLD = SC_TW + 4;   // row stride of the per-wave output staging
 #ifndef SC_FWD_OCC
 #define SC_FWD_OCC 2
 #endif
-template <int MT>
+template <int MT, int KH>
 __global__ __launch_bounds__(IG_THREADS, SC_FWD_OCC) void smallc_fwd_kernel(SmallGeom g, const float* __restrict__ x,
                                                                const float* __restrict__ Wp,
                                                                const int* __restrict__ koff_tab,
@@ -156,23 +150,25 @@ __global__ __launch_bounds__(IG_THREADS, SC_FWD_OCC) void smallc_fwd_kernel(Smal
     // whole 256-byte rows
     float* Ys = smem + g.C * g.plane + 16 + wid * (16 * MT * SC_YLD);
     const bool vec = (g.Wo & 3) == 0;
-    HaloRegs halo;
-    halo_load(g, xb, (blockIdx.y * SC_NV) * SC_TH - g.ph, ox0 - g.pw, tid, halo);
+    using S = ScShape<KH>;
+    const HaloStage<KH> hs(g, xb, ox0 - g.pw, tid);
+    typename HaloStage<KH>::Regs halo;
+    hs.load(g, (blockIdx.y * SC_NV) * SC_TH - g.ph, halo);
 #pragma unroll 1
     for (int vt = 0; vt < SC_NV; ++vt) {
     const int oy0 = (blockIdx.y * SC_NV + vt) * SC_TH;
     if (oy0 >= g.Ho) break;
     __syncthreads();                                // the previous tile's fragment reads are done
-    halo_store(g, Xh, tid, halo);
+    hs.store(g, Xh, halo);
     __syncthreads();
     if (vt + 1 < SC_NV && oy0 + SC_TH < g.Ho)       // next tile's halo: in flight under this tile's MFMAs
-        halo_load(g, xb, (oy0 + SC_TH) - g.ph, ox0 - g.pw, tid, halo);
+        hs.load(g, (oy0 + SC_TH) - g.ph, halo);
 
     const int oy = oy0 + wid;                       // one output row per wave
     float* yb = y + (size_t)b * g.Co * HoWo + (size_t)oy * g.Wo;
     if (oy < g.Ho) {
         constexpr int NP = SC_TW / 16;                  // four 16-pixel tiles along the row, processed together
-        const int pbase0 = wid * g.HC + il;          // (stride 1 only: smallc_supported)
+        const int pbase0 = wid * S::HC + il;         // (stride 1 only: smallc_supported)
         f32x4 acc[MT][NP];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -284,7 +280,7 @@ __global__ __launch_bounds__(IG_THREADS, SC_FWD_OCC) void smallc_fwd_kernel(Smal
 // ---------------------------------------------------------------------------------------------
 constexpr int SC_MAXNT = SC_MAXK / 16;   // column tiles of 16 k
 
-template <int MT>
+template <int MT, int KH>
 __global__ __launch_bounds__(IG_THREADS) void smallc_wgrad_kernel(SmallGeom g, const float* __restrict__ x,
                                                                  const float* __restrict__ gy,
                                                                  const int* __restrict__ koff_tab,
@@ -300,6 +296,7 @@ __global__ __launch_bounds__(IG_THREADS) void smallc_wgrad_kernel(SmallGeom g, c
     const float* xb = x + (size_t)b * g.C * g.H * g.W;
     const float* gb = gy + (size_t)b * g.Co * HoWo;
     const int ntiles = Kp16 / 16;
+    const HaloStage<KH> hs(g, xb, ox0 - g.pw, tid);
 
     // this lane's column k = nt*16 + il of every column tile -> halo offset (B operand, lanes = columns)
     int koff[SC_MAXNT];
@@ -317,7 +314,11 @@ __global__ __launch_bounds__(IG_THREADS) void smallc_wgrad_kernel(SmallGeom g, c
     const int oy0 = (blockIdx.y * SC_NV + vt) * SC_TH;
     if (oy0 >= g.Ho) break;
     __syncthreads();
-    stage_halo(g, xb, oy0 - g.ph, ox0 - g.pw, Xh, tid);
+    {
+        typename HaloStage<KH>::Regs halo;
+        hs.load(g, oy0 - g.ph, halo);
+        hs.store(g, Xh, halo);
+    }
     // gy tile: Gs[o][row*64 + col], zero outside the image / beyond Co; wave w stages rows (o, ty) w, w+4, ...
     {
         float gv[4 * MT * SC_TH];
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(IG_THREADS) void smallc_wgrad_kernel(SmallGeom g, c
 #pragma unroll 2
     for (int ps = 0; ps < SC_TW / 4; ++ps) {
         const int px = ps * 4 + kq;                       // this lane's pixel (k index of the MFMA)
-        const int pbase = wid * g.HC + px;
+        const int pbase = wid * ScShape<KH>::HC + px;
         float a[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) a[m] = Gs[(m * 16 + il) * GLD + wid * SC_TW + px];
@@ -446,8 +447,10 @@ bool fill_small(SmallGeom& g, int B, int C, int H, int W, int Co, int kh, int kw
 // ---- entry points used by conv.hip -----------------------------------------------------------------
 bool smallc_supported(int C, int Co, int kh, int kw, int sh, int sw) {
     // stride 2 needs a halo tile of ~75 KB (one workgroup per CU): measured slower than the generic kernels
-    return sh == 1 && sw == 1 && C <= 16 && Co <= 32 && C * kh * kw <= SC_MAXK - 12 &&
-           C * (SC_TH - 1 + kh) <= 4 * SC_ROWS_PER_WAVE && SC_TW - 1 + kw <= 128;
+    // (square 3x3 / 7x7 filters: the halo geometry is compiled in, ScShape)
+    const int cpw = (C + 3) / 4;
+    return sh == 1 && sw == 1 && kh == kw && (kh == 3 || kh == 7) && C <= 16 && Co <= 32 && C * kh * kw <= SC_MAXK - 12 &&
+           cpw <= (kh == 3 ? ScShape<3>::CPW : ScShape<7>::CPW);
 }
 size_t smallc_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int s, int ph, int pw) {
     SmallGeom g;
@@ -494,10 +497,13 @@ int smallc_forward(const float* x, const float* w, const float* bias, float* y, 
     const dim3 grid(ceil_div(g.Wo, SC_TW), ceil_div(g.Ho, SC_TH * SC_NV), B);
     ProfScope prof(st);
     prof.name("smallc_fwd_kernel<%d>", mt);
-    if (mt == 1)
-        CNUDA_LAUNCH(smallc_fwd_kernel<1>, grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope, stats);
-    else
-        CNUDA_LAUNCH(smallc_fwd_kernel<2>, grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope, stats);
+    CNUDA_REQUIRE(kh == kw && (kh == 3 || kh == 7) && g.plane == (kh == 3 ? ScShape<3>::plane : ScShape<7>::plane),
+                  "smallc_forward: filter size without a compiled halo geometry");
+#define CNUDA_SC_FWD(MTV, KHV) \
+    CNUDA_LAUNCH((smallc_fwd_kernel<MTV, KHV>), grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope, stats)
+    if (mt == 1) { if (kh == 3) CNUDA_SC_FWD(1, 3); else CNUDA_SC_FWD(1, 7); }
+    else         { if (kh == 3) CNUDA_SC_FWD(2, 3); else CNUDA_SC_FWD(2, 7); }
+#undef CNUDA_SC_FWD
     return check_launch("smallc_forward");
 }
 
@@ -518,21 +524,23 @@ int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, in
     const size_t stage = (size_t)(g.C * g.plane + 16) + (size_t)16 * mt * (SC_TH * SC_TW + 1);
     const size_t red = (size_t)4 * 16 * mt * Kp16;
     const size_t lds = (stage > red ? stage : red) * sizeof(float);
+    CNUDA_REQUIRE(kh == kw && (kh == 3 || kh == 7) && g.plane == (kh == 3 ? ScShape<3>::plane : ScShape<7>::plane),
+                  "smallc_backward_weight: filter size without a compiled halo geometry");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(smallc_wgrad_kernel<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(smallc_wgrad_kernel<2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const void* fns[] = {reinterpret_cast<const void*>(smallc_wgrad_kernel<1, 3>), reinterpret_cast<const void*>(smallc_wgrad_kernel<2, 3>),
+                             reinterpret_cast<const void*>(smallc_wgrad_kernel<1, 7>), reinterpret_cast<const void*>(smallc_wgrad_kernel<2, 7>)};
+        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     {
         ProfScope prof(st);
         prof.name("smallc_wgrad_kernel<%d>", mt);
-        if (mt == 1)
-            CNUDA_LAUNCH(smallc_wgrad_kernel<1>, grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16);
-        else
-            CNUDA_LAUNCH(smallc_wgrad_kernel<2>, grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16);
+#define CNUDA_SC_WG(MTV, KHV) \
+    CNUDA_LAUNCH((smallc_wgrad_kernel<MTV, KHV>), grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16)
+        if (mt == 1) { if (kh == 3) CNUDA_SC_WG(1, 3); else CNUDA_SC_WG(1, 7); }
+        else         { if (kh == 3) CNUDA_SC_WG(2, 3); else CNUDA_SC_WG(2, 7); }
+#undef CNUDA_SC_WG
     }
     if (int rc = check_launch("smallc_backward_weight")) return rc;
     const int slab_elems = 16 * mt * Kp16;

@@ -26,7 +26,9 @@ def timeit(kind, fn, n=3):
     (name,d),=r.items()
     return d['ms']/d['launches'], d['flops']/d['launches'], name
 print('%-18s %28s %28s %28s'%('layer','fwd ms / TF','dgrad ms / TF','wgrad ms / TF'))
+ONLY=os.environ.get('CONV_BENCH_ONLY')
 for name,C,H,Co,k,s in shapes:
+    if ONLY and not any(name.startswith(o) for o in ONLY.split(',')): continue
     x=torch.randn(B,C,H,H,device=dev); w=torch.randn(Co,C,k,k,device=dev)*0.05
     x.requires_grad_(True); w.requires_grad_(True)
     y=ops.conv2d(x,w,None,s,k//2); gy=torch.randn_like(y)
