@@ -278,10 +278,11 @@ __global__ __launch_bounds__(IG_THREADS, SC_FWD_OCC) void smallc_fwd_kernel(Smal
 // ---------------------------------------------------------------------------------------------
 // weight gradient.  grid = (tiles_x, tiles_y, B); slab per workgroup: [16*MT][Kp16] (Kp16 = K padded to 16)
 // ---------------------------------------------------------------------------------------------
-constexpr int SC_MAXNT = SC_MAXK / 16;   // column tiles of 16 k
-
-template <int MT, int KH>
-__global__ __launch_bounds__(IG_THREADS) void smallc_wgrad_kernel(SmallGeom g, const float* __restrict__ x,
+// NT: column tiles (of 16 k) the instance computes -- >= Kp16 / 16; tiles past the real ones read halo cell 0 and are
+// never written out.  A compile-time count keeps the MFMA loop free of branches: the first version tested `nt < ntiles`
+// per MFMA, which serialised every MFMA behind its own LDS read (read, wait, multiply; nine times per k-step).
+template <int MT, int KH, int NT>
+__global__ __launch_bounds__(IG_THREADS, (MT == 1 ? 3 : 2)) void smallc_wgrad_kernel(SmallGeom g, const float* __restrict__ x,
                                                                  const float* __restrict__ gy,
                                                                  const int* __restrict__ koff_tab,
                                                                  float* __restrict__ slabs, int Kp16) {
@@ -298,62 +299,88 @@ __global__ __launch_bounds__(IG_THREADS) void smallc_wgrad_kernel(SmallGeom g, c
     const int ntiles = Kp16 / 16;
     const HaloStage<KH> hs(g, xb, ox0 - g.pw, tid);
 
-    // this lane's column k = nt*16 + il of every column tile -> halo offset (B operand, lanes = columns)
-    int koff[SC_MAXNT];
+    // this lane's column k = nt*16 + il of every column tile -> halo cell of its pixel 0 (B operand, lanes = columns):
+    // row `wid` of the tile, pixel kq of a k-step
+    int kaddr[NT];
 #pragma unroll
-    for (int nt = 0; nt < SC_MAXNT; ++nt) koff[nt] = nt < ntiles ? koff_tab[nt * 16 + il] : 0;
+    for (int nt = 0; nt < NT; ++nt) kaddr[nt] = (nt < ntiles ? koff_tab[nt * 16 + il] : 0) + wid * ScShape<KH>::HC + kq;
 
-    f32x4 acc[MT][SC_MAXNT];
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int nt = 0; nt < SC_MAXNT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 1
-    for (int vt = 0; vt < SC_NV; ++vt) {
-    const int oy0 = (blockIdx.y * SC_NV + vt) * SC_TH;
-    if (oy0 >= g.Ho) break;
-    __syncthreads();
-    {
-        typename HaloStage<KH>::Regs halo;
+    // staging registers of one tile: the halo rows and the grad_y rows (o, ty) = wid, wid + 4, ... of this wave.  Both are
+    // buffer loads issued together (one exposed round trip per tile at most); with one row tile of output channels
+    // (MT == 1) the NEXT tile's loads go out before this tile's MFMA loop and the round trip hides behind it.
+#ifndef SC_WG_PREFETCH
+#define SC_WG_PREFETCH 1
+#endif
+    constexpr bool PF = MT == 1 && SC_WG_PREFETCH;
+    typename HaloStage<KH>::Regs halo;
+    float gv[4 * MT * SC_TH];
+    const buf_rsrc grs = ig_make_rsrc(gb, (unsigned)((size_t)g.Co * HoWo * sizeof(float)));
+    const unsigned gva = ox0 + lane < g.Wo ? (unsigned)(ox0 + lane) * 4u : IG_BUF_OOB;
+    auto tile_load = [&](int oy0) {
         hs.load(g, oy0 - g.ph, halo);
-        hs.store(g, Xh, halo);
-    }
-    // gy tile: Gs[o][row*64 + col], zero outside the image / beyond Co; wave w stages rows (o, ty) w, w+4, ...
-    {
-        float gv[4 * MT * SC_TH];
 #pragma unroll
         for (int i = 0; i < 4 * MT * SC_TH; ++i) {
             const int row = wid + 4 * i;
             const int o = row / SC_TH, ty = row - o * SC_TH;     // wave-uniform
-            const int oy = oy0 + ty, ox = ox0 + lane;
-            gv[i] = (o < g.Co && oy < g.Ho && ox < g.Wo) ? gb[(size_t)o * HoWo + (size_t)oy * g.Wo + ox] : 0.0f;
+            const int oy = oy0 + ty;
+            const bool ok = o < g.Co && oy < g.Ho;
+            gv[i] = ig_buf_load(grs, ok ? gva : IG_BUF_OOB, ok ? (unsigned)(o * HoWo + oy * g.Wo) * 4u : 0u);
         }
+    };
+    if (PF) tile_load(blockIdx.y * SC_NV * SC_TH);
+#pragma unroll 1
+    for (int vt = 0; vt < SC_NV; ++vt) {
+    const int oy0 = (blockIdx.y * SC_NV + vt) * SC_TH;
+    if (oy0 >= g.Ho) break;
+    const bool more = vt + 1 < SC_NV && oy0 + SC_TH < g.Ho;
+    __syncthreads();                                    // the previous tile's fragment reads are done
+    if (!PF) tile_load(oy0);
+    hs.store(g, Xh, halo);
+    // gy tile: Gs[o][row*64 + col], zero outside the image / beyond Co
 #pragma unroll
-        for (int i = 0; i < 4 * MT * SC_TH; ++i) {
-            const int row = wid + 4 * i;
-            const int o = row / SC_TH, ty = row - o * SC_TH;
-            Gs[o * GLD + ty * SC_TW + lane] = gv[i];
-        }
+    for (int i = 0; i < 4 * MT * SC_TH; ++i) {
+        const int row = wid + 4 * i;
+        const int o = row / SC_TH, ty = row - o * SC_TH;
+        Gs[o * GLD + ty * SC_TW + lane] = gv[i];
     }
     __syncthreads();
+    if (PF && more) tile_load(oy0 + SC_TH);
 
-    // wave `wid` reduces over row `wid` of the tile: 64 pixels = 16 MFMA k-steps of 4 pixels
-#pragma unroll 2
-    for (int ps = 0; ps < SC_TW / 4; ++ps) {
-        const int px = ps * 4 + kq;                       // this lane's pixel (k index of the MFMA)
-        const int pbase = wid * ScShape<KH>::HC + px;
-        float a[MT];
+    // wave `wid` reduces over row `wid` of the tile: 64 pixels = 16 MFMA k-steps of 4 pixels (lane's pixel 4 ps + kq), in an
+    // explicit two-deep pipeline: the fragments of step ps + 1 are read while the MFMAs of step ps run
+    {
+        const float* ga = Gs + il * GLD + wid * SC_TW + kq;
+        float a0[MT], b0[NT], a1[MT], b1[NT];
+        auto frag = [&](int ps, float (&fa)[MT], float (&fb)[NT]) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = Gs[(m * 16 + il) * GLD + wid * SC_TW + px];
+            for (int m = 0; m < MT; ++m) fa[m] = ga[m * 16 * GLD + ps * 4];
 #pragma unroll
-        for (int nt = 0; nt < SC_MAXNT; ++nt) {
-            if (nt < ntiles) {
-                const float bv = Xh[koff[nt] + pbase];
+            for (int nt = 0; nt < NT; ++nt) fb[nt] = Xh[kaddr[nt] + ps * 4];
+        };
+        auto mma = [&](const float (&fa)[MT], const float (&fb)[NT]) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[m][nt], 0, 0, 0);
-            }
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m], fb[nt], acc[m][nt], 0, 0, 0);
+        };
+        frag(0, a0, b0);
+#pragma unroll
+        for (int ps = 0; ps < SC_TW / 4; ps += 2) {
+            frag(ps + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ps + 2 < SC_TW / 4) frag(ps + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     }
@@ -364,7 +391,7 @@ __global__ __launch_bounds__(IG_THREADS) void smallc_wgrad_kernel(SmallGeom g, c
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int nt = 0; nt < SC_MAXNT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
             if (nt < ntiles)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -526,20 +553,28 @@ int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, in
     const size_t lds = (stage > red ? stage : red) * sizeof(float);
     CNUDA_REQUIRE(kh == kw && (kh == 3 || kh == 7) && g.plane == (kh == 3 ? ScShape<3>::plane : ScShape<7>::plane),
                   "smallc_backward_weight: filter size without a compiled halo geometry");
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void* fns[] = {reinterpret_cast<const void*>(smallc_wgrad_kernel<1, 3>), reinterpret_cast<const void*>(smallc_wgrad_kernel<2, 3>),
-                             reinterpret_cast<const void*>(smallc_wgrad_kernel<1, 7>), reinterpret_cast<const void*>(smallc_wgrad_kernel<2, 7>)};
-        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    // column tiles the instance computes: all of a 16-channel 3x3 (9) / a 3-channel 7x7 (10) filter, or 4 for the small
+    // shapes (K <= 64)
+    const int nt_real = Kp16 / 16, nt_full = kh == 3 ? 9 : 10;
+    CNUDA_REQUIRE(nt_real <= nt_full, "smallc_backward_weight: K exceeds the compiled column tiles");
     {
         ProfScope prof(st);
         prof.name("smallc_wgrad_kernel<%d>", mt);
-#define CNUDA_SC_WG(MTV, KHV) \
-    CNUDA_LAUNCH((smallc_wgrad_kernel<MTV, KHV>), grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16)
-        if (mt == 1) { if (kh == 3) CNUDA_SC_WG(1, 3); else CNUDA_SC_WG(1, 7); }
-        else         { if (kh == 3) CNUDA_SC_WG(2, 3); else CNUDA_SC_WG(2, 7); }
+#define CNUDA_SC_WG(MTV, KHV, NTV) do {                                                                              \
+        static bool raised = false;                                                                                   \
+        if (!raised) {                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(smallc_wgrad_kernel<MTV, KHV, NTV>),              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
+            raised = true;                                                                                            \
+        }                                                                                                             \
+        CNUDA_LAUNCH((smallc_wgrad_kernel<MTV, KHV, NTV>), grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16); \
+    } while (0)
+#define CNUDA_SC_WG_KH(MTV) do {                                                                                     \
+        if (kh == 3) { if (nt_real <= 4) CNUDA_SC_WG(MTV, 3, 4); else CNUDA_SC_WG(MTV, 3, 9); }                       \
+        else         { if (nt_real <= 4) CNUDA_SC_WG(MTV, 7, 4); else CNUDA_SC_WG(MTV, 7, 10); }                      \
+    } while (0)
+        if (mt == 1) CNUDA_SC_WG_KH(1); else CNUDA_SC_WG_KH(2);
+#undef CNUDA_SC_WG_KH
 #undef CNUDA_SC_WG
     }
     if (int rc = check_launch("smallc_backward_weight")) return rc;

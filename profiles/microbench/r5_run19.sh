@@ -1,3 +1,3 @@
 R=$GRAFT_REPO_ROOT
 timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_fuzz.py -x -q 2>&1 | tail -3
-CONV_BENCH_B=32 CONV_BENCH_ONLY="stem,l0" timeout 120 python profiles/microbench/conv_layers.py 2>&1 | grep -E "stem|l0"
+for v in wgpf0 wgpf1; do echo "== $v"; CONV_BENCH_B=32 CONV_BENCH_ONLY="stem,l0" ABL_LIB=$R/abl/lib_$v.so timeout 120 python profiles/microbench/conv_layers.py 2>&1 | grep -E "stem|l0"; done
