@@ -15,6 +15,7 @@
 #include <algorithm>
 #include "igemm.cuh"
 #include "hconv.cuh"
+#include "hwgrad.cuh"
 #include "igemm_host.h"
 
 namespace cnuda {
@@ -645,8 +646,18 @@ int pick_bm(int M, long long N) {
     return bm;
 }
 
+// hwgrad_kernel (hwgrad.cuh) takes the weight gradient of the narrow 3x3 convolutions (the DCN offset / mask layers)
+bool hwgrad_ok(const ConvGeom& g) {
+    static const bool on = !(getenv("CNUDA_HWGRAD") && getenv("CNUDA_HWGRAD")[0] == '0');
+    return on && matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
+           g.Co <= 32 && g.C % 16 == 0 && (g.W == 16 || g.W == 32 || g.W == 64 || g.W == 128) &&
+           ((long long)g.H * g.W) % HW_BN == 0 && wgrad_buffer_ok(g);
+}
+
 struct ConvPlan {
     int T;
+    bool hw;                  // weight gradient on halo tiles (hwgrad_kernel): Z = pixel-tile splits per channel group
+    int hw_tiles, hw_tiles_per_split;
     int Kf, Kpf, bmf, Mpf;   // forward:  K = T*C,  M = Co
     int Kd, Kpd, bmd, Mpd;   // dgrad:    K = T*Co, M = C
     int Mpw, Jp, Z, wbm, wbj; // wgrad slabs and tile shape
@@ -675,6 +686,17 @@ ConvPlan make_plan(const ConvGeom& g) {
     const long long z = wgrad_splits(tiles, q.wbm, q.wbj, (q.Nf + WG_BP - 1) / WG_BP);
     q.pix_per_split = ((q.Nf + z - 1) / z + WG_BP - 1) / WG_BP * WG_BP;
     q.Z = (int)((q.Nf + q.pix_per_split - 1) / q.pix_per_split);
+    q.hw = hwgrad_ok(g);
+    q.hw_tiles = q.hw_tiles_per_split = 0;
+    if (q.hw) {
+        // (C / 16) channel groups x Z splits of the 256-pixel tiles: two workgroups per CU, at least one tile each
+        q.hw_tiles = (int)(q.Nf / HW_BN);
+        const int groups = g.C / 16;
+        int zz = std::max(1, 512 / groups);
+        if (zz > q.hw_tiles) zz = q.hw_tiles;
+        q.hw_tiles_per_split = (q.hw_tiles + zz - 1) / zz;
+        q.Z = (q.hw_tiles + q.hw_tiles_per_split - 1) / q.hw_tiles_per_split;
+    }
     q.fwd_bytes = carve_bytes(ig_a_bytes(q.Kpf, q.Mpf), 1) + 256;
     q.dgrad_bytes = carve_bytes(ig_a_bytes(q.Kpd, q.Mpd), 1) + 256;
     // (slabs, then the bias row sums per split: [Z][Mpw] -- never less than the [Co][B] scratch of the channel-sum kernels)
@@ -1102,7 +1124,24 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
     // bias gradient: row sums of grad_y per split from the GEMM's own staging registers, summed with the slabs
     float* bsl = grad_bias ? cv.take<float>((size_t)q.Z * q.Mpw) : nullptr;
     ConvWParams p{g, x, grad_y};
-    {
+    if (q.hw) {
+        ProfScope prof(st);
+        prof.name("hwgrad_kernel<%d>", W);
+        const HwParams hp{x, grad_y, B, C, H, Cout, q.hw_tiles, q.hw_tiles_per_split};
+        const dim3 grid(C / 16, q.Z), blk(IG_THREADS);
+#define CNUDA_HWGRAD(WV) do {                                                                                        \
+        const size_t lds = HwShape<WV>::lds_floats * sizeof(float);                                                   \
+        static bool raised = false;                                                                                   \
+        if (lds > 64 * 1024 && !raised) {                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hwgrad_kernel<WV>),                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
+            raised = true;                                                                                            \
+        }                                                                                                             \
+        CNUDA_LAUNCH((hwgrad_kernel<WV>), grid, blk, lds, st, hp, slabs, q.Mpw, q.Jp, bsl);                           \
+    } while (0)
+        if (W == 128) CNUDA_HWGRAD(128); else if (W == 64) CNUDA_HWGRAD(64); else if (W == 32) CNUDA_HWGRAD(32); else CNUDA_HWGRAD(16);
+#undef CNUDA_HWGRAD
+    } else {
         ProfScope prof(st);
         const dim3 grid(q.Jp / q.wbj, q.Mpw / q.wbm, q.Z), blk(IG_THREADS);
         const bool fast = C % 64 == 0;

@@ -1,0 +1,214 @@
+// Halo-tile weight gradient for 3x3 / stride 1 / padding 1 convolutions with few output channels (Co <= 32: the 27-channel
+// offset / mask convolutions of the 16 DCN layers, libs/DCNv2/dcn_v2.py:104-110) on the fp32 MFMA.
+//
+//   gw[o][c][r][s] = sum over (b, y, x) of  gy[b][o][y][x] * x[b][c][y + r - 1][x + s - 1]
+//
+// The im2col-style kernel (igemm_wgrad_kernel<., 32, 128>) gathers every tap's column tile from global memory: nine
+// 4-byte loads of (nearly) the same input element, each feeding ONE 32-row MFMA tile -- 20 loads and 20 LDS stores per
+// thread for 16 MFMAs per wave, 59-66 TFLOP/s.  Here a workgroup owns a group of 16 input channels and a range of
+// 256-pixel tiles (full image rows, W <= 128): per tile it stages the group's INPUT rows once with their one-pixel halo
+// (16-byte loads) and the grad_y tile [32][256] once, and every wave reduces a quarter of the tile's pixels for all nine
+// taps on v_mfma_f32_16x16x4_f32 (rows = output channels, two tiles of 16; columns = the 16 channels; k = 4 consecutive
+// pixels): the tap only shifts the LDS address of the B fragment.  One A read serves nine taps, one B read two row tiles:
+// 11 LDS reads per 18 MFMAs, no global gather at all.  The four waves' partial sums meet through LDS in a fixed order
+// (wave 0 + 1 + 2 + 3) and the workgroup writes its 32 x 144 block of the split's slab; slab_reduce_* adds the splits
+// (bitwise reproducible, no float atomics) -- the slab layout, the bias row sums and the reduction launch are those of
+// igemm_wgrad_kernel.
+//
+// Host-side conditions (conv.hip hwgrad_ok): 3x3, stride 1, padding 1, Co <= 32, C % 16 == 0, W in {16, 32, 64, 128},
+// H * W % 256 == 0, both tensors below 2 GiB, f32 matrix mode.
+#pragma once
+#include "igemm.cuh"
+
+namespace cnuda {
+
+constexpr int HW_BN = 256;                       // pixels per tile
+template <int W> struct HwShape {
+    static constexpr int TR = HW_BN / W;         // image rows per tile
+    // LDS row: image column x at x + 4 (16-byte aligned interior), the halo columns at 3 and W + 4
+    static constexpr int RS = W + 8;
+    // channel-plane stride == 2 (mod 32): a B fragment read has lanes (pixel kq, channel il) -> cell il * PL + kq + const,
+    // and the 32 lanes of a half-wave (kq in {0, 1}) then fall on 32 different banks.  Same for the grad_y rows.
+    static constexpr int PL = ((TR + 2) * RS + 29) / 32 * 32 + 2;
+    static constexpr int GLD = HW_BN + 2;
+    static constexpr int CPR = W / 4, CPP = (TR + 2) * CPR, XCELLS = 16 * CPP;      // 16-byte cells per row / plane / group
+    static constexpr int XPER = (XCELLS + IG_THREADS - 1) / IG_THREADS;
+    static constexpr int GPER = 32 * (HW_BN / 4) / IG_THREADS;                       // 8
+    static constexpr size_t lds_floats = (size_t)16 * PL + (size_t)32 * GLD;
+    static_assert(PL % 32 == 2 && PL >= (TR + 2) * RS && GLD % 32 == 2, "bank layout");
+    static_assert(32 * 146 <= (int)lds_floats, "the cross-wave reduction reuses the staging area");
+};
+
+struct HwParams {
+    const float* x;         // [B][C][H][W]
+    const float* gy;        // [B][Co][H][W]
+    int B, C, H, Co;
+    int n_tiles, tiles_per_split;
+};
+
+template <int W>
+__global__ __launch_bounds__(IG_THREADS, 2) void hwgrad_kernel(HwParams p, float* __restrict__ slabs, int Mp, int Jp,
+                                                               float* __restrict__ bslab) {
+    using S = HwShape<W>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Hs = smem;                          // [16][PL]
+    float* const Gs = smem + 16 * S::PL;             // [32][GLD]
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, il = lane & 15;
+    const int grp = blockIdx.x, z = blockIdx.y;
+    const int HWp = p.H * W, tiles_per_image = HWp / HW_BN;
+    const int t0 = z * p.tiles_per_split;
+    const int t1 = t0 + p.tiles_per_split < p.n_tiles ? t0 + p.tiles_per_split : p.n_tiles;
+    const buf_rsrc rx = ig_make_rsrc(p.x, (unsigned)((size_t)p.B * p.C * HWp * sizeof(float)));
+    const buf_rsrc rg = ig_make_rsrc(p.gy, (unsigned)((size_t)p.B * p.Co * HWp * sizeof(float)));
+
+    // input cells of this thread: byte offset relative to (image, channel group, tile row 0) -- negative for the row above
+    // the tile, so the tile's row offset is added per lane and only the non-negative (image, group) term is the scalar
+    // offset -- LDS cell, and whether the cell lies in the row above / below the tile (those may leave the image: decided
+    // per tile by two scalar flags)
+    unsigned xv[S::XPER];
+    int xl[S::XPER], xedge[S::XPER];
+#pragma unroll
+    for (int i = 0; i < S::XPER; ++i) {
+        const int e = tid + i * IG_THREADS;
+        xv[i] = IG_BUF_OOB; xl[i] = -1; xedge[i] = 0;
+        if (e < S::XCELLS) {
+            const int c = e / S::CPP, rem = e - c * S::CPP, row = rem / S::CPR, q = rem - row * S::CPR;
+            xv[i] = (unsigned)((c * HWp + (row - 1) * W + 4 * q) * (int)sizeof(float));      // (row 0: one row above the tile)
+            xl[i] = c * S::PL + row * S::RS + 4 + 4 * q;
+            xedge[i] = row == 0 ? 1 : (row == S::TR + 1 ? 2 : 0);
+        }
+    }
+    // grad_y cells: rows wid, wid + 4, ... (wave-uniform), lane = 16-byte cell of the 256-pixel row
+    const unsigned gvoff = (unsigned)(lane * 16);
+    // the halo columns left and right of the image are zero for every tile: written once
+    for (int e = tid; e < 16 * (S::TR + 2) * 2; e += IG_THREADS) {
+        const int side = e & 1, cr = e >> 1, c = cr / (S::TR + 2), row = cr - c * (S::TR + 2);
+        Hs[c * S::PL + row * S::RS + (side ? W + 4 : 3)] = 0.0f;
+    }
+
+    f32x4 acc[2][9];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient (bslab != nullptr): row sums of grad_y from the staging registers, by the workgroups of channel group 0
+    const bool do_bias = bslab != nullptr && grp == 0;
+    float bs[S::GPER];
+#pragma unroll
+    for (int i = 0; i < S::GPER; ++i) bs[i] = 0.0f;
+
+    f32x4 xr[S::XPER], gr[S::GPER];
+    auto tile_load = [&](int t) {
+        const int b = t / tiles_per_image, y0 = (t - b * tiles_per_image) * S::TR;
+        const bool top_ok = y0 > 0, bot_ok = y0 + S::TR < p.H;
+        const unsigned xs = (unsigned)(((b * p.C + grp * 16) * HWp) * (int)sizeof(float));
+        const unsigned ys = (unsigned)(y0 * W * (int)sizeof(float));
+#pragma unroll
+        for (int i = 0; i < S::XPER; ++i) {
+            const bool out = xl[i] < 0 || (xedge[i] == 1 && !top_ok) || (xedge[i] == 2 && !bot_ok);
+            xr[i] = ig_buf_load4(rx, out ? IG_BUF_OOB : xv[i] + ys, xs);
+        }
+#pragma unroll
+        for (int i = 0; i < S::GPER; ++i) {
+            const int m = wid + 4 * i;
+            const bool ok = m < p.Co;
+            gr[i] = ig_buf_load4(rg, ok ? gvoff : IG_BUF_OOB,
+                                 ok ? (unsigned)(((b * p.Co + m) * HWp + y0 * W) * (int)sizeof(float)) : 0u);
+        }
+    };
+    auto tile_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < S::XPER; ++i)
+            if (xl[i] >= 0) {        // (plane stride == 2 mod 4: 8-byte aligned cells)
+                *reinterpret_cast<float2*>(Hs + xl[i]) = make_float2(xr[i][0], xr[i][1]);
+                *reinterpret_cast<float2*>(Hs + xl[i] + 2) = make_float2(xr[i][2], xr[i][3]);
+            }
+#pragma unroll
+        for (int i = 0; i < S::GPER; ++i) {
+            float* d = Gs + (wid + 4 * i) * S::GLD + 4 * lane;
+            *reinterpret_cast<float2*>(d) = make_float2(gr[i][0], gr[i][1]);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(gr[i][2], gr[i][3]);
+            if (do_bias) bs[i] += (gr[i][0] + gr[i][1]) + (gr[i][2] + gr[i][3]);
+        }
+    };
+
+    // wave `wid` reduces pixels [64 wid, 64 wid + 64) of the tile: 16 k-steps of 4 pixels.  Pixel 64 wid sits at
+    // (row, column) = (64 wid / W, 64 wid % W); step ks moves on by 4 ks pixels -- a compile-time (row, column) delta.
+    const int prow = (64 * wid) / W, pcol = (64 * wid) % W;
+    const float* const bbase = Hs + il * S::PL + prow * S::RS + pcol + 3 + kq;      // tap (0, 0) of pixel kq of step 0
+    const float* const abase = Gs + il * S::GLD + 64 * wid + kq;
+
+    if (t0 < t1) tile_load(t0);
+    for (int t = t0; t < t1; ++t) {
+        __syncthreads();                 // the previous tile's fragment reads are done
+        tile_store();
+        __syncthreads();
+        if (t + 1 < t1) tile_load(t + 1);          // in flight under this tile's MFMAs
+        float a0[2], b0[9], a1[2], b1[9];
+        auto frag = [&](int ks, float (&fa)[2], float (&fb)[9]) {
+            const int d = ((4 * ks) / W) * S::RS + (4 * ks) % W;      // (compile-time: ks is unrolled)
+            fa[0] = abase[4 * ks];
+            fa[1] = abase[16 * S::GLD + 4 * ks];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) fb[r * 3 + s] = bbase[d + r * S::RS + s];
+        };
+        auto mma = [&](const float (&fa)[2], const float (&fb)[9]) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[m][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m], fb[tp], acc[m][tp], 0, 0, 0);
+        };
+        frag(0, a0, b0);
+#pragma unroll
+        for (int ks = 0; ks < 16; ks += 2) {
+            frag(ks + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < 16) frag(ks + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // the four waves' partial sums, added in the fixed order ((w0 + w1) + w2) + w3 through LDS
+    constexpr int RLD = 146;
+    float* const red = smem;             // [32][RLD]: row = output channel, column = tap * 16 + channel of the group
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wid == w) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* d = red + (m * 16 + kq * 4 + r) * RLD + tp * 16 + il;
+                        *d = w == 0 ? acc[m][tp][r] : *d + acc[m][tp][r];
+                    }
+        }
+    }
+    __syncthreads();
+    float* const slab = slabs + (size_t)z * Mp * Jp;
+    for (int e = tid; e < 32 * 144; e += IG_THREADS) {
+        const int m = e / 144, jj = e - m * 144, tp = jj >> 4, c = jj & 15;
+        if (m < Mp) slab[(size_t)m * Jp + tp * p.C + grp * 16 + c] = red[m * RLD + jj];
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < S::GPER; ++i) {
+            float v = bs[i];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            const int m = wid + 4 * i;
+            if (lane == 0 && m < Mp) bslab[(size_t)z * Mp + m] = v;
+        }
+    }
+}
+
+}  // namespace cnuda

@@ -19,6 +19,18 @@ MANIFEST = {
     'dcnw_fwd_kernel<64, 16>': [
         'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle[dla_64',
     ],
+    'hwgrad_kernel<128>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset27_w128',
+    ],
+    'hwgrad_kernel<16>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset18_w16',
+    ],
+    'hwgrad_kernel<32>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset27_w32',
+    ],
+    'hwgrad_kernel<64>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset27_w64',
+    ],
     'hconv_kernel<32, 256, HconvFwd>': [
         'tests/test_gpu_fullsize.py::test_full_size_halo_tile_convolutions_match_fp64[64to27_128sq',
         'tests/test_gpu_fullsize.py::test_full_size_halo_tile_convolutions_match_fp64[128to27_64sq',
@@ -288,20 +300,25 @@ MANIFEST = {
         'tests/test_gpu_fullsize.py::test_full_size_3x3_convolution_matches_fp64',
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
     ],
-    'smallc_fwd_kernel<1>': [
-        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
-        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
-        'tests/test_gpu_dcn.py::test_known_answer_col2im_four_weights',
+    'smallc_fwd_kernel<1, 3>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[c16_3x3',
+        'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics[B2C16H20W64Co16k3s1g1',
+        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry[0-B3C3H8W11Co16k3s1p1ba',
+    ],
+    'smallc_fwd_kernel<1, 7>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[stem7x7',
+        'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics[B2C3H24W72Co16k7s1g2',
+        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry[0-B1C1H18W17Co2k7s1p3',
     ],
     'smallc_koff_kernel': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
         'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
-        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
     ],
     'smallc_pack_kernel': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
         'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
-        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
     ],
     'smallc_slab_reduce1_kernel': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
@@ -313,10 +330,13 @@ MANIFEST = {
         'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
         'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
     ],
-    'smallc_wgrad_kernel<1>': [
-        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
-        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
-        'tests/test_gpu_fuzz.py::test_conv_transpose2d_random_geometry',
+    'smallc_wgrad_kernel<1, 3, 9>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[c16_3x3',
+        'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics[B2C16H20W64Co16k3s1g1',
+    ],
+    'smallc_wgrad_kernel<1, 7, 10>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[stem7x7',
+        'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics[B2C3H24W72Co16k7s1g2',
     ],
     'softmax_loss_bwd_kernel': [
         'tests/test_gpu_losses.py::test_full_size_losses_vs_oracle_cfg3',

@@ -45,6 +45,14 @@ CONV_CASES = {
     # stride 2) run at full size (tests/kernel_manifest.py: igemm_fwd_ws_kernel<64, ConvFwdLoader<false>, 16>)
     'disc4x4_full': (2, 6, 256, 256, 64, 4, 2, 1, True, 0.2),
     'resnet_stem_full': (2, 3, 256, 256, 64, 7, 2, 3, False, -1.0),
+    # the DCN offset / mask convolutions (C -> 27, 3x3) at map widths 128 / 64 / 32 / 16: their weight gradient runs on
+    # halo tiles (hwgrad_kernel<W>: 256-pixel tiles of full rows); `_b8`: four tiles per workgroup (the prefetch loop),
+    # `w16`: a tile is a whole image and fewer than 27 output channels
+    'offset27_w128': (2, 64, 128, 128, 27, 3, 1, 1, True, -1.0),
+    'offset27_w128_b8': (8, 64, 128, 128, 27, 3, 1, 1, True, -1.0),
+    'offset27_w64': (2, 128, 64, 64, 27, 3, 1, 1, True, -1.0),
+    'offset27_w32': (3, 48, 32, 32, 27, 3, 1, 1, True, -1.0),
+    'offset18_w16': (5, 32, 16, 16, 18, 3, 1, 1, False, -1.0),
 }
 
 
