@@ -8,7 +8,8 @@ python3 $R/bench.py > $R/gpurun_out/${TAG}_bench_line.json 2> $R/gpurun_out/${TA
 tail -c 300 $R/gpurun_out/${TAG}_bench_line.json
 bash $R/profiles/collect_kernel_stats.sh > $R/gpurun_out/${TAG}_kernel_stats.txt 2>&1
 cp $(ls -t $R/gpurun_out/prof_tmp/*/*kernel_stats.csv | head -1) $R/gpurun_out/${TAG}_bench_kernel_stats.csv
-head -12 $R/gpurun_out/${TAG}_kernel_stats.txt
+cp $R/gpurun_out/launches_per_step.json $R/gpurun_out/${TAG}_launches_per_step.json
+head -12 $R/gpurun_out/${TAG}_kernel_stats.txt; tail -1 $R/gpurun_out/${TAG}_kernel_stats.txt
 bash $R/profiles/collect_pmc_traffic.sh > $R/gpurun_out/${TAG}_pmc_traffic.txt 2>&1
 cp $R/gpurun_out/pmc_traffic.json $R/gpurun_out/${TAG}_pmc_traffic.json
 head -12 $R/gpurun_out/${TAG}_pmc_traffic.txt

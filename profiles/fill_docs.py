@@ -51,6 +51,13 @@ for r in rows:
     b = bucket(short(r['Name']))
     bk[b] = bk.get(b, 0.0) + float(r['TotalDurationNs']) / 1e6 / STEPS
 launches = sum(int(r['Calls']) for r in rows) // STEPS
+launch_note = ''
+lp = os.path.join(ROOT, 'profiles', '%s_launches_per_step.json' % TAG)
+if os.path.exists(lp):       # the step's own launches: differential of two traces (collect_kernel_stats.sh)
+    lj = json.load(open(lp))
+    launch_note = (' (the trace\'s total / steps; it includes %d one-time launches of the process -- arena and optimizer-state '
+                   'copies -- and the step\'s own count, from the difference of a 10- and a 5-step trace, is %d)'
+                   % (round(lj['one_time_launches']), round(lj['launches_per_step'])))
 busy = None
 dom = rf['kernel'].split(' (')[0].replace(' ', '')
 for k, v in mfma.items():          # the PMC row of the line's dominant kernel (profiler names carry template defaults)
@@ -63,7 +70,7 @@ prev_launches = sum(int(r['Calls']) for r in prev_rows) // STEPS
 state = []
 state.append('Measured state at the end of round %d (MI355X, `profiles/%s_*`, written by `profiles/fill_docs.py`): '
              '**%.1f ms/step = %.1f source img/s** (sd %.2f ms over the timed steps; round %d: %.1f ms, %.1f img/s; different '
-             'boxes differ by ±1 %%); kernel time under rocprofv3 %.1f ms/step in %d launches (round %d: %d): the step is '
+             'boxes differ by ±1 %%); kernel time under rocprofv3 %.1f ms/step in %d launches (round %d: %d)' + launch_note + ': the step is '
              'GPU-bound. `step_mfma_fraction` = %.3f of the fp32 MFMA peak on SURVEY\'s nominal 6.26 TFLOP, '
              '`step_mfma_fraction_executed` = %.3f on the %.2f TFLOP the GEMM launches execute.'
              % (N, TAG, line['ms_per_step'], line['value'], line.get('ms_per_step_sd', 0.0), N - 1, prev['ms_per_step'],
