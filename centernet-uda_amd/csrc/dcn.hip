@@ -1770,7 +1770,17 @@ static int dcn_forward_impl(const float* input, const float* weight, const float
             CNUDA_LAUNCH(dcn_sample_kernel, dim3(B * tiles), dim3(64, tw), 0, st, sp, tiles);
         }
         DcnColsParams p{g, cols, bias, act_slope, output, stats, q.Mp};
-        if (buf && q.bm == 128)
+#ifndef DCN_COLS_WS
+#define DCN_COLS_WS 1
+#endif
+        // (a plain GEMM over coalesced rows: the 8-wave producer / consumer kernel of the dense convolutions takes it)
+        if (DCN_COLS_WS && buf && q.bm == 128 && wave_specialised() && matrix_mode() == 0)
+            CNUDA_LAUNCH((igemm_fwd_ws_kernel<128, DcnColsBufLoader>), grid, dim3(2 * IG_THREADS), 0, st, p, A, q.Mp, q.Kp, Cout,
+                               q.N, n_tiles, m_tiles);
+        else if (DCN_COLS_WS && buf && q.bm == 64 && wave_specialised() && matrix_mode() == 0)
+            CNUDA_LAUNCH((igemm_fwd_ws_kernel<64, DcnColsBufLoader>), grid, dim3(2 * IG_THREADS), 0, st, p, A, q.Mp, q.Kp, Cout,
+                               q.N, n_tiles, m_tiles);
+        else if (buf && q.bm == 128)
             CNUDA_LAUNCH((igemm_fwd_kernel<128, DcnColsBufLoader>), grid, block, 0, st, p, A, q.Mp, q.Kp, Cout, q.N,
                                n_tiles, m_tiles);
         else if (buf && q.bm == 64)

@@ -25,7 +25,10 @@ args = ap.parse_args()
 torch.manual_seed(0)
 if args.margin:
     hr.lib().cnuda_dcn_set_scatter_margin(args.margin)
-for (B, C, S, Co) in [(32, 64, 128, 64), (32, 128, 64, 64)]:
+SHAPES = [(32, 64, 128, 64), (32, 128, 64, 64)]
+if os.environ.get('DCN_LAYER_SHAPES') == 'small_maps':      # the layers that take the sample + GEMM pair / the gathering loader
+    SHAPES = [(32, 256, 32, 128), (32, 256, 32, 256), (32, 512, 16, 256), (32, 128, 64, 128)]
+for (B, C, S, Co) in SHAPES:
     m = DCN(C, Co, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).cuda()
     with torch.no_grad():
         if args.offsets == 'small':          # offsets ~ N(0.3, 0.5 px): the regime after the first optimizer steps

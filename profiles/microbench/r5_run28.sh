@@ -1,0 +1,3 @@
+R=$GRAFT_REPO_ROOT
+for v in colsws0 colsws1; do echo "== $v"; DCN_LAYER_SHAPES=small_maps ABL_LIB=$R/abl/lib_$v.so timeout 200 python profiles/dcn_layer.py --offsets small --iters 3 --time 2>&1 | grep -E "B=|fwd|sample"; done
+timeout 600 python -m pytest tests/test_gpu_dcn.py -x -q 2>&1 | tail -2

@@ -152,7 +152,7 @@ MANIFEST = {
         'tests/test_gpu_losses.py::test_full_size_losses_vs_oracle_cfg3',
         'tests/test_gpu_losses.py::test_keypoint_detection_loss_golden',
     ],
-    'igemm_fwd_kernel<128, DcnColsBufLoader, false>': [
+    'igemm_fwd_ws_kernel<128, DcnColsBufLoader, 16>': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[256to256_32sq',
     ],
     'igemm_fwd_kernel<128, DcnFwdLoaderT<true>, false>': [
@@ -178,7 +178,7 @@ MANIFEST = {
         'tests/test_gpu_dcn.py::test_known_answer_half_pixel_offsets_are_box_blurs',
         'tests/test_gpu_dcn.py::test_known_answer_linear_ramp_gradients',
     ],
-    'igemm_fwd_kernel<64, DcnColsBufLoader, false>': [
+    'igemm_fwd_ws_kernel<64, DcnColsBufLoader, 16>': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[256to128_32sq',
     ],
     'igemm_fwd_kernel<64, DcnFwdLoaderT<true>, false>': [      # (since round 4: only layers the window kernel does not take)
