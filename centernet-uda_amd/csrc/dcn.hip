@@ -660,12 +660,36 @@ __global__ __launch_bounds__(1024) void dcn_sample_kernel(DcnSampleParams p, int
         const float w00 = t.c00 ? t.hh * t.hw * mk : 0.0f, w01 = t.c01 ? t.hh * t.lw * mk : 0.0f;
         const float w10 = t.c10 ? t.lh * t.hw * mk : 0.0f, w11 = t.c11 ? t.lh * t.lw * mk : 0.0f;
         float* dst = p.col + ((size_t)b * T + tap) * g.C * HoWo + px;
+        // the two corners of a row as ONE 8-byte load (as the coordinate-gradient walk does): the pair starts at column
+        // w0, moved inside the row at the left / right edge, where the corner that exists sits in the pair's other half --
+        // the same four values and weights as four single loads (bit-identical), half the gather instructions
+        const bool paired = g.W >= 2;                           // (uniform)
+        const bool ledge = t.w0 < 0, redge = t.w0 > g.W - 2;
+        const int wa = ledge ? 0 : (redge ? g.W - 2 : t.w0);
+        const int ht = t.h0 < 0 ? 0 : t.h0, hb = t.h0 + 1 > g.H - 1 ? g.H - 1 : t.h0 + 1;
+        const int qT = t.inside ? ht * g.W + wa : 0, qB = t.inside ? hb * g.W + wa : 0;
+        struct __attribute__((packed, aligned(4))) Pair { float l, r; };
         for (int c0 = 0; c0 < g.C; c0 += 8) {
             float e00[8], e01[8], e10[8], e11[8];
+            if (paired) {
+                Pair pt[8], pb[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float* plane = in_b + (size_t)(c0 + u < g.C ? c0 + u : g.C - 1) * HW;
-                e00[u] = plane[t.o00]; e01[u] = plane[t.o01]; e10[u] = plane[t.o10]; e11[u] = plane[t.o11];
+                for (int u = 0; u < 8; ++u) {
+                    const float* plane = in_b + (size_t)(c0 + u < g.C ? c0 + u : g.C - 1) * HW;
+                    pt[u] = *reinterpret_cast<const Pair*>(plane + qT);
+                    pb[u] = *reinterpret_cast<const Pair*>(plane + qB);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    e00[u] = redge ? pt[u].r : pt[u].l; e01[u] = ledge ? pt[u].l : pt[u].r;
+                    e10[u] = redge ? pb[u].r : pb[u].l; e11[u] = ledge ? pb[u].l : pb[u].r;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float* plane = in_b + (size_t)(c0 + u < g.C ? c0 + u : g.C - 1) * HW;
+                    e00[u] = plane[t.o00]; e01[u] = plane[t.o01]; e10[u] = plane[t.o10]; e11[u] = plane[t.o11];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)

@@ -419,8 +419,8 @@ DCN_LAYERS = {
     '128to64_64sq_one_launch': dict(B=32, C=128, Co=64, S=64, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel']),
     '32to64_96sq': dict(B=8, C=32, Co=64, S=96, kernels=['igemm_fwd_kernel<64, DcnFwdLoaderT<true>']),      # a map the window kernels do not take
     '128to128_64sq': dict(B=16, C=128, Co=128, S=64, kernels=['igemm_fwd_kernel<128, DcnFwdLoaderT<true>']),
-    '256to256_32sq': dict(B=32, C=256, Co=256, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_kernel<128, DcnColsBufLoader']),
-    '256to128_32sq': dict(B=32, C=256, Co=128, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_kernel<64, DcnColsBufLoader']),
+    '256to256_32sq': dict(B=32, C=256, Co=256, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_ws_kernel<128, DcnColsBufLoader']),
+    '256to128_32sq': dict(B=32, C=256, Co=128, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_ws_kernel<64, DcnColsBufLoader']),
 }
 # offset scales: 1e-3 px of either sign is the benched step after its first optimizer step (a sample at y - 1e-4 has its anchor
 # one cell above its neighbour's at y + 1e-4: jittered anchors, all four corner weights non-zero, one of them ~1)
