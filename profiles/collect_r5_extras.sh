@@ -18,3 +18,4 @@ python3 $R/profiles/microbench/ab_bn_stats.py 2>/dev/null > $O/${TAG}_ab_bn_epil
 python3 $R/profiles/microbench/ab_margin.py 2>/dev/null > $O/${TAG}_ab_scatter_margin.txt
 python3 $R/profiles/microbench/dcn_offset_stats.py 3 2>/dev/null > $O/${TAG}_dcn_offset_regime.txt
 python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras --dcn-offset-std 2 > $O/${TAG}_bench_sigma2_line.json 2>/dev/null
+DCN_LAYER_SHAPES=small_maps python3 $R/profiles/dcn_layer.py --time --iters 3 > $O/${TAG}_dcn_small_map_layers.txt 2>&1
