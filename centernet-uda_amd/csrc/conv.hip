@@ -648,8 +648,7 @@ int pick_bm(int M, long long N) {
 
 // hwgrad_kernel (hwgrad.cuh) takes the weight gradient of the narrow 3x3 convolutions (the DCN offset / mask layers)
 bool hwgrad_ok(const ConvGeom& g) {
-    static const bool on = !(getenv("CNUDA_HWGRAD") && getenv("CNUDA_HWGRAD")[0] == '0');
-    return on && matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
+    return matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
            g.Co <= 32 && g.C % 16 == 0 && (g.W == 16 || g.W == 32 || g.W == 64 || g.W == 128) &&
            ((long long)g.H * g.W) % HW_BN == 0 && wgrad_buffer_ok(g);
 }
