@@ -1926,13 +1926,28 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
             static const bool buf_on = !(getenv("CNUDA_BUF") && getenv("CNUDA_BUF")[0] == '0');
             const bool buf = buf_on && (size_t)B * q.T * C * HoWo * sizeof(float) < IG_BUF_OOB &&
                              (size_t)B * Cout * HoWo * sizeof(float) < IG_BUF_OOB && HoWo < (1 << 23);
-            wscope.name("igemm_wgrad_kernel<%s, 64, %d>", buf ? "DcnColWBufLoader" : "DcnColWLoader", q.Jp % 128 == 0 ? 128 : 64);
-            if (buf && q.Jp % 128 == 0)
-                CNUDA_LAUNCH((igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
-                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split, bsl);
-            else if (buf)
-                CNUDA_LAUNCH((igemm_wgrad_kernel<DcnColWBufLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
-                                   dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split, bsl);
+#ifndef DCN_COLW_WS
+#define DCN_COLW_WS 1
+#endif
+            // (plain row reads of the saved columns: the 8-wave producer / consumer kernel of the dense convolutions takes them)
+            const bool ws = DCN_COLW_WS && wave_specialised() && matrix_mode() == 0;
+            wscope.name(ws && buf ? "igemm_wgrad_ws_kernel<%s, 64, %d>" : "igemm_wgrad_kernel<%s, 64, %d>",
+                        buf ? "DcnColWBufLoader" : "DcnColWLoader", q.Jp % 128 == 0 ? 128 : 64);
+            if (buf && q.Jp % 128 == 0) {
+                if (ws)
+                    CNUDA_LAUNCH((igemm_wgrad_ws_kernel<DcnColWBufLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
+                                       dim3(2 * IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split, bsl);
+                else
+                    CNUDA_LAUNCH((igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
+                                       dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split, bsl);
+            } else if (buf) {
+                if (ws)
+                    CNUDA_LAUNCH((igemm_wgrad_ws_kernel<DcnColWBufLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+                                       dim3(2 * IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split, bsl);
+                else
+                    CNUDA_LAUNCH((igemm_wgrad_kernel<DcnColWBufLoader, 64, 64>), dim3(q.Jp / WG_BJ, q.Mpw / WG_BM, q.Z),
+                                       dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split, bsl);
+            }
             else if (q.Jp % 128 == 0)
                 CNUDA_LAUNCH((igemm_wgrad_kernel<DcnColWLoader, 64, 128>), dim3(q.Jp / 128, q.Mpw / WG_BM, q.Z),
                                    dim3(IG_THREADS), 0, wst, p, slabs, q.Mpw, q.Jp, q.N, q.pix_per_split, bsl);

@@ -222,12 +222,12 @@ MANIFEST = {
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[disc4x4_full',
         'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
     ],
-    'igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>': [
+    'igemm_wgrad_ws_kernel<DcnColWBufLoader, 64, 128>': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
         'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
         'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
     ],
-    'igemm_wgrad_kernel<DcnColWBufLoader, 64, 64>': [
+    'igemm_wgrad_ws_kernel<DcnColWBufLoader, 64, 64>': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
         'tests/test_gpu_dcn.py::test_autograd_module_path_and_argument_order',
         'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',

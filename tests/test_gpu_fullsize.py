@@ -413,9 +413,9 @@ def _dcn_full_case(B, C, Co, S, off_scale, seed):
 #   128 -> 128 at 64 x 64: the 128-row `DcnFwdLoader` tile;
 #   256 -> 256 and 256 -> 128 at 32 x 32: the two-kernel forward (dcn_sample_kernel + a 128- / 64-row GEMM over the columns).
 DCN_LAYERS = {
-    '64to64_128sq': dict(B=4, C=64, Co=64, S=128, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_col2im_kernel', 'dcn_coord_grad_kernel', 'igemm_fwd_shortk_kernel', 'igemm_wgrad_kernel<DcnColWBufLoader, 64, 64>']),
+    '64to64_128sq': dict(B=4, C=64, Co=64, S=128, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_col2im_kernel', 'dcn_coord_grad_kernel', 'igemm_fwd_shortk_kernel', 'igemm_wgrad_ws_kernel<DcnColWBufLoader, 64, 64>']),
     '64to64_128sq_one_launch': dict(B=8, C=64, Co=64, S=128, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel', 'igemm_fwd_shortk_kernel']),
-    '128to64_64sq': dict(B=16, C=128, Co=64, S=64, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_col2im_kernel', 'dcn_coord_grad_kernel', 'igemm_wgrad_kernel<DcnColWBufLoader, 64, 128>']),
+    '128to64_64sq': dict(B=16, C=128, Co=64, S=64, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_col2im_kernel', 'dcn_coord_grad_kernel', 'igemm_wgrad_ws_kernel<DcnColWBufLoader, 64, 128>']),
     '128to64_64sq_one_launch': dict(B=32, C=128, Co=64, S=64, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel']),
     '32to64_96sq': dict(B=8, C=32, Co=64, S=96, kernels=['igemm_fwd_kernel<64, DcnFwdLoaderT<true>']),      # a map the window kernels do not take
     '128to128_64sq': dict(B=16, C=128, Co=128, S=64, kernels=['igemm_fwd_kernel<128, DcnFwdLoaderT<true>']),
