@@ -70,11 +70,11 @@ prev_launches = sum(int(r['Calls']) for r in prev_rows) // STEPS
 state = []
 state.append('Measured state at the end of round %d (MI355X, `profiles/%s_*`, written by `profiles/fill_docs.py`): '
              '**%.1f ms/step = %.1f source img/s** (sd %.2f ms over the timed steps; round %d: %.1f ms, %.1f img/s; different '
-             'boxes differ by ±1 %%); kernel time under rocprofv3 %.1f ms/step in %d launches (round %d: %d)' + launch_note + ': the step is '
+             'boxes differ by ±1 %%); kernel time under rocprofv3 %.1f ms/step in %d launches (round %d: %d)%s: the step is '
              'GPU-bound. `step_mfma_fraction` = %.3f of the fp32 MFMA peak on SURVEY\'s nominal 6.26 TFLOP, '
              '`step_mfma_fraction_executed` = %.3f on the %.2f TFLOP the GEMM launches execute.'
              % (N, TAG, line['ms_per_step'], line['value'], line.get('ms_per_step_sd', 0.0), N - 1, prev['ms_per_step'],
-                prev['value'], tot / 1e6 / STEPS, launches, N - 1, prev_launches, line['step_mfma_fraction'],
+                prev['value'], tot / 1e6 / STEPS, launches, N - 1, prev_launches, launch_note, line['step_mfma_fraction'],
                 line.get('step_mfma_fraction_executed') or 0.0, rf.get('executed_tflop_per_step') or 0.0))
 state.append('Dominant kernel `%s`: %.1f ms over %d launches, %.1f TFLOP/s = `roofline.frac` %.3f%s, %.0f MB of HBM traffic per '
              'launch (PMC).' % (rf['kernel'], rf['kernel_ms_per_step'], rf['launches_per_step'], rf['achieved'], rf['frac'],
