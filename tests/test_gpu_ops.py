@@ -53,6 +53,7 @@ CONV_CASES = {
     'offset27_w64': (2, 128, 64, 64, 27, 3, 1, 1, True, -1.0),
     'offset27_w32': (3, 48, 32, 32, 27, 3, 1, 1, True, -1.0),
     'offset18_w16': (5, 32, 16, 16, 18, 3, 1, 1, False, -1.0),
+    'offset27_24x64': (3, 32, 24, 64, 27, 3, 1, 1, True, -1.0),      # H != W: six 4-row tiles per image
 }
 
 
