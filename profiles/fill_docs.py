@@ -107,7 +107,9 @@ if fam:
     tab.append('| the forward kernel `igemm_fwd_ws_kernel<128, ConvFwdBuf*>` (rounds 1-4\'s dominant one; two instances since round 5) | %.1f TF = %.3f | %.1f TF = %.3f |'
                % (prf['achieved'], prf['frac'], fam['tflops'], fam['frac']))
 tab += [
-       '| kernel launches per step | %d | %d |' % (prev_launches, launches)]
+       '| kernel launches per step (whole trace / steps%s) | %d | %d%s |'
+       % (('; the step\'s own, by trace difference' if launch_note else ''), prev_launches, launches,
+          (' (%d)' % round(lj['launches_per_step'])) if launch_note else '')]
 for c in cfgs:
     name = c['config']['workload'].split(':')[0]
     pc = prev_cfgs.get(name)
