@@ -653,9 +653,16 @@ bool hwgrad_ok(const ConvGeom& g) {
            ((long long)g.H * g.W) % HW_BN == 0 && wgrad_buffer_ok(g);
 }
 
+// ... and hwgrad_s2_kernel that of the narrow 3x3 / stride 2 convolutions (DLA-34's level1)
+bool hwgrad_s2_ok(const ConvGeom& g) {
+    return matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 2 && g.sw == 2 && g.ph == 1 && g.pw == 1 && g.Co <= 32 &&
+           g.C % 16 == 0 && g.H % 2 == 0 && g.W % 2 == 0 && g.Wo % HS_BN == 0 && wgrad_buffer_ok(g);
+}
+
 struct ConvPlan {
     int T;
     bool hw;                  // weight gradient on halo tiles (hwgrad_kernel): Z = pixel-tile splits per channel group
+    bool hw_s2;               // ... the stride-2 form (hwgrad_s2_kernel: 128-pixel tiles)
     int hw_tiles, hw_tiles_per_split;
     int Kf, Kpf, bmf, Mpf;   // forward:  K = T*C,  M = Co
     int Kd, Kpd, bmd, Mpd;   // dgrad:    K = T*Co, M = C
@@ -686,10 +693,11 @@ ConvPlan make_plan(const ConvGeom& g) {
     q.pix_per_split = ((q.Nf + z - 1) / z + WG_BP - 1) / WG_BP * WG_BP;
     q.Z = (int)((q.Nf + q.pix_per_split - 1) / q.pix_per_split);
     q.hw = hwgrad_ok(g);
+    q.hw_s2 = !q.hw && hwgrad_s2_ok(g);
     q.hw_tiles = q.hw_tiles_per_split = 0;
-    if (q.hw) {
-        // (C / 16) channel groups x Z splits of the 256-pixel tiles: two workgroups per CU, at least one tile each
-        q.hw_tiles = (int)(q.Nf / HW_BN);
+    if (q.hw || q.hw_s2) {
+        // (C / 16) channel groups x Z splits of the 256- (128-) pixel tiles: two workgroups per CU, at least one tile each
+        q.hw_tiles = (int)(q.Nf / (q.hw ? HW_BN : HS_BN));
         const int groups = g.C / 16;
         int zz = std::max(1, 512 / groups);
         if (zz > q.hw_tiles) zz = q.hw_tiles;
@@ -1123,7 +1131,19 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
     // bias gradient: row sums of grad_y per split from the GEMM's own staging registers, summed with the slabs
     float* bsl = grad_bias ? cv.take<float>((size_t)q.Z * q.Mpw) : nullptr;
     ConvWParams p{g, x, grad_y};
-    if (q.hw) {
+    if (q.hw_s2) {
+        ProfScope prof(st);
+        prof.name("hwgrad_s2_kernel");
+        const HwS2Params hp{x, grad_y, B, C, H, W, Cout, g.Ho, g.Wo, q.hw_tiles, q.hw_tiles_per_split};
+        const size_t lds = HS_LDS_FLOATS * sizeof(float);
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hwgrad_s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+            raised = true;
+        }
+        CNUDA_LAUNCH(hwgrad_s2_kernel, dim3(C / 16, q.Z), dim3(IG_THREADS), lds, st, hp, slabs, q.Mpw, q.Jp, bsl);
+    } else if (q.hw) {
         ProfScope prof(st);
         prof.name("hwgrad_kernel<%d>", W);
         const HwParams hp{x, grad_y, B, C, H, Cout, q.hw_tiles, q.hw_tiles_per_split};

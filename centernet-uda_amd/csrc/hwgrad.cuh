@@ -211,4 +211,192 @@ __global__ __launch_bounds__(IG_THREADS, 2) void hwgrad_kernel(HwParams p, float
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same reduction for a 3x3 / STRIDE 2 / padding 1 convolution with <= 32 output channels (DLA-34's level1, 16 -> 32
+// at 512 x 512 -> 256 x 256, backends/dla.py:233-241): the im2col-style kernel pads its K = 144 columns to 256 and gathers
+// 4 bytes at a time (35 TFLOP/s).  Tile = 128 consecutive output pixels of one output row; its three input rows
+// (2 oy - 1 .. 2 oy + 1) are staged DE-INTERLEAVED by column parity -- a 16-byte cell of four input columns goes as two
+// 8-byte stores into the even and the odd plane -- so that the four consecutive output pixels of an MFMA k-step read
+// consecutive LDS cells for every tap: tap column s = 1 is the even plane at ox, s = 2 the odd plane at ox, s = 0 the odd
+// plane at ox - 1 (the column left of the tile: a real column for the tile's right-hand neighbours, zero at the image
+// edge).  Everything else -- rows = output channels in two tiles of 16, columns = 16 input channels, k = pixels, the waves'
+// fixed-order sum, slabs, bias row sums -- as hwgrad_kernel.
+// Host-side conditions (conv.hip hwgrad_s2_ok): 3x3, stride 2, padding 1, even H and W, Co <= 32, C % 16 == 0,
+// Wo % 128 == 0, both tensors below 2 GiB, f32 matrix mode.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int HS_BN = 128;                                   // output pixels per tile
+constexpr int HS_PW = HS_BN + 8;                             // a parity plane of one row: output column j at j + 4, column -1 at 3
+constexpr int HS_ROW = 2 * HS_PW;                            // even plane | odd plane
+constexpr int HS_PL = (3 * HS_ROW + 29) / 32 * 32 + 2;       // channel stride == 2 (mod 32), see HwShape
+constexpr int HS_GLD = HS_BN + 2;
+constexpr size_t HS_LDS_FLOATS = (size_t)16 * HS_PL + (size_t)32 * HS_GLD;
+static_assert(32 * 146 <= (int)HS_LDS_FLOATS, "the cross-wave reduction reuses the staging area");
+
+struct HwS2Params {
+    const float* x;         // [B][C][H][W], H = 2 Ho, W = 2 Wo
+    const float* gy;        // [B][Co][Ho][Wo]
+    int B, C, H, W, Co, Ho, Wo;
+    int n_tiles, tiles_per_split;
+};
+
+__global__ __launch_bounds__(IG_THREADS, 2) void hwgrad_s2_kernel(HwS2Params p, float* __restrict__ slabs, int Mp, int Jp,
+                                                                  float* __restrict__ bslab) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Hs = smem;                          // [16][3 rows][even | odd][HS_PW]
+    float* const Gs = smem + 16 * HS_PL;             // [32][HS_GLD]
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, il = lane & 15;
+    const int grp = blockIdx.x, z = blockIdx.y;
+    const int HWp = p.H * p.W, HoWo = p.Ho * p.Wo, halves = p.Wo / HS_BN;
+    const int t0 = z * p.tiles_per_split;
+    const int t1 = t0 + p.tiles_per_split < p.n_tiles ? t0 + p.tiles_per_split : p.n_tiles;
+    const buf_rsrc rx = ig_make_rsrc(p.x, (unsigned)((size_t)p.B * p.C * HWp * sizeof(float)));
+    const buf_rsrc rg = ig_make_rsrc(p.gy, (unsigned)((size_t)p.B * p.Co * HoWo * sizeof(float)));
+
+    // input cells of this thread: 16 channels x 3 rows x 64 cells of four input columns -> twelve per thread; byte offset
+    // relative to (image, group, row 2 oy, column 256 h) -- the row above is at -W, added per lane -- and the LDS cell
+    constexpr int XPER = 16 * 3 * 64 / IG_THREADS;
+    unsigned xv[XPER];
+    int xl[XPER];
+    bool xtop[XPER];
+#pragma unroll
+    for (int i = 0; i < XPER; ++i) {
+        const int e = tid + i * IG_THREADS;
+        const int c = e / 192, rem = e - c * 192, row = rem >> 6, q = rem & 63;
+        xv[i] = (unsigned)((c * HWp + (row - 1) * p.W + 4 * q) * (int)sizeof(float));
+        xl[i] = c * HS_PL + row * HS_ROW + 4 + 2 * q;
+        xtop[i] = row == 0;
+    }
+    // the column left of the tile (odd plane, index -1): one element per (channel, row), threads 0..47
+    const int hc = tid / 3, hr = tid - hc * 3;
+    const bool hon = tid < 48;
+    const int hl = hc * HS_PL + hr * HS_ROW + HS_PW + 3;
+    // grad_y cells: 32 rows x 32 cells -> four per thread (row tid / 32 + 8 i, cell tid % 32)
+    constexpr int GPER = 32 * (HS_BN / 4) / IG_THREADS;
+    const int gm0 = tid >> 5, gq = tid & 31;
+
+    f32x4 acc[2][9];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = bslab != nullptr && grp == 0;
+    float bs[GPER];
+#pragma unroll
+    for (int i = 0; i < GPER; ++i) bs[i] = 0.0f;
+
+    f32x4 xr[XPER], gr[GPER];
+    float hv = 0.0f;
+    auto tile_load = [&](int t) {
+        const int b = t / (p.Ho * halves), rem = t - b * (p.Ho * halves), oy = rem / halves, h = rem - oy * halves;
+        const bool top_ok = oy > 0;                              // (input row 2 oy - 1; the row below, 2 oy + 1, always exists)
+        const unsigned xs = (unsigned)(((b * p.C + grp * 16) * HWp) * (int)sizeof(float));
+        const unsigned ys = (unsigned)((2 * oy * p.W + 2 * HS_BN * h) * (int)sizeof(float));
+#pragma unroll
+        for (int i = 0; i < XPER; ++i) xr[i] = ig_buf_load4(rx, (xtop[i] && !top_ok) ? IG_BUF_OOB : xv[i] + ys, xs);
+        {
+            const bool ok = hon && h > 0 && (hr > 0 || top_ok);
+            hv = ig_buf_load(rx, ok ? (unsigned)((hc * HWp + (hr - 1) * p.W - 1) * (int)sizeof(float)) + ys : IG_BUF_OOB, xs);
+        }
+        const unsigned gs = (unsigned)(((b * p.Co) * HoWo + oy * p.Wo + HS_BN * h) * (int)sizeof(float));
+#pragma unroll
+        for (int i = 0; i < GPER; ++i) {
+            const int m = gm0 + 8 * i;
+            gr[i] = ig_buf_load4(rg, m < p.Co ? (unsigned)((m * HoWo + 4 * gq) * (int)sizeof(float)) : IG_BUF_OOB, gs);
+        }
+    };
+    auto tile_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < XPER; ++i) {                         // columns 4q, 4q + 2 -> even plane; 4q + 1, 4q + 3 -> odd plane
+            *reinterpret_cast<float2*>(Hs + xl[i]) = make_float2(xr[i][0], xr[i][2]);
+            *reinterpret_cast<float2*>(Hs + xl[i] + HS_PW) = make_float2(xr[i][1], xr[i][3]);
+        }
+        if (hon) Hs[hl] = hv;
+#pragma unroll
+        for (int i = 0; i < GPER; ++i) {
+            float* d = Gs + (gm0 + 8 * i) * HS_GLD + 4 * gq;
+            *reinterpret_cast<float2*>(d) = make_float2(gr[i][0], gr[i][1]);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(gr[i][2], gr[i][3]);
+            if (do_bias) bs[i] += (gr[i][0] + gr[i][1]) + (gr[i][2] + gr[i][3]);
+        }
+    };
+
+    // wave `wid` reduces output pixels [32 wid, 32 wid + 32) of the tile: 8 k-steps of 4 pixels
+    const float* const bbase = Hs + il * HS_PL + 4 + 32 * wid + kq;
+    const float* const abase = Gs + il * HS_GLD + 32 * wid + kq;
+
+    if (t0 < t1) tile_load(t0);
+    for (int t = t0; t < t1; ++t) {
+        __syncthreads();
+        tile_store();
+        __syncthreads();
+        if (t + 1 < t1) tile_load(t + 1);
+        float a0[2], b0[9], a1[2], b1[9];
+        auto frag = [&](int ks, float (&fa)[2], float (&fb)[9]) {
+            fa[0] = abase[4 * ks];
+            fa[1] = abase[16 * HS_GLD + 4 * ks];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float* row = bbase + r * HS_ROW + 4 * ks;
+                fb[r * 3 + 0] = row[HS_PW - 1];                  // input column 2 ox - 1: odd plane at ox - 1
+                fb[r * 3 + 1] = row[0];                          //              2 ox    : even plane at ox
+                fb[r * 3 + 2] = row[HS_PW];                      //              2 ox + 1: odd plane at ox
+            }
+        };
+        auto mma = [&](const float (&fa)[2], const float (&fb)[9]) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[m][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[m], fb[tp], acc[m][tp], 0, 0, 0);
+        };
+        frag(0, a0, b0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ks += 2) {
+            frag(ks + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < 8) frag(ks + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    constexpr int RLD = 146;
+    float* const red = smem;
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wid == w) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* d = red + (m * 16 + kq * 4 + r) * RLD + tp * 16 + il;
+                        *d = w == 0 ? acc[m][tp][r] : *d + acc[m][tp][r];
+                    }
+        }
+    }
+    __syncthreads();
+    float* const slab = slabs + (size_t)z * Mp * Jp;
+    for (int e = tid; e < 32 * 144; e += IG_THREADS) {
+        const int m = e / 144, jj = e - m * 144, tp = jj >> 4, c = jj & 15;
+        if (m < Mp) slab[(size_t)m * Jp + tp * p.C + grp * 16 + c] = red[m * RLD + jj];
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < GPER; ++i) {
+            float v = bs[i];
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);      // the 32 lanes of a row: one half of the wave
+            const int m = gm0 + 8 * i;
+            if ((tid & 31) == 0 && m < Mp) bslab[(size_t)z * Mp + m] = v;
+        }
+    }
+}
+
 }  // namespace cnuda

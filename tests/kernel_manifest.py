@@ -19,6 +19,9 @@ MANIFEST = {
     'dcnw_fwd_kernel<64, 16>': [
         'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle[dla_64',
     ],
+    'hwgrad_s2_kernel': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[l1_s2_',
+    ],
     'hwgrad_kernel<128>': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset27_w128',
     ],
