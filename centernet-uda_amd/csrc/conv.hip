@@ -655,7 +655,7 @@ bool hwgrad_ok(const ConvGeom& g) {
 
 // ... and hwgrad_s2_kernel that of the narrow 3x3 / stride 2 convolutions (DLA-34's level1)
 bool hwgrad_s2_ok(const ConvGeom& g) {
-    return matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 2 && g.sw == 2 && g.ph == 1 && g.pw == 1 && g.Co <= 32 &&
+    return matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 2 && g.sw == 2 && g.ph == 1 && g.pw == 1 && g.Co <= 64 &&
            g.C % 16 == 0 && g.H % 2 == 0 && g.W % 2 == 0 && g.Wo % HS_BN == 0 && wgrad_buffer_ok(g);
 }
 
@@ -698,7 +698,7 @@ ConvPlan make_plan(const ConvGeom& g) {
     if (q.hw || q.hw_s2) {
         // (C / 16) channel groups x Z splits of the 256- (128-) pixel tiles: two workgroups per CU, at least one tile each
         q.hw_tiles = (int)(q.Nf / (q.hw ? HW_BN : HS_BN));
-        const int groups = g.C / 16;
+        const int groups = (g.C / 16) * (q.hw_s2 ? (g.Co + 31) / 32 : 1);
         int zz = std::max(1, 512 / groups);
         if (zz > q.hw_tiles) zz = q.hw_tiles;
         q.hw_tiles_per_split = (q.hw_tiles + zz - 1) / zz;
@@ -1142,7 +1142,7 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
                                       160 * 1024);
             raised = true;
         }
-        CNUDA_LAUNCH(hwgrad_s2_kernel, dim3(C / 16, q.Z), dim3(IG_THREADS), lds, st, hp, slabs, q.Mpw, q.Jp, bsl);
+        CNUDA_LAUNCH(hwgrad_s2_kernel, dim3(C / 16, q.Z, (Cout + 31) / 32), dim3(IG_THREADS), lds, st, hp, slabs, q.Mpw, q.Jp, bsl);
     } else if (q.hw) {
         ProfScope prof(st);
         prof.name("hwgrad_kernel<%d>", W);

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void hwgrad_kernel(HwParams p, float
 // plane at ox - 1 (the column left of the tile: a real column for the tile's right-hand neighbours, zero at the image
 // edge).  Everything else -- rows = output channels in two tiles of 16, columns = 16 input channels, k = pixels, the waves'
 // fixed-order sum, slabs, bias row sums -- as hwgrad_kernel.
-// Host-side conditions (conv.hip hwgrad_s2_ok): 3x3, stride 2, padding 1, even H and W, Co <= 32, C % 16 == 0,
+// Host-side conditions (conv.hip hwgrad_s2_ok): 3x3, stride 2, padding 1, even H and W, Co <= 64 (blockIdx.z: 32-row block), C % 16 == 0,
 // Wo % 128 == 0, both tensors below 2 GiB, f32 matrix mode.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int HS_BN = 128;                                   // output pixels per tile
@@ -248,6 +248,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void hwgrad_s2_kernel(HwS2Params p, 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = lane >> 4, il = lane & 15;
     const int grp = blockIdx.x, z = blockIdx.y;
+    const int m_off = blockIdx.z * 32;               // output channels [m_off, m_off + 32) (two row blocks for 33..64 channels)
     const int HWp = p.H * p.W, HoWo = p.Ho * p.Wo, halves = p.Wo / HS_BN;
     const int t0 = z * p.tiles_per_split;
     const int t1 = t0 + p.tiles_per_split < p.n_tiles ? t0 + p.tiles_per_split : p.n_tiles;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void hwgrad_s2_kernel(HwS2Params p, 
         const unsigned gs = (unsigned)(((b * p.Co) * HoWo + oy * p.Wo + HS_BN * h) * (int)sizeof(float));
 #pragma unroll
         for (int i = 0; i < GPER; ++i) {
-            const int m = gm0 + 8 * i;
+            const int m = m_off + gm0 + 8 * i;
             gr[i] = ig_buf_load4(rg, m < p.Co ? (unsigned)((m * HoWo + 4 * gq) * (int)sizeof(float)) : IG_BUF_OOB, gs);
         }
     };
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void hwgrad_s2_kernel(HwS2Params p, 
     float* const slab = slabs + (size_t)z * Mp * Jp;
     for (int e = tid; e < 32 * 144; e += IG_THREADS) {
         const int m = e / 144, jj = e - m * 144, tp = jj >> 4, c = jj & 15;
-        if (m < Mp) slab[(size_t)m * Jp + tp * p.C + grp * 16 + c] = red[m * RLD + jj];
+        if (m_off + m < Mp) slab[(size_t)(m_off + m) * Jp + tp * p.C + grp * 16 + c] = red[m * RLD + jj];
     }
     if (do_bias) {
 #pragma unroll
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void hwgrad_s2_kernel(HwS2Params p, 
             float v = bs[i];
 #pragma unroll
             for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);      // the 32 lanes of a row: one half of the wave
-            const int m = gm0 + 8 * i;
+            const int m = m_off + gm0 + 8 * i;
             if ((tid & 31) == 0 && m < Mp) bslab[(size_t)z * Mp + m] = v;
         }
     }

@@ -21,6 +21,7 @@ MANIFEST = {
     ],
     'hwgrad_s2_kernel': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[l1_s2_',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[l2_s2_',
     ],
     'hwgrad_kernel<128>': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset27_w128',

@@ -55,10 +55,13 @@ CONV_CASES = {
     'offset18_w16': (5, 32, 16, 16, 18, 3, 1, 1, False, -1.0),
     'offset27_24x64': (3, 32, 24, 64, 27, 3, 1, 1, True, -1.0),      # H != W: six 4-row tiles per image
     # DLA-34's level1 shape class (16 -> 32, 3x3 stride 2) at output widths that are multiples of 128: its weight gradient runs
-    # on parity-split halo tiles (hwgrad_s2_kernel); two tiles per output row, several tiles per workgroup, and a bias
+    # on parity-split halo tiles (hwgrad_s2_kernel); two tiles per output row, several tiles per workgroup, a bias, and
+    # (l2_*) the 32 -> 64 shape of level2's first convolution
     'l1_s2_w256': (2, 16, 64, 512, 32, 3, 2, 1, False, -1.0),
     'l1_s2_w128_b': (3, 32, 48, 256, 24, 3, 2, 1, True, -1.0),
     'l1_s2_many': (9, 16, 128, 256, 32, 3, 2, 1, False, -1.0),
+    'l2_s2_co64': (2, 32, 32, 256, 64, 3, 2, 1, False, -1.0),        # 33..64 output channels: two 32-row blocks
+    'l2_s2_co48_b': (2, 16, 16, 256, 48, 3, 2, 1, True, -1.0),
 }
 
 
