@@ -1,13 +1,14 @@
-// Convolutions with few channels at full image resolution -- the DLA-34 stem (3->16, 7x7 @512x512),
-// level0 (16->16, 3x3) and level1 (16->32, 3x3 stride 2): backends/dla.py:233-241, 277-287.
+// Convolutions with few channels at full image resolution and stride 1 -- the DLA-34 stem (3->16, 7x7 @512x512) and
+// level0 (16->16, 3x3): backends/dla.py:233-241, 277-287.  (level1, 16->32 at stride 2, runs on igemm.cuh's forward
+// kernel, dgrad_s2_c16_kernel and hwgrad_s2_kernel.)
 // Their K = C*kh*kw is tiny (144-147) while the pixel count is huge, so the generic im2col-style implicit
 // GEMM spends its time re-gathering the same input pixel kh*kw times and pads the 16 output channels to a
 // 32-row MFMA tile.  Here the input tile is staged ONCE in LDS with its halo (zero-filled outside the
 // image) and the GEMM runs on v_mfma_f32_16x16x4_f32 tiles that match 16 output channels exactly:
 //
 //   forward : out[o][px] = sum_k Wp[k][o] * Xh[koff(k) + pix(px)]            k = (tap, c), c fastest
-//             A (weights) lives in registers for the whole workgroup (K/4 values per lane),
-//             B is one conflict-free ds_read_b32 per MFMA (lanes = 16 consecutive pixels).
+//             A (weights) and the halo offset of every k live in LDS for the whole workgroup,
+//             B is one ds_read_b32 per MFMA (lanes = 16 consecutive pixels).
 //   weight gradient : gw[o][k] = sum_px gy[o][px] * Xh[koff(k) + pix(px)]
 //             A = gy tile from LDS, B = the same halo image read with lanes = 16 consecutive k
 //             (c fastest -> plane stride, odd -> conflict-free); every wave owns a quarter of the
