@@ -38,7 +38,7 @@ def m(n, c):
     return a[0] / a[1] if a and a[1] else float('nan')
 rows = []
 for n in agg:
-    if not any(t in n for t in ('hconv', 'igemm', 'smallc_fwd', 'smallc_wgrad', 'dgrad_s2_c16_kernel', 'hwgrad_kernel')):
+    if not any(t in n for t in ('hconv', 'igemm', 'smallc_fwd', 'smallc_wgrad', 'dgrad_s2_c16_kernel', 'hwgrad')):
         continue
     wc = m(n, 'SQ_WAVE_CYCLES') or float('nan')
     rows.append((dur[n][0], n, dur[n][1], dur[n][0] / max(dur[n][1], 1),

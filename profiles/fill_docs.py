@@ -36,7 +36,7 @@ def bucket(name):
     if 'dcn_bwd_data' in n or 'dcn_prep' in n: return 'DCN coord-grad + col2im (one launch)'
     if 'dcn_coord' in n: return 'DCN coord-grad'
     if 'dcn_col2im' in n: return 'DCN col2im'
-    if 'igemm_wgrad' in n or 'smallc_wgrad' in n or 'slab_reduce' in n or 'hwgrad_kernel' in n: return 'conv wgrad'
+    if 'igemm_wgrad' in n or 'smallc_wgrad' in n or 'slab_reduce' in n or 'hwgrad' in n: return 'conv wgrad'
     if 'Dgrad' in n: return 'conv dgrad'
     if 'igemm_fwd' in n or 'smallc_fwd' in n or 'hconv_kernel' in n: return 'conv fwd (incl. DCN column-gradient GEMMs, stride-1 smallc dgrad)'
     if n.startswith('bn_') or 'bn_' in n.split('<')[0]: return 'BatchNorm'
