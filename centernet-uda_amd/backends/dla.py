@@ -122,6 +122,15 @@ def _conv(cin, cout, k, stride=1):
     return hnn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False, emit_stats=True)    # (every caller: conv -> BatchNorm)
 
 
+def _norm_on_load_ok(cin, cout, k):
+    """Does a k x k / stride 1 convolution cin -> cout of this library normalise its input on load?"""
+    try:
+        import hip_runtime as hr
+        return bool(hr.lib().cnuda_conv2d_norm_input_supported(1, cin, 64, 64, cout, k, k, 1, 1, k // 2, k // 2))
+    except Exception:       # (no library in this process: the structure tests on a CPU-only box build the model anyway)
+        return False
+
+
 class ConvBnRelu(nn.Sequential):
     """children '0' (conv) and '1' (bn); ReLU is fused into the BN kernel."""
 
@@ -264,6 +273,10 @@ class DLA(nn.Module):
         c = self.channels = list(channels)
         self.base_layer = ConvBnRelu(3, c[0], 7)
         self.level0 = ConvBnRelu(c[0], c[0], 3)
+        # the stem's BatchNorm + ReLU is applied by level0's convolution while it stages its input (hip_runtime.ops.conv2d,
+        # apply on load: the 16-channel full-resolution activation is neither written nor read back) -- level0 is its only
+        # consumer (forward below)
+        self.base_layer[1].defer_apply = _norm_on_load_ok(c[0], c[0], 3)
         self.level1 = ConvBnRelu(c[0], c[1], 3, stride=2)
         self.level2 = Tree(levels[2], c[1], c[2], 2, level_root=False)
         self.level3 = Tree(levels[3], c[2], c[3], 2, level_root=True)

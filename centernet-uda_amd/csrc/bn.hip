@@ -191,6 +191,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
             if (c == 0 && num_batches_tracked) *num_batches_tracked += groups;     // nn.BatchNorm2d's counter
         }
     }
+    if (y == nullptr) return;       // statistics only: the consumer of x applies the normalisation while it stages x (apply on load)
     __syncthreads();
     const float sc = __fmul_rn(stat[1], gamma[c]);
     const float sh = bn_shift(beta[c], stat[0], sc);
@@ -410,7 +411,9 @@ extern "C" int cnuda_bn_train_forward_stats(const float* x, const float* stats, 
                                             long long* num_batches_tracked, float momentum, float eps, int relu, int B,
                                             int C, long long HW, int groups, void* workspace, size_t workspace_bytes,
                                             cnuda_stream_t stream) {
-    CNUDA_REQUIRE(x && stats && gamma && beta && y && save_mean && save_invstd, "cnuda_bn_train_forward_stats: null pointer");
+    // (y == nullptr: statistics, saved mean / invstd and the running statistics only -- no pass over x)
+    CNUDA_REQUIRE(x && stats && gamma && beta && save_mean && save_invstd, "cnuda_bn_train_forward_stats: null pointer");
+    CNUDA_REQUIRE(y || !residual, "cnuda_bn_train_forward_stats: a deferred apply has no residual");
     CNUDA_REQUIRE(B > 0 && C > 0 && HW > 0 && blocks_per_group > 0 && rows >= C, "cnuda_bn_train_forward_stats: bad geometry");
     CNUDA_REQUIRE(groups >= 1 && B % groups == 0, "cnuda_bn_train_forward_stats: batch %d not divisible into %d groups", B, groups);
     CNUDA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "cnuda_bn_train_forward_stats: running stats");
@@ -429,7 +432,7 @@ extern "C" int cnuda_bn_train_forward_stats(const float* x, const float* stats, 
     CNUDA_LAUNCH(bn_fold_stats_kernel, dim3((C + 15) / 16, S), dim3(256), 0, st, stats, rows, bpg, spl, partial, C, S);
     const Split sp = pick_split(B, C, HW, Bg);                // (the apply pass's own grid: unchanged)
     const long long planes = (long long)B * C / sp.ips;
-    CNUDA_LAUNCH(bn_apply_kernel, dim3((unsigned)planes, plane_splits(planes, HW, kBnThreads * 4)),
+    CNUDA_LAUNCH(bn_apply_kernel, dim3((unsigned)planes, y ? plane_splits(planes, HW, kBnThreads * 4) : 1),
                        dim3(kBnThreads), 0, st, x, partial, S, count, momentum, eps, save_mean, save_invstd,
                        running_mean, running_var, num_batches_tracked, gamma, beta, residual, y, C, HW, relu, groups, Bg,
                        sp.per_plane, sp.ips, spl);

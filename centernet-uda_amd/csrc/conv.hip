@@ -1025,6 +1025,55 @@ extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weig
                                           workspace_bytes, stream);
 }
 
+// ---- apply on load (round 5): convolutions whose INPUT is another convolution's output with a train-mode BatchNorm + ReLU
+// still to be applied (cnuda_bn_train_forward_stats with y == nullptr left mean / invstd).  The kernel normalises while it
+// stages x -- one pass over the activation less in each direction.  Only where the staging touches every input element once:
+// cnuda_conv2d_norm_input_supported says for which geometries (today: the LDS-tile kernels' 3x3 / one-row-tile instances,
+// i.e. DLA-34's level0 behind the stem).  Values are bit-identical to the materialised form (same two rounded operations).
+extern "C" int cnuda_conv2d_norm_input_supported(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph,
+                                                 int pw) {
+    (void)B; (void)H; (void)W;
+    return ph == (kh - 1) / 2 && pw == (kw - 1) / 2 && smallc_norm_supported(C, Cout, kh, kw, sh, sw) ? 1 : 0;
+}
+extern "C" int cnuda_conv2d_forward_norm_input(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                               const float* beta, int imgs_per_group, const float* weight, const float* bias,
+                                               float* y, float* stats, int B, int C, int H, int W, int Cout, int kh, int kw,
+                                               int sh, int sw, int ph, int pw, float act_slope, void* workspace,
+                                               size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && mean && invstd && gamma && beta && weight && y, "cnuda_conv2d_forward_norm_input: null pointer");
+    CNUDA_REQUIRE(imgs_per_group > 0 && B % imgs_per_group == 0, "cnuda_conv2d_forward_norm_input: statistics groups");
+    CNUDA_REQUIRE(cnuda_conv2d_norm_input_supported(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw),
+                  "cnuda_conv2d_forward_norm_input: geometry without an apply-on-load kernel");
+    if (stats) {
+        int rows = 0;
+        CNUDA_REQUIRE(act_slope < 0.0f && cnuda_conv2d_stats_block(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, &rows, nullptr) != 0,
+                      "cnuda_conv2d_forward_norm_input: no statistics for this call");
+    }
+    const SmallNorm nm{mean, invstd, gamma, beta, imgs_per_group};
+    return smallc_forward(x, weight, bias, y, B, C, H, W, Cout, kh, kw, sh, ph, pw, act_slope, 0, workspace, workspace_bytes,
+                          (hipStream_t)stream, stats, &nm);
+}
+extern "C" int cnuda_conv2d_backward_weight_norm_input(const float* x, const float* mean, const float* invstd,
+                                                       const float* gamma, const float* beta, int imgs_per_group,
+                                                       const float* grad_y, float* grad_weight, float* grad_bias, int B, int C,
+                                                       int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                                                       void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && mean && invstd && gamma && beta && grad_y && grad_weight,
+                  "cnuda_conv2d_backward_weight_norm_input: null pointer");
+    CNUDA_REQUIRE(imgs_per_group > 0 && B % imgs_per_group == 0, "cnuda_conv2d_backward_weight_norm_input: statistics groups");
+    CNUDA_REQUIRE(cnuda_conv2d_norm_input_supported(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw),
+                  "cnuda_conv2d_backward_weight_norm_input: geometry without an apply-on-load kernel");
+    ConvGeom g;
+    if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_backward_weight_norm_input")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const SmallNorm nm{mean, invstd, gamma, beta, imgs_per_group};
+    if (int rc = smallc_backward_weight(x, grad_y, grad_weight, B, C, H, W, Cout, kh, kw, sh, ph, pw, workspace, workspace_bytes,
+                                        st, &nm))
+        return rc;
+    if (grad_bias) launch_channel_sum(grad_y, grad_bias, B, Cout, (long long)g.Ho * g.Wo, st);
+    return check_launch("cnuda_conv2d_backward_weight_norm_input");
+}
+
 extern "C" int cnuda_conv2d_backward_data_add(const float* grad_y, const float* weight, const float* addend,
                                               const float* addend2, float* grad_x, int B, int C, int H, int W, int Cout,
                                               int kh, int kw, int sh, int sw, int ph, int pw, void* workspace,

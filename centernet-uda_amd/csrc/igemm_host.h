@@ -52,15 +52,23 @@ void launch_slab_reduce(const float* slabs, float* gw, int Z, int Mp, int Jp,
 void launch_channel_sum(const float* x, float* out, int B, int C, long long HW, hipStream_t st);
 
 // small-channel, full-resolution convolutions with LDS halo tiles (smallc.hip)
+// Apply on load: the input is a convolution output whose train-mode BatchNorm + ReLU is applied while the kernel stages it
+// (smallc.hip); mean / invstd [groups][C] as cnuda_bn_train_forward* saved them, gamma / beta [C].
+struct SmallNorm {
+    const float *mean, *invstd, *gamma, *beta;
+    int imgs_per_group;
+};
+bool smallc_norm_supported(int C, int Co, int kh, int kw, int sh, int sw);     // the instances compiled with the transform
 bool smallc_supported(int C, int Co, int kh, int kw, int sh, int sw);
 size_t smallc_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int s, int ph, int pw);
 int smallc_forward(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W, int Co,
                    int kh, int kw, int s, int ph, int pw, float act_slope, int transposed, void* ws, size_t ws_bytes,
-                   hipStream_t st, float* stats = nullptr);
+                   hipStream_t st, float* stats = nullptr, const SmallNorm* norm = nullptr);
 int smallc_stats_blocks(int B, int C, int H, int W, int Co, int kh, int kw, int s, int ph, int pw, int* blocks_per_image,
                         int* rows);
 int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, int C, int H, int W, int Co, int kh,
-                           int kw, int s, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t st);
+                           int kw, int s, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t st,
+                           const SmallNorm* norm = nullptr);
 
 struct Carver {
     uintptr_t cur, end;

@@ -39,6 +39,14 @@ struct SmallGeom {
 // of every halo row by a run-time division and guarded every load with a branch: ~100 scalar instructions per row, 24
 // rows per wave and tile -- measured, with the MFMA loop compiled out the 16 -> 16 layer still took 509 of its 723 us.)
 constexpr int SC_ROWS_PER_WAVE = 24;
+
+// Apply on load (round 5): the input x is the OUTPUT OF A CONVOLUTION whose train-mode BatchNorm + ReLU was not applied --
+// the kernels normalise while they stage: a = max(x * sc + sh, 0) with sc = invstd * gamma, sh = beta - mean * sc per
+// (statistics group of the image, channel), the two operations bn_apply_kernel performs, rounded the same way (bit-identical
+// to the materialised activation), and zero outside the image AFTER the transform.  mean == nullptr: x is taken as it is.
+__device__ __forceinline__ float sc_bn_shift(float beta, float mean, float sc) { return __fsub_rn(beta, __fmul_rn(mean, sc)); }
+__device__ __forceinline__ float sc_bn_act(float x, float sc, float sh) { return fmaxf(__fadd_rn(__fmul_rn(x, sc), sh), 0.0f); }
+
 template <int KH> struct ScShape {
     static constexpr int HR = SC_TH - 1 + KH, HC = SC_TW - 1 + KH;
     static constexpr int NX = HC - 64;                      // halo columns beyond a wave's 64 lanes
@@ -55,10 +63,11 @@ template <int KH> struct ScShape {
 // image read 0.0f through the buffer range check (the padding value), no compare on the data path.
 // load() only ISSUES the global loads (into registers); store() writes them to LDS: the forward kernel loads the NEXT
 // tile's halo before the MFMA loop of the current one.
-template <int KH>
+template <int KH, bool NORM = false>
 struct HaloStage {
     using S = ScShape<KH>;
     struct Regs { float v[S::ROWS]; float vx; };
+    float nsc[S::CPW], nsh[S::CPW], xsc, xsh;    // NORM: scale / shift of the channels this wave stages, and of the extra lane's
     buf_rsrc rs;
     unsigned va;                 // byte offset of column ix0 + lane inside an input row, or the sentinel
     unsigned xcol;               // the extra-column lane: byte offset of ITS column, or the sentinel
@@ -81,6 +90,22 @@ struct HaloStage {
         x_lds = (slot < S::ROWS && x_c < g.C) ? x_c * S::plane + x_hy * S::HC + xc : -1;
         if (x_lds < 0) xcol = IG_BUF_OOB;
     }
+    // NORM: the scale / shift of image b's statistics group
+    __device__ __forceinline__ void set_norm(const SmallGeom& g, const SmallNorm& nm, int b) {
+        const int grp = b / nm.imgs_per_group;
+        auto coef = [&](int c, float& sc, float& sh) {
+            sc = __fmul_rn(nm.invstd[grp * g.C + c], nm.gamma[c]);
+            sh = sc_bn_shift(nm.beta[c], nm.mean[grp * g.C + c], sc);
+        };
+#pragma unroll
+        for (int cc = 0; cc < S::CPW; ++cc) {
+            const int c = wid + 4 * cc;
+            nsc[cc] = 0.f; nsh[cc] = 0.f;
+            if (c < g.C) coef(c, nsc[cc], nsh[cc]);
+        }
+        xsc = 0.f; xsh = 0.f;
+        if (x_lds >= 0) coef(x_c, xsc, xsh);
+    }
     __device__ __forceinline__ void load(const SmallGeom& g, int iy0, Regs& r) const {
 #pragma unroll
         for (int cc = 0; cc < S::CPW; ++cc) {
@@ -96,14 +121,29 @@ struct HaloStage {
         const bool ok = iy >= 0 && iy < g.H;
         r.vx = ig_buf_load(rs, ok ? xcol + (unsigned)((x_c * g.H + iy) * g.W) * 4u : IG_BUF_OOB, 0u);
     }
-    __device__ __forceinline__ void store(const SmallGeom& g, float* __restrict__ Xh, const Regs& r) const {
+    // iy0: the tile's first halo row in the image (NORM: which staged cells lie inside the image)
+    __device__ __forceinline__ void store(const SmallGeom& g, float* __restrict__ Xh, const Regs& r, int iy0) const {
 #pragma unroll
         for (int cc = 0; cc < S::CPW; ++cc) {
             if (wid + 4 * cc >= g.C) break;                   // (uniform)
 #pragma unroll
-            for (int hy = 0; hy < S::HR; ++hy) Xh[lds0 + 4 * cc * S::plane + hy * S::HC] = r.v[cc * S::HR + hy];
+            for (int hy = 0; hy < S::HR; ++hy) {
+                float v = r.v[cc * S::HR + hy];
+                if constexpr (NORM) {
+                    const bool in = iy0 + hy >= 0 && iy0 + hy < g.H && va != IG_BUF_OOB;
+                    v = in ? sc_bn_act(v, nsc[cc], nsh[cc]) : 0.0f;
+                }
+                Xh[lds0 + 4 * cc * S::plane + hy * S::HC] = v;
+            }
         }
-        if (x_lds >= 0) Xh[x_lds] = r.vx;
+        if (x_lds >= 0) {
+            float v = r.vx;
+            if constexpr (NORM) {
+                const bool in = iy0 + x_hy >= 0 && iy0 + x_hy < g.H && xcol != IG_BUF_OOB;
+                v = in ? sc_bn_act(v, xsc, xsh) : 0.0f;
+            }
+            Xh[x_lds] = v;
+        }
     }
 };
 
@@ -124,12 +164,12 @@ constexpr int SC_YLD = SC_TW + 4;   // row stride of the per-wave output staging
 #ifndef SC_FWD_OCC
 #define SC_FWD_OCC 2
 #endif
-template <int MT, int KH>
+template <int MT, int KH, bool NORM = false>
 __global__ __launch_bounds__(IG_THREADS, SC_FWD_OCC) void smallc_fwd_kernel(SmallGeom g, const float* __restrict__ x,
                                                                const float* __restrict__ Wp,
                                                                const int* __restrict__ koff_tab,
                                                                const float* __restrict__ bias, float* __restrict__ y,
-                                                               float act_slope, float* __restrict__ stats) {
+                                                               float act_slope, float* __restrict__ stats, SmallNorm nm) {
     extern __shared__ __align__(16) float smem[];
     float* Xh = smem;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and the compiler knows it)
@@ -152,15 +192,16 @@ __global__ __launch_bounds__(IG_THREADS, SC_FWD_OCC) void smallc_fwd_kernel(Smal
     float* Ys = smem + g.C * g.plane + 16 + wid * (16 * MT * SC_YLD);
     const bool vec = (g.Wo & 3) == 0;
     using S = ScShape<KH>;
-    const HaloStage<KH> hs(g, xb, ox0 - g.pw, tid);
-    typename HaloStage<KH>::Regs halo;
+    HaloStage<KH, NORM> hs(g, xb, ox0 - g.pw, tid);
+    if constexpr (NORM) hs.set_norm(g, nm, b);
+    typename HaloStage<KH, NORM>::Regs halo;
     hs.load(g, (blockIdx.y * SC_NV) * SC_TH - g.ph, halo);
 #pragma unroll 1
     for (int vt = 0; vt < SC_NV; ++vt) {
     const int oy0 = (blockIdx.y * SC_NV + vt) * SC_TH;
     if (oy0 >= g.Ho) break;
     __syncthreads();                                // the previous tile's fragment reads are done
-    hs.store(g, Xh, halo);
+    hs.store(g, Xh, halo, oy0 - g.ph);
     __syncthreads();
     if (vt + 1 < SC_NV && oy0 + SC_TH < g.Ho)       // next tile's halo: in flight under this tile's MFMAs
         hs.load(g, (oy0 + SC_TH) - g.ph, halo);
@@ -282,11 +323,11 @@ __global__ __launch_bounds__(IG_THREADS, SC_FWD_OCC) void smallc_fwd_kernel(Smal
 // NT: column tiles (of 16 k) the instance computes -- >= Kp16 / 16; tiles past the real ones read halo cell 0 and are
 // never written out.  A compile-time count keeps the MFMA loop free of branches: the first version tested `nt < ntiles`
 // per MFMA, which serialised every MFMA behind its own LDS read (read, wait, multiply; nine times per k-step).
-template <int MT, int KH, int NT>
+template <int MT, int KH, int NT, bool NORM = false>
 __global__ __launch_bounds__(IG_THREADS, (MT == 1 ? 3 : 2)) void smallc_wgrad_kernel(SmallGeom g, const float* __restrict__ x,
                                                                  const float* __restrict__ gy,
                                                                  const int* __restrict__ koff_tab,
-                                                                 float* __restrict__ slabs, int Kp16) {
+                                                                 float* __restrict__ slabs, int Kp16, SmallNorm nm) {
     extern __shared__ __align__(16) float smem[];
     float* Xh = smem;                                   // [C][plane]
     float* Gs = Xh + g.C * g.plane + 16;                // [16*MT][SC_TH*SC_TW + 1]  (o, pixel of the tile)
@@ -298,7 +339,8 @@ __global__ __launch_bounds__(IG_THREADS, (MT == 1 ? 3 : 2)) void smallc_wgrad_ke
     const float* xb = x + (size_t)b * g.C * g.H * g.W;
     const float* gb = gy + (size_t)b * g.Co * HoWo;
     const int ntiles = Kp16 / 16;
-    const HaloStage<KH> hs(g, xb, ox0 - g.pw, tid);
+    HaloStage<KH, NORM> hs(g, xb, ox0 - g.pw, tid);
+    if constexpr (NORM) hs.set_norm(g, nm, b);
 
     // this lane's column k = nt*16 + il of every column tile -> halo cell of its pixel 0 (B operand, lanes = columns):
     // row `wid` of the tile, pixel kq of a k-step
@@ -319,7 +361,7 @@ __global__ __launch_bounds__(IG_THREADS, (MT == 1 ? 3 : 2)) void smallc_wgrad_ke
 #define SC_WG_PREFETCH 1
 #endif
     constexpr bool PF = MT == 1 && SC_WG_PREFETCH;
-    typename HaloStage<KH>::Regs halo;
+    typename HaloStage<KH, NORM>::Regs halo;
     float gv[4 * MT * SC_TH];
     const buf_rsrc grs = ig_make_rsrc(gb, (unsigned)((size_t)g.Co * HoWo * sizeof(float)));
     const unsigned gva = ox0 + lane < g.Wo ? (unsigned)(ox0 + lane) * 4u : IG_BUF_OOB;
@@ -342,7 +384,7 @@ __global__ __launch_bounds__(IG_THREADS, (MT == 1 ? 3 : 2)) void smallc_wgrad_ke
     const bool more = vt + 1 < SC_NV && oy0 + SC_TH < g.Ho;
     __syncthreads();                                    // the previous tile's fragment reads are done
     if (!PF) tile_load(oy0);
-    hs.store(g, Xh, halo);
+    hs.store(g, Xh, halo, oy0 - g.ph);
     // gy tile: Gs[o][row*64 + col], zero outside the image / beyond Co
 #pragma unroll
     for (int i = 0; i < 4 * MT * SC_TH; ++i) {
@@ -480,6 +522,11 @@ bool smallc_supported(int C, int Co, int kh, int kw, int sh, int sw) {
     return sh == 1 && sw == 1 && kh == kw && (kh == 3 || kh == 7) && C <= 16 && Co <= 32 && C * kh * kw <= SC_MAXK - 12 &&
            cpw <= (kh == 3 ? ScShape<3>::CPW : ScShape<7>::CPW);
 }
+bool smallc_norm_supported(int C, int Co, int kh, int kw, int sh, int sw) {
+    // (one row tile of output channels, 3x3: DLA-34's level0 behind the stem's BatchNorm; K = 9 C must fill more than four
+    // column tiles -- the weight-gradient instance compiled with the transform is the nine-tile one)
+    return smallc_supported(C, Co, kh, kw, sh, sw) && kh == 3 && Co <= 16 && (C * 9 + 15) / 16 > 4;
+}
 size_t smallc_workspace_bytes(int B, int C, int H, int W, int Co, int kh, int kw, int s, int ph, int pw) {
     SmallGeom g;
     fill_small(g, B, C, H, W, Co, kh, kw, s, ph, pw);
@@ -503,7 +550,7 @@ int smallc_stats_blocks(int B, int C, int H, int W, int Co, int kh, int kw, int 
 
 int smallc_forward(const float* x, const float* w, const float* bias, float* y, int B, int C, int H, int W, int Co,
                    int kh, int kw, int s, int ph, int pw, float act_slope, int transposed, void* ws, size_t ws_bytes,
-                   hipStream_t st, float* stats) {
+                   hipStream_t st, float* stats, const SmallNorm* norm) {
     // transposed: computes the stride-1 input gradient: x := grad_y [B, Co_orig, H, W], w is the ORIGINAL
     // weight [Co_orig = C here][C_orig = Co here][kh][kw]; the caller passes C/Co already swapped.
     SmallGeom g;
@@ -527,16 +574,23 @@ int smallc_forward(const float* x, const float* w, const float* bias, float* y, 
     prof.name("smallc_fwd_kernel<%d>", mt);
     CNUDA_REQUIRE(kh == kw && (kh == 3 || kh == 7) && g.plane == (kh == 3 ? ScShape<3>::plane : ScShape<7>::plane),
                   "smallc_forward: filter size without a compiled halo geometry");
+    const SmallNorm none{nullptr, nullptr, nullptr, nullptr, 1};
 #define CNUDA_SC_FWD(MTV, KHV) \
-    CNUDA_LAUNCH((smallc_fwd_kernel<MTV, KHV>), grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope, stats)
-    if (mt == 1) { if (kh == 3) CNUDA_SC_FWD(1, 3); else CNUDA_SC_FWD(1, 7); }
+    CNUDA_LAUNCH((smallc_fwd_kernel<MTV, KHV>), grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope, stats, none)
+    if (norm) {
+        CNUDA_REQUIRE(!transposed && smallc_norm_supported(C, Co, kh, kw, s, s) && norm->mean && norm->invstd && norm->gamma &&
+                      norm->beta && norm->imgs_per_group > 0, "smallc_forward: apply-on-load is not compiled for this geometry");
+        CNUDA_LAUNCH((smallc_fwd_kernel<1, 3, true>), grid, dim3(IG_THREADS), lds, st, g, x, Wp, koff, bias, y, act_slope, stats,
+                     *norm);
+    } else if (mt == 1) { if (kh == 3) CNUDA_SC_FWD(1, 3); else CNUDA_SC_FWD(1, 7); }
     else         { if (kh == 3) CNUDA_SC_FWD(2, 3); else CNUDA_SC_FWD(2, 7); }
 #undef CNUDA_SC_FWD
     return check_launch("smallc_forward");
 }
 
 int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, int C, int H, int W, int Co, int kh,
-                           int kw, int s, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t st) {
+                           int kw, int s, int ph, int pw, void* ws, size_t ws_bytes, hipStream_t st,
+                           const SmallNorm* norm) {
     SmallGeom g;
     fill_small(g, B, C, H, W, Co, kh, kw, s, ph, pw);
     const int mt = (Co + 15) / 16, Kp16 = (g.K + 15) / 16 * 16;
@@ -556,6 +610,7 @@ int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, in
                   "smallc_backward_weight: filter size without a compiled halo geometry");
     // column tiles the instance computes: all of a 16-channel 3x3 (9) / a 3-channel 7x7 (10) filter, or 4 for the small
     // shapes (K <= 64)
+    const SmallNorm none{nullptr, nullptr, nullptr, nullptr, 1};
     const int nt_real = Kp16 / 16, nt_full = kh == 3 ? 9 : 10;
     CNUDA_REQUIRE(nt_real <= nt_full, "smallc_backward_weight: K exceeds the compiled column tiles");
     {
@@ -568,13 +623,24 @@ int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, in
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
             raised = true;                                                                                            \
         }                                                                                                             \
-        CNUDA_LAUNCH((smallc_wgrad_kernel<MTV, KHV, NTV>), grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16); \
+        CNUDA_LAUNCH((smallc_wgrad_kernel<MTV, KHV, NTV>), grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16, none); \
     } while (0)
 #define CNUDA_SC_WG_KH(MTV) do {                                                                                     \
         if (kh == 3) { if (nt_real <= 4) CNUDA_SC_WG(MTV, 3, 4); else CNUDA_SC_WG(MTV, 3, 9); }                       \
         else         { if (nt_real <= 4) CNUDA_SC_WG(MTV, 7, 4); else CNUDA_SC_WG(MTV, 7, 10); }                      \
     } while (0)
-        if (mt == 1) CNUDA_SC_WG_KH(1); else CNUDA_SC_WG_KH(2);
+        if (norm) {
+            CNUDA_REQUIRE(smallc_norm_supported(C, Co, kh, kw, s, s) && nt_real > 4 && norm->mean && norm->invstd &&
+                          norm->gamma && norm->beta && norm->imgs_per_group > 0,
+                          "smallc_backward_weight: apply-on-load is not compiled for this geometry");
+            static bool raised = false;
+            if (!raised) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(smallc_wgrad_kernel<1, 3, 9, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                raised = true;
+            }
+            CNUDA_LAUNCH((smallc_wgrad_kernel<1, 3, 9, true>), grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16, *norm);
+        } else if (mt == 1) CNUDA_SC_WG_KH(1); else CNUDA_SC_WG_KH(2);
 #undef CNUDA_SC_WG_KH
 #undef CNUDA_SC_WG
     }

@@ -80,6 +80,9 @@ class _Sig:
     cnuda_conv2d_forward_stats = (_I, [_P] * 6 + [_I] * 11 + [_F] + _WS)
     cnuda_bn_train_forward_stats = (_I, [_P, _P, _LL, _I] + [_P] * 9 + [_F, _F, _I, _I, _I, _LL, _I] + _WS)
     cnuda_conv2d_backward_weight = (_I, [_P] * 4 + [_I] * 11 + _WS)
+    cnuda_conv2d_norm_input_supported = (_I, [_I] * 11)
+    cnuda_conv2d_forward_norm_input = (_I, [_P] * 5 + [_I] + [_P] * 4 + [_I] * 11 + [_F] + _WS)
+    cnuda_conv2d_backward_weight_norm_input = (_I, [_P] * 5 + [_I] + [_P] * 3 + [_I] * 11 + _WS)
     cnuda_bn_workspace_bytes = (c_size_t, [_I, _I, _LL])
     cnuda_bn_train_forward = (_I, [_P] * 10 + [_F, _F, _I, _I, _I, _LL, _I] + _WS)
     cnuda_bn_eval_forward = (_I, [_P] * 7 + [_F, _I, _I, _I, _LL, _P])

@@ -63,11 +63,16 @@ class BatchNorm2d(nn.Module):
         self.register_buffer('running_var', torch.ones(num_features))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
+    # defer_apply: set by an owner whose ONLY consumer of this module's output is a convolution that normalises on load
+    # (ops.conv2d / cnuda_conv2d_norm_input_supported): in training mode the output tensor is then returned unwritten
+    defer_apply = False
+
     def forward(self, x, residual=None, relu=False):
         if x.shape[1] != self.num_features:
             raise RuntimeError("BatchNorm2d: expected %d channels, got %d" % (self.num_features, x.shape[1]))
         return ops.batch_norm_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                  self.momentum, self.eps, residual, relu, self.num_batches_tracked)
+                                  self.momentum, self.eps, residual, relu, self.num_batches_tracked,
+                                  defer_apply=self.defer_apply and self.training)
 
 
 class MaxPool2d(nn.Module):

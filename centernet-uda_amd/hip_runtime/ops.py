@@ -47,7 +47,11 @@ def _conv_geom(x, weight, stride, padding):
 
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, act_slope, pack_token=0, stats_box=None):
+    def forward(ctx, x, weight, bias, stride, padding, act_slope, pack_token=0, stats_box=None, norm=None):
+        """norm: None, or (x_raw, mean, invstd, gamma, beta, imgs_per_group) when `x` is the never-written output of a
+        BatchNorm + ReLU in deferred mode (batch_norm_act(defer_apply=True)): the kernel reads x_raw and normalises while it
+        stages it (cnuda_conv2d_forward_norm_input); the gradient this node returns for `x` is the one with respect to the
+        normalised activation, exactly what the BatchNorm's backward expects."""
         require_gpu(x, weight, bias)
         ctx.slot = slot_of(x)          # (hip_runtime.fanout: where the other consumers of x leave their share of its gradient)
         x, weight = f32c(x), f32c(weight)
@@ -71,20 +75,31 @@ class _Conv2d(Function):
                 stats_box.append((stats, 0 if bpi.value else blk, rows.value, bpi.value))
         prof_arm('conv_fwd', B, C, H, W, Co, kh, kw, Ho, Wo)
         with pack_stamp(pack_token, weight):
-            if stats is None:
+            if norm is not None:
+                xr, mean, invstd, gamma, beta, ipg = norm
+                check(L.cnuda_conv2d_forward_norm_input(ptr(xr), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), int(ipg),
+                                                        ptr(weight), ptr(bias), ptr(y), ptr(stats), *g, float(act_slope),
+                                                        wp, wn, stream()), 'conv2d_forward_norm_input')
+            elif stats is None:
                 check(L.cnuda_conv2d_forward(ptr(x), ptr(weight), ptr(bias), ptr(y), *g, float(act_slope),
                                              wp, wn, stream()), 'conv2d_forward')
             else:
                 check(L.cnuda_conv2d_forward_stats(ptr(x), ptr(weight), ptr(bias), ptr(None), ptr(y), ptr(stats), *g,
                                                    float(act_slope), wp, wn, stream()), 'conv2d_forward_stats')
         ctx.geom, ctx.act_slope, ctx.has_bias, ctx.pack_token = g, act_slope, bias is not None, pack_token
-        ctx.save_for_backward(x, weight, y if act_slope >= 0 else None, bias)
+        ctx.norm_ipg = None
+        if norm is not None:
+            # (x itself holds nothing: the weight gradient normalises x_raw again while it stages it)
+            ctx.norm_ipg = int(norm[5])
+            ctx.save_for_backward(norm[0], weight, y if act_slope >= 0 else None, bias, norm[1], norm[2], norm[3], norm[4])
+        else:
+            ctx.save_for_backward(x, weight, y if act_slope >= 0 else None, bias)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, weight, y, bias = ctx.saved_tensors
+        x, weight, y, bias = ctx.saved_tensors[:4]
         g = ctx.geom
         L = lib()
         gy = f32c(gy)
@@ -106,9 +121,15 @@ class _Conv2d(Function):
             gw_buf, gw = _param_grad(weight)
             gb_buf, gb = _param_grad(bias, ctx.has_bias)
             prof_arm('conv_wgrad', B, C, H, W, Co, kh, kw, Ho, Wo)
-            check(L.cnuda_conv2d_backward_weight(ptr(x), ptr(gy), ptr(gw_buf), ptr(gb_buf), *g, wp, wn, stream()),
-                  'conv2d_backward_weight')
-        return gx, gw, gb, None, None, None, None, None
+            if ctx.norm_ipg is not None:
+                mean, invstd, gamma, beta = ctx.saved_tensors[4:]
+                check(L.cnuda_conv2d_backward_weight_norm_input(ptr(x), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta),
+                                                                ctx.norm_ipg, ptr(gy), ptr(gw_buf), ptr(gb_buf), *g, wp, wn,
+                                                                stream()), 'conv2d_backward_weight_norm_input')
+            else:
+                check(L.cnuda_conv2d_backward_weight(ptr(x), ptr(gy), ptr(gw_buf), ptr(gb_buf), *g, wp, wn, stream()),
+                      'conv2d_backward_weight')
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 EPILOGUE_STATS = True      # (A/B measurements flip it: profiles/microbench/ab_bn_stats.py)
@@ -118,12 +139,18 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0, pack_token
     """y = act(conv2d(x, weight) + bias); act_slope < 0 none, 0 ReLU, 0.2 LeakyReLU(0.2).  pack_token: identity of
     the module that owns `weight` (hip_runtime.new_pack_token) -- lets the library keep the packed weight image
     until the weights change; 0 = re-pack on every call."""
+    norm = getattr(x, '_cnuda_deferred_bn', None)        # (batch_norm_act(defer_apply=True): x was never written)
+    if norm is not None:
+        g = _conv_geom(x, weight, stride, padding)
+        if not lib().cnuda_conv2d_norm_input_supported(*g):
+            raise RuntimeError("conv2d: the input is a deferred BatchNorm output, but no apply-on-load kernel takes this "
+                               "convolution (cnuda_conv2d_norm_input_supported); ask batch_norm_act to apply it")
     if not (emit_stats and EPILOGUE_STATS):
-        return _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope), pack_token)
+        return _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope), pack_token, None, norm)
     # emit_stats: the caller's next layer is a train-mode BatchNorm over y.  Where the kernel can, it leaves
     # sum / sum of squares per (pixel block, channel) beside y; batch_norm_act finds them on the tensor.
     box = []
-    y = _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope), pack_token, box)
+    y = _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope), pack_token, box, norm)
     if box:
         y._cnuda_bn_stats = box[0]
     return y
@@ -337,7 +364,7 @@ def _act_code(relu):
 class _BatchNormAct(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, num_batches_tracked,
-                groups, pre=None):
+                groups, pre=None, defer=False):
         require_gpu(x, gamma, beta, residual)
         ctx.res_slot = None if residual is None else slot_of(residual)
         x = f32c(x)
@@ -358,10 +385,12 @@ class _BatchNormAct(Function):
                 bpg = B // groups * pre[3]
             elif (B // groups * HW) % pre[1] == 0:
                 bpg = B // groups * HW // pre[1]
+        # defer: the statistics only -- y stays unwritten, its consumer (ops.conv2d) normalises x while it stages it
+        ctx.deferred = bool(defer and bpg and residual is None and relu in (True, 1))
         if bpg:
             # sum(x) / sum(x^2) came with x from the producing GEMM's epilogue: no statistics pass over x
             check(L.cnuda_bn_train_forward_stats(ptr(x), ptr(pre[0]), bpg, pre[2], ptr(gamma), ptr(beta), ptr(residual),
-                                                 ptr(y), ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var),
+                                                 ptr(None if ctx.deferred else y), ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var),
                                                  ptr(num_batches_tracked), float(momentum), float(eps), _act_code(relu),
                                                  B, C, HW, groups, wp, wn, stream()), 'bn_train_forward_stats')
         else:
@@ -373,11 +402,14 @@ class _BatchNormAct(Function):
         # y is read by the backward only where a residual entered the activation; without one the gate is recomputed
         # from x (cnuda_bn_backward, `beta` given) and y is not kept
         ctx.save_for_backward(x, y if (relu and residual is not None) else None, gamma, mean, invstd, beta)
+        if ctx.deferred:
+            ctx.mark_non_differentiable(mean, invstd)
+            return y, mean, invstd
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gy):
+    def backward(ctx, gy, *_unused):
         x, y, gamma, mean, invstd, beta = ctx.saved_tensors
         B, C, HW = ctx.dims
         gy = f32c(gy)
@@ -392,14 +424,17 @@ class _BatchNormAct(Function):
         check(L.cnuda_bn_backward(ptr(gy), ptr(x), ptr(y), ptr(gamma), ptr(regate), ptr(mean), ptr(invstd), ptr(gx),
                                   ptr(gres), ptr(gg_buf), ptr(gb_buf), _act_code(ctx.relu), B, C, HW, ctx.groups, wp, wn,
                                   stream()), 'bn_backward')
-        return gx, gg, gb, gres, None, None, None, None, None, None, None, None
+        return gx, gg, gb, gres, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5,
-                   residual=None, relu=False, num_batches_tracked=None, groups=None):
+                   residual=None, relu=False, num_batches_tracked=None, groups=None, defer_apply=False):
     """`num_batches_tracked` (int64 scalar buffer, optional) is incremented by the statistics kernel in training
     mode, like nn.BatchNorm2d.forward does on the host.  `groups` (default: hip_runtime.current_groups()):
-    statistics groups of a batch that carries several domains, see hip_runtime.domain_groups."""
+    statistics groups of a batch that carries several domains, see hip_runtime.domain_groups.
+    defer_apply (training, ReLU, no residual, statistics from the producing GEMM's epilogue; ignored otherwise): the
+    returned tensor is NOT written -- it carries `_cnuda_deferred_bn`, and the one consumer the caller vouches for,
+    ops.conv2d, normalises x while it stages it (apply on load: one write and one read of the activation less)."""
     if groups is None:
         from . import current_groups
         groups = current_groups()
@@ -409,8 +444,14 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, training, momentum
             raise RuntimeError("batch_norm_act: num_batches_tracked must be an int64 tensor on the GPU")
         from . import bump_buffer_epoch
         bump_buffer_epoch()         # the kernel rewrites the running statistics behind torch's version counters
-        return _BatchNormAct.apply(x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu,
-                                   num_batches_tracked, int(groups), getattr(x, '_cnuda_bn_stats', None))
+        out = _BatchNormAct.apply(x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu,
+                                  num_batches_tracked, int(groups), getattr(x, '_cnuda_bn_stats', None), bool(defer_apply))
+        if isinstance(out, tuple):                  # deferred: (unwritten y, mean, invstd)
+            y, mean, invstd = out
+            y._cnuda_deferred_bn = (f32c(x).detach(), mean, invstd, f32c(gamma).detach(), f32c(beta).detach(),
+                                    x.shape[0] // int(groups))
+            return y
+        return out
     if torch.is_grad_enabled() and (x.requires_grad or gamma.requires_grad):
         raise RuntimeError("batch_norm_act: eval-mode BN has no backward in this build "
                            "(the reference evaluates under torch.no_grad(), train.py:172)")

@@ -280,6 +280,23 @@ int cnuda_conv2d_backward_data(const float* grad_y, const float* weight, float* 
                                int B, int C, int H, int W, int Cout, int kh, int kw,
                                int sh, int sw, int ph, int pw,
                                void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+/* Apply on load: x is the output of a convolution whose train-mode BatchNorm + ReLU has NOT been applied
+ * (cnuda_bn_train_forward_stats with y == NULL left save_mean / save_invstd, [groups][C]); the kernel computes
+ * max(x * (invstd * gamma) + (beta - mean * invstd * gamma), 0) while it stages x, per statistics group of imgs_per_group
+ * images -- bit-identical to convolving the materialised activation, one pass over it less in each direction.  Replaces
+ * the pass of reference backends/dla.py:19,40 (nn.BatchNorm2d + ReLU between two convolutions) for the geometries
+ * cnuda_conv2d_norm_input_supported() returns 1 for; the other arguments as cnuda_conv2d_forward_stats /
+ * cnuda_conv2d_backward_weight. */
+int cnuda_conv2d_norm_input_supported(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw);
+int cnuda_conv2d_forward_norm_input(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, int imgs_per_group, const float* weight, const float* bias, float* y,
+                                    float* stats, int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph,
+                                    int pw, float act_slope, void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+int cnuda_conv2d_backward_weight_norm_input(const float* x, const float* mean, const float* invstd, const float* gamma,
+                                            const float* beta, int imgs_per_group, const float* grad_y, float* grad_weight,
+                                            float* grad_bias, int B, int C, int H, int W, int Cout, int kh, int kw, int sh,
+                                            int sw, int ph, int pw, void* workspace, size_t workspace_bytes,
+                                            cnuda_stream_t stream);
 /* grad_x = input gradient + addend + addend2 (both nullable, shaped like grad_x, either may BE grad_x): where a tensor
  * feeds a convolution and something else (a skip connection, a concatenation, a DCN's sampling), the other consumers'
  * shares of its gradient are summed in the epilogue of this one instead of by passes of their own (what autograd's

@@ -304,12 +304,18 @@ MANIFEST = {
         'tests/test_gpu_fullsize.py::test_full_size_3x3_convolution_matches_fp64',
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
     ],
-    'smallc_fwd_kernel<1, 3>': [
+    'smallc_fwd_kernel<1, 3, true>': [      # (BatchNorm + ReLU of the input applied while staging: apply on load)
+        'tests/test_gpu_ops.py::test_batchnorm_applied_on_load_equals_the_materialised_activation',
+    ],
+    'smallc_wgrad_kernel<1, 3, 9, true>': [
+        'tests/test_gpu_ops.py::test_batchnorm_applied_on_load_equals_the_materialised_activation',
+    ],
+    'smallc_fwd_kernel<1, 3, false>': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[c16_3x3',
         'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics[B2C16H20W64Co16k3s1g1',
         'tests/test_gpu_fuzz.py::test_conv2d_random_geometry[0-B3C3H8W11Co16k3s1p1ba',
     ],
-    'smallc_fwd_kernel<1, 7>': [
+    'smallc_fwd_kernel<1, 7, false>': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[stem7x7',
         'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics[B2C3H24W72Co16k7s1g2',
         'tests/test_gpu_fuzz.py::test_conv2d_random_geometry[0-B1C1H18W17Co2k7s1p3',
@@ -334,11 +340,11 @@ MANIFEST = {
         'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
         'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
     ],
-    'smallc_wgrad_kernel<1, 3, 9>': [
+    'smallc_wgrad_kernel<1, 3, 9, false>': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[c16_3x3',
         'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics[B2C16H20W64Co16k3s1g1',
     ],
-    'smallc_wgrad_kernel<1, 7, 10>': [
+    'smallc_wgrad_kernel<1, 7, 10, false>': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[stem7x7',
         'tests/test_gpu_ops.py::test_convolution_epilogue_leaves_batchnorm_statistics[B2C3H24W72Co16k7s1g2',
     ],

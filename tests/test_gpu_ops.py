@@ -755,3 +755,64 @@ def test_stride2_sixteen_channel_input_gradient(shape):
     hr.check(L.cnuda_conv2d_backward_data_add(hr.ptr(gyd), hr.ptr(wd), hr.ptr(acc), hr.ptr(a2), hr.ptr(acc), *geom, wp, wn,
                                               hr.stream()), 'dgrad_add')
     _close(acc, (want + a1.double().cpu() + a2.double().cpu()).float(), 1e-5)
+
+
+@pytest.mark.parametrize('groups', [1, 2])
+def test_batchnorm_applied_on_load_equals_the_materialised_activation(groups):
+    """conv -> BatchNorm + ReLU -> conv with the BatchNorm's apply pass deferred into the second convolution's staging
+    (hip_runtime.ops.batch_norm_act(defer_apply=True), cnuda_conv2d_forward_norm_input / _backward_weight_norm_input: DLA-34's
+    stem -> level0): outputs, every gradient and the running statistics bit for bit those of the materialised form, and
+    (one statistics group) within 1e-4 of torch's own conv / batch_norm / relu on the CPU."""
+    import hip_runtime as hr
+    from hip_runtime import nn as hnn
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 4, 40, 72
+    x = torch.randn(B, 3, H, W, generator=g)
+    gy = torch.randn(B, 16, H, W, generator=g)
+    conv1 = hnn.Conv2d(3, 16, 7, padding=3, bias=False, emit_stats=True).to(DEV)
+    bn1 = hnn.BatchNorm2d(16).to(DEV)
+    conv2 = hnn.Conv2d(16, 16, 3, padding=1, bias=False, emit_stats=True).to(DEV)
+    bn2 = hnn.BatchNorm2d(16).to(DEV)
+    with torch.no_grad():
+        bn1.weight.uniform_(0.5, 1.5, generator=None); bn1.bias.uniform_(-0.5, 0.5)
+    mods = [conv1, bn1, conv2, bn2]
+    state = [{k: v.clone() for k, v in m.state_dict().items()} for m in mods]
+    for m in mods:
+        m.train()
+    assert hr.lib().cnuda_conv2d_norm_input_supported(B, 16, H, W, 16, 3, 3, 1, 1, 1, 1) == 1
+
+    def run(defer):
+        for m, st in zip(mods, state):
+            m.load_state_dict(st)
+            for p in m.parameters():
+                p.grad = None
+        bn1.defer_apply = defer
+        xd = x.to(DEV).requires_grad_(True)
+        with hr.domain_groups(groups), hr.launch_log() as log:
+            a = bn1(conv1(xd), relu=True)
+            assert hasattr(a, '_cnuda_deferred_bn') == defer
+            y = bn2(conv2(a), relu=True)
+            y.backward(gy.to(DEV))
+        names = ' '.join(log.names)
+        assert ('smallc_fwd_kernelILi1ELi3ELb1' in names or 'smallc_fwd_kernel<1, 3, true>' in names) == defer, names
+        out = [y.detach(), xd.grad] + [p.grad for m in mods for p in m.parameters()]
+        return out + [bn1.running_mean.clone(), bn1.running_var.clone(), bn2.running_mean.clone(), bn2.running_var.clone()]
+
+    plain, deferred = run(False), run(True)
+    for i, (a, b) in enumerate(zip(plain, deferred)):
+        assert torch.equal(a, b), (i, (a - b).abs().max().item())
+    if groups == 1:
+        ref = torch.nn.Sequential(torch.nn.Conv2d(3, 16, 7, padding=3, bias=False), torch.nn.BatchNorm2d(16), torch.nn.ReLU(),
+                                  torch.nn.Conv2d(16, 16, 3, padding=1, bias=False), torch.nn.BatchNorm2d(16), torch.nn.ReLU())
+        ref[0].load_state_dict({k: v.cpu() for k, v in state[0].items()})
+        ref[1].load_state_dict({k: v.cpu() for k, v in state[1].items()})
+        ref[3].load_state_dict({k: v.cpu() for k, v in state[2].items()})
+        ref[4].load_state_dict({k: v.cpu() for k, v in state[3].items()})
+        ref.train()
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr)
+        yr.backward(gy)
+        _close(deferred[0], yr)
+        _close(deferred[1], xr.grad)
+        _close(deferred[2], ref[0].weight.grad)
+        _close(deferred[5], ref[3].weight.grad)
