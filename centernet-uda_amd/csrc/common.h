@@ -70,6 +70,11 @@ void launch_log(const void* host_function);
         }                                        \
     } while (0)
 
+// Dynamic LDS beyond 64 KiB is opt-in per kernel AND per device (hipFuncAttributeMaxDynamicSharedMemorySize): raised
+// once per (kernel, current device), the return code checked.  `lds` <= 64 KiB: nothing to do.  false = the runtime
+// refused (the error text is set).
+bool raise_dynamic_lds(const void* host_function, size_t lds, size_t limit = 160 * 1024);
+
 // Matrix-pipe mode of the implicit GEMMs: 0 = f32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split operands on the bf16
 // MFMA (igemm.cuh, "X3").  Process-wide; set through cnuda_set_matrix_mode() or CNUDA_MATRIX_MODE at load time.
 int matrix_mode();

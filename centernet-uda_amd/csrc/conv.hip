@@ -647,16 +647,23 @@ int pick_bm(int M, long long N) {
 }
 
 // hwgrad_kernel (hwgrad.cuh) takes the weight gradient of the narrow 3x3 convolutions (the DCN offset / mask layers)
+// (round 6: any row width that is a multiple of 8 -- rectangular tiles, hwgrad.cuh; the overhang of a map whose height is
+// no multiple of the tile's stays under a quarter)
+int hwgrad_tiles_y(const ConvGeom& g) { const int tr = HW_BN / halo_tile_width(g.W); return (g.H + tr - 1) / tr; }
 bool hwgrad_ok(const ConvGeom& g) {
-    return matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
-           g.Co <= 32 && g.C % 16 == 0 && (g.W == 16 || g.W == 32 || g.W == 64 || g.W == 128) &&
-           ((long long)g.H * g.W) % HW_BN == 0 && wgrad_buffer_ok(g);
+    if (!(matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
+          g.Co <= 32 && g.C % 16 == 0 && halo_tile_width(g.W) != 0 && wgrad_buffer_ok(g)))
+        return false;
+    return 4 * (hwgrad_tiles_y(g) * (HW_BN / halo_tile_width(g.W)) - g.H) <= g.H;
 }
 
 // ... and hwgrad_s2_kernel that of the narrow 3x3 / stride 2 convolutions (DLA-34's level1)
+// (round 6: any output row width that is a multiple of 4 -- the last tile of a row may be ragged, its missing columns stage
+// zeros -- as long as the padding stays under a quarter of the row)
 bool hwgrad_s2_ok(const ConvGeom& g) {
     return matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 2 && g.sw == 2 && g.ph == 1 && g.pw == 1 && g.Co <= 64 &&
-           g.C % 16 == 0 && g.H % 2 == 0 && g.W % 2 == 0 && g.Wo % HS_BN == 0 && wgrad_buffer_ok(g);
+           g.C % 16 == 0 && g.H % 2 == 0 && g.W % 2 == 0 && g.Wo % 4 == 0 &&
+           4 * (round_up(g.Wo, HS_BN) - g.Wo) <= g.Wo && wgrad_buffer_ok(g);
 }
 
 struct ConvPlan {
@@ -697,7 +704,7 @@ ConvPlan make_plan(const ConvGeom& g) {
     q.hw_tiles = q.hw_tiles_per_split = 0;
     if (q.hw || q.hw_s2) {
         // (C / 16) channel groups x Z splits of the 256- (128-) pixel tiles: two workgroups per CU, at least one tile each
-        q.hw_tiles = (int)(q.Nf / (q.hw ? HW_BN : HS_BN));
+        q.hw_tiles = q.hw ? g.B * hwgrad_tiles_y(g) * (g.W / halo_tile_width(g.W)) : g.B * g.Ho * (round_up(g.Wo, HS_BN) / HS_BN);
         const int groups = (g.C / 16) * (q.hw_s2 ? (g.Co + 31) / 32 : 1);
         int zz = std::max(1, 512 / groups);
         if (zz > q.hw_tiles) zz = q.hw_tiles;
@@ -737,42 +744,49 @@ int hconv_level() { return g_hconv_level; }
 // kc: channels of the gathered tensor (x for the forward, grad_y for the input gradient); bm: the GEMM's row tile.
 // Small problems (under 128 pixel tiles) keep the im2col kernels: nothing to gain, and their results stay bit for bit
 // what the golden step fixtures were calibrated on.
+// Any row width that is a multiple of 8 (round 6; rounds 4-5: 16 / 32 / 64 / 128 only): the tile is TR rows x TW columns,
+// TW = the largest power of two that divides W (hconv.cuh) -- 5 column tiles on the 160- / 80- / 40-wide maps of a 640 x 640
+// input.  A map whose height is no multiple of the tile's keeps the halo kernels while the overhang stays under a quarter.
 bool hconv_ok(const ConvGeom& g, int kc, int bm) {
     const int lv = hconv_level();
-    return lv != 0 && (lv == 1 || bm == 32) && matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 &&
-           g.ph == 1 && g.pw == 1 && kc % 16 == 0 && (g.W == 16 || g.W == 32 || g.W == 64 || g.W == 128) &&
-           ((long long)g.H * g.W) % IG_BN == 0 && (long long)g.B * g.H * g.W >= (long long)g_hconv_min_tiles * IG_BN &&
-           (size_t)g.B * kc * g.H * g.W * sizeof(float) < IG_BUF_OOB;
+    if (!(lv != 0 && (lv == 1 || bm == 32) && matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 &&
+          g.ph == 1 && g.pw == 1 && kc % 16 == 0 && halo_tile_width(g.W) != 0 &&
+          (long long)g.B * g.H * g.W >= (long long)g_hconv_min_tiles * IG_BN &&
+          (size_t)g.B * kc * g.H * g.W * sizeof(float) < IG_BUF_OOB))
+        return false;
+    const HaloGeom hg = make_halo_geom(kc, g.H, g.W, IG_BN);
+    return hg.cells <= HC_MAXCELLS * IG_THREADS && 4 * (hg.tiles_y * hg.TR - g.H) <= g.H;
 }
 template <int BM, int BN, class Ad>
-void hconv_launch_one(const typename Ad::Params& p, const float* src, const float* A, int Mp, int Kp, int M, long long N,
+bool hconv_launch_one(const typename Ad::Params& p, const float* src, const float* A, int Mp, int Kp, int M, long long N,
                       int m_tiles, const HaloGeom& hg, hipStream_t st) {
     const size_t lds = hconv_lds_bytes(hg, BM);
-    static size_t allowed = 64 * 1024;                  // dynamic LDS beyond 64 KiB is opt-in per kernel
-    if (lds > allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hconv_kernel<BM, BN, Ad>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        allowed = 160 * 1024;
-    }
-    const int n_tiles = (int)(N / BN);
+    if (!raise_dynamic_lds(reinterpret_cast<const void*>(&hconv_kernel<BM, BN, Ad>), lds)) return false;
+    const int n_tiles = (int)(N / ((long long)hg.H * hg.W)) * hg.tiles_y * hg.tiles_x;
     CNUDA_LAUNCH((hconv_kernel<BM, BN, Ad>), dim3(n_tiles * m_tiles), dim3(IG_THREADS), lds, st, p, src, A, Mp, Kp, M, N,
                  n_tiles, m_tiles, hg);
+    return true;
 }
 template <class Ad>
 int launch_hconv(int bm, const typename Ad::Params& p, const float* src, int kc, const ConvGeom& g, const float* A, int Mp,
                  int Kp, int M, long long N, hipStream_t st, const char* who) {
     CNUDA_REQUIRE(N < (1ll << 31) - 256, "%s: more than 2^31 pixels per call", who);
     const int m_tiles = Mp / bm;
-    // 256-pixel tiles for the narrow GEMMs when that still leaves two rounds of workgroups (and the halo fits: W >= 32)
-    const bool wide = bm <= 64 && g.W >= 32 && ((long long)g.H * g.W) % 256 == 0 && (N / 256) * m_tiles >= 1024;
-    const HaloGeom hg = make_halo_geom(kc, g.H, g.W, wide ? 256 : 128);
+    // 256-pixel tiles for the narrow GEMMs when that still leaves two rounds of workgroups (and the halo fits: tile
+    // columns >= 32, whole tile rows, at most HC_MAXCELLS cells per thread)
+    const HaloGeom hg2 = make_halo_geom(kc, g.H, g.W, 256);
+    const bool wide = bm <= 64 && hg2.TW >= 32 && g.H % hg2.TR == 0 && hg2.cells <= HC_MAXCELLS * IG_THREADS &&
+                      (N / 256) * m_tiles >= 1024;
+    const HaloGeom hg = wide ? hg2 : make_halo_geom(kc, g.H, g.W, 128);
     ProfScope prof(st);
     prof.name("hconv_kernel<%d, %d, %s>", bm, wide ? 256 : 128, Ad::name());
-    if (bm == 128) hconv_launch_one<128, 128, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
-    else if (bm == 64 && wide) hconv_launch_one<64, 256, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
-    else if (bm == 64) hconv_launch_one<64, 128, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
-    else if (wide) hconv_launch_one<32, 256, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
-    else hconv_launch_one<32, 128, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
+    bool ok;
+    if (bm == 128) ok = hconv_launch_one<128, 128, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
+    else if (bm == 64 && wide) ok = hconv_launch_one<64, 256, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
+    else if (bm == 64) ok = hconv_launch_one<64, 128, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
+    else if (wide) ok = hconv_launch_one<32, 256, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
+    else ok = hconv_launch_one<32, 128, Ad>(p, src, A, Mp, Kp, M, N, m_tiles, hg, st);
+    if (!ok) return CNUDA_ERR_INVALID_ARGUMENT;
     return check_launch(who);
 }
 
@@ -1185,29 +1199,29 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
         prof.name("hwgrad_s2_kernel");
         const HwS2Params hp{x, grad_y, B, C, H, W, Cout, g.Ho, g.Wo, q.hw_tiles, q.hw_tiles_per_split};
         const size_t lds = HS_LDS_FLOATS * sizeof(float);
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hwgrad_s2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
-            raised = true;
-        }
+        CNUDA_REQUIRE(raise_dynamic_lds(reinterpret_cast<const void*>(&hwgrad_s2_kernel), lds),
+                      "cnuda_conv2d_backward_weight: dynamic LDS");
         CNUDA_LAUNCH(hwgrad_s2_kernel, dim3(C / 16, q.Z, (Cout + 31) / 32), dim3(IG_THREADS), lds, st, hp, slabs, q.Mpw, q.Jp, bsl);
     } else if (q.hw) {
         ProfScope prof(st);
-        prof.name("hwgrad_kernel<%d>", W);
-        const HwParams hp{x, grad_y, B, C, H, Cout, q.hw_tiles, q.hw_tiles_per_split};
+        const int tw = halo_tile_width(W);
+        const bool side = tw < W;
+        prof.name(side ? "hwgrad_kernel<%d, side>" : "hwgrad_kernel<%d>", tw);
+        const HwParams hp{x, grad_y, B, C, H, W, Cout, W / tw, hwgrad_tiles_y(g), q.hw_tiles, q.hw_tiles_per_split};
         const dim3 grid(C / 16, q.Z), blk(IG_THREADS);
-#define CNUDA_HWGRAD(WV) do {                                                                                        \
-        const size_t lds = HwShape<WV>::lds_floats * sizeof(float);                                                   \
-        static bool raised = false;                                                                                   \
-        if (lds > 64 * 1024 && !raised) {                                                                             \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hwgrad_kernel<WV>),                              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
-            raised = true;                                                                                            \
-        }                                                                                                             \
-        CNUDA_LAUNCH((hwgrad_kernel<WV>), grid, blk, lds, st, hp, slabs, q.Mpw, q.Jp, bsl);                           \
+#define CNUDA_HWGRAD(TWV, SIDEV) do {                                                                                \
+        const size_t lds = HwShape<TWV, SIDEV>::lds_floats * sizeof(float);                                           \
+        CNUDA_REQUIRE(raise_dynamic_lds(reinterpret_cast<const void*>(&hwgrad_kernel<TWV, SIDEV>), lds),              \
+                      "cnuda_conv2d_backward_weight: dynamic LDS");                                                   \
+        CNUDA_LAUNCH((hwgrad_kernel<TWV, SIDEV>), grid, blk, lds, st, hp, slabs, q.Mpw, q.Jp, bsl);                   \
     } while (0)
-        if (W == 128) CNUDA_HWGRAD(128); else if (W == 64) CNUDA_HWGRAD(64); else if (W == 32) CNUDA_HWGRAD(32); else CNUDA_HWGRAD(16);
+        if (!side) {
+            if (tw == 128) CNUDA_HWGRAD(128, false); else if (tw == 64) CNUDA_HWGRAD(64, false);
+            else if (tw == 32) CNUDA_HWGRAD(32, false); else if (tw == 16) CNUDA_HWGRAD(16, false); else CNUDA_HWGRAD(8, false);
+        } else {
+            if (tw == 128) CNUDA_HWGRAD(128, true); else if (tw == 64) CNUDA_HWGRAD(64, true);
+            else if (tw == 32) CNUDA_HWGRAD(32, true); else if (tw == 16) CNUDA_HWGRAD(16, true); else CNUDA_HWGRAD(8, true);
+        }
 #undef CNUDA_HWGRAD
     } else {
         ProfScope prof(st);

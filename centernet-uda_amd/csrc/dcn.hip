@@ -319,7 +319,7 @@ using DcnFwdBufLoader = DcnFwdLoaderT<true>;
 
 // ---------------------------------------------------------------------------
 // forward from an LDS input window (round 4): 3x3, stride 1, padding 1, dilation 1, deformable_group 1, C % 16 == 0,
-// row width 16 / 32 / 64 / 128, one M tile (Co <= 128).
+// row width a multiple of 16 (tiles of 4 x 32 or 8 x 16 pixels; H a multiple of the tile's rows), one M tile (Co <= 128).
 //
 // The loader above gathers two unaligned 8-byte corner pairs per (pixel, tap, channel) from global memory: the
 // texture-address unit is busy 0.77 of the kernel's cycles and the matrix pipe 0.38 (profiles/r3_pmc_dcn.md).  Here --
@@ -1678,13 +1678,16 @@ extern "C" int cnuda_dcn_v2_forward_cols(const float* input, const float* weight
 }
 
 namespace {
-// the LDS-window kernel's layers: 3x3 / stride 1 / padding 1 / dilation 1 on maps 16..128 wide, one M tile.  CNUDA_DCNW=0
+// the LDS-window kernel's layers: 3x3 / stride 1 / padding 1 / dilation 1, row width a multiple of 16, one M tile.  CNUDA_DCNW=0
 // keeps the gathering loader (A/B measurements; tests/test_gpu_kernel_switches.py).
+// (round 6: any row width that is a multiple of 16 -- 160 / 80 / 96 -- in whole tiles of 4 x 32 or 8 x 16 pixels; rounds 4-5:
+// 16 / 32 / 64 / 128 only)
+int dcnw_tile_cols(int W) { return W % 32 == 0 ? 32 : 16; }
 bool dcnw_takes(const DcnGeom& g) {
     static const bool dcnw_on = !(getenv("CNUDA_DCNW") && getenv("CNUDA_DCNW")[0] == '0');
     return dcnw_on && (g_offset_regime & 2) == 0 && matrix_mode() == 0 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 &&
            g.dh == 1 && g.dw == 1 && g.dg == 1 && g.C % 16 == 0 && g.Co <= 64 &&
-           (g.W == 16 || g.W == 32 || g.W == 64 || g.W == 128) && g.H % (IG_BN / (g.W >= 32 ? 32 : g.W)) == 0 &&
+           g.W % 16 == 0 && g.H % (IG_BN / dcnw_tile_cols(g.W)) == 0 &&
            (size_t)g.B * g.C * g.H * g.W * sizeof(float) < IG_BUF_OOB;
 }
 }  // namespace
@@ -1757,17 +1760,13 @@ static int dcn_forward_impl(const float* input, const float* weight, const float
         DcnFwdParams p{g, input, offset, mask, bias, act_slope, output, columns, stats, 64};
         ProfScope prof(st);
         prof.name("dcnw_fwd_kernel<%d>%s", bm, columns ? " (+ column side output)" : "");
-        const int tc = W >= 32 ? 32 : W, tiles_x = W / tc, n_tiles = (int)(q.N / IG_BN);
+        const int tc = dcnw_tile_cols(W), tiles_x = W / tc, n_tiles = (int)(q.N / IG_BN);
 #define CNUDA_DCNW_LAUNCH(BMV, TCV)                                                                                    \
     do {                                                                                                               \
         const size_t fl = dcnw_lds_floats<TCV>(BMV);                                                                   \
         const size_t lds = (fl < (size_t)4 * IG_EPI_WAVE ? (size_t)4 * IG_EPI_WAVE : fl) * sizeof(float);             \
-        static bool raised = false;                                                                                    \
-        if (lds > 64 * 1024 && !raised) {                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnw_fwd_kernel<BMV, TCV>),                       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
-            raised = true;                                                                                             \
-        }                                                                                                              \
+        CNUDA_REQUIRE(raise_dynamic_lds(reinterpret_cast<const void*>(&dcnw_fwd_kernel<BMV, TCV>), lds),               \
+                      "cnuda_dcn_v2_forward: dynamic LDS");                                                            \
         CNUDA_LAUNCH((dcnw_fwd_kernel<BMV, TCV>), dim3(n_tiles), dim3(IG_THREADS), lds, st, p, Aw, bm, q.Kp, n_tiles,  \
                      tiles_x);                                                                                         \
     } while (0)
@@ -1982,12 +1981,9 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
             const int n_wg = B * q.tiles_y * q.tiles_x * q.fused_split;
             ProfScope scope(st, 3);
             scope.name("dcn_bwd_data_kernel");
-            static bool raised = false;                       // (a wide-margin window: dynamic LDS beyond 64 KiB is opt-in)
-            if (q.col2im_lds > 64 * 1024 && !raised) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_bwd_data_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                raised = true;
-            }
+            // (a wide-margin window: dynamic LDS beyond 64 KiB is opt-in)
+            CNUDA_REQUIRE(raise_dynamic_lds(reinterpret_cast<const void*>(&dcn_bwd_data_kernel), q.col2im_lds),
+                          "cnuda_dcn_v2_backward: dynamic LDS");
             CNUDA_LAUNCH(dcn_bwd_data_kernel, dim3(n_wg), dim3(512), q.col2im_lds, st, p, n_wg);
         } else {
             {
@@ -2003,12 +1999,8 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
                 const int n_wg = B * q.tiles_y * q.tiles_x * q.ncg;
                 ProfScope scope(st, 2);
                 scope.name("dcn_col2im_kernel");
-                static bool raised2 = false;
-                if (q.col2im_lds > 64 * 1024 && !raised2) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_col2im_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    raised2 = true;
-                }
+                CNUDA_REQUIRE(raise_dynamic_lds(reinterpret_cast<const void*>(&dcn_col2im_kernel), q.col2im_lds),
+                              "cnuda_dcn_v2_backward: dynamic LDS");
                 CNUDA_LAUNCH(dcn_col2im_kernel, dim3(n_wg), dim3(256), q.col2im_lds, st, p, n_wg);
             }
         }

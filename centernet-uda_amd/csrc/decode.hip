@@ -821,14 +821,9 @@ extern "C" int cnuda_decode_detection(const float* heat, const float* wh, const 
     // arrays (about 27 KB) in the CU's 160 KB: planes up to 180 x 180
     const size_t bits_bytes = (size_t)H * W * sizeof(uint32_t);
     const int lds_plane = bits_bytes <= 128 * 1024 ? 1 : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(plane_topk_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(merge_decode_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-        attr_set = true;
-    }
+    CNUDA_REQUIRE(raise_dynamic_lds(reinterpret_cast<const void*>(plane_topk_kernel), 128 * 1024, 128 * 1024) &&
+                      raise_dynamic_lds(reinterpret_cast<const void*>(merge_decode_kernel), 112 * 1024, 112 * 1024),
+                  "cnuda_decode_detection: dynamic LDS");
     CNUDA_LAUNCH(plane_topk_kernel, dim3(B * C), dim3(kPlaneThreads), lds_plane ? bits_bytes : 0, st, heat, cand,
                        H, W, K, KP, pad, lds_plane);
     int rc = check_launch("cnuda_decode_detection(stage 1)");

@@ -11,9 +11,13 @@
 // Per channel group a thread issues 2..6 16-byte loads instead of 72 4-byte ones.  The A (weight) tile is staged per
 // chunk exactly as in igemm_fwd_kernel; the packed weights use the same K order (PACK_HALO_FWD / PACK_HALO_DGRAD).
 //
-// Pixel tile = BN (128 or 256) consecutive pixels n of the flattened (b, y, x) axis, i.e. BN / W full image rows, so the
-// 16-byte epilogue of igemm.cuh applies as it stands.  Host-side conditions (conv.hip hconv_ok): 3x3, stride 1,
-// padding 1, gathered channels % 16 == 0, W in {16, 32, 64, 128}, H * W % BN == 0, tensor below 2 GiB, f32 matrix mode.
+// Pixel tile = BN (128 or 256) pixels of ONE image as a rectangle of TR rows x TW columns, TW = the largest power of two
+// that divides the row width W (at most 128): a 128- / 64- / 32- / 16-wide map is tiled by full rows as in round 4, a
+// 160- / 80- / 40-wide one (640 x 640 inputs) by 5 column tiles of 32 / 16 / 8 (round 6).  A tile that does not span the
+// row stages four more columns on either side (the neighbouring tile's, or zero at the image edge) instead of the two
+// constant zero columns; a tile that hangs over the last image row (H % TR != 0) stages zeros there and does not store.
+// The four pixels of a lane's 16-byte epilogue store lie in one tile row (4 | TW).  Host-side conditions (conv.hip
+// hconv_ok): 3x3, stride 1, padding 1, gathered channels % 16 == 0, W % 8 == 0, tensor below 2 GiB, f32 matrix mode.
 #pragma once
 #include "igemm.cuh"
 
@@ -30,23 +34,38 @@ template <> struct HcTile<64, 256>  { static constexpr int WM = 2, WN = 2, TM = 
 template <> struct HcTile<32, 256>  { static constexpr int WM = 1, WN = 4, TM = 1, TN = 2; };
 
 struct HaloGeom {
-    int Kc, H, W, w_shift;     // gathered channels, plane size, log2(W)
-    int TR;                    // image rows per pixel tile (BN / W)
+    int Kc, H, W;              // gathered channels, plane size
+    int TW, tw_shift;          // tile columns (a power of two that divides W), log2
+    int TR;                    // tile rows (BN / TW)
+    int tiles_x, tiles_y;      // W / TW, ceil(H / TR)
+    int side;                  // 1: TW < W -- the tile's left / right neighbour columns are staged (one 16-byte cell each side)
     int RS, PL;                // LDS row stride and plane size of the halo tile, floats
-    int cpr, cpp, cells;       // 16-byte cells per row (W / 4), per plane ((TR + 2) * cpr), per channel group (16 * cpp)
+    int cpr, cpp, cells;       // 16-byte cells per row (TW / 4 + 2 side), per plane ((TR + 2) * cpr), per channel group (16 * cpp)
 };
 constexpr int HC_MAXCELLS = 8;      // per thread: W = 128, 256-pixel tile -> 16 * 4 * 32 / 256
 
+// tile width of a map W columns wide: the largest power of two that divides W, at most 128 (0: none of at least 8)
+inline int halo_tile_width(int W) {
+    int tw = 128;
+    while (tw >= 8 && W % tw != 0) tw >>= 1;
+    return tw >= 8 ? tw : 0;
+}
 inline HaloGeom make_halo_geom(int Kc, int H, int W, int bn) {
     HaloGeom h;
     h.Kc = Kc; h.H = H; h.W = W;
-    h.w_shift = W == 128 ? 7 : (W == 64 ? 6 : (W == 32 ? 5 : 4));
-    h.TR = bn / W;
-    // column index of image column x is x + 4 (16-byte aligned interior), the halo columns are 3 and W + 4.  W = 16:
-    // a 32-pixel MFMA column block spans two rows, a stride of 48 puts the second row 16 banks away from the first
-    h.RS = W == 16 ? 48 : W + 8;
+    h.TW = halo_tile_width(W);
+    h.tw_shift = 0;
+    while ((1 << h.tw_shift) < h.TW) ++h.tw_shift;
+    h.TR = bn / h.TW;
+    h.tiles_x = W / h.TW;
+    h.tiles_y = (H + h.TR - 1) / h.TR;
+    h.side = h.TW < W ? 1 : 0;
+    // column index of tile column j is j + 4 (16-byte aligned interior), the halo columns are 3 and TW + 4.  A 32-pixel
+    // MFMA column block spans 32 / TW tile rows: TW = 16 -> a stride of 48 puts the second row 16 banks away from the
+    // first, TW = 8 -> a stride of 40 the four rows 8 banks apart
+    h.RS = h.TW == 16 ? 48 : (h.TW == 8 ? 40 : h.TW + 8);
     h.PL = (h.TR + 2) * h.RS;
-    h.cpr = W / 4;
+    h.cpr = h.TW / 4 + 2 * h.side;
     h.cpp = (h.TR + 2) * h.cpr;
     h.cells = 16 * h.cpp;
     return h;
@@ -100,16 +119,20 @@ __device__ __forceinline__ void hc_mma_chunk(const float* __restrict__ As, const
 }
 
 // ig_epilogue_vec4 for these tiles: every wave stages its 32 x 32 tiles through LDS and stores 16 bytes per lane
+// (tile pixel px -> flat pixel index: row px / TW, column px % TW of the tile at (image b, row y0, column x0))
 template <int BM, int BN, class Ad>
 __device__ __forceinline__ void hc_epilogue_vec4(const typename Ad::Params& p, float* __restrict__ stage,
                                                  const f32x16 (&acc)[HcTile<BM, BN>::TM][HcTile<BM, BN>::TN], int m0,
-                                                 long long n0, int wm_off, int wn_off, int lane, int M, long long N) {
+                                                 int b, int y0, int x0, const HaloGeom& hg, int wm_off, int wn_off, int lane,
+                                                 int M) {
     using T = HcTile<BM, BN>;
     const int col = lane & 31, cg = lane & 7, rsub = lane >> 3;
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
-        const long long n = n0 + wn_off + j * 32 + 4 * cg;
-        typename Ad::Out out(p, n < N ? n : 0);
+        const int px = wn_off + j * 32 + 4 * cg, y = y0 + (px >> hg.tw_shift);
+        const bool n_ok = y < hg.H;
+        const long long n = n_ok ? (long long)(b * hg.H + y) * hg.W + x0 + (px & (hg.TW - 1)) : 0;
+        typename Ad::Out out(p, n);
 #pragma unroll
         for (int i = 0; i < T::TM; ++i) {
 #pragma unroll
@@ -120,7 +143,7 @@ __device__ __forceinline__ void hc_epilogue_vec4(const typename Ad::Params& p, f
                 const int row = it * 8 + rsub;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * IG_EPI_LD + 4 * cg);
                 const int m = m0 + wm_off + i * 32 + row;
-                if (m < M && n < N) out.store4(p, m, v);
+                if (m < M && n_ok) out.store4(p, m, v);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -140,11 +163,13 @@ __global__ __launch_bounds__(IG_THREADS, 2) void hconv_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wg = xcd_remap(blockIdx.x, n_tiles * m_tiles);
     const int m0 = (wg % m_tiles) * BM;
-    const long long n0 = (long long)(wg / m_tiles) * BN;
     const int wm_off = (wid / T::WN) * (T::TM * 32), wn_off = (wid % T::WN) * (T::TN * 32);
     const int HW = hg.H * hg.W;
-    // the tile lies inside one image (H * W % BN == 0) and starts at column 0 (W <= 128)
-    const int b = (int)(n0 / HW), y0 = (int)(n0 - (long long)b * HW) >> hg.w_shift;
+    // pixel tile -> (image, tile row, tile column), image-major
+    int nt = wg / m_tiles;
+    const int tx = nt % hg.tiles_x; nt /= hg.tiles_x;
+    const int ty = nt % hg.tiles_y, b = nt / hg.tiles_y;
+    const int y0 = ty * hg.TR, x0 = tx * hg.TW;
 
     // halo cells of this thread: global byte offset (channel 0 of the group; sentinel for rows outside the image) and LDS slot
     const buf_rsrc rs = ig_make_rsrc(src, (unsigned)((size_t)N * hg.Kc * sizeof(float)));
@@ -159,24 +184,26 @@ __global__ __launch_bounds__(IG_THREADS, 2) void hconv_kernel(
         if (i < ncell && e < hg.cells) {
             const int c = e / hg.cpp, rem = e - c * hg.cpp;
             const int row = rem / hg.cpr, q = rem - row * hg.cpr;
-            const int iy = y0 - 1 + row;
-            loff[i] = c * PL + row * RS + 4 + 4 * q;
-            if (iy >= 0 && iy < hg.H)
-                voff[i] = (unsigned)(((b * hg.Kc + c) * HW + iy * hg.W + 4 * q) * (int)sizeof(float));
+            const int iy = y0 - 1 + row, ix = x0 + 4 * (q - hg.side);     // (side: cell 0 holds the four columns left of the tile)
+            loff[i] = c * PL + row * RS + 4 + 4 * (q - hg.side);
+            if (iy >= 0 && iy < hg.H && ix >= 0 && ix < hg.W)
+                voff[i] = (unsigned)(((b * hg.Kc + c) * HW + iy * hg.W + ix) * (int)sizeof(float));
         }
     }
-    // the halo columns left and right of the image are zero for every group: written once, never overwritten
-    for (int e = tid; e < 16 * (hg.TR + 2) * 2; e += IG_THREADS) {
-        const int side = e & 1, cr = e >> 1;                             // cr over (channel, row)
-        const int c = cr / (hg.TR + 2), row = cr - c * (hg.TR + 2);
-        Hs[c * PL + row * RS + (side ? hg.W + 4 : 3)] = 0.0f;
-    }
+    // a tile that spans the row: the halo columns left and right of the image are zero for every group -- written once,
+    // never overwritten (with side cells the staging itself writes them: the neighbour's columns or the range check's zeros)
+    if (!hg.side)
+        for (int e = tid; e < 16 * (hg.TR + 2) * 2; e += IG_THREADS) {
+            const int side = e & 1, cr = e >> 1;                             // cr over (channel, row)
+            const int c = cr / (hg.TR + 2), row = cr - c * (hg.TR + 2);
+            Hs[c * PL + row * RS + (side ? hg.TW + 4 : 3)] = 0.0f;
+        }
     // B fragment offsets of this lane inside a plane: pixel -> (row, column + 3); the tap adds r * RS + s
     int boff[T::TN];
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
         const int px = wn_off + j * 32 + (lane & 31);
-        boff[j] = (px >> hg.w_shift) * RS + (px & (hg.W - 1)) + 3;
+        boff[j] = (px >> hg.tw_shift) * RS + (px & (hg.TW - 1)) + 3;
     }
 
     f32x16 acc[T::TM][T::TN];
@@ -227,14 +254,14 @@ __global__ __launch_bounds__(IG_THREADS, 2) void hconv_kernel(
         if (++tap == 9) { tap = 0; ++g; }
     }
     if (Ad::Out::vec4_ok(p)) {
-        hc_epilogue_vec4<BM, BN, Ad>(p, smem + wid * IG_EPI_WAVE, acc, m0, n0, wm_off, wn_off, lane, M, N);
+        hc_epilogue_vec4<BM, BN, Ad>(p, smem + wid * IG_EPI_WAVE, acc, m0, b, y0, x0, hg, wm_off, wn_off, lane, M);
         return;
     }
 #pragma unroll
     for (int j = 0; j < T::TN; ++j) {
-        const long long n = n0 + wn_off + j * 32 + (lane & 31);
-        if (n >= N) continue;
-        typename Ad::Out out(p, n);
+        const int px = wn_off + j * 32 + (lane & 31), y = y0 + (px >> hg.tw_shift);
+        if (y >= hg.H) continue;
+        typename Ad::Out out(p, (long long)(b * hg.H + y) * hg.W + x0 + (px & (hg.TW - 1)));
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
 #pragma unroll

@@ -3,6 +3,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -18,6 +21,23 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_error, sizeof(g_error), fmt, ap);
     va_end(ap);
+}
+
+bool raise_dynamic_lds(const void* host_function, size_t lds, size_t limit) {
+    if (lds <= 64 * 1024) return true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { set_error("raise_dynamic_lds: hipGetDevice failed"); return false; }
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({host_function, dev})) return true;
+    const hipError_t e = hipFuncSetAttribute(host_function, hipFuncAttributeMaxDynamicSharedMemorySize, (int)limit);
+    if (e != hipSuccess) {
+        set_error("raise_dynamic_lds: hipFuncSetAttribute(%zu bytes) on device %d: %s", limit, dev, hipGetErrorString(e));
+        return false;
+    }
+    done.insert({host_function, dev});
+    return true;
 }
 }  // namespace cnuda
 

@@ -617,12 +617,8 @@ int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, in
         ProfScope prof(st);
         prof.name("smallc_wgrad_kernel<%d>", mt);
 #define CNUDA_SC_WG(MTV, KHV, NTV) do {                                                                              \
-        static bool raised = false;                                                                                   \
-        if (!raised) {                                                                                                \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(smallc_wgrad_kernel<MTV, KHV, NTV>),              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
-            raised = true;                                                                                            \
-        }                                                                                                             \
+        CNUDA_REQUIRE(raise_dynamic_lds(reinterpret_cast<const void*>(smallc_wgrad_kernel<MTV, KHV, NTV>), lds),       \
+                      "smallc_backward_weight: dynamic LDS");                                                         \
         CNUDA_LAUNCH((smallc_wgrad_kernel<MTV, KHV, NTV>), grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16, none); \
     } while (0)
 #define CNUDA_SC_WG_KH(MTV) do {                                                                                     \
@@ -633,12 +629,8 @@ int smallc_backward_weight(const float* x, const float* gy, float* gw, int B, in
             CNUDA_REQUIRE(smallc_norm_supported(C, Co, kh, kw, s, s) && nt_real > 4 && norm->mean && norm->invstd &&
                           norm->gamma && norm->beta && norm->imgs_per_group > 0,
                           "smallc_backward_weight: apply-on-load is not compiled for this geometry");
-            static bool raised = false;
-            if (!raised) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(smallc_wgrad_kernel<1, 3, 9, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                raised = true;
-            }
+            CNUDA_REQUIRE(raise_dynamic_lds(reinterpret_cast<const void*>(smallc_wgrad_kernel<1, 3, 9, true>), lds),
+                          "smallc_backward_weight: dynamic LDS");
             CNUDA_LAUNCH((smallc_wgrad_kernel<1, 3, 9, true>), grid, dim3(IG_THREADS), lds, st, g, x, gy, koff, slabs, Kp16, *norm);
         } else if (mt == 1) CNUDA_SC_WG_KH(1); else CNUDA_SC_WG_KH(2);
 #undef CNUDA_SC_WG_KH

@@ -23,17 +23,27 @@ MANIFEST = {
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[l1_s2_',
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[l2_s2_',
     ],
-    'hwgrad_kernel<128>': [
+    'hwgrad_kernel<128, false>': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset27_w128',
     ],
-    'hwgrad_kernel<16>': [
+    'hwgrad_kernel<16, false>': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset18_w16',
     ],
-    'hwgrad_kernel<32>': [
+    'hwgrad_kernel<32, false>': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset27_w32',
     ],
-    'hwgrad_kernel<64>': [
+    'hwgrad_kernel<64, false>': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset27_w64',
+    ],
+    'hwgrad_kernel<32, true>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset27_w160',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset27_w96',
+    ],
+    'hwgrad_kernel<16, true>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset27_w80',
+    ],
+    'hwgrad_kernel<8, true>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset27_w40',
     ],
     'hconv_kernel<32, 256, HconvFwd>': [
         'tests/test_gpu_fullsize.py::test_full_size_halo_tile_convolutions_match_fp64[64to27_128sq',
@@ -186,7 +196,7 @@ MANIFEST = {
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[256to128_32sq',
     ],
     'igemm_fwd_kernel<64, DcnFwdLoaderT<true>, false>': [      # (since round 4: only layers the window kernel does not take)
-        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[32to64_96sq',
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[32to64_100sq',
     ],
     'igemm_fwd_shortk_kernel<128, ConvFwdBufLoader, 64>': [
         'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',

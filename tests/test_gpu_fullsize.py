@@ -291,8 +291,9 @@ def test_full_size_strided_convolution_matches_fp64():
         assert (got.double().cpu() - want).abs().max().item() <= 1e-4 * scale, name
 
 
-@pytest.mark.parametrize('B,C,Co,S', [(16, 64, 64, 128), (16, 64, 27, 128), (64, 128, 27, 64), (32, 64, 256, 128)],
-                         ids=['64to64_128sq', '64to27_128sq', '128to27_64sq', '64to256_128sq'])
+@pytest.mark.parametrize('B,C,Co,S', [(16, 64, 64, 128), (16, 64, 27, 128), (64, 128, 27, 64), (32, 64, 256, 128),
+                                      (12, 64, 27, 160), (40, 128, 27, 80)],      # (round 6: configs[4]'s 160- / 80-wide maps)
+                         ids=['64to64_128sq', '64to27_128sq', '128to27_64sq', '64to256_128sq', '64to27_160sq', '128to27_80sq'])
 def test_full_size_halo_tile_convolutions_match_fp64(B, C, Co, S):
     """3x3 / stride 1 layers of the benched step on the halo-tile kernels (csrc/hconv.cuh) at sizes where the launch
     plan picks the 256-pixel tiles (64 x 256 and 32 x 256: two or four image rows per tile, >= 1024 tiles) and the
@@ -318,7 +319,7 @@ def test_full_size_halo_tile_convolutions_match_fp64(B, C, Co, S):
         y.backward(gy.to(DEV))
     names = sorted(short(n) for n in log.names)
     if hr.get_matrix_mode() == 0:
-        want_fwd = 'hconv_kernel<%s, HconvFwd>' % {64: '64, 256', 27: '32, 256', 256: '128, 128'}[Co]
+        want_fwd = 'hconv_kernel<%s, HconvFwd>' % {64: '64, 256', 27: '32, 256' if S % 32 == 0 else '32, 128', 256: '128, 128'}[Co]
         assert want_fwd in names, (want_fwd, names)
         if Co % 16 == 0:
             assert 'hconv_kernel<64, 256, HconvDgrad>' in names, names
@@ -417,7 +418,13 @@ DCN_LAYERS = {
     '64to64_128sq_one_launch': dict(B=8, C=64, Co=64, S=128, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel', 'igemm_fwd_shortk_kernel']),
     '128to64_64sq': dict(B=16, C=128, Co=64, S=64, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_col2im_kernel', 'dcn_coord_grad_kernel', 'igemm_wgrad_ws_kernel<DcnColWBufLoader, 64, 128>']),
     '128to64_64sq_one_launch': dict(B=32, C=128, Co=64, S=64, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel']),
-    '32to64_96sq': dict(B=8, C=32, Co=64, S=96, kernels=['igemm_fwd_kernel<64, DcnFwdLoaderT<true>']),      # a map the window kernels do not take
+    '32to64_100sq': dict(B=8, C=32, Co=64, S=100, kernels=['igemm_fwd_kernel<64, DcnFwdLoaderT<true>']),      # a map the window kernels do not take (100 % 16 != 0)
+    # round 6: the maps of a 640 x 640 input (configs[4]) and an odd multiple of 32 -- the window forward on 5 x 32-, 5 x 16- and
+    # 3 x 32-column tiles; the data-gradient walk with a ragged last column tile (160 = 2.5 x 64, 80 = 1.25 x 64)
+    '64to64_160sq': dict(B=2, C=64, Co=64, S=160, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_col2im_kernel', 'dcn_coord_grad_kernel']),
+    '64to64_160sq_one_launch': dict(B=5, C=64, Co=64, S=160, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel']),
+    '128to64_80sq_one_launch': dict(B=16, C=128, Co=64, S=80, kernels=['dcnw_fwd_kernel<64, 16>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel']),
+    '32to64_96sq': dict(B=8, C=32, Co=64, S=96, kernels=['dcnw_fwd_kernel<64, 32>']),
     '128to128_64sq': dict(B=16, C=128, Co=128, S=64, kernels=['igemm_fwd_kernel<128, DcnFwdLoaderT<true>']),
     '256to256_32sq': dict(B=32, C=256, Co=256, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_ws_kernel<128, DcnColsBufLoader']),
     '256to128_32sq': dict(B=32, C=256, Co=128, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_ws_kernel<64, DcnColsBufLoader']),

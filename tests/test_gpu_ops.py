@@ -62,6 +62,18 @@ CONV_CASES = {
     'l1_s2_many': (9, 16, 128, 256, 32, 3, 2, 1, False, -1.0),
     'l2_s2_co64': (2, 32, 32, 256, 64, 3, 2, 1, False, -1.0),        # 33..64 output channels: two 32-row blocks
     'l2_s2_co48_b': (2, 16, 16, 256, 48, 3, 2, 1, True, -1.0),
+    # round 6: the same two kernels on the map widths of a 640 x 640 input (160 / 80 / 40; 96 as the odd case) -- the tile is a
+    # rectangle of TR rows x TW columns, TW the largest power of two dividing the width (hwgrad_kernel<TW, side>: 5 x 32,
+    # 5 x 16, 5 x 8, 3 x 32), `rag`: the last tile row hangs over the image, `w256`: 128-column tiles with neighbours;
+    # `l1_s2_w320`: stride 2 to a 320-wide map, the third 128-pixel tile of a row half empty
+    'offset27_w160': (2, 64, 160, 160, 27, 3, 1, 1, True, -1.0),
+    'offset27_w160_rag': (1, 32, 36, 160, 27, 3, 1, 1, True, -1.0),
+    'offset27_w80': (2, 128, 80, 80, 27, 3, 1, 1, True, -1.0),
+    'offset27_w96': (1, 32, 96, 96, 27, 3, 1, 1, False, -1.0),
+    'offset27_w40': (3, 32, 64, 40, 27, 3, 1, 1, True, -1.0),
+    'offset27_w256': (1, 16, 8, 256, 27, 3, 1, 1, True, -1.0),
+    'offset27_w192': (1, 16, 12, 192, 20, 3, 1, 1, True, -1.0),
+    'l1_s2_w320': (1, 16, 16, 640, 32, 3, 2, 1, True, -1.0),
 }
 
 
@@ -274,7 +286,11 @@ def test_head_pair_is_one_tape_node_with_the_two_layers_values(B, C, Ch, Co, H, 
 
 @pytest.mark.parametrize('B,C,Co,H,W', [(2, 32, 27, 8, 16), (1, 32, 64, 16, 16), (3, 64, 100, 4, 32), (2, 48, 27, 8, 32),
                                         (2, 64, 64, 8, 64), (1, 128, 256, 6, 64), (2, 32, 48, 2, 128), (1, 64, 27, 3, 128),
-                                        (2, 256, 144, 16, 16)])
+                                        (2, 256, 144, 16, 16),
+                                        # round 6: rectangular tiles -- 5 x 32 / 5 x 16 / 5 x 8 / 3 x 32 columns, a last
+                                        # tile row that hangs over the image (10 rows of 4), 128-column tiles with neighbours
+                                        (2, 32, 27, 8, 160), (1, 64, 64, 16, 80), (2, 32, 27, 16, 40), (1, 32, 27, 8, 96),
+                                        (1, 48, 32, 10, 160), (1, 32, 27, 4, 256), (1, 16, 48, 6, 192)])
 def test_halo_tile_convolution_3x3(B, C, Co, H, W):
     """3x3 / stride 1 / padding 1 with channels % 16 == 0 on maps 16 / 32 / 64 / 128 wide takes the halo-tile kernels
     (csrc/hconv.cuh: the input tile of a 16-channel group staged once with its halo, K ordered (group, tap, channel)):
