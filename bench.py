@@ -34,6 +34,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 matrix peak (dense, = vector peak)
+PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured with a float4 copy)
 NUM_CLASSES = 6                     # configs/defaults.yaml:16
 MAX_OBJS = 150                      # max_detections
 
@@ -466,6 +467,23 @@ def pmc_traffic(kernel_name):
     return round((fetch + t['write_kb_per_launch']) * 1024), note
 
 
+def pmc_step_bytes():
+    """HBM bytes of one step from the newest committed counter profile: `_meta.hbm_bytes_per_step`, the sum over EVERY kernel
+    of the two `--pmc` passes (profiles/collect_pmc_traffic.sh) -- or None for a profile of an older round."""
+    import glob
+    import re
+    files = glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json'))
+    if not files:
+        return None, None
+    path = max(files, key=lambda f: int(re.match(r'r(\d+)', os.path.basename(f)).group(1)))
+    meta = json.load(open(path)).get('_meta', {})
+    if 'hbm_bytes_per_step' not in meta:
+        return None, '%s carries no per-step total' % os.path.basename(path)
+    same = meta.get('code_sha16') == code_fingerprint()
+    return int(meta['hbm_bytes_per_step']), ('profiles/%s, %s' % (os.path.basename(path), 'same kernel code' if same else
+                                                                'COLLECTED FROM DIFFERENT KERNEL CODE: indicative only'))
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` -> `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
     arguments>` as a child process; returns its exit code (non-zero when any rank failed)."""
@@ -515,6 +533,8 @@ def main():
     ap.add_argument('--profile-steps', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the decode-latency and inference legs (profiling runs)')
+    ap.add_argument('--matrix-mode-split', action='store_true',
+                    help='also time the step in matrix mode 1 (split bf16 operands; round-1 kernel set): `matrix_mode_split`')
     ap.add_argument('--dcn-offset-std', type=float, default=None,
                     help='profiling runs only: re-initialise every conv_offset_mask for sampling offsets of this standard '
                          'deviation in pixels before the warm-up (set_dcn_offset_std); the metric name then says so')
@@ -599,13 +619,14 @@ def main():
         torch.cuda.synchronize()
         per_kernel = hr.prof_end() if rank == 0 else None
         if per_kernel:
+            all_kernels = per_kernel
             hbm_kernels = {k: v for k, v in per_kernel.items() if v['flops'] == 0}
             per_kernel = {k: v for k, v in per_kernel.items() if v['flops'] > 0}
             name, d = max(per_kernel.items(), key=lambda kv: kv[1]['ms'])
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
             traffic, traffic_note = pmc_traffic(name)
             executed_tflop = sum(v['flops'] for v in per_kernel.values()) / args.profile_steps / 1e12
-            roofline = {
+            top_mfma = {
                 'bound': 'mfma', 'kernel': name, 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
                 'traffic_note': traffic_note,
@@ -613,8 +634,42 @@ def main():
                 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                 'algorithmic_gflop_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
                 'kernel_ms_per_step': round(d['ms'] / args.profile_steps, 3),
+            }
+            # `roofline` proper: the kernel with the most time per step over ALL profiled kernels, against its OWN bound --
+            # the fp32 MFMA peak for a GEMM, 8 TB/s of HBM for a streaming kernel (algorithmic bytes / time) -- so that
+            # the line names what the top row of the rocprofv3 summary names (a selection over the
+            # MFMA kernels alone hid dcn_bwd_data_kernel, the largest row since round 5).  The largest MFMA kernel
+            # stays beside it under `top_mfma_kernel`.
+            tname, td = max(all_kernels.items(), key=lambda kv: kv[1]['ms'])
+            if td['flops'] > 0:
+                roofline = dict(top_mfma)
+            else:
+                gbs = td['bytes'] / (td['ms'] * 1e-3) / 1e9
+                ttraffic, tnote = pmc_traffic(tname)
+                roofline = {
+                    'bound': 'hbm', 'kernel': tname, 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
+                    'frac': round(gbs / PEAK_HBM_GBPS, 4), 'traffic': ttraffic, 'traffic_note': tnote,
+                    'launches_per_step': td['launches'] // args.profile_steps,
+                    'avg_launch_ms': round(td['ms'] / td['launches'], 4),
+                    'algorithmic_mb_per_launch': round(td['bytes'] / td['launches'] / 1e6, 1),
+                    'kernel_ms_per_step': round(td['ms'] / args.profile_steps, 3),
+                }
+            dcn_family = {k: v for k, v in all_kernels.items()
+                          if 'dcn' in k.lower() or k.startswith('igemm_fwd_shortk_kernel')}
+            hbm_step, hbm_note = pmc_step_bytes()
+            roofline.update({
+                'top_mfma_kernel': top_mfma,
                 # FLOPs the timed GEMM launches of one step actually execute (sum over all_mfma_kernels)
                 'executed_tflop_per_step': round(executed_tflop, 4),
+                # every kernel of the deformable convolutions (window / gathering forward, sample + GEMM pairs, the
+                # column-gradient GEMM -- the only user of the short-K kernel --, prep, the data-gradient walks, the
+                # weight gradient from the saved columns); the 27-channel offset convolutions are plain convolutions
+                'dcn_family_ms': round(sum(v['ms'] for v in dcn_family.values()) / args.profile_steps, 3),
+                'dcn_family_kernels': sorted(dcn_family),
+                # HBM bytes of one step, summed over every kernel of the committed counter profile (FETCH_SIZE as
+                # reported + WRITE_SIZE; profiles/collect_pmc_traffic.sh), and the time they take at 6.3 TB/s
+                'hbm_bytes_per_step': hbm_step, 'hbm_bytes_note': hbm_note,
+                'hbm_ms_at_6p3TBps': round(hbm_step / 6.3e12 * 1e3, 2) if hbm_step else None,
                 # continuity with rounds 1-4, whose dominant kernel was igemm_fwd_ws_kernel<128, ConvFwdBufLoader>: since
                 # round 5 that kernel exists twice -- with and without the BatchNorm-statistics tail in its epilogue
                 # (ConvFwdBufStatsLoader / ConvFwdBufLoader) -- and the two instances together are reported here
@@ -637,9 +692,11 @@ def main():
                                     'frac_of_8TBps': round(v['bytes'] / (v['ms'] * 1e-3) / 8e12, 4),
                                     'launches': v['launches'] // args.profile_steps}
                                 for k, v in sorted(hbm_kernels.items(), key=lambda kv: -kv[1]['ms'])},
-            }
+            })
     split_leg = None
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and args.matrix_mode_split:
+        # (opt-in since round 6, --matrix-mode-split: mode 1 keeps the round-1 kernel set -- no wave-specialised, halo-tile,
+        # short-K or window kernels -- so beside the round-6 f32 set it is no longer an A/B of the matrix pipe alone)
         # the same step with the convolution GEMMs on the bf16 matrix pipe (exact three-way operand split, six
         # partial products, f32 accumulation: DESIGN.md section 4a); reported beside the headline, never as it
         import hip_runtime as hr

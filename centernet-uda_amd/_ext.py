@@ -65,7 +65,8 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
     with hr.pack_stamp(_pack_token, weight, _pack_version):     # (private) identity of the weights: pack cache
         if stats is not None:
             hr.check(L.cnuda_dcn_v2_forward_stats(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),
-                                                  hr.ptr(out), hr.ptr(cols), hr.ptr(stats), *geom, hr.ptr(ws), ws.numel(),
+                                                  hr.ptr(out), hr.ptr(cols), hr.ptr(stats), blk, rows.value, *geom, hr.ptr(ws),
+                                                  ws.numel(),
                                                   hr.stream()), 'dcn_v2_forward_stats')
         else:
             hr.check(L.cnuda_dcn_v2_forward_act(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(offset), hr.ptr(mask),

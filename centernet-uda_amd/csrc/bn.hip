@@ -158,7 +158,12 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(
     bn_sum_partials(partial, c, S, grp * s_per_group, (grp + 1) * s_per_group, s0, s1, red);
     if (threadIdx.x == 0) {
         const double mu = s0 / n;
-        double var = s1 / n - mu * mu;   // biased; fp64 sums make the subtraction safe
+        // biased.  With partials from bn_reduce_kernel<0> (squares and sums formed in fp64) the subtraction is safe for any
+        // float32 input.  With partials folded from a GEMM epilogue (bn_fold_stats_kernel: per-block f32 sums of f32 squares,
+        // fp64 only across blocks) it loses ~2 log10(|mean| / std) of float32's seven digits: fine for the zero-centred
+        // outputs of bias-free convolutions in front of a BatchNorm (|mean| <~ 10 std: 1e-5), NOT for a channel whose
+        // mean dwarfs its spread (`epilogue statistics`); such a layer must not request them.
+        double var = s1 / n - mu * mu;
         if (var < 0.0) var = 0.0;
         const float m = (float)mu, is = (float)(1.0 / sqrt(var + (double)eps));
         stat[0] = m;

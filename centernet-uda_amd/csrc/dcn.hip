@@ -1723,11 +1723,21 @@ extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight,
 // (backends/dla.py:351-372).  stats as cnuda_conv2d_forward_stats; cnuda_dcn_v2_stats_block says block size and rows.
 extern "C" int cnuda_dcn_v2_forward_stats(const float* input, const float* weight, const float* bias,
                                           const float* offset, const float* mask, float* output, float* columns,
-                                          float* stats, int B, int C, int H, int W, int Cout, int kh, int kw, int sh,
+                                          float* stats, int stats_block, int stats_rows, int B, int C, int H, int W,
+                                          int Cout, int kh, int kw, int sh,
                                           int sw, int ph, int pw, int dh, int dw, int dg, void* workspace,
                                           size_t workspace_bytes, cnuda_stream_t stream) {
-    CNUDA_REQUIRE(!stats || cnuda_dcn_v2_stats_block(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, nullptr) != 0,
-                  "cnuda_dcn_v2_forward_stats: no statistics for this call (cnuda_dcn_v2_stats_block says which)");
+    if (stats) {
+        // the layout THIS call will write (it follows the kernel choice, and that the offset regime in force now) against
+        // the one the caller sized the buffer for
+        int rows = 0;
+        const int blk = cnuda_dcn_v2_stats_block(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, &rows);
+        CNUDA_REQUIRE(blk != 0, "cnuda_dcn_v2_forward_stats: no statistics for this call (cnuda_dcn_v2_stats_block says which)");
+        CNUDA_REQUIRE(blk == stats_block && rows == stats_rows,
+                      "cnuda_dcn_v2_forward_stats: the statistics buffer was sized for blocks of %d pixels x %d rows, this call "
+                      "writes %d x %d (did the offset regime change between cnuda_dcn_v2_stats_block and the call?)",
+                      stats_block, stats_rows, blk, rows);
+    }
     return dcn_forward_impl(input, weight, bias, offset, mask, output, columns, stats, -1.0f, B, C, H, W, Cout, kh, kw, sh,
                             sw, ph, pw, dh, dw, dg, workspace, workspace_bytes, stream);
 }

@@ -67,7 +67,7 @@ class _Sig:
     cnuda_dcn_v2_backward = (_I, [_P] * 11 + [_I] * 14 + _WS)
     cnuda_dcn_v2_forward_cols = (_I, [_P] * 7 + [_I] * 14 + _WS)
     cnuda_dcn_v2_forward_act = (_I, [_P] * 7 + [_F] + [_I] * 14 + _WS)
-    cnuda_dcn_v2_forward_stats = (_I, [_P] * 8 + [_I] * 14 + _WS)
+    cnuda_dcn_v2_forward_stats = (_I, [_P] * 8 + [_I] * 16 + _WS)
     cnuda_dcn_v2_stats_block = (_I, [_I] * 14 + [_P])
     cnuda_dcn_v2_backward_cols = (_I, [_P] * 12 + [_I] * 14 + _WS)
     cnuda_dcn_v2_backward_acc = (_I, [_P] * 8 + [_I] + [_P] * 4 + [_I] * 14 + _WS)
@@ -321,6 +321,11 @@ def f32c(t):
     """contiguous fp32 view/copy -- the native side reads raw NCHW fp32 (dcn_v2_cuda.cu:58,219-220)."""
     if t.dtype != torch.float32:
         raise RuntimeError("expected float32, got %s" % t.dtype)
+    if getattr(t, '_cnuda_deferred_bn', None) is not None:
+        # the never-written output of a BatchNorm in deferred mode (ops.batch_norm_act(defer_apply=True)): a 4-byte
+        # placeholder that only ops.conv2d's apply-on-load kernels may consume -- anything else would read garbage
+        raise RuntimeError("this tensor is the unwritten output of a deferred BatchNorm (apply on load): only ops.conv2d "
+                           "may consume it; build the BatchNorm without defer_apply for other consumers")
     return t if t.is_contiguous() else t.contiguous()
 
 

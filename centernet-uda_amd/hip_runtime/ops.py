@@ -54,7 +54,8 @@ class _Conv2d(Function):
         normalised activation, exactly what the BatchNorm's backward expects."""
         require_gpu(x, weight, bias)
         ctx.slot = slot_of(x)          # (hip_runtime.fanout: where the other consumers of x leave their share of its gradient)
-        x, weight = f32c(x), f32c(weight)
+        # (norm: `x` is the 4-byte placeholder of a deferred BatchNorm -- shape only; the kernel reads norm[0])
+        x, weight = (x if norm is not None else f32c(x)), f32c(weight)
         bias = None if bias is None else f32c(bias)
         g = _conv_geom(x, weight, stride, padding)
         B, C, H, W, Co, kh, kw, sh, sw, ph, pw = g
@@ -373,7 +374,6 @@ class _BatchNormAct(Function):
         if B % groups:
             raise RuntimeError("batch_norm_act: batch of %d images cannot be split into %d domain groups" % (B, groups))
         HW = x.numel() // (B * C)
-        y = torch.empty_like(x)
         mean = torch.empty(groups * C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(groups * C, dtype=torch.float32, device=x.device)
         L = lib()
@@ -387,6 +387,10 @@ class _BatchNormAct(Function):
                 bpg = B // groups * HW // pre[1]
         # defer: the statistics only -- y stays unwritten, its consumer (ops.conv2d) normalises x while it stages it
         ctx.deferred = bool(defer and bpg and residual is None and relu in (True, 1))
+        # deferred: nothing is ever written, so the output is a 4-byte placeholder of the right SHAPE (all strides 0) --
+        # no 537-MB allocation at the stem, and an accidental reader (f32c raises on the mark) cannot mistake it for data
+        y = torch.empty_strided(x.shape, (0,) * x.dim(), dtype=torch.float32, device=x.device) if ctx.deferred \
+            else torch.empty_like(x)
         if bpg:
             # sum(x) / sum(x^2) came with x from the producing GEMM's epilogue: no statistics pass over x
             check(L.cnuda_bn_train_forward_stats(ptr(x), ptr(pre[0]), bpg, pre[2], ptr(gamma), ptr(beta), ptr(residual),

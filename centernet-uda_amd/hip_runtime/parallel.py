@@ -42,7 +42,10 @@ class DataParallel(nn.Module):
         self.process_group = process_group
         self._sync = True
         self._works = []
-        self._avg_in_collective = None      # decided at the first all-reduce: RCCL yes, gloo no
+        # RCCL averages inside the collective (ncclAvg), gloo sums and finish_gradient_sync() scales: decided HERE from the
+        # process group's backend, so that a step in which no bucket was launched cannot read an undecided flag as 'scale'
+        self._avg_in_collective = bool(dist.is_available() and dist.is_initialized() and
+                                       dist.get_backend(self.process_group) == 'nccl')
         # what the exchange step did since the last reset_exchange_stats(): bytes / buckets all-reduced, and the time the
         # compute stream spent waiting for collectives that had not finished under the backward pass ("exposed")
         self.measure_exchange = False
@@ -169,8 +172,6 @@ class DataParallel(nn.Module):
         """RCCL averages inside the collective (ncclAvg: every rank's contribution is scaled by 1 / world as it is
         read, no pass of its own over the 78.6 MB arena); gloo has no such operator -> SUM, and
         finish_gradient_sync() scales."""
-        if self._avg_in_collective is None:
-            self._avg_in_collective = dist.get_backend(self.process_group) == 'nccl'
         return dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
 
     def _param_ready(self, i):

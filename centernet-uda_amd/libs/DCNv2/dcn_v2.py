@@ -71,20 +71,20 @@ class _DeformConvFn(torch.autograd.Function):
 
 
 class _offset_regime:
-    """The library's offset regime (cnuda_dcn_set_offset_regime) for the calls inside the block, 0 again behind it."""
+    """The library's offset regime (cnuda_dcn_set_offset_regime) for the calls inside the block; behind it the regime that
+    was in force before (the setter returns it), so that nested or interleaved users do not reset each other."""
 
     def __init__(self, regime):
         self.regime = regime
+        self.prev = 0
 
     def __enter__(self):
-        if self.regime:
-            import hip_runtime as hr
-            hr.lib().cnuda_dcn_set_offset_regime(self.regime)
+        import hip_runtime as hr
+        self.prev = hr.lib().cnuda_dcn_set_offset_regime(self.regime)
 
     def __exit__(self, *exc):
-        if self.regime:
-            import hip_runtime as hr
-            hr.lib().cnuda_dcn_set_offset_regime(0)
+        import hip_runtime as hr
+        hr.lib().cnuda_dcn_set_offset_regime(self.prev)
 
 
 def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, pack_token=0,

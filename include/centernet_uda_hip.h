@@ -199,8 +199,12 @@ int cnuda_dcn_v2_forward_act(const float* input, const float* weight, const floa
  * else pixels per block (blocks are numbered image-major and never straddle images), *rows = rows per block. */
 int cnuda_dcn_v2_stats_block(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                              int dh, int dw, int dg, int* rows);
+/* stats_block / stats_rows: the layout the caller sized `stats` for (what cnuda_dcn_v2_stats_block answered).  The answer
+ * depends on the kernel the call picks, and that on the offset regime (cnuda_dcn_set_offset_regime): a call whose own plan
+ * disagrees with these two numbers fails instead of writing another layout into the caller's buffer. */
 int cnuda_dcn_v2_forward_stats(const float* input, const float* weight, const float* bias, const float* offset,
-                               const float* mask, float* output, float* columns, float* stats,
+                               const float* mask, float* output, float* columns, float* stats, int stats_block,
+                               int stats_rows,
                                int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                                int dh, int dw, int dg, void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 
