@@ -440,6 +440,28 @@ struct ConvDgradClassBufLoader {
     using Out = ConvDgradClassLoader::Out;
 };
 
+// All parity classes of one input gradient in ONE launch (round 6): blockIdx.y = class.  The classes share M, the pixel count
+// and the row tile; their K differs (1 + 2 + 2 + 4 taps for 3x3 / stride 2), so the class with the most taps goes first.
+// One launch fills the chip where four small ones each left it half empty and paid their own ramp and tail.
+constexpr int MAX_CLASSES = 4;
+struct ConvDgradClassSet {
+    ConvDgradClassParams cls[MAX_CLASSES];
+    const float* A[MAX_CLASSES];
+    int Kp[MAX_CLASSES];
+};
+template <int BM>
+__global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd_ws_classes_kernel(
+    ConvDgradClassSet s, int Mp, int M, long long N, int n_tiles, int m_tiles) {
+    const int c = blockIdx.y;
+    igemm_fwd_ws_body<BM, ConvDgradClassBufLoader, IG_KC>(s.cls[c], s.A[c], Mp, s.Kp[c], M, N, n_tiles, m_tiles);
+}
+template <int BM>
+__global__ __launch_bounds__(IG_THREADS, (BM == 128 ? 3 : 1)) void igemm_fwd_classes_kernel(
+    ConvDgradClassSet s, int Mp, int M, long long N, int n_tiles, int m_tiles) {
+    const int c = blockIdx.y;
+    igemm_fwd_body<BM, ConvDgradClassBufLoader>(s.cls[c], s.A[c], Mp, s.Kp[c], M, N, n_tiles, m_tiles);
+}
+
 // Weight gradient: gw[o][(tap,c)] = sum_{b,p} gy[b][o][p] * x[b][c][window(p, tap)]
 struct ConvWParams {
     ConvGeom g;
@@ -646,6 +668,36 @@ int pick_bm(int M, long long N) {
     return bm;
 }
 
+// Split-K (round 6, igemm.cuh igemm_fwd_*splitk_kernel): a forward-type GEMM whose pixel x row tiles at the NATURAL row tile
+// cover less than half the chip but whose K is long keeps that tile and cuts K over grid.y -- partial slabs, a fixed-order
+// reduce that runs the loader's epilogue.  pick_bm's answer to the same problem is a smaller row tile (more, emptier
+// workgroups: 12-20 TFLOP/s on the ADVENT discriminator's 4 x 4 convolutions and the 512 -> 27 offset convolution).
+// CNUDA_SPLITK=0 keeps pick_bm's plan (A/B measurements; tests/test_gpu_kernel_switches.py).
+struct SplitK {
+    int bm = 0, z = 1, split_k = 0;          // row tile, splits, K elements per split (a multiple of the chunk)
+    bool on() const { return z > 1; }
+};
+int g_splitk_max_tiles = 128;                // cnuda_conv_set_splitk_policy (tests, measurements)
+SplitK pick_splitk(int M, long long N, int Kp) {
+    static const bool enabled = !(getenv("CNUDA_SPLITK") && getenv("CNUDA_SPLITK")[0] == '0');
+    SplitK s;
+    if (!enabled || matrix_mode() != 0) return s;
+    const int bm0 = M > 64 ? 128 : (M > 32 ? 64 : 32);
+    const long long tiles = ((N + IG_BN - 1) / IG_BN) * ((M + bm0 - 1) / bm0);
+    const int nchunk = Kp / IG_KC;
+    if (tiles >= g_splitk_max_tiles || nchunk < 32) return s;
+    int z = (int)std::min<long long>(nchunk / 16, 512 / tiles);          // >= 16 chunks per split, ~two workgroups per CU
+    if (z < 2) return s;
+    const int per = (nchunk + z - 1) / z;
+    s.bm = bm0;
+    s.z = (nchunk + per - 1) / per;
+    s.split_k = per * IG_KC;
+    return s;
+}
+size_t splitk_slab_bytes(const SplitK& s, int M, long long N) {
+    return s.on() ? (size_t)s.z * round_up(M, s.bm) * (size_t)((N + IG_BN - 1) / IG_BN * IG_BN) * sizeof(float) : 0;
+}
+
 // hwgrad_kernel (hwgrad.cuh) takes the weight gradient of the narrow 3x3 convolutions (the DCN offset / mask layers)
 // (round 6: any row width that is a multiple of 8 -- rectangular tiles, hwgrad.cuh; the overhang of a map whose height is
 // no multiple of the tile's stays under a quarter)
@@ -673,6 +725,7 @@ struct ConvPlan {
     int hw_tiles, hw_tiles_per_split;
     int Kf, Kpf, bmf, Mpf;   // forward:  K = T*C,  M = Co
     int Kd, Kpd, bmd, Mpd;   // dgrad:    K = T*Co, M = C
+    SplitK skf, skd;         // split-K plans of the two (z == 1: none)
     int Mpw, Jp, Z, wbm, wbj; // wgrad slabs and tile shape
     long long Nf, Nd, pix_per_split;
     size_t fwd_bytes, dgrad_bytes, wgrad_bytes;
@@ -682,8 +735,18 @@ ConvPlan make_plan(const ConvGeom& g) {
     q.T = g.kh * g.kw;
     q.Nf = (long long)g.B * g.Ho * g.Wo;
     q.Nd = (long long)g.B * g.H * g.W;
-    q.Kf = q.T * g.C;   q.Kpf = round_up(q.Kf, IG_KC);  q.bmf = pick_bm(g.Co, q.Nf);  q.Mpf = round_up(g.Co, q.bmf);
-    q.Kd = q.T * round_up(g.Co, IG_BK);  q.Kpd = round_up(q.Kd, IG_KC);  q.bmd = pick_bm(g.C, q.Nd);   q.Mpd = round_up(g.C, q.bmd);
+    q.Kf = q.T * g.C;   q.Kpf = round_up(q.Kf, IG_KC);  q.bmf = pick_bm(g.Co, q.Nf);
+    q.Kd = q.T * round_up(g.Co, IG_BK);  q.Kpd = round_up(q.Kd, IG_KC);  q.bmd = pick_bm(g.C, q.Nd);
+    // (split-K only for the buffer-addressed loaders of the plain stride-1 paths; the parity-class input gradient plans per class)
+    const bool sk_ok = buffer_addressing() && q.T <= 32 && g.C % IG_BK == 0 &&
+                       (size_t)g.B * g.C * g.H * g.W * sizeof(float) < IG_BUF_OOB &&
+                       (size_t)g.B * g.Co * g.Ho * g.Wo * sizeof(float) < IG_BUF_OOB;
+    if (sk_ok) q.skf = pick_splitk(g.Co, q.Nf, q.Kpf);
+    if (sk_ok && g.sh == 1 && g.sw == 1) q.skd = pick_splitk(g.C, q.Nd, q.Kpd);
+    if (q.skf.on()) q.bmf = q.skf.bm;
+    if (q.skd.on()) q.bmd = q.skd.bm;
+    q.Mpf = round_up(g.Co, q.bmf);
+    q.Mpd = round_up(g.C, q.bmd);
     q.wbj = (g.Co <= 32 || (g.C % 64 == 0 && q.Kf % 128 == 0)) ? 128 : 64;   // 64 x 128: +8-13 % where nothing is padded
     // 128 x 64 where the columns do not fill 128 (K = 9 * 64) but the output channels do: the same two accumulator
     // tiles per wave and loads per MFMA as 64 x 128 (the 64 -> 256 head convolutions at 128 x 128)
@@ -711,8 +774,20 @@ ConvPlan make_plan(const ConvGeom& g) {
         q.hw_tiles_per_split = (q.hw_tiles + zz - 1) / zz;
         q.Z = (q.hw_tiles + q.hw_tiles_per_split - 1) / q.hw_tiles_per_split;
     }
-    q.fwd_bytes = carve_bytes(ig_a_bytes(q.Kpf, q.Mpf), 1) + 256;
-    q.dgrad_bytes = carve_bytes(ig_a_bytes(q.Kpd, q.Mpd), 1) + 256;
+    q.fwd_bytes = carve_bytes(ig_a_bytes(q.Kpf, q.Mpf), 1) + carve_bytes(splitk_slab_bytes(q.skf, g.Co, q.Nf), 1) + 256;
+    q.dgrad_bytes = carve_bytes(ig_a_bytes(q.Kpd, q.Mpd), 1) + carve_bytes(splitk_slab_bytes(q.skd, g.C, q.Nd), 1) + 256;
+    if (g.sh > 1 || g.sw > 1) {
+        // parity-class input gradient: the largest class (all classes have Nd / (sh sw) pixels; K at most ceil(kh / sh) *
+        // ceil(kw / sw) taps) bounds the packed matrix and the split-K slabs of every class
+        const long long Nc = q.Nd / (g.sh * g.sw);
+        const int Kpc = round_up(ceil_div(g.kh, g.sh) * ceil_div(g.kw, g.sw) * g.Co, IG_KC);
+        const SplitK sc = pick_splitk(g.C, Nc, Kpc);
+        const int mp = round_up(g.C, sc.on() ? sc.bm : 32);
+        // (one launch for all classes: their packed matrices side by side, each at most the largest class's, rows at most 128)
+        const size_t need = (size_t)g.sh * g.sw * carve_bytes(ig_a_bytes(Kpc, std::max(round_up(g.C, 128), std::max(mp, q.Mpd))), 1) +
+                            carve_bytes(splitk_slab_bytes(sc, g.C, Nc), 1) + 256;
+        if (need > q.dgrad_bytes) q.dgrad_bytes = need;
+    }
     // (slabs, then the bias row sums per split: [Z][Mpw] -- never less than the [Co][B] scratch of the channel-sum kernels)
     q.wgrad_bytes = carve_bytes((size_t)q.Z * q.Mpw * q.Jp, 4) +
                     carve_bytes(std::max((size_t)g.Co * g.B, (size_t)q.Z * q.Mpw), 4) + 256;
@@ -873,13 +948,41 @@ __global__ __launch_bounds__(256) void dgrad_s2_c16_kernel(DgradS2Params p) {
     }
 }
 
+template <class Loader> struct SplitKLoader : std::false_type {};
+template <> struct SplitKLoader<ConvFwdBufLoader> : std::true_type {};
+template <> struct SplitKLoader<ConvDgradBufLoader> : std::true_type {};
+template <> struct SplitKLoader<ConvDgradClassBufLoader> : std::true_type {};
+
 template <class Loader>
 int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp, int Kp, int M, long long N,
-               hipStream_t st, const char* who) {
+               hipStream_t st, const char* who, const SplitK& sk = SplitK(), float* slab = nullptr) {
     CNUDA_REQUIRE(N < (1ll << 31) - IG_BN, "%s: more than 2^31 pixels per call", who);
     const int n_tiles = ceil_div(N, IG_BN), m_tiles = Mp / bm;
     const dim3 grid(n_tiles * m_tiles), block(IG_THREADS);
     ProfScope prof(st);
+    if constexpr (SplitKLoader<Loader>::value) {
+        if (sk.on()) {
+            CNUDA_REQUIRE(slab && bm == sk.bm && matrix_mode() == 0, "%s: split-K plan without its slabs", who);
+            const bool ws = wave_specialised() && bm >= 64;
+            prof.name(ws ? "igemm_fwd_ws_splitk_kernel<%d, %s> x %d + reduce" : "igemm_fwd_splitk_kernel<%d, %s> x %d + reduce",
+                      bm, Loader::name(), sk.z);
+            const dim3 gridz(n_tiles * m_tiles, sk.z);
+            if (bm == 128 && ws)
+                CNUDA_LAUNCH((igemm_fwd_ws_splitk_kernel<128, Loader>), gridz, dim3(2 * IG_THREADS), 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles, slab, sk.split_k);
+            else if (bm == 64 && ws)
+                CNUDA_LAUNCH((igemm_fwd_ws_splitk_kernel<64, Loader>), gridz, dim3(2 * IG_THREADS), 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles, slab, sk.split_k);
+            else if (bm == 128)
+                CNUDA_LAUNCH((igemm_fwd_splitk_kernel<128, Loader>), gridz, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles, slab, sk.split_k);
+            else if (bm == 64)
+                CNUDA_LAUNCH((igemm_fwd_splitk_kernel<64, Loader>), gridz, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles, slab, sk.split_k);
+            else
+                CNUDA_LAUNCH((igemm_fwd_splitk_kernel<32, Loader>), gridz, block, 0, st, p, A, Mp, Kp, M, N, n_tiles, m_tiles, slab, sk.split_k);
+            CNUDA_LAUNCH((splitk_reduce_kernel<Loader>), dim3(ceil_div(N, 256), ceil_div(M, SK_ROWS)), dim3(256), 0, st, p, slab, sk.z,
+                         Mp, (long long)n_tiles * IG_BN, M, N);
+            return check_launch(who);
+        }
+    }
+    CNUDA_REQUIRE(!sk.on(), "%s: split-K plan for a loader without split-K kernels", who);
     if constexpr (std::is_same<Loader, ConvFwdBufLoader>::value || std::is_same<Loader, ConvFwdBufStatsLoader>::value ||
                   std::is_same<Loader, ConvFwdLoader<true>>::value) {
         // few chunks, several row tiles (the DCN column-gradient GEMM: a 1x1 forward with K = 64 and 9*C rows)
@@ -933,6 +1036,12 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
 using namespace cnuda;
 
 
+extern "C" int cnuda_conv_set_splitk_policy(int max_tiles) {
+    const int prev = g_splitk_max_tiles;
+    g_splitk_max_tiles = max_tiles < 0 ? 128 : max_tiles;
+    return prev;
+}
+
 extern "C" int cnuda_conv_set_halo_policy(int level, int min_tiles) {
     if (level >= 0) g_hconv_level = level;
     if (min_tiles >= 1) g_hconv_min_tiles = min_tiles;
@@ -974,7 +1083,7 @@ extern "C" int cnuda_conv2d_stats_block(int B, int C, int H, int W, int Cout, in
     if (smallc_supported(C, Cout, kh, kw, sh, sw)) return smallc_stats_blocks(B, C, H, W, Cout, kh, kw, sh, ph, pw, blocks_per_image, rows);
     if (((g.Ho * g.Wo) & 3) != 0) return 0;
     const ConvPlan q = make_plan(g);
-    if (hconv_ok(g, C, q.bmf)) return 0;
+    if (q.skf.on() || hconv_ok(g, C, q.bmf)) return 0;
     // (the statistics kernels exist for the buffer-addressed loader: every DLA-34 / ResNet layer behind the stem)
     if (!(C % IG_BK == 0 && buffer_addressing() && q.T <= 32 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB) || matrix_mode() != 0)
         return 0;
@@ -1011,7 +1120,7 @@ extern "C" int cnuda_conv2d_forward_stats(const float* x, const float* weight, c
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
     ConvFwdParams p{g, x, bias, y, act_slope, residual};
-    if (hconv_ok(g, C, q.bmf)) {      // (K = 9 C is already a multiple of the chunk: the same packed size, another K order)
+    if (!q.skf.on() && hconv_ok(g, C, q.bmf)) {      // (K = 9 C is already a multiple of the chunk: the same packed size, another K order)
         const float* Ah = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),
                                       ig_a_bytes(q.Kpf, q.Mpf), Cout, C, q.T, PACK_HALO_FWD, q.Kpf, q.Mpf, 0, st);
         return launch_hconv<HconvFwd>(q.bmf, p, x, C, g, Ah, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
@@ -1025,8 +1134,11 @@ extern "C" int cnuda_conv2d_forward_stats(const float* x, const float* weight, c
         ps.stats_mp = q.Mpf;
         return launch_fwd<ConvFwdBufStatsLoader>(q.bmf, ps, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward_stats");
     }
-    if (C % IG_BK == 0 && buffer_addressing() && q.T <= 32 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB)
-        return launch_fwd<ConvFwdBufLoader>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
+    if (C % IG_BK == 0 && buffer_addressing() && q.T <= 32 && (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB) {
+        float* slab = q.skf.on() ? reinterpret_cast<float*>(cv.take<char>(splitk_slab_bytes(q.skf, Cout, q.Nf))) : nullptr;
+        return launch_fwd<ConvFwdBufLoader>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward", q.skf, slab);
+    }
+    CNUDA_REQUIRE(!q.skf.on(), "cnuda_conv2d_forward: split-K plan off the buffer-addressed path");
     if (C % IG_BK == 0)
         return launch_fwd<ConvFwdLoader<true>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
     return launch_fwd<ConvFwdLoader<false>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
@@ -1127,38 +1239,89 @@ extern "C" int cnuda_conv2d_backward_data_add(const float* grad_y, const float* 
     const bool buf_ok = buffer_addressing() && q.T <= 32 && (size_t)B * Cout * g.Ho * g.Wo * sizeof(float) < IG_BUF_OOB;
     if ((sh > 1 || sw > 1) && H % sh == 0 && W % sw == 0 && Cout % IG_BK == 0 &&
         ceil_div(kh, sh) * ceil_div(kw, sw) <= 9) {   // taps one class can see (tap_r/tap_s hold 9)
-        // one launch per parity class, K restricted to the taps that class can see
+        // K restricted to the taps a parity class can see; all classes in ONE launch (blockIdx.y = class) unless a class
+        // cuts K over the grid (split-K, small maps) or the tensors need the pointer loaders
         ProfScope prof(st);   // brackets the whole class group (inner scopes find nothing armed)
         prof.name("igemm_fwd*_kernel<*, ConvDgradClassLoader> x %d parity classes", sh * sw);
+        const long long Nc = (long long)B * (H / sh) * (W / sw);
+        ConvDgradClassParams cps[16];
+        int Kpcs[16], taps_all[16][9], ncls = 0;
+        bool any_split = false;
         for (int py = 0; py < sh; ++py)
             for (int px = 0; px < sw; ++px) {
-                ConvDgradClassParams cp;
+                CNUDA_REQUIRE(ncls < 16, "cnuda_conv2d_backward_data: more than 16 parity classes");
+                ConvDgradClassParams& cp = cps[ncls];
                 cp.g = g; cp.gy = grad_y; cp.gx = grad_x; cp.py = py; cp.px = px; cp.Hc = H / sh; cp.Wc = W / sw;
                 cp.add = addend; cp.add2 = addend2;
                 cp.ntaps = 0;
-                int taps[9];   // at most ceil(kh/sh)*ceil(kw/sw) entries
                 for (int r = 0; r < kh; ++r)
                     for (int t = 0; t < kw; ++t)
                         // (iy + ph - r) must be a multiple of sh for every iy = py + sh*qy: decided by py alone
                         // (C++ % keeps the dividend's sign; zero is zero either way)
                         if ((py + ph - r) % sh == 0 && (px + pw - t) % sw == 0) {
-                            cp.tap_r[cp.ntaps] = r; cp.tap_s[cp.ntaps] = t; taps[cp.ntaps] = r * kw + t;
+                            cp.tap_r[cp.ntaps] = r; cp.tap_s[cp.ntaps] = t; taps_all[ncls][cp.ntaps] = r * kw + t;
                             cp.tap_dy[cp.ntaps] = (py + ph - r) / sh; cp.tap_dx[cp.ntaps] = (px + pw - t) / sw;
                             ++cp.ntaps;
                         }
-                const long long Nc = (long long)B * cp.Hc * cp.Wc;
                 // ntaps == 0 (a class no tap reaches): K is all padding, the kernel writes zeros
-                const int Kc = cp.ntaps * Cout, Kpc = round_up(Kc > 0 ? Kc : IG_KC, IG_KC);
-                const int bm = pick_bm(C, Nc), Mp = round_up(C, bm);
-                CNUDA_REQUIRE(ig_a_bytes(Kpc, Mp) + 256 <= workspace_bytes, "cnuda_conv2d_backward_data: workspace");
+                const int Kc = cp.ntaps * Cout;
+                Kpcs[ncls] = round_up(Kc > 0 ? Kc : IG_KC, IG_KC);
+                any_split = any_split || (buf_ok && pick_splitk(C, Nc, Kpcs[ncls]).on());
+                ++ncls;
+            }
+        if (buf_ok && !any_split && ncls <= MAX_CLASSES && matrix_mode() == 0) {
+            const int bm = pick_bm(C, Nc * ncls), Mp = round_up(C, bm);      // (the grid is ncls times one class's)
+            // classes in order of decreasing K: the long ones start first
+            int order[MAX_CLASSES];
+            for (int i = 0; i < ncls; ++i) order[i] = i;
+            std::stable_sort(order, order + ncls, [&](int a, int b2) { return Kpcs[a] > Kpcs[b2]; });
+            ConvDgradClassSet set;
+            size_t used = 0;
+            for (int i = 0; i < ncls; ++i) {
+                const int c = order[i];
+                const size_t bytes = carve_bytes(ig_a_bytes(Kpcs[c], Mp), 1);
+                CNUDA_REQUIRE(used + bytes + 256 <= workspace_bytes, "cnuda_conv2d_backward_data: workspace");
+                float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(Aws) + used);
+                used += bytes;
+                set.cls[i] = cps[c];
+                set.Kp[i] = Kpcs[c];
+                set.A[i] = launch_pack_taps(weight, dst, ig_a_bytes(Kpcs[c], Mp), Cout, C, q.T, taps_all[c], cps[c].ntaps, Kpcs[c], Mp, st);
+            }
+            for (int i = ncls; i < MAX_CLASSES; ++i) { set.cls[i] = set.cls[0]; set.Kp[i] = set.Kp[0]; set.A[i] = set.A[0]; }
+            CNUDA_REQUIRE(Nc < (1ll << 31) - IG_BN, "cnuda_conv2d_backward_data: more than 2^31 pixels per call");
+            const int n_tiles = ceil_div(Nc, IG_BN), m_tiles = Mp / bm;
+            const dim3 grid(n_tiles * m_tiles, ncls);
+            if (wave_specialised() && bm == 128)
+                CNUDA_LAUNCH((igemm_fwd_ws_classes_kernel<128>), grid, dim3(2 * IG_THREADS), 0, st, set, Mp, C, Nc, n_tiles, m_tiles);
+            else if (wave_specialised() && bm == 64)
+                CNUDA_LAUNCH((igemm_fwd_ws_classes_kernel<64>), grid, dim3(2 * IG_THREADS), 0, st, set, Mp, C, Nc, n_tiles, m_tiles);
+            else if (bm == 128)
+                CNUDA_LAUNCH((igemm_fwd_classes_kernel<128>), grid, dim3(IG_THREADS), 0, st, set, Mp, C, Nc, n_tiles, m_tiles);
+            else if (bm == 64)
+                CNUDA_LAUNCH((igemm_fwd_classes_kernel<64>), grid, dim3(IG_THREADS), 0, st, set, Mp, C, Nc, n_tiles, m_tiles);
+            else
+                CNUDA_LAUNCH((igemm_fwd_classes_kernel<32>), grid, dim3(IG_THREADS), 0, st, set, Mp, C, Nc, n_tiles, m_tiles);
+            return check_launch("cnuda_conv2d_backward_data(classes)");
+        }
+        for (int ci = 0; ci < ncls; ++ci) {
+                const ConvDgradClassParams& cp = cps[ci];
+                const int Kpc = Kpcs[ci];
+                const int* taps = taps_all[ci];
+                const SplitK sc = buf_ok ? pick_splitk(C, Nc, Kpc) : SplitK();
+                const int bm = sc.on() ? sc.bm : pick_bm(C, Nc), Mp = round_up(C, bm);
+                const size_t slab_bytes = splitk_slab_bytes(sc, C, Nc);
+                CNUDA_REQUIRE(carve_bytes(ig_a_bytes(Kpc, Mp), 1) + carve_bytes(slab_bytes, 1) + 256 <= workspace_bytes,
+                              "cnuda_conv2d_backward_data: workspace");
                 const float* A = launch_pack_taps(weight, Aws, ig_a_bytes(Kpc, Mp), Cout, C, q.T, taps, cp.ntaps, Kpc, Mp, st);
-                if (int rc = buf_ok ? launch_fwd<ConvDgradClassBufLoader>(bm, cp, A, Mp, Kpc, C, Nc, st, "cnuda_conv2d_backward_data(class)")
+                // (the slabs of a class behind the packed matrix -- whose room is that of the plan's largest: the same carve)
+                float* slab = sc.on() ? reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(Aws) + ig_a_bytes(Kpc, Mp) + 255) & ~(uintptr_t)255) : nullptr;
+                if (int rc = buf_ok ? launch_fwd<ConvDgradClassBufLoader>(bm, cp, A, Mp, Kpc, C, Nc, st, "cnuda_conv2d_backward_data(class)", sc, slab)
                                     : launch_fwd<ConvDgradClassLoader>(bm, cp, A, Mp, Kpc, C, Nc, st, "cnuda_conv2d_backward_data(class)"))
                     return rc;
-            }
+        }
         return 0;
     }
-    if (hconv_ok(g, Cout, q.bmd)) {   // (Co % 16 == 0: Kpd = 9 Co, no padded rows)
+    if (!q.skd.on() && hconv_ok(g, Cout, q.bmd)) {   // (Co % 16 == 0: Kpd = 9 Co, no padded rows)
         const float* Ah = launch_pack(weight, Aws, ig_a_bytes(q.Kpd, q.Mpd), Cout, C, q.T, PACK_HALO_DGRAD, q.Kpd, q.Mpd, 0, st);
         ConvDgradParams ph{g, grad_y, grad_x, Cout, addend, addend2};
         return launch_hconv<HconvDgrad>(q.bmd, ph, grad_y, Cout, g, Ah, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
@@ -1166,8 +1329,11 @@ extern "C" int cnuda_conv2d_backward_data_add(const float* grad_y, const float* 
     const float* A = launch_pack(weight, Aws, ig_a_bytes(q.Kpd, q.Mpd), Cout, C, q.T, PACK_DGRAD, q.Kpd, q.Mpd,
                                  round_up(Cout, IG_BK), st);
     ConvDgradParams p{g, grad_y, grad_x, round_up(Cout, IG_BK), addend, addend2};
-    if (buf_ok && sh == 1 && sw == 1)
-        return launch_fwd<ConvDgradBufLoader>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
+    if (buf_ok && sh == 1 && sw == 1) {
+        float* slab = q.skd.on() ? reinterpret_cast<float*>(cv.take<char>(splitk_slab_bytes(q.skd, C, q.Nd))) : nullptr;
+        return launch_fwd<ConvDgradBufLoader>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data", q.skd, slab);
+    }
+    CNUDA_REQUIRE(!q.skd.on(), "cnuda_conv2d_backward_data: split-K plan off the buffer-addressed path");
     return launch_fwd<ConvDgradLoader>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_backward_data");
 }
 

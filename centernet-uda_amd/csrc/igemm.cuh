@@ -370,11 +370,30 @@ template <class Loader> struct IgRaw<Loader, true> { using type = typename Loade
 //   them into values one chunk later, when the kernel stores that chunk to LDS
 // Epilogue contract:
 //   void store(const Params&, int m, long long n, float value)
-template <int BM, class Loader, bool X3 = false>
-__global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void igemm_fwd_kernel(
-    typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
-    int n_tiles, int m_tiles) {
+// Split-K epilogue (round 6): the accumulator tile as it stands -- no bias, no activation -- into split z's slab
+// [Mp][Np] (Np = n_tiles * 128: every tile whole, no bounds tests); splitk_reduce_kernel adds the slabs in order and runs
+// the loader's own epilogue (Out::store) on the sums.
+template <int BM>
+__device__ __forceinline__ void ig_store_slab(float* __restrict__ slab, const f32x16 (&acc)[IgTile<BM>::TM][IgTile<BM>::TN],
+                                              int Mp, long long Np, int m0, long long n0, int wm_off, int wn_off, int lane) {
     using T = IgTile<BM>;
+    float* const d = slab + (size_t)blockIdx.y * Mp * Np;
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const long long n = n0 + wn_off + j * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[(size_t)(m0 + wm_off + i * 32 + mfma_row(r, lane)) * Np + n] = acc[i][j][r];
+    }
+}
+
+template <int BM, class Loader, bool X3 = false, bool SPLITK = false>
+__device__ __forceinline__ void igemm_fwd_body(
+    const typename Loader::Params& p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
+    int n_tiles, int m_tiles, float* __restrict__ slab = nullptr, int split_k = 0) {
+    using T = IgTile<BM>;
+    static_assert(!(X3 && SPLITK), "split-K runs on the f32 pipe");
     // two LDS stages: chunk k+1 is written while chunk k's fragments are still being read, one barrier per chunk
     // (X3: three bf16 pieces per operand, 1.5x the bytes)
     constexpr int LDS_A = X3 ? 3 * 2 * BM * 4 : IG_KC * BM, LDS_B = X3 ? 3 * 2 * IG_BN * 4 : IG_KC * IG_BN;   // floats
@@ -507,20 +526,27 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void ig
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += total[i][j][r];
     } else {
-    stage_load(0);
+    // (SPLITK: blockIdx.y takes the K range [kb, ke), split_k elements each)
+    const int kb = SPLITK ? (int)blockIdx.y * split_k : 0;
+    const int ke = SPLITK ? (kb + split_k < Kp ? kb + split_k : Kp) : Kp;
+    stage_load(kb);
     stage_store(0);
-    if (IG_KC < Kp) stage_load(IG_KC);
+    if (kb + IG_KC < ke) stage_load(kb + IG_KC);
     __syncthreads();
     int cur = 0;
-    for (int k0 = 0; k0 < Kp; k0 += IG_KC) {
+    for (int k0 = kb; k0 < ke; k0 += IG_KC) {
         ig_mma_chunk<BM>(As[cur], Bs[cur], acc, wm_off, wn_off, lane);
-        if (k0 + IG_KC < Kp) {
+        if (k0 + IG_KC < ke) {
             stage_store(cur ^ 1);                      // chunk k+1 (its global loads were issued one chunk ago)
-            if (k0 + 2 * IG_KC < Kp) stage_load(k0 + 2 * IG_KC);
+            if (k0 + 2 * IG_KC < ke) stage_load(k0 + 2 * IG_KC);
         }
         __syncthreads();
         cur ^= 1;
     }
+    }
+    if constexpr (SPLITK) {
+        ig_store_slab<BM>(slab, acc, Mp, (long long)n_tiles * IG_BN, m0, n0, wm_off, wn_off, lane);
+        return;
     }
     if constexpr (Loader::Out::kVec4) {
         if (Loader::Out::vec4_ok(p)) {      // (uniform; the K loop ended with a barrier: the operand buffers are free)
@@ -544,6 +570,39 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void ig
     }
 }
 
+template <int BM, class Loader, bool X3 = false>
+__global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void igemm_fwd_kernel(
+    typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
+    int n_tiles, int m_tiles) {
+    igemm_fwd_body<BM, Loader, X3, false>(p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+}
+// Split-K form (grid.y = splits): problems whose pixel x row tiles do not fill the chip but whose K is long -- the 4 x 4
+// convolutions of the ADVENT discriminator on 20 x 20 ... 5 x 5 maps (uda/adversarial_entropy_minimization.py:51-68), the
+// 512 -> 27 offset convolution of the 16 x 16 level -- keep their natural row tile and cut K instead of shrinking the tile
+// until the grid is large enough (a 32-row tile runs at 12-20 TFLOP/s there).
+template <int BM, class Loader>
+__global__ __launch_bounds__(IG_THREADS, (BM == 128 ? 3 : 1)) void igemm_fwd_splitk_kernel(
+    typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
+    int n_tiles, int m_tiles, float* __restrict__ slab, int split_k) {
+    igemm_fwd_body<BM, Loader, false, true>(p, A, Mp, Kp, M, N, n_tiles, m_tiles, slab, split_k);
+}
+// y[m][n] = epilogue(sum over z of slab[z][m][n]): the splits in order (bit-reproducible), then the loader's own
+// Out::store (bias, residual, activation / addends / strided scatter).  Thread = pixel n, blockIdx.y = 8 rows.
+constexpr int SK_ROWS = 8;
+template <class Loader>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(typename Loader::Params p, const float* __restrict__ slab, int Z,
+                                                            int Mp, long long Np, int M, long long N) {
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    typename Loader::Out out(p, n);
+    const int m_end = ((int)blockIdx.y + 1) * SK_ROWS < M ? ((int)blockIdx.y + 1) * SK_ROWS : M;
+    for (int m = blockIdx.y * SK_ROWS; m < m_end; ++m) {
+        float v = 0.0f;
+        for (int z = 0; z < Z; ++z) v += slab[((size_t)z * Mp + m) * Np + n];
+        out.store(p, m, v);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Wave-specialised variant of the f32 forward-type kernel: 8 waves per workgroup.  Waves 4-7 (threads 256..511) are
 // PRODUCERS -- they run the Loader, stage the next chunk's A and B tiles into LDS and issue the loads after it;
@@ -553,11 +612,14 @@ __global__ __launch_bounds__(IG_THREADS, (BM == 128 ? (X3 ? 2 : 3) : 1)) void ig
 // stages, one barrier per chunk (all 8 waves); the two roles never hold registers at the same time, so the
 // kernel needs fewer registers than the 4-wave one (78 vs 113 for the 128-row tile).
 // ---------------------------------------------------------------------------
-template <int BM, class Loader, int KC>
+template <int BM, class Loader, int KC, bool SPLITK = false>
 __device__ __forceinline__ void igemm_fwd_ws_body(
     const typename Loader::Params& p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
-    int n_tiles, int m_tiles) {
+    int n_tiles, int m_tiles, float* __restrict__ slab = nullptr, int split_k = 0) {
     using T = IgTile<BM>;
+    // (SPLITK: blockIdx.y takes the K range [kb, ke), split_k elements each)
+    const int kb = SPLITK ? (int)blockIdx.y * split_k : 0;
+    const int ke = SPLITK ? (kb + split_k < Kp ? kb + split_k : Kp) : Kp;
     constexpr int LDS_AB = 2 * KC * BM + 2 * KC * IG_BN;
     static_assert(LDS_AB >= 4 * IG_EPI_WAVE, "the operand buffers hold the epilogue staging tiles");
     __shared__ __attribute__((aligned(16))) float smem[LDS_AB];    // operand stages; reused by the vec4 epilogue
@@ -601,15 +663,15 @@ __device__ __forceinline__ void igemm_fwd_ws_body(
                 else ld.load(k0 + h * IG_BK, ksub, r.rb[h]);
             }
         };
-        stage_load(0, r0);
+        stage_load(kb, r0);
         stage_store(0, r0);
-        if (KC < Kp) stage_load(KC, r0);
+        if (kb + KC < ke) stage_load(kb + KC, r0);
         __syncthreads();
         int c1 = 0;
-        for (int k0 = 0; k0 < Kp; k0 += KC) {
-            if (k0 + KC < Kp) {
+        for (int k0 = kb; k0 < ke; k0 += KC) {
+            if (k0 + KC < ke) {
                 stage_store(c1 ^ 1, r0);
-                if (k0 + 2 * KC < Kp) stage_load(k0 + 2 * KC, r0);
+                if (k0 + 2 * KC < ke) stage_load(k0 + 2 * KC, r0);
             }
             __syncthreads();
             c1 ^= 1;
@@ -626,10 +688,14 @@ __device__ __forceinline__ void igemm_fwd_ws_body(
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     __syncthreads();
     int cur = 0;
-    for (int k0 = 0; k0 < Kp; k0 += KC) {
+    for (int k0 = kb; k0 < ke; k0 += KC) {
         ig_mma_chunk<BM, KC>(As[cur], Bs[cur], acc, wm_off, wn_off, lane);
         __syncthreads();
         cur ^= 1;
+    }
+    if constexpr (SPLITK) {
+        ig_store_slab<BM>(slab, acc, Mp, (long long)n_tiles * IG_BN, m0, n0, wm_off, wn_off, lane);
+        return;
     }
     if constexpr (Loader::Out::kVec4) {
         if (Loader::Out::vec4_ok(p)) {      // (the producers wrote their last stage before the last barrier)
@@ -657,6 +723,12 @@ __global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd
     typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
     int n_tiles, int m_tiles) {
     igemm_fwd_ws_body<BM, Loader, KC>(p, A, Mp, Kp, M, N, n_tiles, m_tiles);
+}
+template <int BM, class Loader, int KC = IG_KC>
+__global__ __launch_bounds__(2 * IG_THREADS, (BM == 128 ? 2 : 1)) void igemm_fwd_ws_splitk_kernel(
+    typename Loader::Params p, const float* __restrict__ A, int Mp, int Kp, int M, long long N,
+    int n_tiles, int m_tiles, float* __restrict__ slab, int split_k) {
+    igemm_fwd_ws_body<BM, Loader, KC, true>(p, A, Mp, Kp, M, N, n_tiles, m_tiles, slab, split_k);
 }
 
 // ---------------------------------------------------------------------------

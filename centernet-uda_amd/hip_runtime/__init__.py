@@ -142,6 +142,7 @@ class _Sig:
     cnuda_dcn_set_offset_regime = (_I, [_I])
     cnuda_dcn_offset_census = (_I, [_P, _I, _I, _LL, _P, _P])
     cnuda_conv_set_halo_policy = (_I, [_I, _I])
+    cnuda_conv_set_splitk_policy = (_I, [_I])
 
 
 # ---------------------------------------------------------------------------
@@ -471,6 +472,20 @@ class dcn_fused_min_tiles:
 
     def __exit__(self, *exc):
         lib().cnuda_dcn_set_fused_min_tiles(self.prev)
+
+
+class splitk:
+    """with splitk(max_tiles): forward-type convolution GEMMs with fewer than `max_tiles` pixel x row tiles (and a long K)
+    inside the block cut K over the grid (cnuda_conv_set_splitk_policy); 0 = never."""
+
+    def __init__(self, max_tiles):
+        self.max_tiles = int(max_tiles)
+
+    def __enter__(self):
+        self.prev = lib().cnuda_conv_set_splitk_policy(self.max_tiles)
+
+    def __exit__(self, *exc):
+        lib().cnuda_conv_set_splitk_policy(self.prev)
 
 
 class halo_conv:

@@ -117,6 +117,13 @@ int cnuda_dcn_set_scatter_margin(int margin);
 int cnuda_dcn_set_offset_regime(int regime);
 int cnuda_dcn_offset_census(const float* offset, int B, int taps, long long HW, unsigned* counts, cnuda_stream_t stream);
 int cnuda_conv_set_halo_policy(int level, int min_tiles);
+/* Split-K of the forward-type convolution GEMMs (forward, stride-1 and parity-class input gradient; csrc/igemm.cuh
+ * igemm_fwd_*splitk_kernel): a call whose pixel x row tiles at the natural row tile number fewer than max_tiles (default
+ * 128: half the chip) and whose K has at least 32 chunks cuts K over grid.y -- partial slabs in the workspace, a fixed-order
+ * reduce with the usual epilogue -- instead of shrinking the row tile.  max_tiles 0 = never; < 0 restores the default.
+ * Returns the previous value.  Speed only: results differ by summation order (blocked over the splits).  CNUDA_SPLITK=0
+ * disables it for the process. */
+int cnuda_conv_set_splitk_policy(int max_tiles);
 
 /* ------------------------------------------------------------------------
  * Detection decode -- replaces backends/decode.py:35-76 (decode_detection),

@@ -264,9 +264,8 @@ def test_full_size_1x1_convolutions_match_fp64_and_repeat(B, C, S, Co):
 
 def test_full_size_strided_convolution_matches_fp64():
     """3x3 stride 2, 64 -> 128 from 128 x 128 to 64 x 64, B = 32 (level3.tree1.tree1.conv1 of the benched step): the
-    input gradient runs one launch per input-pixel parity class on the wave-specialised 64-row tile
-    (`igemm_fwd_ws_kernel<64, ConvDgradClassBufLoader>`, 36 launches per benched step and no value test before round 4's
-    kernel-coverage manifest), against the CPU's fp64 convolution; forward and weight gradient ride along."""
+    input gradient runs its four input-pixel parity classes as ONE launch on the wave-specialised 64-row tile
+    (`igemm_fwd_ws_classes_kernel<64>`: blockIdx.y = class; rounds 2-5: one launch per class), against the CPU's fp64 convolution; forward and weight gradient ride along."""
     import torch.nn.functional as F
     import hip_runtime as hr
     from hip_runtime import ops
@@ -285,7 +284,7 @@ def test_full_size_strided_convolution_matches_fp64():
     names = sorted(short(n) for n in log.names)
     import os
     if not any(os.environ.get(v) == '0' for v in ('CNUDA_BUF', 'CNUDA_WS')):
-        assert any(n.startswith('igemm_fwd_ws_kernel<64, ConvDgradClassBufLoader') for n in names), names
+        assert 'igemm_fwd_ws_classes_kernel<64>' in names, names       # (round 6: the four parity classes in one launch)
     for name, got, want in (('y', y.detach(), want_y.detach()), ('gx', xx.grad, xr.grad), ('gw', ww.grad, wr.grad)):
         scale = want.abs().max().item()
         assert (got.double().cpu() - want).abs().max().item() <= 1e-4 * scale, name

@@ -74,6 +74,13 @@ CONV_CASES = {
     'offset27_w256': (1, 16, 8, 256, 27, 3, 1, 1, True, -1.0),
     'offset27_w192': (1, 16, 12, 192, 20, 3, 1, 1, True, -1.0),
     'l1_s2_w320': (1, 16, 16, 640, 32, 3, 2, 1, True, -1.0),
+    # round 6, split-K (igemm_fwd_*splitk_kernel + splitk_reduce_kernel): few pixel x row tiles, long K -- the ADVENT
+    # discriminator's 4 x 4 / stride 2 layers on 20 x 20 and 10 x 10 maps (forward on the 128-row tile, parity-class input
+    # gradient), the 512 -> 27 offset convolution of the 16 x 16 level (32-row tile), a 3 x 3 with 64 input rows (64-row tile)
+    'sk_disc_256to512': (4, 256, 20, 20, 512, 4, 2, 1, True, 0.2),
+    'sk_disc_128to256': (4, 128, 40, 40, 256, 4, 2, 1, True, 0.2),
+    'sk_512to27_16sq': (8, 512, 16, 16, 27, 3, 1, 1, True, -1.0),
+    'sk_256to64_8sq': (3, 256, 8, 8, 64, 3, 1, 1, False, 0.0),
 }
 
 
@@ -99,6 +106,35 @@ def test_conv2d_fwd_bwd(name):
     _close(dw.grad, w.grad)
     if bias:
         _close(db.grad, b.grad)
+
+
+@pytest.mark.parametrize('name', ['sk_disc_256to512', 'sk_512to27_16sq', 'sk_256to64_8sq'])
+def test_split_k_takes_the_starved_long_k_convolutions(name):
+    """The `sk_*` cases of test_conv2d_fwd_bwd hold the values; here: the launch plan really cuts K for them (forward and
+    input gradient), `hr.splitk(0)` restores pick_bm's small-tile plan, and the two plans agree to summation order."""
+    import hip_runtime as hr
+    from hip_runtime import ops
+    from test_zz_kernel_coverage import short
+    B, C, H, W, Co, k, s, p, bias, act = CONV_CASES[name]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g).to(DEV)
+    w = (torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5).to(DEV)
+    gy = None
+    res = []
+    for max_tiles in (128, 0):
+        xx, ww = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        with hr.splitk(max_tiles), hr.launch_log() as log:
+            y = ops.conv2d(xx, ww, None, s, p, act)
+            gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(6)).to(DEV) if gy is None else gy
+            y.backward(gy)
+        names = sorted(short(n) for n in log.names)
+        print(max_tiles, names)
+        if hr.get_matrix_mode() == 0 and os.environ.get('CNUDA_SPLITK') != '0' and os.environ.get('CNUDA_BUF') != '0':
+            assert any('splitk_kernel' in n for n in names) == (max_tiles > 0), names
+            assert any(n.startswith('splitk_reduce_kernel') for n in names) == (max_tiles > 0), names
+        res.append((y.detach(), xx.grad, ww.grad))
+    for a, b in zip(*res):
+        _close(a, b, 2e-5)
 
 
 @pytest.mark.parametrize('relu,res', [(False, False), (True, False), (True, True), (False, True)])
