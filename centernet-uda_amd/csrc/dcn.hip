@@ -1518,6 +1518,7 @@ int pick_bm(int M, long long N) {
 constexpr int kFusedMinTilesDefault = 512;
 int g_fused_min_tiles = kFusedMinTilesDefault;      // cnuda_dcn_set_fused_min_tiles (tests)
 int g_scatter_margin = 0;                           // cnuda_dcn_set_scatter_margin (measurements, tests); 0: by regime
+int g_walk_tc = 0;                                  // cnuda_dcn_set_walk_tile (measurements); 0: by the map width
 // Offset regime of the NEXT forward / backward call (cnuda_dcn_set_offset_regime; the host layer sets it per call from a
 // census of the layer's own offsets, libs/DCNv2/dcn_v2.py).  A freshly initialised model samples within a fraction of a
 // pixel of the regular grid; a trained CenterNet has learned offsets of pixels.  The kernels that keep a window on chip
@@ -1575,6 +1576,7 @@ DcnPlan make_plan(const DcnGeom& g) {
     // col2im tile: 256 output pixels, lanes along x
     q.TC = 64;
     while (q.TC > 16 && q.TC / 2 >= g.Wo) q.TC >>= 1;
+    if (g_walk_tc == 16 || g_walk_tc == 32 || g_walk_tc == 64) q.TC = g_walk_tc;     // (measurements: cnuda_dcn_set_walk_tile)
     q.TR = 256 / q.TC;
     q.tc_shift = q.TC == 64 ? 6 : (q.TC == 32 ? 5 : 4);
     q.tiles_y = ceil_div(g.Ho, q.TR);
@@ -1603,6 +1605,11 @@ using namespace cnuda;
 extern "C" int cnuda_dcn_set_scatter_margin(int margin) {
     const int prev = g_scatter_margin;
     g_scatter_margin = margin < 1 ? 0 : (margin > 8 ? 8 : margin);
+    return prev;
+}
+extern "C" int cnuda_dcn_set_walk_tile(int tile_cols) {
+    const int prev = g_walk_tc;
+    g_walk_tc = tile_cols;
     return prev;
 }
 extern "C" int cnuda_dcn_set_offset_regime(int regime) {

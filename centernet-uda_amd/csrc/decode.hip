@@ -17,7 +17,6 @@
 namespace cnuda {
 namespace {
 
-constexpr int kThreads = 1024;
 constexpr int kMaxK = 1024;
 constexpr int kSelSlack = 64;
 
@@ -174,7 +173,7 @@ __device__ void block_topk(KeyAt key_at, int n, int K, int KP, SelectScratch& s)
         __syncthreads();
     }
     // the selected keys (exactly K of them: keys are unique) sit unordered in s.sel[0..K), zeros behind them
-    static_assert(kMaxK <= NT, "one key per thread at least");
+    static_assert(kMaxK <= kSortKeys * NT, "rank_sort_desc holds kSortKeys keys per thread");
     const int cnt = min(s.out_count, KP);
     rank_sort_prepare<NT>(s, cnt);
     __syncthreads();
@@ -569,18 +568,32 @@ __device__ __forceinline__ bool seed_select(KeyAt key_at, int C, int K, int* __r
 // Maps with fewer than K positive scores or a plateau at the threshold (a trained model's background is clamped to
 // exactly 1e-4: whole regions survive the NMS) write the NMS'd score bits over the raw plane and run lds_plane_topk;
 // planes that do not fit the LDS run block_topk with the NMS recomputed from the L1/L2-resident plane.
+// Round 6 -- SUB-PLANES: with few planes (the reference's 6 classes x 16 images = 96 workgroups on 256 CUs) a plane is cut
+// into `nsub` bands of `sub_rows` rows, one workgroup each: the band's rows plus the row above and below it (the NMS
+// window's reach: pad == 1) go to LDS as a small plane of its own, the halo rows' pixels are not candidates (score 0 on
+// the fast path, the lowest possible order image on the general one), and every band leaves ITS K best with their pixel
+// indices in the whole plane.  The union holds the plane's K best; stage 2 sees nsub lists per class, in band order --
+// position (class, band, rank) still orders ties by class, then pixel index, as before.
 constexpr int kPlaneThreads = 1024;
 constexpr int kPlanePer = 32;        // pixels per thread held in registers
 __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* __restrict__ heat,
-                                                                   uint64_t* __restrict__ cand, int H, int W, int K,
-                                                                   int KP, int pad, int lds_plane) {
+                                                                   uint64_t* __restrict__ cand, int Hfull, int W, int K,
+                                                                   int KP, int pad, int lds_plane, int nsub, int sub_rows) {
     __shared__ SelectScratch s;
     __shared__ int hist[kBins];                       // later: the per-wave histograms of lds_plane_topk
     __shared__ int wave_tot[2 * (kPlaneThreads / 64)];
     extern __shared__ float plane_lds[];              // [HW] the raw plane, then (general path) its NMS'd score bits
     const int tid = threadIdx.x, lane = tid & 63;
+    // band `sub` of plane `pl`: rows [r0, r1) + the halo row above (has_top) / below (has_bot); H, HW: the band's own
+    // small plane, halo rows included; goff: pixel index in the whole plane = index in the band's plane + goff
+    const int pl = nsub > 1 ? (int)blockIdx.x / nsub : (int)blockIdx.x, sub = nsub > 1 ? (int)blockIdx.x - pl * nsub : 0;
+    const int r0 = sub * sub_rows, r1 = min(Hfull, r0 + sub_rows);
+    const int has_top = (nsub > 1 && r0 > 0) ? 1 : 0, has_bot = (nsub > 1 && r1 < Hfull) ? 1 : 0;
+    const int H = nsub > 1 ? (r1 - r0) + has_top + has_bot : Hfull;
     const int HW = H * W;
-    const float* plane = heat + (size_t)blockIdx.x * HW;
+    const int goff = (r0 - has_top) * W;
+    const int real_lo = has_top * W, real_hi = HW - has_bot * W;       // the band's own pixels: [real_lo, real_hi)
+    const float* plane = heat + (size_t)pl * Hfull * W + goff;
     uint64_t* dst = cand + (size_t)blockIdx.x * K;
     if (!lds_plane) {
         block_topk<kPlaneThreads>([&](int i) { return make_key(nms_value(plane, H, W, i / W, i % W, pad), (uint32_t)i); },
@@ -623,6 +636,14 @@ __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* 
                     if (i < HW) o[j] = nms_value(plane_lds, H, W, y, i - y * W, pad);
                 }
             }
+            if (nsub > 1) {            // halo rows are another band's pixels (a quad never straddles rows: W % 4 == 0)
+                const int i0 = quads ? (q * kPlaneThreads + tid) * 4 : 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = quads ? i0 + j : (4 * q + j) * kPlaneThreads + tid;
+                    if (i < real_lo || i >= real_hi) o[j] = 0.0f;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (o[j] > 0.0f) atomicAdd(&hist[__float_as_uint(o[j]) >> 19], 1);
@@ -658,7 +679,7 @@ __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* 
                 for (int j = 0; j < 4; ++j) {
                     const float x = v[4 * q + j];
                     const unsigned long long m = __ballot(x >= edge);
-                    if (x >= edge) s.sel[at + __popcll(m & below)] = make_key(x, (uint32_t)pixel(4 * q + j));
+                    if (x >= edge) s.sel[at + __popcll(m & below)] = make_key(x, (uint32_t)(pixel(4 * q + j) + goff));
                     at += __popcll(m);
                 }
             }
@@ -671,19 +692,25 @@ __global__ __launch_bounds__(kPlaneThreads) void plane_topk_kernel(const float* 
 #pragma unroll
     for (int u = 0; u < kPlanePer; ++u) {
         const int pix = pixel(u);
-        if (pix < HW) reinterpret_cast<uint32_t*>(plane_lds)[pix] = float_order_bits(v[u]);
+        // (a halo pixel: order image 0, below every score's -- never selected while the band has K pixels of its own)
+        if (pix < HW) reinterpret_cast<uint32_t*>(plane_lds)[pix] = (pix >= real_lo && pix < real_hi) ? float_order_bits(v[u]) : 0u;
     }
     __syncthreads();
     static_assert(sizeof(hist) >= (kPlaneThreads / 64) * 256 * sizeof(int), "the per-wave histograms fit");
     lds_plane_topk<kPlaneThreads>(reinterpret_cast<const uint32_t*>(plane_lds), HW, K, KP, s, hist, wave_tot);
-    for (int i = tid; i < K; i += kPlaneThreads) dst[i] = s.sel[i];
+    // (low word = ~index: index + goff <-> low word - goff; the order of the keys is unchanged)
+    for (int i = tid; i < K; i += kPlaneThreads) dst[i] = s.sel[i] - (uint64_t)(uint32_t)goff;
 }
 
-// Stage 2: per image, top-K over C*K candidates + box assembly.
+// Stage 2: per image, top-K over C*K candidates + box assembly.  kThreads: 1,024; the 256- / 512-thread instances exist for the
+// measurement of round 6 (cnuda_decode_set_stage2_threads; 900 candidates, B = 16: 8.98 / 7.01 / 7.42 us with 256 / 512 /
+// 1,024 threads -- the kernel waits for its chain of dependent phases, not for its barriers: profiles/r6_decode_bands_ab.txt).
+template <int kThreads>
 __global__ __launch_bounds__(kThreads) void merge_decode_kernel(
     const uint64_t* __restrict__ cand, const float* __restrict__ wh, const float* __restrict__ reg,
     float* __restrict__ dets, int64_t* __restrict__ inds,
-    int C, int H, int W, int K, int KP, int wh_ch, int rotated, int lds_cand) {
+    int C /* candidate lists per image: classes x bands */, int H, int W, int K, int KP, int wh_ch, int rotated, int lds_cand,
+    int nsub) {
     __shared__ SelectScratch s;
     extern __shared__ uint64_t cand_lds[];            // [C*K] this image's candidates (0 bytes: too many, read in place)
     const int b = blockIdx.x;
@@ -724,14 +751,14 @@ __global__ __launch_bounds__(kThreads) void merge_decode_kernel(
         static_assert(kBins2 >= 2 * kThreads, "the lists' counts and places fit the histogram");
         // few candidates (the reference's 6 classes: 900): one histogram pass is cheaper than two sorts (6.8 vs 8.4 us);
         // many (80 classes: 12,000): the seed bound spares the passes over all of them (17.5 -> 13.6 us)
-        const bool seeded = n > 4 * kThreads && seed_select<kThreads>(key2, C, K, hist, hist + kThreads, wave_tot, s);
+        const bool seeded = n > 4096 && seed_select<kThreads>(key2, C, K, hist, hist + kThreads, wave_tot, s);
         if (!seeded && !merge_select<kThreads>(key2, n, K, hist, wave_tot, s)) block_topk<kThreads>(key2, n, K, KP, s);
     }
     const int ncol = rotated ? 7 : 6;
     for (int k = threadIdx.x; k < K; k += kThreads) {
         const uint64_t key = s.sel[k];
         const uint32_t pos = 0xffffffffu - (uint32_t)(key & 0xffffffffu);
-        const int cls = (int)(pos / (uint32_t)K);
+        const int cls = (int)(pos / (uint32_t)(K * nsub));
         const float score = order_bits_float((uint32_t)(key >> 32));
         const uint32_t idx = 0xffffffffu - (uint32_t)(cb[pos] & 0xffffffffu);
         float xs = (float)(int)(idx % (uint32_t)W);
@@ -772,6 +799,25 @@ __global__ __launch_bounds__(kThreads) void merge_decode_kernel(
     else body(cb);
 }
 
+constexpr int kMaxSub = 4;
+// bands per plane (plane_topk_kernel): while the planes alone leave CUs idle -- twice the workgroups per step, as long as
+// every band keeps >= 16 rows, >= 2048 pixels and >= 4 K pixels of its own (the general path never runs out of real
+// pixels) and the grid stays within two workgroups per CU.  3x3 window and 4-aligned rows only (the halo is one row).
+// Measured (round 6, B = 16, C = 6, 128 x 128, rocprofv3, profiles/r6_decode_bands_ab.txt): stage 1 takes 12.1 / 11.0 / 15.1 us
+// with 1 / 2 / 4 bands -- the kernel is a chain of latency-bound phases (barriers, dependent LDS round trips), NOT bound by
+// its pixels: half the pixels save 9 %, and four bands put two 1,024-thread workgroups on a CU, each 1.4x slower.  Default 2.
+constexpr int kDefaultSub = 2;
+int g_decode_stage2_threads = 0;     // CNUDA_DECODE_STAGE2_THREADS (measurements): 0 = by the candidate count
+int g_decode_max_sub = kDefaultSub;  // cnuda_decode_set_max_bands (tests, measurements)
+int pick_bands(int planes, int H, int W, int K, int pad, bool lds_plane) {
+    int s = 1;
+    if (!lds_plane || pad != 1 || (W & 3)) return 1;
+    while (s * 2 <= g_decode_max_sub && planes * s * 2 <= 512 && H % (s * 2) == 0 && H / (s * 2) >= 16 &&
+           (long long)(H / (s * 2)) * W >= 2048 && (long long)(H / (s * 2)) * W >= 4ll * K)
+        s *= 2;
+    return s;
+}
+
 int next_pow2(int v) {
     int p = 2;
     while (p < v) p <<= 1;
@@ -783,9 +829,20 @@ int next_pow2(int v) {
 
 using namespace cnuda;
 
+extern "C" int cnuda_decode_set_stage2_threads(int threads) {
+    const int prev = g_decode_stage2_threads;
+    g_decode_stage2_threads = (threads == 256 || threads == 512 || threads == 1024) ? threads : 0;
+    return prev;
+}
+extern "C" int cnuda_decode_set_max_bands(int max_bands) {
+    const int prev = g_decode_max_sub;
+    g_decode_max_sub = max_bands < 1 ? kDefaultSub : (max_bands > kMaxSub ? kMaxSub : max_bands);
+    return prev;
+}
+
 extern "C" size_t cnuda_decode_workspace_bytes(int B, int C, int H, int W, int K) {
     (void)H; (void)W;
-    return (size_t)B * C * K * sizeof(uint64_t) + 256;     // stage-1 candidates
+    return (size_t)B * C * K * kMaxSub * sizeof(uint64_t) + 256;     // stage-1 candidates (up to kMaxSub bands per plane)
 }
 
 extern "C" int cnuda_nms(const float* heat, float* out, int B, int C, int H, int W, int nms_size,
@@ -822,16 +879,28 @@ extern "C" int cnuda_decode_detection(const float* heat, const float* wh, const 
     const size_t bits_bytes = (size_t)H * W * sizeof(uint32_t);
     const int lds_plane = bits_bytes <= 128 * 1024 ? 1 : 0;
     CNUDA_REQUIRE(raise_dynamic_lds(reinterpret_cast<const void*>(plane_topk_kernel), 128 * 1024, 128 * 1024) &&
-                      raise_dynamic_lds(reinterpret_cast<const void*>(merge_decode_kernel), 112 * 1024, 112 * 1024),
+                      raise_dynamic_lds(reinterpret_cast<const void*>(merge_decode_kernel<1024>), 112 * 1024, 112 * 1024) &&
+                      raise_dynamic_lds(reinterpret_cast<const void*>(merge_decode_kernel<512>), 112 * 1024, 112 * 1024) &&
+                      raise_dynamic_lds(reinterpret_cast<const void*>(merge_decode_kernel<256>), 112 * 1024, 112 * 1024),
                   "cnuda_decode_detection: dynamic LDS");
-    CNUDA_LAUNCH(plane_topk_kernel, dim3(B * C), dim3(kPlaneThreads), lds_plane ? bits_bytes : 0, st, heat, cand,
-                       H, W, K, KP, pad, lds_plane);
+    const int nsub = pick_bands(B * C, H, W, K, pad, lds_plane != 0), sub_rows = H / nsub;
+    const size_t band_bytes = nsub > 1 ? (size_t)(sub_rows + 2) * W * sizeof(uint32_t) : bits_bytes;
+    CNUDA_LAUNCH(plane_topk_kernel, dim3(B * C * nsub), dim3(kPlaneThreads), lds_plane ? band_bytes : 0, st, heat, cand,
+                       H, W, K, KP, pad, lds_plane, nsub, sub_rows);
     int rc = check_launch("cnuda_decode_detection(stage 1)");
     if (rc) return rc;
     // stage 2 keeps an image's C*K candidates in LDS when they fit beside its 42 KB of static arrays
-    const size_t cand_bytes = (size_t)C * K * sizeof(uint64_t);
+    const size_t cand_bytes = (size_t)C * nsub * K * sizeof(uint64_t);
     const int lds_cand = cand_bytes <= 112 * 1024 ? 1 : 0;
-    CNUDA_LAUNCH(merge_decode_kernel, dim3(B), dim3(kThreads), lds_cand ? cand_bytes : 0, st,
-                       cand, wh, reg, dets, inds, C, H, W, K, KP, wh_ch, rotated ? 1 : 0, lds_cand);
+    const int small2 = g_decode_stage2_threads ? g_decode_stage2_threads : 1024;      // (256 / 512: measured no faster, see above)
+    if (small2 == 256)
+        CNUDA_LAUNCH(merge_decode_kernel<256>, dim3(B), dim3(256), lds_cand ? cand_bytes : 0, st,
+                           cand, wh, reg, dets, inds, C * nsub, H, W, K, KP, wh_ch, rotated ? 1 : 0, lds_cand, nsub);
+    else if (small2 == 512)
+        CNUDA_LAUNCH(merge_decode_kernel<512>, dim3(B), dim3(512), lds_cand ? cand_bytes : 0, st,
+                           cand, wh, reg, dets, inds, C * nsub, H, W, K, KP, wh_ch, rotated ? 1 : 0, lds_cand, nsub);
+    else
+        CNUDA_LAUNCH(merge_decode_kernel<1024>, dim3(B), dim3(1024), lds_cand ? cand_bytes : 0, st,
+                           cand, wh, reg, dets, inds, C * nsub, H, W, K, KP, wh_ch, rotated ? 1 : 0, lds_cand, nsub);
     return check_launch("cnuda_decode_detection(stage 2)");
 }

@@ -60,6 +60,8 @@ _WS = [_P, c_size_t, _P]          # workspace, workspace_bytes, stream
 class _Sig:
     """restype, argtypes for every exported symbol (mirrors include/centernet_uda_hip.h)."""
     cnuda_decode_workspace_bytes = (c_size_t, [_I] * 5)
+    cnuda_decode_set_max_bands = (_I, [_I])
+    cnuda_decode_set_stage2_threads = (_I, [_I])
     cnuda_decode_detection = (_I, [_P] * 5 + [_I] * 8 + _WS)
     cnuda_nms = (_I, [_P, _P] + [_I] * 5 + [_P])
     cnuda_dcn_v2_workspace_bytes = (c_size_t, [_I] * 14)
@@ -140,6 +142,7 @@ class _Sig:
     cnuda_dcn_set_fused_min_tiles = (_I, [_I])
     cnuda_dcn_set_scatter_margin = (_I, [_I])
     cnuda_dcn_set_offset_regime = (_I, [_I])
+    cnuda_dcn_set_walk_tile = (_I, [_I])
     cnuda_dcn_offset_census = (_I, [_P, _I, _I, _LL, _P, _P])
     cnuda_conv_set_halo_policy = (_I, [_I, _I])
     cnuda_conv_set_splitk_policy = (_I, [_I])

@@ -109,6 +109,9 @@ int cnuda_dcn_set_fused_min_tiles(int min_tiles);
  * previous value.  Samples further out than this are strays (global atomics): a wider window for models whose offsets are
  * pixels, at fewer workgroups per CU.  Measurements and tests; results do not depend on it beyond summation order. */
 int cnuda_dcn_set_scatter_margin(int margin);
+/* columns of the data-gradient walk's pixel tile (16, 32 or 64; 256 pixels per tile; 0 = by the map width, the default).
+ * Returns the previous value.  Measurements only; results do not depend on it beyond summation order. */
+int cnuda_dcn_set_walk_tile(int tile_cols);
 /* Offset regime of the next cnuda_dcn_v2_* calls (process-wide, the host layer sets it per call): bit 0 -> the data-gradient
  * walk's window takes a margin of 4 cells (many samples beyond +-2 px), bit 1 -> the forward takes the gathering loader
  * instead of the LDS-window kernel (many samples beyond +-3 px).  Returns the previous value.  Speed only: results do not
@@ -140,6 +143,12 @@ int cnuda_conv_set_splitk_policy(int max_tiles);
  * class ascending, then spatial index ascending.  1 <= K <= min(H*W, 1024).
  * nms_size must be odd (reference default 3).
  * ---------------------------------------------------------------------- */
+/* Stage 1 cuts a plane into up to `max_bands` (1, 2 or 4; default 2; < 1 restores it) bands of rows, one workgroup each, when
+ * the planes alone would leave CUs idle (B * C * bands <= 512).  Returns the previous value.  Speed only: the result is the
+ * same bit for bit (tests/test_gpu_decode.py runs every case with 1, 2 and 4). */
+int cnuda_decode_set_max_bands(int max_bands);
+/* threads of stage 2's workgroup: 256, 512 or 1024; 0 = the default (1,024).  Returns the previous value.  Measurements; the result does not depend on it. */
+int cnuda_decode_set_stage2_threads(int threads);
 size_t cnuda_decode_workspace_bytes(int B, int C, int H, int W, int K);
 int cnuda_decode_detection(const float* heat, const float* wh, const float* reg,
                            float* dets, int64_t* inds,

@@ -19,13 +19,18 @@ from libs.DCNv2.dcn_v2 import DCN  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--offsets', default='small', choices=['zero', 'small', 'sigma1', 'sigma1.4', 'sigma2'])
 ap.add_argument('--margin', type=int, default=0, help='cnuda_dcn_set_scatter_margin for the run (0: default)')
+ap.add_argument('--walk-tile', type=int, default=0, help='cnuda_dcn_set_walk_tile for the run (0: default)')
 ap.add_argument('--iters', type=int, default=1)
 ap.add_argument('--time', action='store_true')
 args = ap.parse_args()
 torch.manual_seed(0)
 if args.margin:
     hr.lib().cnuda_dcn_set_scatter_margin(args.margin)
+if args.walk_tile:
+    hr.lib().cnuda_dcn_set_walk_tile(args.walk_tile)
 SHAPES = [(32, 64, 128, 64), (32, 128, 64, 64)]
+if os.environ.get('DCN_LAYER_SHAPES') == 'maps640':         # configs[4]: the 160- / 80-wide maps of a 640 x 640 input
+    SHAPES = [(32, 64, 160, 64), (32, 128, 80, 64)]
 if os.environ.get('DCN_LAYER_SHAPES') == 'small_maps':      # the layers that take the sample + GEMM pair / the gathering loader
     SHAPES = [(32, 256, 32, 128), (32, 256, 32, 256), (32, 512, 16, 256), (32, 128, 64, 128)]
 for (B, C, S, Co) in SHAPES:

@@ -11,6 +11,12 @@ import torch  # noqa: E402
 from backends.decode import decode_detection  # noqa: E402
 
 B, K = 16, 150
+if os.environ.get('CNUDA_DECODE_STAGE2_THREADS'):
+    import hip_runtime as hr
+    hr.lib().cnuda_decode_set_stage2_threads(int(os.environ['CNUDA_DECODE_STAGE2_THREADS']))
+if os.environ.get('CNUDA_DECODE_BANDS'):      # A/B of the row bands of stage 1 (cnuda_decode_set_max_bands)
+    import hip_runtime as hr
+    hr.lib().cnuda_decode_set_max_bands(int(os.environ['CNUDA_DECODE_BANDS']))
 cases = [(int(sys.argv[1]), int(sys.argv[2]))] if len(sys.argv) > 2 else [(6, 128), (80, 128), (6, 160), (80, 160)]
 for C, H in cases:
     g = torch.Generator(device='cpu').manual_seed(7 + C + H)

@@ -239,3 +239,55 @@ def test_negative_and_zero_scores_general_path():
     os_, oi, oc, oy, ox = od.topk(x, 40)
     assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(c.cpu().numpy(), oc)
     assert np.array_equal(s.cpu().numpy(), os_)
+
+
+@pytest.mark.parametrize('kind', ['noise128', 'trained128', 'trained160', 'ties128', 'negative64', 'coco80_64'])
+def test_row_bands_give_the_same_detections_bit_for_bit(kind):
+    """Round 6: with few planes stage 1 cuts a plane into 2 or 4 bands of rows, one workgroup each (halo rows from the
+    neighbouring bands, stage 2 merges classes x bands lists).  Every band count must give the detections of the
+    one-workgroup-per-plane form bit for bit -- and those the oracle's -- on noise maps (fast path), trained-like maps
+    (plateaus and fewer than K positives per band: the general path with halo pixels below every score), heavily tied
+    scores (ties across bands resolve by pixel index), raw logits, and a class count that leaves no room for bands."""
+    import hip_runtime as hr
+    from backends import decode as hd
+    rs = np.random.RandomState(len(kind) * 7 + 1)
+    if kind == 'noise128':
+        B, C, H, W, K = 3, 6, 128, 128, 150
+        heat = np.clip(1 / (1 + np.exp(-(rs.standard_normal((B, C, H, W)) - 2.19))), 1e-4, 1 - 1e-4).astype(np.float32)
+        wh = rs.uniform(1, 50, (B, 2, H, W)).astype(np.float32)
+    elif kind == 'trained128':
+        B, C, H, W, K = 2, 6, 128, 128, 150
+        heat, wh, _ = _trained_like_map(B, C, H, W, 5)
+    elif kind == 'trained160':
+        B, C, H, W, K = 2, 3, 160, 160, 150
+        heat, wh, _ = _trained_like_map(B, C, H, W, 6, peaks=(100, 400))
+    elif kind == 'ties128':
+        B, C, H, W, K = 2, 4, 128, 128, 150
+        heat = (np.round(np.clip(1 / (1 + np.exp(-(rs.standard_normal((B, C, H, W)) - 2))), 1e-4, 1 - 1e-4) * 16) / 16).astype(np.float32)
+        wh = rs.uniform(1, 50, (B, 2, H, W)).astype(np.float32)
+    elif kind == 'negative64':
+        B, C, H, W, K = 2, 3, 64, 64, 100
+        heat = (rs.standard_normal((B, C, H, W)) * 3).astype(np.float32)
+        heat[:, :, 20:30] = 0.0
+        wh = rs.uniform(1, 50, (B, 2, H, W)).astype(np.float32)
+    else:
+        B, C, H, W, K = 8, 80, 64, 64, 100                   # 640 planes: no bands
+        heat = rs.uniform(1e-4, 0.99, (B, C, H, W)).astype(np.float32)
+        wh = rs.uniform(1, 50, (B, 2, H, W)).astype(np.float32)
+    reg = rs.uniform(0, 1, (B, 2, H, W)).astype(np.float32)
+    L = hr.lib()
+    res = []
+    for bands in (1, 2, 4):
+        prev = L.cnuda_decode_set_max_bands(bands)
+        try:
+            dets, inds = hd._run(T(heat), T(wh), T(reg), K, False, 3)
+            torch.cuda.synchronize()
+        finally:
+            L.cnuda_decode_set_max_bands(prev)
+        res.append((dets.cpu().numpy(), inds.cpu().numpy()))
+    for d, i in res[1:]:
+        assert np.array_equal(i, res[0][1]) and np.array_equal(d, res[0][0])
+    want, winds, wcls = od.decode_detection(heat, wh, reg, K=K, return_inds=True)
+    assert np.array_equal(res[2][1], winds)
+    assert np.array_equal(res[2][0][..., 5].astype(np.int32), wcls)
+    np.testing.assert_allclose(res[2][0], want, rtol=1e-6, atol=1e-5)

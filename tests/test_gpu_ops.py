@@ -306,7 +306,16 @@ def test_head_pair_is_one_tape_node_with_the_two_layers_values(B, C, Ch, Co, H, 
     unfused = [xb.grad] + [p.grad for p in head.parameters()]
     xr = x.detach().cpu().requires_grad_(True)
     ps = [p.detach().cpu().requires_grad_(True) for p in head.parameters()]
-    yr = F.conv2d(F.relu(F.conv2d(xr, ps[0], ps[1], padding=k // 2)), ps[2], ps[3])
+    # The ReLU's gate is a discontinuity: a hidden value within rounding noise of zero may pass on one side and not on the
+    # other (a different summation order -- split-K since round 6 -- moves one of the 196,608 values of the 64 -> 256 case
+    # across).  The reference therefore takes the gate from the HIP hidden map, after checking that the two gates differ
+    # only where the pre-activation is zero to 1e-5.
+    pre = F.conv2d(xr, ps[0], ps[1], padding=k // 2)
+    with torch.no_grad():
+        gate = (head[0](x) > 0).cpu()
+        differ = gate != (pre > 0)
+        assert int(differ.sum()) <= 4 and (pre[differ].abs() < 1e-5).all(), (int(differ.sum()), pre[differ])
+    yr = F.conv2d(pre * gate, ps[2], ps[3])
     yr.backward(gy.cpu())
     for a, b, r in zip(fused, unfused, [xr.grad] + [p.grad for p in ps]):
         _close(a, b, 1e-5)
