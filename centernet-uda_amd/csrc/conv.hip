@@ -677,7 +677,7 @@ struct SplitK {
     int bm = 0, z = 1, split_k = 0;          // row tile, splits, K elements per split (a multiple of the chunk)
     bool on() const { return z > 1; }
 };
-int g_splitk_max_tiles = 128;                // cnuda_conv_set_splitk_policy (tests, measurements)
+int g_splitk_max_tiles = getenv("CNUDA_SPLITK_TILES") ? atoi(getenv("CNUDA_SPLITK_TILES")) : 128;   // cnuda_conv_set_splitk_policy (tests, measurements)
 SplitK pick_splitk(int M, long long N, int Kp) {
     static const bool enabled = !(getenv("CNUDA_SPLITK") && getenv("CNUDA_SPLITK")[0] == '0');
     SplitK s;

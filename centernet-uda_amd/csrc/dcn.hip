@@ -1576,6 +1576,11 @@ DcnPlan make_plan(const DcnGeom& g) {
     // col2im tile: 256 output pixels, lanes along x
     q.TC = 64;
     while (q.TC > 16 && q.TC / 2 >= g.Wo) q.TC >>= 1;
+    // (round 6) a row width that 64-column tiles cover with a half-empty last tile -- 160 = 2.5 x 64, 80 = 1.25 x 64: the maps of
+    // a 640 x 640 input -- takes 32-column tiles when those pad less: idle lanes cost the walk whole steps.  Measured, B = 32:
+    // 64 -> 64 at 160 x 160 1861 -> 1702 us, 128 -> 64 at 80 x 80 1177 -> 1071 us (profiles/r6_dcn_walk_tile.txt), although the
+    // 32-column tile ranks colliding lanes through the claim map instead of three DPP shifts (two rows per wave step).
+    if (q.TC == 64 && round_up(g.Wo, 32) < round_up(g.Wo, 64)) q.TC = 32;
     if (g_walk_tc == 16 || g_walk_tc == 32 || g_walk_tc == 64) q.TC = g_walk_tc;     // (measurements: cnuda_dcn_set_walk_tile)
     q.TR = 256 / q.TC;
     q.tc_shift = q.TC == 64 ? 6 : (q.TC == 32 ? 5 : 4);
@@ -1988,6 +1993,28 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
             const int geo_blocks = q.fused_consumers ? stream_grid((long long)B * q.T * HoWo, 256) : 0;
             DcnPrepParams pp{g, weight, offset, mask, wt, q.fused_consumers ? geo : nullptr, wt_blocks};
             CNUDA_LAUNCH(dcn_prep_kernel, dim3(wt_blocks + geo_blocks), dim3(256), 0, st, pp);
+        }
+        // Image chunks (measurement, CNUDA_DCN_BWD_CHUNK = images per chunk): column-gradient GEMM and walk alternate over
+        // chunks of the batch, the chunk's dcol written and read back while it is still in the Infinity Cache
+        static const int chunk_env = getenv("CNUDA_DCN_BWD_CHUNK") ? atoi(getenv("CNUDA_DCN_BWD_CHUNK")) : 0;
+        if (q.fused_consumers && chunk_env > 0 && chunk_env < B) {
+            CNUDA_REQUIRE(raise_dynamic_lds(reinterpret_cast<const void*>(&dcn_bwd_data_kernel), q.col2im_lds),
+                          "cnuda_dcn_v2_backward: dynamic LDS");
+            for (int b0 = 0; b0 < B; b0 += chunk_env) {
+                const int nb = std::min(chunk_env, B - b0);
+                if (int rc = cnuda_conv2d_forward(grad_output + (size_t)b0 * Cout * HoWo, wt, nullptr, dcol, nb, Cout, g.Ho, g.Wo,
+                                                  q.T * C, 1, 1, 1, 1, 0, 0, -1.0f, gemm_ws, q.gemm_bytes, stream))
+                    return rc;
+                DcnBwdDataParams p{g, input + (size_t)b0 * C * H * W, dcol, geo + (size_t)b0 * q.T * HoWo,
+                                   grad_input + (size_t)b0 * C * H * W, grad_offset + (size_t)b0 * 2 * q.T * HoWo,
+                                   grad_mask + (size_t)b0 * q.T * HoWo, q.TR, q.TC, q.tc_shift,
+                                   q.tiles_y, q.tiles_x, q.ncg, q.WSZmax, q.claim_sz, q.margin, q.fused_split};
+                const int n_wg = nb * q.tiles_y * q.tiles_x * q.fused_split;
+                ProfScope scope(st, 3);
+                scope.name("dcn_bwd_data_kernel");
+                CNUDA_LAUNCH(dcn_bwd_data_kernel, dim3(n_wg), dim3(512), q.col2im_lds, st, p, n_wg);
+            }
+            return check_launch("cnuda_dcn_v2_backward(data, chunked)");
         }
         if (int rc = cnuda_conv2d_forward(grad_output, wt, nullptr, dcol, B, Cout, g.Ho, g.Wo, q.T * C, 1, 1, 1, 1, 0,
                                           0, -1.0f, gemm_ws, q.gemm_bytes, stream))

@@ -688,11 +688,43 @@ __device__ __forceinline__ void igemm_fwd_ws_body(
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     __syncthreads();
     int cur = 0;
+#ifdef IG_FOLD
+    // Measurement build only (-DIG_FOLD=n, profiles/experiments/r6_blocked_accumulation.md): the MFMA's k-ordered chain is
+    // cut every n chunks -- the running tile is added into a second accumulator set with rounded adds and cleared -- which
+    // makes the sum blocked like the CPU reference's (oneDNN), at the price of TM x TN x 16 more registers per consumer wave.
+    f32x16 tot[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.0f;
+    int since = 0;
+#endif
     for (int k0 = kb; k0 < ke; k0 += KC) {
         ig_mma_chunk<BM, KC>(As[cur], Bs[cur], acc, wm_off, wn_off, lane);
+#ifdef IG_FOLD
+        if (++since == IG_FOLD) {
+            since = 0;
+#pragma unroll
+            for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.0f; }
+        }
+#endif
         __syncthreads();
         cur ^= 1;
     }
+#ifdef IG_FOLD
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += tot[i][j][r];
+#endif
     if constexpr (SPLITK) {
         ig_store_slab<BM>(slab, acc, Mp, (long long)n_tiles * IG_BN, m0, n0, wm_off, wn_off, lane);
         return;

@@ -45,6 +45,51 @@ MANIFEST = {
     'hwgrad_kernel<8, true>': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[offset27_w40',
     ],
+    # round 6: split-K of the starved long-K forward-type GEMMs, and the parity classes of a strided input gradient in one launch
+    'igemm_fwd_splitk_kernel<32, ConvFwdBufLoader>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[sk_512to27_16sq',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[disc_last',
+    ],
+    'igemm_fwd_ws_splitk_kernel<64, ConvFwdBufLoader, 16>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[sk_256to64_8sq',
+    ],
+    'igemm_fwd_ws_splitk_kernel<128, ConvFwdBufLoader, 16>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[sk_disc_',
+    ],
+    'igemm_fwd_ws_splitk_kernel<64, ConvDgradBufLoader, 16>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[head_relu',
+    ],
+    'igemm_fwd_ws_splitk_kernel<128, ConvDgradBufLoader, 16>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[sk_256to64_8sq',
+    ],
+    'igemm_fwd_ws_splitk_kernel<64, ConvDgradClassBufLoader, 16>': [
+        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
+    ],
+    'igemm_fwd_ws_splitk_kernel<128, ConvDgradClassBufLoader, 16>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[sk_disc_',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[c512',
+    ],
+    'splitk_reduce_kernel<ConvFwdBufLoader>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[sk_',
+    ],
+    'splitk_reduce_kernel<ConvDgradBufLoader>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[sk_256to64_8sq',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[head_relu',
+    ],
+    'splitk_reduce_kernel<ConvDgradClassBufLoader>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[sk_disc_',
+    ],
+    'igemm_fwd_classes_kernel<32>': [
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[s2_even',
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[disc4x4',
+    ],
+    'igemm_fwd_ws_classes_kernel<64>': [
+        'tests/test_gpu_fullsize.py::test_full_size_strided_convolution_matches_fp64[64to128_128sq',
+    ],
+    'igemm_fwd_ws_classes_kernel<128>': [
+        'tests/test_gpu_fullsize.py::test_full_size_strided_convolution_matches_fp64[128to256_64sq',
+    ],
     'hconv_kernel<32, 256, HconvFwd>': [
         'tests/test_gpu_fullsize.py::test_full_size_halo_tile_convolutions_match_fp64[64to27_128sq',
         'tests/test_gpu_fullsize.py::test_full_size_halo_tile_convolutions_match_fp64[128to27_64sq',
@@ -177,11 +222,6 @@ MANIFEST = {
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
         'tests/test_gpu_ops.py::test_head_pair_is_one_tape_node_with_the_two_layers_values',
     ],
-    'igemm_fwd_kernel<32, ConvDgradClassBufLoader, false>': [
-        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
-        'tests/test_gpu_fuzz.py::test_conv2d_random_geometry',
-        'tests/test_gpu_fuzz.py::test_conv_transpose2d_random_geometry',
-    ],
     'igemm_fwd_kernel<32, ConvFwdBufLoader, false>': [
         'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd',
@@ -214,9 +254,6 @@ MANIFEST = {
         'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
         'tests/test_gpu_fullsize.py::test_full_size_3x3_convolution_matches_fp64',
         'tests/test_gpu_resnet.py::test_model_step_resnet18_config0',
-    ],
-    'igemm_fwd_ws_kernel<64, ConvDgradClassBufLoader, 16>': [
-        'tests/test_gpu_fullsize.py::test_full_size_strided_convolution_matches_fp64',
     ],
     'igemm_fwd_ws_kernel<64, ConvFwdBufLoader, 16>': [
         'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',

@@ -262,8 +262,10 @@ def test_full_size_1x1_convolutions_match_fp64_and_repeat(B, C, S, Co):
         assert (got.double() - want).abs().max().item() <= 1e-4 * scale, name
 
 
-def test_full_size_strided_convolution_matches_fp64():
-    """3x3 stride 2, 64 -> 128 from 128 x 128 to 64 x 64, B = 32 (level3.tree1.tree1.conv1 of the benched step): the
+@pytest.mark.parametrize('C,Co,S', [(64, 128, 128), (128, 256, 64)], ids=['64to128_128sq', '128to256_64sq'])
+def test_full_size_strided_convolution_matches_fp64(C, Co, S):
+    """3x3 stride 2, 64 -> 128 from 128 x 128 to 64 x 64 and 128 -> 256 from 64 x 64 to 32 x 32, B = 32 (level3 / level4
+    .tree1.tree1.conv1 of the benched step: the 64- and the 128-row tile of the input gradient): the
     input gradient runs its four input-pixel parity classes as ONE launch on the wave-specialised 64-row tile
     (`igemm_fwd_ws_classes_kernel<64>`: blockIdx.y = class; rounds 2-5: one launch per class), against the CPU's fp64 convolution; forward and weight gradient ride along."""
     import torch.nn.functional as F
@@ -271,9 +273,9 @@ def test_full_size_strided_convolution_matches_fp64():
     from hip_runtime import ops
     from test_zz_kernel_coverage import short
     g = torch.Generator().manual_seed(78)
-    x = torch.randn(32, 64, 128, 128, generator=g)
-    w = torch.randn(128, 64, 3, 3, generator=g) * 0.05
-    gy = torch.randn(32, 128, 64, 64, generator=g)
+    x = torch.randn(32, C, S, S, generator=g)
+    w = torch.randn(Co, C, 3, 3, generator=g) * 0.05
+    gy = torch.randn(32, Co, S // 2, S // 2, generator=g)
     xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
     want_y = F.conv2d(xr, wr, None, 2, 1)
     want_y.backward(gy.double())
@@ -284,7 +286,7 @@ def test_full_size_strided_convolution_matches_fp64():
     names = sorted(short(n) for n in log.names)
     import os
     if not any(os.environ.get(v) == '0' for v in ('CNUDA_BUF', 'CNUDA_WS')):
-        assert 'igemm_fwd_ws_classes_kernel<64>' in names, names       # (round 6: the four parity classes in one launch)
+        assert 'igemm_fwd_ws_classes_kernel<%d>' % C in names, names       # (round 6: the four parity classes in one launch)
     for name, got, want in (('y', y.detach(), want_y.detach()), ('gx', xx.grad, xr.grad), ('gw', ww.grad, wr.grad)):
         scale = want.abs().max().item()
         assert (got.double().cpu() - want).abs().max().item() <= 1e-4 * scale, name
@@ -419,10 +421,10 @@ DCN_LAYERS = {
     '128to64_64sq_one_launch': dict(B=32, C=128, Co=64, S=64, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel']),
     '32to64_100sq': dict(B=8, C=32, Co=64, S=100, kernels=['igemm_fwd_kernel<64, DcnFwdLoaderT<true>']),      # a map the window kernels do not take (100 % 16 != 0)
     # round 6: the maps of a 640 x 640 input (configs[4]) and an odd multiple of 32 -- the window forward on 5 x 32-, 5 x 16- and
-    # 3 x 32-column tiles; the data-gradient walk with a ragged last column tile (160 = 2.5 x 64, 80 = 1.25 x 64)
+    # 3 x 32-column tiles; the data-gradient walk on 8 x 32-pixel tiles (5 x 32 = 160; 3 x 32 = 96 > 80: a ragged last column tile)
     '64to64_160sq': dict(B=2, C=64, Co=64, S=160, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_col2im_kernel', 'dcn_coord_grad_kernel']),
-    '64to64_160sq_one_launch': dict(B=5, C=64, Co=64, S=160, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel']),
-    '128to64_80sq_one_launch': dict(B=16, C=128, Co=64, S=80, kernels=['dcnw_fwd_kernel<64, 16>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel']),
+    '64to64_160sq_one_launch': dict(B=6, C=64, Co=64, S=160, kernels=['dcnw_fwd_kernel<64, 32>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel']),
+    '128to64_80sq_one_launch': dict(B=18, C=128, Co=64, S=80, kernels=['dcnw_fwd_kernel<64, 16>', 'dcn_bwd_data_kernel', 'dcn_prep_kernel']),
     '32to64_96sq': dict(B=8, C=32, Co=64, S=96, kernels=['dcnw_fwd_kernel<64, 32>']),
     '128to128_64sq': dict(B=16, C=128, Co=128, S=64, kernels=['igemm_fwd_kernel<128, DcnFwdLoaderT<true>']),
     '256to256_32sq': dict(B=32, C=256, Co=256, S=32, kernels=['dcn_sample_kernel', 'igemm_fwd_ws_kernel<128, DcnColsBufLoader']),

@@ -354,7 +354,8 @@ def test_halo_tile_convolution_3x3(B, C, Co, H, W):
     yr = F.relu(F.conv2d(xr, wr, br, 1, 1))
     yr.backward(gy)
     xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, bias))
-    with hr.halo_conv(1, 1), hr.launch_log() as log:           # every eligible layer, whatever its size
+    # every eligible layer, whatever its size -- and no split-K, which would otherwise take these few-tile problems first
+    with hr.halo_conv(1, 1), hr.splitk(0), hr.launch_log() as log:
         yd = ops.conv2d(xd, wd, bd, 1, 1, act_slope=0.0)
         yd.backward(gy.to(DEV))
     names = [short(n) for n in log.names]
