@@ -1994,28 +1994,6 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
             DcnPrepParams pp{g, weight, offset, mask, wt, q.fused_consumers ? geo : nullptr, wt_blocks};
             CNUDA_LAUNCH(dcn_prep_kernel, dim3(wt_blocks + geo_blocks), dim3(256), 0, st, pp);
         }
-        // Image chunks (measurement, CNUDA_DCN_BWD_CHUNK = images per chunk): column-gradient GEMM and walk alternate over
-        // chunks of the batch, the chunk's dcol written and read back while it is still in the Infinity Cache
-        static const int chunk_env = getenv("CNUDA_DCN_BWD_CHUNK") ? atoi(getenv("CNUDA_DCN_BWD_CHUNK")) : 0;
-        if (q.fused_consumers && chunk_env > 0 && chunk_env < B) {
-            CNUDA_REQUIRE(raise_dynamic_lds(reinterpret_cast<const void*>(&dcn_bwd_data_kernel), q.col2im_lds),
-                          "cnuda_dcn_v2_backward: dynamic LDS");
-            for (int b0 = 0; b0 < B; b0 += chunk_env) {
-                const int nb = std::min(chunk_env, B - b0);
-                if (int rc = cnuda_conv2d_forward(grad_output + (size_t)b0 * Cout * HoWo, wt, nullptr, dcol, nb, Cout, g.Ho, g.Wo,
-                                                  q.T * C, 1, 1, 1, 1, 0, 0, -1.0f, gemm_ws, q.gemm_bytes, stream))
-                    return rc;
-                DcnBwdDataParams p{g, input + (size_t)b0 * C * H * W, dcol, geo + (size_t)b0 * q.T * HoWo,
-                                   grad_input + (size_t)b0 * C * H * W, grad_offset + (size_t)b0 * 2 * q.T * HoWo,
-                                   grad_mask + (size_t)b0 * q.T * HoWo, q.TR, q.TC, q.tc_shift,
-                                   q.tiles_y, q.tiles_x, q.ncg, q.WSZmax, q.claim_sz, q.margin, q.fused_split};
-                const int n_wg = nb * q.tiles_y * q.tiles_x * q.fused_split;
-                ProfScope scope(st, 3);
-                scope.name("dcn_bwd_data_kernel");
-                CNUDA_LAUNCH(dcn_bwd_data_kernel, dim3(n_wg), dim3(512), q.col2im_lds, st, p, n_wg);
-            }
-            return check_launch("cnuda_dcn_v2_backward(data, chunked)");
-        }
         if (int rc = cnuda_conv2d_forward(grad_output, wt, nullptr, dcol, B, Cout, g.Ho, g.Wo, q.T * C, 1, 1, 1, 1, 0,
                                           0, -1.0f, gemm_ws, q.gemm_bytes, stream))
             return rc;
