@@ -55,18 +55,20 @@ __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 
 // issued (explicit two-deep register pipeline): left to itself the compiler emits read -> s_waitcnt lgkmcnt(0) ->
 // MFMA per step, and the ~100-cycle LDS round trip then idles the matrix pipe between steps (measured with
 // SQ_VALU_MFMA_BUSY_CYCLES: 46 / 56 / 67 % busy for the 32 / 64 / 128-row tiles = 1 / 2 / 4 MFMAs per wait).
-template <int BM, int KC = IG_KC>
+// (LDA: row stride of the A image in LDS -- BM, unless a narrower tile is computed from a wider staged image: the short-K
+// kernel's last row tile)
+template <int BM, int KC = IG_KC, int LDA = BM>
 __device__ __forceinline__ void ig_mma_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
                                              f32x16 (&acc)[IgTile<BM>::TM][IgTile<BM>::TN],
                                              int wm_off, int wn_off, int lane) {
     using T = IgTile<BM>;
     const int kl = lane >> 5, il = lane & 31;
-    const float* ap = As + kl * BM + wm_off + il;
+    const float* ap = As + kl * LDA + wm_off + il;
     const float* bp = Bs + kl * IG_BN + wn_off + il;
     float a[2][T::TM], b[2][T::TN];
     auto frag = [&](int kk, float (&fa)[T::TM], float (&fb)[T::TN]) {
 #pragma unroll
-        for (int i = 0; i < T::TM; ++i) fa[i] = ap[kk * BM + i * 32];
+        for (int i = 0; i < T::TM; ++i) fa[i] = ap[kk * LDA + i * 32];
 #pragma unroll
         for (int j = 0; j < T::TN; ++j) fb[j] = bp[kk * IG_BN + j * 32];
     };
@@ -814,6 +816,44 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_fwd_shortk_kernel(
         // the next row tile's A loads go out BEFORE this tile's stores: vmcnt counts in issue order, so a load issued
         // after the epilogue would wait for every one of its stores to drain
         if (mt + 1 < m_tiles) load_a(mt + 1);
+        if constexpr (BM == 128) {
+            // The LAST row tile when at most 64 of its rows exist (M = 9 * 64 = 576 = 4.5 tiles for the 64-channel DCN layers):
+            // computed as a 64 x 128 tile over the four waves -- half the MFMAs of a 128-row tile whose upper half would be
+            // all padding (round 6: a tenth of this kernel's matrix work)
+            if (M - m0 <= 64) {
+                using T2 = IgTile<64>;
+                const int wm2 = (wid / T2::WN) * (T2::TM * 32), wn2 = (wid % T2::WN) * (T2::TN * 32);
+                f32x16 acc2[T2::TM][T2::TN];
+#pragma unroll
+                for (int i = 0; i < T2::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < T2::TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.0f;
+#pragma unroll
+                for (int c = 0; c < KP / IG_KC; ++c)
+                    ig_mma_chunk<64, IG_KC, BM>(As + c * IG_KC * BM, Bs + c * IG_KC * IG_BN, acc2, wm2, wn2, lane);
+                __syncthreads();
+                if (Loader::Out::vec4_ok(p)) {
+                    ig_epilogue_vec4<64, Loader>(p, As + wid * IG_EPI_WAVE, acc2, m0, n0, wm2, wn2, lane, M, N);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < T2::TN; ++j) {
+                        const long long n = n0 + wn2 + j * 32 + (lane & 31);
+                        if (n >= N) continue;
+                        typename Loader::Out out(p, n);
+#pragma unroll
+                        for (int i = 0; i < T2::TM; ++i)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int m = m0 + wm2 + i * 32 + mfma_row(r, lane);
+                                if (m < M) out.store(p, m, acc2[i][j][r]);
+                            }
+                    }
+                }
+                continue;
+            }
+        }
         f32x16 acc[T::TM][T::TN];
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
