@@ -58,8 +58,10 @@ if os.path.exists(lp):       # the step's own launches: differential of two trac
     launch_note = (' (the trace\'s total / steps; it includes %d one-time launches of the process -- arena and optimizer-state '
                    'copies -- and the step\'s own count, from the difference of a 10- and a 5-step trace, is %d)'
                    % (round(lj['one_time_launches']), round(lj['launches_per_step'])))
+# since round 6 `roofline` is the top kernel over ALL kernels (its own bound); the largest MFMA kernel sits beside it
+tm = rf.get('top_mfma_kernel') or rf
 busy = None
-dom = rf['kernel'].split(' (')[0].replace(' ', '')
+dom = tm['kernel'].split(' (')[0].replace(' ', '')
 for k, v in mfma.items():          # the PMC row of the line's dominant kernel (profiler names carry template defaults)
     if isinstance(v, dict) and 'mfma_util' in v and k.replace(' ', '').startswith(dom.rstrip('>')):
         busy = v['mfma_util']
@@ -76,9 +78,20 @@ state.append('Measured state at the end of round %d (MI355X, `profiles/%s_*`, wr
              % (N, TAG, line['ms_per_step'], line['value'], line.get('ms_per_step_sd', 0.0), N - 1, prev['ms_per_step'],
                 prev['value'], tot / 1e6 / STEPS, launches, N - 1, prev_launches, launch_note, line['step_mfma_fraction'],
                 line.get('step_mfma_fraction_executed') or 0.0, rf.get('executed_tflop_per_step') or 0.0))
-state.append('Dominant kernel `%s`: %.1f ms over %d launches, %.1f TFLOP/s = `roofline.frac` %.3f%s, %.0f MB of HBM traffic per '
-             'launch (PMC).' % (rf['kernel'], rf['kernel_ms_per_step'], rf['launches_per_step'], rf['achieved'], rf['frac'],
-                                (', MFMA pipe busy %.0f %% (PMC)' % (100 * busy)) if busy else '', (rf['traffic'] or 0) / 1e6))
+if rf.get('bound') == 'hbm':
+    state.append('Top kernel by time (`roofline`, over all kernels since round 6) `%s`: %.1f ms over %d launches, %.0f GB/s of algorithmic '
+                 'traffic = `roofline.frac` %.3f of 8 TB/s, %.0f MB of HBM traffic per launch (PMC) against %.0f MB algorithmic.'
+                 % (rf['kernel'], rf['kernel_ms_per_step'], rf['launches_per_step'], rf['achieved'], rf['frac'],
+                    (rf['traffic'] or 0) / 1e6, rf.get('algorithmic_mb_per_launch', 0.0)))
+state.append('%s `%s`: %.1f ms over %d launches, %.1f TFLOP/s = %.3f of the fp32 MFMA peak%s, %.0f MB of HBM traffic per '
+             'launch (PMC).' % ('Largest MFMA kernel (`roofline.top_mfma_kernel`)' if rf.get('bound') == 'hbm' else 'Dominant kernel',
+                                tm['kernel'], tm['kernel_ms_per_step'], tm['launches_per_step'], tm['achieved'], tm['frac'],
+                                (', MFMA pipe busy %.0f %% (PMC)' % (100 * busy)) if busy else '', (tm['traffic'] or 0) / 1e6))
+if rf.get('dcn_family_ms') is not None:
+    state.append('DCN family (every kernel of the deformable convolutions, `roofline.dcn_family_ms`): %.1f ms per step. HBM bytes of one '
+                 'step (PMC, all kernels; `roofline.hbm_bytes_per_step`): %s.'
+                 % (rf['dcn_family_ms'], ('%.1f GB = %.1f ms at 6.3 TB/s' % (rf['hbm_bytes_per_step'] / 1e9, rf['hbm_ms_at_6p3TBps']))
+                    if rf.get('hbm_bytes_per_step') else 'not collected'))
 if fam:
     state.append('The dominant kernel of rounds 1-4, `igemm_fwd_ws_kernel<128, ConvFwdBufLoader>`, now exists as two instances (with / '
                  'without the BatchNorm-statistics tail, §13): together %.1f ms per step at %.1f TFLOP/s = %.3f of the peak.'
@@ -90,10 +103,11 @@ state.append('Other BASELINE configs at full size on one GPU (`bench.py --config
                                                     c['ms_per_step'], c['value']) for c in cfgs) + '.')
 state.append('Decode (B=16, K=150): 128×128 C=6 %.0f µs, C=80 %.0f µs; 160×160 C=6 %.0f µs, C=80 %.0f µs. Inference wrapper '
              '(`export.CenterNet`, BatchNorm folded, eval forward + decode, fp32): %.0f img/s (%.2f ms per batch of 16). '
-             'Split-operand matrix mode (opt-in, §4a): %.1f ms/step = %.1f img/s. CPU baseline (`kind: %s`, %d threads, '
+             '%sCPU baseline (`kind: %s`, %d threads, '
              'median of %d 512×512 steps): %.3f img/s.'
              % (d['C6']['us'], d['C80']['us'], d['C6_160']['us'], d['C80_160']['us'], inf['images_per_s'],
-                inf['ms_per_batch'], sp['ms_per_step'], sp['value'], cb['kind'], cb['cores'],
+                inf['ms_per_batch'], ('Split-operand matrix mode (opt-in, §4a): %.1f ms/step = %.1f img/s. ' % (sp['ms_per_step'], sp['value'])) if sp else '',
+                cb['kind'], cb['cores'],
                 cb.get('s_per_step_512', {}).get('repeats', 1) if isinstance(cb.get('s_per_step_512'), dict) else 1, cb['value']))
 state_txt = '\n'.join(state)
 
@@ -101,8 +115,14 @@ pd, pinf, pcb, psp, prf = prev['decode_latency'], prev['inference'], prev['cpu_b
 tab = ['| | round %d | round %d |' % (N - 1, N), '|---|---|---|',
        '| UDA step, DLA-34 + DCNv2 512², 16 + 16 images (the headline, `bench.py`) | %.1f ms = %.1f img/s | **%.1f ms = %.1f img/s** |'
        % (prev['ms_per_step'], prev['value'], line['ms_per_step'], line['value']),
-       '| `roofline` (dominant kernel by time, fp32 MFMA, peak 157.3 TFLOP/s) | `%s`: %.1f TF = %.3f | `%s`: %.1f TF = %.3f |'
-       % (prf['kernel'].replace('igemm_', ''), prf['achieved'], prf['frac'], rf['kernel'].replace('igemm_', ''), rf['achieved'], rf['frac'])]
+       '| largest MFMA kernel by time (fp32 MFMA, peak 157.3 TFLOP/s; `roofline` until round 5, `roofline.top_mfma_kernel` since) | `%s`: %.1f TF = %.3f | `%s`: %.1f TF = %.3f |'
+       % ((prf.get('top_mfma_kernel') or prf)['kernel'].replace('igemm_', ''), (prf.get('top_mfma_kernel') or prf)['achieved'], (prf.get('top_mfma_kernel') or prf)['frac'],
+          tm['kernel'].replace('igemm_', ''), tm['achieved'], tm['frac'])]
+if rf.get('bound') == 'hbm':
+    ph = (prf.get('hbm_kernels') or {}).get(rf['kernel'])
+    tab.append('| `roofline` since round 6: the top kernel over all kernels, `%s` (HBM-bound: algorithmic bytes / time against 8 TB/s) | %s | %.1f ms/step, %.0f GB/s = %.3f |'
+               % (rf['kernel'], ('%.1f ms/step, %.0f GB/s = %.3f' % (ph['ms_per_step'], ph['gb_per_s'], ph['frac_of_8TBps'])) if ph else '—',
+                  rf['kernel_ms_per_step'], rf['achieved'], rf['frac']))
 if fam:
     tab.append('| the forward kernel `igemm_fwd_ws_kernel<128, ConvFwdBuf*>` (rounds 1-4\'s dominant one; two instances since round 5) | %.1f TF = %.3f | %.1f TF = %.3f |'
                % (prf['achieved'], prf['frac'], fam['tflops'], fam['frac']))
@@ -118,7 +138,8 @@ for c in cfgs:
 tab += ['| decode B=16, K=150, 128² maps: C=6 / C=80 | %.0f / %.0f µs | %.0f / %.0f µs |' % (pd['C6']['us'], pd['C80']['us'], d['C6']['us'], d['C80']['us']),
         '| decode 160² maps (cfg5 shape): C=6 / C=80 | %.0f / %.0f µs | %.0f / %.0f µs |' % (pd['C6_160']['us'], pd['C80_160']['us'], d['C6_160']['us'], d['C80_160']['us']),
         '| inference wrapper (eval forward + decode, batch 16) | %.0f img/s | %.0f img/s |' % (pinf['images_per_s'], inf['images_per_s']),
-        '| split-operand matrix mode (opt-in) | %.1f ms | %.1f ms |' % (psp['ms_per_step'], sp['ms_per_step']),
+        '| split-operand matrix mode (opt-in; since round 6 only with `--matrix-mode-split`) | %s | %s |'
+        % (('%.1f ms' % psp['ms_per_step']) if psp else '—', ('%.1f ms' % sp['ms_per_step']) if sp else 'not in the default run'),
         '| CPU baseline (oracle port, %d host threads; 1 / seconds per 512² step) | %.3f img/s | %.3f img/s |' % (cb['cores'], pcb['value'], cb['value'])]
 tab_txt = '\n'.join(tab)
 

@@ -53,11 +53,22 @@ for r in rows[:48]:
                                                      100 * float(r['TotalDurationNs']) / tot))
 out.append('')
 out.append('Launches per step: %d.\n' % (sum(int(r['Calls']) for r in rows) // STEPS))
-out.append('Dominant kernel `%s`: avg launch %.4f ms (in-library hipEvents; rocprofv3 above), %.2f algorithmic GFLOP per launch '
+if rf.get('bound') == 'hbm':      # (since round 6 `roofline` is the top kernel over all kernels, against its own bound)
+    out.append('Top kernel by time `%s` (`roofline`): avg launch %.4f ms (in-library hipEvents; rocprofv3 above), %.1f MB algorithmic '
+               'per launch => %.0f GB/s = %.1f %% of 8 TB/s; HBM traffic %.0f MB per launch from the PMC passes.\n'
+               % (rf['kernel'], rf['avg_launch_ms'], rf.get('algorithmic_mb_per_launch', 0.0), rf['achieved'], 100 * rf['frac'],
+                  (rf['traffic'] or 0) / 1e6))
+    if rf.get('hbm_bytes_per_step'):
+        out.append('HBM bytes of one step, all kernels (PMC): %.1f GB = %.1f ms at 6.3 TB/s; DCN family %.1f ms per step.\n'
+                   % (rf['hbm_bytes_per_step'] / 1e9, rf['hbm_ms_at_6p3TBps'], rf['dcn_family_ms']))
+rf = rf.get('top_mfma_kernel') or rf
+out.append('%s `%s`: avg launch %.4f ms (in-library hipEvents; rocprofv3 above), %.2f algorithmic GFLOP per launch '
            '=> %.1f TFLOP/s = %.1f %% of the %.1f TFLOP/s fp32 MFMA peak; HBM traffic %.0f MB per launch from the PMC passes '
            '(`%s_pmc_traffic.json`, `profiles/collect_pmc_traffic.sh`: separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs, KB per '
-           'launch, FETCH uncorrected).\n' % (rf['kernel'], rf['avg_launch_ms'], rf['algorithmic_gflop_per_launch'], rf['achieved'],
+           'launch, FETCH uncorrected).\n' % ('Largest MFMA kernel' if line['roofline'].get('bound') == 'hbm' else 'Dominant kernel',
+                                              rf['kernel'], rf['avg_launch_ms'], rf['algorithmic_gflop_per_launch'], rf['achieved'],
                                               100 * rf['frac'], rf['peak'], (rf['traffic'] or 0) / 1e6, TAG))
+rf = line['roofline']
 hb = rf.get('hbm_kernels') or {}
 if hb:
     out.append('HBM-streaming kernels of the DCN backward (algorithmic bytes / time): ' +

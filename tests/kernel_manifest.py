@@ -80,6 +80,10 @@ MANIFEST = {
     'splitk_reduce_kernel<ConvDgradClassBufLoader>': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[sk_disc_',
     ],
+    'igemm_fwd_kernel<32, ConvDgradClassBufLoader, false>': [      # (round 6: only where another class of the same call cuts K)
+        'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[sk_s2_mixed',
+        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+    ],
     'igemm_fwd_classes_kernel<32>': [
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[s2_even',
         'tests/test_gpu_ops.py::test_conv2d_fwd_bwd[disc4x4',

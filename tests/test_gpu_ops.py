@@ -81,6 +81,10 @@ CONV_CASES = {
     'sk_disc_128to256': (4, 128, 40, 40, 256, 4, 2, 1, True, 0.2),
     'sk_512to27_16sq': (8, 512, 16, 16, 27, 3, 1, 1, True, -1.0),
     'sk_256to64_8sq': (3, 256, 8, 8, 64, 3, 1, 1, False, 0.0),
+    # stride 2 with 256 outputs on a 16 x 16 input: the 4-tap parity class of the input gradient (K = 1,024) cuts K, the 1- and
+    # 2-tap classes (K = 256 / 512 < 32 chunks... / = 32) do not -- one launch per class (igemm_fwd_kernel<32, ConvDgradClassBufLoader>
+    # beside the split-K instance), as in the ResNet-18 step of configs[0]
+    'sk_s2_mixed': (2, 64, 16, 16, 256, 3, 2, 1, False, -1.0),
 }
 
 
