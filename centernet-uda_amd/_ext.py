@@ -103,3 +103,65 @@ def dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kernel_h, ke
                                          hr.ptr(ws), ws.numel(), hr.stream()),
              'dcn_v2_backward')
     return grads        # [grad_input, grad_offset, grad_mask, grad_weight, grad_bias]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 6 (not part of the reference's `_ext`): offsets and mask read straight out of `om`, the 3T-channel output of DCN's own
+# offset convolution whose mask channels already went through the sigmoid (hip_runtime.ops.conv2d_rowsig) -- see
+# include/centernet_uda_hip.h, cnuda_dcn_v2_forward_om.  Used by libs.DCNv2.dcn_v2.DCN only; deformable_group == 1.
+# ---------------------------------------------------------------------------------------------------------------------
+def dcn_v2_forward_om(input, weight, bias, om, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+                      _want_columns=False, _pack_token=0, _stats_box=None):
+    hr.require_gpu(input, weight, bias, om)
+    input, weight, bias, om = [hr.f32c(t) for t in (input, weight, bias, om)]
+    B, C, H, W = input.shape
+    Co = weight.shape[0]
+    if weight.shape[1] != C or tuple(weight.shape[2:]) != (kernel_h, kernel_w):
+        raise RuntimeError("dcn_v2_forward_om: weight %s does not match %d input channels / a %dx%d kernel"
+                           % (tuple(weight.shape), C, kernel_h, kernel_w))
+    Ho, Wo = _out_hw(H, W, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w)
+    T = kernel_h * kernel_w
+    if tuple(om.shape) != (B, 3 * T, Ho, Wo):
+        raise RuntimeError("dcn_v2_forward_om: om %s does not match [%d, %d, %d, %d]" % (tuple(om.shape), B, 3 * T, Ho, Wo))
+    geom = (B, C, H, W, Co, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, 1)
+    out = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=input.device)
+    cols = torch.empty((B, T * C, Ho * Wo), dtype=torch.float32, device=input.device) if _want_columns else None
+    L = hr.lib()
+    ws = hr.workspace(L.cnuda_dcn_v2_workspace_bytes(*geom), input.device)
+    hr.prof_arm('dcn_fwd', B, C, H, W, Co, kernel_h, kernel_w, Ho, Wo)
+    stats, blk, nrows = None, 0, 0
+    if _stats_box is not None:
+        import ctypes
+        rows = ctypes.c_int(0)
+        blk = L.cnuda_dcn_v2_stats_block(*geom, ctypes.byref(rows))
+        if blk:
+            nrows = rows.value
+            stats = torch.empty(((B * Ho * Wo + 127) // 128 * (128 // blk), nrows, 2), dtype=torch.float32, device=input.device)
+            _stats_box.append((stats, blk, nrows, 0))
+    with hr.pack_stamp(_pack_token, weight):
+        hr.check(L.cnuda_dcn_v2_forward_om(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(om), hr.ptr(out), hr.ptr(cols),
+                                           hr.ptr(stats), blk, nrows, *geom, hr.ptr(ws), ws.numel(), hr.stream()),
+                 'dcn_v2_forward_om')
+    return out, cols
+
+
+def dcn_v2_backward_om(input, weight, bias, om, grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
+                       dilation_h, dilation_w, _columns=None, _grad_weight=None, _grad_bias=None, _grad_input=None):
+    """-> [grad_input, grad_om, grad_weight, grad_bias]; grad_om: the offsets' gradient in channels 0 .. 2T-1, the gradient of
+    the mask's LOGIT in channels 2T .. 3T-1."""
+    hr.require_gpu(input, weight, bias, om, grad_output)
+    input, weight, bias, om, grad_output = [hr.f32c(t) for t in (input, weight, bias, om, grad_output)]
+    B, C, H, W = input.shape
+    Co = weight.shape[0]
+    geom = (B, C, H, W, Co, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, 1)
+    grads = [_grad_input if _grad_input is not None else torch.empty_like(input), torch.empty_like(om),
+             _grad_weight if _grad_weight is not None else torch.empty_like(weight),
+             _grad_bias if _grad_bias is not None else torch.empty_like(bias)]
+    L = hr.lib()
+    ws = hr.workspace(L.cnuda_dcn_v2_workspace_bytes(*geom), input.device)
+    hr.prof_arm('dcn_bwd', B, C, H, W, Co, kernel_h, kernel_w, grad_output.shape[2], grad_output.shape[3])
+    hr.check(L.cnuda_dcn_v2_backward_om(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(om), hr.ptr(grad_output),
+                                        hr.ptr(_columns), hr.ptr(grads[0]), 1 if _grad_input is not None else 0,
+                                        hr.ptr(grads[1]), hr.ptr(grads[2]), hr.ptr(grads[3]), *geom, hr.ptr(ws), ws.numel(),
+                                        hr.stream()), 'dcn_v2_backward_om')
+    return grads

@@ -41,6 +41,15 @@ struct ConvFwdStatsParams : ConvFwdParams {
     int stats_mp;            // rows per pixel block of `stats` (>= the padded row count of the launch)
 };
 
+// ... with a sigmoid on the output rows m >= sig_from (after the bias): DCN's offset convolution, whose rows 2T .. 3T-1 are the
+// modulation mask's logits (libs/DCNv2/dcn_v2.py:118-122) -- the DCN kernels then read offsets and mask straight out of this
+// one tensor (cnuda_dcn_v2_forward_om).  Its own parameter type and kernel instances, like the statistics variant.
+struct ConvFwdSigParams : ConvFwdParams {
+    int sig_from;
+};
+// (the expression of cnuda_split_offset_mask, which this replaces: bit-identical masks)
+__device__ __forceinline__ float conv_row_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+
 // B[k = tap*C + c][n] = x[b][c][oy*sh - ph + r][ox*sw - pw + s]   (0 outside)
 template <bool FAST>
 struct ConvFwdLoader {
@@ -175,6 +184,30 @@ struct ConvFwdBufLoader {
         for (int j = 0; j < 8; ++j) v[j] = ig_buf_load(rs, voff, (unsigned)((c0 + 2 * j) * HW) * (unsigned)sizeof(float));
     }
     using Out = ConvFwdLoader<true>::Out;
+};
+
+// ConvFwdBufLoader with the row-wise sigmoid epilogue (ConvFwdSigParams): the 27-channel offset convolutions that no halo-tile
+// kernel takes (small maps, split-K)
+struct ConvFwdBufSigLoader : ConvFwdBufLoader {
+    using Params = ConvFwdSigParams;
+    static const char* name() { return "ConvFwdBufSigLoader"; }
+    __device__ ConvFwdBufSigLoader(const Params& p, long long n, bool n_valid) : ConvFwdBufLoader(p, n, n_valid) {}
+    struct Out : ConvFwdLoader<true>::Out {
+        __device__ Out(const Params& p, long long n) : ConvFwdLoader<true>::Out(p, n) {}
+        __device__ __forceinline__ void store(const Params& p, int m, float v) {
+            if (p.bias) v += p.bias[m];
+            if (m >= p.sig_from) v = conv_row_sigmoid(v);
+            base[(size_t)m * HoWo] = v;
+        }
+        __device__ __forceinline__ void store4(const Params& p, int m, f32x4 v) {
+            if (p.bias) v += p.bias[m];
+            if (m >= p.sig_from) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = conv_row_sigmoid(v[e]);
+            }
+            *reinterpret_cast<f32x4*>(base + (size_t)m * HoWo) = v;
+        }
+    };
 };
 
 // ConvFwdBufLoader for the calls that leave BatchNorm statistics (cnuda_conv2d_forward_stats): same gather, same epilogue
@@ -803,6 +836,11 @@ struct HconvFwd {
     using Out = ConvFwdLoader<true>::Out;
     static const char* name() { return "fwd"; }
 };
+struct HconvFwdSig {          // (the row-wise sigmoid epilogue, see ConvFwdSigParams)
+    using Params = ConvFwdSigParams;
+    using Out = ConvFwdBufSigLoader::Out;
+    static const char* name() { return "fwd, row sigmoid"; }
+};
 struct HconvDgrad {
     using Params = ConvDgradParams;
     using Out = ConvDgradLoader::Out;
@@ -950,6 +988,7 @@ __global__ __launch_bounds__(256) void dgrad_s2_c16_kernel(DgradS2Params p) {
 
 template <class Loader> struct SplitKLoader : std::false_type {};
 template <> struct SplitKLoader<ConvFwdBufLoader> : std::true_type {};
+template <> struct SplitKLoader<ConvFwdBufSigLoader> : std::true_type {};
 template <> struct SplitKLoader<ConvDgradBufLoader> : std::true_type {};
 template <> struct SplitKLoader<ConvDgradClassBufLoader> : std::true_type {};
 
@@ -1142,6 +1181,43 @@ extern "C" int cnuda_conv2d_forward_stats(const float* x, const float* weight, c
     if (C % IG_BK == 0)
         return launch_fwd<ConvFwdLoader<true>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
     return launch_fwd<ConvFwdLoader<false>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
+}
+
+// y = conv(x) + bias with a sigmoid on the output channels >= sig_from: the offset / mask convolution of a DCN layer when the
+// deformable convolution reads both out of this tensor (cnuda_dcn_v2_forward_om).  cnuda_conv2d_rowsig_supported: the
+// geometries with such an epilogue compiled (C % 16 == 0, at most 32 output channels, tensors below 2 GiB, f32 matrix mode).
+extern "C" int cnuda_conv2d_rowsig_supported(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph,
+                                             int pw) {
+    ConvGeom g;
+    if (fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_rowsig_supported")) return 0;
+    return (Cout <= 32 && C % IG_BK == 0 && buffer_addressing() && kh * kw <= 32 && matrix_mode() == 0 &&
+            (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB && (size_t)B * Cout * g.Ho * g.Wo * sizeof(float) < IG_BUF_OOB &&
+            !smallc_supported(C, Cout, kh, kw, sh, sw)) ? 1 : 0;
+}
+extern "C" int cnuda_conv2d_forward_rowsig(const float* x, const float* weight, const float* bias, float* y, int sig_from,
+                                           int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                                           void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && weight && y && sig_from >= 0, "cnuda_conv2d_forward_rowsig: bad arguments");
+    CNUDA_REQUIRE(cnuda_conv2d_rowsig_supported(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw),
+                  "cnuda_conv2d_forward_rowsig: geometry without a row-sigmoid epilogue (cnuda_conv2d_rowsig_supported)");
+    ConvGeom g;
+    if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_forward_rowsig")) return rc;
+    const ConvPlan q = make_plan(g);
+    CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_conv2d_forward_rowsig: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    ConvFwdSigParams p;
+    static_cast<ConvFwdParams&>(p) = ConvFwdParams{g, x, bias, y, -1.0f, nullptr};
+    p.sig_from = sig_from;
+    if (!q.skf.on() && hconv_ok(g, C, q.bmf)) {
+        const float* Ah = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),
+                                      ig_a_bytes(q.Kpf, q.Mpf), Cout, C, q.T, PACK_HALO_FWD, q.Kpf, q.Mpf, 0, st);
+        return launch_hconv<HconvFwdSig>(q.bmf, p, x, C, g, Ah, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward_rowsig");
+    }
+    const float* A = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),
+                                 ig_a_bytes(q.Kpf, q.Mpf), Cout, C, q.T, PACK_FWD, q.Kpf, q.Mpf, 0, st);
+    float* slab = q.skf.on() ? reinterpret_cast<float*>(cv.take<char>(splitk_slab_bytes(q.skf, Cout, q.Nf))) : nullptr;
+    return launch_fwd<ConvFwdBufSigLoader>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward_rowsig", q.skf, slab);
 }
 
 extern "C" int cnuda_conv2d_backward_data(const float* grad_y, const float* weight, float* grad_x, int B, int C, int H,

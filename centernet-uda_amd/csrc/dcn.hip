@@ -27,6 +27,12 @@ namespace {
 
 struct DcnGeom {
     int B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg, Ho, Wo;
+    // elements per image of the offset / mask tensors and of their gradients: dg * 2T * HoWo and dg * T * HoWo for the
+    // reference's separate tensors; 3T * HoWo for all four when offsets and mask are read straight out of the 27-channel
+    // output `om` of DCN's own offset convolution (rows 0 .. 2T-1 offsets, 2T .. 3T-1 the mask, already sigmoid:
+    // cnuda_dcn_v2_forward_om / _backward_om, round 6).  gmask_logit: the mask gradient is written as the gradient of the
+    // mask's LOGIT, g * m * (1 - m) -- what the offset convolution's backward wants (libs/DCNv2/dcn_v2.py:120-122).
+    int off_bs, mask_bs, goff_bs, gmask_bs, gmask_logit;
 };
 
 // Per-(pixel, tap) sampling state: four corner offsets inside a plane, the
@@ -144,8 +150,8 @@ struct DcnFwdLoaderT {
         ox = pp - oy * g.Wo;
         const int T = g.kh * g.kw;
         in_b = p.in + (size_t)b * g.C * g.H * g.W;
-        off_b = p.off + (size_t)b * 2 * T * HoWo;
-        mask_b = p.mask + (size_t)b * T * HoWo;
+        off_b = p.off + (size_t)b * g.off_bs;
+        mask_b = p.mask + (size_t)b * g.mask_bs;
         K = T * g.C;
         col_n = (p.col && n_valid) ? p.col + (size_t)b * K * HoWo + pp : nullptr;
         col_stride = HoWo;
@@ -396,8 +402,8 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcnw_fwd_kernel(DcnFwdParams p,
     float flh[9], flw[9], fmk[9];
     unsigned stray = 0;
     {
-        const float* off_b = p.off + (size_t)b * 18 * HW + pp;
-        const float* mask_b = p.mask + (size_t)b * 9 * HW + pp;
+        const float* off_b = p.off + (size_t)b * g.off_bs + pp;
+        const float* mask_b = p.mask + (size_t)b * g.mask_bs + pp;
         float dy[9], dx[9], mk[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -548,11 +554,11 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcnw_fwd_kernel(DcnFwdParams p,
                 if ((stray >> t) & 1u) {
                     // the tap's state again from the raw offsets, corner addresses clamped into the plane, weights zeroed
                     // where a corner lies outside it (dcn_v2_im2col_cuda.cu:37-48)
-                    const float* off_b = p.off + (size_t)b * 18 * HW + pp;
+                    const float* off_b = p.off + (size_t)b * g.off_bs + pp;
                     const int tr = t / 3;
                     const float sh_ = (float)(py - 1 + tr) + off_b[(size_t)(2 * t) * HW];
                     const float sw_ = (float)(px - 1 + t - 3 * tr) + off_b[(size_t)(2 * t + 1) * HW];
-                    const float smk = p.mask[((size_t)b * 9 + t) * HW + pp];
+                    const float smk = p.mask[(size_t)b * g.mask_bs + (size_t)t * HW + pp];
                     const float shf = floorf(sh_), swf = floorf(sw_);
                     const int sh0 = (int)shf, sw0 = (int)swf;
                     const float slh = sh_ - shf, slw = sw_ - swf, shh = 1.0f - slh, shw = 1.0f - slw;
@@ -655,7 +661,7 @@ __global__ __launch_bounds__(1024) void dcn_sample_kernel(DcnSampleParams p, int
     const int oy = px / g.Wo, ox = px - oy * g.Wo;
     const float* in_b = p.in + (size_t)b * g.C * HW;
     for (int tap = threadIdx.y; tap < T; tap += blockDim.y) {
-        const Tap t = make_tap(g, p.off + (size_t)b * 2 * T * HoWo, p.mask + (size_t)b * T * HoWo, 0, tap, oy, ox);
+        const Tap t = make_tap(g, p.off + (size_t)b * g.off_bs, p.mask + (size_t)b * g.mask_bs, 0, tap, oy, ox);
         const float mk = t.inside ? t.mask : 0.0f;
         const float w00 = t.c00 ? t.hh * t.hw * mk : 0.0f, w01 = t.c01 ? t.hh * t.lw * mk : 0.0f;
         const float w10 = t.c10 ? t.lh * t.hw * mk : 0.0f, w11 = t.c11 ? t.lh * t.lw * mk : 0.0f;
@@ -811,7 +817,7 @@ __global__ __launch_bounds__(1024) void dcn_coord_grad_kernel(DcnCoordParams p, 
     const int oy = px / g.Wo, ox = px - oy * g.Wo;
     const float* in_b = p.in + (size_t)b * g.C * HW;
     for (int tap = threadIdx.y; tap < T; tap += blockDim.y) {
-        const Tap t = make_tap(g, p.off + (size_t)b * 2 * T * HoWo, p.mask + (size_t)b * T * HoWo, 0, tap, oy, ox);
+        const Tap t = make_tap(g, p.off + (size_t)b * g.off_bs, p.mask + (size_t)b * g.mask_bs, 0, tap, oy, ox);
         const float* dc = p.dcol + ((size_t)b * T + tap) * g.C * HoWo + px;
         float sm = 0.f, sh_ = 0.f, sw_ = 0.f;
         if (t.inside && g.W >= 2) {
@@ -877,9 +883,10 @@ __global__ __launch_bounds__(1024) void dcn_coord_grad_kernel(DcnCoordParams p, 
                 sw_ += (-t.hh * a00 + t.hh * a01 - t.lh * a10 + t.lh * a11) * dm;
             }
         }
-        p.gmask[((size_t)b * T + tap) * HoWo + px] = sm;
-        p.goff[((size_t)b * 2 * T + 2 * tap) * HoWo + px] = sh_;
-        p.goff[((size_t)b * 2 * T + 2 * tap + 1) * HoWo + px] = sw_;
+        if (g.gmask_logit) sm = sm * t.mask * (1.0f - t.mask);        // (cnuda_split_offset_mask_backward's own expression)
+        p.gmask[(size_t)b * g.gmask_bs + (size_t)tap * HoWo + px] = sm;
+        p.goff[(size_t)b * g.goff_bs + (size_t)(2 * tap) * HoWo + px] = sh_;
+        p.goff[(size_t)b * g.goff_bs + (size_t)(2 * tap + 1) * HoWo + px] = sw_;
         DcnGeo r;
         r.cell = t.inside ? (int)(((unsigned)t.h0 << 16) | ((unsigned)t.w0 & 0xffffu)) : (int)0x80000000u;
         r.lh = t.lh; r.lw = t.lw; r.mask = t.inside ? t.mask : 0.f;
@@ -1143,7 +1150,7 @@ __global__ __launch_bounds__(256) void dcn_prep_kernel(DcnPrepParams p) {
         const long long r = i / HoWo;
         const int tap = (int)(r % T), b = (int)(r / T);
         const int oy = px / g.Wo, ox = px - oy * g.Wo;
-        const Tap t = make_tap(g, p.off + (size_t)b * 2 * T * HoWo, p.mask + (size_t)b * T * HoWo, 0, tap, oy, ox);
+        const Tap t = make_tap(g, p.off + (size_t)b * g.off_bs, p.mask + (size_t)b * g.mask_bs, 0, tap, oy, ox);
         DcnGeo rec;
         rec.cell = t.inside ? (int)(((unsigned)t.h0 << 16) | ((unsigned)t.w0 & 0xffffu)) : (int)0x80000000u;
         rec.lh = t.lh; rec.lw = t.lw; rec.mask = t.inside ? t.mask : 0.f;
@@ -1234,9 +1241,10 @@ __global__ __launch_bounds__(512, 6) void dcn_bwd_data_kernel(DcnBwdDataParams p
                 sh_ = (hTl * uTl + hTr * uTr + hBl * uBl + hBr * uBr) * rec.mask;
                 sw_ = (wTl * uTl + wTr * uTr + wBl * uBl + wBr * uBr) * rec.mask;
             }
-            p.gmask[((size_t)b * T + tap) * HoWo + px] = sm;
-            p.goff[((size_t)b * 2 * T + 2 * tap) * HoWo + px] = sh_;
-            p.goff[((size_t)b * 2 * T + 2 * tap + 1) * HoWo + px] = sw_;
+            if (g.gmask_logit) sm = sm * rec.mask * (1.0f - rec.mask);    // (sm == 0 where the record's mask was zeroed: outside taps)
+            p.gmask[(size_t)b * g.gmask_bs + (size_t)tap * HoWo + px] = sm;
+            p.goff[(size_t)b * g.goff_bs + (size_t)(2 * tap) * HoWo + px] = sh_;
+            p.goff[(size_t)b * g.goff_bs + (size_t)(2 * tap + 1) * HoWo + px] = sw_;
         }
         return;
     }
@@ -1305,10 +1313,10 @@ struct DcnWLoader {
     template <int NV, int STEP>
     __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[NV]) {
         const DcnGeom& g = p.g;
-        const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, K = T * g.C;
+        const int HW = g.H * g.W, T = g.kh * g.kw, K = T * g.C;
         const float* in_b = p.in + (size_t)b_ * g.C * HW;
-        const float* off_b = p.off + (size_t)b_ * 2 * T * HoWo;
-        const float* mask_b = p.mask + (size_t)b_ * T * HoWo;
+        const float* off_b = p.off + (size_t)b_ * g.off_bs;
+        const float* mask_b = p.mask + (size_t)b_ * g.mask_bs;
         int cur = -1;
         Tap t;
 #pragma unroll
@@ -1444,8 +1452,8 @@ __global__ void dcn_naive_fwd_kernel(DcnNaiveParams p) {
         float s = p.bias[o];
         for (int grp = 0; grp < g.dg; ++grp)
             for (int tap = 0; tap < T; ++tap) {
-                const Tap t = make_tap(g, p.off + (size_t)b * g.dg * 2 * T * HoWo,
-                                       p.mask + (size_t)b * g.dg * T * HoWo, grp, tap, oy, ox);
+                const Tap t = make_tap(g, p.off + (size_t)b * g.off_bs,
+                                       p.mask + (size_t)b * g.mask_bs, grp, tap, oy, ox);
                 if (!t.inside) continue;
                 for (int cc = 0; cc < cpg; ++cc) {
                     const int c = grp * cpg + cc;
@@ -1469,7 +1477,7 @@ __global__ void dcn_naive_bwd_kernel(DcnNaiveParams p) {
         const int pp = (int)(i % HoWo), tap = (int)((i / HoWo) % T), c = (int)((i / ((long long)HoWo * T)) % g.C);
         const int b = (int)(i / ((long long)HoWo * T * g.C));
         const int oy = pp / g.Wo, ox = pp - oy * g.Wo, grp = c / cpg;
-        const Tap t = make_tap(g, p.off + (size_t)b * g.dg * 2 * T * HoWo, p.mask + (size_t)b * g.dg * T * HoWo, grp,
+        const Tap t = make_tap(g, p.off + (size_t)b * g.off_bs, p.mask + (size_t)b * g.mask_bs, grp,
                                tap, oy, ox);
         if (!t.inside) continue;
         float v00, v01, v10, v11;
@@ -1503,8 +1511,11 @@ int fill_geom(DcnGeom& g, int B, int C, int H, int W, int Co, int kh, int kw, in
                   "%s: bad kernel geometry", who);
     CNUDA_REQUIRE(dg > 0 && C % dg == 0, "%s: channels (%d) not divisible by deformable_group (%d)", who, C, dg);
     g = DcnGeom{B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg,
-                (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1, (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1};
+                (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1, (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1, 0, 0, 0, 0, 0};
     CNUDA_REQUIRE(g.Ho > 0 && g.Wo > 0, "%s: kernel larger than padded input", who);
+    CNUDA_REQUIRE((long long)dg * 3 * kh * kw * g.Ho * g.Wo < (1ll << 31), "%s: offset planes of an image exceed 2^31 elements", who);
+    g.off_bs = g.goff_bs = dg * 2 * kh * kw * g.Ho * g.Wo;       // the reference's separate offset / mask tensors
+    g.mask_bs = g.gmask_bs = dg * kh * kw * g.Ho * g.Wo;
     return 0;
 }
 
@@ -1720,7 +1731,7 @@ extern "C" int cnuda_dcn_v2_stats_block(int B, int C, int H, int W, int Cout, in
 static int dcn_forward_impl(const float* input, const float* weight, const float* bias, const float* offset,
                             const float* mask, float* output, float* columns, float* stats, float act_slope, int B, int C,
                             int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg,
-                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream, int om_mode = 0);
 
 extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight, const float* bias,
                                         const float* offset, const float* mask, float* output, float* columns,
@@ -1757,12 +1768,13 @@ extern "C" int cnuda_dcn_v2_forward_stats(const float* input, const float* weigh
 static int dcn_forward_impl(const float* input, const float* weight, const float* bias, const float* offset,
                             const float* mask, float* output, float* columns, float* stats, float act_slope, int B, int C,
                             int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg,
-                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream, int om_mode) {
     CNUDA_REQUIRE(input && weight && bias && offset && mask && output, "cnuda_dcn_v2_forward: null pointer");
     CNUDA_REQUIRE(!columns || (dg == 1 && W >= 2),
                   "cnuda_dcn_v2_forward_cols: columns output needs deformable_group == 1 and width >= 2");
     DcnGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, "cnuda_dcn_v2_forward")) return rc;
+    if (om_mode) g.off_bs = g.mask_bs = 3 * kh * kw * g.Ho * g.Wo;      // offsets and mask are rows of one 3T-channel tensor
     hipStream_t st = (hipStream_t)stream;
     CNUDA_REQUIRE(act_slope < 0.0f || (dg == 1 && W >= 2), "cnuda_dcn_v2_forward_act: fused activation needs deformable_group == 1 and width >= 2");
     if (dg != 1 || W < 2) {   // the MFMA path samples horizontally adjacent pairs
@@ -1892,6 +1904,13 @@ extern "C" int cnuda_dcn_v2_backward_cols(const float* input, const float* weigh
                                      workspace, workspace_bytes, stream);
 }
 
+static int dcn_backward_impl(const float* input, const float* weight, const float* bias,
+                             const float* offset, const float* mask, const float* grad_output,
+                             const float* columns, float* grad_input, int accumulate_input,
+                             float* grad_offset, float* grad_mask, float* grad_weight, float* grad_bias, int B,
+                             int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                             int dh, int dw, int dg, void* workspace, size_t workspace_bytes,
+                             cnuda_stream_t stream, int om_mode);
 extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight, const float* bias,
                                          const float* offset, const float* mask, const float* grad_output,
                                          const float* columns, float* grad_input, int accumulate_input,
@@ -1899,6 +1918,55 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
                                          int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                                          int dh, int dw, int dg, void* workspace, size_t workspace_bytes,
                                          cnuda_stream_t stream) {
+    return dcn_backward_impl(input, weight, bias, offset, mask, grad_output, columns, grad_input, accumulate_input, grad_offset,
+                             grad_mask, grad_weight, grad_bias, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, workspace,
+                             workspace_bytes, stream, 0);
+}
+
+// Offsets and mask read straight out of `om`, the 3T-channel output of DCN's own offset convolution
+// (libs/DCNv2/dcn_v2.py:118-122: o1, o2, mask = chunk(out, 3); offset = cat(o1, o2); mask = sigmoid(mask)): rows 0 .. 2T-1
+// ARE the offsets, rows 2T .. 3T-1 the mask -- ALREADY sigmoid (cnuda_conv2d_forward_rowsig applies it in the
+// convolution's epilogue) -- and the backward writes one tensor `gom` of the same shape: the offsets' gradient and the
+// gradient of the mask's LOGIT (the walk multiplies by m (1 - m) where it stores).  No split / concatenate / sigmoid passes:
+// 32 launches of a benched step and two tensors per layer less (round 6).  deformable_group == 1.
+extern "C" int cnuda_dcn_v2_forward_om(const float* input, const float* weight, const float* bias, const float* om,
+                                       float* output, float* columns, float* stats, int stats_block, int stats_rows, int B,
+                                       int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                                       int dw, int dg, void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(om && dg == 1 && W >= 2, "cnuda_dcn_v2_forward_om: needs deformable_group == 1 and width >= 2");
+    DcnGeom g;
+    if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, "cnuda_dcn_v2_forward_om")) return rc;
+    if (stats) {
+        int rows = 0;
+        const int blk = cnuda_dcn_v2_stats_block(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, &rows);
+        CNUDA_REQUIRE(blk != 0 && blk == stats_block && rows == stats_rows,
+                      "cnuda_dcn_v2_forward_om: the statistics buffer was sized for blocks of %d pixels x %d rows, this call "
+                      "writes %d x %d", stats_block, stats_rows, blk, rows);
+    }
+    return dcn_forward_impl(input, weight, bias, om, om + (size_t)2 * kh * kw * g.Ho * g.Wo, output, columns, stats, -1.0f, B, C, H,
+                            W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, workspace, workspace_bytes, stream, 1);
+}
+extern "C" int cnuda_dcn_v2_backward_om(const float* input, const float* weight, const float* bias, const float* om,
+                                        const float* grad_output, const float* columns, float* grad_input,
+                                        int accumulate_input, float* grad_om, float* grad_weight, float* grad_bias, int B,
+                                        int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                                        int dw, int dg, void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(om && grad_om && dg == 1 && W >= 2, "cnuda_dcn_v2_backward_om: needs deformable_group == 1 and width >= 2");
+    DcnGeom g;
+    if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, "cnuda_dcn_v2_backward_om")) return rc;
+    const size_t mo = (size_t)2 * kh * kw * g.Ho * g.Wo;
+    return dcn_backward_impl(input, weight, bias, om, om + mo, grad_output, columns, grad_input, accumulate_input, grad_om,
+                             grad_om + mo, grad_weight, grad_bias, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, workspace,
+                             workspace_bytes, stream, 1);
+}
+
+static int dcn_backward_impl(const float* input, const float* weight, const float* bias,
+                             const float* offset, const float* mask, const float* grad_output,
+                             const float* columns, float* grad_input, int accumulate_input,
+                             float* grad_offset, float* grad_mask, float* grad_weight, float* grad_bias, int B,
+                             int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                             int dh, int dw, int dg, void* workspace, size_t workspace_bytes,
+                             cnuda_stream_t stream, int om_mode) {
     CNUDA_REQUIRE(!columns || dg == 1, "cnuda_dcn_v2_backward_cols: columns input needs deformable_group == 1");
     CNUDA_REQUIRE(input && weight && offset && mask && grad_output && grad_input && grad_offset && grad_mask &&
                       grad_weight && grad_bias,
@@ -1906,6 +1974,10 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
     (void)bias;
     DcnGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, "cnuda_dcn_v2_backward")) return rc;
+    if (om_mode) {      // offsets / mask and their gradients as rows of 3T-channel tensors; the mask's gradient as its logit's
+        g.off_bs = g.mask_bs = g.goff_bs = g.gmask_bs = 3 * kh * kw * g.Ho * g.Wo;
+        g.gmask_logit = 1;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int T = kh * kw, HoWo = g.Ho * g.Wo;
     // (every data-gradient walk below ADDS into grad_input -- window flushes and strays are atomics -- so a caller that

@@ -71,11 +71,15 @@ class _Sig:
     cnuda_dcn_v2_forward_act = (_I, [_P] * 7 + [_F] + [_I] * 14 + _WS)
     cnuda_dcn_v2_forward_stats = (_I, [_P] * 8 + [_I] * 16 + _WS)
     cnuda_dcn_v2_stats_block = (_I, [_I] * 14 + [_P])
+    cnuda_dcn_v2_forward_om = (_I, [_P] * 7 + [_I] * 16 + _WS)
+    cnuda_dcn_v2_backward_om = (_I, [_P] * 7 + [_I] + [_P] * 3 + [_I] * 14 + _WS)
     cnuda_dcn_v2_backward_cols = (_I, [_P] * 12 + [_I] * 14 + _WS)
     cnuda_dcn_v2_backward_acc = (_I, [_P] * 8 + [_I] + [_P] * 4 + [_I] * 14 + _WS)
     cnuda_conv2d_workspace_bytes = (c_size_t, [_I] * 11)
     cnuda_conv2d_forward = (_I, [_P] * 4 + [_I] * 11 + [_F] + _WS)
     cnuda_conv2d_forward_res = (_I, [_P] * 5 + [_I] * 11 + [_F] + _WS)
+    cnuda_conv2d_rowsig_supported = (_I, [_I] * 11)
+    cnuda_conv2d_forward_rowsig = (_I, [_P] * 4 + [_I] * 12 + _WS)
     cnuda_conv2d_backward_data = (_I, [_P] * 3 + [_I] * 11 + _WS)
     cnuda_conv2d_backward_data_add = (_I, [_P] * 5 + [_I] * 11 + _WS)
     cnuda_conv2d_stats_block = (_I, [_I] * 11 + [_P, _P])

@@ -47,8 +47,12 @@ def _conv_geom(x, weight, stride, padding):
 
 class _Conv2d(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, act_slope, pack_token=0, stats_box=None, norm=None):
-        """norm: None, or (x_raw, mean, invstd, gamma, beta, imgs_per_group) when `x` is the never-written output of a
+    def forward(ctx, x, weight, bias, stride, padding, act_slope, pack_token=0, stats_box=None, norm=None, sig_from=None):
+        """sig_from (private, DCN's offset convolution): output channels >= sig_from get a sigmoid in the epilogue
+        (cnuda_conv2d_forward_rowsig) and the gradient this node RECEIVES for them is taken as the gradient of their LOGITS
+        -- the deformable convolution's backward multiplies by m (1 - m) where it stores (cnuda_dcn_v2_backward_om) -- so
+        the backward below is the plain convolution's.
+        norm: None, or (x_raw, mean, invstd, gamma, beta, imgs_per_group) when `x` is the never-written output of a
         BatchNorm + ReLU in deferred mode (batch_norm_act(defer_apply=True)): the kernel reads x_raw and normalises while it
         stages it (cnuda_conv2d_forward_norm_input); the gradient this node returns for `x` is the one with respect to the
         normalised activation, exactly what the BatchNorm's backward expects."""
@@ -81,6 +85,9 @@ class _Conv2d(Function):
                 check(L.cnuda_conv2d_forward_norm_input(ptr(xr), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), int(ipg),
                                                         ptr(weight), ptr(bias), ptr(y), ptr(stats), *g, float(act_slope),
                                                         wp, wn, stream()), 'conv2d_forward_norm_input')
+            elif sig_from is not None:
+                check(L.cnuda_conv2d_forward_rowsig(ptr(x), ptr(weight), ptr(bias), ptr(y), int(sig_from), *g, wp, wn, stream()),
+                      'conv2d_forward_rowsig')
             elif stats is None:
                 check(L.cnuda_conv2d_forward(ptr(x), ptr(weight), ptr(bias), ptr(y), *g, float(act_slope),
                                              wp, wn, stream()), 'conv2d_forward')
@@ -130,7 +137,17 @@ class _Conv2d(Function):
             else:
                 check(L.cnuda_conv2d_backward_weight(ptr(x), ptr(gy), ptr(gw_buf), ptr(gb_buf), *g, wp, wn, stream()),
                       'conv2d_backward_weight')
-        return gx, gw, gb, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None
+
+
+def conv2d_rowsig(x, weight, bias, stride, padding, sig_from, pack_token=0):
+    """(private to libs.DCNv2.dcn_v2.DCN) y = conv2d(x, weight) + bias with a sigmoid on the channels >= sig_from; the
+    gradient handed back to this node must already be that of those channels' logits.  None where no kernel has the
+    epilogue (cnuda_conv2d_rowsig_supported): the caller then takes the split path."""
+    g = _conv_geom(x, weight, stride, padding)
+    if bias is None or not lib().cnuda_conv2d_rowsig_supported(*g):
+        return None
+    return _Conv2d.apply(x, weight, bias, stride, padding, -1.0, pack_token, None, None, int(sig_from))
 
 
 EPILOGUE_STATS = True      # (A/B measurements flip it: profiles/microbench/ab_bn_stats.py)
@@ -147,11 +164,11 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act_slope=-1.0, pack_token
             raise RuntimeError("conv2d: the input is a deferred BatchNorm output, but no apply-on-load kernel takes this "
                                "convolution (cnuda_conv2d_norm_input_supported); ask batch_norm_act to apply it")
     if not (emit_stats and EPILOGUE_STATS):
-        return _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope), pack_token, None, norm)
+        return _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope), pack_token, None, norm, None)
     # emit_stats: the caller's next layer is a train-mode BatchNorm over y.  Where the kernel can, it leaves
     # sum / sum of squares per (pixel block, channel) beside y; batch_norm_act finds them on the tensor.
     box = []
-    y = _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope), pack_token, box, norm)
+    y = _Conv2d.apply(x, weight, bias, stride, padding, float(act_slope), pack_token, box, norm, None)
     if box:
         y._cnuda_bn_stats = box[0]
     return y

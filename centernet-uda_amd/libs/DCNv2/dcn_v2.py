@@ -18,6 +18,9 @@ import _ext as _backend
 # default keeps them (one 1 GB side output per 128 x 128 layer, read once by a plain-GEMM weight gradient)
 import os as _os
 _KEEP_COLUMNS = _os.environ.get('CNUDA_DCN_KEEP_COLS', '1') != '0'
+# CNUDA_DCN_OM=0 (or dcn_v2.USE_OM = False): DCN.forward materialises offset and mask tensors like the reference
+# (split + sigmoid kernel, its backward twin) instead of reading them out of the offset convolution's output
+USE_OM = _os.environ.get('CNUDA_DCN_OM', '1') != '0'
 
 
 def _pair(v):
@@ -68,6 +71,46 @@ class _DeformConvFn(torch.autograd.Function):
             slot.included.append(acc)
         return g_in, g_off, g_mask, (None if sw is not None else g_w), (None if sb is not None else g_b), \
             None, None, None, None, None, None, None
+
+
+class _DeformConvOmFn(torch.autograd.Function):
+    """The same operation with offsets and mask read out of `om`, the 3T-channel output of the layer's own offset convolution
+    whose mask channels already went through the sigmoid (ops.conv2d_rowsig): no split / concatenate / sigmoid tensors in the
+    forward, and ONE gradient tensor for `om` in the backward -- the offsets' gradient and the gradient of the mask's LOGIT,
+    which is what that convolution's backward consumes (round 6; `DCN.forward` only, deformable_groups == 1)."""
+
+    @staticmethod
+    def forward(ctx, input, om, weight, bias, stride, padding, dilation, pack_token=0, stats_box=None, regime=0):
+        kh, kw = weight.shape[2], weight.shape[3]
+        ctx.regime = int(regime)
+        from hip_runtime.fanout import slot_of
+        ctx.slot = slot_of(input)
+        ctx.geom = (kh, kw) + _pair(stride) + _pair(padding) + _pair(dilation)
+        keep = any(ctx.needs_input_grad[:4]) and _KEEP_COLUMNS
+        with _offset_regime(ctx.regime):
+            out, cols = _backend.dcn_v2_forward_om(input, weight, bias, om, *ctx.geom, _want_columns=keep,
+                                                   _pack_token=pack_token, _stats_box=stats_box)
+        ctx.save_for_backward(input, om, weight, bias, cols)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        input, om, weight, bias, cols = ctx.saved_tensors
+        from hip_runtime.arena import grad_sink
+        sw, sb = grad_sink(weight), grad_sink(bias)
+        slot = ctx.slot
+        acc = slot.buf if (slot is not None and slot.buf is not None and slot.owned) else None
+        with _offset_regime(ctx.regime):
+            g_in, g_om, g_w, g_b = _backend.dcn_v2_backward_om(input, weight, bias, om, grad_output, *ctx.geom, _columns=cols,
+                                                               _grad_weight=sw, _grad_bias=sb, _grad_input=acc)
+        if acc is None:
+            from hip_runtime.fanout import claim
+            claim(slot, g_in)
+        else:
+            slot.included.append(acc)
+        return g_in, g_om, (None if sw is not None else g_w), (None if sb is not None else g_b), \
+            None, None, None, None, None, None
 
 
 class _offset_regime:
@@ -154,7 +197,24 @@ class DCN(DCNv2):
         from hip_runtime.fanout import fork
         # the input feeds the offset / mask convolution AND the sampling: their gradients meet in a slot, not in the engine
         input_om, input = fork(input, 2)
-        om = self.conv_offset_mask(input_om)
+        taps = self.kernel_size[0] * self.kernel_size[1]
+        cm = self.conv_offset_mask
+        if self.deformable_groups == 1 and input.shape[3] >= 2 and USE_OM:
+            # round 6: the offset convolution's epilogue applies the mask's sigmoid and the deformable convolution reads
+            # offsets and mask out of its one output tensor (no split kernels, no offset / mask tensors of their own)
+            om = ops.conv2d_rowsig(input_om, cm.weight, cm.bias, cm.stride, cm.padding, 2 * taps, cm._pack_token)
+            if om is not None:
+                if self.training:
+                    self._census_calls += 1
+                    if self._census_calls % self.CENSUS_EVERY == 1:
+                        self._regime = self._census(om.detach()[:, :2 * taps].contiguous())
+                box = [] if (self.emit_stats and self.training and ops.EPILOGUE_STATS) else None
+                out = _DeformConvOmFn.apply(input, om, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                                            self._pack_token, box, self._regime)
+                if box:
+                    out._cnuda_bn_stats = box[0]
+                return out
+        om = cm(input_om)
         # channels [0, 2*taps) are offsets (chunks o1|o2 re-concatenated, dcn_v2.py:120-121),
         # [2*taps, 3*taps) the mask logits
         offset, mask = ops.split_offset_mask(om)

@@ -224,6 +224,23 @@ int cnuda_dcn_v2_forward_stats(const float* input, const float* weight, const fl
                                int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                                int dh, int dw, int dg, void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 
+/* Round 6 -- offsets and mask read straight out of `om` [B, 3*kh*kw, Ho, Wo], the output of DCN's own offset convolution
+ * (libs/DCNv2/dcn_v2.py:118-122: o1, o2, mask = chunk(out, 3); offset = cat(o1, o2); mask = sigmoid(mask)): channels
+ * 0 .. 2T-1 ARE the offsets, channels 2T .. 3T-1 the mask, ALREADY sigmoid (cnuda_conv2d_forward_rowsig applies it in the
+ * convolution's epilogue).  backward_om writes ONE tensor grad_om of the same shape: the offsets' gradient and the gradient of
+ * the mask's LOGIT (g * m * (1 - m), multiplied where the kernel stores) -- exactly what the offset convolution's backward
+ * consumes.  Replaces the split / concatenate / sigmoid passes of the Python layer (32 launches of a benched step).
+ * deformable_group == 1; columns / stats / accumulate_input as in forward_stats / backward_acc. */
+int cnuda_dcn_v2_forward_om(const float* input, const float* weight, const float* bias, const float* om, float* output,
+                            float* columns, float* stats, int stats_block, int stats_rows,
+                            int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                            int dh, int dw, int dg, void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+int cnuda_dcn_v2_backward_om(const float* input, const float* weight, const float* bias, const float* om,
+                             const float* grad_output, const float* columns, float* grad_input, int accumulate_input,
+                             float* grad_om, float* grad_weight, float* grad_bias,
+                             int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                             int dh, int dw, int dg, void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+
 /* Same two operations with the sampled column buffer kept between them (the
  * product's autograd path; deformable_group == 1 only): forward_cols stores
  * columns[B, kh*kw*C, Ho*Wo] (rows in (tap, channel) order, mask already applied)
@@ -282,6 +299,14 @@ int cnuda_conv2d_forward_res(const float* x, const float* weight, const float* b
                              int B, int C, int H, int W, int Cout, int kh, int kw,
                              int sh, int sw, int ph, int pw, float act_slope,
                              void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+/* forward with a sigmoid on the output channels >= sig_from (after the bias): the offset / mask convolution of a DCN layer
+ * (libs/DCNv2/dcn_v2.py:104-122: channels 2T .. 3T-1 of its output are the modulation mask's logits) when the deformable
+ * convolution reads offsets and mask out of this one tensor (cnuda_dcn_v2_forward_om).  cnuda_conv2d_rowsig_supported: 1 for
+ * the geometries that have this epilogue (at most 32 output channels, C % 16 == 0, tensors below 2 GiB, f32 matrix mode). */
+int cnuda_conv2d_rowsig_supported(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw);
+int cnuda_conv2d_forward_rowsig(const float* x, const float* weight, const float* bias, float* y, int sig_from,
+                                int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                                void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 /* forward that also leaves the statistics a train-mode BatchNorm of y needs (the layer behind almost every convolution of
  * DLA-34, backends/dla.py:37-62,150-168: the reference's cuDNN BatchNorm re-reads y for them; here the GEMM's epilogue sums
  * what it stores).  stats: [blocks][rows][2] floats = (sum, sum of squares) of y over one block of `cnuda_conv2d_stats_block`
