@@ -316,3 +316,45 @@ def test_offset_census_picks_the_kernels_and_not_the_values(sigma, want):
     assert (y1 - y0).abs().max().item() <= 1e-5 * scale
     for a, b in zip(g1, g0):
         assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize('B,C,Co,S', [(8, 64, 64, 64), (4, 128, 64, 32), (8, 512, 256, 16), (2, 32, 32, 24)],
+                         ids=['halo_tile_offsets', 'im2col_offsets', 'split_k_offsets', 'small_odd'])
+def test_offsets_and_mask_read_out_of_the_offset_convolutions_output(B, C, Co, S):
+    """Round 6: `DCN.forward` no longer materialises offset and mask tensors -- the offset convolution's epilogue applies the
+    mask's sigmoid (cnuda_conv2d_forward_rowsig: halo-tile, im2col and split-K instances), the deformable convolution reads
+    both out of that one tensor (cnuda_dcn_v2_forward_om) and its backward writes one gradient tensor with the mask's part
+    already multiplied by m (1 - m) (cnuda_dcn_v2_backward_om).  Same expressions as the split kernels it replaces
+    (libs/DCNv2/dcn_v2.py:118-122 of the reference): everything is bit-identical to the split form except grad_input, whose
+    straggler atomics may arrive in another order, and no split kernel is launched."""
+    import hip_runtime as hr
+    from libs.DCNv2 import dcn_v2
+    from test_zz_kernel_coverage import short
+    torch.manual_seed(3 + C)
+    m = dcn_v2.DCN(C, Co, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(DEV)
+    with torch.no_grad():
+        m.conv_offset_mask.weight.normal_(0, 0.5 / (9 * C) ** 0.5)
+        m.conv_offset_mask.bias.normal_(0, 0.3)
+    m.train()
+    x = torch.randn(B, C, S, S, device=DEV)
+    gy = torch.randn(B, Co, S, S, device=DEV)
+    res = {}
+    for use_om in (True, False):
+        prev, dcn_v2.USE_OM = dcn_v2.USE_OM, use_om
+        try:
+            for p in m.parameters():
+                p.grad = None
+            xx = x.clone().requires_grad_(True)
+            with hr.launch_log() as log:
+                y = m(xx)
+                y.backward(gy)
+            names = sorted(short(n) for n in log.names)
+            assert any('split_offset_mask' in n for n in names) == (not use_om), names
+            res[use_om] = [y.detach().clone(), xx.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+        finally:
+            dcn_v2.USE_OM = prev
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        if i == 1:
+            assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+        else:
+            assert torch.equal(a, b), i
