@@ -1127,9 +1127,19 @@ struct DcnPrepParams {
     float* wt;
     DcnGeo* geo;
     int wt_blocks;
+    float* zero;              // nullable: grad_input, cleared by the blocks behind the other two kinds (round 6: was a memset launch)
+    long long zero_quads;     // its size in 16-byte quads (the tensor is 16-byte aligned and a multiple of 4 elements, else nullptr)
+    int zero_first;           // first block of that kind
 };
 __global__ __launch_bounds__(256) void dcn_prep_kernel(DcnPrepParams p) {
     const DcnGeom& g = p.g;
+    if (p.zero && (int)blockIdx.x >= p.zero_first) {
+        const long long nb = (long long)gridDim.x - p.zero_first;
+        float4* z = reinterpret_cast<float4*>(p.zero);
+        for (long long i = ((long long)blockIdx.x - p.zero_first) * 256 + threadIdx.x; i < p.zero_quads; i += nb * 256)
+            z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     const int T = g.kh * g.kw;
     if ((int)blockIdx.x < p.wt_blocks) {          // wt[(tap*C + c)][o] = w[o][c][tap]
         const long long total = (long long)g.Co * g.C * T;
@@ -1144,7 +1154,7 @@ __global__ __launch_bounds__(256) void dcn_prep_kernel(DcnPrepParams p) {
     if (!p.geo) return;
     const int HoWo = g.Ho * g.Wo;
     const long long total = (long long)g.B * T * HoWo;
-    const long long nb = (long long)gridDim.x - p.wt_blocks;
+    const long long nb = (long long)(p.zero ? p.zero_first : (int)gridDim.x) - p.wt_blocks;
     for (long long i = ((long long)blockIdx.x - p.wt_blocks) * 256 + threadIdx.x; i < total; i += nb * 256) {
         const int px = (int)(i % HoWo);
         const long long r = i / HoWo;
@@ -1982,7 +1992,12 @@ static int dcn_backward_impl(const float* input, const float* weight, const floa
     const int T = kh * kw, HoWo = g.Ho * g.Wo;
     // (every data-gradient walk below ADDS into grad_input -- window flushes and strays are atomics -- so a caller that
     // already holds another consumer's share of the input's gradient there passes accumulate_input and saves the sum)
-    if (!accumulate_input && hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), st) != hipSuccess)
+    // (deformable_group == 1: dcn_prep_kernel clears it beside its other work -- one launch less per layer; the walks run
+    // behind it on the same stream)
+    const long long gin_elems = (long long)B * C * H * W;
+    const bool zero_in_prep = !accumulate_input && dg == 1 && (gin_elems & 3) == 0 && (reinterpret_cast<uintptr_t>(grad_input) & 15) == 0;
+    if (!accumulate_input && !zero_in_prep &&
+        hipMemsetAsync(grad_input, 0, (size_t)gin_elems * sizeof(float), st) != hipSuccess)
         return check_launch("cnuda_dcn_v2_backward(memset)");
     if (dg != 1) {
         launch_channel_sum(grad_output, grad_bias, B, Cout, HoWo, st);
@@ -2063,8 +2078,10 @@ static int dcn_backward_impl(const float* input, const float* weight, const floa
             // transposed weights of the 1x1 GEMM + (fused form) the geometry records, one launch
             const int wt_blocks = stream_grid((long long)q.T * C * Cout, 256);
             const int geo_blocks = q.fused_consumers ? stream_grid((long long)B * q.T * HoWo, 256) : 0;
-            DcnPrepParams pp{g, weight, offset, mask, wt, q.fused_consumers ? geo : nullptr, wt_blocks};
-            CNUDA_LAUNCH(dcn_prep_kernel, dim3(wt_blocks + geo_blocks), dim3(256), 0, st, pp);
+            const int zero_blocks = zero_in_prep ? stream_grid(gin_elems / 4, 256) : 0;
+            DcnPrepParams pp{g, weight, offset, mask, wt, q.fused_consumers ? geo : nullptr, wt_blocks,
+                             zero_in_prep ? grad_input : nullptr, gin_elems / 4, wt_blocks + geo_blocks};
+            CNUDA_LAUNCH(dcn_prep_kernel, dim3(wt_blocks + geo_blocks + zero_blocks), dim3(256), 0, st, pp);
         }
         if (int rc = cnuda_conv2d_forward(grad_output, wt, nullptr, dcol, B, Cout, g.Ho, g.Wo, q.T * C, 1, 1, 1, 1, 0,
                                           0, -1.0f, gemm_ws, q.gemm_bytes, stream))
