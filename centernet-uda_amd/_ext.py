@@ -111,7 +111,7 @@ def dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kernel_h, ke
 # include/centernet_uda_hip.h, cnuda_dcn_v2_forward_om.  Used by libs.DCNv2.dcn_v2.DCN only; deformable_group == 1.
 # ---------------------------------------------------------------------------------------------------------------------
 def dcn_v2_forward_om(input, weight, bias, om, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
-                      _want_columns=False, _pack_token=0, _stats_box=None):
+                      _want_columns=False, _pack_token=0, _stats_box=None, _act_slope=-1.0, _pack_version=None):
     hr.require_gpu(input, weight, bias, om)
     input, weight, bias, om = [hr.f32c(t) for t in (input, weight, bias, om)]
     B, C, H, W = input.shape
@@ -130,7 +130,7 @@ def dcn_v2_forward_om(input, weight, bias, om, kernel_h, kernel_w, stride_h, str
     ws = hr.workspace(L.cnuda_dcn_v2_workspace_bytes(*geom), input.device)
     hr.prof_arm('dcn_fwd', B, C, H, W, Co, kernel_h, kernel_w, Ho, Wo)
     stats, blk, nrows = None, 0, 0
-    if _stats_box is not None:
+    if _stats_box is not None and _act_slope < 0:
         import ctypes
         rows = ctypes.c_int(0)
         blk = L.cnuda_dcn_v2_stats_block(*geom, ctypes.byref(rows))
@@ -138,9 +138,10 @@ def dcn_v2_forward_om(input, weight, bias, om, kernel_h, kernel_w, stride_h, str
             nrows = rows.value
             stats = torch.empty(((B * Ho * Wo + 127) // 128 * (128 // blk), nrows, 2), dtype=torch.float32, device=input.device)
             _stats_box.append((stats, blk, nrows, 0))
-    with hr.pack_stamp(_pack_token, weight):
+    with hr.pack_stamp(_pack_token, weight, _pack_version):
         hr.check(L.cnuda_dcn_v2_forward_om(hr.ptr(input), hr.ptr(weight), hr.ptr(bias), hr.ptr(om), hr.ptr(out), hr.ptr(cols),
-                                           hr.ptr(stats), blk, nrows, *geom, hr.ptr(ws), ws.numel(), hr.stream()),
+                                           hr.ptr(stats), blk, nrows, float(_act_slope), *geom, hr.ptr(ws), ws.numel(),
+                                           hr.stream()),
                  'dcn_v2_forward_om')
     return out, cols
 

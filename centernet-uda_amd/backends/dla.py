@@ -349,7 +349,17 @@ class DeformConv(nn.Module):
             # offsets / mask from the unchanged 27-channel convolution, then DCN + BatchNorm + ReLU as one launch
             import _ext
             c = self.conv
-            offset, mask = ops.split_offset_mask(c.conv_offset_mask(x))
+            from libs.DCNv2 import dcn_v2 as _dcn
+            cm = c.conv_offset_mask
+            taps = c.kernel_size[0] * c.kernel_size[1]
+            # (round 6) offsets and mask straight out of the offset convolution's output, its mask rows sigmoid in the epilogue
+            om = ops.conv2d_rowsig(x, cm.weight, cm.bias, cm.stride, cm.padding, 2 * taps, cm._pack_token) \
+                if (_dcn.USE_OM and c.deformable_groups == 1 and x.shape[3] >= 2) else None
+            if om is not None:
+                return _ext.dcn_v2_forward_om(x, self._fold[0], self._fold[1], om, *c.kernel_size, *c.stride, *c.padding,
+                                              *c.dilation, _act_slope=0.0, _pack_token=self._fold_token,
+                                              _pack_version=self._fold_gen)[0]
+            offset, mask = ops.split_offset_mask(cm(x))
             return _ext.dcn_v2_forward(x, self._fold[0], self._fold[1], offset, mask, *c.kernel_size, *c.stride,
                                        *c.padding, *c.dilation, c.deformable_groups, _act_slope=0.0,
                                        _pack_token=self._fold_token, _pack_version=self._fold_gen)

@@ -1940,7 +1940,8 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
 // gradient of the mask's LOGIT (the walk multiplies by m (1 - m) where it stores).  No split / concatenate / sigmoid passes:
 // 32 launches of a benched step and two tensors per layer less (round 6).  deformable_group == 1.
 extern "C" int cnuda_dcn_v2_forward_om(const float* input, const float* weight, const float* bias, const float* om,
-                                       float* output, float* columns, float* stats, int stats_block, int stats_rows, int B,
+                                       float* output, float* columns, float* stats, int stats_block, int stats_rows,
+                                       float act_slope, int B,
                                        int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
                                        int dw, int dg, void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
     CNUDA_REQUIRE(om && dg == 1 && W >= 2, "cnuda_dcn_v2_forward_om: needs deformable_group == 1 and width >= 2");
@@ -1953,8 +1954,9 @@ extern "C" int cnuda_dcn_v2_forward_om(const float* input, const float* weight, 
                       "cnuda_dcn_v2_forward_om: the statistics buffer was sized for blocks of %d pixels x %d rows, this call "
                       "writes %d x %d", stats_block, stats_rows, blk, rows);
     }
-    return dcn_forward_impl(input, weight, bias, om, om + (size_t)2 * kh * kw * g.Ho * g.Wo, output, columns, stats, -1.0f, B, C, H,
-                            W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, workspace, workspace_bytes, stream, 1);
+    CNUDA_REQUIRE(!stats || act_slope < 0.0f, "cnuda_dcn_v2_forward_om: statistics are those of the output before an activation");
+    return dcn_forward_impl(input, weight, bias, om, om + (size_t)2 * kh * kw * g.Ho * g.Wo, output, columns, stats, act_slope, B, C,
+                            H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, workspace, workspace_bytes, stream, 1);
 }
 extern "C" int cnuda_dcn_v2_backward_om(const float* input, const float* weight, const float* bias, const float* om,
                                         const float* grad_output, const float* columns, float* grad_input,

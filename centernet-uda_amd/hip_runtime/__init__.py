@@ -71,7 +71,7 @@ class _Sig:
     cnuda_dcn_v2_forward_act = (_I, [_P] * 7 + [_F] + [_I] * 14 + _WS)
     cnuda_dcn_v2_forward_stats = (_I, [_P] * 8 + [_I] * 16 + _WS)
     cnuda_dcn_v2_stats_block = (_I, [_I] * 14 + [_P])
-    cnuda_dcn_v2_forward_om = (_I, [_P] * 7 + [_I] * 16 + _WS)
+    cnuda_dcn_v2_forward_om = (_I, [_P] * 7 + [_I] * 2 + [_F] + [_I] * 14 + _WS)
     cnuda_dcn_v2_backward_om = (_I, [_P] * 7 + [_I] + [_P] * 3 + [_I] * 14 + _WS)
     cnuda_dcn_v2_backward_cols = (_I, [_P] * 12 + [_I] * 14 + _WS)
     cnuda_dcn_v2_backward_acc = (_I, [_P] * 8 + [_I] + [_P] * 4 + [_I] * 14 + _WS)

@@ -233,6 +233,7 @@ int cnuda_dcn_v2_forward_stats(const float* input, const float* weight, const fl
  * deformable_group == 1; columns / stats / accumulate_input as in forward_stats / backward_acc. */
 int cnuda_dcn_v2_forward_om(const float* input, const float* weight, const float* bias, const float* om, float* output,
                             float* columns, float* stats, int stats_block, int stats_rows,
+                            float act_slope /* < 0 none, 0 ReLU: the BatchNorm-folded inference path, as forward_act */,
                             int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                             int dh, int dw, int dg, void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 int cnuda_dcn_v2_backward_om(const float* input, const float* weight, const float* bias, const float* om,
