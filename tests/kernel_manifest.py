@@ -409,15 +409,32 @@ MANIFEST = {
         'tests/test_gpu_losses.py::test_uda_losses_golden',
         'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
     ],
+    # (round 6: DCN.forward reads offsets / mask out of the offset convolution's output; the split pair remains for
+    # DCNv2.forward(input, offset, mask)'s callers and CNUDA_DCN_OM=0)
     'split_offset_mask_bwd_kernel': [
         'tests/test_gpu_ops.py::test_cat_add_split',
-        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
-        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+        'tests/test_gpu_dcn.py::test_offsets_and_mask_read_out_of_the_offset_convolutions_output',
     ],
     'split_offset_mask_kernel': [
         'tests/test_gpu_ops.py::test_cat_add_split',
-        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
-        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
+        'tests/test_gpu_dcn.py::test_offsets_and_mask_read_out_of_the_offset_convolutions_output',
+    ],
+    # round 6: the offset convolution with the mask's sigmoid in its epilogue (cnuda_conv2d_forward_rowsig), bit-identical to
+    # convolution + split kernel in these tests; values against the reference fixtures through every DLA step test
+    'hconv_kernel<32, 128, HconvFwdSig>': [
+        'tests/test_gpu_dcn.py::test_offsets_and_mask_read_out_of_the_offset_convolutions_output[halo_tile_offsets',
+    ],
+    'hconv_kernel<32, 256, HconvFwdSig>': [
+        'tests/test_gpu_dcn.py::test_offsets_and_mask_read_out_of_the_offset_convolutions_output[halo_tile_256_offsets',
+    ],
+    'igemm_fwd_splitk_kernel<32, ConvFwdBufSigLoader>': [
+        'tests/test_gpu_dcn.py::test_offsets_and_mask_read_out_of_the_offset_convolutions_output[split_k',
+    ],
+    'splitk_reduce_kernel<ConvFwdBufSigLoader>': [
+        'tests/test_gpu_dcn.py::test_offsets_and_mask_read_out_of_the_offset_convolutions_output[split_k',
+    ],
+    'igemm_fwd_kernel<32, ConvFwdBufSigLoader, false>': [
+        'tests/test_gpu_dcn.py::test_offsets_and_mask_read_out_of_the_offset_convolutions_output[small_odd',
     ],
     # ---- kernels only the other BASELINE configs launch (round 5: the guard runs configs[0], [1], [3], [4] at full size too) ----
     'act_bwd_kernel': [           # LeakyReLU(0.2) gate of the discriminator's convolutions (configs[4])

@@ -318,8 +318,8 @@ def test_offset_census_picks_the_kernels_and_not_the_values(sigma, want):
         assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
 
 
-@pytest.mark.parametrize('B,C,Co,S', [(8, 64, 64, 64), (4, 128, 64, 32), (8, 512, 256, 16), (2, 32, 32, 24)],
-                         ids=['halo_tile_offsets', 'im2col_offsets', 'split_k_offsets', 'small_odd'])
+@pytest.mark.parametrize('B,C,Co,S', [(8, 64, 64, 64), (16, 64, 64, 128), (4, 128, 64, 32), (8, 512, 256, 16), (2, 32, 32, 24)],
+                         ids=['halo_tile_offsets', 'halo_tile_256_offsets', 'split_k4_offsets', 'split_k_offsets', 'small_odd'])
 def test_offsets_and_mask_read_out_of_the_offset_convolutions_output(B, C, Co, S):
     """Round 6: `DCN.forward` no longer materialises offset and mask tensors -- the offset convolution's epilogue applies the
     mask's sigmoid (cnuda_conv2d_forward_rowsig: halo-tile, im2col and split-K instances), the deformable convolution reads
