@@ -354,7 +354,8 @@ class DeformConv(nn.Module):
             taps = c.kernel_size[0] * c.kernel_size[1]
             # (round 6) offsets and mask straight out of the offset convolution's output, its mask rows sigmoid in the epilogue
             om = ops.conv2d_rowsig(x, cm.weight, cm.bias, cm.stride, cm.padding, 2 * taps, cm._pack_token) \
-                if (_dcn.USE_OM and c.deformable_groups == 1 and x.shape[3] >= 2) else None
+                if (_dcn.USE_OM and c.deformable_groups == 1 and x.shape[3] >= 2 and
+                    not (cm._forward_hooks or cm._forward_pre_hooks)) else None
             if om is not None:
                 return _ext.dcn_v2_forward_om(x, self._fold[0], self._fold[1], om, *c.kernel_size, *c.stride, *c.padding,
                                               *c.dilation, _act_slope=0.0, _pack_token=self._fold_token,

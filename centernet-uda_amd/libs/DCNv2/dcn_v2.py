@@ -199,7 +199,10 @@ class DCN(DCNv2):
         input_om, input = fork(input, 2)
         taps = self.kernel_size[0] * self.kernel_size[1]
         cm = self.conv_offset_mask
-        if self.deformable_groups == 1 and input.shape[3] >= 2 and USE_OM:
+        # (a forward hook on `conv_offset_mask` -- bench.measure_dcn_offsets, a user's probe -- wants that module CALLED: then,
+        # as with CNUDA_DCN_OM=0, the module runs and its output is split like the reference does)
+        hooked = bool(cm._forward_hooks or cm._forward_pre_hooks or cm._backward_hooks)
+        if self.deformable_groups == 1 and input.shape[3] >= 2 and USE_OM and not hooked:
             # round 6: the offset convolution's epilogue applies the mask's sigmoid and the deformable convolution reads
             # offsets and mask out of its one output tensor (no split kernels, no offset / mask tensors of their own)
             om = ops.conv2d_rowsig(input_om, cm.weight, cm.bias, cm.stride, cm.padding, 2 * taps, cm._pack_token)

@@ -358,3 +358,24 @@ def test_offsets_and_mask_read_out_of_the_offset_convolutions_output(B, C, Co, S
             assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
         else:
             assert torch.equal(a, b), i
+
+
+def test_a_forward_hook_on_the_offset_convolution_still_fires():
+    """`DCN.forward` calls the offset convolution's kernel directly (row-sigmoid epilogue) -- unless somebody hooked the
+    `conv_offset_mask` module (bench.measure_dcn_offsets does; so may a user's probe): then the module is CALLED, its output
+    split like the reference does, and the layer's result is the same."""
+    from libs.DCNv2 import dcn_v2
+    torch.manual_seed(9)
+    m = dcn_v2.DCN(32, 32, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(DEV)
+    with torch.no_grad():
+        m.conv_offset_mask.weight.normal_(0, 0.05)
+    x = torch.randn(2, 32, 16, 16, device=DEV)
+    with torch.no_grad():
+        want = m(x)
+        seen = []
+        h = m.conv_offset_mask.register_forward_hook(lambda mod, inp, out: seen.append(tuple(out.shape)))
+        got = m(x)
+        h.remove()
+        again = m(x)
+    assert seen == [(2, 27, 16, 16)]
+    assert torch.equal(got, want) and torch.equal(again, want)
