@@ -42,7 +42,7 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
             dilation_h, dilation_w, deformable_group)
     out = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=input.device)
     cols = None
-    if _want_columns and deformable_group == 1 and W >= 2:
+    if _want_columns and W >= 2:          # (deformable_group > 1: the groups' buffers one behind the other, same size)
         cols = torch.empty((B, T * C, Ho * Wo), dtype=torch.float32, device=input.device)
     L = hr.lib()
     nbytes = L.cnuda_dcn_v2_workspace_bytes(*geom)

@@ -1689,6 +1689,12 @@ extern "C" size_t cnuda_dcn_v2_workspace_bytes(int B, int C, int H, int W, int C
                                                int ph, int pw, int dh, int dw, int dg) {
     DcnGeom g;
     if (fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, "cnuda_dcn_v2_workspace_bytes")) return 0;
+    if (dg > 1 && W >= 2) {     // the composed path: group copies of input / weights and their gradients, one output, the inner call's
+        const int Cg = C / dg, T = kh * kw;
+        const size_t inner = cnuda_dcn_v2_workspace_bytes(B, Cg, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, 1);
+        return 2 * carve_bytes((size_t)B * Cg * H * W, 4) + 2 * carve_bytes((size_t)Cout * Cg * T, 4) +
+               carve_bytes((size_t)B * Cout * g.Ho * g.Wo, 4) + 2 * carve_bytes((size_t)Cout, 4) + carve_bytes(inner, 1) + 512;
+    }
     const DcnPlan q = make_plan(g);
     return q.fwd_bytes > q.bwd_bytes ? q.fwd_bytes : q.bwd_bytes;
 }
@@ -1738,10 +1744,15 @@ extern "C" int cnuda_dcn_v2_stats_block(int B, int C, int H, int W, int Cout, in
     return q.bm == 32 ? 32 : 64;
 }
 
+// elements per image of the offset / mask tensors and of their gradients when they are NOT the reference's own contiguous
+// tensors (0: default): rows of the offset convolution's 3T-channel output (cnuda_dcn_v2_*_om), or one deformable group's
+// rows of the dg-group tensors (the composed deformable_group > 1 path)
+struct DcnStrides { int off_bs = 0, mask_bs = 0, goff_bs = 0, gmask_bs = 0, gmask_logit = 0; };
 static int dcn_forward_impl(const float* input, const float* weight, const float* bias, const float* offset,
                             const float* mask, float* output, float* columns, float* stats, float act_slope, int B, int C,
                             int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg,
-                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream, int om_mode = 0);
+                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream,
+                            const DcnStrides* strides = nullptr);
 
 extern "C" int cnuda_dcn_v2_forward_act(const float* input, const float* weight, const float* bias,
                                         const float* offset, const float* mask, float* output, float* columns,
@@ -1778,15 +1789,48 @@ extern "C" int cnuda_dcn_v2_forward_stats(const float* input, const float* weigh
 static int dcn_forward_impl(const float* input, const float* weight, const float* bias, const float* offset,
                             const float* mask, float* output, float* columns, float* stats, float act_slope, int B, int C,
                             int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg,
-                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream, int om_mode) {
+                            void* workspace, size_t workspace_bytes, cnuda_stream_t stream, const DcnStrides* strides) {
     CNUDA_REQUIRE(input && weight && bias && offset && mask && output, "cnuda_dcn_v2_forward: null pointer");
-    CNUDA_REQUIRE(!columns || (dg == 1 && W >= 2),
-                  "cnuda_dcn_v2_forward_cols: columns output needs deformable_group == 1 and width >= 2");
+    // (deformable_group > 1: the groups' column buffers one behind the other, [dg][B][T * C / dg][Ho * Wo] -- the same bytes)
+    CNUDA_REQUIRE(!columns || W >= 2, "cnuda_dcn_v2_forward_cols: columns output needs width >= 2");
     DcnGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, "cnuda_dcn_v2_forward")) return rc;
-    if (om_mode) g.off_bs = g.mask_bs = 3 * kh * kw * g.Ho * g.Wo;      // offsets and mask are rows of one 3T-channel tensor
+    if (strides && strides->off_bs) g.off_bs = strides->off_bs;
+    if (strides && strides->mask_bs) g.mask_bs = strides->mask_bs;
     hipStream_t st = (hipStream_t)stream;
     CNUDA_REQUIRE(act_slope < 0.0f || (dg == 1 && W >= 2), "cnuda_dcn_v2_forward_act: fused activation needs deformable_group == 1 and width >= 2");
+    if (dg > 1 && W >= 2) {
+        // deformable_group > 1 (libs/DCNv2/dcn_v2.py:54-94 accepts any; testcpu.py:169-180 uses 2), round 6: the output is the sum
+        // over the groups of a deformable_group = 1 convolution of the group's C / dg input channels with its own offsets and
+        // mask -- the fast kernels run per group on a contiguous copy of the group's channels and weights, offsets / mask are
+        // read in place (batch stride of the dg-group tensors, DcnStrides); the group outputs are added in group order.
+        // (rounds 1-5: one thread per output element with global atomics in the backward: 45 ms / 1.5 s for the layer that
+        // takes 0.9 / 2.5 ms with one group, profiles/r6_dcn_dg2.txt)
+        const int Cg = C / dg, T = kh * kw, HoWo = g.Ho * g.Wo;
+        const long long HW = (long long)H * W;
+        const size_t inner = cnuda_dcn_v2_workspace_bytes(B, Cg, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, 1);
+        Carver cv(workspace, workspace_bytes);
+        float* xg = cv.take<float>((size_t)B * Cg * HW);
+        float* wg = cv.take<float>((size_t)Cout * Cg * T);
+        float* tmp = cv.take<float>((size_t)B * Cout * HoWo);
+        float* zero = cv.take<float>((size_t)Cout);
+        void* iws = cv.take<char>(inner);
+        CNUDA_REQUIRE(workspace && cv.cur <= cv.end, "cnuda_dcn_v2_forward: workspace too small");
+        if (hipMemsetAsync(zero, 0, (size_t)Cout * sizeof(float), st) != hipSuccess) return check_launch("cnuda_dcn_v2_forward(dg>1)");
+        const DcnStrides gs{dg * 2 * T * HoWo, dg * T * HoWo, 0, 0, 0};
+        for (int grp = 0; grp < dg; ++grp) {
+            if (int rc = cnuda_copy_channels(input, xg, B, Cg, HW, C, grp * Cg, Cg, 0, stream)) return rc;
+            if (int rc = cnuda_copy_channels(weight, wg, Cout, Cg, T, C, grp * Cg, Cg, 0, stream)) return rc;
+            if (int rc = dcn_forward_impl(xg, wg, grp == 0 ? bias : zero, offset + (size_t)grp * 2 * T * HoWo,
+                                          mask + (size_t)grp * T * HoWo, grp == 0 ? output : tmp,
+                                          columns ? columns + (size_t)grp * B * T * Cg * HoWo : nullptr, nullptr, -1.0f, B, Cg, H,
+                                          W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, 1, iws, inner, stream, &gs))
+                return rc;
+            if (grp > 0)
+                if (int rc = cnuda_add(output, tmp, output, (long long)B * Cout * HoWo, stream)) return rc;
+        }
+        return check_launch("cnuda_dcn_v2_forward(dg>1)");
+    }
     if (dg != 1 || W < 2) {   // the MFMA path samples horizontally adjacent pairs
         DcnNaiveParams p{g, input, weight, bias, offset, mask, nullptr, output, nullptr, nullptr, nullptr, nullptr};
         CNUDA_LAUNCH(dcn_naive_fwd_kernel, dim3(stream_grid((long long)B * Cout * g.Ho * g.Wo, 256)), dim3(256),
@@ -1920,7 +1964,7 @@ static int dcn_backward_impl(const float* input, const float* weight, const floa
                              float* grad_offset, float* grad_mask, float* grad_weight, float* grad_bias, int B,
                              int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                              int dh, int dw, int dg, void* workspace, size_t workspace_bytes,
-                             cnuda_stream_t stream, int om_mode);
+                             cnuda_stream_t stream, const DcnStrides* strides);
 extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight, const float* bias,
                                          const float* offset, const float* mask, const float* grad_output,
                                          const float* columns, float* grad_input, int accumulate_input,
@@ -1930,7 +1974,7 @@ extern "C" int cnuda_dcn_v2_backward_acc(const float* input, const float* weight
                                          cnuda_stream_t stream) {
     return dcn_backward_impl(input, weight, bias, offset, mask, grad_output, columns, grad_input, accumulate_input, grad_offset,
                              grad_mask, grad_weight, grad_bias, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, workspace,
-                             workspace_bytes, stream, 0);
+                             workspace_bytes, stream, nullptr);
 }
 
 // Offsets and mask read straight out of `om`, the 3T-channel output of DCN's own offset convolution
@@ -1955,8 +1999,10 @@ extern "C" int cnuda_dcn_v2_forward_om(const float* input, const float* weight, 
                       "writes %d x %d", stats_block, stats_rows, blk, rows);
     }
     CNUDA_REQUIRE(!stats || act_slope < 0.0f, "cnuda_dcn_v2_forward_om: statistics are those of the output before an activation");
+    const int s3 = 3 * kh * kw * g.Ho * g.Wo;      // offsets and mask are rows of one 3T-channel tensor
+    const DcnStrides ss{s3, s3, 0, 0, 0};
     return dcn_forward_impl(input, weight, bias, om, om + (size_t)2 * kh * kw * g.Ho * g.Wo, output, columns, stats, act_slope, B, C,
-                            H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, workspace, workspace_bytes, stream, 1);
+                            H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, workspace, workspace_bytes, stream, &ss);
 }
 extern "C" int cnuda_dcn_v2_backward_om(const float* input, const float* weight, const float* bias, const float* om,
                                         const float* grad_output, const float* columns, float* grad_input,
@@ -1967,9 +2013,11 @@ extern "C" int cnuda_dcn_v2_backward_om(const float* input, const float* weight,
     DcnGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, "cnuda_dcn_v2_backward_om")) return rc;
     const size_t mo = (size_t)2 * kh * kw * g.Ho * g.Wo;
+    const int s3 = 3 * kh * kw * g.Ho * g.Wo;      // offsets / mask and their gradients as rows of 3T-channel tensors; the mask's as its logit's
+    const DcnStrides ss{s3, s3, s3, s3, 1};
     return dcn_backward_impl(input, weight, bias, om, om + mo, grad_output, columns, grad_input, accumulate_input, grad_om,
                              grad_om + mo, grad_weight, grad_bias, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, workspace,
-                             workspace_bytes, stream, 1);
+                             workspace_bytes, stream, &ss);
 }
 
 static int dcn_backward_impl(const float* input, const float* weight, const float* bias,
@@ -1978,20 +2026,56 @@ static int dcn_backward_impl(const float* input, const float* weight, const floa
                              float* grad_offset, float* grad_mask, float* grad_weight, float* grad_bias, int B,
                              int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                              int dh, int dw, int dg, void* workspace, size_t workspace_bytes,
-                             cnuda_stream_t stream, int om_mode) {
-    CNUDA_REQUIRE(!columns || dg == 1, "cnuda_dcn_v2_backward_cols: columns input needs deformable_group == 1");
+                             cnuda_stream_t stream, const DcnStrides* strides) {
+    CNUDA_REQUIRE(!columns || W >= 2, "cnuda_dcn_v2_backward_cols: columns input needs width >= 2");
     CNUDA_REQUIRE(input && weight && offset && mask && grad_output && grad_input && grad_offset && grad_mask &&
                       grad_weight && grad_bias,
                   "cnuda_dcn_v2_backward: null pointer");
     (void)bias;
     DcnGeom g;
     if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, "cnuda_dcn_v2_backward")) return rc;
-    if (om_mode) {      // offsets / mask and their gradients as rows of 3T-channel tensors; the mask's gradient as its logit's
-        g.off_bs = g.mask_bs = g.goff_bs = g.gmask_bs = 3 * kh * kw * g.Ho * g.Wo;
-        g.gmask_logit = 1;
+    if (strides) {
+        if (strides->off_bs) g.off_bs = strides->off_bs;
+        if (strides->mask_bs) g.mask_bs = strides->mask_bs;
+        if (strides->goff_bs) g.goff_bs = strides->goff_bs;
+        if (strides->gmask_bs) g.gmask_bs = strides->gmask_bs;
+        g.gmask_logit = strides->gmask_logit;
     }
     hipStream_t st = (hipStream_t)stream;
     const int T = kh * kw, HoWo = g.Ho * g.Wo;
+    if (dg > 1 && W >= 2) {
+        // deformable_group > 1, composed from the deformable_group = 1 kernels (see dcn_forward_impl): per group the data
+        // gradient of its C / dg input channels, its rows of grad_offset / grad_mask (written in place through the batch strides
+        // of the dg-group tensors) and its slice of grad_weight; grad_bias by the first group's call
+        const int Cg = C / dg;
+        const long long HW = (long long)H * W;
+        const size_t inner = cnuda_dcn_v2_workspace_bytes(B, Cg, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, 1);
+        Carver cv(workspace, workspace_bytes);
+        float* xg = cv.take<float>((size_t)B * Cg * HW);
+        float* wg = cv.take<float>((size_t)Cout * Cg * T);
+        float* ging = cv.take<float>((size_t)B * Cg * HW);
+        float* gwg = cv.take<float>((size_t)Cout * Cg * T);
+        float* gbt = cv.take<float>((size_t)Cout);
+        void* iws = cv.take<char>(inner);
+        CNUDA_REQUIRE(workspace && cv.cur <= cv.end, "cnuda_dcn_v2_backward: workspace too small");
+        const DcnStrides gs{dg * 2 * T * HoWo, dg * T * HoWo, dg * 2 * T * HoWo, dg * T * HoWo, 0};
+        for (int grp = 0; grp < dg; ++grp) {
+            if (int rc = cnuda_copy_channels(input, xg, B, Cg, HW, C, grp * Cg, Cg, 0, stream)) return rc;
+            if (int rc = cnuda_copy_channels(weight, wg, Cout, Cg, T, C, grp * Cg, Cg, 0, stream)) return rc;
+            // (a caller's running sum in grad_input: the group's slice goes in, is added to, and comes back)
+            if (accumulate_input)
+                if (int rc = cnuda_copy_channels(grad_input, ging, B, Cg, HW, C, grp * Cg, Cg, 0, stream)) return rc;
+            if (int rc = dcn_backward_impl(xg, wg, bias, offset + (size_t)grp * 2 * T * HoWo, mask + (size_t)grp * T * HoWo,
+                                           grad_output, columns ? columns + (size_t)grp * B * T * Cg * HoWo : nullptr, ging,
+                                           accumulate_input, grad_offset + (size_t)grp * 2 * T * HoWo,
+                                           grad_mask + (size_t)grp * T * HoWo, gwg, grp == 0 ? grad_bias : gbt, B, Cg, H, W, Cout,
+                                           kh, kw, sh, sw, ph, pw, dh, dw, 1, iws, inner, stream, &gs))
+                return rc;
+            if (int rc = cnuda_copy_channels(ging, grad_input, B, Cg, HW, Cg, 0, C, grp * Cg, stream)) return rc;
+            if (int rc = cnuda_copy_channels(gwg, grad_weight, Cout, Cg, T, Cg, 0, C, grp * Cg, stream)) return rc;
+        }
+        return check_launch("cnuda_dcn_v2_backward(dg>1)");
+    }
     // (every data-gradient walk below ADDS into grad_input -- window flushes and strays are atomics -- so a caller that
     // already holds another consumer's share of the input's gradient there passes accumulate_input and saves the sum)
     // (deformable_group == 1: dcn_prep_kernel clears it beside its other work -- one launch less per layer; the walks run

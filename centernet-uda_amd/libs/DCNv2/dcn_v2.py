@@ -39,7 +39,7 @@ class _DeformConvFn(torch.autograd.Function):
         ctx.geom = (kh, kw) + _pair(stride) + _pair(padding) + _pair(dilation) + (deformable_groups,)
         # keep the sampled columns (a side output of the forward kernel) for the weight gradient:
         # on a 288 GB part re-reading ~0.3 GB per layer beats re-sampling the input
-        keep = deformable_groups == 1 and input.shape[3] >= 2 and any(ctx.needs_input_grad[:5]) and _KEEP_COLUMNS
+        keep = input.shape[3] >= 2 and any(ctx.needs_input_grad[:5]) and _KEEP_COLUMNS
         with _offset_regime(ctx.regime):
             if keep:
                 out, cols = _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geom, _want_columns=True,

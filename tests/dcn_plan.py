@@ -1,16 +1,19 @@
 """Which DCN backward calls CAN take the one-launch data-gradient walk (`dcn_bwd_data_kernel`): an independent
 restatement of the window rule in csrc/dcn.hip make_plan, so that a test that forces the one-launch form
 (`hip_runtime.dcn_fused_min_tiles(1)`) can assert that the kernel it means to check really ran -- and that the cases
-that fall back (deformable groups, width 1, windows beyond the LDS budget) are the expected ones."""
+that fall back (width 1, windows beyond the LDS budget) are the expected ones."""
 
 
 def one_launch_possible(H, W, k=3, s=1, p=1, d=1, dg=1):
-    if dg != 1 or W < 2:
+    # (deformable_group > 1 is composed of deformable_group = 1 calls since round 6: the same rule per group)
+    if W < 2:
         return False
     Wo = (W + 2 * p - (d * (k - 1) + 1)) // s + 1
     tc = 64
     while tc > 16 and tc // 2 >= Wo:
         tc //= 2
+    if tc == 64 and (Wo + 31) // 32 * 32 < (Wo + 63) // 64 * 64:      # (round 6: the tile width that pads the row less)
+        tc = 32
     tr = 256 // tc
     margin = 2
     wr = (tr - 1) * s + (k - 1) * d + 2 * margin + 1

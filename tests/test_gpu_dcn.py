@@ -44,6 +44,10 @@ CASES = {
     'big_offsets_oob': dict(B=2, C=16, Co=16, H=8, W=8, off_scale=6.0),
     'k1': dict(B=2, C=16, Co=8, H=6, W=7, k=1, p=0),
     'dg2': dict(B=2, C=8, Co=6, H=10, W=10, dg=2),                   # testcpu.py:169-180 uses dg=2
+    # round 6: deformable_group > 1 is composed from the deformable_group = 1 kernels per group (offsets / mask read in place
+    # through the batch strides of the dg-group tensors): 32 channels per group on the MFMA loaders, 4 groups, a window layer
+    'dg2_64ch': dict(B=2, C=64, Co=32, H=16, W=32, dg=2),
+    'dg4_odd': dict(B=1, C=32, Co=20, H=9, W=13, dg=4, off_scale=1.0),
     'c512': dict(B=1, C=512, Co=256, H=4, W=4),                      # ida_0.proj_1 shape at 128^2 input
     'width1': dict(B=1, C=4, Co=4, H=5, W=1),                          # no horizontal neighbour: generic kernels
     'width2': dict(B=2, C=16, Co=16, H=5, W=2, off_scale=1.0),
@@ -85,7 +89,7 @@ class _walk:
             can = [dcn_plan.one_launch_possible(*g) for g in self.geoms]
             if self.walk == 'one_launch' and all(can):
                 assert ran == 'one_launch', (ran, names)
-            elif self.walk == 'two_kernels' and all(g[6] == 1 and g[1] >= 2 for g in self.geoms):
+            elif self.walk == 'two_kernels' and all(g[1] >= 2 for g in self.geoms):
                 assert ran == 'two_kernels', (ran, names)
 
 
@@ -111,13 +115,14 @@ def test_forward_backward_vs_oracle(name, walk):
 
 
 def test_the_one_launch_walk_is_reachable_for_the_expected_cases():
-    """the cases above that cannot take the one-launch walk are exactly: deformable groups, width 1, and the two
-    strided layers whose LDS window exceeds the budget (they run windowless two-kernel / generic paths)"""
+    """the cases above that cannot take the one-launch walk are exactly: width 1, and the two strided layers whose LDS
+    window exceeds the budget (they run windowless two-kernel / generic paths); deformable groups are composed of
+    deformable_group = 1 calls since round 6 and follow the same rule"""
     import dcn_plan
     cannot = sorted(n for n, c in CASES.items()
                     if not dcn_plan.one_launch_possible(c['H'], c['W'], c.get('k', 3), c.get('s', 1), c.get('p', 1),
                                                         c.get('d', 1), c.get('dg', 1)))
-    assert cannot == ['dg2', 'stride2', 'stride2_wide', 'width1'], cannot
+    assert cannot == ['stride2', 'stride2_wide', 'width1'], cannot
 
 
 def test_zero_offset_identity_testcpu_32_67():
@@ -379,3 +384,23 @@ def test_a_forward_hook_on_the_offset_convolution_still_fires():
         again = m(x)
     assert seen == [(2, 27, 16, 16)]
     assert torch.equal(got, want) and torch.equal(again, want)
+
+
+@pytest.mark.parametrize('name', ['dg2', 'dg2_64ch', 'dg4_odd'])
+def test_deformable_groups_through_the_autograd_path_with_saved_columns(name):
+    """deformable_group > 1 (round 6: composed of deformable_group = 1 calls per group) through the product's autograd
+    Function, which keeps the sampled columns of every group between forward and backward: values against the C oracle."""
+    from libs.DCNv2.dcn_v2 import dcn_v2_conv
+    (x, w, b, off, m, go), geom = _case(zlib.crc32(name.encode()) % 1000, **CASES[name])
+    want = od.dcn_v2_forward(x, w, b, off, m, *geom)
+    wg = od.dcn_v2_backward(x, w, b, off, m, go, *geom)           # input, offset, mask, weight, bias
+    leaves = [t.to(DEV).requires_grad_(True) for t in (x, off, m, w, b)]
+    kh, kw, sh, sw, ph, pw, dh, dw, dg = geom
+    y = dcn_v2_conv(*leaves, (sh, sw), (ph, pw), (dh, dw), dg)
+    assert y.grad_fn.saved_tensors[5] is not None                 # the columns were kept
+    _close(y, want)
+    y.backward(go.to(DEV))
+    for got, ref, nm in zip([leaves[0].grad, leaves[1].grad, leaves[2].grad, leaves[3].grad, leaves[4].grad], wg,
+                            ['input', 'offset', 'mask', 'weight', 'bias']):
+        assert got.shape == ref.shape, nm
+        _close(got, ref)
