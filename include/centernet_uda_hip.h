@@ -186,9 +186,9 @@ int cnuda_nms(const float* heat, float* out, int B, int C, int H, int W, int nms
  * one atomic per corner (:238-252), but grad_input is still bit-reproducible only up
  * to the order of those.  deformable_group > 1 (round 6): composed of deformable_group = 1 calls on contiguous copies
  * of each group's input channels and weights (offsets / mask and their gradients in place, through their batch strides),
- * the group outputs added in group order -- 64 -> 64 at 128 x 128, B = 32, dg = 2: 1.05 / 4.6 ms forward / backward
- * against 0.9 / 2.4 ms with one group (rounds 1-5: one thread per element and global atomics, 45 ms / 1.5 s).  Width 1
- * keeps that plain path.
+ * the group outputs added in group order -- 64 -> 64 at 128 x 128, B = 32, dg = 2 with the groups' columns saved: 1.18 / 2.90 ms
+ * forward / backward against 0.89 / 2.36 ms with one group (rounds 1-5: one thread per element and global atomics, 45 ms /
+ * 1.5 s; profiles/r6_dcn_dg2.txt).  Width 1 keeps that plain path.
  * ---------------------------------------------------------------------- */
 size_t cnuda_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout, int kh, int kw,
                                     int sh, int sw, int ph, int pw, int dh, int dw, int dg);
