@@ -210,6 +210,33 @@ struct ConvFwdBufSigLoader : ConvFwdBufLoader {
     };
 };
 
+// ConvFwdBufLoader whose output ROWS are interleaved in quads: y[b][Cout / 4][Ho * Wo][4] -- channel m of pixel p at
+// ((m >> 2) * Ho*Wo + p) * 4 + (m & 3).  The DCN column gradient (a 1x1 convolution with 9 C output rows) is written this way
+// since round 6: its two consumers then read the four channels of a (pixel, tap) with ONE 16-byte load instead of four
+// 4-byte loads from rows 4 Ho*Wo bytes apart, and this epilogue stores a lane's four consecutive accumulator rows as one cell
+// without the LDS transpose of the pixel-major epilogue (igemm.cuh ig_epilogue_quads).  No bias, no activation, no residual.
+struct ConvFwdBufQuadLoader : ConvFwdBufLoader {
+    static const char* name() { return "ConvFwdBufQuadLoader"; }
+    __device__ ConvFwdBufQuadLoader(const Params& p, long long n, bool n_valid) : ConvFwdBufLoader(p, n, n_valid) {}
+    struct Out {
+        float* base;
+        size_t quad_stride;       // floats between row quads: 4 Ho*Wo
+        __device__ Out(const Params& p, long long n) {
+            const int HoWo = p.g.Ho * p.g.Wo;
+            const int ni = (int)n, b = ni / HoWo, pp = ni - b * HoWo;
+            base = p.y + (size_t)b * p.g.Co * HoWo + (size_t)pp * 4;
+            quad_stride = (size_t)HoWo * 4;
+        }
+        __device__ __forceinline__ void store(const Params&, int m, float v) { base[(size_t)(m >> 2) * quad_stride + (m & 3)] = v; }
+        static constexpr bool kVec4 = false;
+        __device__ static bool vec4_ok(const Params&) { return false; }
+        static constexpr bool kQuads = true;
+        __device__ __forceinline__ void store_quad(const Params&, int m, f32x4 v) {
+            *reinterpret_cast<f32x4*>(base + (size_t)(m >> 2) * quad_stride) = v;
+        }
+    };
+};
+
 // ConvFwdBufLoader for the calls that leave BatchNorm statistics (cnuda_conv2d_forward_stats): same gather, same epilogue
 // stores; the parameter type carries the statistics pointer, which is what turns ig_epilogue_vec4's statistics tail on.
 struct ConvFwdBufStatsLoader : ConvFwdBufLoader {
@@ -1023,7 +1050,7 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     }
     CNUDA_REQUIRE(!sk.on(), "%s: split-K plan for a loader without split-K kernels", who);
     if constexpr (std::is_same<Loader, ConvFwdBufLoader>::value || std::is_same<Loader, ConvFwdBufStatsLoader>::value ||
-                  std::is_same<Loader, ConvFwdLoader<true>>::value) {
+                  std::is_same<Loader, ConvFwdLoader<true>>::value || std::is_same<Loader, ConvFwdBufQuadLoader>::value) {
         // few chunks, several row tiles (the DCN column-gradient GEMM: a 1x1 forward with K = 64 and 9*C rows)
         static const bool shortk = !(getenv("CNUDA_SHORTK") && getenv("CNUDA_SHORTK")[0] == '0');
         if (shortk && matrix_mode() == 0 && bm == 128 && Kp <= 64 && m_tiles >= 2) {
@@ -1181,6 +1208,37 @@ extern "C" int cnuda_conv2d_forward_stats(const float* x, const float* weight, c
     if (C % IG_BK == 0)
         return launch_fwd<ConvFwdLoader<true>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
     return launch_fwd<ConvFwdLoader<false>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
+}
+
+// y = conv(x) with the output channels interleaved in quads, y[b][Cout / 4][Ho * Wo][4] (ConvFwdBufQuadLoader): the layout of
+// the DCN column gradient.  cnuda_conv2d_rowquads_supported: Cout % 4 == 0 and the geometry takes the buffer-addressed
+// implicit GEMM without a K split; elsewhere the caller keeps the plain layout.  Workspace: cnuda_conv2d_workspace_bytes.
+extern "C" int cnuda_conv2d_rowquads_supported(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph,
+                                               int pw) {
+    ConvGeom g;
+    if (fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_rowquads_supported")) return 0;
+    if (Cout % 4 != 0 || smallc_supported(C, Cout, kh, kw, sh, sw)) return 0;
+    const ConvPlan q = make_plan(g);
+    return !q.skf.on() && C % IG_BK == 0 && buffer_addressing() && q.T <= 32 &&
+           (size_t)B * C * H * W * sizeof(float) < IG_BUF_OOB;
+}
+
+extern "C" int cnuda_conv2d_forward_rowquads(const float* x, const float* weight, float* y, int B, int C, int H, int W,
+                                             int Cout, int kh, int kw, int sh, int sw, int ph, int pw, void* workspace,
+                                             size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(x && weight && y, "cnuda_conv2d_forward_rowquads: null pointer");
+    CNUDA_REQUIRE(cnuda_conv2d_rowquads_supported(B, C, H, W, Cout, kh, kw, sh, sw, ph, pw),
+                  "cnuda_conv2d_forward_rowquads: geometry without a quad-interleaved epilogue (cnuda_conv2d_rowquads_supported)");
+    ConvGeom g;
+    if (int rc = fill_geom(g, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, "cnuda_conv2d_forward_rowquads")) return rc;
+    const ConvPlan q = make_plan(g);
+    CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_conv2d_forward_rowquads: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    ConvFwdParams p{g, x, nullptr, y, -1.0f, nullptr};
+    const float* A = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),
+                                 ig_a_bytes(q.Kpf, q.Mpf), Cout, C, q.T, PACK_FWD, q.Kpf, q.Mpf, 0, st);
+    return launch_fwd<ConvFwdBufQuadLoader>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward_rowquads");
 }
 
 // y = conv(x) + bias with a sigmoid on the output channels >= sig_from: the offset / mask convolution of a DCN layer when the

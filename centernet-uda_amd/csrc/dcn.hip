@@ -801,13 +801,25 @@ struct DcnColsBufLoader {
 struct DcnGeo { int cell; float lh, lw, mask; };   // cell = h0 << 16 | (w0 & 0xffff); h0 = -32768: tap outside
 static_assert(sizeof(DcnGeo) == 16, "geometry record is one dwordx4");
 
+// channels c0 .. c0+7 of one (pixel, tap) out of the quad-interleaved column gradient: dq = its pixel's cell in row quad 0 of
+// the tap, row quads HoWo cells apart.  C % 4 == 0; a second quad past C is read clamped and the caller drops it.
+__device__ __forceinline__ void dcn_load_dcol_quads(const float* __restrict__ dq, int c0, int C, int HoWo, float (&d)[8]) {
+    const int q0 = c0 >> 2, q1 = c0 + 4 < C ? q0 + 1 : q0;
+    const float4 a = *reinterpret_cast<const float4*>(dq + (size_t)q0 * HoWo * 4);
+    const float4 b = *reinterpret_cast<const float4*>(dq + (size_t)q1 * HoWo * 4);
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
+    d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+}
+
 struct DcnCoordParams {
     DcnGeom g;
     const float *in, *off, *mask, *dcol;
     float *goff, *gmask;
     DcnGeo* geo;
 };
-// block = (64 pixels, TW tap slots); no barriers
+// block = (64 pixels, TW tap slots); no barriers.  QUADS: dcol's rows are interleaved in quads, [T * C / 4][HoWo][4] (C % 4 == 0;
+// cnuda_conv2d_forward_rowquads) -- the four channels of a (pixel, tap) are one 16-byte load.
+template <bool QUADS>
 __global__ __launch_bounds__(1024) void dcn_coord_grad_kernel(DcnCoordParams p, int tiles_per_image) {
     const DcnGeom& g = p.g;
     const int T = g.kh * g.kw, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
@@ -818,7 +830,7 @@ __global__ __launch_bounds__(1024) void dcn_coord_grad_kernel(DcnCoordParams p, 
     const float* in_b = p.in + (size_t)b * g.C * HW;
     for (int tap = threadIdx.y; tap < T; tap += blockDim.y) {
         const Tap t = make_tap(g, p.off + (size_t)b * g.off_bs, p.mask + (size_t)b * g.mask_bs, 0, tap, oy, ox);
-        const float* dc = p.dcol + ((size_t)b * T + tap) * g.C * HoWo + px;
+        const float* dc = p.dcol + ((size_t)b * T + tap) * g.C * HoWo + (QUADS ? (size_t)px * 4 : (size_t)px);
         float sm = 0.f, sh_ = 0.f, sw_ = 0.f;
         if (t.inside && g.W >= 2) {
             // The two corners of a row are ONE 8-byte load starting at column clamp(w0, 0, W-2) (halves the L1/TA
@@ -851,11 +863,12 @@ __global__ __launch_bounds__(1024) void dcn_coord_grad_kernel(DcnCoordParams p, 
             for (int c0 = 0; c0 < g.C; c0 += 8) {
                 float d[8];
                 Pair pt[8], pb[8];
+                if constexpr (QUADS) dcn_load_dcol_quads(dc, c0, g.C, HoWo, d);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int c = c0 + u < g.C ? c0 + u : g.C - 1;
                     const float* plane = in_b + (size_t)c * HW;
-                    d[u] = dc[(size_t)c * HoWo];
+                    if constexpr (!QUADS) d[u] = dc[(size_t)c * HoWo];
                     pt[u] = *reinterpret_cast<const Pair*>(plane + qT);
                     pb[u] = *reinterpret_cast<const Pair*>(plane + qB);
                 }
@@ -874,7 +887,7 @@ __global__ __launch_bounds__(1024) void dcn_coord_grad_kernel(DcnCoordParams p, 
                         f11 = t.c11 ? 1.f : 0.f;
             for (int c = 0; c < g.C; ++c) {
                 const float* plane = in_b + (size_t)c * HW;
-                const float dd = dc[(size_t)c * HoWo];
+                const float dd = QUADS ? dc[(size_t)(c >> 2) * HoWo * 4 + (c & 3)] : dc[(size_t)c * HoWo];
                 const float a00 = plane[t.o00] * f00, a01 = plane[t.o01] * f01, a10 = plane[t.o10] * f10,
                             a11 = plane[t.o11] * f11;
                 sm += dd * tap_sample(t, a00, a01, a10, a11);
@@ -936,6 +949,7 @@ __device__ __forceinline__ void dcn_scatter_window(DcnScatterCtx& x, const DcnGe
     x.WC = WSZmax ? (x.TC - 1) * g.sw + (g.kw - 1) * g.dw + 2 * margin + 1 : 0;
     x.WSZ = x.WR * x.WC;                       // == WSZmax (or 0: the window does not fit the LDS)
 }
+template <bool QUADS>
 __device__ __forceinline__ void dcn_scatter_group(const DcnScatterCtx& x, const DcnGeom& g, const DcnGeo* __restrict__ geo_b,
                                                   const float* __restrict__ dcol_b, float* __restrict__ gin_b, int c_w,
                                                   int lane) {
@@ -947,6 +961,7 @@ __device__ __forceinline__ void dcn_scatter_group(const DcnScatterCtx& x, const 
     int cc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) cc[r] = c_w + r < g.C ? c_w + r : g.C - 1;   // clamped loads; results dropped
+    if constexpr (QUADS) cc[0] = c_w < g.C ? c_w : g.C - 4;                  // (the quad's first channel: C % 4 == 0)
     const float cvf[4] = {c_w < g.C ? 1.f : 0.f, c_w + 1 < g.C ? 1.f : 0.f, c_w + 2 < g.C ? 1.f : 0.f,
                           c_w + 3 < g.C ? 1.f : 0.f};
     const bool one_row = x.TC == 64;                  // a step's 64 lanes are 64 consecutive pixels of one row
@@ -961,10 +976,16 @@ __device__ __forceinline__ void dcn_scatter_group(const DcnScatterCtx& x, const 
         asm volatile("" : "+v"(px));                  // (keeps the zero-extension next to the loads: scalar-base form)
         const unsigned long long gb = reinterpret_cast<unsigned long long>(geo_b + (size_t)f_tap * HoWo);
         o.rec = __builtin_bit_cast(DcnGeo, *reinterpret_cast<__attribute__((address_space(1))) const u32x4*>(gb + (unsigned long long)(px * 16u)));
+        if constexpr (QUADS) {       // (c_w is a multiple of 4 below C: the wave's four channels are one cell)
+            const unsigned long long db = reinterpret_cast<unsigned long long>(dcol_b + (size_t)(f_tap * g.C + cc[0]) * HoWo);
+            const f32x4 t4 = *reinterpret_cast<__attribute__((address_space(1))) const f32x4*>(db + (unsigned long long)(px * 16u));
+            o.d[0] = t4[0]; o.d[1] = t4[1]; o.d[2] = t4[2]; o.d[3] = t4[3];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const unsigned long long db = reinterpret_cast<unsigned long long>(dcol_b + (size_t)(f_tap * g.C + cc[r]) * HoWo);
-            o.d[r] = *reinterpret_cast<__attribute__((address_space(1))) const float*>(db + (unsigned long long)(px * 4u));
+            for (int r = 0; r < 4; ++r) {
+                const unsigned long long db = reinterpret_cast<unsigned long long>(dcol_b + (size_t)(f_tap * g.C + cc[r]) * HoWo);
+                o.d[r] = *reinterpret_cast<__attribute__((address_space(1))) const float*>(db + (unsigned long long)(px * 4u));
+            }
         }
         if (++f_tap == T) { f_tap = 0; ++f_grp; }
     };
@@ -1084,6 +1105,7 @@ __device__ __forceinline__ void dcn_scatter_group(const DcnScatterCtx& x, const 
 }
 
 // Workgroup = (image, TR x TC tile of output pixels (256), 16 channels); the four waves never synchronise.
+template <bool QUADS>
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int n_wg) {
     extern __shared__ __align__(16) float win[];     // 4 waves x [WSZ cells][4 channels] + 256 dump cells x 4 + claim maps
     const DcnGeom& g = p.g;
@@ -1103,8 +1125,8 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(DcnCol2imParams p, int 
     x.dump = reinterpret_cast<float4*>(win + CI_CG * p.WSZmax) + tid;
     x.claim = (lds_vu8*)(reinterpret_cast<unsigned char*>(win + CI_CG * p.WSZmax + 4 * 256) + wid * p.claim_sz);
     *x.dump = make_float4(0.f, 0.f, 0.f, 0.f);
-    dcn_scatter_group(x, g, p.geo + (size_t)b * T * HoWo, p.dcol + (size_t)b * T * g.C * HoWo,
-                      p.gin + (size_t)b * g.C * HW, cg * CI_CG + wid * 4, lane);
+    dcn_scatter_group<QUADS>(x, g, p.geo + (size_t)b * T * HoWo, p.dcol + (size_t)b * T * g.C * HoWo,
+                             p.gin + (size_t)b * g.C * HW, cg * CI_CG + wid * 4, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -1176,6 +1198,7 @@ struct DcnBwdDataParams {
     int TR, TC, tc_shift, tiles_y, tiles_x, ncg, WSZmax, claim_sz, margin;
     int nsplit;      // workgroups per tile: workgroup s takes the channel groups [s*ncg/nsplit, (s+1)*ncg/nsplit) and the taps = s (mod nsplit)
 };
+template <bool QUADS>
 __global__ __launch_bounds__(512, 6) void dcn_bwd_data_kernel(DcnBwdDataParams p, int n_wg) {
     extern __shared__ __align__(16) float win[];     // as dcn_col2im_kernel: 4 waves x [WSZ][4] + dump cells + claim maps
     const DcnGeom& g = p.g;
@@ -1208,7 +1231,7 @@ __global__ __launch_bounds__(512, 6) void dcn_bwd_data_kernel(DcnBwdDataParams p
 #pragma unroll 1
         for (int tap = part; tap < T; tap += p.nsplit) {
             const DcnGeo rec = geo_b[(size_t)tap * HoWo + px];
-            const float* dc = dcol_b + (size_t)tap * g.C * HoWo + px;
+            const float* dc = dcol_b + (size_t)tap * g.C * HoWo + (QUADS ? (size_t)px * 4 : (size_t)px);
             float sm = 0.f, sh_ = 0.f, sw_ = 0.f;
             if (rec.cell != (int)0x80000000u) {
                 const int h0 = rec.cell >> 16, w0 = (int)(short)(rec.cell & 0xffff);
@@ -1232,11 +1255,12 @@ __global__ __launch_bounds__(512, 6) void dcn_bwd_data_kernel(DcnBwdDataParams p
                 for (int c0 = 0; c0 < g.C; c0 += 8) {
                     float d[8];
                     Pair pt[8], pb[8];
+                    if constexpr (QUADS) dcn_load_dcol_quads(dc, c0, g.C, HoWo, d);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int c = c0 + u < g.C ? c0 + u : g.C - 1;
                         const float* plane = in_b + (size_t)c * HW;
-                        d[u] = dc[(size_t)c * HoWo];
+                        if constexpr (!QUADS) d[u] = dc[(size_t)c * HoWo];
                         pt[u] = *reinterpret_cast<const Pair*>(plane + qT);
                         pb[u] = *reinterpret_cast<const Pair*>(plane + qB);
                     }
@@ -1270,7 +1294,7 @@ __global__ __launch_bounds__(512, 6) void dcn_bwd_data_kernel(DcnBwdDataParams p
     const int cg_end = (part + 1) * p.ncg / p.nsplit;
 #pragma unroll 1
     for (int cg = part * p.ncg / p.nsplit; cg < cg_end; ++cg)
-        dcn_scatter_group(x, g, geo_b, dcol_b, gin_b, cg * CI_CG + wid * 4, lane);
+        dcn_scatter_group<QUADS>(x, g, geo_b, dcol_b, gin_b, cg * CI_CG + wid * 4, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -2169,8 +2193,15 @@ static int dcn_backward_impl(const float* input, const float* weight, const floa
                              zero_in_prep ? grad_input : nullptr, gin_elems / 4, wt_blocks + geo_blocks};
             CNUDA_LAUNCH(dcn_prep_kernel, dim3(wt_blocks + geo_blocks + zero_blocks), dim3(256), 0, st, pp);
         }
-        if (int rc = cnuda_conv2d_forward(grad_output, wt, nullptr, dcol, B, Cout, g.Ho, g.Wo, q.T * C, 1, 1, 1, 1, 0,
-                                          0, -1.0f, gemm_ws, q.gemm_bytes, stream))
+        // (round 6) rows interleaved in quads where the GEMM has that epilogue: one 16-byte load per (pixel, tap, 4 channels)
+        // in both consumers
+        static const bool quads_on = !(getenv("CNUDA_DCOL_QUADS") && getenv("CNUDA_DCOL_QUADS")[0] == '0');
+        const bool quads = quads_on && C % 4 == 0 && HoWo < (1 << 26) &&
+                           cnuda_conv2d_rowquads_supported(B, Cout, g.Ho, g.Wo, q.T * C, 1, 1, 1, 1, 0, 0);
+        if (int rc = quads ? cnuda_conv2d_forward_rowquads(grad_output, wt, dcol, B, Cout, g.Ho, g.Wo, q.T * C, 1, 1, 1, 1, 0, 0,
+                                                           gemm_ws, q.gemm_bytes, stream)
+                           : cnuda_conv2d_forward(grad_output, wt, nullptr, dcol, B, Cout, g.Ho, g.Wo, q.T * C, 1, 1, 1, 1, 0,
+                                                  0, -1.0f, gemm_ws, q.gemm_bytes, stream))
             return rc;
         if (q.fused_consumers) {
             DcnBwdDataParams p{g, input, dcol, geo, grad_input, grad_offset, grad_mask, q.TR, q.TC, q.tc_shift,
@@ -2179,16 +2210,19 @@ static int dcn_backward_impl(const float* input, const float* weight, const floa
             ProfScope scope(st, 3);
             scope.name("dcn_bwd_data_kernel");
             // (a wide-margin window: dynamic LDS beyond 64 KiB is opt-in)
-            CNUDA_REQUIRE(raise_dynamic_lds(reinterpret_cast<const void*>(&dcn_bwd_data_kernel), q.col2im_lds),
+            CNUDA_REQUIRE(raise_dynamic_lds(quads ? reinterpret_cast<const void*>(&dcn_bwd_data_kernel<true>)
+                                                  : reinterpret_cast<const void*>(&dcn_bwd_data_kernel<false>), q.col2im_lds),
                           "cnuda_dcn_v2_backward: dynamic LDS");
-            CNUDA_LAUNCH(dcn_bwd_data_kernel, dim3(n_wg), dim3(512), q.col2im_lds, st, p, n_wg);
+            if (quads) CNUDA_LAUNCH((dcn_bwd_data_kernel<true>), dim3(n_wg), dim3(512), q.col2im_lds, st, p, n_wg);
+            else CNUDA_LAUNCH((dcn_bwd_data_kernel<false>), dim3(n_wg), dim3(512), q.col2im_lds, st, p, n_wg);
         } else {
             {
                 DcnCoordParams p{g, input, offset, mask, dcol, grad_offset, grad_mask, geo};
                 const int tiles = ceil_div(HoWo, 64), tw = q.T < 16 ? q.T : 16;
                 ProfScope scope(st, 1);
                 scope.name("dcn_coord_grad_kernel");
-                CNUDA_LAUNCH(dcn_coord_grad_kernel, dim3(B * tiles), dim3(64, tw), 0, st, p, tiles);
+                if (quads) CNUDA_LAUNCH((dcn_coord_grad_kernel<true>), dim3(B * tiles), dim3(64, tw), 0, st, p, tiles);
+                else CNUDA_LAUNCH((dcn_coord_grad_kernel<false>), dim3(B * tiles), dim3(64, tw), 0, st, p, tiles);
             }
             {
                 DcnCol2imParams p{g, dcol, geo, grad_input, q.TR, q.TC, q.tc_shift, q.tiles_y, q.tiles_x,
@@ -2196,9 +2230,11 @@ static int dcn_backward_impl(const float* input, const float* weight, const floa
                 const int n_wg = B * q.tiles_y * q.tiles_x * q.ncg;
                 ProfScope scope(st, 2);
                 scope.name("dcn_col2im_kernel");
-                CNUDA_REQUIRE(raise_dynamic_lds(reinterpret_cast<const void*>(&dcn_col2im_kernel), q.col2im_lds),
+                CNUDA_REQUIRE(raise_dynamic_lds(quads ? reinterpret_cast<const void*>(&dcn_col2im_kernel<true>)
+                                                      : reinterpret_cast<const void*>(&dcn_col2im_kernel<false>), q.col2im_lds),
                               "cnuda_dcn_v2_backward: dynamic LDS");
-                CNUDA_LAUNCH(dcn_col2im_kernel, dim3(n_wg), dim3(256), q.col2im_lds, st, p, n_wg);
+                if (quads) CNUDA_LAUNCH((dcn_col2im_kernel<true>), dim3(n_wg), dim3(256), q.col2im_lds, st, p, n_wg);
+                else CNUDA_LAUNCH((dcn_col2im_kernel<false>), dim3(n_wg), dim3(256), q.col2im_lds, st, p, n_wg);
             }
         }
         if (int rc = check_launch("cnuda_dcn_v2_backward(data)")) return rc;

@@ -361,6 +361,32 @@ __device__ __forceinline__ void ig_epilogue_vec4(const typename Loader::Params& 
     }
 }
 
+// Epilogue for outputs whose ROWS are interleaved in quads (Out::kQuads: y[b][M / 4][pixel][4], the DCN column gradient's
+// layout since round 6).  A lane of a 32x32 MFMA tile holds, per register quad, four CONSECUTIVE rows of one pixel column
+// (mfma_row): exactly one 16-byte cell of that layout -- no LDS transpose, four stores per tile and lane, 512 contiguous
+// bytes per half wave.  M % 4 == 0 (the host's condition for the layout): a quad is inside the matrix or outside it.
+template <class O, class = void> struct IgHasQuads : std::false_type {};
+template <class O> struct IgHasQuads<O, std::void_t<decltype(O::kQuads)>> : std::true_type {};
+template <int BM, class Loader>
+__device__ __forceinline__ void ig_epilogue_quads(const typename Loader::Params& p,
+                                                  const f32x16 (&acc)[IgTile<BM>::TM][IgTile<BM>::TN], int m0, long long n0,
+                                                  int wm_off, int wn_off, int lane, int M, long long N) {
+    using T = IgTile<BM>;
+#pragma unroll
+    for (int j = 0; j < T::TN; ++j) {
+        const long long n = n0 + wn_off + j * 32 + (lane & 31);
+        if (n >= N) continue;
+        typename Loader::Out out(p, n);
+#pragma unroll
+        for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + wm_off + i * 32 + 8 * q + 4 * (lane >> 5);
+                if (m < M) out.store_quad(p, m, f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]});
+            }
+    }
+}
+
 // raw-load storage of two-phase loaders (Loader::kHasSideOutput): Loader::Raw, else an empty placeholder
 template <class Loader, bool TWO_PHASE> struct IgRaw { struct type {}; };
 template <class Loader> struct IgRaw<Loader, true> { using type = typename Loader::Raw; };
@@ -550,6 +576,10 @@ __device__ __forceinline__ void igemm_fwd_body(
         ig_store_slab<BM>(slab, acc, Mp, (long long)n_tiles * IG_BN, m0, n0, wm_off, wn_off, lane);
         return;
     }
+    if constexpr (IgHasQuads<typename Loader::Out>::value) {
+        ig_epilogue_quads<BM, Loader>(p, acc, m0, n0, wm_off, wn_off, lane, M, N);
+        return;
+    }
     if constexpr (Loader::Out::kVec4) {
         if (Loader::Out::vec4_ok(p)) {      // (uniform; the K loop ended with a barrier: the operand buffers are free)
             ig_epilogue_vec4<BM, Loader>(p, smem + wid * IG_EPI_WAVE, acc, m0, n0, wm_off, wn_off, lane, M, N);
@@ -731,6 +761,10 @@ __device__ __forceinline__ void igemm_fwd_ws_body(
         ig_store_slab<BM>(slab, acc, Mp, (long long)n_tiles * IG_BN, m0, n0, wm_off, wn_off, lane);
         return;
     }
+    if constexpr (IgHasQuads<typename Loader::Out>::value) {
+        ig_epilogue_quads<BM, Loader>(p, acc, m0, n0, wm_off, wn_off, lane, M, N);
+        return;
+    }
     if constexpr (Loader::Out::kVec4) {
         if (Loader::Out::vec4_ok(p)) {      // (the producers wrote their last stage before the last barrier)
             ig_epilogue_vec4<BM, Loader>(p, smem + wid * IG_EPI_WAVE, acc, m0, n0, wm_off, wn_off, lane, M, N);
@@ -833,6 +867,9 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_fwd_shortk_kernel(
 #pragma unroll
                 for (int c = 0; c < KP / IG_KC; ++c)
                     ig_mma_chunk<64, IG_KC, BM>(As + c * IG_KC * BM, Bs + c * IG_KC * IG_BN, acc2, wm2, wn2, lane);
+                if constexpr (IgHasQuads<typename Loader::Out>::value) {
+                    ig_epilogue_quads<64, Loader>(p, acc2, m0, n0, wm2, wn2, lane, M, N);     // (no staging: As is not touched)
+                } else {
                 __syncthreads();
                 if (Loader::Out::vec4_ok(p)) {
                     ig_epilogue_vec4<64, Loader>(p, As + wid * IG_EPI_WAVE, acc2, m0, n0, wm2, wn2, lane, M, N);
@@ -851,6 +888,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_fwd_shortk_kernel(
                             }
                     }
                 }
+                }
                 continue;
             }
         }
@@ -864,6 +902,9 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_fwd_shortk_kernel(
 #pragma unroll
         for (int c = 0; c < KP / IG_KC; ++c)
             ig_mma_chunk<BM>(As + c * IG_KC * BM, Bs + c * IG_KC * IG_BN, acc, wm_off, wn_off, lane);
+        if constexpr (IgHasQuads<typename Loader::Out>::value) {
+            ig_epilogue_quads<BM, Loader>(p, acc, m0, n0, wm_off, wn_off, lane, M, N);      // (no staging: As is not touched)
+        } else {
         __syncthreads();                 // every wave has read its last fragments: As becomes the staging area
         if (Loader::Out::vec4_ok(p)) {
             ig_epilogue_vec4<BM, Loader>(p, As + wid * IG_EPI_WAVE, acc, m0, n0, wm_off, wn_off, lane, M, N);
@@ -881,6 +922,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_fwd_shortk_kernel(
                         if (m < M) out.store(p, m, acc[i][j][r]);
                     }
             }
+        }
         }
     }
 }

@@ -80,6 +80,8 @@ class _Sig:
     cnuda_conv2d_forward_res = (_I, [_P] * 5 + [_I] * 11 + [_F] + _WS)
     cnuda_conv2d_rowsig_supported = (_I, [_I] * 11)
     cnuda_conv2d_forward_rowsig = (_I, [_P] * 4 + [_I] * 12 + _WS)
+    cnuda_conv2d_rowquads_supported = (_I, [_I] * 11)
+    cnuda_conv2d_forward_rowquads = (_I, [_P] * 3 + [_I] * 11 + _WS)
     cnuda_conv2d_backward_data = (_I, [_P] * 3 + [_I] * 11 + _WS)
     cnuda_conv2d_backward_data_add = (_I, [_P] * 5 + [_I] * 11 + _WS)
     cnuda_conv2d_stats_block = (_I, [_I] * 11 + [_P, _P])

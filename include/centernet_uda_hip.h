@@ -313,6 +313,16 @@ int cnuda_conv2d_rowsig_supported(int B, int C, int H, int W, int Cout, int kh, 
 int cnuda_conv2d_forward_rowsig(const float* x, const float* weight, const float* bias, float* y, int sig_from,
                                 int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                                 void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
+/* forward whose output channels are interleaved in quads: y[B][Cout / 4][Ho * Wo][4] (channel m of pixel p at
+ * ((m >> 2) * Ho*Wo + p) * 4 + (m & 3)); no bias, no activation.  The layout of the DCN column gradient (round 6): the
+ * gradient walk of cnuda_dcn_v2_backward reads the four channels of a (pixel, tap) with one 16-byte load.  Replaces nothing
+ * of the reference's (its dcn_v2_cuda.cu:262-275 GEMM writes [kh*kw*C][Ho*Wo] rows); internal to the backward, exported so
+ * that the layout has a value test of its own.  cnuda_conv2d_rowquads_supported: Cout % 4 == 0, C % 16 == 0, tensors below
+ * 2 GiB, no K split in the plan. */
+int cnuda_conv2d_rowquads_supported(int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw);
+int cnuda_conv2d_forward_rowquads(const float* x, const float* weight, float* y,
+                                  int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                                  void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 /* forward that also leaves the statistics a train-mode BatchNorm of y needs (the layer behind almost every convolution of
  * DLA-34, backends/dla.py:37-62,150-168: the reference's cuDNN BatchNorm re-reads y for them; here the GEMM's epilogue sums
  * what it stores).  stats: [blocks][rows][2] floats = (sum, sum of squares) of y over one block of `cnuda_conv2d_stats_block`

@@ -145,22 +145,34 @@ MANIFEST = {
         'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
         'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
     ],
-    'dcn_bwd_data_kernel': [
+    'dcn_bwd_data_kernel<true>': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[64to64_128sq_one_launch',
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[128to64_64sq_one_launch',
         'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
         'tests/test_gpu_dcn.py::test_known_answer_validity_window_open_at_minus_one_and_H',
         'tests/test_gpu_fuzz.py::test_dcn_random_geometry_vs_oracle',
     ],
-    'dcn_col2im_kernel': [
+    'dcn_bwd_data_kernel<false>': [      # (the plain column-gradient layout: C % 4 != 0 or an output-channel count the quad GEMM does not take)
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+        'tests/test_gpu_fuzz.py::test_dcn_random_geometry_vs_oracle',
+    ],
+    'dcn_col2im_kernel<true>': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
         'tests/test_gpu_dcn.py::test_autograd_module_path_and_argument_order',
         'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
     ],
-    'dcn_coord_grad_kernel': [
+    'dcn_col2im_kernel<false>': [      # (the plain column-gradient layout: C % 4 != 0 or an output-channel count the quad GEMM does not take)
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+        'tests/test_gpu_fuzz.py::test_dcn_random_geometry_vs_oracle',
+    ],
+    'dcn_coord_grad_kernel<true>': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
         'tests/test_gpu_dcn.py::test_autograd_module_path_and_argument_order',
         'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+    ],
+    'dcn_coord_grad_kernel<false>': [      # (the plain column-gradient layout: C % 4 != 0 or an output-channel count the quad GEMM does not take)
+        'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
+        'tests/test_gpu_fuzz.py::test_dcn_random_geometry_vs_oracle',
     ],
     'dcn_prep_kernel': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
@@ -244,6 +256,19 @@ MANIFEST = {
     ],
     'igemm_fwd_shortk_kernel<128, ConvFwdBufLoader, 64>': [
         'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
+        'tests/test_gpu_ops.py::test_conv2d_forward_with_quad_interleaved_output_rows[shortk',
+    ],
+    # round 6: the DCN column gradient with its rows interleaved in quads (cnuda_conv2d_forward_rowquads)
+    'igemm_fwd_shortk_kernel<128, ConvFwdBufQuadLoader, 64>': [
+        'tests/test_gpu_ops.py::test_conv2d_forward_with_quad_interleaved_output_rows[shortk',
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[64to64_128sq',
+    ],
+    'igemm_fwd_ws_kernel<128, ConvFwdBufQuadLoader, 16>': [
+        'tests/test_gpu_ops.py::test_conv2d_forward_with_quad_interleaved_output_rows[ws128',
+        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
+    ],
+    'igemm_fwd_ws_kernel<64, ConvFwdBufQuadLoader, 16>': [
+        'tests/test_gpu_ops.py::test_conv2d_forward_with_quad_interleaved_output_rows[ws64',
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
     ],
     'igemm_fwd_ws_kernel<128, ConvDgradBufLoader, 16>': [

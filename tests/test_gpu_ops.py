@@ -141,6 +141,52 @@ def test_split_k_takes_the_starved_long_k_convolutions(name):
         _close(a, b, 2e-5)
 
 
+# (B, K = input channels, H, W, rows = output channels): the DCN column-gradient GEMM's shapes -- 9 C rows over K = Cout
+ROWQUAD_CASES = {
+    'shortk_64to576': (2, 64, 32, 32, 576),          # igemm_fwd_shortk_kernel (K = 64, 4.5 row tiles: the 64-row tail tile too)
+    'ws128_128to1152': (2, 128, 16, 32, 1152),       # igemm_fwd_ws_kernel<128>
+    'ws64_256to576': (1, 256, 8, 16, 576),           # few pixel tiles: the 64-row tile
+    'rows36_ragged': (1, 32, 5, 7, 36),              # 35 pixels (no multiple of 4), 36 rows: the 32-row tile's bounds
+    'k1_rows144': (3, 16, 6, 10, 144),
+}
+
+
+@pytest.mark.parametrize('name', sorted(ROWQUAD_CASES))
+def test_conv2d_forward_with_quad_interleaved_output_rows(name):
+    """cnuda_conv2d_forward_rowquads (round 6: the layout of the DCN column gradient): y[b][m / 4][pixel][4] holds the SAME
+    bits as cnuda_conv2d_forward's y[b][m][pixel] -- same GEMM, same accumulation order, another epilogue -- and the values
+    are those of torch's CPU convolution."""
+    import hip_runtime as hr
+    from hip_runtime import ops
+    from test_zz_kernel_coverage import short
+    B, K, H, W, M = ROWQUAD_CASES[name]
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, K, H, W, generator=g)
+    w = torch.randn(M, K, 1, 1, generator=g) / K ** 0.5
+    want = F.conv2d(x, w)
+    xd, wd = x.to(DEV), w.to(DEV)
+    L = hr.lib()
+    geom = (B, K, H, W, M, 1, 1, 1, 1, 0, 0)
+    assert L.cnuda_conv2d_rowquads_supported(*geom) == (0 if os.environ.get('CNUDA_BUF') == '0' else 1)
+    if not L.cnuda_conv2d_rowquads_supported(*geom):
+        pytest.skip('no buffer addressing: the plain layout is what runs')
+    nbytes = L.cnuda_conv2d_workspace_bytes(*geom)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=DEV)
+    plain = torch.full((B, M, H, W), float('nan'), device=DEV)
+    quads = torch.full((B, M // 4, H * W, 4), float('nan'), device=DEV)
+    hr.check(L.cnuda_conv2d_forward(hr.ptr(xd), hr.ptr(wd), None, hr.ptr(plain), *geom, -1.0, hr.ptr(ws), nbytes, hr.stream()))
+    with hr.launch_log() as log:
+        hr.check(L.cnuda_conv2d_forward_rowquads(hr.ptr(xd), hr.ptr(wd), hr.ptr(quads), *geom, hr.ptr(ws), nbytes, hr.stream()))
+    torch.cuda.synchronize()
+    print(sorted(short(n) for n in log.names))
+    assert any('ConvFwdBufQuadLoader' in n for n in log.names), log.names
+    back = quads.permute(0, 1, 3, 2).reshape(B, M, H, W)           # [b][q][p][r] -> [b][4 q + r][p]
+    assert torch.equal(back, plain)
+    _close(back, want)
+    # and an unsupported geometry is refused, not written in another layout
+    assert L.cnuda_conv2d_rowquads_supported(B, K, H, W, M + 2, 1, 1, 1, 1, 0, 0) == 0
+
+
 @pytest.mark.parametrize('relu,res', [(False, False), (True, False), (True, True), (False, True)])
 @pytest.mark.parametrize('shape', [(2, 16, 10, 12), (3, 5, 7, 7), (1, 64, 2, 2), (16, 512, 4, 4)])   # (last: 4 images per workgroup)
 def test_batch_norm_train_fwd_bwd_and_running_stats(shape, relu, res):
