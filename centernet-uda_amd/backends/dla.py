@@ -198,6 +198,9 @@ class BasicBlock(nn.Module):
         return self.bn2(self.conv2(y), residual=residual, relu=True)
 
 
+CAT_FREE_ROOT = os.environ.get('CNUDA_CAT_FREE_ROOT', '1') != '0'     # (A/B measurements, tests/test_gpu_kernel_switches.py)
+
+
 class Root(nn.Module):
     def __init__(self, cin, cout):
         super().__init__()
@@ -212,7 +215,13 @@ class Root(nn.Module):
     def forward(self, *xs):
         if _use_folded(self):
             return ops.conv2d_infer(ops.cat_channels(xs), *self._fold, 1, 0, 0.0, None, self._fold_token, self._fold_gen)
-        return self.bn(self.conv(ops.cat_channels(xs)), relu=True)
+        # the convolution over the concatenation without the concatenation (round 6: ops.conv1x1_cat; 17 copies per forward
+        # pass of DLA-34 and their 17 slices in the backward pass); None where no kernel takes these sources
+        y = ops.conv1x1_cat(xs, self.conv.weight, self.conv._pack_token, emit_stats=self.conv.emit_stats and self.training) \
+            if CAT_FREE_ROOT and self.conv.kernel_size == (1, 1) and self.conv.bias is None else None
+        if y is None:
+            y = self.conv(ops.cat_channels(xs))
+        return self.bn(y, relu=True)
 
 
 class Tree(nn.Module):

@@ -245,6 +245,57 @@ struct ConvFwdBufStatsLoader : ConvFwdBufLoader {
     __device__ ConvFwdBufStatsLoader(const Params& p, long long n, bool n_valid) : ConvFwdBufLoader(p, n, n_valid) {}
 };
 
+// ---------------------------------------------------------------------------
+// A 1x1 convolution over the CHANNEL CONCATENATION of up to four tensors without the concatenation (round 6): DLA's
+// Root is conv(torch.cat(children, 1)) (backends/dla.py:150-168) -- 17 copies into concatenated buffers per forward pass
+// and 17 slices back out of their gradient per backward pass.  The K axis of the GEMM IS the concatenated channel axis:
+// chunk k0 belongs to source s with k0[s] <= k0 < k0[s + 1] (every source has a multiple of 64 channels: a 16-deep chunk
+// and a 64-column weight-gradient group never straddle two), so the loaders switch the buffer they gather from per chunk,
+// the input-gradient epilogue switches the tensor it stores to per row, and nothing is copied.
+// ---------------------------------------------------------------------------
+constexpr int CAT_MAX = 4;
+struct ConvCat {
+    const float* x[CAT_MAX];
+    int c[CAT_MAX];           // channels per source (multiples of 64)
+    int k0[CAT_MAX + 1];      // first concatenated channel of source s; k0[n] = all channels
+    int n;
+};
+struct ConvFwdCatParams : ConvFwdStatsParams {     // (x unused; stats nullable: the statistics tail is compiled in)
+    ConvCat cat;
+};
+struct ConvFwdCatLoader {
+    using Params = ConvFwdCatParams;
+    static const char* name() { return "ConvFwdCatLoader"; }
+    static constexpr bool kHasSideOutput = false;
+    const Params& p;
+    unsigned pix;             // byte offset of the pixel inside a channel plane
+    int b;
+    bool valid;
+    int ck0 = 0, src = 0, cc0 = 0;      // chunk cursor (wave-uniform): source and first channel inside it
+    __device__ ConvFwdCatLoader(const Params& pp, long long n, bool n_valid) : p(pp), valid(n_valid) {
+        const int HW = p.g.H * p.g.W;
+        const int nn = n_valid ? (int)n : 0;
+        b = nn / HW;
+        pix = (unsigned)(nn - b * HW) * 4u;
+    }
+    __device__ __forceinline__ void load(int k0, int ksub, float (&v)[8]) {
+        const int HW = p.g.H * p.g.W;
+        while (ck0 < k0) {
+            ck0 += IG_BK;
+            cc0 += IG_BK;
+            if (src < p.cat.n && cc0 >= p.cat.c[src]) { cc0 = 0; ++src; }
+        }
+        const bool in_k = src < p.cat.n;                                     // (k0 past the last channel: the sentinel)
+        const int s = in_k ? src : 0, cs = p.cat.c[s];
+        const buf_rsrc rs = ig_make_rsrc(p.cat.x[s], (unsigned)((size_t)p.g.B * cs * HW * sizeof(float)));
+        const unsigned voff = (valid && in_k) ? (unsigned)(b * cs * HW) * 4u + pix : IG_BUF_OOB;
+        const int c0 = cc0 + __builtin_amdgcn_readfirstlane(ksub);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ig_buf_load(rs, voff, (unsigned)((c0 + 2 * j) * HW) * (unsigned)sizeof(float));
+    }
+    using Out = ConvFwdLoader<true>::Out;
+};
+
 // Input gradient: gx[b][c][iy][ix] = sum_{tap,o} W[o][c][tap] * gy[b][o][(iy+ph-r)/sh][(ix+pw-s)/sw]
 // (terms exist only where the divisions are exact and land inside the output).
 struct ConvDgradParams {
@@ -381,6 +432,62 @@ struct ConvDgradBufLoader {
         }
     }
     using Out = ConvDgradLoader::Out;
+};
+
+// The input gradient of the concatenated 1x1 convolution (ConvCat above): one GEMM over all concatenated channels, row m
+// of source s stored to that source's own gradient tensor [B][c_s][H*W] -- with the other consumers' shares of that tensor's
+// gradient added per source (hip_runtime.fanout), as ConvDgradParams::add / add2 do for one tensor.
+struct ConvDgradCatParams : ConvDgradParams {      // (gx, add, add2 unused)
+    float* gxs[CAT_MAX];
+    const float* adds[CAT_MAX];
+    const float* add2s[CAT_MAX];
+    int c[CAT_MAX];
+    int n;
+};
+struct ConvDgradCatLoader : ConvDgradBufLoader {
+    using Params = ConvDgradCatParams;
+    static const char* name() { return "ConvDgradCatLoader"; }
+    __device__ ConvDgradCatLoader(const Params& p, long long n, bool n_valid) : ConvDgradBufLoader(p, n, n_valid) {}
+    struct Out {
+        int b, pp, HW;
+        __device__ Out(const Params& p, long long n) {
+            HW = p.g.H * p.g.W;
+            const int ni = (int)n;
+            b = ni / HW;
+            pp = ni - b * HW;
+        }
+        // row m of the concatenation -> its source's tensors and the element offset inside them.  The rows a wave stores with
+        // one instruction lie in one 32-row tile and every source holds a multiple of 64 rows: the source is WAVE-UNIFORM,
+        // found from the first lane's row with scalar compares (a per-lane choice among the parameter arrays would move them
+        // to scratch memory).
+        struct Dest { float* gx; const float *a1, *a2; size_t o; };
+        __device__ __forceinline__ Dest locate(const Params& p, int m) const {
+            const int mu = __builtin_amdgcn_readfirstlane(m);
+            int s = 0, k0 = 0, cs = p.c[0];
+            Dest d{p.gxs[0], p.adds[0], p.add2s[0], 0};
+#define CNUDA_CAT_STEP(i)                                                                                             \
+            if (s == i - 1 && i < p.n && mu >= k0 + cs) { k0 += cs; s = i; cs = p.c[i]; d.gx = p.gxs[i]; d.a1 = p.adds[i]; d.a2 = p.add2s[i]; }
+            CNUDA_CAT_STEP(1) CNUDA_CAT_STEP(2) CNUDA_CAT_STEP(3)
+#undef CNUDA_CAT_STEP
+            static_assert(CAT_MAX == 4, "three steps");
+            d.o = ((size_t)b * cs + (m - k0)) * HW + pp;
+            return d;
+        }
+        __device__ __forceinline__ void store(const Params& p, int m, float v) {
+            const Dest d = locate(p, m);
+            if (d.a1) v += d.a1[d.o];
+            if (d.a2) v += d.a2[d.o];
+            d.gx[d.o] = v;
+        }
+        static constexpr bool kVec4 = true;
+        __device__ static bool vec4_ok(const Params& p) { return ((p.g.H * p.g.W) & 3) == 0; }
+        __device__ __forceinline__ void store4(const Params& p, int m, f32x4 v) {
+            const Dest d = locate(p, m);
+            if (d.a1) v += *reinterpret_cast<const f32x4*>(d.a1 + d.o);
+            if (d.a2) v += *reinterpret_cast<const f32x4*>(d.a2 + d.o);
+            *reinterpret_cast<f32x4*>(d.gx + d.o) = v;
+        }
+    };
 };
 
 // Input gradient for stride > 1, one launch per parity class (py, px) of the input pixel: inside a class
@@ -690,6 +797,55 @@ struct ConvWBufLoaderC8 : ConvWBufLoader {
             const bool ok = c.valid_ && jg < K && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
             const unsigned voff = ok ? corner + (unsigned)((r * g.W + s) * (int)sizeof(float)) : IG_BUF_OOB;
             v[i] = ig_buf_load(rx, voff, (unsigned)(c0 * HW) * (unsigned)sizeof(float));
+        }
+    }
+};
+
+// The weight gradient of the concatenated 1x1 convolution: ConvWBufLoader's x operand gathered from the source that owns the
+// 64-column group (sources hold multiples of 64 channels).  1x1, stride 1, no padding: the cursor's pixel is the input pixel.
+struct ConvWCatParams : ConvWParams {              // (x unused)
+    ConvCat cat;
+};
+struct ConvWCatLoader {
+    using Params = ConvWCatParams;
+    static const char* name() { return "ConvWCatLoader"; }
+    const Params& p;
+    buf_rsrc rg;
+    IgPixelCursor c;
+    unsigned gimg;
+    __device__ ConvWCatLoader(const Params& pp, long long n, long long n_end) : p(pp) {
+        const ConvGeom& g = p.g;
+        rg = ig_make_rsrc(p.gy, (unsigned)((size_t)g.B * g.Co * g.Ho * g.Wo * sizeof(float)));
+        c.init(n, n_end, g.Ho * g.Wo, g.Wo);
+        gimg = (unsigned)(c.b_ * g.Co * g.Ho * g.Wo) * 4u;
+    }
+    __device__ __forceinline__ void advance() {
+        const ConvGeom& g = p.g;
+        c.advance(g.Ho * g.Wo, g.Wo);
+        if (c.crossed_) gimg += (unsigned)(c.crossed_ * g.Co * g.Ho * g.Wo) * 4u;
+    }
+    template <int NV, int STEP>
+    __device__ __forceinline__ void load_g(int m0, int msub, float (&v)[NV]) {
+        ig_buf_rows<NV, STEP>(rg, c, gimg, p.g.Ho * p.g.Wo, m0, msub, v);
+    }
+    template <int NV, int STEP>
+    __device__ __forceinline__ void load_b(int j0, int jsub, float (&v)[NV]) {
+        const ConvGeom& g = p.g;
+        const int HW = g.H * g.W;
+        constexpr int PER = 64 / STEP;
+#pragma unroll
+        for (int h = 0; h < NV / PER; ++h) {
+            const int jg = j0 + 64 * h;                       // wave-uniform: one source per 64 columns
+            int s = 0;
+#pragma unroll
+            for (int i = 1; i < CAT_MAX; ++i) s += (i < p.cat.n && jg >= p.cat.k0[i]) ? 1 : 0;
+            const int cs = p.cat.c[s], c0 = jg - p.cat.k0[s];
+            const buf_rsrc rx = ig_make_rsrc(p.cat.x[s], (unsigned)((size_t)g.B * cs * HW * sizeof(float)));
+            const bool ok = c.valid_ && jg < g.C;
+            const unsigned voff = ok ? (unsigned)(ig_mad24(c.b_, cs, jsub) * HW + c.pp_) * 4u : IG_BUF_OOB;
+#pragma unroll
+            for (int i = 0; i < PER; ++i)
+                v[PER * h + i] = ig_buf_load(rx, voff, (unsigned)((c0 + STEP * i) * HW) * (unsigned)sizeof(float));
         }
     }
 };
@@ -1096,6 +1252,40 @@ int launch_fwd(int bm, const typename Loader::Params& p, const float* A, int Mp,
     return check_launch(who);
 }
 
+// the tile variants of the buffer-addressed weight-gradient GEMM (ConvWBufLoader; ConvWCatLoader)
+template <class Loader>
+void launch_wgrad_buf(const ConvPlan& q, const typename Loader::Params& p, dim3 grid, float* slabs, float* bsl, hipStream_t st) {
+    const dim3 blk(IG_THREADS);
+    const dim3 blk2(2 * IG_THREADS);
+    if (q.wbm == 128 && q.wbj == 128 && wave_specialised())
+        CNUDA_LAUNCH((igemm_wgrad_ws_kernel<Loader, 128, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                           q.Jp, q.Nf, q.pix_per_split, bsl);
+    else if (q.wbm == 128 && q.wbj == 128)
+        CNUDA_LAUNCH((igemm_wgrad_kernel<Loader, 128, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                           q.Jp, q.Nf, q.pix_per_split, bsl);
+    else if (q.wbm == 128 && wave_specialised())
+        CNUDA_LAUNCH((igemm_wgrad_ws_kernel<Loader, 128, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                           q.Jp, q.Nf, q.pix_per_split, bsl);
+    else if (q.wbm == 128)
+        CNUDA_LAUNCH((igemm_wgrad_kernel<Loader, 128, 64>), grid, blk, 0, st, p, slabs, q.Mpw,
+                           q.Jp, q.Nf, q.pix_per_split, bsl);
+    else if (wave_specialised() && q.wbm == 64 && q.wbj == 128)
+        CNUDA_LAUNCH((igemm_wgrad_ws_kernel<Loader, 64, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                           q.Jp, q.Nf, q.pix_per_split, bsl);
+    else if (wave_specialised() && q.wbm == 64)
+        CNUDA_LAUNCH((igemm_wgrad_ws_kernel<Loader, 64, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
+                           q.Jp, q.Nf, q.pix_per_split, bsl);
+    else if (q.wbm == 64 && q.wbj == 128)
+        CNUDA_LAUNCH((igemm_wgrad_kernel<Loader, 64, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                           q.Jp, q.Nf, q.pix_per_split, bsl);
+    else if (q.wbm == 64)
+        CNUDA_LAUNCH((igemm_wgrad_kernel<Loader, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
+                           q.Nf, q.pix_per_split, bsl);
+    else
+        CNUDA_LAUNCH((igemm_wgrad_kernel<Loader, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
+                           q.Jp, q.Nf, q.pix_per_split, bsl);
+}
+
 }  // namespace
 }  // namespace cnuda
 
@@ -1208,6 +1398,126 @@ extern "C" int cnuda_conv2d_forward_stats(const float* x, const float* weight, c
     if (C % IG_BK == 0)
         return launch_fwd<ConvFwdLoader<true>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
     return launch_fwd<ConvFwdLoader<false>>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_forward");
+}
+
+// ---- the 1x1 convolution over a channel concatenation (ConvCat; DLA's Root) ------------------------------------------------
+namespace {
+int fill_cat(ConvCat& cat, const float* const* xs, const int* cs, int n, const char* who) {
+    CNUDA_REQUIRE(xs && cs && n >= 2 && n <= CAT_MAX, "%s: 2 .. %d sources", who, CAT_MAX);
+    int k = 0;
+    for (int i = 0; i < CAT_MAX; ++i) {
+        cat.x[i] = i < n ? xs[i] : nullptr;
+        cat.c[i] = i < n ? cs[i] : 0;
+        cat.k0[i] = k;
+        if (i < n) {
+            CNUDA_REQUIRE(xs[i] && cs[i] > 0 && cs[i] % 64 == 0, "%s: source %d: null or not a multiple of 64 channels", who, i);
+            k += cs[i];
+        }
+    }
+    cat.k0[CAT_MAX] = k;
+    for (int i = n; i < CAT_MAX; ++i) cat.k0[i] = k;
+    cat.n = n;
+    return 0;
+}
+int cat_channels(const int* cs, int n) {
+    int k = 0;
+    for (int i = 0; i < n; ++i) k += cs[i];
+    return k;
+}
+}  // namespace
+
+extern "C" int cnuda_conv2d_cat_supported(const int* cs, int n, int B, int H, int W, int Cout) {
+    if (!cs || n < 2 || n > CAT_MAX || matrix_mode() != 0) return 0;
+    for (int i = 0; i < n; ++i)
+        if (cs[i] <= 0 || cs[i] % 64 != 0) return 0;
+    const int C = cat_channels(cs, n);
+    ConvGeom g;
+    if (fill_geom(g, B, C, H, W, Cout, 1, 1, 1, 1, 0, 0, "cnuda_conv2d_cat_supported")) return 0;
+    int rows = 0;
+    if (!cnuda_conv2d_stats_block(B, C, H, W, Cout, 1, 1, 1, 1, 0, 0, &rows, nullptr)) return 0;   // (buffer-addressed, no K split, H*W % 4 == 0)
+    const ConvPlan q = make_plan(g);
+    return !q.skd.on() && !q.hw && !q.hw_s2 && wgrad_buffer_ok(g) && (size_t)B * Cout * H * W * sizeof(float) < IG_BUF_OOB;
+}
+
+extern "C" int cnuda_conv2d_cat_forward(const float* const* xs, const int* cs, int n, const float* weight, float* y,
+                                        float* stats, int B, int H, int W, int Cout, void* workspace,
+                                        size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(weight && y, "cnuda_conv2d_cat_forward: null pointer");
+    CNUDA_REQUIRE(cnuda_conv2d_cat_supported(cs, n, B, H, W, Cout), "cnuda_conv2d_cat_forward: unsupported (cnuda_conv2d_cat_supported)");
+    ConvFwdCatParams p;
+    if (int rc = fill_cat(p.cat, xs, cs, n, "cnuda_conv2d_cat_forward")) return rc;
+    const int C = p.cat.k0[CAT_MAX];
+    ConvGeom g;
+    if (int rc = fill_geom(g, B, C, H, W, Cout, 1, 1, 1, 1, 0, 0, "cnuda_conv2d_cat_forward")) return rc;
+    const ConvPlan q = make_plan(g);
+    CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_conv2d_cat_forward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    static_cast<ConvFwdParams&>(p) = ConvFwdParams{g, nullptr, nullptr, y, -1.0f, nullptr};
+    p.stats = stats;
+    p.stats_mp = q.Mpf;
+    const float* A = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),
+                                 ig_a_bytes(q.Kpf, q.Mpf), Cout, C, q.T, PACK_FWD, q.Kpf, q.Mpf, 0, st);
+    return launch_fwd<ConvFwdCatLoader>(q.bmf, p, A, q.Mpf, q.Kpf, Cout, q.Nf, st, "cnuda_conv2d_cat_forward");
+}
+
+// grad_xs[i] = input gradient of source i (+ adds[i] + add2s[i], nullable, shaped like it; either may BE grad_xs[i]); a null
+// grad_xs[i] is not allowed (a source without a gradient gets a scratch tensor from the caller).
+extern "C" int cnuda_conv2d_cat_backward_data(const float* grad_y, const float* weight, float* const* grad_xs,
+                                              const float* const* adds, const float* const* add2s, const int* cs, int n,
+                                              int B, int H, int W, int Cout, void* workspace, size_t workspace_bytes,
+                                              cnuda_stream_t stream) {
+    CNUDA_REQUIRE(grad_y && weight && grad_xs, "cnuda_conv2d_cat_backward_data: null pointer");
+    CNUDA_REQUIRE(cnuda_conv2d_cat_supported(cs, n, B, H, W, Cout), "cnuda_conv2d_cat_backward_data: unsupported (cnuda_conv2d_cat_supported)");
+    const int C = cat_channels(cs, n);
+    ConvGeom g;
+    if (int rc = fill_geom(g, B, C, H, W, Cout, 1, 1, 1, 1, 0, 0, "cnuda_conv2d_cat_backward_data")) return rc;
+    const ConvPlan q = make_plan(g);
+    CNUDA_REQUIRE(workspace && workspace_bytes >= q.dgrad_bytes, "cnuda_conv2d_cat_backward_data: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    float* Aws = reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpd, q.Mpd)));
+    const float* A = launch_pack(weight, Aws, ig_a_bytes(q.Kpd, q.Mpd), Cout, C, q.T, PACK_DGRAD, q.Kpd, q.Mpd,
+                                 round_up(Cout, IG_BK), st);
+    ConvDgradCatParams p;
+    static_cast<ConvDgradParams&>(p) = ConvDgradParams{g, grad_y, nullptr, round_up(Cout, IG_BK), nullptr, nullptr};
+    for (int i = 0; i < CAT_MAX; ++i) {
+        p.gxs[i] = i < n ? grad_xs[i] : nullptr;
+        p.adds[i] = (i < n && adds) ? adds[i] : nullptr;
+        p.add2s[i] = (i < n && add2s) ? add2s[i] : nullptr;
+        if (!p.adds[i] && p.add2s[i]) { p.adds[i] = p.add2s[i]; p.add2s[i] = nullptr; }
+        p.c[i] = i < n ? cs[i] : 0;
+        CNUDA_REQUIRE(i >= n || p.gxs[i], "cnuda_conv2d_cat_backward_data: source %d without a gradient tensor", i);
+    }
+    p.n = n;
+    return launch_fwd<ConvDgradCatLoader>(q.bmd, p, A, q.Mpd, q.Kpd, C, q.Nd, st, "cnuda_conv2d_cat_backward_data");
+}
+
+extern "C" int cnuda_conv2d_cat_backward_weight(const float* const* xs, const int* cs, int n, const float* grad_y,
+                                                float* grad_weight, int B, int H, int W, int Cout, void* workspace,
+                                                size_t workspace_bytes, cnuda_stream_t stream) {
+    CNUDA_REQUIRE(grad_y && grad_weight, "cnuda_conv2d_cat_backward_weight: null pointer");
+    CNUDA_REQUIRE(cnuda_conv2d_cat_supported(cs, n, B, H, W, Cout), "cnuda_conv2d_cat_backward_weight: unsupported (cnuda_conv2d_cat_supported)");
+    ConvWCatParams p;
+    if (int rc = fill_cat(p.cat, xs, cs, n, "cnuda_conv2d_cat_backward_weight")) return rc;
+    const int C = p.cat.k0[CAT_MAX];
+    ConvGeom g;
+    if (int rc = fill_geom(g, B, C, H, W, Cout, 1, 1, 1, 1, 0, 0, "cnuda_conv2d_cat_backward_weight")) return rc;
+    const ConvPlan q = make_plan(g);
+    CNUDA_REQUIRE(workspace && workspace_bytes >= q.wgrad_bytes, "cnuda_conv2d_cat_backward_weight: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(workspace, workspace_bytes);
+    float* slabs = cv.take<float>((size_t)q.Z * q.Mpw * q.Jp);
+    static_cast<ConvWParams&>(p) = ConvWParams{g, nullptr, grad_y};
+    {
+        ProfScope prof(st);
+        prof.name((wave_specialised() && q.wbm >= 64) ? "igemm_wgrad_ws_kernel<ConvWCatLoader, %d, %d>" : "igemm_wgrad_kernel<ConvWCatLoader, %d, %d>",
+                  q.wbm, q.wbj);
+        launch_wgrad_buf<ConvWCatLoader>(q, p, dim3(q.Jp / q.wbj, q.Mpw / q.wbm, q.Z), slabs, nullptr, st);
+    }
+    if (int rc = check_launch("cnuda_conv2d_cat_backward_weight")) return rc;
+    launch_slab_reduce(slabs, grad_weight, q.Z, q.Mpw, q.Jp, Cout, C, q.T, st, nullptr, nullptr);
+    return check_launch("cnuda_conv2d_cat_backward_weight(reduce)");
 }
 
 // y = conv(x) with the output channels interleaved in quads, y[b][Cout / 4][Ho * Wo][4] (ConvFwdBufQuadLoader): the layout of
@@ -1539,34 +1849,7 @@ extern "C" int cnuda_conv2d_backward_weight(const float* x, const float* grad_y,
                 CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoaderC8, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
                                    q.Nf, q.pix_per_split, bsl);
         } else if (buf) {
-            const dim3 blk2(2 * IG_THREADS);
-            if (q.wbm == 128 && q.wbj == 128 && wave_specialised())
-                CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split, bsl);
-            else if (q.wbm == 128 && q.wbj == 128)
-                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 128, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split, bsl);
-            else if (q.wbm == 128 && wave_specialised())
-                CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWBufLoader, 128, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split, bsl);
-            else if (q.wbm == 128)
-                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 128, 64>), grid, blk, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split, bsl);
-            else if (wave_specialised() && q.wbm == 64 && q.wbj == 128)
-                CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 128>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split, bsl);
-            else if (wave_specialised() && q.wbm == 64)
-                CNUDA_LAUNCH((igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 64>), grid, blk2, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split, bsl);
-            else if (q.wbm == 64 && q.wbj == 128)
-                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 64, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split, bsl);
-            else if (q.wbm == 64)
-                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 64, 64>), grid, blk, 0, st, p, slabs, q.Mpw, q.Jp,
-                                   q.Nf, q.pix_per_split, bsl);
-            else
-                CNUDA_LAUNCH((igemm_wgrad_kernel<ConvWBufLoader, 32, 128>), grid, blk, 0, st, p, slabs, q.Mpw,
-                                   q.Jp, q.Nf, q.pix_per_split, bsl);
+            launch_wgrad_buf<ConvWBufLoader>(q, p, grid, slabs, bsl, st);
         } else if (wave_specialised() && fast && q.wbm == 64) {
             const dim3 blk2(2 * IG_THREADS);
             if (q.wbj == 128)

@@ -696,6 +696,112 @@ def cat_channels(xs):
     return _Cat.apply(*xs)
 
 
+def _ptr_array(ts):
+    import ctypes
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+class _CatConv1x1(Function):
+    """y = conv1x1(cat(xs, 1), weight) without the concatenation (cnuda_conv2d_cat_*): DLA's Root (backends/dla.py
+    Root.forward; reference dla.py:150-168).  The input gradient of every source goes to that source's own tensor, with the
+    other consumers' shares of its gradient added in the epilogue (hip_runtime.fanout), like _Conv2d's."""
+
+    @staticmethod
+    def forward(ctx, weight, pack_token, stats_box, *xs):
+        import ctypes
+        require_gpu(weight, *xs)
+        ctx.slots = [slot_of(t) for t in xs]
+        xs = [f32c(t) for t in xs]
+        weight = f32c(weight)
+        B, _, H, W = xs[0].shape
+        cs = [int(t.shape[1]) for t in xs]
+        Co = weight.shape[0]
+        for t in xs:
+            if t.shape[0] != B or t.shape[2] != H or t.shape[3] != W:
+                raise RuntimeError("conv1x1_cat: mismatching shapes")
+        if weight.shape[1] != sum(cs) or weight.shape[2] != 1 or weight.shape[3] != 1:
+            raise RuntimeError("conv1x1_cat: weight %s for %d concatenated channels" % (tuple(weight.shape), sum(cs)))
+        g = (B, sum(cs), H, W, Co, 1, 1, 1, 1, 0, 0)
+        L = lib()
+        y = torch.empty((B, Co, H, W), dtype=torch.float32, device=weight.device)
+        wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g), y)
+        stats = None
+        if stats_box is not None:
+            rows, bpi = ctypes.c_int(0), ctypes.c_int(0)
+            blk = L.cnuda_conv2d_stats_block(*g, ctypes.byref(rows), ctypes.byref(bpi))
+            if blk:
+                nblk = B * bpi.value if bpi.value else (B * H * W + 127) // 128 * (128 // blk)
+                stats = torch.empty((nblk, rows.value, 2), dtype=torch.float32, device=weight.device)
+                stats_box.append((stats, 0 if bpi.value else blk, rows.value, bpi.value))
+        cs_arr = (ctypes.c_int * len(cs))(*cs)
+        prof_arm('conv_fwd', B, sum(cs), H, W, Co, 1, 1, H, W)
+        with pack_stamp(pack_token, weight):
+            check(L.cnuda_conv2d_cat_forward(_ptr_array(xs), cs_arr, len(xs), ptr(weight), ptr(y), ptr(stats), B, H, W, Co,
+                                             wp, wn, stream()), 'conv2d_cat_forward')
+        ctx.cs, ctx.pack_token = cs, pack_token
+        ctx.save_for_backward(weight, *xs)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        import ctypes
+        weight, xs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        cs, n = ctx.cs, len(ctx.cs)
+        B, _, H, W = xs[0].shape
+        Co = weight.shape[0]
+        g = (B, sum(cs), H, W, Co, 1, 1, 1, 1, 0, 0)
+        L = lib()
+        gy = f32c(gy)
+        cs_arr = (ctypes.c_int * n)(*cs)
+        wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g), gy)
+        gxs = [None] * n
+        if any(ctx.needs_input_grad[3:]):
+            outs, adds, add2s = [], [], []
+            for i, x in enumerate(xs):
+                if ctx.needs_input_grad[3 + i]:
+                    out, a1, a2 = accumulate_target(ctx.slots[i], x)     # the slot's content is summed in the epilogue
+                    gxs[i] = out
+                else:
+                    out, a1, a2 = torch.empty_like(x), None, None        # (a source outside the tape: its rows go to scratch)
+                outs.append(out)
+                adds.append(a1)
+                add2s.append(a2)
+            prof_arm('conv_dgrad', B, sum(cs), H, W, Co, 1, 1, H, W)
+            with pack_stamp(ctx.pack_token, weight):
+                check(L.cnuda_conv2d_cat_backward_data(ptr(gy), ptr(weight), _ptr_array(outs), _ptr_array(adds),
+                                                       _ptr_array(add2s), cs_arr, n, B, H, W, Co, wp, wn, stream()),
+                      'conv2d_cat_backward_data')
+        gw = None
+        if ctx.needs_input_grad[0]:
+            gw_buf, gw = _param_grad(weight)
+            prof_arm('conv_wgrad', B, sum(cs), H, W, Co, 1, 1, H, W)
+            check(L.cnuda_conv2d_cat_backward_weight(_ptr_array(xs), cs_arr, n, ptr(gy), ptr(gw_buf), B, H, W, Co, wp, wn,
+                                                     stream()), 'conv2d_cat_backward_weight')
+        return (gw, None, None) + tuple(gxs)
+
+
+def conv1x1_cat(xs, weight, pack_token=0, emit_stats=False):
+    """conv2d(cat(xs, 1), weight) for a 1x1 / stride 1 / bias-free convolution, or None where no kernel takes the sources as
+    they are (cnuda_conv2d_cat_supported: 2 .. 4 sources of multiples of 64 channels, H * W % 4 == 0, no K split in the
+    plan): the caller then concatenates.  emit_stats as ops.conv2d."""
+    import ctypes
+    xs = list(xs)
+    if not (2 <= len(xs) <= 4) or any(t.dim() != 4 or getattr(t, '_cnuda_deferred_bn', None) is not None for t in xs):
+        return None
+    B, _, H, W = xs[0].shape
+    cs = [int(t.shape[1]) for t in xs]
+    if not lib().cnuda_conv2d_cat_supported((ctypes.c_int * len(cs))(*cs), len(cs), B, H, W, int(weight.shape[0])):
+        return None
+    if not (emit_stats and EPILOGUE_STATS):
+        return _CatConv1x1.apply(weight, pack_token, None, *xs)
+    box = []
+    y = _CatConv1x1.apply(weight, pack_token, box, *xs)
+    if box:
+        y._cnuda_bn_stats = box[0]
+    return y
+
+
 class _SplitOffsetMask(Function):
     @staticmethod
     def forward(ctx, om):

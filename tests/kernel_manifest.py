@@ -149,30 +149,30 @@ MANIFEST = {
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[64to64_128sq_one_launch',
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle[128to64_64sq_one_launch',
         'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
-        'tests/test_gpu_dcn.py::test_known_answer_validity_window_open_at_minus_one_and_H',
         'tests/test_gpu_fuzz.py::test_dcn_random_geometry_vs_oracle',
     ],
     'dcn_bwd_data_kernel<false>': [      # (the plain column-gradient layout: C % 4 != 0 or an output-channel count the quad GEMM does not take)
         'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
         'tests/test_gpu_fuzz.py::test_dcn_random_geometry_vs_oracle',
+        'tests/test_gpu_dcn.py::test_known_answer_validity_window_open_at_minus_one_and_H',
     ],
     'dcn_col2im_kernel<true>': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
-        'tests/test_gpu_dcn.py::test_autograd_module_path_and_argument_order',
         'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
     ],
     'dcn_col2im_kernel<false>': [      # (the plain column-gradient layout: C % 4 != 0 or an output-channel count the quad GEMM does not take)
         'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
         'tests/test_gpu_fuzz.py::test_dcn_random_geometry_vs_oracle',
+        'tests/test_gpu_dcn.py::test_autograd_module_path_and_argument_order',
     ],
     'dcn_coord_grad_kernel<true>': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
-        'tests/test_gpu_dcn.py::test_autograd_module_path_and_argument_order',
         'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
     ],
     'dcn_coord_grad_kernel<false>': [      # (the plain column-gradient layout: C % 4 != 0 or an output-channel count the quad GEMM does not take)
         'tests/test_gpu_dcn.py::test_forward_backward_vs_oracle',
         'tests/test_gpu_fuzz.py::test_dcn_random_geometry_vs_oracle',
+        'tests/test_gpu_dcn.py::test_autograd_module_path_and_argument_order',
     ],
     'dcn_prep_kernel': [
         'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
@@ -258,6 +258,28 @@ MANIFEST = {
         'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
         'tests/test_gpu_ops.py::test_conv2d_forward_with_quad_interleaved_output_rows[shortk',
     ],
+    # round 6: DLA's Root as a 1x1 convolution over the concatenation without the concatenation (cnuda_conv2d_cat_*)
+    'igemm_fwd_ws_kernel<128, ConvFwdCatLoader, 16>': [
+        'tests/test_gpu_ops.py::test_conv1x1_over_a_concatenation_without_the_concatenation',
+    ],
+    'igemm_fwd_ws_kernel<64, ConvFwdCatLoader, 16>': [
+        'tests/test_gpu_ops.py::test_conv1x1_over_a_concatenation_without_the_concatenation',
+    ],
+    'igemm_fwd_ws_kernel<128, ConvDgradCatLoader, 16>': [
+        'tests/test_gpu_ops.py::test_conv1x1_over_a_concatenation_without_the_concatenation',
+    ],
+    'igemm_fwd_ws_kernel<64, ConvDgradCatLoader, 16>': [
+        'tests/test_gpu_ops.py::test_conv1x1_over_a_concatenation_without_the_concatenation',
+    ],
+    'igemm_wgrad_ws_kernel<ConvWCatLoader, 128, 128>': [
+        'tests/test_gpu_ops.py::test_conv1x1_over_a_concatenation_without_the_concatenation',
+    ],
+    'igemm_wgrad_ws_kernel<ConvWCatLoader, 128, 64>': [
+        'tests/test_gpu_ops.py::test_conv1x1_over_a_concatenation_without_the_concatenation',
+    ],
+    'igemm_wgrad_ws_kernel<ConvWCatLoader, 64, 128>': [
+        'tests/test_gpu_ops.py::test_conv1x1_over_a_concatenation_without_the_concatenation',
+    ],
     # round 6: the DCN column gradient with its rows interleaved in quads (cnuda_conv2d_forward_rowquads)
     'igemm_fwd_shortk_kernel<128, ConvFwdBufQuadLoader, 64>': [
         'tests/test_gpu_ops.py::test_conv2d_forward_with_quad_interleaved_output_rows[shortk',
@@ -269,7 +291,6 @@ MANIFEST = {
     ],
     'igemm_fwd_ws_kernel<64, ConvFwdBufQuadLoader, 16>': [
         'tests/test_gpu_ops.py::test_conv2d_forward_with_quad_interleaved_output_rows[ws64',
-        'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle',
     ],
     'igemm_fwd_ws_kernel<128, ConvDgradBufLoader, 16>': [
         'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',

@@ -141,11 +141,88 @@ def test_split_k_takes_the_starved_long_k_convolutions(name):
         _close(a, b, 2e-5)
 
 
+# (B, H, W, source channels, Cout): DLA-34's Root shapes (backends/dla.py Tree: level 2 .. 5) at sizes the CPU finishes
+CAT_CASES = {
+    'level2_64_64': (4, 32, 32, (64, 64), 64),                      # 128-row... M = 64: the 64-row tile
+    'level3_four_sources': (4, 16, 32, (128, 128, 64, 128), 128),   # a level root: x2, x1, the pooled input, tree1's output
+    'level4_three_sources': (16, 16, 32, (256, 256, 128), 256),     # (enough pixel tiles that the plan does not cut K)
+    'level5_four_m_tiles': (32, 16, 16, (512, 512, 256), 512),
+    'ragged_pixels': (3, 6, 10, (64, 128), 192),                    # 180 pixels: the last pixel tile is partial
+    'level3_128_row_tiles': (16, 64, 64, (128, 128, 64, 128), 128), # enough pixels for the 128-row forward / input-gradient tiles
+}
+
+
+@pytest.mark.parametrize('name', sorted(CAT_CASES))
+def test_conv1x1_over_a_concatenation_without_the_concatenation(name):
+    """ops.conv1x1_cat (round 6, DLA's Root): y, the BatchNorm statistics, every source's input gradient and the weight
+    gradient hold the SAME BITS as conv2d(cat(xs)) -- the same GEMMs in the same order, only the gather / the store switch
+    tensors -- and the values are torch's CPU results.  Source 1 has a second consumer: its share of the gradient is in the
+    fan-in slot when the input-gradient epilogue runs and must be added there."""
+    import hip_runtime as hr
+    from hip_runtime import ops
+    from hip_runtime.fanout import fork
+    from test_zz_kernel_coverage import short
+    B, H, W, cs, Co = CAT_CASES[name]
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in cs]
+    w = torch.randn(Co, sum(cs), 1, 1, generator=g) / sum(cs) ** 0.5
+    gy = torch.randn(B, Co, H, W, generator=g)
+    side = torch.randn(B, cs[1], H, W, generator=g)
+    # CPU reference
+    rx = [t.clone().requires_grad_(True) for t in xs]
+    rw = w.clone().requires_grad_(True)
+    ry = F.conv2d(torch.cat(rx, 1), rw)
+    (ry * gy).sum().backward(retain_graph=True)
+    (rx[1] * side).sum().backward()
+    res = []
+    for fused in (True, False):
+        dx = [t.to(DEV).requires_grad_(True) for t in xs]
+        dw = w.to(DEV).requires_grad_(True)
+        a, b2 = fork(dx[1], 2)                       # source 1: the convolution and an elementwise consumer
+        srcs = [dx[0], a] + dx[2:]
+        with hr.launch_log() as log:
+            if fused:
+                y = ops.conv1x1_cat(srcs, dw, 0, emit_stats=True)
+                assert y is not None, 'cnuda_conv2d_cat_supported refused %s' % name
+            else:
+                y = ops.conv2d(ops.cat_channels(srcs), dw, None, 1, 0, -1.0, 0, emit_stats=True)
+            stats = getattr(y, '_cnuda_bn_stats', None)
+            ((b2 * side.to(DEV)).sum() + (y * gy.to(DEV)).sum()).backward()
+        names = sorted(short(n) for n in log.names)
+        print(fused, names)
+        if fused:
+            assert not any(n.startswith('copy_channels') for n in names), names
+            for frag in ('ConvFwdCatLoader', 'ConvDgradCatLoader', 'ConvWCatLoader'):
+                assert any(frag in n for n in names), (frag, names)
+        res.append((y.detach(), None if stats is None else stats[0], dw.grad) + tuple(t.grad for t in dx))
+    fused, plain = res
+    assert fused[1] is not None and plain[1] is not None
+    for i, (u, v) in enumerate(zip(fused, plain)):
+        if i == 4:                                   # (source 1: its two shares are added in another order)
+            _close(u, v, 1e-6)
+        else:
+            assert torch.equal(u, v), i
+    _close(fused[0], ry.detach())
+    _close(fused[2], rw.grad)
+    for u, r in zip(fused[3:], rx):
+        _close(u, r.grad)
+
+
+def test_conv1x1_cat_declines_what_no_kernel_takes():
+    from hip_runtime import ops
+    w = torch.randn(64, 96, 1, 1, device=DEV)
+    assert ops.conv1x1_cat([torch.randn(2, 64, 8, 8, device=DEV), torch.randn(2, 32, 8, 8, device=DEV)], w) is None       # 32 channels
+    w = torch.randn(64, 128, 1, 1, device=DEV)
+    assert ops.conv1x1_cat([torch.randn(2, 64, 3, 3, device=DEV), torch.randn(2, 64, 3, 3, device=DEV)], w) is None       # 9 pixels per image
+    assert ops.conv1x1_cat([torch.randn(2, 128, 8, 8, device=DEV)], w) is None                                            # one source
+
+
 # (B, K = input channels, H, W, rows = output channels): the DCN column-gradient GEMM's shapes -- 9 C rows over K = Cout
 ROWQUAD_CASES = {
-    'shortk_64to576': (2, 64, 32, 32, 576),          # igemm_fwd_shortk_kernel (K = 64, 4.5 row tiles: the 64-row tail tile too)
-    'ws128_128to1152': (2, 128, 16, 32, 1152),       # igemm_fwd_ws_kernel<128>
-    'ws64_256to576': (1, 256, 8, 16, 576),           # few pixel tiles: the 64-row tile
+    # (sizes: pick_bm keeps the 128-row tile only with >= 512 tiles, the 64-row tile with >= 256)
+    'shortk_64to576': (4, 64, 64, 64, 576),          # igemm_fwd_shortk_kernel (K = 64, 4.5 row tiles: the 64-row tail tile too)
+    'ws128_128to1152': (2, 128, 64, 64, 1152),       # igemm_fwd_ws_kernel<128>
+    'ws64_256to576': (1, 256, 64, 64, 576),          # 32 pixel tiles: the 64-row tile
     'rows36_ragged': (1, 32, 5, 7, 36),              # 35 pixels (no multiple of 4), 36 rows: the 32-row tile's bounds
     'k1_rows144': (3, 16, 6, 10, 144),
 }
