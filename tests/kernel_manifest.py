@@ -346,7 +346,6 @@ MANIFEST = {
     'igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 128>': [
         'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
         'tests/test_gpu_fuzz.py::test_conv_transpose2d_random_geometry',
-        'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
     ],
     'igemm_wgrad_ws_kernel<ConvWBufLoader, 64, 64>': [
         'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
