@@ -214,7 +214,9 @@ class Root(nn.Module):
 
     def forward(self, *xs):
         if _use_folded(self):
-            return ops.conv2d_infer(ops.cat_channels(xs), *self._fold, 1, 0, 0.0, None, self._fold_token, self._fold_gen)
+            y = ops.conv1x1_cat_infer(xs, *self._fold, 0.0, self._fold_token, self._fold_gen) if CAT_FREE_ROOT else None
+            return y if y is not None else ops.conv2d_infer(ops.cat_channels(xs), *self._fold, 1, 0, 0.0, None,
+                                                            self._fold_token, self._fold_gen)
         # the convolution over the concatenation without the concatenation (round 6: ops.conv1x1_cat; 17 copies per forward
         # pass of DLA-34 and their 17 slices in the backward pass); None where no kernel takes these sources
         y = ops.conv1x1_cat(xs, self.conv.weight, self.conv._pack_token, emit_stats=self.conv.emit_stats and self.training) \

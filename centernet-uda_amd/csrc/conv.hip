@@ -1439,10 +1439,11 @@ extern "C" int cnuda_conv2d_cat_supported(const int* cs, int n, int B, int H, in
     return !q.skd.on() && !q.hw && !q.hw_s2 && wgrad_buffer_ok(g) && (size_t)B * Cout * H * W * sizeof(float) < IG_BUF_OOB;
 }
 
-extern "C" int cnuda_conv2d_cat_forward(const float* const* xs, const int* cs, int n, const float* weight, float* y,
-                                        float* stats, int B, int H, int W, int Cout, void* workspace,
-                                        size_t workspace_bytes, cnuda_stream_t stream) {
+extern "C" int cnuda_conv2d_cat_forward(const float* const* xs, const int* cs, int n, const float* weight, const float* bias,
+                                        float* y, float* stats, float act_slope, int B, int H, int W, int Cout,
+                                        void* workspace, size_t workspace_bytes, cnuda_stream_t stream) {
     CNUDA_REQUIRE(weight && y, "cnuda_conv2d_cat_forward: null pointer");
+    CNUDA_REQUIRE(!stats || act_slope < 0.0f, "cnuda_conv2d_cat_forward: statistics are those of the plain convolution");
     CNUDA_REQUIRE(cnuda_conv2d_cat_supported(cs, n, B, H, W, Cout), "cnuda_conv2d_cat_forward: unsupported (cnuda_conv2d_cat_supported)");
     ConvFwdCatParams p;
     if (int rc = fill_cat(p.cat, xs, cs, n, "cnuda_conv2d_cat_forward")) return rc;
@@ -1453,7 +1454,7 @@ extern "C" int cnuda_conv2d_cat_forward(const float* const* xs, const int* cs, i
     CNUDA_REQUIRE(workspace && workspace_bytes >= q.fwd_bytes, "cnuda_conv2d_cat_forward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     Carver cv(workspace, workspace_bytes);
-    static_cast<ConvFwdParams&>(p) = ConvFwdParams{g, nullptr, nullptr, y, -1.0f, nullptr};
+    static_cast<ConvFwdParams&>(p) = ConvFwdParams{g, nullptr, bias, y, act_slope, nullptr};
     p.stats = stats;
     p.stats_mp = q.Mpf;
     const float* A = launch_pack(weight, reinterpret_cast<float*>(cv.take<char>(ig_a_bytes(q.Kpf, q.Mpf))),

@@ -82,7 +82,7 @@ class _Sig:
     cnuda_conv2d_forward_rowsig = (_I, [_P] * 4 + [_I] * 12 + _WS)
     cnuda_conv2d_rowquads_supported = (_I, [_I] * 11)
     cnuda_conv2d_cat_supported = (_I, [_P, _I, _I, _I, _I, _I])
-    cnuda_conv2d_cat_forward = (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I] + _WS)
+    cnuda_conv2d_cat_forward = (_I, [_P, _P, _I, _P, _P, _P, _P, _F, _I, _I, _I, _I] + _WS)
     cnuda_conv2d_cat_backward_data = (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I] + _WS)
     cnuda_conv2d_cat_backward_weight = (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I] + _WS)
     cnuda_conv2d_forward_rowquads = (_I, [_P] * 3 + [_I] * 11 + _WS)

@@ -736,8 +736,8 @@ class _CatConv1x1(Function):
         cs_arr = (ctypes.c_int * len(cs))(*cs)
         prof_arm('conv_fwd', B, sum(cs), H, W, Co, 1, 1, H, W)
         with pack_stamp(pack_token, weight):
-            check(L.cnuda_conv2d_cat_forward(_ptr_array(xs), cs_arr, len(xs), ptr(weight), ptr(y), ptr(stats), B, H, W, Co,
-                                             wp, wn, stream()), 'conv2d_cat_forward')
+            check(L.cnuda_conv2d_cat_forward(_ptr_array(xs), cs_arr, len(xs), ptr(weight), None, ptr(y), ptr(stats), -1.0,
+                                             B, H, W, Co, wp, wn, stream()), 'conv2d_cat_forward')
         ctx.cs, ctx.pack_token = cs, pack_token
         ctx.save_for_backward(weight, *xs)
         return y
@@ -781,17 +781,49 @@ class _CatConv1x1(Function):
         return (gw, None, None) + tuple(gxs)
 
 
+def _cat_supported(xs, weight):
+    import ctypes
+    xs = list(xs)
+    if not (2 <= len(xs) <= 4) or any(t.dim() != 4 or getattr(t, '_cnuda_deferred_bn', None) is not None for t in xs):
+        return False
+    if weight.dim() != 4 or weight.shape[2] != 1 or weight.shape[3] != 1:
+        return False
+    B, _, H, W = xs[0].shape
+    cs = [int(t.shape[1]) for t in xs]
+    return bool(lib().cnuda_conv2d_cat_supported((ctypes.c_int * len(cs))(*cs), len(cs), B, H, W, int(weight.shape[0])))
+
+
+def conv1x1_cat_infer(xs, weight, bias=None, act_slope=-1.0, pack_token=0, pack_version=None):
+    """Tape-free y = act(conv1x1(cat(xs, 1), weight) + bias) without the concatenation (a BatchNorm-folded Root, export.py),
+    or None where no kernel takes the sources (the caller concatenates)."""
+    import ctypes
+    xs = list(xs)
+    if not _cat_supported(xs, weight):
+        return None
+    require_gpu(weight, bias, *xs)
+    xs = [f32c(t.detach()) for t in xs]
+    weight = f32c(weight.detach())
+    bias = None if bias is None else f32c(bias.detach())
+    B, _, H, W = xs[0].shape
+    cs = [int(t.shape[1]) for t in xs]
+    Co = weight.shape[0]
+    g = (B, sum(cs), H, W, Co, 1, 1, 1, 1, 0, 0)
+    L = lib()
+    y = torch.empty((B, Co, H, W), dtype=torch.float32, device=weight.device)
+    wp, wn = _ws(L.cnuda_conv2d_workspace_bytes(*g), y)
+    prof_arm('conv_fwd', B, sum(cs), H, W, Co, 1, 1, H, W)
+    with pack_stamp(pack_token, weight, pack_version):
+        check(L.cnuda_conv2d_cat_forward(_ptr_array(xs), (ctypes.c_int * len(cs))(*cs), len(xs), ptr(weight), ptr(bias), ptr(y),
+                                         None, float(act_slope), B, H, W, Co, wp, wn, stream()), 'conv2d_cat_forward')
+    return y
+
+
 def conv1x1_cat(xs, weight, pack_token=0, emit_stats=False):
     """conv2d(cat(xs, 1), weight) for a 1x1 / stride 1 / bias-free convolution, or None where no kernel takes the sources as
     they are (cnuda_conv2d_cat_supported: 2 .. 4 sources of multiples of 64 channels, H * W % 4 == 0, no K split in the
     plan): the caller then concatenates.  emit_stats as ops.conv2d."""
-    import ctypes
     xs = list(xs)
-    if not (2 <= len(xs) <= 4) or any(t.dim() != 4 or getattr(t, '_cnuda_deferred_bn', None) is not None for t in xs):
-        return None
-    B, _, H, W = xs[0].shape
-    cs = [int(t.shape[1]) for t in xs]
-    if not lib().cnuda_conv2d_cat_supported((ctypes.c_int * len(cs))(*cs), len(cs), B, H, W, int(weight.shape[0])):
+    if not _cat_supported(xs, weight):
         return None
     if not (emit_stats and EPILOGUE_STATS):
         return _CatConv1x1.apply(weight, pack_token, None, *xs)

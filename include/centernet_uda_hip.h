@@ -313,7 +313,7 @@ int cnuda_conv2d_rowsig_supported(int B, int C, int H, int W, int Cout, int kh, 
 int cnuda_conv2d_forward_rowsig(const float* x, const float* weight, const float* bias, float* y, int sig_from,
                                 int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                                 void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
-/* A 1x1 convolution (stride 1, no padding, no bias) over the CHANNEL CONCATENATION of n = 2 .. 4 tensors xs[i] [B, cs[i], H, W]
+/* A 1x1 convolution (stride 1, no padding) over the CHANNEL CONCATENATION of n = 2 .. 4 tensors xs[i] [B, cs[i], H, W]
  * without the concatenation: DLA's Root is conv(torch.cat(children, 1)) (backends/dla.py:150-168; 17 concatenated buffers per
  * forward pass of DLA-34 and their slices in the backward pass).  weight [Cout, sum cs, 1, 1] as for the concatenated tensor.
  * The GEMMs' K axis IS the concatenated channel axis: the gather switches source per 16-deep chunk, the input-gradient
@@ -324,7 +324,8 @@ int cnuda_conv2d_forward_rowsig(const float* x, const float* weight, const float
  * concatenated geometry's plan without a K split, f32 matrix mode; elsewhere the caller concatenates.  Workspace:
  * cnuda_conv2d_workspace_bytes of the concatenated geometry. */
 int cnuda_conv2d_cat_supported(const int* cs, int n, int B, int H, int W, int Cout);
-int cnuda_conv2d_cat_forward(const float* const* xs, const int* cs, int n, const float* weight, float* y, float* stats,
+int cnuda_conv2d_cat_forward(const float* const* xs, const int* cs, int n, const float* weight, const float* bias /* nullable */,
+                             float* y, float* stats, float act_slope /* < 0: none; with stats: none */,
                              int B, int H, int W, int Cout, void* workspace, size_t workspace_bytes, cnuda_stream_t stream);
 int cnuda_conv2d_cat_backward_data(const float* grad_y, const float* weight, float* const* grad_xs, const float* const* adds,
                                    const float* const* add2s, const int* cs, int n, int B, int H, int W, int Cout,

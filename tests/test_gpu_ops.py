@@ -208,6 +208,22 @@ def test_conv1x1_over_a_concatenation_without_the_concatenation(name):
         _close(u, r.grad)
 
 
+@pytest.mark.parametrize('name', ['level2_64_64', 'level3_four_sources', 'ragged_pixels'])
+def test_conv1x1_cat_inference_form_with_bias_and_relu(name):
+    """The BatchNorm-folded Root (export.py): act(conv1x1(cat(xs)) + bias) in one launch, the same bits as the concatenated form."""
+    from hip_runtime import ops
+    B, H, W, cs, Co = CAT_CASES[name]
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(B, c, H, W, generator=g).to(DEV) for c in cs]
+    w = (torch.randn(Co, sum(cs), 1, 1, generator=g) / sum(cs) ** 0.5).to(DEV)
+    b = torch.randn(Co, generator=g).to(DEV)
+    got = ops.conv1x1_cat_infer(xs, w, b, 0.0)
+    assert got is not None
+    want = ops.conv2d_infer(ops.cat_channels(xs), w, b, 1, 0, 0.0)
+    assert torch.equal(got, want)
+    _close(got, F.relu(F.conv2d(torch.cat([t.cpu() for t in xs], 1), w.cpu(), b.cpu())))
+
+
 def test_conv1x1_cat_declines_what_no_kernel_takes():
     from hip_runtime import ops
     w = torch.randn(64, 96, 1, 1, device=DEV)
