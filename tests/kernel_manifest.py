@@ -354,10 +354,16 @@ MANIFEST = {
     ],
     'maxpool_bwd_kernel': [
         'tests/test_gpu_ops.py::test_maxpool',
+    ],
+    'maxpool_fwd_kernel': [
+        'tests/test_gpu_ops.py::test_maxpool',
+    ],
+    'maxpool2_bwd_vec_kernel': [       # round 6: the 2 x 2 pools with 16-byte accesses
+        'tests/test_gpu_ops.py::test_maxpool',
         'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
         'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
     ],
-    'maxpool_fwd_kernel': [
+    'maxpool2_fwd_vec_kernel': [
         'tests/test_gpu_ops.py::test_maxpool',
         'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
         'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',

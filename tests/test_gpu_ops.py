@@ -366,19 +366,45 @@ def test_batch_norm_eval_and_single_value_error():
                            rm[:4].to(DEV), rv[:4].to(DEV), True)
 
 
-@pytest.mark.parametrize('shape,k', [((2, 5, 8, 12), 2), ((1, 3, 9, 7), 2), ((2, 4, 12, 12), 4)])
-def test_maxpool(shape, k):
+@pytest.mark.parametrize('ties', [False, True], ids=['distinct', 'ties_and_nan'])
+@pytest.mark.parametrize('shape,k', [((2, 5, 8, 12), 2), ((1, 3, 9, 7), 2), ((2, 4, 12, 12), 4), ((3, 4, 16, 32), 2), ((1, 2, 6, 10), 2)])
+def test_maxpool(shape, k, ties):
+    """(W % 4 == 0 and H even with k = 2: the 16-byte kernels of round 6; else the scalar ones.)  ties_and_nan: values on a
+    grid of halves -- most windows hold their maximum more than once: the FIRST in scan order takes the gradient -- and a few
+    NaN, which win their window (ATen's rule)."""
     from hip_runtime import ops
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(shape, generator=g).requires_grad_(True)
+    x = torch.randn(shape, generator=g)
+    if ties:
+        x = torch.round(x * 2) / 2
+        x.view(-1)[torch.randperm(x.numel(), generator=g)[:5]] = float('nan')
+    x.requires_grad_(True)
     y = F.max_pool2d(x, k, k)
     gy = torch.randn(y.shape, generator=g)
     y.backward(gy)
     dx = x.detach().to(DEV).requires_grad_(True)
     dy = ops.max_pool2d(dx, k)
-    assert torch.equal(dy.cpu(), y.detach())
+    assert torch.equal(dy.cpu().nan_to_num(nan=1e30), y.detach().nan_to_num(nan=1e30))
     dy.backward(gy.to(DEV))
     assert torch.equal(dx.grad.cpu(), x.grad)
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 8, 16), (1, 2, 5, 7)], ids=['vector', 'scalar'])
+def test_maxpool_backward_accumulates_into_a_held_gradient(shape):
+    """cnuda_maxpool2d_backward_acc(accumulate = 1) (hip_runtime.fanout: the pooled tensor has another consumer whose share is
+    already in the buffer): held + the plain backward, in both kernel forms."""
+    import hip_runtime as hr
+    g = torch.Generator().manual_seed(9)
+    B, C, H, W = shape
+    x = torch.randn(shape, generator=g).to(DEV)
+    gy = torch.randn(B, C, H // 2, W // 2, generator=g).to(DEV)
+    held = torch.randn(shape, generator=g).to(DEV)
+    plain = torch.full(shape, float('nan'), device=DEV)
+    L = hr.lib()
+    hr.check(L.cnuda_maxpool2d_backward_acc(hr.ptr(x), hr.ptr(gy), hr.ptr(plain), 0, B, C, H, W, 2, hr.stream()))
+    acc = held.clone()
+    hr.check(L.cnuda_maxpool2d_backward_acc(hr.ptr(x), hr.ptr(gy), hr.ptr(acc), 1, B, C, H, W, 2, hr.stream()))
+    assert torch.equal(acc, held + plain)
 
 
 @pytest.mark.parametrize('C,H,W,f', [(8, 5, 6, 2), (64, 4, 4, 4), (3, 3, 5, 8), (4, 3, 5, 2), (16, 32, 32, 2), (16, 16, 16, 4),
