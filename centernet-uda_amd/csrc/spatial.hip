@@ -68,7 +68,8 @@ __device__ __forceinline__ void pool2_pick(float a, float b, float c, float d, f
 __global__ void maxpool2_fwd_vec_kernel(const float4* __restrict__ x, float2* __restrict__ y, long long total /* planes * Ho * Wo / 2 */,
                                         int Wq /* W / 4 */) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long row = i / Wq;                         // (plane, output row) flattened: input rows 2 row, 2 row + 1
+        // (plane, output row) flattened: input rows 2 row, 2 row + 1.  32-bit division where the index allows (always, in DLA-34)
+        const long long row = total < (1ll << 32) ? (long long)((unsigned)i / (unsigned)Wq) : i / Wq;
         const int q = (int)(i - row * Wq);
         const float4 r0 = x[(2 * row) * Wq + q], r1 = x[(2 * row + 1) * Wq + q];
         float m0, m1;
@@ -81,7 +82,7 @@ __global__ void maxpool2_fwd_vec_kernel(const float4* __restrict__ x, float2* __
 __global__ void maxpool2_bwd_vec_kernel(const float4* __restrict__ x, const float2* __restrict__ gy, float4* __restrict__ gx,
                                         long long total, int Wq, int accumulate) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long row = i / Wq;
+        const long long row = total < (1ll << 32) ? (long long)((unsigned)i / (unsigned)Wq) : i / Wq;
         const int q = (int)(i - row * Wq);
         const long long i0 = (2 * row) * Wq + q, i1 = (2 * row + 1) * Wq + q;
         const float4 r0 = x[i0], r1 = x[i1];
