@@ -308,7 +308,6 @@ MANIFEST = {
     'igemm_fwd_ws_kernel<64, ConvFwdBufLoader, 16>': [
         'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
         'tests/test_gpu_dla.py::test_uda_step128_plain_1e4',
-        'tests/test_gpu_dla.py::test_base_step_dla_configs1_plain_1e4',
     ],
     'igemm_wgrad_kernel<ConvWBufLoader, 32, 128>': [
         'tests/test_gpu_fullsize.py::test_full_size_1x1_convolutions_match_fp64_and_repeat',
