@@ -452,7 +452,9 @@ def pmc_traffic(kernel_name):
     meta = data.get('_meta', {})
     import re
     # (profiler names carry the template defaults the library's own kernel names leave out)
-    norm = lambda k: re.sub(r'(,(true|false))?(,16)?>$', '>', k.replace(' ', ''))
+    # (... and the QUADS flag of the DCN data-gradient kernels, which the library's scope names do not carry: the benched
+    # layers all take the quad-interleaved column gradient, `<true>`)
+    norm = lambda k: re.sub(r'<(true|false)>$', '', re.sub(r'(,(true|false))?(,16)?>$', '>', k.replace(' ', '')))
     t = {norm(k): v for k, v in data.items() if k != '_meta'}.get(norm(kernel_name.split(' (')[0].split(' [')[0]))
     if not t:
         return None, '%s has no entry for this kernel' % os.path.basename(path)
