@@ -31,6 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--maps640', action='store_true', help='the same layers on the maps of a 640 x 640 input (configs[4])')
     args = ap.parse_args()
     import hip_runtime as hr
     if os.environ.get('ABL_LIB'):          # another build of the library (profiles/microbench/build_variant.sh)
@@ -42,6 +43,8 @@ def main():
     tot = {}
     for C, Co, S, k, s in SHAPES:
         B = args.batch
+        if args.maps640:
+            S = S * 5 // 4
         x = torch.randn(B, C, S, S, device=dev, requires_grad=True)
         w = (torch.randn(Co, C, k, k, device=dev) / (C * k * k) ** 0.5).requires_grad_(True)
         So = (S + 2 * (k // 2) - k) // s + 1
