@@ -3,7 +3,8 @@ and more take; `CNUDA_WS=0`: the 4-wave kernels on the 64- / 128-row tiles -- al
 `CNUDA_SHORTK=0`: the pipelined kernel for the K = 64 column-gradient GEMM; `CNUDA_HCONV=0`: the im2col-style kernels
 for the 27-row DCN offset convolutions that otherwise take the halo-tile kernels; `CNUDA_DCNW=0`: the gathering loader
 for the DCN forward of the layers that otherwise sample from an LDS window; `CNUDA_SPLITK=0`: pick_bm's smaller row tiles
-for the starved long-K GEMMs that otherwise cut K over the grid) are read once per process, so each
+for the starved long-K GEMMs that otherwise cut K over the grid; `CNUDA_DCOL_QUADS=0`: the DCN column gradient in plain
+[9 C][pixel] rows for the layers that otherwise interleave its rows in quads) are read once per process, so each
 alternate runs the operator-level parity tests in a child process: per-operator values against the oracle at small
 sizes, the full-size convolution and DCN value checks.  (The switches whose alternate lost in round 2 are gone.)"""
 import os
@@ -20,7 +21,7 @@ SUBSET = ['tests/test_gpu_ops.py::test_conv2d_fwd_bwd', 'tests/test_gpu_dcn.py::
           'tests/test_gpu_fullsize.py::test_full_size_dcn_layer_matches_the_oracle']
 
 
-@pytest.mark.parametrize('switch', ['CNUDA_BUF', 'CNUDA_WS', 'CNUDA_SHORTK', 'CNUDA_HCONV', 'CNUDA_DCNW', 'CNUDA_SPLITK'])
+@pytest.mark.parametrize('switch', ['CNUDA_BUF', 'CNUDA_WS', 'CNUDA_SHORTK', 'CNUDA_HCONV', 'CNUDA_DCNW', 'CNUDA_SPLITK', 'CNUDA_DCOL_QUADS'])
 def test_alternate_kernel_paths_hold_the_same_parity(switch):
     env = dict(os.environ, **{switch: '0'})
     # (the full-size DCN layers at one offset scale and without the opt-in backward: the alternates differ in loaders and
