@@ -206,3 +206,57 @@ def test_decode_random_geometry_vs_oracle(case):
     assert np.array_equal(dets[..., cc].cpu().numpy().astype(np.int32), wcls)
     assert np.array_equal(dets[..., cc - 1].cpu().numpy(), want[..., cc - 1])
     np.testing.assert_allclose(dets.cpu().numpy(), want, rtol=1e-5, atol=5e-5)
+
+
+def _cat_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        ns = int(rs.randint(2, 5))
+        cs = tuple(int(rs.choice([64, 64, 64, 128, 128, 192, 256])) for _ in range(ns))
+        # (mostly rows of a multiple of four pixels: the library declines the rest -- a quarter of the cases keeps any width)
+        B, H = int(rs.randint(1, 9)), int(rs.randint(1, 17))
+        W = int(rs.randint(1, 13)) if rs.randint(4) == 0 else 4 * int(rs.randint(1, 9))
+        Co = int(rs.choice([16, 27, 64, 100, 128, 192, 256]))
+        out.append((B, H, W, cs, Co))
+    return out
+
+
+@pytest.mark.parametrize('case', _cat_cases(32, 77), ids=lambda c: 'B%dH%dW%d_%s_Co%d' % (c[0], c[1], c[2], 'x'.join(map(str, c[3])), c[4]))
+def test_conv1x1_cat_random_geometry(case):
+    """ops.conv1x1_cat (DLA's Root without the concatenation) on random source lists and map sizes: where the library takes the
+    sources, output, input gradients and weight gradient equal conv2d(cat(xs)) BIT FOR BIT (the same GEMMs) and are torch's CPU
+    values; where it declines (a plan that cuts K, pixels per image no multiple of four), it says so with None."""
+    import ctypes
+    import hip_runtime as hr
+    from hip_runtime import ops
+    B, H, W, cs, Co = case
+    g = torch.Generator().manual_seed(hash(case) % 100000)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in cs]
+    w = torch.randn(Co, sum(cs), 1, 1, generator=g) / sum(cs) ** 0.5
+    gy = torch.randn(B, Co, H, W, generator=g)
+    supported = bool(hr.lib().cnuda_conv2d_cat_supported((ctypes.c_int * len(cs))(*cs), len(cs), B, H, W, Co))
+    dx = [t.to(DEV).requires_grad_(True) for t in xs]
+    dw = w.to(DEV).requires_grad_(True)
+    y = ops.conv1x1_cat(dx, dw)
+    assert (y is not None) == supported
+    if (H * W) % 4:
+        assert not supported
+    if not supported:
+        return
+    y.backward(gy.to(DEV))
+    px = [t.to(DEV).requires_grad_(True) for t in xs]
+    pw = w.to(DEV).requires_grad_(True)
+    py = ops.conv2d(ops.cat_channels(px), pw, None, 1, 0)
+    py.backward(gy.to(DEV))
+    assert torch.equal(y, py) and torch.equal(dw.grad, pw.grad)
+    for a, b in zip(dx, px):
+        assert torch.equal(a.grad, b.grad)
+    rx = [t.clone().requires_grad_(True) for t in xs]
+    rw = w.clone().requires_grad_(True)
+    ry = F.conv2d(torch.cat(rx, 1), rw)
+    ry.backward(gy)
+    _close(y, ry, what='y')
+    _close(dw.grad, rw.grad, what='gw')
+    for a, r in zip(dx, rx):
+        _close(a.grad, r.grad, what='gx')
