@@ -199,6 +199,10 @@ thread_local uint64_t g_pack_token = 0, g_pack_version = 0;
 float* pack_slot(const PackKey& key, size_t bytes, bool& fill, int cpad = 0, const TapList* taps = nullptr) {
     fill = true;
     if (key.token == 0 || !g_pack_arena) return nullptr;
+    // The split-operand matrix mode packs into the caller's workspace: with cached images a training step of the 128 x 128
+    // test net aborted in a strided input gradient (round 6; since round 5 at the latest, not root-caused -- the same calls
+    // without the cache, CNUDA_PACK_CACHE_MB=0, are clean).  Mode 1 is opt-in and not the benched path.
+    if (matrix_mode() != 0) return nullptr;
     std::lock_guard<std::mutex> lock(g_pack_mutex);
     auto it = g_pack_slots.find(key);
     if (it == g_pack_slots.end()) {

@@ -1,0 +1,22 @@
+"""pytest -p spy_plugin (PYTHONPATH=profiles/microbench): prints the geometry of every convolution input-gradient call and
+synchronises after it -- finds the call behind an asynchronous GPU fault."""
+import sys
+
+
+def pytest_sessionstart(session):
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.join(root, 'centernet-uda_amd'))
+    import torch
+    import hip_runtime as hr
+    L = hr.lib()
+    for name, sl in (('cnuda_conv2d_backward_data_add', slice(5, 16)), ('cnuda_conv2d_forward_stats', slice(6, 17)),
+                     ('cnuda_conv2d_backward_weight', slice(4, 15))):
+        orig = getattr(L, name)
+
+        def spy(*a, _orig=orig, _name=name, _sl=sl):
+            print(_name, list(a[_sl]), 'pointers', [bool(x) if not isinstance(x, (int, float)) else x for x in a[:_sl.start]], 'tail', list(a[_sl.stop:]), flush=True)
+            r = _orig(*a)
+            torch.cuda.synchronize()
+            return r
+        setattr(L, name, spy)

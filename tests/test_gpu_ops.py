@@ -163,6 +163,8 @@ def test_conv1x1_over_a_concatenation_without_the_concatenation(name):
     from hip_runtime.fanout import fork
     from test_zz_kernel_coverage import short
     B, H, W, cs, Co = CAT_CASES[name]
+    if hr.get_matrix_mode() != 0:
+        pytest.skip('the concatenation-free kernels are f32-matrix-mode only: Root concatenates in mode 1')
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
     xs = [torch.randn(B, c, H, W, generator=g) for c in cs]
     w = torch.randn(Co, sum(cs), 1, 1, generator=g) / sum(cs) ** 0.5
@@ -211,8 +213,11 @@ def test_conv1x1_over_a_concatenation_without_the_concatenation(name):
 @pytest.mark.parametrize('name', ['level2_64_64', 'level3_four_sources', 'ragged_pixels'])
 def test_conv1x1_cat_inference_form_with_bias_and_relu(name):
     """The BatchNorm-folded Root (export.py): act(conv1x1(cat(xs)) + bias) in one launch, the same bits as the concatenated form."""
+    import hip_runtime as hr
     from hip_runtime import ops
     B, H, W, cs, Co = CAT_CASES[name]
+    if hr.get_matrix_mode() != 0:
+        pytest.skip('the concatenation-free kernels are f32-matrix-mode only: Root concatenates in mode 1')
     g = torch.Generator().manual_seed(3)
     xs = [torch.randn(B, c, H, W, generator=g).to(DEV) for c in cs]
     w = (torch.randn(Co, sum(cs), 1, 1, generator=g) / sum(cs) ** 0.5).to(DEV)
