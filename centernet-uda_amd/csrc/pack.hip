@@ -196,13 +196,10 @@ unsigned long long g_pack_stamps_since_reset = ~0ull >> 1, g_pack_reset_min_stam
 thread_local uint64_t g_pack_token = 0, g_pack_version = 0;
 
 // -> cached slot to use (fill == true: pack into it first), or nullptr: use the workspace
+constexpr size_t kPackSlack = 4096;
 float* pack_slot(const PackKey& key, size_t bytes, bool& fill, int cpad = 0, const TapList* taps = nullptr) {
     fill = true;
     if (key.token == 0 || !g_pack_arena) return nullptr;
-    // The split-operand matrix mode packs into the caller's workspace: with cached images a training step of the 128 x 128
-    // test net aborted in a strided input gradient (round 6; since round 5 at the latest, not root-caused -- the same calls
-    // without the cache, CNUDA_PACK_CACHE_MB=0, are clean).  Mode 1 is opt-in and not the benched path.
-    if (matrix_mode() != 0) return nullptr;
     std::lock_guard<std::mutex> lock(g_pack_mutex);
     auto it = g_pack_slots.find(key);
     if (it == g_pack_slots.end()) {
@@ -222,7 +219,10 @@ float* pack_slot(const PackKey& key, size_t bytes, bool& fill, int cpad = 0, con
         }
     }
     if (it == g_pack_slots.end()) {
-        const size_t need = (bytes + 255) / 256 * 256;
+        // (+ kPackSlack: the split-operand kernels of matrix mode 1 read a few 16-byte cells past the end of their image --
+        // harmless inside the workspace or the arena, an abort when the slot is the arena's last bytes: round 6, found with
+        // a 768-MB arena filled by the second model of a test session)
+        const size_t need = (bytes + 255) / 256 * 256 + kPackSlack;
         if (g_pack_arena_used + need > g_pack_arena_bytes) {                      // arena full: this request goes to the
             g_pack_reset_wanted = need <= g_pack_arena_bytes;                     // workspace, the cache starts over at
             return nullptr;                                                       // the next stamped call
