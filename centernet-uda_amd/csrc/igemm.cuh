@@ -173,8 +173,10 @@ __device__ __forceinline__ void ig_load_a_x3(const u32x4* __restrict__ A3, int M
 #pragma unroll
     for (int i = 0; i < ig_a3_per<BM>(); ++i) {
         const int e = tid + i * IG_THREADS;
-        // (cells past 6*BM: clamp the address, the store below skips them)
-        const int ec = (6 * BM) % IG_THREADS == 0 ? e : (e < 6 * BM ? e : tid);
+        // (cells past 6*BM: an address inside the tile, the store below skips them.  Until round 6 this was `tid`, which for
+        // the 32-row tile -- 192 cells, 256 threads -- is itself past the tile: threads 192..255 read up to 1 KB past the
+        // chunk, on the last chunk past the image; pack.hip kPackSlack tells how that surfaced)
+        const int ec = (6 * BM) % IG_THREADS == 0 ? e : (e < 6 * BM ? e : e % (6 * BM));
         r[i] = base[(size_t)(ec / BM) * Mp + ec % BM];
     }
 }

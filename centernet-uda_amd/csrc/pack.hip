@@ -219,9 +219,10 @@ float* pack_slot(const PackKey& key, size_t bytes, bool& fill, int cpad = 0, con
         }
     }
     if (it == g_pack_slots.end()) {
-        // (+ kPackSlack: the split-operand kernels of matrix mode 1 read a few 16-byte cells past the end of their image --
-        // harmless inside the workspace or the arena, an abort when the slot is the arena's last bytes: round 6, found with
-        // a 768-MB arena filled by the second model of a test session)
+        // (+ kPackSlack: the 32-row split-operand kernel of matrix mode 1 read up to 1 KB past the end of its image (a clamp
+        // in igemm.cuh ig_load_a_x3 that pointed outside the tile, fixed in round 6) -- harmless inside the workspace or the
+        // arena, an abort when the slot was the arena's last bytes, i.e. once a session's later models had filled the 768 MB.
+        // The slack stays: no kernel's read-ahead may depend on what lies behind the arena)
         const size_t need = (bytes + 255) / 256 * 256 + kPackSlack;
         if (g_pack_arena_used + need > g_pack_arena_bytes) {                      // arena full: this request goes to the
             g_pack_reset_wanted = need <= g_pack_arena_bytes;                     // workspace, the cache starts over at
